@@ -1,0 +1,240 @@
+"""TEST INFRASTRUCTURE (see oracle/__init__.py).
+
+Generates tests/golden/* by running the UNMODIFIED reference (imported from
+/root/reference through oracle/refimport.py) on factory weights + seeded
+inputs, and at the same time checks the oracle restatement against it.
+
+Run in the authoring container only:   python -m oracle.gen_golden
+(/root/reference does not exist on the GPU box; the committed fixtures travel.)
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import refimport
+
+refimport.activate()          # must precede any `import mug`
+
+import torch  # noqa: E402
+import yaml  # noqa: E402
+
+from . import cases, host, nets, s4 as s4o, sampler, weights  # noqa: E402
+
+torch.set_grad_enabled(False)
+G = cases.GOLDEN
+os.makedirs(G, exist_ok=True)
+REPORT = {}
+
+
+def note(key, val):
+    REPORT[key] = float(val)
+    print("  %-58s %.3e" % (key, val))
+
+
+def maxdiff(a, b):
+    return (a.double() - b.double()).abs().max().item()
+
+
+def ref_model(case):
+    """Builds the reference DDPM from a config dict shaped like configs/mug/mug_diffusion.yaml."""
+    from mug.util import instantiate_from_config
+    cfg = dict(target="mug.diffusion.diffusion.DDPM", params=dict(
+        linear_start=0.0001, linear_end=0.02, log_every_t=100, timesteps=1000,
+        z_channels=16, z_length=512, parameterization="eps", loss_type="smooth_l1",
+        monitor="val/loss_simple",
+        unet_config=dict(target="mug.diffusion.unet.UNetModel",
+                         params=dict(dropout=0.0, lstm_last=False, lstm_layer=False, use_checkpoint=False,
+                                     **case["unet"])),
+        first_stage_config=dict(target="mug.firststage.autoencoder.AutoencoderKL",
+                                params=dict(monitor="val/loss", kl_weight=1e-6, ddconfig=dict(case["vae"]),
+                                            lossconfig=dict(target="torch.nn.Identity"))),
+        cond_stage_config=dict(target="mug.cond.feature.BeatmapFeatureEmbedder",
+                               params=dict(path_to_yaml="configs/mug/mania_beatmap_features.yaml",
+                                           embed_dim=case["unet"]["context_dim"])),
+        wave_stage_config=dict(target="mug.cond.wave.MelspectrogramScaleEncoder1D",
+                               params=dict(dropout=0.0, use_checkpoint=True, **case["wave"]))))
+    cwd = os.getcwd()
+    os.chdir(refimport.REF)
+    try:
+        torch.manual_seed(0)
+        m = instantiate_from_config(cfg)
+    finally:
+        os.chdir(cwd)
+    return m.eval()
+
+
+def load(model, sd):
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing[:5], unexpected[:5])
+
+
+def run_case(case, z_list, ddim_cfg):
+    tag = case["name"]
+    print("== case %s" % tag)
+    model = ref_model(case)
+    man = weights.manifest_of(model.state_dict())
+    with open(os.path.join(G, case["manifest"]), "w") as f:
+        json.dump(man, f, separators=(",", ":"))
+    print("  manifest entries:", len(man))
+
+    from mug.diffusion.ddim import DDIMSampler
+    for z in z_list:
+        sd = weights.set_s4_lengths(weights.make_state_dict(man, seed=0), case["unet"], z)
+        load(model, sd)
+        # schedule buffers of the factory must equal the reference's own
+        for k, v in sampler.register_schedule().items():
+            assert np.array_equal(v, model.state_dict()[k].numpy()), k
+        for B in ([1, 2] if z <= 128 else [1]):
+            seed = 100 + z + B
+            x = cases.x_T(seed, B, z)
+            t = torch.tensor([981, 21][:B], dtype=torch.long)
+            c = cases.context(case, seed, B)
+            w = cases.audio_maps(case, seed, B, z)
+            t0 = time.time()
+            e_ref = model.model.unet_model(x, t, c, *w)
+            t1 = time.time()
+            e_orc = nets.unet_forward(sd, case["unet"], x, t, c, w)
+            t2 = time.time()
+            note("%s unet z=%d B=%d |oracle-ref|max (ref %.2fs orc %.2fs)" % (tag, z, B, t1 - t0, t2 - t1),
+                 maxdiff(e_ref, e_orc))
+            note("%s unet z=%d B=%d |ref|max" % (tag, z, B), e_ref.abs().max().item())
+            np.savez_compressed(os.path.join(G, "%s_unet_z%d_b%d.npz" % (tag, z, B)),
+                                seed=seed, t=t.numpy(), eps=e_ref.numpy())
+
+        # ---- S4 kernels (two extreme layers), reference vs oracle(reference mode) vs exact
+        ks = {}
+        for name, mod in model.model.unet_model.named_modules():
+            if name.endswith("s4_model.kernel.kernel"):
+                L = int(mod.L)
+                k_ref = mod(L=L)[0][0]
+                p = "model.unet_model." + name
+                k_orc = s4o.s4_kernel(sd, p, L, "reference")
+                k_ex = s4o.s4_kernel(sd, p, L, "exact")
+                ks[name] = (k_ref, k_orc, k_ex)
+        d1 = max(maxdiff(a, b) for a, b, _ in ks.values())
+        d2 = max(maxdiff(a, c_) for a, _, c_ in ks.values())
+        km = max(a.abs().max().item() for a, _, _ in ks.values())
+        note("%s z=%d s4 kernel |oracle-ref|max over %d layers" % (tag, z, len(ks)), d1)
+        note("%s z=%d s4 kernel |exact-ref|max" % (tag, z), d2)
+        note("%s z=%d s4 kernel |ref|max" % (tag, z), km)
+        first, last = list(ks)[0], list(ks)[-1]
+        np.savez_compressed(os.path.join(G, "%s_s4kernel_z%d.npz" % (tag, z)),
+                            names=np.array([first, last]), k0=ks[first][0].numpy(), k1=ks[last][0].numpy(),
+                            k0_exact=ks[first][2].numpy(), k1_exact=ks[last][2].numpy())
+
+        # ---- VAE decode
+        zlat = cases.randn(7 + z, 2, (2, 16, z))
+        d_ref = model.model.decode(zlat)
+        d_orc = nets.vae_decode(sd, case["vae"], zlat)
+        note("%s vae z=%d |oracle-ref|max" % (tag, z), maxdiff(d_ref, d_orc))
+        np.savez_compressed(os.path.join(G, "%s_vae_z%d.npz" % (tag, z)), seed=7 + z, logits=d_ref.numpy())
+
+        # ---- wave encoder
+        frames = z * case["audio_ratio"]
+        mel = cases.mel_input(case, 11 + z, 1, frames)
+        w_ref = model.model.wave_model(mel)
+        w_orc = nets.wave_encode(sd, case["wave"], mel)
+        note("%s wave frames=%d |oracle-ref|max" % (tag, frames), max(maxdiff(a, b) for a, b in zip(w_ref, w_orc)))
+        nl = len(case["unet"]["channel_mult"])
+        np.savez_compressed(os.path.join(G, "%s_wave_z%d.npz" % (tag, z)), seed=11 + z,
+                            **{"w%d" % i: a.numpy() for i, a in enumerate(w_ref[-nl:])},
+                            absmean=np.array([a.abs().mean().item() for a in w_ref]))
+
+        # ---- end-to-end DDIM (+ decode), explicit x_T, eta=0
+        for (S, B, scale) in ddim_cfg.get(z, []):
+            seed = 500 + z + S
+            fy = cases.feature_yaml()
+            prompts = [{"sr": 4.0, "rank_status": "ranked"}, {"sr": 2.5, "ln_ratio": 0.4}][:B]
+            ids = torch.tensor([host.feature_ids(pm, fy) for pm in prompts], dtype=torch.float32)
+            c = model.model.cond_stage_model(ids)
+            assert maxdiff(c, nets.cond_embed(sd, ids)) == 0.0
+            uc = model.model.cond_stage_model(torch.tensor([host.feature_ids({}, fy)] * B, dtype=torch.float32))
+            wl = [wi.repeat(B, 1, 1) for wi in w_ref]
+            xT = cases.x_T(seed, B, z)
+            model.z_length = z
+            smp = DDIMSampler(model)
+            t0 = time.time()
+            lat_ref, _ = smp.sample(S=S, c=c, w=wl, batch_size=B, eta=0.0, verbose=False, x_T=xT,
+                                    unconditional_guidance_scale=scale, unconditional_conditioning=uc,
+                                    tqdm_class=lambda it, **k: it)
+            t1 = time.time()
+            lat_orc = sampler.ddim_sample(sd, case["unet"], S, c, wl, xT, 0.0, scale, uc)
+            dec_ref = model.model.decode(lat_ref)
+            dec_orc = nets.vae_decode(sd, case["vae"], lat_orc)
+            key = "%s ddim z=%d S=%d B=%d cfg=%g" % (tag, z, S, B, scale)
+            note(key + " latent |oracle-ref|max (ref %.1fs)" % (t1 - t0), maxdiff(lat_ref, lat_orc))
+            note(key + " latent |ref|max", lat_ref.abs().max().item())
+            gs_r, gh_r = host.note_grid(dec_ref.numpy())
+            gs_o, gh_o = host.note_grid(dec_orc.numpy())
+            flips = int((gs_r != gs_o).sum() + (gh_r != gh_o).sum())
+            note(key + " grid flips oracle vs ref", flips)
+            note(key + " notes on (start)", int(gs_r.sum()))
+            np.savez_compressed(os.path.join(G, "%s_ddim_z%d_S%d_B%d_cfg%g.npz" % (tag, z, S, B, scale)),
+                                seed=seed, ids=ids.numpy(), latent=lat_ref.numpy(), logits=dec_ref.numpy(),
+                                mel_seed=11 + z)
+    del model
+
+
+def host_goldens():
+    """Schedule arrays and prompt ids straight from the reference's own host functions."""
+    from mug.diffusion.utils import make_ddim_timesteps, make_ddim_sampling_parameters, make_beta_schedule
+    from mug.util import feature_dict_to_embedding_ids, count_beatmap_features
+    with open(os.path.join(refimport.REF, "configs/mug/mania_beatmap_features.yaml")) as f:
+        fy = yaml.safe_load(f)
+    with open(os.path.join(G, "mania_beatmap_features.yaml"), "w") as f:
+        yaml.safe_dump(fy, f, sort_keys=False)
+    betas = make_beta_schedule("linear", 1000, 1e-4, 2e-2)
+    ac = torch.tensor(np.cumprod(1.0 - betas), dtype=torch.float32)
+    out = {}
+    for S in (10, 50, 100, 200, 7):
+        ts = make_ddim_timesteps("uniform", S, 1000, verbose=False)
+        for eta in (0.0, 1.0):
+            sig, a, ap = make_ddim_sampling_parameters(ac.cpu(), ts, eta, verbose=False)
+            o_sig, o_a, o_ap, _ = sampler.ddim_parameters(ac.numpy(), sampler.ddim_timesteps(S), eta)
+            assert np.array_equal(ts, sampler.ddim_timesteps(S))
+            assert np.array_equal(np.asarray(a), o_a) and np.array_equal(np.asarray(ap), o_ap)
+            # eta>0: the reference mixes torch-f32 / numpy-f64 operands; agreement is to f32 rounding, exact for eta=0
+            assert np.allclose(np.asarray(sig), o_sig, rtol=0, atol=(0 if eta == 0 else 1e-7)), (S, eta)
+            out["S%d_eta%g" % (S, eta)] = dict(ts=ts.tolist(), sigmas=np.asarray(sig, dtype=np.float64).tolist(),
+                                               alphas=np.asarray(a, dtype=np.float64).tolist(),
+                                               alphas_prev=np.asarray(ap, dtype=np.float64).tolist())
+    prompts = [{}, {"sr": 4.0, "rank_status": "ranked"}, {"sr": 2.5, "ln_ratio": 0.4},
+               {"sr": 100.0, "ln": True if any(x["name"] == "ln" for x in fy) else None}]
+    for x in fy:   # one prompt exercising every feature at its mid/first value
+        pass
+    full = {}
+    for x in fy:
+        if x["type"] == "numeric":
+            full[x["name"]] = (x["min"] + x["max"]) / 2
+        elif x["type"] == "bool":
+            full[x["name"]] = 1
+        else:
+            full[x["name"]] = x["category"][-1]
+    prompts.append(full)
+    idl = []
+    for pm in prompts:
+        pm = {k: v for k, v in pm.items() if v is not None}
+        r = feature_dict_to_embedding_ids(pm, fy)
+        assert r == host.feature_ids(pm, fy), pm
+        idl.append(dict(prompt=pm, ids=r))
+    assert count_beatmap_features(fy) == host.feature_table_rows(fy)
+    with open(os.path.join(G, "host_golden.json"), "w") as f:
+        json.dump(dict(ddim=out, prompts=idl, table_rows=count_beatmap_features(fy)), f)
+    print("  host goldens: schedules + %d prompts OK" % len(idl))
+
+
+def main():
+    torch.set_num_threads(os.cpu_count())
+    host_goldens()
+    run_case(cases.TINY, [32], {32: [(4, 2, 1.0), (4, 2, 5.0)]})
+    if "--tiny-only" not in sys.argv:
+        run_case(cases.FULL, [96, 512], {96: [(10, 1, 1.0), (10, 1, 5.0)]})
+    with open(os.path.join(G, "oracle_vs_reference.json"), "w") as f:
+        json.dump(REPORT, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
