@@ -1,0 +1,141 @@
+/* mugd.h -- C ABI of libmugd.so, the MI355X (gfx950) implementation of Mug-Diffusion's
+ * sampling hot path:  mel -> wave encoder -> DDIM loop over the 1-D U-Net -> VAE decode.
+ *
+ * The reference (Keytoyze/Mug-Diffusion) has no FFI on this path: it is a Python plugin seam
+ * (`instantiate_from_config`, mug/util.py:93-108) whose objects are torch nn.Modules.  Each
+ * entry point below replaces one of those module calls; the reference interface it stands in
+ * for is cited as file:line (relative to the reference repo).  INTEGRATION.md shows the
+ * ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative mugd_status; it never throws across
+ *     the boundary.  mugd_last_error(ctx) gives the message of the last failure on that ctx.
+ *   - tensors are contiguous row-major fp32 in DEVICE memory, laid out (B, C, T) like the
+ *     reference's; timesteps / token ids are int64.  The caller allocates every output.
+ *   - parameters are BORROWED device pointers (e.g. torch Parameters): the library never
+ *     frees or writes them.  Packed weight copies and baked S4 kernels are library-owned.
+ *   - work is enqueued on the context's stream; calls return without synchronising unless
+ *     noted.  One context per (process, device); not re-entrant (the reference serialises
+ *     requests too: webui.py:858).
+ */
+#ifndef MUGD_H
+#define MUGD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    MUGD_OK = 0,
+    MUGD_ERR_INVALID = -2,      /* bad argument / unsupported shape */
+    MUGD_ERR_HIP = -3,          /* HIP runtime failure */
+    MUGD_ERR_OOM = -4,
+    MUGD_ERR_MISSING_PARAM = -5,/* a state-dict tensor the network needs was not registered */
+    MUGD_ERR_S4_LENGTH = -6,    /* S4 kernel longer than the stored C~ supports (run the host length-doubling first) */
+    MUGD_ERR_INTERNAL = -9
+} mugd_status;
+
+enum { MUGD_F32 = 0, MUGD_I64 = 1 };
+
+typedef struct mugd_ctx mugd_ctx;
+typedef struct mugd_net mugd_net;      /* a U-Net, VAE decoder or wave encoder instance */
+
+/* ---- context ------------------------------------------------------------------------- */
+/* stream: a hipStream_t to enqueue on (e.g. torch's current stream), or NULL to create one. */
+int mugd_create(int device, void* stream, mugd_ctx** out);
+void mugd_destroy(mugd_ctx* ctx);
+const char* mugd_last_error(mugd_ctx* ctx);
+int mugd_synchronize(mugd_ctx* ctx);
+/* 1 (default): replay each DDIM step from a captured hipGraph; 0: launch kernels eagerly. */
+int mugd_set_graph_mode(mugd_ctx* ctx, int enabled);
+const char* mugd_version(void);
+
+/* ---- networks ------------------------------------------------------------------------- */
+/* mug/diffusion/unet.py:262-333 UNetModel.__init__ (the YAML `unet_config.params`). */
+typedef struct {
+    int in_channels, model_channels, out_channels, num_res_blocks;
+    int n_levels;  int channel_mult[8];
+    int n_attn;    int attention_resolutions[8];
+    int num_heads, context_dim;
+    int audio_channels[8];
+    int s4_layer;
+} mugd_unet_config;
+
+/* mug/firststage/autoencoder.py:268-277 Decoder.__init__ (`ddconfig`) + AutoencoderKL.scale. */
+typedef struct {
+    int x_channels, middle_channels, z_channels, num_groups, num_res_blocks;
+    int n_levels;  int channel_mult[8];
+    float scale;
+} mugd_vae_config;
+
+/* mug/cond/wave.py:398-405 MelspectrogramScaleEncoder1D.__init__ (`wave_stage_config.params`). */
+typedef struct {
+    int n_freq, middle_channels, num_res_blocks, num_heads, num_groups;
+    int n_levels;  int channel_mult[16];
+    int n_attn;    int attention_resolutions[8];
+} mugd_wave_config;
+
+int mugd_unet_create(mugd_ctx* ctx, const mugd_unet_config* cfg, mugd_net** out);
+int mugd_vae_create(mugd_ctx* ctx, const mugd_vae_config* cfg, mugd_net** out);
+int mugd_wave_create(mugd_ctx* ctx, const mugd_wave_config* cfg, mugd_net** out);
+void mugd_net_destroy(mugd_net* net);
+
+/* Registers one state-dict tensor (name relative to the sub-model, e.g.
+ * "input_blocks.2.0.in_layers.2.weight"); replaces nn.Module.load_state_dict for the native
+ * side (webui.py:52-58).  dtype MUGD_F32 or MUGD_I64 (the S4 length buffer `...kernel.kernel.L`). */
+int mugd_net_set_param(mugd_net* net, const char* name, const void* dev_ptr, int dtype, int ndim, const int64_t* shape);
+/* Call after parameter VALUES changed in place: drops packed weights, baked S4 kernels, programs. */
+int mugd_net_invalidate(mugd_net* net);
+
+/* UNetModel.forward (mug/diffusion/unet.py:511-550) == MugDiffusionWrapper.forward
+ * (mug/diffusion/diffusion.py:52-54).  x (B,in_ch,z); t (B) int64; context (B,context_dim,n_tok);
+ * audio[l] (B,audio_channels[l], z>>l) for l < n_levels; eps (B,out_ch,z). */
+int mugd_unet_forward(mugd_net* unet, const float* x, const int64_t* t, const float* context, int n_tok,
+                      const float* const* audio, float* eps, int B, int z);
+
+/* DDIMSampler.ddim_sampling + p_sample_ddim (mug/diffusion/ddim.py:110-196): the whole loop on
+ * device.  x: in x_T, out x_0 (B,in_ch,z).  uc may be NULL (no guidance); guidance is applied iff
+ * uc != NULL and scale != 1 (ddim.py:167), as one U-Net call at batch 2B ordered [uncond ; cond].
+ * timesteps[S] (host, already in sampling order, i.e. descending) and sched[S][4] =
+ * {a_t, a_prev, sigma_t, sqrt(1-a_t)} (host fp32, the values p_sample_ddim puts in torch.full).
+ * noise: NULL, or (S,B,in_ch,z) device fp32 consumed as sigma_t * noise[i] (only matters if eta>0).
+ * pred_x0: NULL or (B,in_ch,z) receiving the last step's x_0 prediction. */
+int mugd_ddim_sample(mugd_net* unet, float* x, const float* c, const float* uc, int n_tok,
+                     const float* const* audio, int B, int z, int S, const int64_t* timesteps,
+                     const float* sched, float scale, const float* noise, float* pred_x0);
+
+/* AutoencoderKL.decode (mug/firststage/autoencoder.py:75-77): z (B,z_ch,z) -> logits (B,x_ch,z*2^(n_levels-1)). */
+int mugd_vae_decode(mugd_net* vae, const float* z_lat, float* logits, int B, int z);
+
+/* MelspectrogramScaleEncoder1D.forward (mug/cond/wave.py:450-464): mel (B,n_freq,Ta) ->
+ * outs[l] (B, middle*channel_mult[l], Ta>>l), l < n_levels; a NULL outs[l] skips that copy. */
+int mugd_wave_encode(mugd_net* wave, const float* mel, float* const* outs, int B, int Ta);
+
+/* BeatmapFeatureEmbedder.forward (mug/cond/feature.py:15-21): out[b][h][f] = table[ids[b][f]][h]. */
+int mugd_cond_embed(mugd_ctx* ctx, const float* table, const int64_t* ids, float* out, int B, int n_tok, int dim);
+
+/* load_audio_without_cache's arithmetic after decoding/resampling (mug/util.py:138-143 ->
+ * librosa.feature.melspectrogram, n_fft 512 / hop 128 / 128 mels by default): mono fp32 PCM at
+ * `sr` (device) -> log1p(mel power) rounded to fp16 and widened to fp32, (n_mels, 1 + n/hop). */
+int mugd_log_mel(mugd_ctx* ctx, const float* pcm, int64_t n, int sr, int n_fft, int hop, int n_mels, float* out);
+
+/* ---- single operators (the kernels behind the networks; used by the parity tests) ------ */
+int mugd_op_group_norm(mugd_ctx* ctx, const float* x, const float* gamma, const float* beta, float* y,
+                       int B, int C, int T, int groups, int silu);
+int mugd_op_layer_norm(mugd_ctx* ctx, const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T);
+/* conv1d: w (M, C, taps) torch layout; epi 0 none / 1 GLU / 2 GEGLU (then y has M/2 rows). */
+int mugd_op_conv1d(mugd_ctx* ctx, const float* x, const float* w, const float* bias, const float* resid, float* y,
+                   int B, int C, int Tin, int M, int taps, int dil, int stride, int pad, int upsample, int Tout, int epi);
+int mugd_op_attention(mugd_ctx* ctx, const float* q, const float* k, const float* v, const float* rel, const float* cemb,
+                      float* out, int B, int heads, int d, int Tq, int Tk, int pmax);
+int mugd_op_s4_kernel(mugd_ctx* ctx, const float* C, const float* Bp, const float* P, const float* inv_w_real,
+                      const float* w_imag, const float* log_dt, float* k, int H, int N, int Lint, int L);
+int mugd_op_s4_conv(mugd_ctx* ctx, const float* u, const float* k, const float* D, float* y, int B, int H, int L);
+int mugd_op_timestep_embedding(mugd_ctx* ctx, const int64_t* t, float* out, int B, int dim);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUGD_H */

@@ -1,0 +1,294 @@
+// extern "C" boundary of libmugd.so (see include/mugd.h).  Nothing throws across it.
+#include "../../include/mugd.h"
+
+#include <cstring>
+
+#include "mel.h"
+#include "net.h"
+
+struct mugd_ctx {
+    Ctx c;
+};
+struct mugd_net {
+    mugd_ctx* ctx;
+    int kind;   // 0 unet, 1 vae, 2 wave
+    std::unique_ptr<Net> net;
+};
+
+namespace {
+
+template <class F>
+int guarded(mugd_ctx* ctx, F&& f) {
+    try {
+        f();
+        return MUGD_OK;
+    } catch (const MugdError& e) {
+        if (ctx) ctx->c.last_error = e.what();
+        return e.code;
+    } catch (const std::exception& e) {
+        if (ctx) ctx->c.last_error = e.what();
+        return MUGD_ERR_INTERNAL;
+    } catch (...) {
+        if (ctx) ctx->c.last_error = "unknown exception";
+        return MUGD_ERR_INTERNAL;
+    }
+}
+
+std::vector<int> ivec(const int* p, int n, int cap) {
+    MUGD_CHECK(n >= 0 && n <= cap, MUGD_ERR_INVALID, "config list too long");
+    return std::vector<int>(p, p + n);
+}
+
+// scratch device buffers for the single-operator entry points
+struct Scratch {
+    std::vector<void*> bufs;
+    float* get(size_t nfloats, bool zero, hipStream_t st) {
+        float* p = nullptr;
+        HIP_CHECK(hipMalloc((void**)&p, nfloats * sizeof(float) + 8192));
+        if (zero) HIP_CHECK(hipMemsetAsync(p, 0, nfloats * sizeof(float) + 8192, st));
+        bufs.push_back(p);
+        return p;
+    }
+    ~Scratch() { for (void* p : bufs) hipFree(p); }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* mugd_version(void) { return "mugd 0.1 (gfx950, fp32 MFMA)"; }
+
+int mugd_create(int device, void* stream, mugd_ctx** out) {
+    if (!out) return MUGD_ERR_INVALID;
+    mugd_ctx* ctx = new mugd_ctx();
+    int rc = guarded(ctx, [&] {
+        int n = 0;
+        HIP_CHECK(hipGetDeviceCount(&n));
+        MUGD_CHECK(n > 0, MUGD_ERR_HIP, "no HIP device visible (libmugd has no CPU fallback)");
+        MUGD_CHECK(device >= 0 && device < n, MUGD_ERR_INVALID, "bad device index");
+        HIP_CHECK(hipSetDevice(device));
+        ctx->c.device = device;
+        if (stream) {
+            ctx->c.stream = (hipStream_t)stream;
+        } else {
+            HIP_CHECK(hipStreamCreate(&ctx->c.stream));
+            ctx->c.own_stream = true;
+        }
+        const char* g = getenv("MUGD_NO_GRAPH");
+        ctx->c.use_graph = !(g && g[0] == '1');
+    });
+    if (rc != MUGD_OK) {
+        fprintf(stderr, "mugd_create: %s\n", ctx->c.last_error.c_str());
+        delete ctx;
+        return rc;
+    }
+    *out = ctx;
+    return MUGD_OK;
+}
+
+void mugd_destroy(mugd_ctx* ctx) {
+    if (!ctx) return;
+    hipStreamSynchronize(ctx->c.stream);
+    if (ctx->c.own_stream) hipStreamDestroy(ctx->c.stream);
+    delete ctx;
+}
+
+const char* mugd_last_error(mugd_ctx* ctx) { return ctx ? ctx->c.last_error.c_str() : "null context"; }
+
+int mugd_synchronize(mugd_ctx* ctx) {
+    return guarded(ctx, [&] { HIP_CHECK(hipStreamSynchronize(ctx->c.stream)); });
+}
+
+int mugd_set_graph_mode(mugd_ctx* ctx, int enabled) {
+    if (!ctx) return MUGD_ERR_INVALID;
+    ctx->c.use_graph = enabled != 0;
+    return MUGD_OK;
+}
+
+int mugd_unet_create(mugd_ctx* ctx, const mugd_unet_config* c, mugd_net** out) {
+    return guarded(ctx, [&] {
+        MUGD_CHECK(c && out, MUGD_ERR_INVALID, "null argument");
+        UNetConfig u;
+        u.in_channels = c->in_channels; u.model_channels = c->model_channels; u.out_channels = c->out_channels;
+        u.num_res_blocks = c->num_res_blocks;
+        u.channel_mult = ivec(c->channel_mult, c->n_levels, 8);
+        u.attention_resolutions = ivec(c->attention_resolutions, c->n_attn, 8);
+        u.audio_channels = ivec(c->audio_channels, c->n_levels, 8);
+        u.num_heads = c->num_heads; u.context_dim = c->context_dim; u.s4 = c->s4_layer != 0;
+        MUGD_CHECK(c->n_levels >= 1, MUGD_ERR_INVALID, "need at least one level");
+        mugd_net* n = new mugd_net{ctx, 0, std::unique_ptr<Net>(new UNet(&ctx->c, u))};
+        *out = n;
+    });
+}
+
+int mugd_vae_create(mugd_ctx* ctx, const mugd_vae_config* c, mugd_net** out) {
+    return guarded(ctx, [&] {
+        MUGD_CHECK(c && out, MUGD_ERR_INVALID, "null argument");
+        VaeConfig v;
+        v.x_channels = c->x_channels; v.middle_channels = c->middle_channels; v.z_channels = c->z_channels;
+        v.num_groups = c->num_groups; v.num_res_blocks = c->num_res_blocks;
+        v.channel_mult = ivec(c->channel_mult, c->n_levels, 8);
+        v.scale = c->scale;
+        *out = new mugd_net{ctx, 1, std::unique_ptr<Net>(new VaeDecoder(&ctx->c, v))};
+    });
+}
+
+int mugd_wave_create(mugd_ctx* ctx, const mugd_wave_config* c, mugd_net** out) {
+    return guarded(ctx, [&] {
+        MUGD_CHECK(c && out, MUGD_ERR_INVALID, "null argument");
+        WaveConfig w;
+        w.n_freq = c->n_freq; w.middle_channels = c->middle_channels; w.num_res_blocks = c->num_res_blocks;
+        w.num_heads = c->num_heads; w.num_groups = c->num_groups;
+        w.channel_mult = ivec(c->channel_mult, c->n_levels, 16);
+        w.attention_resolutions = ivec(c->attention_resolutions, c->n_attn, 8);
+        *out = new mugd_net{ctx, 2, std::unique_ptr<Net>(new WaveEncoder(&ctx->c, w))};
+    });
+}
+
+void mugd_net_destroy(mugd_net* net) {
+    if (!net) return;
+    hipStreamSynchronize(net->ctx->c.stream);
+    delete net;
+}
+
+int mugd_net_set_param(mugd_net* net, const char* name, const void* dev_ptr, int dtype, int ndim, const int64_t* shape) {
+    if (!net) return MUGD_ERR_INVALID;
+    return guarded(net->ctx, [&] {
+        MUGD_CHECK(name && dev_ptr && ndim >= 0 && ndim <= 8, MUGD_ERR_INVALID, "bad parameter registration");
+        long long sh[8];
+        for (int i = 0; i < ndim; ++i) sh[i] = shape[i];
+        net->net->set_param(name, dev_ptr, dtype, ndim, sh);
+    });
+}
+
+int mugd_net_invalidate(mugd_net* net) {
+    if (!net) return MUGD_ERR_INVALID;
+    return guarded(net->ctx, [&] { net->net->invalidate(); });
+}
+
+int mugd_unet_forward(mugd_net* net, const float* x, const int64_t* t, const float* context, int n_tok,
+                      const float* const* audio, float* eps, int B, int z) {
+    if (!net) return MUGD_ERR_INVALID;
+    return guarded(net->ctx, [&] {
+        MUGD_CHECK(net->kind == 0, MUGD_ERR_INVALID, "not a U-Net handle");
+        MUGD_CHECK(x && t && context && audio && eps && B > 0 && z > 0, MUGD_ERR_INVALID, "null/empty argument");
+        static_cast<UNet*>(net->net.get())->forward(x, (const long long*)t, context, n_tok, audio, eps, B, z);
+    });
+}
+
+int mugd_ddim_sample(mugd_net* net, float* x, const float* c, const float* uc, int n_tok,
+                     const float* const* audio, int B, int z, int S, const int64_t* timesteps,
+                     const float* sched, float scale, const float* noise, float* pred_x0) {
+    if (!net) return MUGD_ERR_INVALID;
+    return guarded(net->ctx, [&] {
+        MUGD_CHECK(net->kind == 0, MUGD_ERR_INVALID, "not a U-Net handle");
+        MUGD_CHECK(x && c && audio && timesteps && sched && B > 0 && z > 0 && S > 0, MUGD_ERR_INVALID, "null/empty argument");
+        static_cast<UNet*>(net->net.get())->sample(x, c, uc, n_tok, audio, B, z, S, (const long long*)timesteps, sched, scale, noise, pred_x0);
+    });
+}
+
+int mugd_vae_decode(mugd_net* net, const float* z_lat, float* logits, int B, int z) {
+    if (!net) return MUGD_ERR_INVALID;
+    return guarded(net->ctx, [&] {
+        MUGD_CHECK(net->kind == 1, MUGD_ERR_INVALID, "not a VAE handle");
+        MUGD_CHECK(z_lat && logits && B > 0 && z > 0, MUGD_ERR_INVALID, "null/empty argument");
+        static_cast<VaeDecoder*>(net->net.get())->decode(z_lat, logits, B, z);
+    });
+}
+
+int mugd_wave_encode(mugd_net* net, const float* mel, float* const* outs, int B, int Ta) {
+    if (!net) return MUGD_ERR_INVALID;
+    return guarded(net->ctx, [&] {
+        MUGD_CHECK(net->kind == 2, MUGD_ERR_INVALID, "not a wave-encoder handle");
+        MUGD_CHECK(mel && outs && B > 0 && Ta > 0, MUGD_ERR_INVALID, "null/empty argument");
+        static_cast<WaveEncoder*>(net->net.get())->encode(mel, outs, B, Ta);
+    });
+}
+
+int mugd_cond_embed(mugd_ctx* ctx, const float* table, const int64_t* ids, float* out, int B, int n_tok, int dim) {
+    return guarded(ctx, [&] {
+        MUGD_CHECK(table && ids && out && B > 0, MUGD_ERR_INVALID, "null/empty argument");
+        launch_embed_tokens(ctx->c.stream, table, (const long long*)ids, out, B, n_tok, dim);
+    });
+}
+
+int mugd_log_mel(mugd_ctx* ctx, const float* pcm, int64_t n, int sr, int n_fft, int hop, int n_mels, float* out) {
+    return guarded(ctx, [&] {
+        MUGD_CHECK(pcm && out && n > 0, MUGD_ERR_INVALID, "null/empty argument");
+        log_mel(&ctx->c, pcm, (long long)n, sr, n_fft, hop, n_mels, out);
+    });
+}
+
+// ---------------------------------------------------------------- single operators
+int mugd_op_group_norm(mugd_ctx* ctx, const float* x, const float* gamma, const float* beta, float* y,
+                       int B, int C, int T, int groups, int silu) {
+    return guarded(ctx, [&] {
+        GnArgs a{};
+        a.seg[0] = NormSeg{x, C, 0};
+        a.nseg = 1; a.Ctot = C; a.T = T; a.groups = groups; a.B = B; a.silu = silu;
+        a.gamma = gamma; a.beta = beta; a.eps = 1e-6f; a.y = y;
+        launch_group_norm(ctx->c.stream, a);
+    });
+}
+
+int mugd_op_layer_norm(mugd_ctx* ctx, const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T) {
+    return guarded(ctx, [&] {
+        LnArgs a{x, y, gamma, beta, B, C, T, 1e-5f};
+        launch_layer_norm(ctx->c.stream, a);
+    });
+}
+
+int mugd_op_conv1d(mugd_ctx* ctx, const float* x, const float* w, const float* bias, const float* resid, float* y,
+                   int B, int C, int Tin, int M, int taps, int dil, int stride, int pad, int upsample, int Tout, int epi) {
+    return guarded(ctx, [&] {
+        MUGD_CHECK(C % CONV_CK == 0, MUGD_ERR_INVALID, "conv1d: C must be a multiple of 16");
+        hipStream_t st = ctx->c.stream;
+        Scratch sc;
+        const int MT = cdiv(M, 32);
+        const long long mts = (long long)(C / CONV_CK) * taps * 512;
+        float* wpk = sc.get((size_t)MT * mts, true, st);
+        PackArgs pa{wpk, mts, 0, C, taps, w, C * taps, 0, M, 0};
+        launch_pack_weights(st, pa);
+        ConvArgs a{};
+        a.nseg = 1;
+        a.seg[0] = ConvSeg{x, C, Tin, taps, dil, stride, pad, upsample, 0, 0, 0};
+        a.wpk = wpk; a.w_mt_stride = mts; a.bias = bias; a.resid = resid; a.y = y;
+        a.B = B; a.Mrows = M; a.Mout = epi ? M / 2 : M; a.Tout = Tout; a.nchunk = C / CONV_CK; a.epi = epi;
+        launch_conv_gemm(st, a);
+        HIP_CHECK(hipStreamSynchronize(st));
+    });
+}
+
+int mugd_op_attention(mugd_ctx* ctx, const float* q, const float* k, const float* v, const float* rel, const float* cemb,
+                      float* out, int B, int heads, int d, int Tq, int Tk, int pmax) {
+    return guarded(ctx, [&] {
+        AttnArgs a{};
+        const int C = heads * d;
+        a.q = q; a.q_bstride = C * Tq; a.k = k; a.k_bstride = C * Tk; a.v = v; a.v_bstride = C * Tk;
+        a.out = out; a.o_bstride = C * Tq; a.rel = rel; a.cemb = cemb;
+        a.B = B; a.heads = heads; a.d = d; a.Tq = Tq; a.Tk = Tk; a.pmax = pmax;
+        a.scale = 1.0f / sqrtf((float)d);
+        launch_attention(ctx->c.stream, a);
+    });
+}
+
+int mugd_op_s4_kernel(mugd_ctx* ctx, const float* C, const float* Bp, const float* P, const float* inv_w_real,
+                      const float* w_imag, const float* log_dt, float* k, int H, int N, int Lint, int L) {
+    return guarded(ctx, [&] {
+        S4GenArgs a{C, Bp, P, inv_w_real, w_imag, log_dt, H, N, Lint, L, nullptr, k};
+        launch_s4_kernel_gen(ctx->c.stream, a);
+    });
+}
+
+int mugd_op_s4_conv(mugd_ctx* ctx, const float* u, const float* k, const float* D, float* y, int B, int H, int L) {
+    return guarded(ctx, [&] {
+        S4ConvArgs a{u, k, D, y, B, H, L};
+        launch_s4_conv(ctx->c.stream, a);
+    });
+}
+
+int mugd_op_timestep_embedding(mugd_ctx* ctx, const int64_t* t, float* out, int B, int dim) {
+    return guarded(ctx, [&] { launch_timestep_embedding(ctx->c.stream, (const long long*)t, nullptr, out, B, dim); });
+}
+
+}  // extern "C"

@@ -1,0 +1,228 @@
+// conv_gemm: conv1d / linear layers as an implicit GEMM on the gfx950 fp32 matrix cores.
+//
+// One workgroup = 4 wavefronts = one 32(rows) x 32(samples) output tile of one batch row;
+// the 4 waves split the reduction (K) axis between them (intra-workgroup split-K, combined
+// through LDS, deterministic), so even the 512-channel / 64-sample layers put >= 128
+// workgroups x 4 waves on the chip and every SIMD of a CU gets a matrix-core stream.
+//
+// Per wave and K-chunk (16 input channels x taps):
+//   A (weights)     : global -> VGPR, pre-packed in fragment order, 1 KiB coalesced dwordx4
+//                     loads, 16 B/lane, each feeding 4 MFMAs; next chunk prefetched while the
+//                     current one is on the matrix pipe.
+//   B (activations) : global -> VGPR -> per-wave LDS window [16 ch][window], read back in MFMA
+//                     B-fragment order (lane n = sample, lanes 32..63 = +4 channels); the 3 taps
+//                     / dilation / stride / nearest-upsample are just shifted reads of the window.
+//   v_mfma_f32_32x32x2_f32: lane (h,r) supplies A[row r][k=h], lane (h,n) supplies B[k=h][col n];
+//   the K order inside a chunk is permuted to (k=h -> channel 4h+j) so a lane's float4 of
+//   weights is used by 4 consecutive MFMAs.  fp32 in, fp32 accumulate: bitwise an fma chain.
+#include "kernels.h"
+
+namespace {
+
+constexpr int RS = CONV_RS;
+constexpr int WAVE_LDS = CONV_CK * RS;          // floats per wave window (1088)
+constexpr int RED_LDS = 4 * 16 * 64;            // floats for one 4-wave partial-tile exchange
+
+__device__ __forceinline__ void stage_load(const ConvSeg& s, int b, int c0, int t0, int h, int n, float (&r)[24]) {
+    const int RW = 31 * s.stride + (s.taps - 1) * s.dil + 1;
+    const int vlen = s.ups ? 2 * s.Tin : s.Tin;
+    const int u0 = t0 * s.stride - s.pad;
+    const int bb = s.bmod > 0 ? b % s.bmod : b;
+    const float* base = s.x + ((size_t)bb * s.C + c0) * s.Tin;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float* row = base + (size_t)(2 * i + h) * s.Tin;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int cc = n + 32 * k;
+            const int u = u0 + cc;
+            float v = 0.f;
+            if (cc < RW && u >= 0 && u < vlen) v = row[s.ups ? (u >> 1) : u];
+            r[i * 3 + k] = v;
+        }
+    }
+}
+
+__device__ __forceinline__ void stage_store(float* lb, int RW, int h, int n, const float (&r)[24]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int cc = n + 32 * k;
+            if (cc < RW) lb[(2 * i + h) * RS + cc] = r[i * 3 + k];
+        }
+    }
+}
+
+template <int TAPS, bool DUAL>
+__device__ __forceinline__ void load_a(const float* wp, const float* wp2, float4 (&A)[6], float4 (&A2)[6]) {
+#pragma unroll
+    for (int i = 0; i < TAPS * 2; ++i) {
+        A[i] = *reinterpret_cast<const float4*>(wp + i * 256);
+        if (DUAL) A2[i] = *reinterpret_cast<const float4*>(wp2 + i * 256);
+    }
+}
+
+template <int TAPS, bool DUAL>
+__device__ __forceinline__ void compute_chunk(const float* lb, const float4 (&A)[6], const float4 (&A2)[6],
+                                              f32x16& acc, f32x16& acc2, int stride, int dil, int h, int n) {
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+#pragma unroll
+        for (int g8 = 0; g8 < 2; ++g8) {
+            const float* p = lb + (g8 * 8 + 4 * h) * RS + n * stride + tap * dil;
+            const float b0 = p[0], b1 = p[RS], b2 = p[2 * RS], b3 = p[3 * RS];
+            const float4 av = A[tap * 2 + g8];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b3, acc, 0, 0, 0);
+            if (DUAL) {
+                const float4 gv = A2[tap * 2 + g8];
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.x, b0, acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.y, b1, acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.z, b2, acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.w, b3, acc2, 0, 0, 0);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ int find_seg(const ConvArgs& a, int g) {
+    int si = 0;
+    if (a.nseg > 1 && g >= a.seg[1].chunk0) si = 1;
+    if (a.nseg > 2 && g >= a.seg[2].chunk0) si = 2;
+    if (a.nseg > 3 && g >= a.seg[3].chunk0) si = 3;
+    return si;
+}
+
+template <bool DUAL>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
+    __shared__ float smem[DUAL ? 2 * RED_LDS : (4 * WAVE_LDS > RED_LDS ? 4 * WAVE_LDS : RED_LDS)];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, h = lane >> 5, n = lane & 31;
+    const int t0 = blockIdx.x * CONV_TN, mt = blockIdx.y, b = blockIdx.z;
+
+    const int per = (a.nchunk + 3) >> 2;
+    const int g0 = wave * per;
+    const int g1 = (g0 + per < a.nchunk) ? g0 + per : a.nchunk;
+
+    f32x16 acc, acc2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; }
+
+    const float* wtile = a.wpk + (size_t)mt * a.w_mt_stride + lane * 4;
+    const float* wtile2 = DUAL ? wtile + (size_t)(a.Mout >> 5) * a.w_mt_stride : wtile;
+    float* lb = smem + wave * WAVE_LDS;
+
+    float4 A[6], A2[6], An[6], An2[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { A[i] = make_float4(0.f, 0.f, 0.f, 0.f); A2[i] = A[i]; An[i] = A[i]; An2[i] = A[i]; }
+    float xr[24];
+    int si = 0;
+    if (g0 < g1) {
+        si = find_seg(a, g0);
+        const ConvSeg& s = a.seg[si];
+        const int woff = s.woff + (g0 - s.chunk0) * s.taps * 512;
+        if (s.taps == 3) load_a<3, DUAL>(wtile + woff, wtile2 + woff, A, A2);
+        else load_a<1, DUAL>(wtile + woff, wtile2 + woff, A, A2);
+        stage_load(s, b, (g0 - s.chunk0) * CONV_CK, t0, h, n, xr);
+    }
+    for (int g = g0; g < g1; ++g) {
+        const int taps = a.seg[si].taps, stride = a.seg[si].stride, dil = a.seg[si].dil;
+        stage_store(lb, 31 * stride + (taps - 1) * dil + 1, h, n, xr);
+        wave_sync();
+        if (g + 1 < g1) {          // prefetch the next chunk while this one is on the matrix pipe
+            si = find_seg(a, g + 1);
+            const ConvSeg& s = a.seg[si];
+            const int woff = s.woff + (g + 1 - s.chunk0) * s.taps * 512;
+            if (s.taps == 3) load_a<3, DUAL>(wtile + woff, wtile2 + woff, An, An2);
+            else load_a<1, DUAL>(wtile + woff, wtile2 + woff, An, An2);
+            stage_load(s, b, (g + 1 - s.chunk0) * CONV_CK, t0, h, n, xr);
+        }
+        if (taps == 3) compute_chunk<3, DUAL>(lb, A, A2, acc, acc2, stride, dil, h, n);
+        else compute_chunk<1, DUAL>(lb, A, A2, acc, acc2, stride, dil, h, n);
+        wave_sync();               // all lanes done reading the window before it is overwritten
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { A[i] = An[i]; if (DUAL) A2[i] = An2[i]; }
+    }
+
+    // ---- combine the 4 K-slices through LDS (the staging windows are dead after this barrier)
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        smem[(wave * 16 + r) * 64 + lane] = acc[r];
+        if (DUAL) smem[RED_LDS + (wave * 16 + r) * 64 + lane] = acc2[r];
+    }
+    __syncthreads();
+
+    const float* resid = a.resid;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = wave * 4 + q;
+        float v = smem[(0 * 16 + r) * 64 + lane] + smem[(1 * 16 + r) * 64 + lane] +
+                  smem[(2 * 16 + r) * 64 + lane] + smem[(3 * 16 + r) * 64 + lane];
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int m = mt * 32 + row;
+        const int t = t0 + n;
+        if (m < a.Mout && t < a.Tout) {
+            if (a.bias) v += a.bias[m];
+            if (DUAL) {
+                float gte = smem[RED_LDS + (0 * 16 + r) * 64 + lane] + smem[RED_LDS + (1 * 16 + r) * 64 + lane] +
+                            smem[RED_LDS + (2 * 16 + r) * 64 + lane] + smem[RED_LDS + (3 * 16 + r) * 64 + lane];
+                if (a.bias) gte += a.bias[m + a.Mout];
+                v = (a.epi == EPI_GLU) ? v * sigmoid_f(gte) : v * gelu_erf_f(gte);
+            }
+            if (a.rowadd) v += a.rowadd[(size_t)b * a.rowadd_stride + m];
+            const size_t o = ((size_t)b * a.Mout + m) * a.Tout + t;
+            if (resid) v += resid[o];
+            a.y[o] = v;
+        }
+    }
+}
+
+__global__ void pack_weights_kernel(const PackArgs p) {
+    const long long total = (long long)p.rows * p.C * p.taps;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % p.taps);
+        const long long q = i / p.taps;
+        const int ci = (int)(q % p.C);
+        const int ms = (int)(q / p.C);
+        const int m = ms + p.row_off;
+        const int mt = m >> 5, r = m & 31;
+        const int chunk = ci >> 4, within = ci & 15;
+        const int g8 = within >> 3, w8 = within & 7, hh = w8 >> 2, j = w8 & 3;
+        const int lane = hh * 32 + r;
+        const long long d = (long long)mt * p.w_mt_stride + p.seg_woff + (long long)chunk * (p.taps * 512) +
+                            (tap * 2 + g8) * 256 + lane * 4 + j;
+        p.dst[d] = p.src[(long long)ms * p.src_ld + (long long)(p.src_ci_off + ci) * p.taps + tap];
+    }
+}
+
+}  // namespace
+
+void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
+    MUGD_CHECK(a.nseg >= 1 && a.nseg <= CONV_MAXSEG, -2, "conv_gemm: bad segment count");
+    for (int i = 0; i < a.nseg; ++i) {
+        const ConvSeg& s = a.seg[i];
+        MUGD_CHECK(s.C % CONV_CK == 0, -2, "conv_gemm: channels must be a multiple of 16");
+        MUGD_CHECK(s.taps == 1 || s.taps == 3, -2, "conv_gemm: taps must be 1 or 3");
+        MUGD_CHECK(31 * s.stride + (s.taps - 1) * s.dil + 1 <= CONV_RS, -2, "conv_gemm: window exceeds LDS row");
+    }
+    const bool dual = a.epi != EPI_NONE;
+    if (dual) MUGD_CHECK(a.Mout % 32 == 0 && a.Mrows == 2 * a.Mout, -2, "conv_gemm: gated epilogue needs Mout % 32 == 0");
+    else MUGD_CHECK(a.Mrows == a.Mout, -2, "conv_gemm: Mrows != Mout");
+    dim3 grid(cdiv(a.Tout, CONV_TN), cdiv(a.Mout, 32), a.B);
+    if (dual) hipLaunchKernelGGL((conv_gemm_kernel<true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<false>), grid, dim3(256), 0, st, a);
+}
+
+void launch_pack_weights(hipStream_t st, const PackArgs& a) {
+    const long long total = (long long)a.rows * a.C * a.taps;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, st, a);
+}

@@ -1,0 +1,121 @@
+// Small kernels around the U-Net: timestep embedding + its MLP (GEMV class), the fused
+// classifier-free-guidance combine + DDIM update, prompt-token gather, batch duplication and
+// the device-side step counter that lets one captured graph be replayed for every DDIM step.
+#include "kernels.h"
+
+namespace {
+
+// mug/model/util.py:156-176.  freqs follow the reference's fp32 evaluation order:
+// fl32(fl32(-ln(1e4)) * i) / half, then exp; the angle t*f is an fp32 product.
+__global__ void timestep_embedding_kernel(const long long* t, const int* step_idx, float* out, int B, int dim) {
+    const int half = dim / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * half) return;
+    (void)step_idx;
+    const int b = i / half, k = i % half;
+    const float c = (float)(-9.210340371976184);      // -ln(10000)
+    const float x = (c * (float)k) / (float)half;
+    const float f = (float)exp((double)x);
+    const float arg = (float)t[b] * f;
+    out[(size_t)b * dim + k] = cosf(arg);
+    out[(size_t)b * dim + half + k] = sinf(arg);
+    if ((dim & 1) && k == 0) out[(size_t)b * dim + dim - 1] = 0.f;
+}
+
+// y[b][m] = act_out( bias[m] + sum_k W[m][k] * act_in(x[b][k]) ); one wavefront per output row.
+__global__ __launch_bounds__(256) void linear_small_kernel(const LinSmallArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + wave, b = blockIdx.y;
+    if (m >= a.M) return;
+    const float* w = a.W + (size_t)m * a.K;
+    const float* x = a.x + (size_t)b * a.x_stride;
+    float s = 0.f;
+    for (int k = lane; k < a.K; k += 64) {
+        float xv = x[k];
+        if (a.act_in) xv = silu_f(xv);
+        s += w[k] * xv;
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        if (a.bias) s += a.bias[m];
+        if (a.act_out) s = silu_f(s);
+        a.y[(size_t)b * a.y_stride + m] = s;
+    }
+}
+
+// mug/diffusion/ddim.py:170-196 (eta-general; noise may be null when sigma == 0).
+__global__ void ddim_update_kernel(const DdimArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const float* sc = a.sched + 4 * (*a.step_idx);
+    const float a_t = sc[0], a_prev = sc[1], sigma = sc[2], s1m = sc[3];
+    float e;
+    if (a.cfg) {
+        const float e_uc = a.eps[i], e_c = a.eps[a.n + i];
+        e = e_uc + a.scale * (e_c - e_uc);
+    } else {
+        e = a.eps[i];
+    }
+    const float x = a.x[i];
+    const float pred = (x - s1m * e) / sqrtf(a_t);
+    const float dir = sqrtf(1.0f - a_prev - sigma * sigma) * e;
+    float xn = sqrtf(a_prev) * pred + dir;
+    if (a.noise) xn += sigma * a.noise[(size_t)(*a.step_idx) * a.n + i];
+    a.x[i] = xn;
+    if (a.pred_x0) a.pred_x0[i] = pred;
+}
+
+// mug/cond/feature.py:15-21: out[b][h][f] = table[ids[b][f]][h]
+__global__ void embed_tokens_kernel(const float* table, const long long* ids, float* out, int B, int ntok, int dim) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * ntok * dim) return;
+    const int f = i % ntok, hdim = (i / ntok) % dim, b = i / (ntok * dim);
+    out[i] = table[(size_t)ids[b * ntok + f] * dim + hdim];
+}
+
+__global__ void dup_batch_kernel(const float* src, float* dst, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const float v = src[i]; dst[i] = v; dst[n + i] = v; }
+}
+
+__global__ void fill_t_kernel(long long* t_dev, const long long* t_table, const int* step_idx, int B) {
+    const int i = threadIdx.x;
+    if (i < B) t_dev[i] = t_table[*step_idx];
+}
+
+__global__ void advance_kernel(int* step_idx) {
+    if (threadIdx.x == 0) *step_idx += 1;
+}
+
+__global__ void bias_sum_kernel(const float* x, const float* y, float* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (x ? x[i] : 0.f) + (y ? y[i] : 0.f);
+}
+
+}  // namespace
+
+void launch_timestep_embedding(hipStream_t st, const long long* t, const int* step_idx, float* out, int B, int dim) {
+    const int n = B * (dim / 2);
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, t, step_idx, out, B, dim);
+}
+void launch_linear_small(hipStream_t st, const LinSmallArgs& a) {
+    hipLaunchKernelGGL(linear_small_kernel, dim3(cdiv(a.M, 4), a.B), dim3(256), 0, st, a);
+}
+void launch_ddim_update(hipStream_t st, const DdimArgs& a) {
+    hipLaunchKernelGGL(ddim_update_kernel, dim3(cdiv(a.n, 256)), dim3(256), 0, st, a);
+}
+void launch_embed_tokens(hipStream_t st, const float* table, const long long* ids, float* out, int B, int ntok, int dim) {
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3(cdiv(B * ntok * dim, 256)), dim3(256), 0, st, table, ids, out, B, ntok, dim);
+}
+void launch_dup_batch(hipStream_t st, const float* src, float* dst, long long n) {
+    hipLaunchKernelGGL(dup_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n);
+}
+void launch_fill_t(hipStream_t st, long long* t_dev, const long long* t_table, const int* step_idx, int B) {
+    hipLaunchKernelGGL(fill_t_kernel, dim3(1), dim3(256), 0, st, t_dev, t_table, step_idx, B);
+}
+void launch_advance(hipStream_t st, int* step_idx) {
+    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, st, step_idx);
+}
+void launch_bias_sum(hipStream_t st, const float* a, const float* b, float* out, int n) {
+    hipLaunchKernelGGL(bias_sum_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, a, b, out, n);
+}

@@ -1,0 +1,144 @@
+// Kernel argument blocks + launchers.  All tensors are contiguous row-major
+// (B, C, T) "channel-major" fp32: T is the fastest axis, so a wavefront's 64 lanes
+// read 256 contiguous bytes of one channel row.
+#pragma once
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------
+// conv_gemm: Y[b,m,t] = epi( bias[m] + sum_seg sum_ci sum_tap W[m][ci][tap] * X_seg[b,ci,src(t,tap)] )
+// as an implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain).
+//   - up to 4 K-segments (channel concat [h | audio | skip] and the fused 1x1 skip conv are
+//     extra segments: the concat is never materialised);
+//   - per segment: taps 1|3, dilation, stride 1|2, left pad, optional virtual nearest x2 upsample;
+//   - epilogue: + per-(b,m) row term (time embedding), GLU / GEGLU gating over row pairs
+//     (m, m+Mout), + residual.
+// Weights are pre-packed into MFMA A-fragment order (pack_weights): one coalesced 1 KiB
+// global_load_dwordx4 per wave feeds 4 MFMAs; activations go through a per-wave LDS window.
+// ---------------------------------------------------------------------------------------
+constexpr int CONV_CK = 16;       // channels per K-chunk
+constexpr int CONV_TN = 32;       // output samples per tile
+constexpr int CONV_RS = 68;       // LDS row stride (floats) >= max window 31*2 + 2*1 + 1 = 65
+constexpr int CONV_MAXSEG = 4;
+
+struct ConvSeg {
+    const float* x;   // (B, C, Tin)
+    int C;            // multiple of 16
+    int Tin;
+    int taps;         // 1 or 3
+    int dil;
+    int stride;       // 1 or 2
+    int pad;          // left zero padding, in samples of the (virtually upsampled) input
+    int ups;          // 1: input is read through a nearest x2 upsample (virtual length 2*Tin)
+    int chunk0;       // first global K-chunk of this segment
+    int woff;         // float offset of this segment inside one packed 32-row tile block
+    int bmod;         // >0: read batch row (b % bmod)  (CFG halves share one copy of the audio maps)
+};
+
+enum { EPI_NONE = 0, EPI_GLU = 1, EPI_GEGLU = 2 };
+
+struct ConvArgs {
+    ConvSeg seg[CONV_MAXSEG];
+    int nseg;
+    const float* wpk;        // packed weights [MT][w_mt_stride]
+    long long w_mt_stride;   // floats per 32-row tile
+    const float* bias;       // [Mrows] or null
+    const float* rowadd;     // [B][rowadd_stride] or null: added per (b, m) after gating
+    int rowadd_stride;
+    const float* resid;      // (B, Mout, Tout) or null
+    float* y;                // (B, Mout, Tout)
+    int B, Mrows, Mout, Tout, nchunk, epi;
+};
+
+void launch_conv_gemm(hipStream_t st, const ConvArgs& a);
+
+// packs rows [row_off, row_off+rows) x channels [0, C) of one K-segment.
+struct PackArgs {
+    float* dst;              // packed buffer (zero-initialised by the caller)
+    long long w_mt_stride;
+    int seg_woff;            // ConvSeg::woff
+    int C, taps;             // segment geometry
+    const float* src;        // weight tensor [rows][src_ld]: element (m, ci, tap) at m*src_ld + (src_ci_off+ci)*taps + tap
+    int src_ld, src_ci_off;
+    int rows, row_off;
+};
+void launch_pack_weights(hipStream_t st, const PackArgs& a);
+
+// ---------------------------------------------------------------------------------------
+// GroupNorm (+ optional SiLU) over a virtual channel concat, LayerNorm over channels
+// ---------------------------------------------------------------------------------------
+struct NormSeg { const float* x; int C; int bmod; };
+struct GnArgs {
+    NormSeg seg[CONV_MAXSEG];
+    int nseg, Ctot, T, groups, B, silu;
+    const float* gamma; const float* beta;
+    float eps;
+    float* y;                // (B, Ctot, T) contiguous
+};
+void launch_group_norm(hipStream_t st, const GnArgs& a);
+
+struct LnArgs {              // LayerNorm over C for every (b, t) of a (B, C, T) tensor
+    const float* x; float* y; const float* gamma; const float* beta;
+    int B, C, T; float eps;
+};
+void launch_layer_norm(hipStream_t st, const LnArgs& a);
+
+// ---------------------------------------------------------------------------------------
+// relative-position attention (mug/model/attention.py:91-126)
+//   sim = (q.k + Rel[idx,h]) * scale ; P = softmax_j(sim) * Cemb[idx,h] ; out = P v
+//   idx = clamp(j - i, -pmax, pmax) + pmax.   q/k/v/out are channel-major with channel = h*d + dd.
+// ---------------------------------------------------------------------------------------
+struct AttnArgs {
+    const float* q; int q_bstride;     // q[b] = q + b*q_bstride ; element (c, i) at c*Tq + i
+    const float* k; int k_bstride;     // element (c, j) at c*Tk + j
+    const float* v; int v_bstride;
+    float* out; int o_bstride;
+    const float* rel; const float* cemb;   // (2*pmax+1, heads)
+    int B, heads, d, Tq, Tk, pmax;
+    float scale;
+};
+void launch_attention(hipStream_t st, const AttnArgs& a);
+
+// ---------------------------------------------------------------------------------------
+// S4: kernel generation (SSKernelNPLR.forward, s4.py:706-832) and the causal long conv
+// ---------------------------------------------------------------------------------------
+struct S4GenArgs {
+    const float* C; const float* Bp; const float* P;     // (H, N, 2) interleaved complex
+    const float* inv_w_real; const float* w_imag;        // (H, N)
+    const float* log_dt;                                 // (H)
+    int H, N, Lint, L;
+    float* kf;       // workspace (H, Lint/2+1, 2)
+    float* k;        // out (H, L)
+};
+void launch_s4_kernel_gen(hipStream_t st, const S4GenArgs& a);
+
+struct S4ConvArgs {      // y = gelu( causal_conv(k, u) + D*u ),  u,y: (B,H,L), k: (H,L)
+    const float* u; const float* k; const float* D; float* y;
+    int B, H, L;
+};
+void launch_s4_conv(hipStream_t st, const S4ConvArgs& a);
+
+// ---------------------------------------------------------------------------------------
+// small host-visible helpers
+// ---------------------------------------------------------------------------------------
+// y[b][m] = bias[m] + sum_k W[m][k] * f(x[b][k]),  f = SiLU if act_in
+struct LinSmallArgs { const float* x; const float* W; const float* bias; float* y; int B, K, M, act_in, act_out; int x_stride, y_stride; };
+void launch_linear_small(hipStream_t st, const LinSmallArgs& a);
+
+// sinusoidal timestep embedding (mug/model/util.py:156-176): out[b] = [cos(t f) | sin(t f)]
+void launch_timestep_embedding(hipStream_t st, const long long* t, const int* step_idx, float* out, int B, int dim);
+
+// CFG combine + DDIM update (ddim.py:170-196).  eps holds [uncond ; cond] when cfg != 0.
+struct DdimArgs {
+    float* x; const float* eps; const float* noise; float* pred_x0;   // noise: [S][n] indexed by *step_idx
+    const float* sched;      // [S][4] = a_t, a_prev, sigma, sqrt(1-a_t) (device)
+    const int* step_idx;     // device scalar: which row of sched
+    int n;                   // elements per batch half (B*C*T)
+    int cfg; float scale;
+};
+void launch_ddim_update(hipStream_t st, const DdimArgs& a);
+
+void launch_embed_tokens(hipStream_t st, const float* table, const long long* ids, float* out, int B, int ntok, int dim);
+void launch_dup_batch(hipStream_t st, const float* src, float* dst, long long n);          // dst = [src ; src]
+void launch_fill_t(hipStream_t st, long long* t_dev, const long long* t_table, const int* step_idx, int B);
+void launch_advance(hipStream_t st, int* step_idx);
+void launch_bias_sum(hipStream_t st, const float* a, const float* b, float* out, int n);

@@ -1,0 +1,195 @@
+// Host-side runtime: parameter registry, workspace arena, packed-weight cache and the
+// op-program builders for the three networks on the sampling path (U-Net, VAE decoder,
+// wave encoder).  A network is compiled once per (batch, length) into a flat list of kernel
+// launches over arena buffers; the DDIM sampler wraps the U-Net program and replays it from a
+// captured hipGraph, one replay per denoising step.
+#pragma once
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+struct Tensor {
+    float* p = nullptr;
+    int C = 0, T = 0;
+    int bmod = 0;     // >0: batch index is taken modulo bmod (CFG shares the audio maps of both halves)
+};
+
+struct Param {
+    const void* ptr = nullptr;
+    int dtype = 0;                       // 0 = f32, 1 = i64
+    std::vector<long long> shape;
+    long long numel() const { long long n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string last_error;
+    bool use_graph = true;
+};
+
+class Arena {
+public:
+    void begin(bool dry) { dry_ = dry; top_ = 0; if (dry) peak_ = 0; }
+    float* alloc(size_t nfloats);
+    size_t mark() const { return top_; }
+    void release(size_t m) { top_ = m; }
+    size_t peak() const { return peak_; }
+    void reserve(size_t bytes);
+    void free_all();
+private:
+    char* base_ = nullptr;
+    size_t cap_ = 0, top_ = 0, peak_ = 0;
+    bool dry_ = true;
+};
+
+struct ConvIn { Tensor x; int taps = 1, dil = 1, stride = 1, pad = 0, ups = 0; };
+struct WBlock { std::string name; int seg; int row_off; int ci_off; };
+struct ConvSpec {
+    std::string key;
+    std::vector<ConvIn> in;
+    std::vector<WBlock> w;
+    std::vector<std::pair<std::string, int>> bias;
+    int Mrows = 0, Mout = 0, Tout = 0, epi = EPI_NONE;
+    const float* rowadd = nullptr;
+    int rowadd_stride = 0;
+    Tensor resid;
+    Tensor out;
+};
+
+struct PackedW {
+    float* wpk = nullptr;
+    float* bias = nullptr;
+    long long mt_stride = 0;
+    int nchunk = 0;
+    std::vector<int> chunk0, woff;
+};
+
+class Net {
+public:
+    explicit Net(Ctx* c) : ctx(c) {}
+    virtual ~Net();
+    void set_param(const std::string& name, const void* ptr, int dtype, int ndim, const long long* shape);
+    void invalidate();               // parameters changed: drop packed weights / baked kernels / programs
+
+protected:
+    Ctx* ctx;
+    std::map<std::string, Param> params;
+    std::map<std::string, PackedW> packed;
+    std::map<std::string, float*> baked;          // S4 kernels and other derived device tensors
+    std::vector<void*> owned;
+    Arena arena;
+    std::vector<std::function<void(hipStream_t)>> ops;
+    bool dry = true;
+    int Bn = 0;                                   // batch the program is compiled for
+
+    bool has(const std::string& n) const { return params.count(n) != 0; }
+    const Param& P(const std::string& n) const;
+    const float* PF(const std::string& n) const { return (const float*)P(n).ptr; }
+    float* dev_alloc(size_t nfloats, bool zero = false);
+    Tensor talloc(int C, int T) { Tensor t; t.C = C; t.T = T; t.p = arena.alloc((size_t)Bn * C * T); return t; }
+    void emit(std::function<void(hipStream_t)> f) { if (!dry) ops.push_back(std::move(f)); }
+    void run_ops(hipStream_t st) { for (auto& f : ops) f(st); }
+
+    // layer emitters
+    Tensor group_norm(const std::string& prefix, const std::vector<Tensor>& segs, int groups, bool silu);
+    Tensor layer_norm(const std::string& prefix, const Tensor& x);
+    Tensor conv(const ConvSpec& s);
+    Tensor conv_simple(const std::string& prefix, const Tensor& x, int taps, int dil, int stride, int pad, int ups,
+                       int Tout, const Tensor& resid = Tensor(), const Tensor& out = Tensor());
+    Tensor attention(const std::string& prefix, const Tensor& q, const Tensor& k, const Tensor& v, int C, int heads,
+                     int q_off, int k_off, int v_off);
+    Tensor transformer(const std::string& prefix, const Tensor& x, const Tensor* context, int heads);
+    Tensor resnet_block(const std::string& prefix, const Tensor& x, int Cout, int groups, int d0, int d1);
+    Tensor downsample(const std::string& prefix, const Tensor& x);
+    Tensor upsample(const std::string& prefix, const Tensor& x);
+    const float* s4_kernel(const std::string& prefix, int H, int L);
+    Tensor s4_layer(const std::string& prefix, const Tensor& x);
+    const PackedW& get_packed(const ConvSpec& s);
+};
+
+// ---------------------------------------------------------------------------------------
+struct UNetConfig {
+    int in_channels = 16, model_channels = 128, out_channels = 16, num_res_blocks = 2;
+    std::vector<int> channel_mult, attention_resolutions, audio_channels;
+    int num_heads = 8, context_dim = 128;
+    bool s4 = true;
+};
+
+class UNet : public Net {
+public:
+    UNet(Ctx* c, const UNetConfig& cfg) : Net(c), cfg(cfg) {}
+    // eps = unet(x, t, context, audio...)   (mug/diffusion/unet.py:511-550)
+    void forward(const float* x, const long long* t, const float* context, int n_tok,
+                 const float* const* audio, float* eps, int B, int z);
+    // DDIM loop (mug/diffusion/ddim.py:110-196), x updated in place.
+    void sample(float* x, const float* c, const float* uc, int n_tok, const float* const* audio,
+                int B, int z, int S, const long long* t_host, const float* sched_host, float scale,
+                const float* noise, float* pred_x0);
+    void drop_programs();
+    UNetConfig cfg;
+
+private:
+    struct Key { int B = 0, z = 0, ntok = 0, bmod = 0; bool operator==(const Key& o) const { return B == o.B && z == o.z && ntok == o.ntok && bmod == o.bmod; } };
+    Key key;
+    bool built = false;
+    // fixed input / state buffers of the compiled program
+    Tensor in_x, in_ctx, out_eps;
+    std::vector<Tensor> in_audio;
+    long long* t_dev = nullptr;
+    float* emb_rowadd = nullptr;
+    int rowadd_total = 0;
+    // sampler state
+    float* x_state = nullptr;
+    float* sched_dev = nullptr; long long* ttab_dev = nullptr; int* step_dev = nullptr; int sched_cap = 0;
+    float* noise_dev = nullptr; size_t noise_cap = 0;
+    float* pred_dev = nullptr;
+    hipGraphExec_t graph = nullptr; bool graph_cfg = false; bool graph_noise = false; bool graph_pred = false; float graph_scale = 0.f;
+
+    void ensure(int B, int z, int ntok, int bmod);
+    void build(bool dry_run);
+    Tensor resblock(const std::string& prefix, const std::vector<Tensor>& segs, int Cout, int rowadd_off);
+    void prepare_emb();
+    std::vector<std::pair<std::string, int>> resblock_list() const;   // (prefix, Cout) in execution order
+    void step_body(hipStream_t st, bool cfg, float scale, bool with_noise, bool with_pred, int nstate);
+};
+
+struct VaeConfig {
+    int x_channels = 16, middle_channels = 64, z_channels = 16, num_groups = 8, num_res_blocks = 1;
+    std::vector<int> channel_mult;
+    float scale = 1.0f;
+};
+
+class VaeDecoder : public Net {
+public:
+    VaeDecoder(Ctx* c, const VaeConfig& cfg) : Net(c), cfg(cfg) {}
+    void decode(const float* z_lat, float* logits, int B, int z);     // autoencoder.py:75-77,329-354
+    VaeConfig cfg;
+private:
+    int kB = 0, kz = 0; bool built = false;
+    Tensor in_z, out_x;
+    void build(bool dry_run);
+};
+
+struct WaveConfig {
+    int n_freq = 128, middle_channels = 128, num_res_blocks = 2, num_heads = 8, num_groups = 32;
+    std::vector<int> channel_mult, attention_resolutions;
+};
+
+class WaveEncoder : public Net {
+public:
+    WaveEncoder(Ctx* c, const WaveConfig& cfg) : Net(c), cfg(cfg) {}
+    // mel (B, n_freq, Ta) -> one map per level (mug/cond/wave.py:450-464); outs[i] may be null to skip the copy
+    void encode(const float* mel, float* const* outs, int B, int Ta);
+    WaveConfig cfg;
+private:
+    int kB = 0, kT = 0; bool built = false;
+    Tensor in_mel;
+    std::vector<Tensor> level_out;
+    void build(bool dry_run);
+};

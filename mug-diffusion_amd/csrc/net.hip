@@ -1,0 +1,695 @@
+#include "net.h"
+
+#include <algorithm>
+#include <cstring>
+
+// =======================================================================================
+// Arena / Net plumbing
+// =======================================================================================
+static constexpr size_t ALIGN = 256;
+
+float* Arena::alloc(size_t nfloats) {
+    size_t bytes = (nfloats * sizeof(float) + ALIGN - 1) / ALIGN * ALIGN;
+    size_t off = top_;
+    top_ += bytes;
+    if (top_ > peak_) peak_ = top_;
+    if (dry_) return reinterpret_cast<float*>(ALIGN + off);      // never dereferenced
+    MUGD_CHECK(top_ <= cap_, -4, "workspace arena overflow");
+    return reinterpret_cast<float*>(base_ + off);
+}
+void Arena::reserve(size_t bytes) {
+    if (bytes <= cap_) return;
+    if (base_) HIP_CHECK(hipFree(base_));
+    base_ = nullptr;
+    HIP_CHECK(hipMalloc((void**)&base_, bytes));
+    cap_ = bytes;
+}
+void Arena::free_all() {
+    if (base_) hipFree(base_);
+    base_ = nullptr;
+    cap_ = 0;
+}
+
+Net::~Net() {
+    for (void* p : owned) hipFree(p);
+    arena.free_all();
+}
+
+void Net::set_param(const std::string& name, const void* ptr, int dtype, int ndim, const long long* shape) {
+    Param p;
+    p.ptr = ptr;
+    p.dtype = dtype;
+    p.shape.assign(shape, shape + ndim);
+    params[name] = p;
+}
+
+void Net::invalidate() {
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (void* p : owned) hipFree(p);
+    owned.clear();
+    packed.clear();
+    baked.clear();
+    ops.clear();
+}
+
+const Param& Net::P(const std::string& n) const {
+    auto it = params.find(n);
+    MUGD_CHECK(it != params.end(), -5, "missing parameter: " + n);
+    return it->second;
+}
+
+float* Net::dev_alloc(size_t nfloats, bool zero) {
+    float* p = nullptr;
+    size_t bytes = std::max<size_t>(nfloats, 1) * sizeof(float) + 8192;     // slack: A-fragment prefetch may run past the end
+    HIP_CHECK(hipMalloc((void**)&p, bytes));
+    owned.push_back(p);
+    if (zero) HIP_CHECK(hipMemsetAsync(p, 0, bytes, ctx->stream));
+    return p;
+}
+
+// =======================================================================================
+// layer emitters
+// =======================================================================================
+Tensor Net::group_norm(const std::string& prefix, const std::vector<Tensor>& segs, int groups, bool silu) {
+    MUGD_CHECK(!segs.empty() && (int)segs.size() <= CONV_MAXSEG, -2, "group_norm: bad segment count");
+    GnArgs a{};
+    a.nseg = (int)segs.size();
+    int C = 0;
+    for (int i = 0; i < a.nseg; ++i) {
+        a.seg[i] = NormSeg{segs[i].p, segs[i].C, segs[i].bmod};
+        C += segs[i].C;
+        MUGD_CHECK(segs[i].T == segs[0].T, -2, "group_norm: segment lengths differ at " + prefix);
+    }
+    MUGD_CHECK(P(prefix + ".weight").numel() == C, -2, "group_norm: weight size mismatch at " + prefix);
+    Tensor y = talloc(C, segs[0].T);
+    a.Ctot = C; a.T = segs[0].T; a.groups = groups; a.B = Bn; a.silu = silu ? 1 : 0;
+    a.gamma = PF(prefix + ".weight"); a.beta = PF(prefix + ".bias");
+    a.eps = 1e-6f; a.y = y.p;
+    emit([a](hipStream_t st) { launch_group_norm(st, a); });
+    return y;
+}
+
+Tensor Net::layer_norm(const std::string& prefix, const Tensor& x) {
+    Tensor y = talloc(x.C, x.T);
+    LnArgs a{x.p, y.p, PF(prefix + ".weight"), PF(prefix + ".bias"), Bn, x.C, x.T, 1e-5f};
+    emit([a](hipStream_t st) { launch_layer_norm(st, a); });
+    return y;
+}
+
+const PackedW& Net::get_packed(const ConvSpec& s) {
+    auto it = packed.find(s.key);
+    if (it != packed.end()) return it->second;
+    PackedW pw;
+    int chunk = 0, woff = 0;
+    for (auto& in : s.in) {
+        MUGD_CHECK(in.x.C % CONV_CK == 0, -2, "conv: channel count not a multiple of 16 at " + s.key);
+        pw.chunk0.push_back(chunk);
+        pw.woff.push_back(woff);
+        chunk += in.x.C / CONV_CK;
+        woff += (in.x.C / CONV_CK) * in.taps * 512;
+    }
+    pw.nchunk = chunk;
+    pw.mt_stride = woff;
+    const int MT = cdiv(s.Mrows, 32);
+    pw.wpk = dev_alloc((size_t)MT * pw.mt_stride, true);
+    for (auto& wb : s.w) {
+        const Param& p = P(wb.name);
+        MUGD_CHECK(p.dtype == 0 && p.shape.size() >= 2, -2, "conv: bad weight tensor " + wb.name);
+        const ConvIn& in = s.in[wb.seg];
+        const int rows = (int)p.shape[0];
+        const int cw = (int)p.shape[1];
+        const int tw = p.shape.size() > 2 ? (int)p.shape[2] : 1;
+        MUGD_CHECK(tw == in.taps, -2, "conv: kernel width mismatch for " + wb.name);
+        MUGD_CHECK(wb.ci_off + in.x.C <= cw && wb.row_off + rows <= s.Mrows, -2, "conv: weight block out of range: " + wb.name);
+        PackArgs pa{pw.wpk, pw.mt_stride, pw.woff[wb.seg], in.x.C, in.taps, (const float*)p.ptr, cw * tw, wb.ci_off, rows, wb.row_off};
+        launch_pack_weights(ctx->stream, pa);
+    }
+    if (!s.bias.empty()) {
+        pw.bias = dev_alloc(s.Mrows, true);
+        for (auto& b : s.bias) {
+            const Param& p = P(b.first);
+            MUGD_CHECK(b.second + p.numel() <= s.Mrows, -2, "conv: bias out of range: " + b.first);
+            launch_bias_sum(ctx->stream, pw.bias + b.second, (const float*)p.ptr, pw.bias + b.second, (int)p.numel());
+        }
+    }
+    return packed[s.key] = pw;
+}
+
+Tensor Net::conv(const ConvSpec& s) {
+    MUGD_CHECK(!s.in.empty() && (int)s.in.size() <= CONV_MAXSEG, -2, "conv: bad segment count at " + s.key);
+    const PackedW& pw = get_packed(s);
+    Tensor y = s.out.p ? s.out : talloc(s.Mout, s.Tout);
+    ConvArgs a{};
+    a.nseg = (int)s.in.size();
+    for (int i = 0; i < a.nseg; ++i) {
+        const ConvIn& in = s.in[i];
+        a.seg[i] = ConvSeg{in.x.p, in.x.C, in.x.T, in.taps, in.dil, in.stride, in.pad, in.ups, pw.chunk0[i], pw.woff[i], in.x.bmod};
+    }
+    a.wpk = pw.wpk; a.w_mt_stride = pw.mt_stride; a.bias = pw.bias;
+    a.rowadd = s.rowadd; a.rowadd_stride = s.rowadd_stride;
+    a.resid = s.resid.p;
+    if (s.resid.p) MUGD_CHECK(s.resid.C == s.Mout && s.resid.T == s.Tout && s.resid.bmod == 0, -2, "conv: residual shape mismatch at " + s.key);
+    a.y = y.p; a.B = Bn; a.Mrows = s.Mrows; a.Mout = s.Mout; a.Tout = s.Tout; a.nchunk = pw.nchunk; a.epi = s.epi;
+    emit([a](hipStream_t st) { launch_conv_gemm(st, a); });
+    return y;
+}
+
+Tensor Net::conv_simple(const std::string& prefix, const Tensor& x, int taps, int dil, int stride, int pad, int ups,
+                        int Tout, const Tensor& resid, const Tensor& out) {
+    ConvSpec s;
+    s.key = prefix;
+    s.in.push_back(ConvIn{x, taps, dil, stride, pad, ups});
+    s.w.push_back(WBlock{prefix + ".weight", 0, 0, 0});
+    if (has(prefix + ".bias")) s.bias.push_back({prefix + ".bias", 0});
+    s.Mrows = s.Mout = (int)P(prefix + ".weight").shape[0];
+    s.Tout = Tout;
+    s.resid = resid;
+    s.out = out;
+    return conv(s);
+}
+
+Tensor Net::attention(const std::string& prefix, const Tensor& q, const Tensor& k, const Tensor& v, int C, int heads,
+                      int q_off, int k_off, int v_off) {
+    Tensor o = talloc(C, q.T);
+    AttnArgs a{};
+    a.q = q.p + (size_t)q_off * q.T; a.q_bstride = q.C * q.T;
+    a.k = k.p + (size_t)k_off * k.T; a.k_bstride = k.C * k.T;
+    a.v = v.p + (size_t)v_off * v.T; a.v_bstride = v.C * v.T;
+    a.out = o.p; a.o_bstride = C * q.T;
+    const Param& rel = P(prefix + ".relative_position_embedding");
+    a.rel = (const float*)rel.ptr; a.cemb = PF(prefix + ".C_embedding");
+    a.pmax = (int)(rel.shape[0] - 1) / 2;
+    MUGD_CHECK((int)rel.shape[1] == heads, -2, "attention: head count mismatch at " + prefix);
+    a.B = Bn; a.heads = heads; a.d = C / heads; a.Tq = q.T; a.Tk = k.T;
+    a.scale = 1.0f / sqrtf((float)a.d);
+    emit([a](hipStream_t st) { launch_attention(st, a); });
+    return o;
+}
+
+// mug/model/attention.py:154-199 (depth 1).  context == nullptr: attn2 is a second self-attention.
+Tensor Net::transformer(const std::string& prefix, const Tensor& x, const Tensor* context, int heads) {
+    const int C = x.C, T = x.T;
+    Tensor out = talloc(C, T);
+    const size_t mk = arena.mark();
+    Tensor g = group_norm(prefix + ".norm", {x}, 32, false);
+    Tensor h0 = conv_simple(prefix + ".proj_in", g, 1, 1, 1, 0, 0, T);
+    const std::string b = prefix + ".transformer_blocks.0";
+
+    auto self_attn = [&](const std::string& ap, const Tensor& nx) {
+        ConvSpec s;
+        s.key = ap + ".qkv";
+        s.in.push_back(ConvIn{nx});
+        s.w = {WBlock{ap + ".to_q.weight", 0, 0, 0}, WBlock{ap + ".to_k.weight", 0, C, 0}, WBlock{ap + ".to_v.weight", 0, 2 * C, 0}};
+        s.Mrows = s.Mout = 3 * C; s.Tout = T;
+        Tensor qkv = conv(s);
+        return attention(ap, qkv, qkv, qkv, C, heads, 0, C, 2 * C);
+    };
+
+    Tensor n1 = layer_norm(b + ".norm1", h0);
+    Tensor a1 = self_attn(b + ".attn1", n1);
+    Tensor h1 = conv_simple(b + ".attn1.to_out.0", a1, 1, 1, 1, 0, 0, T, h0);
+    Tensor n2 = layer_norm(b + ".norm2", h1);
+    Tensor a2;
+    if (context) {
+        Tensor q2 = conv_simple(b + ".attn2.to_q", n2, 1, 1, 1, 0, 0, T);
+        ConvSpec s;
+        s.key = b + ".attn2.kv";
+        s.in.push_back(ConvIn{*context});
+        s.w = {WBlock{b + ".attn2.to_k.weight", 0, 0, 0}, WBlock{b + ".attn2.to_v.weight", 0, C, 0}};
+        s.Mrows = s.Mout = 2 * C; s.Tout = context->T;
+        Tensor kv = conv(s);
+        a2 = attention(b + ".attn2", q2, kv, kv, C, heads, 0, 0, C);
+    } else {
+        a2 = self_attn(b + ".attn2", n2);
+    }
+    Tensor h2 = conv_simple(b + ".attn2.to_out.0", a2, 1, 1, 1, 0, 0, T, h1);
+    Tensor n3 = layer_norm(b + ".norm3", h2);
+    ConvSpec ff;
+    ff.key = b + ".ff.net.0.proj";
+    ff.in.push_back(ConvIn{n3});
+    ff.w = {WBlock{ff.key + ".weight", 0, 0, 0}};
+    ff.bias = {{ff.key + ".bias", 0}};
+    ff.Mrows = (int)P(ff.key + ".weight").shape[0];
+    ff.Mout = ff.Mrows / 2; ff.Tout = T; ff.epi = EPI_GEGLU;
+    Tensor f = conv(ff);
+    Tensor h3 = conv_simple(b + ".ff.net.2", f, 1, 1, 1, 0, 0, T, h2);
+    conv_simple(prefix + ".proj_out", h3, 1, 1, 1, 0, 0, T, x, out);
+    arena.release(mk);
+    return out;
+}
+
+// mug/model/models.py:94-159 (temb_channels = 0 on this path)
+Tensor Net::resnet_block(const std::string& prefix, const Tensor& x, int Cout, int groups, int d0, int d1) {
+    const int T = x.T;
+    Tensor out = talloc(Cout, T);
+    const size_t mk = arena.mark();
+    Tensor n1 = group_norm(prefix + ".norm1", {x}, groups, true);
+    Tensor h1 = conv_simple(prefix + ".conv1", n1, 3, d0, 1, d0, 0, T);
+    Tensor n2 = group_norm(prefix + ".norm2", {h1}, groups, true);
+    if (has(prefix + ".nin_shortcut.weight")) {
+        ConvSpec s;
+        s.key = prefix + ".conv2+nin";
+        s.in = {ConvIn{n2, 3, d1, 1, d1, 0}, ConvIn{x}};
+        s.w = {WBlock{prefix + ".conv2.weight", 0, 0, 0}, WBlock{prefix + ".nin_shortcut.weight", 1, 0, 0}};
+        s.bias = {{prefix + ".conv2.bias", 0}, {prefix + ".nin_shortcut.bias", 0}};
+        s.Mrows = s.Mout = Cout; s.Tout = T; s.out = out;
+        conv(s);
+    } else {
+        MUGD_CHECK(x.C == Cout, -2, "resnet_block without shortcut must keep channels: " + prefix);
+        conv_simple(prefix + ".conv2", n2, 3, d1, 1, d1, 0, T, x, out);
+    }
+    arena.release(mk);
+    return out;
+}
+
+Tensor Net::downsample(const std::string& prefix, const Tensor& x) {      // models.py:73-91
+    return conv_simple(prefix + ".conv", x, 3, 1, 2, 0, 0, (x.T + 1 - 3) / 2 + 1);
+}
+Tensor Net::upsample(const std::string& prefix, const Tensor& x) {        // models.py:55-70
+    return conv_simple(prefix + ".conv", x, 3, 1, 1, 1, 1, 2 * x.T);
+}
+
+const float* Net::s4_kernel(const std::string& kp, int H, int L) {
+    const std::string key = kp + "#" + std::to_string(L);
+    auto it = baked.find(key);
+    if (it != baked.end()) return it->second;
+    const Param& pl = P(kp + ".L");
+    long long Lst = 0;
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    HIP_CHECK(hipMemcpy(&Lst, pl.ptr, sizeof(long long), hipMemcpyDeviceToHost));
+    MUGD_CHECK(Lst > 0 && Lst >= L, -6,
+               "S4 kernel " + kp + ": stored length L=" + std::to_string(Lst) + " < requested " + std::to_string(L) +
+                   " (the host module must run the length-doubling C~ setup first)");
+    const Param& pc = P(kp + ".C");
+    const int N = (int)pc.shape[pc.shape.size() - 2];
+    MUGD_CHECK(pc.numel() == (long long)H * N * 2, -2, "S4: unexpected C shape at " + kp);
+    float* k = dev_alloc((size_t)H * L);
+    S4GenArgs a{PF(kp + ".C"), PF(kp + ".B"), PF(kp + ".P"), PF(kp + ".inv_w_real"), PF(kp + ".w_imag"), PF(kp + ".log_dt"),
+                H, N, (int)Lst, L, nullptr, k};
+    launch_s4_kernel_gen(ctx->stream, a);
+    return baked[key] = k;
+}
+
+// mug/diffusion/unet.py:76-91 + mug/model/s4.py:1471-1541
+Tensor Net::s4_layer(const std::string& prefix, const Tensor& x) {
+    const int H = x.C, L = x.T;
+    Tensor out = talloc(H, L);
+    const size_t mk = arena.mark();
+    Tensor u = group_norm(prefix + ".norm", {x}, 32, false);
+    const float* k = s4_kernel(prefix + ".s4_model.kernel.kernel", H, L);
+    Tensor y = talloc(H, L);
+    S4ConvArgs ca{u.p, k, PF(prefix + ".s4_model.D"), y.p, Bn, H, L};
+    emit([ca](hipStream_t st) { launch_s4_conv(st, ca); });
+    ConvSpec gl;
+    gl.key = prefix + ".s4_model.output_linear.0";
+    gl.in.push_back(ConvIn{y});
+    gl.w = {WBlock{gl.key + ".weight", 0, 0, 0}};
+    gl.bias = {{gl.key + ".bias", 0}};
+    gl.Mrows = 2 * H; gl.Mout = H; gl.Tout = L; gl.epi = EPI_GLU;
+    Tensor g = conv(gl);
+    conv_simple(prefix + ".out_layer", g, 3, 1, 1, 1, 0, L, x, out);
+    arena.release(mk);
+    return out;
+}
+
+// =======================================================================================
+// U-Net
+// =======================================================================================
+std::vector<std::pair<std::string, int>> UNet::resblock_list() const {
+    std::vector<std::pair<std::string, int>> r;
+    const int mc = cfg.model_channels, nl = (int)cfg.channel_mult.size();
+    int idx = 1;
+    for (int level = 0; level < nl; ++level) {
+        ++idx;                                   // AudioConcatBlock
+        for (int i = 0; i < cfg.num_res_blocks; ++i) r.push_back({"input_blocks." + std::to_string(idx++) + ".0", cfg.channel_mult[level] * mc});
+        if (level != nl - 1) ++idx;              // Downsample
+    }
+    r.push_back({"middle_block.0", cfg.channel_mult[nl - 1] * mc});
+    r.push_back({"middle_block.2", cfg.channel_mult[nl - 1] * mc});
+    idx = 0;
+    for (int level = nl - 1; level >= 0; --level) {
+        ++idx;
+        for (int i = 0; i <= cfg.num_res_blocks; ++i) r.push_back({"output_blocks." + std::to_string(idx++) + ".0", cfg.channel_mult[level] * mc});
+    }
+    return r;
+}
+
+// All 22 `emb_layers` Linear(4mc -> Cout) are stacked into one GEMV so a step needs one launch.
+void UNet::prepare_emb() {
+    if (baked.count("emb.W")) return;
+    auto list = resblock_list();
+    int total = 0;
+    for (auto& e : list) total += e.second;
+    const int K = 4 * cfg.model_channels;
+    float* W = dev_alloc((size_t)total * K);
+    float* bias = dev_alloc(total);
+    int off = 0;
+    for (auto& e : list) {
+        const Param& w = P(e.first + ".emb_layers.1.weight");
+        MUGD_CHECK(w.numel() == (long long)e.second * K, -2, "emb_layers shape mismatch at " + e.first);
+        HIP_CHECK(hipMemcpyAsync(W + (size_t)off * K, w.ptr, (size_t)e.second * K * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(bias + off, P(e.first + ".emb_layers.1.bias").ptr, (size_t)e.second * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        off += e.second;
+    }
+    baked["emb.W"] = W;
+    baked["emb.b"] = bias;
+    rowadd_total = total;
+}
+
+// mug/diffusion/unet.py:212-239
+Tensor UNet::resblock(const std::string& prefix, const std::vector<Tensor>& segs, int Cout, int rowadd_off) {
+    const int T = segs[0].T;
+    Tensor out = talloc(Cout, T);
+    const size_t mk = arena.mark();
+    Tensor n1 = group_norm(prefix + ".in_layers.0", segs, 32, true);
+    ConvSpec c1;
+    c1.key = prefix + ".in_layers.2";
+    c1.in.push_back(ConvIn{n1, 3, 1, 1, 1, 0});
+    c1.w = {WBlock{c1.key + ".weight", 0, 0, 0}};
+    c1.bias = {{c1.key + ".bias", 0}};
+    c1.Mrows = c1.Mout = Cout; c1.Tout = T;
+    c1.rowadd = emb_rowadd + rowadd_off; c1.rowadd_stride = rowadd_total;
+    Tensor h1 = conv(c1);
+    Tensor n2 = group_norm(prefix + ".out_layers.0", {h1}, 32, true);
+    if (has(prefix + ".skip_connection.weight")) {
+        ConvSpec s;
+        s.key = prefix + ".out_layers.3+skip";
+        s.in.push_back(ConvIn{n2, 3, 1, 1, 1, 0});
+        s.w.push_back(WBlock{prefix + ".out_layers.3.weight", 0, 0, 0});
+        int ci = 0;
+        for (size_t i = 0; i < segs.size(); ++i) {
+            s.in.push_back(ConvIn{segs[i]});
+            s.w.push_back(WBlock{prefix + ".skip_connection.weight", (int)i + 1, 0, ci});
+            ci += segs[i].C;
+        }
+        s.bias = {{prefix + ".out_layers.3.bias", 0}, {prefix + ".skip_connection.bias", 0}};
+        s.Mrows = s.Mout = Cout; s.Tout = T; s.out = out;
+        conv(s);
+    } else {
+        MUGD_CHECK(segs.size() == 1 && segs[0].C == Cout, -2, "identity skip needs a single input: " + prefix);
+        conv_simple(prefix + ".out_layers.3", n2, 3, 1, 1, 1, 0, T, segs[0], out);
+    }
+    arena.release(mk);
+    return out;
+}
+
+void UNet::build(bool dry_run) {
+    dry = dry_run;
+    arena.begin(dry_run);
+    ops.clear();
+    Bn = key.B;
+    const int mc = cfg.model_channels, nl = (int)cfg.channel_mult.size(), z = key.z;
+    const bool attn_any = !cfg.attention_resolutions.empty();
+    auto is_attn = [&](int ds) { return std::find(cfg.attention_resolutions.begin(), cfg.attention_resolutions.end(), ds) != cfg.attention_resolutions.end(); };
+    (void)attn_any;
+
+    // ---- fixed buffers
+    in_x = talloc(cfg.in_channels, z);
+    in_ctx = talloc(cfg.context_dim, key.ntok);
+    in_audio.clear();
+    {
+        const int save = Bn;
+        if (key.bmod > 0) Bn = key.bmod;            // the audio maps are stored once and shared by both CFG halves
+        for (int l = 0; l < nl; ++l) {
+            Tensor a = talloc(cfg.audio_channels[l], z >> l);
+            a.bmod = key.bmod;
+            in_audio.push_back(a);
+        }
+        Bn = save;
+    }
+    out_eps = talloc(cfg.out_channels, z);
+    t_dev = reinterpret_cast<long long*>(arena.alloc(2 * (size_t)Bn + 2));
+    Tensor temb = talloc(mc, 1), e1 = talloc(4 * mc, 1), emb = talloc(4 * mc, 1);
+    prepare_emb();
+    emb_rowadd = arena.alloc((size_t)Bn * rowadd_total);
+
+    // ---- time embedding (unet.py:522-523) + all resblock emb_layers in one GEMV
+    {
+        long long* tp = t_dev; float* o = temb.p; int B = Bn, dim = mc;
+        emit([=](hipStream_t st) { launch_timestep_embedding(st, tp, nullptr, o, B, dim); });
+        LinSmallArgs l1{temb.p, PF("time_embed.0.weight"), PF("time_embed.0.bias"), e1.p, Bn, mc, 4 * mc, 0, 1, mc, 4 * mc};
+        emit([=](hipStream_t st) { launch_linear_small(st, l1); });
+        LinSmallArgs l2{e1.p, PF("time_embed.2.weight"), PF("time_embed.2.bias"), emb.p, Bn, 4 * mc, 4 * mc, 0, 0, 4 * mc, 4 * mc};
+        emit([=](hipStream_t st) { launch_linear_small(st, l2); });
+        LinSmallArgs l3{emb.p, baked["emb.W"], baked["emb.b"], emb_rowadd, Bn, 4 * mc, rowadd_total, 1, 0, 4 * mc, rowadd_total};
+        emit([=](hipStream_t st) { launch_linear_small(st, l3); });
+    }
+
+    // ---- down path (unet.py:341-405, 527-535)
+    int ra = 0;                                    // running offset into the stacked emb_layers output
+    std::vector<Tensor> hs;
+    Tensor h = conv_simple("input_blocks.0.0", in_x, 3, 1, 1, 1, 0, z);
+    hs.push_back(h);
+    int idx = 1, ds = 1;
+    for (int level = 0; level < nl; ++level) {
+        ++idx;                                     // AudioConcatBlock: concat is a second K-segment, never materialised
+        std::vector<Tensor> segs = {h, in_audio[level]};
+        const int Cout = cfg.channel_mult[level] * mc;
+        for (int i = 0; i < cfg.num_res_blocks; ++i) {
+            const std::string p = "input_blocks." + std::to_string(idx);
+            h = resblock(p + ".0", segs, Cout, ra);
+            ra += Cout;
+            int j = 1;
+            if (is_attn(ds)) h = transformer(p + "." + std::to_string(j++), h, &in_ctx, cfg.num_heads);
+            if (cfg.s4) h = s4_layer(p + "." + std::to_string(j++), h);
+            hs.push_back(h);
+            segs = {h};
+            ++idx;
+        }
+        if (level != nl - 1) {
+            h = downsample("input_blocks." + std::to_string(idx) + ".0", h);
+            hs.push_back(h);
+            ++idx;
+            ds *= 2;
+        }
+    }
+    // ---- middle (unet.py:412-437)
+    {
+        const int C = cfg.channel_mult[nl - 1] * mc;
+        h = resblock("middle_block.0", {h}, C, ra); ra += C;
+        h = transformer("middle_block.1", h, &in_ctx, cfg.num_heads);
+        h = resblock("middle_block.2", {h}, C, ra); ra += C;
+    }
+    // ---- up path (unet.py:440-487, 539-546)
+    idx = 0;
+    for (int level = nl - 1; level >= 0; --level) {
+        ++idx;
+        std::vector<Tensor> pend = {h, in_audio[level]};
+        const int Cout = cfg.channel_mult[level] * mc;
+        for (int i = 0; i <= cfg.num_res_blocks; ++i) {
+            const std::string p = "output_blocks." + std::to_string(idx);
+            std::vector<Tensor> segs = pend;
+            segs.push_back(hs.back());
+            hs.pop_back();
+            h = resblock(p + ".0", segs, Cout, ra);
+            ra += Cout;
+            int j = 1;
+            if (is_attn(ds)) h = transformer(p + "." + std::to_string(j++), h, &in_ctx, cfg.num_heads);
+            if (cfg.s4 && i != cfg.num_res_blocks) h = s4_layer(p + "." + std::to_string(j++), h);
+            if (level && i == cfg.num_res_blocks) { h = upsample(p + "." + std::to_string(j++), h); ds /= 2; }
+            pend = {h};
+            ++idx;
+        }
+    }
+    MUGD_CHECK(ra == rowadd_total, -2, "internal: emb_layers bookkeeping");
+    Tensor n = group_norm("out.0", {h}, 32, true);
+    conv_simple("out.2", n, 3, 1, 1, 1, 0, z, Tensor(), out_eps);
+}
+
+void UNet::drop_programs() {
+    if (graph) { hipGraphExecDestroy(graph); graph = nullptr; }
+    built = false;
+    ops.clear();
+}
+
+void UNet::ensure(int B, int z, int ntok, int bmod) {
+    Key k{B, z, ntok, bmod};
+    if (built && k == key) return;
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    drop_programs();
+    MUGD_CHECK(z % (1 << ((int)cfg.channel_mult.size() - 1)) == 0, -2, "latent length must be divisible by 2^(levels-1)");
+    key = k;
+    build(true);
+    arena.reserve(arena.peak());
+    build(false);
+    built = true;
+}
+
+void UNet::forward(const float* x, const long long* t, const float* context, int n_tok,
+                   const float* const* audio, float* eps, int B, int z) {
+    ensure(B, z, n_tok, 0);
+    hipStream_t st = ctx->stream;
+    const int nl = (int)cfg.channel_mult.size();
+    HIP_CHECK(hipMemcpyAsync(in_x.p, x, (size_t)B * in_x.C * z * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(t_dev, t, (size_t)B * sizeof(long long), hipMemcpyDeviceToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(in_ctx.p, context, (size_t)B * in_ctx.C * n_tok * sizeof(float), hipMemcpyDeviceToDevice, st));
+    for (int l = 0; l < nl; ++l)
+        HIP_CHECK(hipMemcpyAsync(in_audio[l].p, audio[l], (size_t)B * in_audio[l].C * in_audio[l].T * sizeof(float), hipMemcpyDeviceToDevice, st));
+    run_ops(st);
+    HIP_CHECK(hipMemcpyAsync(eps, out_eps.p, (size_t)B * out_eps.C * z * sizeof(float), hipMemcpyDeviceToDevice, st));
+}
+
+void UNet::step_body(hipStream_t st, bool cfg_on, float scale, bool with_noise, bool with_pred, int nstate) {
+    launch_fill_t(st, t_dev, ttab_dev, step_dev, key.B);
+    if (cfg_on) launch_dup_batch(st, x_state, in_x.p, nstate);
+    else HIP_CHECK(hipMemcpyAsync(in_x.p, x_state, (size_t)nstate * sizeof(float), hipMemcpyDeviceToDevice, st));
+    run_ops(st);
+    DdimArgs d{x_state, out_eps.p, with_noise ? noise_dev : nullptr, with_pred ? pred_dev : nullptr, sched_dev, step_dev, nstate, cfg_on ? 1 : 0, scale};
+    launch_ddim_update(st, d);
+    launch_advance(st, step_dev);
+}
+
+void UNet::sample(float* x, const float* c, const float* uc, int n_tok, const float* const* audio,
+                  int B, int z, int S, const long long* t_host, const float* sched_host, float scale,
+                  const float* noise, float* pred_x0) {
+    const bool cfg_on = (uc != nullptr) && (scale != 1.0f);       // ddim.py:167
+    const int Bnet = cfg_on ? 2 * B : B;
+    ensure(Bnet, z, n_tok, cfg_on ? B : 0);
+    hipStream_t st = ctx->stream;
+    const int nl = (int)cfg.channel_mult.size();
+    const int nstate = B * cfg.in_channels * z;
+    const size_t ctx_n = (size_t)B * in_ctx.C * n_tok;
+
+    if (!x_state || sched_cap < S) {
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (graph) { hipGraphExecDestroy(graph); graph = nullptr; }
+        sched_cap = std::max(S, 64);
+        sched_dev = dev_alloc((size_t)sched_cap * 4);
+        ttab_dev = reinterpret_cast<long long*>(dev_alloc((size_t)sched_cap * 2));
+        step_dev = reinterpret_cast<int*>(dev_alloc(4));
+    }
+    static_assert(sizeof(long long) == 8, "");
+    if (!x_state || (size_t)nstate > noise_cap) {       // state buffers sized for this (B, z)
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (graph) { hipGraphExecDestroy(graph); graph = nullptr; }
+        x_state = dev_alloc(nstate);
+        pred_dev = dev_alloc(nstate);
+        noise_cap = nstate;
+        noise_dev = nullptr;
+    }
+    if (noise) {
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (graph) { hipGraphExecDestroy(graph); graph = nullptr; }
+        noise_dev = dev_alloc((size_t)S * nstate);
+        HIP_CHECK(hipMemcpyAsync(noise_dev, noise, (size_t)S * nstate * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    HIP_CHECK(hipMemcpyAsync(sched_dev, sched_host, (size_t)S * 4 * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(ttab_dev, t_host, (size_t)S * sizeof(long long), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemsetAsync(step_dev, 0, sizeof(int), st));
+    HIP_CHECK(hipMemcpyAsync(x_state, x, (size_t)nstate * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (cfg_on) {                                         // batch order [uncond ; cond]  (ddim.py:173)
+        HIP_CHECK(hipMemcpyAsync(in_ctx.p, uc, ctx_n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(in_ctx.p + ctx_n, c, ctx_n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else {
+        HIP_CHECK(hipMemcpyAsync(in_ctx.p, c, ctx_n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    for (int l = 0; l < nl; ++l)
+        HIP_CHECK(hipMemcpyAsync(in_audio[l].p, audio[l], (size_t)B * in_audio[l].C * in_audio[l].T * sizeof(float), hipMemcpyDeviceToDevice, st));
+
+    const bool wn = noise != nullptr, wp = pred_x0 != nullptr;
+    if (ctx->use_graph) {
+        if (graph && (graph_cfg != cfg_on || graph_noise != wn || graph_pred != wp || graph_scale != scale)) {
+            HIP_CHECK(hipStreamSynchronize(st));
+            hipGraphExecDestroy(graph);
+            graph = nullptr;
+        }
+        if (!graph) {
+            hipGraph_t g = nullptr;
+            HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            step_body(st, cfg_on, scale, wn, wp, nstate);
+            HIP_CHECK(hipStreamEndCapture(st, &g));
+            HIP_CHECK(hipGraphInstantiate(&graph, g, nullptr, nullptr, 0));
+            HIP_CHECK(hipGraphDestroy(g));
+            graph_cfg = cfg_on; graph_noise = wn; graph_pred = wp; graph_scale = scale;
+        }
+        for (int i = 0; i < S; ++i) HIP_CHECK(hipGraphLaunch(graph, st));
+    } else {
+        for (int i = 0; i < S; ++i) step_body(st, cfg_on, scale, wn, wp, nstate);
+    }
+    HIP_CHECK(hipMemcpyAsync(x, x_state, (size_t)nstate * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (wp) HIP_CHECK(hipMemcpyAsync(pred_x0, pred_dev, (size_t)nstate * sizeof(float), hipMemcpyDeviceToDevice, st));
+}
+
+// =======================================================================================
+// VAE decoder  (mug/firststage/autoencoder.py:268-354)
+// =======================================================================================
+void VaeDecoder::build(bool dry_run) {
+    dry = dry_run;
+    arena.begin(dry_run);
+    ops.clear();
+    Bn = kB;
+    const int nres = (int)cfg.channel_mult.size(), g = cfg.num_groups;
+    in_z = talloc(cfg.z_channels, kz);
+    out_x = talloc(cfg.x_channels, kz << (nres - 1));
+    MUGD_CHECK(cfg.scale == 1.0f, -2, "VAE scale != 1 is not supported");    // active config has no `scale` key
+    int block_in = cfg.middle_channels * cfg.channel_mult[nres - 1];
+    Tensor h = conv_simple("decoder.conv_in", in_z, 3, 1, 1, 1, 0, kz);
+    h = resnet_block("decoder.mid.block_1", h, block_in, g, 1, 1);
+    h = resnet_block("decoder.mid.block_2", h, block_in, g, 1, 1);
+    for (int lvl = nres - 1; lvl >= 0; --lvl) {
+        const int block_out = cfg.middle_channels * cfg.channel_mult[lvl];
+        for (int ib = 0; ib <= cfg.num_res_blocks; ++ib)
+            h = resnet_block("decoder.up." + std::to_string(lvl) + ".block." + std::to_string(ib), h, block_out, g, 1, 1);
+        if (lvl != 0) h = upsample("decoder.up." + std::to_string(lvl) + ".upsample", h);
+    }
+    Tensor n = group_norm("decoder.norm_out", {h}, g, true);
+    conv_simple("decoder.conv_out", n, 3, 1, 1, 1, 0, h.T, Tensor(), out_x);
+}
+
+void VaeDecoder::decode(const float* z_lat, float* logits, int B, int z) {
+    if (!built || B != kB || z != kz) {
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        kB = B; kz = z;
+        build(true);
+        arena.reserve(arena.peak());
+        build(false);
+        built = true;
+    }
+    hipStream_t st = ctx->stream;
+    HIP_CHECK(hipMemcpyAsync(in_z.p, z_lat, (size_t)B * in_z.C * z * sizeof(float), hipMemcpyDeviceToDevice, st));
+    run_ops(st);
+    HIP_CHECK(hipMemcpyAsync(logits, out_x.p, (size_t)B * out_x.C * out_x.T * sizeof(float), hipMemcpyDeviceToDevice, st));
+}
+
+// =======================================================================================
+// wave encoder  (mug/cond/wave.py:398-464)
+// =======================================================================================
+void WaveEncoder::build(bool dry_run) {
+    dry = dry_run;
+    arena.begin(dry_run);
+    ops.clear();
+    Bn = kB;
+    const int nres = (int)cfg.channel_mult.size(), g = cfg.num_groups, mid = cfg.middle_channels;
+    in_mel = talloc(cfg.n_freq, kT);
+    level_out.clear();
+    Tensor h = conv_simple("conv_in", in_mel, 3, 1, 1, 1, 0, kT);
+    int ds = 1;
+    for (int lvl = 0; lvl < nres; ++lvl) {
+        const std::string q = "down." + std::to_string(lvl);
+        if (lvl != 0) { h = downsample(q + ".downsample", h); ds *= 2; }
+        const int block_out = mid * cfg.channel_mult[lvl];
+        const bool at = std::find(cfg.attention_resolutions.begin(), cfg.attention_resolutions.end(), ds) != cfg.attention_resolutions.end();
+        for (int ib = 0; ib < cfg.num_res_blocks; ++ib) {
+            const bool even = (ib % 2 == 0);
+            h = resnet_block(q + ".block." + std::to_string(ib), h, block_out, g, even ? 1 : 4, even ? 2 : 8);
+            if (at) h = transformer(q + ".attn." + std::to_string(ib), h, nullptr, cfg.num_heads);
+        }
+        level_out.push_back(h);
+    }
+}
+
+void WaveEncoder::encode(const float* mel, float* const* outs, int B, int Ta) {
+    if (!built || B != kB || Ta != kT) {
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        kB = B; kT = Ta;
+        build(true);
+        arena.reserve(arena.peak());
+        build(false);
+        built = true;
+    }
+    hipStream_t st = ctx->stream;
+    HIP_CHECK(hipMemcpyAsync(in_mel.p, mel, (size_t)B * in_mel.C * Ta * sizeof(float), hipMemcpyDeviceToDevice, st));
+    run_ops(st);
+    for (size_t i = 0; i < level_out.size(); ++i)
+        if (outs[i]) HIP_CHECK(hipMemcpyAsync(outs[i], level_out[i].p, (size_t)B * level_out[i].C * level_out[i].T * sizeof(float), hipMemcpyDeviceToDevice, st));
+}

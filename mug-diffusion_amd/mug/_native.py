@@ -1,0 +1,369 @@
+"""ctypes binding of libmugd.so (the C ABI in include/mugd.h).
+
+PyTorch is used only as the owner of device memory: every call passes raw
+``tensor.data_ptr()`` values and enqueues on torch's current HIP stream.  There
+is NO CPU fallback: if the in-tree HIP library is missing or no GPU is visible,
+``get_lib()`` raises.
+
+(``Lib(path=..., device='cpu')`` can also be pointed at another build of the same
+C ABI; the test-suite uses that to drive tests/emu/libmugd_emu.so, the functional
+CPU emulation of the kernels.  Product code never does.)
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmugd.so")
+
+F32, I64 = 0, 1
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+
+
+class UNetConfig(C.Structure):
+    _fields_ = [("in_channels", _i), ("model_channels", _i), ("out_channels", _i), ("num_res_blocks", _i),
+                ("n_levels", _i), ("channel_mult", _i * 8),
+                ("n_attn", _i), ("attention_resolutions", _i * 8),
+                ("num_heads", _i), ("context_dim", _i),
+                ("audio_channels", _i * 8), ("s4_layer", _i)]
+
+
+class VaeConfig(C.Structure):
+    _fields_ = [("x_channels", _i), ("middle_channels", _i), ("z_channels", _i), ("num_groups", _i),
+                ("num_res_blocks", _i), ("n_levels", _i), ("channel_mult", _i * 8), ("scale", _f)]
+
+
+class WaveConfig(C.Structure):
+    _fields_ = [("n_freq", _i), ("middle_channels", _i), ("num_res_blocks", _i), ("num_heads", _i),
+                ("num_groups", _i), ("n_levels", _i), ("channel_mult", _i * 16),
+                ("n_attn", _i), ("attention_resolutions", _i * 8)]
+
+
+_SIGS = {
+    "mugd_create": [_i, _p, C.POINTER(_p)],
+    "mugd_synchronize": [_p],
+    "mugd_set_graph_mode": [_p, _i],
+    "mugd_unet_create": [_p, C.POINTER(UNetConfig), C.POINTER(_p)],
+    "mugd_vae_create": [_p, C.POINTER(VaeConfig), C.POINTER(_p)],
+    "mugd_wave_create": [_p, C.POINTER(WaveConfig), C.POINTER(_p)],
+    "mugd_net_set_param": [_p, C.c_char_p, _p, _i, _i, C.POINTER(C.c_int64)],
+    "mugd_net_invalidate": [_p],
+    "mugd_unet_forward": [_p, _p, _p, _p, _i, C.POINTER(_p), _p, _i, _i],
+    "mugd_ddim_sample": [_p, _p, _p, _p, _i, C.POINTER(_p), _i, _i, _i, C.POINTER(C.c_int64), C.POINTER(_f), _f, _p, _p],
+    "mugd_vae_decode": [_p, _p, _p, _i, _i],
+    "mugd_wave_encode": [_p, _p, C.POINTER(_p), _i, _i],
+    "mugd_cond_embed": [_p, _p, _p, _p, _i, _i, _i],
+    "mugd_log_mel": [_p, _p, C.c_int64, _i, _i, _i, _i, _p],
+    "mugd_op_group_norm": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i],
+    "mugd_op_layer_norm": [_p, _p, _p, _p, _p, _i, _i, _i],
+    "mugd_op_conv1d": [_p, _p, _p, _p, _p, _p] + [_i] * 11,
+    "mugd_op_attention": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i],
+    "mugd_op_s4_kernel": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i],
+    "mugd_op_s4_conv": [_p, _p, _p, _p, _p, _i, _i, _i],
+    "mugd_op_timestep_embedding": [_p, _p, _p, _i, _i],
+}
+EXPORTS = sorted(list(_SIGS) + ["mugd_destroy", "mugd_net_destroy", "mugd_last_error", "mugd_version"])
+
+
+def _ptr(t):
+    return _p(t.data_ptr()) if t is not None else _p(None)
+
+
+def _ilist(ctype_arr, values):
+    for k, v in enumerate(values):
+        ctype_arr[k] = int(v)
+
+
+class MugdError(RuntimeError):
+    pass
+
+
+class Lib:
+    def __init__(self, path=None, device=None):
+        path = path or LIB_PATH
+        if not os.path.exists(path):
+            raise MugdError("%s not found: build it with `python mug-diffusion_amd/build.py` "
+                            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+        self.path = path
+        self.dll = C.CDLL(path)
+        for name, args in _SIGS.items():
+            fn = getattr(self.dll, name)
+            fn.argtypes = args
+            fn.restype = _i
+        self.dll.mugd_last_error.argtypes = [_p]
+        self.dll.mugd_last_error.restype = C.c_char_p
+        self.dll.mugd_version.restype = C.c_char_p
+        self.dll.mugd_destroy.argtypes = [_p]
+        self.dll.mugd_destroy.restype = None
+        self.dll.mugd_net_destroy.argtypes = [_p]
+        self.dll.mugd_net_destroy.restype = None
+        if device is None:
+            if not torch.cuda.is_available():
+                raise MugdError("no GPU visible to torch: libmugd.so needs an MI355X (no CPU fallback)")
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        stream = None
+        index = 0
+        if self.device.type == "cuda":
+            index = self.device.index or 0
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.ctx = _p()
+        rc = self.dll.mugd_create(index, _p(stream), C.byref(self.ctx))
+        if rc != 0:
+            raise MugdError("mugd_create failed with status %d" % rc)
+        self._nets = []
+
+    # ------------------------------------------------------------------ plumbing
+    def check(self, rc):
+        if rc != 0:
+            msg = self.dll.mugd_last_error(self.ctx)
+            raise MugdError("mugd status %d: %s" % (rc, (msg or b"").decode(errors="replace")))
+
+    def version(self):
+        return self.dll.mugd_version().decode()
+
+    def synchronize(self):
+        self.check(self.dll.mugd_synchronize(self.ctx))
+
+    def set_graph_mode(self, on):
+        self.check(self.dll.mugd_set_graph_mode(self.ctx, 1 if on else 0))
+
+    def f32(self, t):
+        return t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+
+    def empty(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self.device)
+
+    def close(self):
+        if self.ctx:
+            for n in self._nets:
+                n.close()
+            self.dll.mugd_destroy(self.ctx)
+            self.ctx = _p()
+
+    # ------------------------------------------------------------------ networks
+    def unet(self, cfg):
+        c = UNetConfig()
+        c.in_channels, c.model_channels, c.out_channels = cfg["in_channels"], cfg["model_channels"], cfg["out_channels"]
+        c.num_res_blocks = cfg["num_res_blocks"]
+        c.n_levels = len(cfg["channel_mult"])
+        _ilist(c.channel_mult, cfg["channel_mult"])
+        c.n_attn = len(cfg["attention_resolutions"])
+        _ilist(c.attention_resolutions, cfg["attention_resolutions"])
+        c.num_heads, c.context_dim = cfg["num_heads"], cfg["context_dim"]
+        _ilist(c.audio_channels, cfg["audio_channels"])
+        c.s4_layer = 1 if cfg.get("s4_layer", False) else 0
+        h = _p()
+        self.check(self.dll.mugd_unet_create(self.ctx, C.byref(c), C.byref(h)))
+        n = Net(self, h, "unet", dict(cfg))
+        self._nets.append(n)
+        return n
+
+    def vae(self, cfg, scale=1.0):
+        c = VaeConfig()
+        c.x_channels, c.middle_channels, c.z_channels = cfg["x_channels"], cfg["middle_channels"], cfg["z_channels"]
+        c.num_groups, c.num_res_blocks = cfg["num_groups"], cfg["num_res_blocks"]
+        c.n_levels = len(cfg["channel_mult"])
+        _ilist(c.channel_mult, cfg["channel_mult"])
+        c.scale = float(scale)
+        h = _p()
+        self.check(self.dll.mugd_vae_create(self.ctx, C.byref(c), C.byref(h)))
+        n = Net(self, h, "vae", dict(cfg))
+        self._nets.append(n)
+        return n
+
+    def wave(self, cfg):
+        c = WaveConfig()
+        c.n_freq, c.middle_channels, c.num_res_blocks = cfg["n_freq"], cfg["middle_channels"], cfg["num_res_blocks"]
+        c.num_heads, c.num_groups = cfg["num_heads"], cfg["num_groups"]
+        c.n_levels = len(cfg["channel_mult"])
+        _ilist(c.channel_mult, cfg["channel_mult"])
+        c.n_attn = len(cfg["attention_resolutions"])
+        _ilist(c.attention_resolutions, cfg["attention_resolutions"])
+        h = _p()
+        self.check(self.dll.mugd_wave_create(self.ctx, C.byref(c), C.byref(h)))
+        n = Net(self, h, "wave", dict(cfg))
+        self._nets.append(n)
+        return n
+
+    # ------------------------------------------------------------------ helpers
+    def cond_embed(self, table, ids):
+        table = self.f32(table)
+        ids = ids.to(device=self.device, dtype=torch.int64).contiguous()
+        B, ntok = ids.shape
+        out = self.empty(B, table.shape[1], ntok)
+        self.check(self.dll.mugd_cond_embed(self.ctx, _ptr(table), _ptr(ids), _ptr(out), B, ntok, table.shape[1]))
+        return out
+
+    def log_mel(self, pcm, sr=22050, n_fft=512, hop=128, n_mels=128):
+        pcm = self.f32(pcm).reshape(-1)
+        n = pcm.numel()
+        out = self.empty(n_mels, 1 + n // hop)
+        self.check(self.dll.mugd_log_mel(self.ctx, _ptr(pcm), n, sr, n_fft, hop, n_mels, _ptr(out)))
+        return out
+
+    # ------------------------------------------------------------------ single operators
+    def op_group_norm(self, x, gamma, beta, groups, silu):
+        x, gamma, beta = self.f32(x), self.f32(gamma), self.f32(beta)
+        y = torch.empty_like(x)
+        B, Cc, T = x.shape
+        self.check(self.dll.mugd_op_group_norm(self.ctx, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), B, Cc, T, groups, int(silu)))
+        return y
+
+    def op_layer_norm(self, x, gamma, beta):
+        x, gamma, beta = self.f32(x), self.f32(gamma), self.f32(beta)
+        y = torch.empty_like(x)
+        B, Cc, T = x.shape
+        self.check(self.dll.mugd_op_layer_norm(self.ctx, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), B, Cc, T))
+        return y
+
+    def op_conv1d(self, x, w, bias=None, resid=None, dil=1, stride=1, pad=0, upsample=False, Tout=None, epi=0):
+        x, w = self.f32(x), self.f32(w)
+        if w.dim() == 2:
+            w = w[:, :, None].contiguous()
+        bias = self.f32(bias) if bias is not None else None
+        resid = self.f32(resid) if resid is not None else None
+        B, Cc, Tin = x.shape
+        M, _, taps = w.shape
+        if Tout is None:
+            vin = 2 * Tin if upsample else Tin
+            Tout = (vin + 2 * pad - dil * (taps - 1) - 1) // stride + 1
+        y = self.empty(B, M // 2 if epi else M, Tout)
+        self.check(self.dll.mugd_op_conv1d(self.ctx, _ptr(x), _ptr(w), _ptr(bias), _ptr(resid), _ptr(y),
+                                           B, Cc, Tin, M, taps, dil, stride, pad, int(upsample), Tout, epi))
+        return y
+
+    def op_attention(self, q, k, v, rel, cemb, heads):
+        q, k, v, rel, cemb = map(self.f32, (q, k, v, rel, cemb))
+        B, Cc, Tq = q.shape
+        Tk = k.shape[2]
+        out = torch.empty_like(q)
+        self.check(self.dll.mugd_op_attention(self.ctx, _ptr(q), _ptr(k), _ptr(v), _ptr(rel), _ptr(cemb), _ptr(out),
+                                              B, heads, Cc // heads, Tq, Tk, (rel.shape[0] - 1) // 2))
+        return out
+
+    def op_s4_kernel(self, Cp, Bp, Pp, inv_w_real, w_imag, log_dt, Lint, L):
+        Cp, Bp, Pp, inv_w_real, w_imag, log_dt = map(self.f32, (Cp, Bp, Pp, inv_w_real, w_imag, log_dt))
+        H, N = inv_w_real.shape
+        k = self.empty(H, L)
+        self.check(self.dll.mugd_op_s4_kernel(self.ctx, _ptr(Cp), _ptr(Bp), _ptr(Pp), _ptr(inv_w_real), _ptr(w_imag),
+                                              _ptr(log_dt), _ptr(k), H, N, Lint, L))
+        return k
+
+    def op_s4_conv(self, u, k, D):
+        u, k, D = self.f32(u), self.f32(k), self.f32(D)
+        B, H, L = u.shape
+        y = torch.empty_like(u)
+        self.check(self.dll.mugd_op_s4_conv(self.ctx, _ptr(u), _ptr(k), _ptr(D), _ptr(y), B, H, L))
+        return y
+
+    def op_timestep_embedding(self, t, dim):
+        t = t.to(device=self.device, dtype=torch.int64).contiguous()
+        out = self.empty(t.shape[0], dim)
+        self.check(self.dll.mugd_op_timestep_embedding(self.ctx, _ptr(t), _ptr(out), t.shape[0], dim))
+        return out
+
+
+class Net:
+    """A native network instance (U-Net / VAE decoder / wave encoder)."""
+
+    def __init__(self, lib, handle, kind, cfg):
+        self.lib, self.h, self.kind, self.cfg = lib, handle, kind, cfg
+        self._keep = {}      # name -> tensor: keeps the borrowed device memory alive
+
+    def close(self):
+        if self.h:
+            self.lib.dll.mugd_net_destroy(self.h)
+            self.h = _p()
+
+    def set_params(self, tensors, prefix=""):
+        """tensors: name -> torch tensor.  Names starting with `prefix` are registered (prefix stripped)."""
+        lib = self.lib
+        for name, t in tensors.items():
+            if prefix and not name.startswith(prefix):
+                continue
+            key = name[len(prefix):]
+            if t.dtype == torch.int64:
+                td, code = t.detach().to(lib.device).contiguous(), I64
+            else:
+                td, code = lib.f32(t), F32
+            self._keep[key] = td
+            shape = (C.c_int64 * max(1, td.dim()))(*td.shape)
+            lib.check(lib.dll.mugd_net_set_param(self.h, key.encode(), _ptr(td), code, td.dim(), shape))
+        lib.check(lib.dll.mugd_net_invalidate(self.h))
+
+    # U-Net ------------------------------------------------------------------
+    def _audio_ptrs(self, audio, B):
+        nl = len(self.cfg["channel_mult"])
+        maps = [self.lib.f32(a) for a in list(audio)[-nl:]]
+        arr = (_p * nl)(*[_p(a.data_ptr()) for a in maps])
+        return maps, arr
+
+    def forward(self, x, t, context, audio):
+        lib = self.lib
+        x, context = lib.f32(x), lib.f32(context)
+        t = t.to(device=lib.device, dtype=torch.int64).contiguous()
+        B, _, z = x.shape
+        maps, arr = self._audio_ptrs(audio, B)
+        eps = lib.empty(B, self.cfg["out_channels"], z)
+        lib.check(lib.dll.mugd_unet_forward(self.h, _ptr(x), _ptr(t), _ptr(context), context.shape[2], arr, _ptr(eps), B, z))
+        return eps
+
+    def ddim_sample(self, x_T, c, audio, timesteps, sched, uc=None, scale=1.0, noise=None, want_pred_x0=False):
+        """timesteps: sequence of ints in sampling order; sched: (S,4) float32 rows {a_t, a_prev, sigma, sqrt(1-a_t)}."""
+        lib = self.lib
+        x = lib.f32(x_T).clone()
+        c = lib.f32(c)
+        uc = lib.f32(uc) if uc is not None else None
+        B, _, z = x.shape
+        maps, arr = self._audio_ptrs(audio, B)
+        S = len(timesteps)
+        ts = (C.c_int64 * S)(*[int(v) for v in timesteps])
+        flat = [float(v) for row in sched for v in row]
+        sc = (_f * (4 * S))(*flat)
+        noise = lib.f32(noise) if noise is not None else None
+        pred = torch.empty_like(x) if want_pred_x0 else None
+        lib.check(lib.dll.mugd_ddim_sample(self.h, _ptr(x), _ptr(c), _ptr(uc), c.shape[2], arr, B, z, S, ts, sc,
+                                           float(scale), _ptr(noise), _ptr(pred)))
+        return (x, pred) if want_pred_x0 else x
+
+    # VAE --------------------------------------------------------------------
+    def decode(self, z_lat):
+        lib = self.lib
+        z_lat = lib.f32(z_lat)
+        B, _, z = z_lat.shape
+        up = 2 ** (len(self.cfg["channel_mult"]) - 1)
+        out = lib.empty(B, self.cfg["x_channels"], z * up)
+        lib.check(lib.dll.mugd_vae_decode(self.h, _ptr(z_lat), _ptr(out), B, z))
+        return out
+
+    # wave encoder -------------------------------------------------------------
+    def encode(self, mel, only_last=None):
+        lib = self.lib
+        mel = lib.f32(mel)
+        B, _, Ta = mel.shape
+        mults = self.cfg["channel_mult"]
+        nl = len(mults)
+        outs = []
+        for l in range(nl):
+            if only_last is not None and l < nl - only_last:
+                outs.append(None)
+            else:
+                outs.append(lib.empty(B, self.cfg["middle_channels"] * mults[l], Ta >> l))
+        arr = (_p * nl)(*[_ptr(o) for o in outs])
+        lib.check(lib.dll.mugd_wave_encode(self.h, _ptr(mel), arr, B, Ta))
+        return outs
+
+
+_default = None
+
+
+def get_lib():
+    """The process-wide library instance on the current GPU.  Raises if the HIP build or a GPU is missing."""
+    global _default
+    if _default is None:
+        _default = Lib()
+    return _default

@@ -96,8 +96,12 @@ void mfma_16x16x4(float a, float b, const float* c, float* d);
 int lane_id();
 }  // namespace emu
 
+template <class F, class... A>
+static inline std::function<void()> emu_bind(F f, A... a) {   // arguments are evaluated at launch time, like a real launch
+    return [=]() { f(a...); };
+}
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
-    emu::launch((grid), (block), (stream), [=]() { kern(__VA_ARGS__); })
+    emu::launch((grid), (block), (stream), emu_bind(kern, __VA_ARGS__))
 
 // ---------------------------------------------------------------- device intrinsics
 static inline void __syncthreads() { emu::block_barrier(); }
@@ -107,6 +111,7 @@ static inline void __builtin_amdgcn_wave_barrier_emu() { emu::wave_barrier(); }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_nontemporal_load(p) (*(p))
+#define __builtin_amdgcn_readfirstlane(x) (x)
 
 static inline float __shfl_xor(float v, int mask, int width = 64) { (void)width; return emu::wave_xchg(v, emu::lane_id() ^ mask); }
 static inline float __shfl_down(float v, unsigned d, int width = 64) {
@@ -142,8 +147,6 @@ static inline emu_f32x4 emu_mfma16(float a, float b, emu_f32x4 c) {
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu_mfma16((a), (b), (c))
 
 // math
-static inline float __expf(float x) { return expf(x); }
-static inline float __logf(float x) { return logf(x); }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline float __fdividef(float a, float b) { return a / b; }

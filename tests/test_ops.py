@@ -1,0 +1,146 @@
+"""Operator parity: each HIP kernel (through the C ABI) against the plain PyTorch-CPU fp32
+op it replaces, on seeded inputs.  Runs on the emulated build here and on the MI355X under
+`-m gpu`.  Tolerances are fp32-reassociation level (the kernels compute in exact fp32)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import nets, s4 as s4o, weights
+
+
+def rnd(seed, *shape, scale=1.0):
+    return torch.from_numpy(np.random.default_rng(seed).standard_normal(shape).astype(np.float32)) * scale
+
+
+def close(got, ref, atol, rtol=1e-5, what=""):
+    got = got.detach().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = ~(err <= tol)
+    if bad.any():
+        i = int(torch.where(bad.flatten())[0][0])
+        raise AssertionError("%s: %d/%d off, max err %.3e; first bad at %s (ref %.5f got %.5f)" % (
+            what, int(bad.sum()), bad.numel(), float(err[~torch.isnan(err)].max()) if (~torch.isnan(err)).any() else float("nan"),
+            tuple(int(v) for v in np.unravel_index(i, tuple(err.shape))), ref.flatten()[i].item(), got.flatten()[i].item()))
+
+
+@pytest.mark.parametrize("B,C,T,groups,silu", [(2, 64, 48, 32, 1), (1, 96, 100, 32, 0), (2, 32, 33, 8, 1), (1, 32, 16, 32, 1)])
+def test_group_norm(lib, B, C, T, groups, silu):
+    x, g, b = rnd(1, B, C, T, scale=2.0) + 0.5, 1 + 0.1 * rnd(2, C), 0.1 * rnd(3, C)
+    ref = F.group_norm(x, groups, g, b, eps=1e-6)
+    if silu:
+        ref = F.silu(ref)
+    close(lib.op_group_norm(x, g, b, groups, silu), ref, 2e-5, what="group_norm")
+
+
+@pytest.mark.parametrize("B,C,T", [(2, 64, 40), (1, 48, 21), (1, 256, 7)])
+def test_layer_norm(lib, B, C, T):
+    x, g, b = rnd(4, B, C, T, scale=3.0), 1 + 0.1 * rnd(5, C), 0.1 * rnd(6, C)
+    ref = F.layer_norm(x.transpose(1, 2), (C,), g, b, eps=1e-5).transpose(1, 2)
+    close(lib.op_layer_norm(x, g, b), ref, 2e-5, what="layer_norm")
+
+
+CONV_CASES = [
+    # B, C, T, M, taps, dil, stride, pad, ups
+    (2, 32, 40, 32, 3, 1, 1, 1, 0),      # plain k3
+    (1, 48, 33, 64, 1, 1, 1, 0, 0),      # 1x1, ragged T
+    (2, 16, 64, 48, 3, 1, 1, 1, 0),      # single K-chunk (only one wave has work), M not multiple of 32
+    (1, 32, 50, 16, 3, 2, 1, 2, 0),      # dilation 2, M=16 (padded tile)
+    (1, 32, 70, 32, 3, 8, 1, 8, 0),      # dilation 8 (wave encoder)
+    (1, 32, 64, 32, 3, 4, 1, 4, 0),      # dilation 4
+    (2, 32, 48, 32, 3, 1, 2, 0, 0),      # Downsample: pad right 1, stride 2
+    (1, 32, 37, 32, 3, 1, 2, 0, 0),      # Downsample, odd length
+    (2, 32, 24, 32, 3, 1, 1, 1, 1),      # Upsample: nearest x2 then k3
+    (1, 144, 12, 96, 3, 1, 1, 1, 0),     # short sequence (z=96 level 3), K split unevenly over 4 waves
+]
+
+
+@pytest.mark.parametrize("B,C,T,M,taps,dil,stride,pad,ups", CONV_CASES)
+def test_conv1d(lib, B, C, T, M, taps, dil, stride, pad, ups):
+    x, w, b = rnd(7, B, C, T), rnd(8, M, C, taps, scale=1.0 / math.sqrt(C * taps)), 0.1 * rnd(9, M)
+    xin = x.repeat_interleave(2, dim=-1) if ups else x
+    if stride == 2:
+        xin = F.pad(xin, (0, 1))
+    ref = F.conv1d(xin, w, b, stride, pad, dil)
+    resid = rnd(10, *ref.shape)
+    got = lib.op_conv1d(x, w, b, resid, dil=dil, stride=stride, pad=pad, upsample=bool(ups), Tout=ref.shape[-1])
+    close(got, ref + resid, 2e-5, what="conv1d")
+
+
+@pytest.mark.parametrize("epi", [1, 2])
+def test_conv1d_gated(lib, epi):
+    B, C, T, M = 2, 32, 40, 128
+    x, w, b = rnd(11, B, C, T), rnd(12, M, C, 1, scale=1.0 / math.sqrt(C)), 0.1 * rnd(13, M)
+    y = F.conv1d(x, w, b)
+    a, g = y.chunk(2, dim=1)
+    ref = a * torch.sigmoid(g) if epi == 1 else a * F.gelu(g)
+    close(lib.op_conv1d(x, w, b, epi=epi), ref, 2e-5, what="gated conv")
+
+
+def ref_attention(q, k, v, rel, cemb, heads):
+    """mug/model/attention.py:98-124 on channel-major tensors."""
+    B, C, Tq = q.shape
+    Tk = k.shape[2]
+    d = C // heads
+    qh = q.view(B, heads, d, Tq).transpose(2, 3)
+    kh = k.view(B, heads, d, Tk).transpose(2, 3)
+    vh = v.view(B, heads, d, Tk).transpose(2, 3)
+    pm = (rel.shape[0] - 1) // 2
+    idx = (torch.arange(Tk)[None, :] - torch.arange(Tq)[:, None]).clamp(-pm, pm) + pm
+    sim = (qh @ kh.transpose(-1, -2) + rel[idx].permute(2, 0, 1)[None]) * d ** -0.5
+    attn = sim.softmax(-1) * cemb[idx].permute(2, 0, 1)[None]
+    return (attn @ vh).transpose(2, 3).reshape(B, C, Tq)
+
+
+@pytest.mark.parametrize("B,heads,d,Tq,Tk", [(2, 4, 16, 40, 40), (1, 8, 48, 64, 64), (1, 2, 64, 33, 21), (1, 4, 32, 12, 12),
+                                             (1, 2, 32, 100, 100)])
+def test_attention(lib, B, heads, d, Tq, Tk):
+    C = heads * d
+    q, k, v = rnd(14, B, C, Tq), rnd(15, B, C, Tk), rnd(16, B, C, Tk)
+    rel, cemb = 0.5 * rnd(17, 129, heads), 1 + 0.3 * rnd(18, 129, heads)
+    close(lib.op_attention(q, k, v, rel, cemb, heads), ref_attention(q, k, v, rel, cemb, heads), 3e-5, what="attention")
+
+
+def s4_params(H, L, seed=0):
+    man = [["s.kernel.kernel.%s" % n, sh, dt] for n, sh, dt in [
+        ("C", [1, H, 32, 2], "float32"), ("log_dt", [H], "float32"), ("B", [1, H, 32, 2], "float32"),
+        ("P", [1, H, 32, 2], "float32"), ("inv_w_real", [H, 32], "float32"), ("w_imag", [H, 32], "float32"),
+        ("L", [], "int64")]]
+    sd = weights.make_state_dict(man, seed)
+    sd["s.kernel.kernel.L"] = torch.tensor(L, dtype=torch.int64)
+    return sd
+
+
+@pytest.mark.parametrize("H,Lint,L", [(32, 32, 32), (32, 64, 48), (64, 96, 96)])
+def test_s4_kernel(lib, H, Lint, L):
+    sd = s4_params(H, Lint)
+    p = "s.kernel.kernel"
+    got = lib.op_s4_kernel(sd[p + ".C"], sd[p + ".B"], sd[p + ".P"], sd[p + ".inv_w_real"], sd[p + ".w_imag"],
+                           sd[p + ".log_dt"], Lint, L).cpu()
+    exact = s4o.s4_kernel(sd, p, L, "exact")
+    ref = s4o.s4_kernel(sd, p, L, "reference")
+    e_hip, e_ref = (got - exact).abs().max().item(), (ref - exact).abs().max().item()
+    # the fp32 HIP evaluation must be as close to the real-number kernel as the reference's own complex64 one
+    assert e_hip < max(4 * e_ref, 2e-5), (e_hip, e_ref)
+    close(got, ref, 3e-5, what="s4 kernel vs reference arithmetic")
+
+
+@pytest.mark.parametrize("B,H,L", [(2, 32, 40), (1, 48, 300)])
+def test_s4_conv(lib, B, H, L):
+    u, k, D = rnd(20, B, H, L), rnd(21, H, L, scale=0.2), rnd(22, H)
+    ref = F.gelu(s4o.s4_direct_conv(k, u, D).float())
+    close(lib.op_s4_conv(u, k, D), ref, 3e-5, what="s4 conv")
+    # and the reference's FFT formulation agrees with the direct one it stands for
+    k_f, u_f = torch.fft.rfft(k, n=2 * L), torch.fft.rfft(u, n=2 * L)
+    fft = torch.fft.irfft(u_f * k_f[None], n=2 * L)[..., :L] + u * D[None, :, None]
+    close(lib.op_s4_conv(u, k, D), F.gelu(fft), 5e-5, what="s4 conv vs FFT form")
+
+
+def test_timestep_embedding(lib):
+    t = torch.tensor([1, 21, 501, 981], dtype=torch.long)
+    ref = nets.timestep_embedding(t, 128)
+    close(lib.op_timestep_embedding(t, 128), ref, 2e-4, rtol=0, what="timestep embedding")
