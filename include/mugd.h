@@ -91,9 +91,11 @@ int mugd_net_invalidate(mugd_net* net);
 
 /* UNetModel.forward (mug/diffusion/unet.py:511-550) == MugDiffusionWrapper.forward
  * (mug/diffusion/diffusion.py:52-54).  x (B,in_ch,z); t (B) int64; context (B,context_dim,n_tok);
- * audio[l] (B,audio_channels[l], z>>l) for l < n_levels; eps (B,out_ch,z). */
+ * audio[l] (audio_batch, audio_channels[l], z>>l) for l < n_levels; eps (B,out_ch,z).
+ * audio_batch divides B: batch row b reads audio row b % audio_batch, so seeds that share one
+ * audio (webui.py:369-374 stacks `count` copies of it) share one copy of its feature maps. */
 int mugd_unet_forward(mugd_net* unet, const float* x, const int64_t* t, const float* context, int n_tok,
-                      const float* const* audio, float* eps, int B, int z);
+                      const float* const* audio, int audio_batch, float* eps, int B, int z);
 
 /* DDIMSampler.ddim_sampling + p_sample_ddim (mug/diffusion/ddim.py:110-196): the whole loop on
  * device.  x: in x_T, out x_0 (B,in_ch,z).  uc may be NULL (no guidance); guidance is applied iff
@@ -103,8 +105,16 @@ int mugd_unet_forward(mugd_net* unet, const float* x, const int64_t* t, const fl
  * noise: NULL, or (S,B,in_ch,z) device fp32 consumed as sigma_t * noise[i] (only matters if eta>0).
  * pred_x0: NULL or (B,in_ch,z) receiving the last step's x_0 prediction. */
 int mugd_ddim_sample(mugd_net* unet, float* x, const float* c, const float* uc, int n_tok,
-                     const float* const* audio, int B, int z, int S, const int64_t* timesteps,
+                     const float* const* audio, int audio_batch, int B, int z, int S, const int64_t* timesteps,
                      const float* sched, float scale, const float* noise, float* pred_x0);
+
+/* Measurement hook: runs the program last compiled by mugd_unet_forward / mugd_ddim_sample /
+ * mugd_vae_decode / mugd_wave_encode ONCE, eagerly, with a HIP event pair around every kernel
+ * launch, and accumulates per kernel class k < MUGD_PROFILE_KINDS: ms[k], algorithmic flops[k]
+ * (2*MAC of the contractions), launches[k].  mugd_profile_kind_name(k) names the class. */
+#define MUGD_PROFILE_KINDS 7
+int mugd_net_profile(mugd_net* net, double* ms, double* flops, int64_t* launches);
+const char* mugd_profile_kind_name(int k);
 
 /* AutoencoderKL.decode (mug/firststage/autoencoder.py:75-77): z (B,z_ch,z) -> logits (B,x_ch,z*2^(n_levels-1)). */
 int mugd_vae_decode(mugd_net* vae, const float* z_lat, float* logits, int B, int z);

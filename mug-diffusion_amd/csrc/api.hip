@@ -167,25 +167,38 @@ int mugd_net_invalidate(mugd_net* net) {
 }
 
 int mugd_unet_forward(mugd_net* net, const float* x, const int64_t* t, const float* context, int n_tok,
-                      const float* const* audio, float* eps, int B, int z) {
+                      const float* const* audio, int audio_batch, float* eps, int B, int z) {
     if (!net) return MUGD_ERR_INVALID;
     return guarded(net->ctx, [&] {
         MUGD_CHECK(net->kind == 0, MUGD_ERR_INVALID, "not a U-Net handle");
         MUGD_CHECK(x && t && context && audio && eps && B > 0 && z > 0, MUGD_ERR_INVALID, "null/empty argument");
-        static_cast<UNet*>(net->net.get())->forward(x, (const long long*)t, context, n_tok, audio, eps, B, z);
+        static_cast<UNet*>(net->net.get())->forward(x, (const long long*)t, context, n_tok, audio, audio_batch, eps, B, z);
     });
 }
 
 int mugd_ddim_sample(mugd_net* net, float* x, const float* c, const float* uc, int n_tok,
-                     const float* const* audio, int B, int z, int S, const int64_t* timesteps,
+                     const float* const* audio, int audio_batch, int B, int z, int S, const int64_t* timesteps,
                      const float* sched, float scale, const float* noise, float* pred_x0) {
     if (!net) return MUGD_ERR_INVALID;
     return guarded(net->ctx, [&] {
         MUGD_CHECK(net->kind == 0, MUGD_ERR_INVALID, "not a U-Net handle");
         MUGD_CHECK(x && c && audio && timesteps && sched && B > 0 && z > 0 && S > 0, MUGD_ERR_INVALID, "null/empty argument");
-        static_cast<UNet*>(net->net.get())->sample(x, c, uc, n_tok, audio, B, z, S, (const long long*)timesteps, sched, scale, noise, pred_x0);
+        static_cast<UNet*>(net->net.get())->sample(x, c, uc, n_tok, audio, audio_batch, B, z, S, (const long long*)timesteps, sched, scale, noise, pred_x0);
     });
 }
+
+int mugd_net_profile(mugd_net* net, double* ms, double* flops, int64_t* launches) {
+    if (!net) return MUGD_ERR_INVALID;
+    return guarded(net->ctx, [&] {
+        MUGD_CHECK(ms && flops && launches, MUGD_ERR_INVALID, "null argument");
+        static_assert(MUGD_PROFILE_KINDS == OP_KINDS, "profile kinds out of sync");
+        ProfileRow rows[OP_KINDS];
+        net->net->profile_program(rows);
+        for (int k = 0; k < OP_KINDS; ++k) { ms[k] = rows[k].ms; flops[k] = rows[k].flops; launches[k] = rows[k].launches; }
+    });
+}
+
+const char* mugd_profile_kind_name(int k) { return op_kind_name(k); }
 
 int mugd_vae_decode(mugd_net* net, const float* z_lat, float* logits, int B, int z) {
     if (!net) return MUGD_ERR_INVALID;

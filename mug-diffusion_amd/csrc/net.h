@@ -70,12 +70,25 @@ struct PackedW {
     std::vector<int> chunk0, woff;
 };
 
+enum OpKind { OP_CONV = 0, OP_CONV_GATED, OP_GROUP_NORM, OP_LAYER_NORM, OP_ATTENTION, OP_S4_CONV, OP_SMALL, OP_KINDS };
+const char* op_kind_name(int k);
+
+struct Op {
+    std::function<void(hipStream_t)> fn;
+    int kind;
+    double flops;     // algorithmic 2*MAC count of the contractions (0 for bandwidth-class ops)
+};
+
+struct ProfileRow { double ms = 0, flops = 0; long long launches = 0; };
+
 class Net {
 public:
     explicit Net(Ctx* c) : ctx(c) {}
     virtual ~Net();
     void set_param(const std::string& name, const void* ptr, int dtype, int ndim, const long long* shape);
-    void invalidate();               // parameters changed: drop packed weights / baked kernels / programs
+    virtual void invalidate();       // parameters changed: drop packed weights / baked kernels / programs
+    // runs the currently compiled program once, eagerly, with a HIP event pair around every launch
+    void profile_program(ProfileRow* rows /*[OP_KINDS]*/);
 
 protected:
     Ctx* ctx;
@@ -84,7 +97,7 @@ protected:
     std::map<std::string, float*> baked;          // S4 kernels and other derived device tensors
     std::vector<void*> owned;
     Arena arena;
-    std::vector<std::function<void(hipStream_t)>> ops;
+    std::vector<Op> ops;
     bool dry = true;
     int Bn = 0;                                   // batch the program is compiled for
 
@@ -93,8 +106,8 @@ protected:
     const float* PF(const std::string& n) const { return (const float*)P(n).ptr; }
     float* dev_alloc(size_t nfloats, bool zero = false);
     Tensor talloc(int C, int T) { Tensor t; t.C = C; t.T = T; t.p = arena.alloc((size_t)Bn * C * T); return t; }
-    void emit(std::function<void(hipStream_t)> f) { if (!dry) ops.push_back(std::move(f)); }
-    void run_ops(hipStream_t st) { for (auto& f : ops) f(st); }
+    void emit(std::function<void(hipStream_t)> f, int kind = OP_SMALL, double flops = 0) { if (!dry) ops.push_back(Op{std::move(f), kind, flops}); }
+    void run_ops(hipStream_t st) { for (auto& o : ops) o.fn(st); }
 
     // layer emitters
     Tensor group_norm(const std::string& prefix, const std::vector<Tensor>& segs, int groups, bool silu);
@@ -126,12 +139,13 @@ public:
     UNet(Ctx* c, const UNetConfig& cfg) : Net(c), cfg(cfg) {}
     // eps = unet(x, t, context, audio...)   (mug/diffusion/unet.py:511-550)
     void forward(const float* x, const long long* t, const float* context, int n_tok,
-                 const float* const* audio, float* eps, int B, int z);
+                 const float* const* audio, int audio_batch, float* eps, int B, int z);
     // DDIM loop (mug/diffusion/ddim.py:110-196), x updated in place.
-    void sample(float* x, const float* c, const float* uc, int n_tok, const float* const* audio,
+    void sample(float* x, const float* c, const float* uc, int n_tok, const float* const* audio, int audio_batch,
                 int B, int z, int S, const long long* t_host, const float* sched_host, float scale,
                 const float* noise, float* pred_x0);
     void drop_programs();
+    void invalidate() override;
     UNetConfig cfg;
 
 private:
@@ -147,7 +161,7 @@ private:
     // sampler state
     float* x_state = nullptr;
     float* sched_dev = nullptr; long long* ttab_dev = nullptr; int* step_dev = nullptr; int sched_cap = 0;
-    float* noise_dev = nullptr; size_t noise_cap = 0;
+    float* noise_dev = nullptr; size_t noise_cap = 0, state_cap = 0;
     float* pred_dev = nullptr;
     hipGraphExec_t graph = nullptr; bool graph_cfg = false; bool graph_noise = false; bool graph_pred = false; float graph_scale = 0.f;
 
@@ -169,6 +183,7 @@ class VaeDecoder : public Net {
 public:
     VaeDecoder(Ctx* c, const VaeConfig& cfg) : Net(c), cfg(cfg) {}
     void decode(const float* z_lat, float* logits, int B, int z);     // autoencoder.py:75-77,329-354
+    void invalidate() override { Net::invalidate(); built = false; }
     VaeConfig cfg;
 private:
     int kB = 0, kz = 0; bool built = false;
@@ -186,6 +201,7 @@ public:
     WaveEncoder(Ctx* c, const WaveConfig& cfg) : Net(c), cfg(cfg) {}
     // mel (B, n_freq, Ta) -> one map per level (mug/cond/wave.py:450-464); outs[i] may be null to skip the copy
     void encode(const float* mel, float* const* outs, int B, int Ta);
+    void invalidate() override { Net::invalidate(); built = false; }
     WaveConfig cfg;
 private:
     int kB = 0, kT = 0; bool built = false;

@@ -43,6 +43,31 @@ void Net::set_param(const std::string& name, const void* ptr, int dtype, int ndi
     params[name] = p;
 }
 
+const char* op_kind_name(int k) {
+    static const char* n[OP_KINDS] = {"conv_gemm", "conv_gemm_gated", "group_norm", "layer_norm", "attention", "s4_conv", "small"};
+    return (k >= 0 && k < OP_KINDS) ? n[k] : "?";
+}
+
+void Net::profile_program(ProfileRow* rows) {
+    hipStream_t st = ctx->stream;
+    std::vector<hipEvent_t> ev(ops.size() + 1);
+    for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipEventRecord(ev[0], st));
+    for (size_t i = 0; i < ops.size(); ++i) {
+        ops[i].fn(st);
+        HIP_CHECK(hipEventRecord(ev[i + 1], st));
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+    for (size_t i = 0; i < ops.size(); ++i) {
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+        ProfileRow& r = rows[ops[i].kind];
+        r.ms += ms; r.flops += ops[i].flops; r.launches += 1;
+    }
+    for (auto& e : ev) hipEventDestroy(e);
+}
+
 void Net::invalidate() {
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (void* p : owned) hipFree(p);
@@ -85,14 +110,14 @@ Tensor Net::group_norm(const std::string& prefix, const std::vector<Tensor>& seg
     a.Ctot = C; a.T = segs[0].T; a.groups = groups; a.B = Bn; a.silu = silu ? 1 : 0;
     a.gamma = PF(prefix + ".weight"); a.beta = PF(prefix + ".bias");
     a.eps = 1e-6f; a.y = y.p;
-    emit([a](hipStream_t st) { launch_group_norm(st, a); });
+    emit([a](hipStream_t st) { launch_group_norm(st, a); }, OP_GROUP_NORM);
     return y;
 }
 
 Tensor Net::layer_norm(const std::string& prefix, const Tensor& x) {
     Tensor y = talloc(x.C, x.T);
     LnArgs a{x.p, y.p, PF(prefix + ".weight"), PF(prefix + ".bias"), Bn, x.C, x.T, 1e-5f};
-    emit([a](hipStream_t st) { launch_layer_norm(st, a); });
+    emit([a](hipStream_t st) { launch_layer_norm(st, a); }, OP_LAYER_NORM);
     return y;
 }
 
@@ -150,7 +175,9 @@ Tensor Net::conv(const ConvSpec& s) {
     a.resid = s.resid.p;
     if (s.resid.p) MUGD_CHECK(s.resid.C == s.Mout && s.resid.T == s.Tout && s.resid.bmod == 0, -2, "conv: residual shape mismatch at " + s.key);
     a.y = y.p; a.B = Bn; a.Mrows = s.Mrows; a.Mout = s.Mout; a.Tout = s.Tout; a.nchunk = pw.nchunk; a.epi = s.epi;
-    emit([a](hipStream_t st) { launch_conv_gemm(st, a); });
+    double kdim = 0;
+    for (auto& in : s.in) kdim += (double)in.x.C * in.taps;
+    emit([a](hipStream_t st) { launch_conv_gemm(st, a); }, s.epi ? OP_CONV_GATED : OP_CONV, 2.0 * s.Mrows * kdim * s.Tout * Bn);
     return y;
 }
 
@@ -182,7 +209,7 @@ Tensor Net::attention(const std::string& prefix, const Tensor& q, const Tensor& 
     MUGD_CHECK((int)rel.shape[1] == heads, -2, "attention: head count mismatch at " + prefix);
     a.B = Bn; a.heads = heads; a.d = C / heads; a.Tq = q.T; a.Tk = k.T;
     a.scale = 1.0f / sqrtf((float)a.d);
-    emit([a](hipStream_t st) { launch_attention(st, a); });
+    emit([a](hipStream_t st) { launch_attention(st, a); }, OP_ATTENTION, 4.0 * Bn * C * (double)q.T * k.T);
     return o;
 }
 
@@ -299,7 +326,7 @@ Tensor Net::s4_layer(const std::string& prefix, const Tensor& x) {
     const float* k = s4_kernel(prefix + ".s4_model.kernel.kernel", H, L);
     Tensor y = talloc(H, L);
     S4ConvArgs ca{u.p, k, PF(prefix + ".s4_model.D"), y.p, Bn, H, L};
-    emit([ca](hipStream_t st) { launch_s4_conv(st, ca); });
+    emit([ca](hipStream_t st) { launch_s4_conv(st, ca); }, OP_S4_CONV);
     ConvSpec gl;
     gl.key = prefix + ".s4_model.output_linear.0";
     gl.in.push_back(ConvIn{y});
@@ -496,6 +523,14 @@ void UNet::build(bool dry_run) {
     conv_simple("out.2", n, 3, 1, 1, 1, 0, z, Tensor(), out_eps);
 }
 
+void UNet::invalidate() {
+    drop_programs();
+    Net::invalidate();
+    x_state = pred_dev = noise_dev = sched_dev = nullptr;
+    ttab_dev = nullptr; step_dev = nullptr;
+    sched_cap = 0; noise_cap = state_cap = 0;
+}
+
 void UNet::drop_programs() {
     if (graph) { hipGraphExecDestroy(graph); graph = nullptr; }
     built = false;
@@ -515,16 +550,21 @@ void UNet::ensure(int B, int z, int ntok, int bmod) {
     built = true;
 }
 
+static int audio_bmod(int audio_batch, int Bnet, int B) {
+    MUGD_CHECK(audio_batch >= 1 && audio_batch <= B && B % audio_batch == 0, -2, "audio_batch must divide the batch size");
+    return audio_batch == Bnet ? 0 : audio_batch;
+}
+
 void UNet::forward(const float* x, const long long* t, const float* context, int n_tok,
-                   const float* const* audio, float* eps, int B, int z) {
-    ensure(B, z, n_tok, 0);
+                   const float* const* audio, int audio_batch, float* eps, int B, int z) {
+    ensure(B, z, n_tok, audio_bmod(audio_batch, B, B));
     hipStream_t st = ctx->stream;
     const int nl = (int)cfg.channel_mult.size();
     HIP_CHECK(hipMemcpyAsync(in_x.p, x, (size_t)B * in_x.C * z * sizeof(float), hipMemcpyDeviceToDevice, st));
     HIP_CHECK(hipMemcpyAsync(t_dev, t, (size_t)B * sizeof(long long), hipMemcpyDeviceToDevice, st));
     HIP_CHECK(hipMemcpyAsync(in_ctx.p, context, (size_t)B * in_ctx.C * n_tok * sizeof(float), hipMemcpyDeviceToDevice, st));
     for (int l = 0; l < nl; ++l)
-        HIP_CHECK(hipMemcpyAsync(in_audio[l].p, audio[l], (size_t)B * in_audio[l].C * in_audio[l].T * sizeof(float), hipMemcpyDeviceToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(in_audio[l].p, audio[l], (size_t)audio_batch * in_audio[l].C * in_audio[l].T * sizeof(float), hipMemcpyDeviceToDevice, st));
     run_ops(st);
     HIP_CHECK(hipMemcpyAsync(eps, out_eps.p, (size_t)B * out_eps.C * z * sizeof(float), hipMemcpyDeviceToDevice, st));
 }
@@ -539,38 +579,41 @@ void UNet::step_body(hipStream_t st, bool cfg_on, float scale, bool with_noise, 
     launch_advance(st, step_dev);
 }
 
-void UNet::sample(float* x, const float* c, const float* uc, int n_tok, const float* const* audio,
+void UNet::sample(float* x, const float* c, const float* uc, int n_tok, const float* const* audio, int audio_batch,
                   int B, int z, int S, const long long* t_host, const float* sched_host, float scale,
                   const float* noise, float* pred_x0) {
     const bool cfg_on = (uc != nullptr) && (scale != 1.0f);       // ddim.py:167
     const int Bnet = cfg_on ? 2 * B : B;
-    ensure(Bnet, z, n_tok, cfg_on ? B : 0);
+    ensure(Bnet, z, n_tok, audio_bmod(audio_batch, Bnet, B));
     hipStream_t st = ctx->stream;
     const int nl = (int)cfg.channel_mult.size();
     const int nstate = B * cfg.in_channels * z;
     const size_t ctx_n = (size_t)B * in_ctx.C * n_tok;
 
-    if (!x_state || sched_cap < S) {
+    static_assert(sizeof(long long) == 8, "");
+    auto drop_graph = [&] {
         HIP_CHECK(hipStreamSynchronize(st));
         if (graph) { hipGraphExecDestroy(graph); graph = nullptr; }
+    };
+    if (sched_cap < S) {
+        drop_graph();
         sched_cap = std::max(S, 64);
         sched_dev = dev_alloc((size_t)sched_cap * 4);
         ttab_dev = reinterpret_cast<long long*>(dev_alloc((size_t)sched_cap * 2));
         step_dev = reinterpret_cast<int*>(dev_alloc(4));
     }
-    static_assert(sizeof(long long) == 8, "");
-    if (!x_state || (size_t)nstate > noise_cap) {       // state buffers sized for this (B, z)
-        HIP_CHECK(hipStreamSynchronize(st));
-        if (graph) { hipGraphExecDestroy(graph); graph = nullptr; }
+    if ((size_t)nstate > state_cap) {                    // sampler state sized for this (B, z)
+        drop_graph();
         x_state = dev_alloc(nstate);
         pred_dev = dev_alloc(nstate);
-        noise_cap = nstate;
-        noise_dev = nullptr;
+        state_cap = nstate;
     }
     if (noise) {
-        HIP_CHECK(hipStreamSynchronize(st));
-        if (graph) { hipGraphExecDestroy(graph); graph = nullptr; }
-        noise_dev = dev_alloc((size_t)S * nstate);
+        if ((size_t)S * nstate > noise_cap) {
+            drop_graph();
+            noise_cap = (size_t)S * nstate;
+            noise_dev = dev_alloc(noise_cap);
+        }
         HIP_CHECK(hipMemcpyAsync(noise_dev, noise, (size_t)S * nstate * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
     HIP_CHECK(hipMemcpyAsync(sched_dev, sched_host, (size_t)S * 4 * sizeof(float), hipMemcpyHostToDevice, st));
@@ -584,7 +627,7 @@ void UNet::sample(float* x, const float* c, const float* uc, int n_tok, const fl
         HIP_CHECK(hipMemcpyAsync(in_ctx.p, c, ctx_n * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
     for (int l = 0; l < nl; ++l)
-        HIP_CHECK(hipMemcpyAsync(in_audio[l].p, audio[l], (size_t)B * in_audio[l].C * in_audio[l].T * sizeof(float), hipMemcpyDeviceToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(in_audio[l].p, audio[l], (size_t)audio_batch * in_audio[l].C * in_audio[l].T * sizeof(float), hipMemcpyDeviceToDevice, st));
 
     const bool wn = noise != nullptr, wp = pred_x0 != nullptr;
     if (ctx->use_graph) {

@@ -51,8 +51,9 @@ _SIGS = {
     "mugd_wave_create": [_p, C.POINTER(WaveConfig), C.POINTER(_p)],
     "mugd_net_set_param": [_p, C.c_char_p, _p, _i, _i, C.POINTER(C.c_int64)],
     "mugd_net_invalidate": [_p],
-    "mugd_unet_forward": [_p, _p, _p, _p, _i, C.POINTER(_p), _p, _i, _i],
-    "mugd_ddim_sample": [_p, _p, _p, _p, _i, C.POINTER(_p), _i, _i, _i, C.POINTER(C.c_int64), C.POINTER(_f), _f, _p, _p],
+    "mugd_unet_forward": [_p, _p, _p, _p, _i, C.POINTER(_p), _i, _p, _i, _i],
+    "mugd_ddim_sample": [_p, _p, _p, _p, _i, C.POINTER(_p), _i, _i, _i, _i, C.POINTER(C.c_int64), C.POINTER(_f), _f, _p, _p],
+    "mugd_net_profile": [_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)],
     "mugd_vae_decode": [_p, _p, _p, _i, _i],
     "mugd_wave_encode": [_p, _p, C.POINTER(_p), _i, _i],
     "mugd_cond_embed": [_p, _p, _p, _p, _i, _i, _i],
@@ -65,7 +66,9 @@ _SIGS = {
     "mugd_op_s4_conv": [_p, _p, _p, _p, _p, _i, _i, _i],
     "mugd_op_timestep_embedding": [_p, _p, _p, _i, _i],
 }
-EXPORTS = sorted(list(_SIGS) + ["mugd_destroy", "mugd_net_destroy", "mugd_last_error", "mugd_version"])
+EXPORTS = sorted(list(_SIGS) + ["mugd_destroy", "mugd_net_destroy", "mugd_last_error", "mugd_version",
+                                "mugd_profile_kind_name"])
+PROFILE_KINDS = 7
 
 
 def _ptr(t):
@@ -96,6 +99,8 @@ class Lib:
         self.dll.mugd_last_error.argtypes = [_p]
         self.dll.mugd_last_error.restype = C.c_char_p
         self.dll.mugd_version.restype = C.c_char_p
+        self.dll.mugd_profile_kind_name.argtypes = [_i]
+        self.dll.mugd_profile_kind_name.restype = C.c_char_p
         self.dll.mugd_destroy.argtypes = [_p]
         self.dll.mugd_destroy.restype = None
         self.dll.mugd_net_destroy.argtypes = [_p]
@@ -297,20 +302,34 @@ class Net:
 
     # U-Net ------------------------------------------------------------------
     def _audio_ptrs(self, audio, B):
+        """audio: the wave-encoder maps (the last n_levels are used); their batch size may be any
+        divisor of B (seeds sharing one audio share one copy of its features)."""
         nl = len(self.cfg["channel_mult"])
         maps = [self.lib.f32(a) for a in list(audio)[-nl:]]
+        ab = maps[0].shape[0]
+        if any(m.shape[0] != ab for m in maps) or B % ab != 0:
+            raise MugdError("audio maps must share a batch size that divides %d" % B)
         arr = (_p * nl)(*[_p(a.data_ptr()) for a in maps])
-        return maps, arr
+        return maps, arr, ab
 
     def forward(self, x, t, context, audio):
         lib = self.lib
         x, context = lib.f32(x), lib.f32(context)
         t = t.to(device=lib.device, dtype=torch.int64).contiguous()
         B, _, z = x.shape
-        maps, arr = self._audio_ptrs(audio, B)
+        maps, arr, ab = self._audio_ptrs(audio, B)
         eps = lib.empty(B, self.cfg["out_channels"], z)
-        lib.check(lib.dll.mugd_unet_forward(self.h, _ptr(x), _ptr(t), _ptr(context), context.shape[2], arr, _ptr(eps), B, z))
+        lib.check(lib.dll.mugd_unet_forward(self.h, _ptr(x), _ptr(t), _ptr(context), context.shape[2], arr, ab, _ptr(eps), B, z))
         return eps
+
+    def profile(self):
+        """Per-kernel-class {ms, flops, launches} of one eager pass of the last compiled program."""
+        ms = (C.c_double * PROFILE_KINDS)()
+        fl = (C.c_double * PROFILE_KINDS)()
+        ln = (C.c_int64 * PROFILE_KINDS)()
+        self.lib.check(self.lib.dll.mugd_net_profile(self.h, ms, fl, ln))
+        return {self.lib.dll.mugd_profile_kind_name(k).decode(): dict(ms=ms[k], flops=fl[k], launches=int(ln[k]))
+                for k in range(PROFILE_KINDS)}
 
     def ddim_sample(self, x_T, c, audio, timesteps, sched, uc=None, scale=1.0, noise=None, want_pred_x0=False):
         """timesteps: sequence of ints in sampling order; sched: (S,4) float32 rows {a_t, a_prev, sigma, sqrt(1-a_t)}."""
@@ -319,14 +338,14 @@ class Net:
         c = lib.f32(c)
         uc = lib.f32(uc) if uc is not None else None
         B, _, z = x.shape
-        maps, arr = self._audio_ptrs(audio, B)
+        maps, arr, ab = self._audio_ptrs(audio, B)
         S = len(timesteps)
         ts = (C.c_int64 * S)(*[int(v) for v in timesteps])
         flat = [float(v) for row in sched for v in row]
         sc = (_f * (4 * S))(*flat)
         noise = lib.f32(noise) if noise is not None else None
         pred = torch.empty_like(x) if want_pred_x0 else None
-        lib.check(lib.dll.mugd_ddim_sample(self.h, _ptr(x), _ptr(c), _ptr(uc), c.shape[2], arr, B, z, S, ts, sc,
+        lib.check(lib.dll.mugd_ddim_sample(self.h, _ptr(x), _ptr(c), _ptr(uc), c.shape[2], arr, ab, B, z, S, ts, sc,
                                            float(scale), _ptr(noise), _ptr(pred)))
         return (x, pred) if want_pred_x0 else x
 

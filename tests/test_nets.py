@@ -128,7 +128,7 @@ def run_ddim(lib, case, z, S, B, scale, g):
     mel = cases.mel_input(case, int(g["mel_seed"]), 1, z * case["audio_ratio"])
     wave = native(lib, case, z, "wave")
     nl = len(case["unet"]["channel_mult"])
-    w = [o.repeat(B, 1, 1) for o in wave.encode(mel)[-nl:]]
+    w = wave.encode(mel)[-nl:]          # batch 1: the B seeds share one copy of the audio features
     xT = cases.x_T(seed, B, z)
     steps = sampler.ddim_step_scalars(sd["alphas_cumprod"].numpy(), S, 0.0)
     ts = [s["t"] for s in steps]

@@ -144,3 +144,18 @@ def test_timestep_embedding(lib):
     t = torch.tensor([1, 21, 501, 981], dtype=torch.long)
     ref = nets.timestep_embedding(t, 128)
     close(lib.op_timestep_embedding(t, 128), ref, 2e-4, rtol=0, what="timestep embedding")
+
+
+@pytest.mark.parametrize("seconds", [0.37, 1.0])
+def test_log_mel(lib, seconds):
+    """HIP STFT->mel->log1p->fp16 against the numpy restatement of librosa's algorithm (oracle/host.py)."""
+    from oracle import host
+    y = host.synth_audio(seconds, seed=3)
+    ref = torch.from_numpy(host.log_mel(y).astype(np.float32))
+    got = lib.log_mel(torch.from_numpy(y)).cpu()
+    assert got.shape == ref.shape == (128, 1 + len(y) // 128)
+    # values are fp16-rounded: allow one fp16 ulp (2^-10 relative) on the rare rounding-boundary cases
+    err = (got - ref).abs()
+    ulp = torch.maximum(ref.abs(), torch.tensor(2.0 ** -14)) * 2.0 ** -10
+    assert (err <= ulp * 1.01).all(), float((err / ulp).max())
+    assert (err > 0).float().mean().item() < 0.02
