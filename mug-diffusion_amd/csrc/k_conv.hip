@@ -15,6 +15,8 @@
 //   v_mfma_f32_32x32x2_f32: lane (h,r) supplies A[row r][k=h], lane (h,n) supplies B[k=h][col n];
 //   the K order inside a chunk is permuted to (k=h -> channel 4h+j) so a lane's float4 of
 //   weights is used by 4 consecutive MFMAs.  fp32 in, fp32 accumulate: bitwise an fma chain.
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace {
@@ -23,34 +25,46 @@ constexpr int RS = CONV_RS;
 constexpr int WAVE_LDS = CONV_CK * RS;          // floats per wave window (1088)
 constexpr int RED_LDS = 4 * 16 * 64;            // floats for one 4-wave partial-tile exchange
 
-__device__ __forceinline__ void stage_load(const ConvSeg& s, int b, int c0, int t0, int h, int n, float (&r)[24]) {
+// Window staging, branch-free: the 16 x RW window is walked as a flat index (lane + 64 k), row/col by an
+// exact float reciprocal; out-of-range samples read a clamped address and are zeroed by a select, and the
+// tail of the last pass re-writes the final element (same value, same address).  No exec-masked branch, so
+// all NIT loads of a chunk are in flight together.
+template <int NIT>
+__device__ __forceinline__ void stage_load(const ConvSeg& s, int b, int c0, int t0, int lane, float (&r)[NIT]) {
     const int RW = 31 * s.stride + (s.taps - 1) * s.dil + 1;
+    const float inv = 1.0f / (float)RW;
+    const int last = CONV_CK * RW - 1;
     const int vlen = s.ups ? 2 * s.Tin : s.Tin;
     const int u0 = t0 * s.stride - s.pad;
     const int bb = s.bmod > 0 ? b % s.bmod : b;
     const float* base = s.x + ((size_t)bb * s.C + c0) * s.Tin;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float* row = base + (size_t)(2 * i + h) * s.Tin;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int cc = n + 32 * k;
-            const int u = u0 + cc;
-            float v = 0.f;
-            if (cc < RW && u >= 0 && u < vlen) v = row[s.ups ? (u >> 1) : u];
-            r[i * 3 + k] = v;
-        }
+    for (int k = 0; k < NIT; ++k) {
+        int idx = lane + 64 * k;
+        idx = idx < last ? idx : last;
+        const int row = (int)(((float)idx + 0.5f) * inv);
+        const int col = idx - row * RW;
+        const int u = u0 + col;
+        const bool ok = (u >= 0) && (u < vlen);
+        int uc = u < 0 ? 0 : u;
+        uc = uc < vlen ? uc : vlen - 1;
+        (void)ok;
+        r[k] = base[(size_t)row * s.Tin + (s.ups ? (uc >> 1) : uc)];     // raw; zeroed in stage_store (keeps the load in flight)
     }
 }
 
-__device__ __forceinline__ void stage_store(float* lb, int RW, int h, int n, const float (&r)[24]) {
+template <int NIT>
+__device__ __forceinline__ void stage_store(float* lb, int RW, int u0, int vlen, int lane, const float (&r)[NIT]) {
+    const float inv = 1.0f / (float)RW;
+    const int last = CONV_CK * RW - 1;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int cc = n + 32 * k;
-            if (cc < RW) lb[(2 * i + h) * RS + cc] = r[i * 3 + k];
-        }
+    for (int k = 0; k < NIT; ++k) {
+        int idx = lane + 64 * k;
+        idx = idx < last ? idx : last;
+        const int row = (int)(((float)idx + 0.5f) * inv);
+        const int col = idx - row * RW;
+        const int u = u0 + col;
+        lb[row * RS + col] = (u >= 0 && u < vlen) ? r[k] : 0.f;      // conv zero padding
     }
 }
 
@@ -66,24 +80,30 @@ __device__ __forceinline__ void load_a(const float* wp, const float* wp2, float4
 template <int TAPS, bool DUAL>
 __device__ __forceinline__ void compute_chunk(const float* lb, const float4 (&A)[6], const float4 (&A2)[6],
                                               f32x16& acc, f32x16& acc2, int stride, int dil, int h, int n) {
+    // all B fragments of the chunk are read up front so the MFMAs issue back to back
+    float bf[TAPS * 8];
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
 #pragma unroll
         for (int g8 = 0; g8 < 2; ++g8) {
             const float* p = lb + (g8 * 8 + 4 * h) * RS + n * stride + tap * dil;
-            const float b0 = p[0], b1 = p[RS], b2 = p[2 * RS], b3 = p[3 * RS];
-            const float4 av = A[tap * 2 + g8];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b2, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b3, acc, 0, 0, 0);
-            if (DUAL) {
-                const float4 gv = A2[tap * 2 + g8];
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.x, b0, acc2, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.y, b1, acc2, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.z, b2, acc2, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.w, b3, acc2, 0, 0, 0);
-            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[(tap * 2 + g8) * 4 + j] = p[j * RS];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TAPS * 2; ++i) {
+        const float4 av = A[i];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf[i * 4 + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf[i * 4 + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf[i * 4 + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf[i * 4 + 3], acc, 0, 0, 0);
+        if (DUAL) {
+            const float4 gv = A2[i];
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.x, bf[i * 4 + 0], acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.y, bf[i * 4 + 1], acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.z, bf[i * 4 + 2], acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.w, bf[i * 4 + 3], acc2, 0, 0, 0);
         }
     }
 }
@@ -96,7 +116,7 @@ __device__ __forceinline__ int find_seg(const ConvArgs& a, int g) {
     return si;
 }
 
-template <bool DUAL>
+template <bool DUAL, int NIT>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
     __shared__ float smem[DUAL ? 2 * RED_LDS : (4 * WAVE_LDS > RED_LDS ? 4 * WAVE_LDS : RED_LDS)];
 
@@ -120,7 +140,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
     float4 A[6], A2[6], An[6], An2[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) { A[i] = make_float4(0.f, 0.f, 0.f, 0.f); A2[i] = A[i]; An[i] = A[i]; An2[i] = A[i]; }
-    float xr[24];
+    float xr[NIT];
     int si = 0;
     if (g0 < g1) {
         si = find_seg(a, g0);
@@ -128,11 +148,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
         const int woff = s.woff + (g0 - s.chunk0) * s.taps * 512;
         if (s.taps == 3) load_a<3, DUAL>(wtile + woff, wtile2 + woff, A, A2);
         else load_a<1, DUAL>(wtile + woff, wtile2 + woff, A, A2);
-        stage_load(s, b, (g0 - s.chunk0) * CONV_CK, t0, h, n, xr);
+        stage_load<NIT>(s, b, (g0 - s.chunk0) * CONV_CK, t0, lane, xr);
     }
     for (int g = g0; g < g1; ++g) {
         const int taps = a.seg[si].taps, stride = a.seg[si].stride, dil = a.seg[si].dil;
-        stage_store(lb, 31 * stride + (taps - 1) * dil + 1, h, n, xr);
+        stage_store<NIT>(lb, 31 * stride + (taps - 1) * dil + 1, t0 * stride - a.seg[si].pad,
+                         a.seg[si].ups ? 2 * a.seg[si].Tin : a.seg[si].Tin, lane, xr);
         wave_sync();
         if (g + 1 < g1) {          // prefetch the next chunk while this one is on the matrix pipe
             si = find_seg(a, g + 1);
@@ -140,7 +161,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
             const int woff = s.woff + (g + 1 - s.chunk0) * s.taps * 512;
             if (s.taps == 3) load_a<3, DUAL>(wtile + woff, wtile2 + woff, An, An2);
             else load_a<1, DUAL>(wtile + woff, wtile2 + woff, An, An2);
-            stage_load(s, b, (g + 1 - s.chunk0) * CONV_CK, t0, h, n, xr);
+            stage_load<NIT>(s, b, (g + 1 - s.chunk0) * CONV_CK, t0, lane, xr);
         }
         if (taps == 3) compute_chunk<3, DUAL>(lb, A, A2, acc, acc2, stride, dil, h, n);
         else compute_chunk<1, DUAL>(lb, A, A2, acc, acc2, stride, dil, h, n);
@@ -158,28 +179,48 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
     }
     __syncthreads();
 
-    const float* resid = a.resid;
+    // ---- epilogue: all side loads (bias / row term / residual) are issued together from clamped
+    // addresses under wave-uniform conditions; only the final store is predicated.
+    float acc_v[4], acc_g[4], bv[4], bg[4], ra[4], rs[4];
+    size_t oo[4];
+    int mm[4];
+    bool valid[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int r = wave * 4 + q;
-        float v = smem[(0 * 16 + r) * 64 + lane] + smem[(1 * 16 + r) * 64 + lane] +
-                  smem[(2 * 16 + r) * 64 + lane] + smem[(3 * 16 + r) * 64 + lane];
+        acc_v[q] = smem[(0 * 16 + r) * 64 + lane] + smem[(1 * 16 + r) * 64 + lane] +
+                   smem[(2 * 16 + r) * 64 + lane] + smem[(3 * 16 + r) * 64 + lane];
+        acc_g[q] = 0.f;
+        if (DUAL) acc_g[q] = smem[RED_LDS + (0 * 16 + r) * 64 + lane] + smem[RED_LDS + (1 * 16 + r) * 64 + lane] +
+                             smem[RED_LDS + (2 * 16 + r) * 64 + lane] + smem[RED_LDS + (3 * 16 + r) * 64 + lane];
         const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int m = mt * 32 + row;
-        const int t = t0 + n;
-        if (m < a.Mout && t < a.Tout) {
-            if (a.bias) v += a.bias[m];
-            if (DUAL) {
-                float gte = smem[RED_LDS + (0 * 16 + r) * 64 + lane] + smem[RED_LDS + (1 * 16 + r) * 64 + lane] +
-                            smem[RED_LDS + (2 * 16 + r) * 64 + lane] + smem[RED_LDS + (3 * 16 + r) * 64 + lane];
-                if (a.bias) gte += a.bias[m + a.Mout];
-                v = (a.epi == EPI_GLU) ? v * sigmoid_f(gte) : v * gelu_erf_f(gte);
-            }
-            if (a.rowadd) v += a.rowadd[(size_t)b * a.rowadd_stride + m];
-            const size_t o = ((size_t)b * a.Mout + m) * a.Tout + t;
-            if (resid) v += resid[o];
-            a.y[o] = v;
+        const int m = mt * 32 + row, t = t0 + n;
+        valid[q] = (m < a.Mout) && (t < a.Tout);
+        mm[q] = m < a.Mout ? m : a.Mout - 1;
+        oo[q] = ((size_t)b * a.Mout + mm[q]) * a.Tout + (t < a.Tout ? t : a.Tout - 1);
+        bv[q] = 0.f; bg[q] = 0.f; ra[q] = 0.f; rs[q] = 0.f;
+    }
+    if (a.bias) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { bv[q] = a.bias[mm[q]]; if (DUAL) bg[q] = a.bias[mm[q] + a.Mout]; }
+    }
+    if (a.rowadd) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ra[q] = a.rowadd[(size_t)b * a.rowadd_stride + mm[q]];
+    }
+    if (a.resid) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rs[q] = a.resid[oo[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float v = acc_v[q] + bv[q];
+        if (DUAL) {
+            const float gte = acc_g[q] + bg[q];
+            v = (a.epi == EPI_GLU) ? v * sigmoid_f(gte) : v * gelu_erf_f(gte);
         }
+        v = (v + ra[q]) + rs[q];
+        if (valid[q]) a.y[oo[q]] = v;
     }
 }
 
@@ -215,8 +256,16 @@ void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
     if (dual) MUGD_CHECK(a.Mout % 32 == 0 && a.Mrows == 2 * a.Mout, -2, "conv_gemm: gated epilogue needs Mout % 32 == 0");
     else MUGD_CHECK(a.Mrows == a.Mout, -2, "conv_gemm: Mrows != Mout");
     dim3 grid(cdiv(a.Tout, CONV_TN), cdiv(a.Mout, 32), a.B);
-    if (dual) hipLaunchKernelGGL((conv_gemm_kernel<true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv_gemm_kernel<false>), grid, dim3(256), 0, st, a);
+    int nit = 0;                          // staging passes: ceil(16 * window / 64) for the widest segment
+    for (int i = 0; i < a.nseg; ++i) {
+        const ConvSeg& s = a.seg[i];
+        nit = std::max(nit, cdiv(CONV_CK * (31 * s.stride + (s.taps - 1) * s.dil + 1), 64));
+    }
+#define MUGD_CONV_LAUNCH(D, N) hipLaunchKernelGGL((conv_gemm_kernel<D, N>), grid, dim3(256), 0, st, a)
+    if (nit <= 9) { if (dual) MUGD_CONV_LAUNCH(true, 9); else MUGD_CONV_LAUNCH(false, 9); }
+    else if (nit <= 12) { if (dual) MUGD_CONV_LAUNCH(true, 12); else MUGD_CONV_LAUNCH(false, 12); }
+    else { if (dual) MUGD_CONV_LAUNCH(true, 17); else MUGD_CONV_LAUNCH(false, 17); }
+#undef MUGD_CONV_LAUNCH
 }
 
 void launch_pack_weights(hipStream_t st, const PackArgs& a) {
