@@ -15,6 +15,11 @@
 //   v_mfma_f32_32x32x2_f32: lane (h,r) supplies A[row r][k=h], lane (h,n) supplies B[k=h][col n];
 //   the K order inside a chunk is permuted to (k=h -> channel 4h+j) so a lane's float4 of
 //   weights is used by 4 consecutive MFMAs.  fp32 in, fp32 accumulate: bitwise an fma chain.
+//
+// All per-lane addressing (window walk, zero-padding mask, LDS addresses) is computed ONCE per
+// K-segment; a chunk iteration is then NIT loads at (uniform base + fixed 32-bit lane offset),
+// NIT selects + LDS stores, 8*TAPS LDS reads and 8*TAPS MFMAs.  Workgroups are renumbered so
+// that each XCD (private L2) owns a contiguous range of row tiles, i.e. of the weight stream.
 #include <algorithm>
 
 #include "kernels.h"
@@ -25,49 +30,6 @@ constexpr int RS = CONV_RS;
 constexpr int WAVE_LDS = CONV_CK * RS;          // floats per wave window (1088)
 constexpr int RED_LDS = 4 * 16 * 64;            // floats for one 4-wave partial-tile exchange
 
-// Window staging, branch-free: the 16 x RW window is walked as a flat index (lane + 64 k), row/col by an
-// exact float reciprocal; out-of-range samples read a clamped address and are zeroed by a select, and the
-// tail of the last pass re-writes the final element (same value, same address).  No exec-masked branch, so
-// all NIT loads of a chunk are in flight together.
-template <int NIT>
-__device__ __forceinline__ void stage_load(const ConvSeg& s, int b, int c0, int t0, int lane, float (&r)[NIT]) {
-    const int RW = 31 * s.stride + (s.taps - 1) * s.dil + 1;
-    const float inv = 1.0f / (float)RW;
-    const int last = CONV_CK * RW - 1;
-    const int vlen = s.ups ? 2 * s.Tin : s.Tin;
-    const int u0 = t0 * s.stride - s.pad;
-    const int bb = s.bmod > 0 ? b % s.bmod : b;
-    const float* base = s.x + ((size_t)bb * s.C + c0) * s.Tin;
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-        int idx = lane + 64 * k;
-        idx = idx < last ? idx : last;
-        const int row = (int)(((float)idx + 0.5f) * inv);
-        const int col = idx - row * RW;
-        const int u = u0 + col;
-        const bool ok = (u >= 0) && (u < vlen);
-        int uc = u < 0 ? 0 : u;
-        uc = uc < vlen ? uc : vlen - 1;
-        (void)ok;
-        r[k] = base[(size_t)row * s.Tin + (s.ups ? (uc >> 1) : uc)];     // raw; zeroed in stage_store (keeps the load in flight)
-    }
-}
-
-template <int NIT>
-__device__ __forceinline__ void stage_store(float* lb, int RW, int u0, int vlen, int lane, const float (&r)[NIT]) {
-    const float inv = 1.0f / (float)RW;
-    const int last = CONV_CK * RW - 1;
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-        int idx = lane + 64 * k;
-        idx = idx < last ? idx : last;
-        const int row = (int)(((float)idx + 0.5f) * inv);
-        const int col = idx - row * RW;
-        const int u = u0 + col;
-        lb[row * RS + col] = (u >= 0 && u < vlen) ? r[k] : 0.f;      // conv zero padding
-    }
-}
-
 template <int TAPS, bool DUAL>
 __device__ __forceinline__ void load_a(const float* wp, const float* wp2, float4 (&A)[6], float4 (&A2)[6]) {
 #pragma unroll
@@ -77,53 +39,108 @@ __device__ __forceinline__ void load_a(const float* wp, const float* wp2, float4
     }
 }
 
-template <int TAPS, bool DUAL>
-__device__ __forceinline__ void compute_chunk(const float* lb, const float4 (&A)[6], const float4 (&A2)[6],
-                                              f32x16& acc, f32x16& acc2, int stride, int dil, int h, int n) {
-    // all B fragments of the chunk are read up front so the MFMAs issue back to back
-    float bf[TAPS * 8];
+// One K-segment (one input tensor of the virtual concat), chunks [lo, hi) of it, for this wave.
+template <int TAPS, bool DUAL, int NIT>
+__device__ __forceinline__ void run_segment(const ConvSeg& s, const float* wseg, const float* wseg2, int lo, int hi,
+                                            int b, int t0, int lane, int h, int n, char* smem_bytes, int wave_base,
+                                            f32x16& acc, f32x16& acc2) {
+    // ---- per-segment lane constants: the 16 x RW window is walked as a flat index (lane + 64 k);
+    // out-of-range samples read a clamped address and are zeroed by a select when stored to LDS;
+    // the tail of the last pass re-writes the final element (same value, same address).
+    const int RW = 31 * s.stride + (TAPS - 1) * s.dil + 1;
+    const float inv = 1.0f / (float)RW;
+    const int last = CONV_CK * RW - 1;
+    const int vlen = s.ups ? 2 * s.Tin : s.Tin;
+    const int u0 = t0 * s.stride - s.pad;
+    unsigned goff[NIT];        // byte offset from the chunk's first channel row
+    int loff[NIT];             // absolute LDS byte address
+    bool ok[NIT];
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-#pragma unroll
-        for (int g8 = 0; g8 < 2; ++g8) {
-            const float* p = lb + (g8 * 8 + 4 * h) * RS + n * stride + tap * dil;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bf[(tap * 2 + g8) * 4 + j] = p[j * RS];
-        }
+    for (int k = 0; k < NIT; ++k) {
+        int idx = lane + 64 * k;
+        idx = idx < last ? idx : last;
+        const int row = (int)(((float)idx + 0.5f) * inv);
+        const int col = idx - row * RW;
+        const int u = u0 + col;
+        ok[k] = (u >= 0) && (u < vlen);
+        int uc = u < 0 ? 0 : u;
+        uc = uc < vlen ? uc : vlen - 1;
+        goff[k] = (unsigned)(row * s.Tin + (s.ups ? (uc >> 1) : uc)) * 4u;
+        loff[k] = wave_base + (row * RS + col) * 4;
     }
-#pragma unroll
-    for (int i = 0; i < TAPS * 2; ++i) {
-        const float4 av = A[i];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf[i * 4 + 0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf[i * 4 + 1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf[i * 4 + 2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf[i * 4 + 3], acc, 0, 0, 0);
-        if (DUAL) {
-            const float4 gv = A2[i];
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.x, bf[i * 4 + 0], acc2, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.y, bf[i * 4 + 1], acc2, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.z, bf[i * 4 + 2], acc2, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.w, bf[i * 4 + 3], acc2, 0, 0, 0);
-        }
-    }
-}
+    const int bb = s.bmod > 0 ? b % s.bmod : b;
+    const char* xb = reinterpret_cast<const char*>(s.x + ((size_t)bb * s.C + (size_t)lo * CONV_CK) * s.Tin);
+    const size_t xstep = (size_t)CONV_CK * s.Tin * 4;
+    const float* wp = wseg + (size_t)lo * (TAPS * 512);
+    const float* wp2 = wseg2 + (size_t)lo * (TAPS * 512);
+    const int rb0 = wave_base + (4 * h * RS + n * s.stride) * 4;      // this lane's B-fragment read base (bytes)
 
-__device__ __forceinline__ int find_seg(const ConvArgs& a, int g) {
-    int si = 0;
-    if (a.nseg > 1 && g >= a.seg[1].chunk0) si = 1;
-    if (a.nseg > 2 && g >= a.seg[2].chunk0) si = 2;
-    if (a.nseg > 3 && g >= a.seg[3].chunk0) si = 3;
-    return si;
+    float4 A[6], A2[6], An[6], An2[6];
+    float xr[NIT];
+    load_a<TAPS, DUAL>(wp, wp2, A, A2);
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) xr[k] = *reinterpret_cast<const float*>(xb + goff[k]);
+
+    for (int c = lo; c < hi; ++c) {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) *reinterpret_cast<float*>(smem_bytes + loff[k]) = ok[k] ? xr[k] : 0.f;
+        wave_sync();
+        if (c + 1 < hi) {          // prefetch the next chunk while this one is on the matrix pipe
+            wp += TAPS * 512;
+            wp2 += TAPS * 512;
+            xb += xstep;
+            load_a<TAPS, DUAL>(wp, wp2, An, An2);
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) xr[k] = *reinterpret_cast<const float*>(xb + goff[k]);
+        }
+        float bf[TAPS * 8];
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const char* p = smem_bytes + rb0 + tap * s.dil * 4;
+#pragma unroll
+            for (int g8 = 0; g8 < 2; ++g8)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[(tap * 2 + g8) * 4 + j] = *reinterpret_cast<const float*>(p + (g8 * 8 + j) * RS * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < TAPS * 2; ++i) {
+            const float4 av = A[i];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf[i * 4 + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf[i * 4 + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf[i * 4 + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf[i * 4 + 3], acc, 0, 0, 0);
+            if (DUAL) {
+                const float4 gv = A2[i];
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.x, bf[i * 4 + 0], acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.y, bf[i * 4 + 1], acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.z, bf[i * 4 + 2], acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.w, bf[i * 4 + 3], acc2, 0, 0, 0);
+            }
+        }
+        wave_sync();               // all lanes done reading the window before it is overwritten
+#pragma unroll
+        for (int i = 0; i < TAPS * 2; ++i) { A[i] = An[i]; if (DUAL) A2[i] = An2[i]; }
+    }
 }
 
 template <bool DUAL, int NIT>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a, int gx, int gy, int gz) {
     __shared__ float smem[DUAL ? 2 * RED_LDS : (4 * WAVE_LDS > RED_LDS ? 4 * WAVE_LDS : RED_LDS)];
+
+    // ---- XCD-aware renumbering: hardware deals consecutive workgroup ids round-robin to the 8 XCDs;
+    // give each XCD a contiguous slab of the (row tile major) tile order so a weight tile is pulled
+    // into ONE private L2 and reused there by all sample tiles / batch rows.
+    const int nblk = gx * gy * gz;
+    int lid = blockIdx.x;
+    if ((nblk & 7) == 0) lid = (lid & 7) * (nblk >> 3) + (lid >> 3);
+    const int mt = lid / (gx * gz);
+    const int rem = lid - mt * (gx * gz);
+    const int b = rem / gx;
+    const int t0 = (rem - b * gx) * CONV_TN;
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, h = lane >> 5, n = lane & 31;
-    const int t0 = blockIdx.x * CONV_TN, mt = blockIdx.y, b = blockIdx.z;
 
     const int per = (a.nchunk + 3) >> 2;
     const int g0 = wave * per;
@@ -135,39 +152,21 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
 
     const float* wtile = a.wpk + (size_t)mt * a.w_mt_stride + lane * 4;
     const float* wtile2 = DUAL ? wtile + (size_t)(a.Mout >> 5) * a.w_mt_stride : wtile;
-    float* lb = smem + wave * WAVE_LDS;
+    char* smem_bytes = reinterpret_cast<char*>(smem);
+    const int wave_base = wave * WAVE_LDS * 4;
 
-    float4 A[6], A2[6], An[6], An2[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { A[i] = make_float4(0.f, 0.f, 0.f, 0.f); A2[i] = A[i]; An[i] = A[i]; An2[i] = A[i]; }
-    float xr[NIT];
-    int si = 0;
-    if (g0 < g1) {
-        si = find_seg(a, g0);
-        const ConvSeg& s = a.seg[si];
-        const int woff = s.woff + (g0 - s.chunk0) * s.taps * 512;
-        if (s.taps == 3) load_a<3, DUAL>(wtile + woff, wtile2 + woff, A, A2);
-        else load_a<1, DUAL>(wtile + woff, wtile2 + woff, A, A2);
-        stage_load<NIT>(s, b, (g0 - s.chunk0) * CONV_CK, t0, lane, xr);
-    }
-    for (int g = g0; g < g1; ++g) {
-        const int taps = a.seg[si].taps, stride = a.seg[si].stride, dil = a.seg[si].dil;
-        stage_store<NIT>(lb, 31 * stride + (taps - 1) * dil + 1, t0 * stride - a.seg[si].pad,
-                         a.seg[si].ups ? 2 * a.seg[si].Tin : a.seg[si].Tin, lane, xr);
-        wave_sync();
-        if (g + 1 < g1) {          // prefetch the next chunk while this one is on the matrix pipe
-            si = find_seg(a, g + 1);
+    for (int si = 0; si < CONV_MAXSEG; ++si) {
+        if (si < a.nseg) {
             const ConvSeg& s = a.seg[si];
-            const int woff = s.woff + (g + 1 - s.chunk0) * s.taps * 512;
-            if (s.taps == 3) load_a<3, DUAL>(wtile + woff, wtile2 + woff, An, An2);
-            else load_a<1, DUAL>(wtile + woff, wtile2 + woff, An, An2);
-            stage_load<NIT>(s, b, (g + 1 - s.chunk0) * CONV_CK, t0, lane, xr);
+            const int nch = s.C / CONV_CK;
+            const int lo = (g0 > s.chunk0 ? g0 : s.chunk0) - s.chunk0;
+            const int hi = (g1 < s.chunk0 + nch ? g1 : s.chunk0 + nch) - s.chunk0;
+            if (lo < hi) {
+                if (s.taps == 3) run_segment<3, DUAL, NIT>(s, wtile + s.woff, wtile2 + s.woff, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, acc, acc2);
+                else run_segment<1, DUAL, NIT>(s, wtile + s.woff, wtile2 + s.woff, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, acc, acc2);
+            }
         }
-        if (taps == 3) compute_chunk<3, DUAL>(lb, A, A2, acc, acc2, stride, dil, h, n);
-        else compute_chunk<1, DUAL>(lb, A, A2, acc, acc2, stride, dil, h, n);
-        wave_sync();               // all lanes done reading the window before it is overwritten
-#pragma unroll
-        for (int i = 0; i < 6; ++i) { A[i] = An[i]; if (DUAL) A2[i] = An2[i]; }
     }
 
     // ---- combine the 4 K-slices through LDS (the staging windows are dead after this barrier)
@@ -246,22 +245,22 @@ __global__ void pack_weights_kernel(const PackArgs p) {
 
 void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
     MUGD_CHECK(a.nseg >= 1 && a.nseg <= CONV_MAXSEG, -2, "conv_gemm: bad segment count");
+    int nit = 0;                          // staging passes: ceil(16 * window / 64) for the widest segment
     for (int i = 0; i < a.nseg; ++i) {
         const ConvSeg& s = a.seg[i];
         MUGD_CHECK(s.C % CONV_CK == 0, -2, "conv_gemm: channels must be a multiple of 16");
         MUGD_CHECK(s.taps == 1 || s.taps == 3, -2, "conv_gemm: taps must be 1 or 3");
-        MUGD_CHECK(31 * s.stride + (s.taps - 1) * s.dil + 1 <= CONV_RS, -2, "conv_gemm: window exceeds LDS row");
+        const int rw = 31 * s.stride + (s.taps - 1) * s.dil + 1;
+        MUGD_CHECK(rw <= CONV_RS, -2, "conv_gemm: window exceeds LDS row");
+        MUGD_CHECK((long long)CONV_CK * s.Tin * 4 < (1ll << 31), -2, "conv_gemm: sequence too long for 32-bit window offsets");
+        nit = std::max(nit, cdiv(CONV_CK * rw, 64));
     }
     const bool dual = a.epi != EPI_NONE;
     if (dual) MUGD_CHECK(a.Mout % 32 == 0 && a.Mrows == 2 * a.Mout, -2, "conv_gemm: gated epilogue needs Mout % 32 == 0");
     else MUGD_CHECK(a.Mrows == a.Mout, -2, "conv_gemm: Mrows != Mout");
-    dim3 grid(cdiv(a.Tout, CONV_TN), cdiv(a.Mout, 32), a.B);
-    int nit = 0;                          // staging passes: ceil(16 * window / 64) for the widest segment
-    for (int i = 0; i < a.nseg; ++i) {
-        const ConvSeg& s = a.seg[i];
-        nit = std::max(nit, cdiv(CONV_CK * (31 * s.stride + (s.taps - 1) * s.dil + 1), 64));
-    }
-#define MUGD_CONV_LAUNCH(D, N) hipLaunchKernelGGL((conv_gemm_kernel<D, N>), grid, dim3(256), 0, st, a)
+    const int gx = cdiv(a.Tout, CONV_TN), gy = cdiv(a.Mout, 32), gz = a.B;
+    const dim3 grid((unsigned)gx * gy * gz);
+#define MUGD_CONV_LAUNCH(D, N) hipLaunchKernelGGL((conv_gemm_kernel<D, N>), grid, dim3(256), 0, st, a, gx, gy, gz)
     if (nit <= 9) { if (dual) MUGD_CONV_LAUNCH(true, 9); else MUGD_CONV_LAUNCH(false, 9); }
     else if (nit <= 12) { if (dual) MUGD_CONV_LAUNCH(true, 12); else MUGD_CONV_LAUNCH(false, 12); }
     else { if (dual) MUGD_CONV_LAUNCH(true, 17); else MUGD_CONV_LAUNCH(false, 17); }

@@ -82,29 +82,35 @@ __global__ __launch_bounds__(256) void group_norm_kernel(const GnArgs a) {
     }
 }
 
-// grid (ceil(T/64), B), block 256 = 64 samples x 4 channel slices.  nn.LayerNorm over C, eps 1e-5.
+// grid (ceil(T/16), B), block 256 = 16 samples x 16 channel slices (the sequences are short -- 64..256
+// samples at the attention levels -- so the tile is kept narrow in T to put enough workgroups in flight).
+// nn.LayerNorm over C, eps 1e-5.
+constexpr int LN_TT = 16, LN_CS = 16;
 __global__ __launch_bounds__(256) void layer_norm_kernel(const LnArgs a) {
-    __shared__ double red[2][4][64];
-    const int tl = threadIdx.x & 63, cs = threadIdx.x >> 6;
-    const int t = blockIdx.x * 64 + tl, b = blockIdx.y;
+    __shared__ double red[2][LN_CS][LN_TT + 1];
+    const int tl = threadIdx.x & (LN_TT - 1), cs = threadIdx.x / LN_TT;
+    const int t = blockIdx.x * LN_TT + tl, b = blockIdx.y;
     const bool ok = t < a.T;
     const int C = a.C;
     const float* x = a.x + (size_t)b * C * a.T + (ok ? t : a.T - 1);
     double s = 0.0, q = 0.0;
 #pragma unroll 8
-    for (int c = cs; c < C; c += 4) { const double v = x[(size_t)c * a.T]; s += v; q += v * v; }
+    for (int c = cs; c < C; c += LN_CS) { const double v = x[(size_t)c * a.T]; s += v; q += v * v; }
     red[0][cs][tl] = s;
     red[1][cs][tl] = q;
     __syncthreads();
-    const double mean_d = (red[0][0][tl] + red[0][1][tl] + red[0][2][tl] + red[0][3][tl]) / (double)C;
-    double var_d = (red[1][0][tl] + red[1][1][tl] + red[1][2][tl] + red[1][3][tl]) / (double)C - mean_d * mean_d;
+    double ss = 0.0, qq = 0.0;
+#pragma unroll
+    for (int i = 0; i < LN_CS; ++i) { ss += red[0][i][tl]; qq += red[1][i][tl]; }
+    const double mean_d = ss / (double)C;
+    double var_d = qq / (double)C - mean_d * mean_d;
     var_d = var_d > 0.0 ? var_d : 0.0;
     const float mean = (float)mean_d;
     const float rstd = (float)(1.0 / sqrt(var_d + (double)a.eps));
     if (ok) {
         float* y = a.y + (size_t)b * C * a.T + t;
 #pragma unroll 8
-        for (int c = cs; c < C; c += 4) y[(size_t)c * a.T] = (x[(size_t)c * a.T] - mean) * rstd * a.gamma[c] + a.beta[c];
+        for (int c = cs; c < C; c += LN_CS) y[(size_t)c * a.T] = (x[(size_t)c * a.T] - mean) * rstd * a.gamma[c] + a.beta[c];
     }
 }
 
@@ -120,5 +126,5 @@ void launch_group_norm(hipStream_t st, const GnArgs& a) {
 }
 
 void launch_layer_norm(hipStream_t st, const LnArgs& a) {
-    hipLaunchKernelGGL(layer_norm_kernel, dim3(cdiv(a.T, 64), a.B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(layer_norm_kernel, dim3(cdiv(a.T, LN_TT), a.B), dim3(256), 0, st, a);
 }
