@@ -1,7 +1,7 @@
 // conv_gemm: conv1d / linear layers as an implicit GEMM on the gfx950 fp32 matrix cores.
 //
-// One workgroup = 4 wavefronts = one 32(rows) x 32(samples) output tile of one batch row;
-// the 4 waves split the reduction (K) axis between them (intra-workgroup split-K, combined
+// One workgroup = 8 wavefronts = one 32(rows) x 32(samples) output tile of one batch row;
+// the 8 waves split the reduction (K) axis between them (intra-workgroup split-K, combined
 // through LDS, deterministic), so even the 512-channel / 64-sample layers put >= 128
 // workgroups x 4 waves on the chip and every SIMD of a CU gets a matrix-core stream.
 //
@@ -28,7 +28,8 @@ namespace {
 
 constexpr int RS = CONV_RS;
 constexpr int WAVE_LDS = CONV_CK * RS;          // floats per wave window (1088)
-constexpr int RED_LDS = 4 * 16 * 64;            // floats for one 4-wave partial-tile exchange
+constexpr int NWAVE = 8;                        // waves per workgroup = K slices (2 per SIMD: one computes while one waits)
+constexpr int RED_LDS = NWAVE * 16 * 64;        // floats for one partial-tile exchange
 
 template <int TAPS, bool DUAL>
 __device__ __forceinline__ void load_a(const float* wp, const float* wp2, float4 (&A)[6], float4 (&A2)[6]) {
@@ -75,17 +76,18 @@ __device__ __forceinline__ void run_segment(const ConvSeg& s, const float* wseg,
     const float* wp2 = wseg2 + (size_t)lo * (TAPS * 512);
     const int rb0 = wave_base + (4 * h * RS + n * s.stride) * 4;      // this lane's B-fragment read base (bytes)
 
-    float4 A[6], A2[6], An[6], An2[6];
+    float4 Aa[6], Aa2[6], Ab[6], Ab2[6];       // ping-pong weight fragments: no register copies in the loop
     float xr[NIT];
-    load_a<TAPS, DUAL>(wp, wp2, A, A2);
+    load_a<TAPS, DUAL>(wp, wp2, Aa, Aa2);
 #pragma unroll
     for (int k = 0; k < NIT; ++k) xr[k] = *reinterpret_cast<const float*>(xb + goff[k]);
 
-    for (int c = lo; c < hi; ++c) {
+    // one chunk: park the window in LDS, launch the next chunk's loads, run this chunk on the matrix pipe
+    auto step = [&](const float4 (&A)[6], const float4 (&A2)[6], float4 (&An)[6], float4 (&An2)[6], bool more) {
 #pragma unroll
         for (int k = 0; k < NIT; ++k) *reinterpret_cast<float*>(smem_bytes + loff[k]) = ok[k] ? xr[k] : 0.f;
         wave_sync();
-        if (c + 1 < hi) {          // prefetch the next chunk while this one is on the matrix pipe
+        if (more) {
             wp += TAPS * 512;
             wp2 += TAPS * 512;
             xb += xstep;
@@ -118,14 +120,20 @@ __device__ __forceinline__ void run_segment(const ConvSeg& s, const float* wseg,
             }
         }
         wave_sync();               // all lanes done reading the window before it is overwritten
-#pragma unroll
-        for (int i = 0; i < TAPS * 2; ++i) { A[i] = An[i]; if (DUAL) A2[i] = An2[i]; }
+    };
+
+    int c = lo;
+    for (;;) {
+        step(Aa, Aa2, Ab, Ab2, c + 1 < hi);
+        if (++c >= hi) break;
+        step(Ab, Ab2, Aa, Aa2, c + 1 < hi);
+        if (++c >= hi) break;
     }
 }
 
 template <bool DUAL, int NIT>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a, int gx, int gy, int gz) {
-    __shared__ float smem[DUAL ? 2 * RED_LDS : (4 * WAVE_LDS > RED_LDS ? 4 * WAVE_LDS : RED_LDS)];
+__global__ __launch_bounds__(NWAVE * 64) void conv_gemm_kernel(const ConvArgs a, int gx, int gy, int gz) {
+    __shared__ float smem[DUAL ? 2 * RED_LDS : (NWAVE * WAVE_LDS > RED_LDS ? NWAVE * WAVE_LDS : RED_LDS)];
 
     // ---- XCD-aware renumbering: hardware deals consecutive workgroup ids round-robin to the 8 XCDs;
     // give each XCD a contiguous slab of the (row tile major) tile order so a weight tile is pulled
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a, int gx
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, h = lane >> 5, n = lane & 31;
 
-    const int per = (a.nchunk + 3) >> 2;
+    const int per = (a.nchunk + NWAVE - 1) / NWAVE;
     const int g0 = wave * per;
     const int g1 = (g0 + per < a.nchunk) ? g0 + per : a.nchunk;
 
@@ -180,18 +188,21 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a, int gx
 
     // ---- epilogue: all side loads (bias / row term / residual) are issued together from clamped
     // addresses under wave-uniform conditions; only the final store is predicated.
-    float acc_v[4], acc_g[4], bv[4], bg[4], ra[4], rs[4];
-    size_t oo[4];
-    int mm[4];
-    bool valid[4];
+    constexpr int EPT = 16 / NWAVE;      // tile rows (accumulator registers) finished by each wave
+    float acc_v[EPT], acc_g[EPT], bv[EPT], bg[EPT], ra[EPT], rs[EPT];
+    size_t oo[EPT];
+    int mm[EPT];
+    bool valid[EPT];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = wave * 4 + q;
-        acc_v[q] = smem[(0 * 16 + r) * 64 + lane] + smem[(1 * 16 + r) * 64 + lane] +
-                   smem[(2 * 16 + r) * 64 + lane] + smem[(3 * 16 + r) * 64 + lane];
+    for (int q = 0; q < EPT; ++q) {
+        const int r = wave * EPT + q;
+        acc_v[q] = 0.f;
         acc_g[q] = 0.f;
-        if (DUAL) acc_g[q] = smem[RED_LDS + (0 * 16 + r) * 64 + lane] + smem[RED_LDS + (1 * 16 + r) * 64 + lane] +
-                             smem[RED_LDS + (2 * 16 + r) * 64 + lane] + smem[RED_LDS + (3 * 16 + r) * 64 + lane];
+#pragma unroll
+        for (int w = 0; w < NWAVE; ++w) {
+            acc_v[q] += smem[(w * 16 + r) * 64 + lane];
+            if (DUAL) acc_g[q] += smem[RED_LDS + (w * 16 + r) * 64 + lane];
+        }
         const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
         const int m = mt * 32 + row, t = t0 + n;
         valid[q] = (m < a.Mout) && (t < a.Tout);
@@ -201,18 +212,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a, int gx
     }
     if (a.bias) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { bv[q] = a.bias[mm[q]]; if (DUAL) bg[q] = a.bias[mm[q] + a.Mout]; }
+        for (int q = 0; q < EPT; ++q) { bv[q] = a.bias[mm[q]]; if (DUAL) bg[q] = a.bias[mm[q] + a.Mout]; }
     }
     if (a.rowadd) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) ra[q] = a.rowadd[(size_t)b * a.rowadd_stride + mm[q]];
+        for (int q = 0; q < EPT; ++q) ra[q] = a.rowadd[(size_t)b * a.rowadd_stride + mm[q]];
     }
     if (a.resid) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) rs[q] = a.resid[oo[q]];
+        for (int q = 0; q < EPT; ++q) rs[q] = a.resid[oo[q]];
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < EPT; ++q) {
         float v = acc_v[q] + bv[q];
         if (DUAL) {
             const float gte = acc_g[q] + bg[q];
@@ -260,7 +271,7 @@ void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
     else MUGD_CHECK(a.Mrows == a.Mout, -2, "conv_gemm: Mrows != Mout");
     const int gx = cdiv(a.Tout, CONV_TN), gy = cdiv(a.Mout, 32), gz = a.B;
     const dim3 grid((unsigned)gx * gy * gz);
-#define MUGD_CONV_LAUNCH(D, N) hipLaunchKernelGGL((conv_gemm_kernel<D, N>), grid, dim3(256), 0, st, a, gx, gy, gz)
+#define MUGD_CONV_LAUNCH(D, N) hipLaunchKernelGGL((conv_gemm_kernel<D, N>), grid, dim3(NWAVE * 64), 0, st, a, gx, gy, gz)
     if (nit <= 9) { if (dual) MUGD_CONV_LAUNCH(true, 9); else MUGD_CONV_LAUNCH(false, 9); }
     else if (nit <= 12) { if (dual) MUGD_CONV_LAUNCH(true, 12); else MUGD_CONV_LAUNCH(false, 12); }
     else { if (dual) MUGD_CONV_LAUNCH(true, 17); else MUGD_CONV_LAUNCH(false, 17); }

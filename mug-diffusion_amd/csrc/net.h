@@ -77,6 +77,7 @@ struct Op {
     std::function<void(hipStream_t)> fn;
     int kind;
     double flops;     // algorithmic 2*MAC count of the contractions (0 for bandwidth-class ops)
+    std::string label;
 };
 
 struct ProfileRow { double ms = 0, flops = 0; long long launches = 0; };
@@ -106,7 +107,9 @@ protected:
     const float* PF(const std::string& n) const { return (const float*)P(n).ptr; }
     float* dev_alloc(size_t nfloats, bool zero = false);
     Tensor talloc(int C, int T) { Tensor t; t.C = C; t.T = T; t.p = arena.alloc((size_t)Bn * C * T); return t; }
-    void emit(std::function<void(hipStream_t)> f, int kind = OP_SMALL, double flops = 0) { if (!dry) ops.push_back(Op{std::move(f), kind, flops}); }
+    void emit(std::function<void(hipStream_t)> f, int kind = OP_SMALL, double flops = 0, const std::string& label = "") {
+        if (!dry) ops.push_back(Op{std::move(f), kind, flops, label});
+    }
     void run_ops(hipStream_t st) { for (auto& o : ops) o.fn(st); }
 
     // layer emitters

@@ -65,6 +65,17 @@ void Net::profile_program(ProfileRow* rows) {
         ProfileRow& r = rows[ops[i].kind];
         r.ms += ms; r.flops += ops[i].flops; r.launches += 1;
     }
+    if (const char* path = getenv("MUGD_PROFILE_CSV")) {          // per-launch rows for offline analysis
+        if (FILE* f = fopen(path, "a")) {
+            fprintf(f, "idx,kind,us,gflop,label\n");
+            for (size_t i = 0; i < ops.size(); ++i) {
+                float ms = 0.f;
+                hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+                fprintf(f, "%zu,%s,%.2f,%.4f,%s\n", i, op_kind_name(ops[i].kind), ms * 1e3, ops[i].flops / 1e9, ops[i].label.c_str());
+            }
+            fclose(f);
+        }
+    }
     for (auto& e : ev) hipEventDestroy(e);
 }
 
@@ -110,14 +121,15 @@ Tensor Net::group_norm(const std::string& prefix, const std::vector<Tensor>& seg
     a.Ctot = C; a.T = segs[0].T; a.groups = groups; a.B = Bn; a.silu = silu ? 1 : 0;
     a.gamma = PF(prefix + ".weight"); a.beta = PF(prefix + ".bias");
     a.eps = 1e-6f; a.y = y.p;
-    emit([a](hipStream_t st) { launch_group_norm(st, a); }, OP_GROUP_NORM);
+    emit([a](hipStream_t st) { launch_group_norm(st, a); }, OP_GROUP_NORM, 0,
+         prefix + " C=" + std::to_string(C) + " T=" + std::to_string(a.T));
     return y;
 }
 
 Tensor Net::layer_norm(const std::string& prefix, const Tensor& x) {
     Tensor y = talloc(x.C, x.T);
     LnArgs a{x.p, y.p, PF(prefix + ".weight"), PF(prefix + ".bias"), Bn, x.C, x.T, 1e-5f};
-    emit([a](hipStream_t st) { launch_layer_norm(st, a); }, OP_LAYER_NORM);
+    emit([a](hipStream_t st) { launch_layer_norm(st, a); }, OP_LAYER_NORM, 0, prefix + " C=" + std::to_string(x.C) + " T=" + std::to_string(x.T));
     return y;
 }
 
@@ -177,7 +189,9 @@ Tensor Net::conv(const ConvSpec& s) {
     a.y = y.p; a.B = Bn; a.Mrows = s.Mrows; a.Mout = s.Mout; a.Tout = s.Tout; a.nchunk = pw.nchunk; a.epi = s.epi;
     double kdim = 0;
     for (auto& in : s.in) kdim += (double)in.x.C * in.taps;
-    emit([a](hipStream_t st) { launch_conv_gemm(st, a); }, s.epi ? OP_CONV_GATED : OP_CONV, 2.0 * s.Mrows * kdim * s.Tout * Bn);
+    emit([a](hipStream_t st) { launch_conv_gemm(st, a); }, s.epi ? OP_CONV_GATED : OP_CONV, 2.0 * s.Mrows * kdim * s.Tout * Bn,
+         s.key + " M=" + std::to_string(s.Mrows) + " K=" + std::to_string((long long)kdim) + " T=" + std::to_string(s.Tout) +
+             " nseg=" + std::to_string(a.nseg));
     return y;
 }
 
@@ -209,7 +223,8 @@ Tensor Net::attention(const std::string& prefix, const Tensor& q, const Tensor& 
     MUGD_CHECK((int)rel.shape[1] == heads, -2, "attention: head count mismatch at " + prefix);
     a.B = Bn; a.heads = heads; a.d = C / heads; a.Tq = q.T; a.Tk = k.T;
     a.scale = 1.0f / sqrtf((float)a.d);
-    emit([a](hipStream_t st) { launch_attention(st, a); }, OP_ATTENTION, 4.0 * Bn * C * (double)q.T * k.T);
+    emit([a](hipStream_t st) { launch_attention(st, a); }, OP_ATTENTION, 4.0 * Bn * C * (double)q.T * k.T,
+         prefix + " d=" + std::to_string(a.d) + " Tq=" + std::to_string(q.T) + " Tk=" + std::to_string(k.T));
     return o;
 }
 
@@ -326,7 +341,7 @@ Tensor Net::s4_layer(const std::string& prefix, const Tensor& x) {
     const float* k = s4_kernel(prefix + ".s4_model.kernel.kernel", H, L);
     Tensor y = talloc(H, L);
     S4ConvArgs ca{u.p, k, PF(prefix + ".s4_model.D"), y.p, Bn, H, L};
-    emit([ca](hipStream_t st) { launch_s4_conv(st, ca); }, OP_S4_CONV);
+    emit([ca](hipStream_t st) { launch_s4_conv(st, ca); }, OP_S4_CONV, 0, prefix + " H=" + std::to_string(H) + " L=" + std::to_string(L));
     ConvSpec gl;
     gl.key = prefix + ".s4_model.output_linear.0";
     gl.in.push_back(ConvIn{y});
