@@ -226,9 +226,35 @@ def host_goldens():
     print("  host goldens: schedules + %d prompts OK" % len(idl))
 
 
+def s4_host_goldens():
+    """SSKernelNPLR fresh-init values and two lazy `_setup_C` growth steps (s4.py:557-584, 726-730)
+    straight from the reference module: the pin for mug/model/s4.py (product host code)."""
+    from mug.model.s4 import S4
+    torch.manual_seed(3)
+    m = S4(d_model=8, d_state=64)
+    k = m.kernel.kernel
+    names = ["C", "B", "P", "inv_w_real", "w_imag", "log_dt"]
+    out = {"init_" + n: getattr(k, n).detach().clone().numpy() for n in names}
+    out["init_L"] = np.array(int(k.L))
+    k1 = k(L=24)[0].detach().clone()
+    out["C_after24"] = k.C.detach().clone().numpy()
+    out["L_after24"] = np.array(int(k.L))
+    out["k_after24"] = k1.numpy()
+    k2 = k(L=40)[0].detach().clone()
+    out["C_after40"] = k.C.detach().clone().numpy()
+    out["L_after40"] = np.array(int(k.L))
+    out["k_after40"] = k2.numpy()
+    np.savez_compressed(os.path.join(G, "s4_setup_C.npz"), **out)
+    print("  s4 host goldens: L %d -> %d -> %d" % (out["init_L"], out["L_after24"], out["L_after40"]))
+
+
 def main():
     torch.set_num_threads(os.cpu_count())
+    if "--s4-only" in sys.argv:
+        s4_host_goldens()
+        return
     host_goldens()
+    s4_host_goldens()
     run_case(cases.TINY, [32], {32: [(4, 2, 1.0), (4, 2, 5.0)]})
     if "--tiny-only" not in sys.argv:
         run_case(cases.FULL, [96, 512], {96: [(10, 1, 1.0), (10, 1, 5.0)]})
