@@ -19,6 +19,7 @@ Prints ONE JSON line (rank 0) with the contract's fields plus
                    on a bounded sample of the same workload (a reported baseline, not the target).
 """
 import argparse
+import faulthandler
 import json
 import os
 import sys
@@ -59,6 +60,21 @@ def model_config():
         wave_stage_config=dict(target="mug.cond.wave.MelspectrogramScaleEncoder1D", params=SHIPPED["wave"])))
 
 
+_T0 = time.perf_counter()
+
+
+def note(msg):
+    """progress line on stderr (the JSON line on stdout stays alone)"""
+    print("[bench %7.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+def host_threads():
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
 def synth_audio(seconds, sr, seed):
     """0.5 sin(2pi 440 t) + 0.25 chirp(110 -> 3110 Hz) + N(0, 0.01)."""
     n = np.arange(int(round(seconds * sr)), dtype=np.float64)
@@ -78,7 +94,15 @@ def main():
     ap.add_argument("--cfg-scale", type=float, default=1.0, help="1.0 = no guidance (scripts/mapping.py default); webui default is 5.0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (torch scales badly past ~16 on these small tensors)")
+    ap.add_argument("--cpu-timeout", type=int, default=150)
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--z", type=int, default=512, help=argparse.SUPPRESS)
+    ap.add_argument("--n-unet-steps", type=int, default=50, help=argparse.SUPPRESS)
     a = ap.parse_args()
+    faulthandler.dump_traceback_later(180, repeat=True, file=sys.stderr)      # a hung stage shows up in the log
+    if a.cpu_baseline_worker:
+        return cpu_baseline_worker(a)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -100,12 +124,14 @@ def main():
     import yaml
 
     lib = get_lib()
+    note("library loaded")
     model = instantiate_from_config(model_config()).eval()
     unet = model.model.unet_model
     z_cfg = SHIPPED["z_length"]
     seed_all_parameters(model, seed=0, s4_length_of=lambda k: unet.s4_length_of(k[len("model.unet_model."):], z_cfg))
     model = model.to(dev)
     sampler = DDIMSampler(model)
+    note("model instantiated, seeded and moved to %s" % dev)
 
     B, S, sr, hop = a.batch, a.ddim_steps, SHIPPED["sr"], SHIPPED["n_fft"] // 4
     pcm = torch.from_numpy(synth_audio(a.seconds, sr, seed=rank)).to(dev)          # resident before the timed region
@@ -145,8 +171,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    for i in range(a.warmup):
         one_step()
+        torch.cuda.synchronize()
+        note("warmup step %d done" % i)
     sync_all()
     t0 = time.perf_counter()
     notes = 0
@@ -156,6 +184,7 @@ def main():
     ddim_ms.append(ev0.elapsed_time(ev1))
     sync_all()
     elapsed = time.perf_counter() - t0
+    note("timed region done: %.1f ms per step" % (elapsed / a.steps * 1e3))
     notes = int(grid.sum().item())
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -190,30 +219,59 @@ def main():
                                "launches_per_unet_eval": k["launches"], "avg_launch_us": k["ms"] * 1e3 / max(k["launches"], 1),
                                "algorithmic_gflop_per_launch": k["flops"] / 1e9 / max(k["launches"], 1),
                                "by_kernel_ms": {n: round(v["ms"], 4) for n, v in prof.items()}}
+        note("roofline probe done")
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, a, z, n_unet_steps)
+            out["cpu_baseline"] = cpu_baseline(a, z, n_unet_steps)
+            note("cpu baseline done")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(model, a, z, n_steps):
+def cpu_baseline(a, z, n_steps):
+    """Runs `bench.py --cpu-baseline-worker` in a fresh process: OMP/torch thread count is fixed BEFORE torch
+    creates its pools (a 256-thread pool makes the small-tensor oracle 100x slower), under a hard timeout."""
+    import subprocess
+    nthr = max(1, min(host_threads(), a.cpu_threads))
+    env = dict(os.environ, OMP_NUM_THREADS=str(nthr), MKL_NUM_THREADS=str(nthr), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--batch", str(a.batch), "--seconds", str(a.seconds),
+           "--cpu-threads", str(nthr), "--z", str(z), "--n-unet-steps", str(n_steps)]
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=sys.stderr, text=True, timeout=a.cpu_timeout)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and line:
+            return json.loads(line[-1])
+        return {"value": None, "unit": "charts/s", "cores": nthr, "kind": "port", "sample": "worker failed (rc %d)" % r.returncode}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "charts/s", "cores": nthr, "kind": "port", "sample": "worker exceeded %d s" % a.cpu_timeout}
+
+
+def cpu_baseline_worker(a):
     """The oracle (oracle/: PyTorch-CPU fp32 restatement of the reference path, bit-identical to the real
-    reference on the golden fixtures) on this host's cores, same weights, bounded sample."""
+    reference on the golden fixtures) on this host's cores, same seeded weights, bounded sample."""
     from oracle import host, nets
-    torch.set_num_threads(os.cpu_count())
+    from mug.model.paramtree import seed_all_parameters
+    from mug.util import instantiate_from_config
+    nthr = a.cpu_threads
+    torch.set_num_threads(nthr)
+    z, n_steps, B = a.z, a.n_unet_steps, a.batch
+    model = instantiate_from_config(model_config()).eval()
+    unet = model.model.unet_model
+    seed_all_parameters(model, seed=0, s4_length_of=lambda k: unet.s4_length_of(k[len("model.unet_model."):], SHIPPED["z_length"]))
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    B = a.batch
+    note("cpu baseline: weights ready (%d threads)" % nthr)
     g = torch.Generator().manual_seed(0)
     t0 = time.perf_counter()
     y = synth_audio(a.seconds, SHIPPED["sr"], 0)
     mel = host.pad_or_trunc_mel(host.log_mel(y).astype(np.float32), z * 64)
     t_mel = time.perf_counter() - t0
+    note("cpu baseline: mel %.2fs" % t_mel)
     with torch.no_grad():
         t0 = time.perf_counter()
         w = nets.wave_encode(sd, nets.WAVE_DEFAULT, torch.from_numpy(mel)[None])
         t_wave = time.perf_counter() - t0
+        note("cpu baseline: wave encoder %.2fs" % t_wave)
         w = [m.repeat(B, 1, 1) for m in w]
         x = torch.randn((B, 16, z), generator=g)
         c = torch.randn((B, 128, 21), generator=g)
@@ -224,14 +282,17 @@ def cpu_baseline(model, a, z, n_steps):
         for i in range(reps):
             nets.unet_forward(sd, nets.UNET_DEFAULT, x, torch.full((B,), 981 - 20 * i), c, w, kernel_cache=kc)
         t_unet = (time.perf_counter() - t0) / reps
+        note("cpu baseline: U-Net eval %.3fs" % t_unet)
         t0 = time.perf_counter()
         nets.vae_decode(sd, nets.VAE_DEFAULT, x)
         t_dec = time.perf_counter() - t0
     per_batch = t_mel + t_wave + n_steps * t_unet + t_dec
-    return {"value": B / per_batch, "unit": "charts/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "1 mel (%.2fs) + 1 wave-encode B=1 (%.2fs) + %d U-Net evals B=%d z=%d (%.3fs each, S4 kernels cached) + 1 decode (%.2fs), "
-                      "extrapolated to %d steps; PyTorch-CPU fp32, %d threads" % (t_mel, t_wave, reps, B, z, t_unet, t_dec, n_steps, os.cpu_count()),
-            "unet_sample_steps_per_s": B / t_unet}
+    print(json.dumps({
+        "value": B / per_batch, "unit": "charts/s", "cores": nthr, "kind": "port",
+        "sample": "1 mel (%.2fs) + 1 wave-encode B=1 (%.2fs) + %d U-Net evals B=%d z=%d (%.3fs each, S4 kernels cached) + 1 decode (%.2fs), "
+                  "extrapolated to %d steps; PyTorch-CPU fp32, %d threads (host exposes %d)"
+                  % (t_mel, t_wave, reps, B, z, t_unet, t_dec, n_steps, nthr, host_threads()),
+        "unet_sample_steps_per_s": B / t_unet}), flush=True)
 
 
 if __name__ == "__main__":
