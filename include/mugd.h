@@ -138,6 +138,12 @@ int mugd_op_layer_norm(mugd_ctx* ctx, const float* x, const float* gamma, const 
 /* conv1d: w (M, C, taps) torch layout; epi 0 none / 1 GLU / 2 GEGLU (then y has M/2 rows). */
 int mugd_op_conv1d(mugd_ctx* ctx, const float* x, const float* w, const float* bias, const float* resid, float* y,
                    int B, int C, int Tin, int M, int taps, int dil, int stride, int pad, int upsample, int Tout, int epi);
+/* The fused form the networks use: conv1d (stride 1) of GroupNorm(groups, eps 1e-6)[+SiLU] (norm = 1) or of
+ * LayerNorm over channels (eps 1e-5, norm = 2) of x, with the normalisation applied to the operand while it
+ * is staged -- the normalised tensor is never written (mug/diffusion/unet.py:212-239 GN->SiLU->conv,
+ * mug/model/attention.py:139-151 LN->Linear).  wk: K-split 1|2|4|8, 0 = heuristic. */
+int mugd_op_norm_conv1d(mugd_ctx* ctx, const float* x, const float* gamma, const float* beta, const float* w, const float* bias,
+                        float* y, int B, int C, int T, int M, int taps, int dil, int pad, int norm, int groups, int silu, int wk);
 int mugd_op_attention(mugd_ctx* ctx, const float* q, const float* k, const float* v, const float* rel, const float* cemb,
                       float* out, int B, int heads, int d, int Tq, int Tk, int pmax);
 int mugd_op_s4_kernel(mugd_ctx* ctx, const float* C, const float* Bp, const float* P, const float* inv_w_real,

@@ -76,6 +76,8 @@ int mugd_create(int device, void* stream, mugd_ctx** out) {
         }
         const char* g = getenv("MUGD_NO_GRAPH");
         ctx->c.use_graph = !(g && g[0] == '1');
+        const char* u = getenv("MUGD_UNFUSED_NORM");
+        ctx->c.fuse_norm = !(u && u[0] == '1');
     });
     if (rc != MUGD_OK) {
         fprintf(stderr, "mugd_create: %s\n", ctx->c.last_error.c_str());
@@ -272,6 +274,43 @@ int mugd_op_conv1d(mugd_ctx* ctx, const float* x, const float* w, const float* b
     });
 }
 
+int mugd_op_norm_conv1d(mugd_ctx* ctx, const float* x, const float* gamma, const float* beta, const float* w, const float* bias,
+                        float* y, int B, int C, int T, int M, int taps, int dil, int pad, int norm, int groups, int silu, int wk) {
+    return guarded(ctx, [&] {
+        MUGD_CHECK(C % CONV_CK == 0, MUGD_ERR_INVALID, "conv1d: C must be a multiple of 16");
+        MUGD_CHECK(norm == 1 || norm == 2, MUGD_ERR_INVALID, "norm must be 1 (GroupNorm) or 2 (LayerNorm)");
+        hipStream_t st = ctx->c.stream;
+        Scratch sc;
+        const int MT = cdiv(M, 32);
+        const long long mts = (long long)(C / CONV_CK) * taps * 512;
+        float* wpk = sc.get((size_t)MT * mts, true, st);
+        PackArgs pa{wpk, mts, 0, C, taps, w, C * taps, 0, M, 0};
+        launch_pack_weights(st, pa);
+        ConvArgs a{};
+        a.nseg = 1;
+        a.seg[0] = ConvSeg{x, C, T, taps, dil, 1, pad, 0, 0, 0, 0};
+        if (norm == 1) {
+            float* aff = sc.get((size_t)B * C * 2, false, st);
+            GnStatArgs g{};
+            g.seg[0] = NormSeg{x, C, 0};
+            g.nseg = 1; g.Ctot = C; g.T = T; g.groups = groups; g.B = B; g.gamma = gamma; g.beta = beta; g.eps = 1e-6f; g.aff = aff;
+            launch_gn_stats(st, g);
+            a.seg[0].xf = 1; a.seg[0].act = silu; a.seg[0].xf_a = aff; a.seg[0].xf_stride = 2 * C;
+        } else {
+            float* stat = sc.get((size_t)B * T * 2, false, st);
+            float* gb = sc.get((size_t)C * 2, false, st);
+            LnStatArgs l{x, stat, B, C, T, 1e-5f};
+            launch_ln_stats(st, l);
+            launch_interleave2(st, gamma, beta, gb, C);
+            a.seg[0].xf = 2; a.seg[0].act = silu; a.seg[0].xf_a = stat; a.seg[0].xf_b = gb; a.seg[0].xf_stride = 2 * T;
+        }
+        a.wpk = wpk; a.w_mt_stride = mts; a.bias = bias; a.y = y;
+        a.B = B; a.Mrows = M; a.Mout = M; a.Tout = T + 2 * pad - dil * (taps - 1); a.nchunk = C / CONV_CK; a.epi = EPI_NONE; a.wk = wk;
+        launch_conv_gemm(st, a);
+        HIP_CHECK(hipStreamSynchronize(st));
+    });
+}
+
 int mugd_op_attention(mugd_ctx* ctx, const float* q, const float* k, const float* v, const float* rel, const float* cemb,
                       float* out, int B, int heads, int d, int Tq, int Tk, int pmax) {
     return guarded(ctx, [&] {
@@ -295,7 +334,7 @@ int mugd_op_s4_kernel(mugd_ctx* ctx, const float* C, const float* Bp, const floa
 
 int mugd_op_s4_conv(mugd_ctx* ctx, const float* u, const float* k, const float* D, float* y, int B, int H, int L) {
     return guarded(ctx, [&] {
-        S4ConvArgs a{u, k, D, y, B, H, L};
+        S4ConvArgs a{u, k, D, y, B, H, L, nullptr};
         launch_s4_conv(ctx->c.stream, a);
     });
 }

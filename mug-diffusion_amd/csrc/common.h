@@ -8,6 +8,14 @@
 #include <stdexcept>
 #include <string>
 
+// register budget hint: at least n waves per SIMD (keeps the MFMA accumulators in the VGPR half).
+// tests/emu compiles these sources for the host, where the attribute does not exist.
+#ifdef MUGD_EMULATED
+#define MUGD_WAVES_PER_EU(n)
+#else
+#define MUGD_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -1,35 +1,45 @@
 // conv_gemm: conv1d / linear layers as an implicit GEMM on the gfx950 fp32 matrix cores.
 //
-// One workgroup = 8 wavefronts = one 32(rows) x 32(samples) output tile of one batch row;
-// the 8 waves split the reduction (K) axis between them (intra-workgroup split-K, combined
-// through LDS, deterministic), so even the 512-channel / 64-sample layers put >= 128
-// workgroups x 4 waves on the chip and every SIMD of a CU gets a matrix-core stream.
+// One workgroup = WK wavefronts = one 32(rows) x 32(samples) output tile of one batch row; the
+// WK waves split the reduction (K) axis between them (intra-workgroup split-K, combined through
+// LDS in a fixed order, deterministic).  WK is picked per layer on the host so that every layer
+// puts ~2 waves on each of the chip's 1024 SIMDs: the U-Net's GEMMs are small (N = B*T is 256
+// .. 2048 columns), so K is the only axis left to parallelise on the 512-channel levels, while
+// the short-K / tall-M layers (GEGLU projections) run with WK = 2 and a 2-term reduction.
 //
 // Per wave and K-chunk (16 input channels x taps):
 //   A (weights)     : global -> VGPR, pre-packed in fragment order, 1 KiB coalesced dwordx4
 //                     loads, 16 B/lane, each feeding 4 MFMAs; next chunk prefetched while the
 //                     current one is on the matrix pipe.
-//   B (activations) : global -> VGPR -> per-wave LDS window [16 ch][window], read back in MFMA
-//                     B-fragment order (lane n = sample, lanes 32..63 = +4 channels); the 3 taps
-//                     / dilation / stride / nearest-upsample are just shifted reads of the window.
+//   B (activations) : global -> VGPR -> (normalise / activate) -> per-wave LDS window
+//                     [16 ch][window], read back in MFMA B-fragment order (lane n = sample,
+//                     lanes 32..63 = +4 channels); the 3 taps / dilation / stride / nearest-upsample
+//                     are just shifted reads of the window.
+//                     Fast path (stride 1, T % 4 == 0): lane (row = lane/4, quarter = lane%4) moves
+//                     two aligned float4 of its row plus <= 4 halo samples, so a chunk is 2 dwordx4
+//                     + 1..4 dword loads per lane; the generic path walks the window as a flat index.
+//   operand transform: GroupNorm / LayerNorm are not separate passes.  A statistics kernel
+//                     (k_norm.hip) leaves {scale, shift} per (batch, channel) or {mean, rstd} per
+//                     (batch, sample); the normalise (+ SiLU) is applied to the staged values on
+//                     their way into LDS, so the normalised tensor never exists in memory.
+//                     Zero padding is applied AFTER the transform, as in the reference (conv pads
+//                     the normalised tensor).
 //   v_mfma_f32_32x32x2_f32: lane (h,r) supplies A[row r][k=h], lane (h,n) supplies B[k=h][col n];
 //   the K order inside a chunk is permuted to (k=h -> channel 4h+j) so a lane's float4 of
 //   weights is used by 4 consecutive MFMAs.  fp32 in, fp32 accumulate: bitwise an fma chain.
 //
-// All per-lane addressing (window walk, zero-padding mask, LDS addresses) is computed ONCE per
-// K-segment; a chunk iteration is then NIT loads at (uniform base + fixed 32-bit lane offset),
-// NIT selects + LDS stores, 8*TAPS LDS reads and 8*TAPS MFMAs.  Workgroups are renumbered so
-// that each XCD (private L2) owns a contiguous range of row tiles, i.e. of the weight stream.
+// Workgroups are renumbered so that each XCD (private L2) owns a contiguous range of row tiles,
+// i.e. of the weight stream.
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.h"
 
 namespace {
 
 constexpr int RS = CONV_RS;
-constexpr int WAVE_LDS = CONV_CK * RS;          // floats per wave window (1088)
-constexpr int NWAVE = 8;                        // waves per workgroup = K slices (2 per SIMD: one computes while one waits)
-constexpr int RED_LDS = NWAVE * 16 * 64;        // floats for one partial-tile exchange
+constexpr int WAVE_LDS = CONV_CK * RS;          // floats per wave window
+constexpr int HL = 8;                           // fast path: window column of sample t0 (left halo lives in [HL-pad, HL))
 
 template <int TAPS, bool DUAL>
 __device__ __forceinline__ void load_a(const float* wp, const float* wp2, float4 (&A)[6], float4 (&A2)[6]) {
@@ -40,85 +50,147 @@ __device__ __forceinline__ void load_a(const float* wp, const float* wp2, float4
     }
 }
 
-// One K-segment (one input tensor of the virtual concat), chunks [lo, hi) of it, for this wave.
-template <int TAPS, bool DUAL, int NIT>
-__device__ __forceinline__ void run_segment(const ConvSeg& s, const float* wseg, const float* wseg2, int lo, int hi,
-                                            int b, int t0, int lane, int h, int n, char* smem_bytes, int wave_base,
-                                            f32x16& acc, f32x16& acc2) {
-    // ---- per-segment lane constants: the 16 x RW window is walked as a flat index (lane + 64 k);
-    // out-of-range samples read a clamped address and are zeroed by a select when stored to LDS;
-    // the tail of the last pass re-writes the final element (same value, same address).
-    const int RW = 31 * s.stride + (TAPS - 1) * s.dil + 1;
-    const float inv = 1.0f / (float)RW;
-    const int last = CONV_CK * RW - 1;
-    const int vlen = s.ups ? 2 * s.Tin : s.Tin;
-    const int u0 = t0 * s.stride - s.pad;
-    unsigned goff[NIT];        // byte offset from the chunk's first channel row
-    int loff[NIT];             // absolute LDS byte address
-    bool ok[NIT];
+template <int TAPS, bool DUAL>
+__device__ __forceinline__ void mfma_chunk(const char* smem_bytes, int rb0, int dil, const float4 (&A)[6], const float4 (&A2)[6],
+                                           f32x16& acc, f32x16& acc2) {
+    float bf[TAPS * 8];
 #pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-        int idx = lane + 64 * k;
-        idx = idx < last ? idx : last;
-        const int row = (int)(((float)idx + 0.5f) * inv);
-        const int col = idx - row * RW;
-        const int u = u0 + col;
-        ok[k] = (u >= 0) && (u < vlen);
-        int uc = u < 0 ? 0 : u;
-        uc = uc < vlen ? uc : vlen - 1;
-        goff[k] = (unsigned)(row * s.Tin + (s.ups ? (uc >> 1) : uc)) * 4u;
-        loff[k] = wave_base + (row * RS + col) * 4;
+    for (int tap = 0; tap < TAPS; ++tap) {
+        const char* p = smem_bytes + rb0 + tap * dil * 4;
+#pragma unroll
+        for (int g8 = 0; g8 < 2; ++g8)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[(tap * 2 + g8) * 4 + j] = *reinterpret_cast<const float*>(p + (g8 * 8 + j) * RS * 4);
     }
+#pragma unroll
+    for (int i = 0; i < TAPS * 2; ++i) {
+        const float4 av = A[i];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf[i * 4 + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf[i * 4 + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf[i * 4 + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf[i * 4 + 3], acc, 0, 0, 0);
+        if (DUAL) {
+            const float4 gv = A2[i];
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.x, bf[i * 4 + 0], acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.y, bf[i * 4 + 1], acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.z, bf[i * 4 + 2], acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.w, bf[i * 4 + 3], acc2, 0, 0, 0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Fast path: stride 1, no upsample, Tin % 4 == 0 (rows are 16-byte aligned).  NH = halo loads per lane.
+// ---------------------------------------------------------------------------------------
+template <int TAPS, bool DUAL, int NH>
+__device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* wseg, const float* wseg2, int lo, int hi,
+                                                int b, int t0, int lane, int h, int n, char* smem_bytes, int wave_base,
+                                                f32x16& acc, f32x16& acc2) {
+    const int r = lane >> 2, q = lane & 3;
+    const int Tin = s.Tin;
+    const int hw = (TAPS - 1) * s.dil;                     // halo samples per row (left pad + right rest)
+    // ---- interior: samples t0 + 8q + {0..3}, {4..7}
+    const int ti0 = t0 + 8 * q, ti1 = ti0 + 4;
+    const bool ok0 = ti0 < Tin, ok1 = ti1 < Tin;           // Tin % 4 == 0: a float4 is wholly inside or outside
+    const unsigned g0 = (unsigned)(r * Tin + (ok0 ? ti0 : Tin - 4)) * 4u;
+    const unsigned g1 = (unsigned)(r * Tin + (ok1 ? ti1 : Tin - 4)) * 4u;
+    const int l0 = wave_base + (r * RS + HL + 8 * q) * 4;
+    // ---- halo: element e = q + 4j of this row: e < pad -> sample t0 - pad + e, else sample t0 + 32 + (e - pad)
+    unsigned gh[NH > 0 ? NH : 1];
+    int lh[NH > 0 ? NH : 1];
+    bool okh[NH > 0 ? NH : 1];
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+        const int e = q + 4 * j;
+        const int col = e < s.pad ? e - s.pad : 32 + (e - s.pad);      // relative to t0
+        const int t = t0 + col;
+        okh[j] = (e < hw) && (t >= 0) && (t < Tin);
+        int tc = t < 0 ? 0 : t;
+        tc = tc < Tin ? tc : Tin - 1;
+        gh[j] = (unsigned)(r * Tin + tc) * 4u;
+        lh[j] = wave_base + (r * RS + (e < hw ? HL + col : 60 + q)) * 4;      // dead lanes park in columns no tap reads
+    }
+    // ---- operand transform constants
+    const int xf = s.xf, act = s.act;
+    float mu[8], rs8[8];
+    float muh[NH > 0 ? NH : 1], rsh[NH > 0 ? NH : 1];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { mu[i] = 0.f; rs8[i] = 1.f; }
+#pragma unroll
+    for (int j = 0; j < NH; ++j) { muh[j] = 0.f; rsh[j] = 1.f; }
+    const float* gb = nullptr;                            // per-channel {g, b} stream, advanced by 32 floats per chunk
+    if (xf == 1) {
+        gb = s.xf_a + (size_t)b * s.xf_stride + 2 * ((size_t)lo * CONV_CK + r);
+    } else if (xf == 2) {
+        gb = s.xf_b + 2 * ((size_t)lo * CONV_CK + r);
+        const float* cs = s.xf_a + (size_t)b * s.xf_stride;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int t = ti0 + i;
+            t = t < Tin ? t : Tin - 1;
+            mu[i] = cs[2 * t]; rs8[i] = cs[2 * t + 1];
+        }
+#pragma unroll
+        for (int j = 0; j < NH; ++j) { muh[j] = cs[gh[j] / 4u % (unsigned)Tin * 2]; rsh[j] = cs[gh[j] / 4u % (unsigned)Tin * 2 + 1]; }
+    }
+
     const int bb = s.bmod > 0 ? b % s.bmod : b;
-    const char* xb = reinterpret_cast<const char*>(s.x + ((size_t)bb * s.C + (size_t)lo * CONV_CK) * s.Tin);
-    const size_t xstep = (size_t)CONV_CK * s.Tin * 4;
+    const char* xb = reinterpret_cast<const char*>(s.x + ((size_t)bb * s.C + (size_t)lo * CONV_CK) * Tin);
+    const size_t xstep = (size_t)CONV_CK * Tin * 4;
     const float* wp = wseg + (size_t)lo * (TAPS * 512);
     const float* wp2 = wseg2 + (size_t)lo * (TAPS * 512);
-    const int rb0 = wave_base + (4 * h * RS + n * s.stride) * 4;      // this lane's B-fragment read base (bytes)
+    const int rb0 = wave_base + (4 * h * RS + HL - s.pad + n) * 4;      // this lane's B-fragment read base (bytes)
 
     float4 Aa[6], Aa2[6], Ab[6], Ab2[6];       // ping-pong weight fragments: no register copies in the loop
-    float xr[NIT];
+    float4 x0, x1;
+    float xh[NH > 0 ? NH : 1];
+    float2 gbv = make_float2(1.f, 0.f);
     load_a<TAPS, DUAL>(wp, wp2, Aa, Aa2);
+    x0 = *reinterpret_cast<const float4*>(xb + g0);
+    x1 = *reinterpret_cast<const float4*>(xb + g1);
 #pragma unroll
-    for (int k = 0; k < NIT; ++k) xr[k] = *reinterpret_cast<const float*>(xb + goff[k]);
+    for (int j = 0; j < NH; ++j) xh[j] = *reinterpret_cast<const float*>(xb + gh[j]);
+    if (xf) gbv = *reinterpret_cast<const float2*>(gb);
 
-    // one chunk: park the window in LDS, launch the next chunk's loads, run this chunk on the matrix pipe
     auto step = [&](const float4 (&A)[6], const float4 (&A2)[6], float4 (&An)[6], float4 (&An2)[6], bool more) {
+        float v[8];
+        float vh[NH > 0 ? NH : 1];
+        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
 #pragma unroll
-        for (int k = 0; k < NIT; ++k) *reinterpret_cast<float*>(smem_bytes + loff[k]) = ok[k] ? xr[k] : 0.f;
+        for (int j = 0; j < NH; ++j) vh[j] = xh[j];
+        if (xf) {
+            const float g = gbv.x, bt = gbv.y;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (v[i] - mu[i]) * rs8[i] * g + bt;
+#pragma unroll
+            for (int j = 0; j < NH; ++j) vh[j] = (vh[j] - muh[j]) * rsh[j] * g + bt;
+            if (act) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = silu_f(v[i]);
+#pragma unroll
+                for (int j = 0; j < NH; ++j) vh[j] = silu_f(vh[j]);
+            }
+        }
+        float4 w0, w1;                                  // zero padding AFTER the transform (component selects: no scratch)
+        w0.x = ok0 ? v[0] : 0.f; w0.y = ok0 ? v[1] : 0.f; w0.z = ok0 ? v[2] : 0.f; w0.w = ok0 ? v[3] : 0.f;
+        w1.x = ok1 ? v[4] : 0.f; w1.y = ok1 ? v[5] : 0.f; w1.z = ok1 ? v[6] : 0.f; w1.w = ok1 ? v[7] : 0.f;
+        *reinterpret_cast<float4*>(smem_bytes + l0) = w0;
+        *reinterpret_cast<float4*>(smem_bytes + l0 + 16) = w1;
+#pragma unroll
+        for (int j = 0; j < NH; ++j) *reinterpret_cast<float*>(smem_bytes + lh[j]) = okh[j] ? vh[j] : 0.f;
         wave_sync();
         if (more) {
             wp += TAPS * 512;
             wp2 += TAPS * 512;
             xb += xstep;
             load_a<TAPS, DUAL>(wp, wp2, An, An2);
+            x0 = *reinterpret_cast<const float4*>(xb + g0);
+            x1 = *reinterpret_cast<const float4*>(xb + g1);
 #pragma unroll
-            for (int k = 0; k < NIT; ++k) xr[k] = *reinterpret_cast<const float*>(xb + goff[k]);
+            for (int j = 0; j < NH; ++j) xh[j] = *reinterpret_cast<const float*>(xb + gh[j]);
+            if (xf) { gb += 2 * CONV_CK; gbv = *reinterpret_cast<const float2*>(gb); }
         }
-        float bf[TAPS * 8];
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const char* p = smem_bytes + rb0 + tap * s.dil * 4;
-#pragma unroll
-            for (int g8 = 0; g8 < 2; ++g8)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bf[(tap * 2 + g8) * 4 + j] = *reinterpret_cast<const float*>(p + (g8 * 8 + j) * RS * 4);
-        }
-#pragma unroll
-        for (int i = 0; i < TAPS * 2; ++i) {
-            const float4 av = A[i];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf[i * 4 + 0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf[i * 4 + 1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf[i * 4 + 2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf[i * 4 + 3], acc, 0, 0, 0);
-            if (DUAL) {
-                const float4 gv = A2[i];
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.x, bf[i * 4 + 0], acc2, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.y, bf[i * 4 + 1], acc2, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.z, bf[i * 4 + 2], acc2, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.w, bf[i * 4 + 3], acc2, 0, 0, 0);
-            }
-        }
+        mfma_chunk<TAPS, DUAL>(smem_bytes, rb0, s.dil, A, A2, acc, acc2);
         wave_sync();               // all lanes done reading the window before it is overwritten
     };
 
@@ -131,9 +203,114 @@ __device__ __forceinline__ void run_segment(const ConvSeg& s, const float* wseg,
     }
 }
 
-template <bool DUAL, int NIT>
-__global__ __launch_bounds__(NWAVE * 64) void conv_gemm_kernel(const ConvArgs a, int gx, int gy, int gz) {
-    __shared__ float smem[DUAL ? 2 * RED_LDS : (NWAVE * WAVE_LDS > RED_LDS ? NWAVE * WAVE_LDS : RED_LDS)];
+// ---------------------------------------------------------------------------------------
+// Generic path (stride 2, nearest-x2 upsample, unaligned rows): the 16 x RW window is walked as a flat
+// index (lane + 64 k); out-of-range samples read a clamped address and are zeroed by a select when stored.
+// ---------------------------------------------------------------------------------------
+template <int TAPS, bool DUAL, int NIT, bool XF>
+__device__ __forceinline__ void run_segment_gen(const ConvSeg& s, const float* wseg, const float* wseg2, int lo, int hi,
+                                                int b, int t0, int lane, int h, int n, char* smem_bytes, int wave_base,
+                                                f32x16& acc, f32x16& acc2) {
+    const int RW = 31 * s.stride + (TAPS - 1) * s.dil + 1;
+    const float inv = 1.0f / (float)RW;
+    const int last = CONV_CK * RW - 1;
+    const int vlen = s.ups ? 2 * s.Tin : s.Tin;
+    const int u0 = t0 * s.stride - s.pad;
+    const int xf = XF ? s.xf : 0, act = s.act;      // the wide (stride-2) instantiation carries no transform: registers
+    unsigned goff[NIT];        // byte offset from the chunk's first channel row
+    int loff[NIT];             // absolute LDS byte address
+    int rowk[NIT];
+    bool ok[NIT];
+    float mu[NIT], rsd[NIT];
+    const float* cs = (xf == 2) ? s.xf_a + (size_t)b * s.xf_stride : nullptr;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        int idx = lane + 64 * k;
+        idx = idx < last ? idx : last;
+        const int row = (int)(((float)idx + 0.5f) * inv);
+        const int col = idx - row * RW;
+        const int u = u0 + col;
+        ok[k] = (u >= 0) && (u < vlen);
+        int uc = u < 0 ? 0 : u;
+        uc = uc < vlen ? uc : vlen - 1;
+        const int tsrc = s.ups ? (uc >> 1) : uc;
+        goff[k] = (unsigned)(row * s.Tin + tsrc) * 4u;
+        loff[k] = wave_base + (row * RS + col) * 4;
+        rowk[k] = row;
+        mu[k] = 0.f; rsd[k] = 1.f;
+        if (xf == 2) { mu[k] = cs[2 * tsrc]; rsd[k] = cs[2 * tsrc + 1]; }
+    }
+    const float* gb = nullptr;
+    if (xf == 1) gb = s.xf_a + (size_t)b * s.xf_stride + 2 * (size_t)lo * CONV_CK;
+    else if (xf == 2) gb = s.xf_b + 2 * (size_t)lo * CONV_CK;
+    const int bb = s.bmod > 0 ? b % s.bmod : b;
+    const char* xb = reinterpret_cast<const char*>(s.x + ((size_t)bb * s.C + (size_t)lo * CONV_CK) * s.Tin);
+    const size_t xstep = (size_t)CONV_CK * s.Tin * 4;
+    const float* wp = wseg + (size_t)lo * (TAPS * 512);
+    const float* wp2 = wseg2 + (size_t)lo * (TAPS * 512);
+    const int rb0 = wave_base + (4 * h * RS + n * s.stride) * 4;      // this lane's B-fragment read base (bytes)
+
+    float4 Aa[6], Aa2[6], Ab[6], Ab2[6];
+    float xr[NIT];
+    float2 gbr[NIT];
+    load_a<TAPS, DUAL>(wp, wp2, Aa, Aa2);
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        xr[k] = *reinterpret_cast<const float*>(xb + goff[k]);
+        gbr[k] = make_float2(1.f, 0.f);
+        if (xf) gbr[k] = *reinterpret_cast<const float2*>(gb + 2 * rowk[k]);
+    }
+
+    auto step = [&](const float4 (&A)[6], const float4 (&A2)[6], float4 (&An)[6], float4 (&An2)[6], bool more) {
+        float v[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) v[k] = xr[k];
+        if (xf) {
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) v[k] = (v[k] - mu[k]) * rsd[k] * gbr[k].x + gbr[k].y;
+            if (act) {
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) v[k] = silu_f(v[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) *reinterpret_cast<float*>(smem_bytes + loff[k]) = ok[k] ? v[k] : 0.f;
+        wave_sync();
+        if (more) {
+            wp += TAPS * 512;
+            wp2 += TAPS * 512;
+            xb += xstep;
+            load_a<TAPS, DUAL>(wp, wp2, An, An2);
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) xr[k] = *reinterpret_cast<const float*>(xb + goff[k]);
+            if (xf) {
+                gb += 2 * CONV_CK;
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) gbr[k] = *reinterpret_cast<const float2*>(gb + 2 * rowk[k]);
+            }
+        }
+        mfma_chunk<TAPS, DUAL>(smem_bytes, rb0, s.dil, A, A2, acc, acc2);
+        wave_sync();
+    };
+
+    int c = lo;
+    for (;;) {
+        step(Aa, Aa2, Ab, Ab2, c + 1 < hi);
+        if (++c >= hi) break;
+        step(Ab, Ab2, Aa, Aa2, c + 1 < hi);
+        if (++c >= hi) break;
+    }
+}
+
+__device__ __forceinline__ bool seg_is_vec(const ConvSeg& s) { return s.stride == 1 && !s.ups && (s.Tin & 3) == 0 && s.pad <= HL; }
+
+// LEAN: every segment takes the fast path with dilation 1 (the whole U-Net except its 6 resampling
+// convs) -- keeps the hot instantiations small.  NITG: staging passes of the generic path.
+template <int WK, bool DUAL, bool LEAN, int NITG>
+__global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel(const ConvArgs a, int gx, int gy, int gz) {
+    constexpr int RED = WK > 1 ? WK * 16 * 64 : 1;                  // floats for one partial-tile exchange
+    constexpr int WIN = WK * WAVE_LDS;
+    __shared__ __attribute__((aligned(16))) float smem[(DUAL ? 2 * RED : RED) > WIN ? (DUAL ? 2 * RED : RED) : WIN];
 
     // ---- XCD-aware renumbering: hardware deals consecutive workgroup ids round-robin to the 8 XCDs;
     // give each XCD a contiguous slab of the (row tile major) tile order so a weight tile is pulled
@@ -150,7 +327,7 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_gemm_kernel(const ConvArgs a,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, h = lane >> 5, n = lane & 31;
 
-    const int per = (a.nchunk + NWAVE - 1) / NWAVE;
+    const int per = (a.nchunk + WK - 1) / WK;
     const int g0 = wave * per;
     const int g1 = (g0 + per < a.nchunk) ? g0 + per : a.nchunk;
 
@@ -171,44 +348,68 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_gemm_kernel(const ConvArgs a,
             const int lo = (g0 > s.chunk0 ? g0 : s.chunk0) - s.chunk0;
             const int hi = (g1 < s.chunk0 + nch ? g1 : s.chunk0 + nch) - s.chunk0;
             if (lo < hi) {
-                if (s.taps == 3) run_segment<3, DUAL, NIT>(s, wtile + s.woff, wtile2 + s.woff, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, acc, acc2);
-                else run_segment<1, DUAL, NIT>(s, wtile + s.woff, wtile2 + s.woff, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, acc, acc2);
+                const float* w1 = wtile + s.woff;
+                const float* w2 = wtile2 + s.woff;
+#define MUGD_SEG_ARGS s, w1, w2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, acc, acc2
+                if (LEAN) {
+                    if (s.taps == 3) run_segment_vec<3, DUAL, 1>(MUGD_SEG_ARGS);
+                    else run_segment_vec<1, DUAL, 0>(MUGD_SEG_ARGS);
+                } else if (seg_is_vec(s)) {
+                    if (s.taps == 1) run_segment_vec<1, DUAL, 0>(MUGD_SEG_ARGS);
+                    else if (s.dil <= 2) run_segment_vec<3, DUAL, 1>(MUGD_SEG_ARGS);
+                    else if (s.dil == 4) run_segment_vec<3, DUAL, 2>(MUGD_SEG_ARGS);
+                    else run_segment_vec<3, DUAL, 4>(MUGD_SEG_ARGS);
+                } else {
+                    if (s.taps == 3) run_segment_gen<3, DUAL, NITG, (NITG <= 9)>(MUGD_SEG_ARGS);
+                    else run_segment_gen<1, DUAL, NITG, (NITG <= 9)>(MUGD_SEG_ARGS);
+                }
+#undef MUGD_SEG_ARGS
             }
         }
     }
 
-    // ---- combine the 4 K-slices through LDS (the staging windows are dead after this barrier)
-    __syncthreads();
+    // ---- combine the WK K-slices through LDS (the staging windows are dead after this barrier)
+    constexpr int EPT = 16 / WK;         // tile rows (accumulator registers) finished by each wave
+    float acc_v[EPT], acc_g[EPT];
+    if (WK > 1) {
+        __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        smem[(wave * 16 + r) * 64 + lane] = acc[r];
-        if (DUAL) smem[RED_LDS + (wave * 16 + r) * 64 + lane] = acc2[r];
+        for (int r = 0; r < 16; ++r) {
+            smem[(wave * 16 + r) * 64 + lane] = acc[r];
+            if (DUAL) smem[RED + (wave * 16 + r) * 64 + lane] = acc2[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int r = wave * EPT + q;
+            acc_v[q] = 0.f;
+            acc_g[q] = 0.f;
+#pragma unroll
+            for (int w = 0; w < WK; ++w) {
+                acc_v[q] += smem[(w * 16 + r) * 64 + lane];
+                if (DUAL) acc_g[q] += smem[RED + (w * 16 + r) * 64 + lane];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) { acc_v[q] = acc[q]; acc_g[q] = acc2[q]; }
     }
-    __syncthreads();
 
     // ---- epilogue: all side loads (bias / row term / residual) are issued together from clamped
     // addresses under wave-uniform conditions; only the final store is predicated.
-    constexpr int EPT = 16 / NWAVE;      // tile rows (accumulator registers) finished by each wave
-    float acc_v[EPT], acc_g[EPT], bv[EPT], bg[EPT], ra[EPT], rs[EPT];
+    float bv[EPT], bg[EPT], ra[EPT], rsv[EPT];
     size_t oo[EPT];
     int mm[EPT];
     bool valid[EPT];
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
         const int r = wave * EPT + q;
-        acc_v[q] = 0.f;
-        acc_g[q] = 0.f;
-#pragma unroll
-        for (int w = 0; w < NWAVE; ++w) {
-            acc_v[q] += smem[(w * 16 + r) * 64 + lane];
-            if (DUAL) acc_g[q] += smem[RED_LDS + (w * 16 + r) * 64 + lane];
-        }
         const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
         const int m = mt * 32 + row, t = t0 + n;
         valid[q] = (m < a.Mout) && (t < a.Tout);
         mm[q] = m < a.Mout ? m : a.Mout - 1;
         oo[q] = ((size_t)b * a.Mout + mm[q]) * a.Tout + (t < a.Tout ? t : a.Tout - 1);
-        bv[q] = 0.f; bg[q] = 0.f; ra[q] = 0.f; rs[q] = 0.f;
+        bv[q] = 0.f; bg[q] = 0.f; ra[q] = 0.f; rsv[q] = 0.f;
     }
     if (a.bias) {
 #pragma unroll
@@ -220,7 +421,7 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_gemm_kernel(const ConvArgs a,
     }
     if (a.resid) {
 #pragma unroll
-        for (int q = 0; q < EPT; ++q) rs[q] = a.resid[oo[q]];
+        for (int q = 0; q < EPT; ++q) rsv[q] = a.resid[oo[q]];
     }
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
@@ -229,7 +430,7 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_gemm_kernel(const ConvArgs a,
             const float gte = acc_g[q] + bg[q];
             v = (a.epi == EPI_GLU) ? v * sigmoid_f(gte) : v * gelu_erf_f(gte);
         }
-        v = (v + ra[q]) + rs[q];
+        v = (v + ra[q]) + rsv[q];
         if (valid[q]) a.y[oo[q]] = v;
     }
 }
@@ -252,30 +453,76 @@ __global__ void pack_weights_kernel(const PackArgs p) {
     }
 }
 
+template <int WK, bool DUAL>
+void launch_wk(hipStream_t st, const ConvArgs& a, dim3 grid, int gx, int gy, int gz, bool lean, int nitg) {
+#define MUGD_CONV_LAUNCH(L, N) hipLaunchKernelGGL((conv_gemm_kernel<WK, DUAL, L, N>), grid, dim3(WK * 64), 0, st, a, gx, gy, gz)
+    if (lean) MUGD_CONV_LAUNCH(true, 1);
+    else if (nitg <= 9) MUGD_CONV_LAUNCH(false, 9);
+    else MUGD_CONV_LAUNCH(false, 17);
+#undef MUGD_CONV_LAUNCH
+}
+
 }  // namespace
+
+int conv_pick_wk(const ConvArgs& a) {
+    // ~2 waves on each of the 1024 SIMDs, every wave with at least 2 chunks of work where K allows
+    const long long tiles = (long long)cdiv(a.Tout, CONV_TN) * cdiv(a.Mout, 32) * a.B;
+    int wk = 8;
+    while (wk > 1 && tiles * wk > 2048) wk >>= 1;
+    while (wk > 1 && a.nchunk < 2 * wk) wk >>= 1;
+    if (wk < 2 && tiles < 2048) wk = a.nchunk >= 4 ? 2 : 1;
+    return wk;
+}
 
 void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
     MUGD_CHECK(a.nseg >= 1 && a.nseg <= CONV_MAXSEG, -2, "conv_gemm: bad segment count");
-    int nit = 0;                          // staging passes: ceil(16 * window / 64) for the widest segment
+    int nitg = 0;                         // staging passes of the generic path: ceil(16 * window / 64) for its widest segment
+    bool lean = true;
     for (int i = 0; i < a.nseg; ++i) {
         const ConvSeg& s = a.seg[i];
         MUGD_CHECK(s.C % CONV_CK == 0, -2, "conv_gemm: channels must be a multiple of 16");
         MUGD_CHECK(s.taps == 1 || s.taps == 3, -2, "conv_gemm: taps must be 1 or 3");
-        const int rw = 31 * s.stride + (s.taps - 1) * s.dil + 1;
-        MUGD_CHECK(rw <= CONV_RS, -2, "conv_gemm: window exceeds LDS row");
+        MUGD_CHECK(s.dil >= 1 && (s.stride == 1 || s.stride == 2), -2, "conv_gemm: bad dilation / stride");
         MUGD_CHECK((long long)CONV_CK * s.Tin * 4 < (1ll << 31), -2, "conv_gemm: sequence too long for 32-bit window offsets");
-        nit = std::max(nit, cdiv(CONV_CK * rw, 64));
+        MUGD_CHECK(s.xf >= 0 && s.xf <= 2 && (s.xf == 0 || s.xf_a) && (s.xf != 2 || s.xf_b), -2, "conv_gemm: bad operand transform");
+        const bool vec = s.stride == 1 && !s.ups && (s.Tin & 3) == 0 && s.pad <= HL;
+        if (vec) {
+            const int hw = (s.taps - 1) * s.dil;
+            MUGD_CHECK(hw <= 16 && s.pad <= hw && HL + 32 + (hw - s.pad) <= CONV_RS, -2, "conv_gemm: window exceeds LDS row");
+            if (s.taps == 3 && s.dil != 1) lean = false;
+        } else {
+            const int rw = 31 * s.stride + (s.taps - 1) * s.dil + 1;
+            MUGD_CHECK(rw <= CONV_RS, -2, "conv_gemm: window exceeds LDS row");
+            const int nit = cdiv(CONV_CK * rw, 64);
+            MUGD_CHECK(s.xf == 0 || nit <= 9, -2, "conv_gemm: no operand transform on strided windows");
+            nitg = std::max(nitg, nit);
+            lean = false;
+        }
     }
+    MUGD_CHECK(nitg <= 17, -2, "conv_gemm: window too wide");
+    if (nitg > 9)
+        for (int i = 0; i < a.nseg; ++i) MUGD_CHECK(a.seg[i].xf == 0 || (a.seg[i].stride == 1 && !a.seg[i].ups && (a.seg[i].Tin & 3) == 0), -2,
+                                                    "conv_gemm: operand transform next to a strided segment needs T % 4 == 0");
     const bool dual = a.epi != EPI_NONE;
     if (dual) MUGD_CHECK(a.Mout % 32 == 0 && a.Mrows == 2 * a.Mout, -2, "conv_gemm: gated epilogue needs Mout % 32 == 0");
     else MUGD_CHECK(a.Mrows == a.Mout, -2, "conv_gemm: Mrows != Mout");
     const int gx = cdiv(a.Tout, CONV_TN), gy = cdiv(a.Mout, 32), gz = a.B;
     const dim3 grid((unsigned)gx * gy * gz);
-#define MUGD_CONV_LAUNCH(D, N) hipLaunchKernelGGL((conv_gemm_kernel<D, N>), grid, dim3(NWAVE * 64), 0, st, a, gx, gy, gz)
-    if (nit <= 9) { if (dual) MUGD_CONV_LAUNCH(true, 9); else MUGD_CONV_LAUNCH(false, 9); }
-    else if (nit <= 12) { if (dual) MUGD_CONV_LAUNCH(true, 12); else MUGD_CONV_LAUNCH(false, 12); }
-    else { if (dual) MUGD_CONV_LAUNCH(true, 17); else MUGD_CONV_LAUNCH(false, 17); }
-#undef MUGD_CONV_LAUNCH
+    int wk = a.wk > 0 ? a.wk : conv_pick_wk(a);
+    if (const char* e = getenv("MUGD_CONV_WK")) {            // development / test knob: force the K-split
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4 || v == 8) wk = v;
+    }
+#define MUGD_WK(W)                                                             \
+    case W:                                                                    \
+        if (dual) launch_wk<W, true>(st, a, grid, gx, gy, gz, lean, nitg);     \
+        else launch_wk<W, false>(st, a, grid, gx, gy, gz, lean, nitg);         \
+        break;
+    switch (wk) {
+        MUGD_WK(1) MUGD_WK(2) MUGD_WK(4) MUGD_WK(8)
+        default: MUGD_CHECK(false, -2, "conv_gemm: K-split must be 1, 2, 4 or 8");
+    }
+#undef MUGD_WK
 }
 
 void launch_pack_weights(hipStream_t st, const PackArgs& a) {

@@ -114,6 +114,114 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const LnArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Statistics-only kernels: the normalisation itself is fused into the consumer's operand
+// path (conv_gemm / s4_conv), see k_conv.hip.
+// ---------------------------------------------------------------------------------------
+// GroupNorm statistics -> per (batch, channel) {g, b} with  normalised = x*g + b,
+// g = gamma*rstd, b = beta - mean*g  (the form torch's CPU GroupNorm kernel uses).
+// grid (groups, B), block 256.  A group (<= ~10k elements in the U-Net) is read ONCE, with
+// GN_U float4 loads per thread in flight before the first use: the kernel is latency-bound.
+constexpr int GN_U = 8;
+template <bool VEC4>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GnStatArgs a) {
+    __shared__ double red[2][4];
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int cg = a.Ctot / a.groups, c_lo = g * cg;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
+    const int T = a.T;
+    // channel -> row pointer of the virtual concat
+    auto row = [&](int c) -> const float* {
+        int s = 0;
+        while (s + 1 < a.nseg && c >= a.seg[s].C) { c -= a.seg[s].C; ++s; }
+        const int bb = a.seg[s].bmod > 0 ? b % a.seg[s].bmod : b;
+        return a.seg[s].x + ((size_t)bb * a.seg[s].C + c) * T;
+    };
+    double s = 0.0, q = 0.0;
+    if (VEC4) {
+        const int T4 = T >> 2, n4 = cg * T4;
+        const float rT4 = 1.0f / (float)T4;
+        for (int base = tid; base < n4; base += 256 * GN_U) {
+            float4 v[GN_U];
+            bool ok[GN_U];
+#pragma unroll
+            for (int u = 0; u < GN_U; ++u) {
+                int idx = base + u * 256;
+                ok[u] = idx < n4;
+                idx = ok[u] ? idx : n4 - 1;
+                int c = (int)(((float)idx + 0.5f) * rT4);          // idx / T4 (exact for idx < 2^20)
+                const int t4 = idx - c * T4;
+                v[u] = reinterpret_cast<const float4*>(row(c_lo + c))[t4];
+            }
+#pragma unroll
+            for (int u = 0; u < GN_U; ++u) {
+                if (ok[u]) {
+                    s += ((double)v[u].x + (double)v[u].y) + ((double)v[u].z + (double)v[u].w);
+                    q += ((double)v[u].x * v[u].x + (double)v[u].y * v[u].y) + ((double)v[u].z * v[u].z + (double)v[u].w * v[u].w);
+                }
+            }
+        }
+    } else {
+        for (int c = wave; c < cg; c += 4) {
+            const float* p = row(c_lo + c);
+            for (int t = lane; t < T; t += 64) { const double v = p[t]; s += v; q += v * v; }
+        }
+    }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    if (lane == 0) { red[0][wave] = s; red[1][wave] = q; }
+    __syncthreads();
+    const double n = (double)cg * (double)T;
+    const double mean_d = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / n;
+    double var_d = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / n - mean_d * mean_d;
+    var_d = var_d > 0.0 ? var_d : 0.0;
+    const float mean = (float)mean_d;
+    const float rstd = (float)(1.0 / sqrt(var_d + (double)a.eps));
+    for (int c = tid; c < cg; c += 256) {
+        const float gg = a.gamma[c_lo + c] * rstd;
+        float* o = a.aff + 2 * ((size_t)b * a.Ctot + c_lo + c);
+        o[0] = gg;
+        o[1] = a.beta[c_lo + c] - mean * gg;
+    }
+}
+
+// LayerNorm statistics -> {mean, rstd} per (batch, sample).  grid (ceil(T/8), B), block 256 =
+// 8 samples x 32 channel slices; every thread has its C/32 loads in flight at once.
+constexpr int LNS_TT = 8, LNS_CS = 32;
+__global__ __launch_bounds__(256) void ln_stats_kernel(const LnStatArgs a) {
+    __shared__ double red[2][LNS_CS][LNS_TT + 1];
+    const int tl = threadIdx.x & (LNS_TT - 1), cs = threadIdx.x / LNS_TT;
+    const int t = blockIdx.x * LNS_TT + tl, b = blockIdx.y;
+    const bool ok = t < a.T;
+    const int C = a.C;
+    const float* x = a.x + (size_t)b * C * a.T + (ok ? t : a.T - 1);
+    double s = 0.0, q = 0.0;
+#pragma unroll 16
+    for (int c = cs; c < C; c += LNS_CS) { const double v = x[(size_t)c * a.T]; s += v; q += v * v; }
+    red[0][cs][tl] = s;
+    red[1][cs][tl] = q;
+    __syncthreads();
+    if (threadIdx.x < LNS_TT) {
+        double ss = 0.0, qq = 0.0;
+#pragma unroll
+        for (int i = 0; i < LNS_CS; ++i) { ss += red[0][i][tl]; qq += red[1][i][tl]; }
+        const double mean_d = ss / (double)C;
+        double var_d = qq / (double)C - mean_d * mean_d;
+        var_d = var_d > 0.0 ? var_d : 0.0;
+        if (ok) {
+            float* o = a.stat + 2 * ((size_t)b * a.T + t);
+            o[0] = (float)mean_d;
+            o[1] = (float)(1.0 / sqrt(var_d + (double)a.eps));
+        }
+    }
+}
+
+__global__ void interleave2_kernel(const float* x, const float* y, float* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { out[2 * i] = x[i]; out[2 * i + 1] = y[i]; }
+}
+
 }  // namespace
 
 void launch_group_norm(hipStream_t st, const GnArgs& a) {
@@ -127,4 +235,22 @@ void launch_group_norm(hipStream_t st, const GnArgs& a) {
 
 void launch_layer_norm(hipStream_t st, const LnArgs& a) {
     hipLaunchKernelGGL(layer_norm_kernel, dim3(cdiv(a.T, LN_TT), a.B), dim3(256), 0, st, a);
+}
+
+void launch_gn_stats(hipStream_t st, const GnStatArgs& a) {
+    MUGD_CHECK(a.groups > 0 && a.Ctot % a.groups == 0, -2, "group_norm: channels not divisible by groups");
+    int ct = 0;
+    for (int i = 0; i < a.nseg; ++i) ct += a.seg[i].C;
+    MUGD_CHECK(ct == a.Ctot, -2, "group_norm: segment channels do not add up");
+    const long long n4 = (long long)(a.Ctot / a.groups) * (a.T / 4);
+    if (a.T % 4 == 0 && n4 < (1 << 20)) hipLaunchKernelGGL((gn_stats_kernel<true>), dim3(a.groups, a.B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gn_stats_kernel<false>), dim3(a.groups, a.B), dim3(256), 0, st, a);
+}
+
+void launch_ln_stats(hipStream_t st, const LnStatArgs& a) {
+    hipLaunchKernelGGL(ln_stats_kernel, dim3(cdiv(a.T, LNS_TT), a.B), dim3(256), 0, st, a);
+}
+
+void launch_interleave2(hipStream_t st, const float* x, const float* y, float* out, int n) {
+    hipLaunchKernelGGL(interleave2_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, x, y, out, n);
 }

@@ -93,7 +93,9 @@ __global__ __launch_bounds__(256) void s4_conv_kernel(const S4ConvArgs a) {
     const int h = blockIdx.x, b = blockIdx.y, L = a.L;
     const float* u = a.u + ((size_t)b * a.H + h) * L;
     const float* k = a.k + (size_t)h * L;
-    for (int t = threadIdx.x; t < L; t += 256) { ks[t] = k[t]; us[t] = u[t]; }
+    float ag = 1.f, ab = 0.f;
+    if (a.aff) { ag = a.aff[2 * ((size_t)b * a.H + h)]; ab = a.aff[2 * ((size_t)b * a.H + h) + 1]; }
+    for (int t = threadIdx.x; t < L; t += 256) { ks[t] = k[t]; us[t] = u[t] * ag + ab; }
     __syncthreads();
     const float Dh = a.D[h];
     float* y = a.y + ((size_t)b * a.H + h) * L;

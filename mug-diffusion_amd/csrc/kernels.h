@@ -32,6 +32,12 @@ struct ConvSeg {
     int chunk0;       // first global K-chunk of this segment
     int woff;         // float offset of this segment inside one packed 32-row tile block
     int bmod;         // >0: read batch row (b % bmod)  (CFG halves share one copy of the audio maps)
+    // operand transform applied while the window is staged (GroupNorm / LayerNorm are never materialised):
+    int xf;           // 0 none | 1 v = x*g + b with {g,b} per (batch, channel) | 2 v = (x-mean)*rstd*g + b with {mean,rstd} per (batch, sample), {g,b} per channel
+    int act;          // 1: SiLU after the transform
+    const float* xf_a;    // xf=1: {g,b} of this segment's first channel, batch stride xf_stride | xf=2: {mean,rstd} (B, Tin, 2), batch stride xf_stride
+    const float* xf_b;    // xf=2: {gamma,beta} (C, 2)
+    int xf_stride;        // floats per batch row of xf_a
 };
 
 enum { EPI_NONE = 0, EPI_GLU = 1, EPI_GEGLU = 2 };
@@ -47,9 +53,11 @@ struct ConvArgs {
     const float* resid;      // (B, Mout, Tout) or null
     float* y;                // (B, Mout, Tout)
     int B, Mrows, Mout, Tout, nchunk, epi;
+    int wk;                  // K-split (waves per workgroup): 1|2|4|8, 0 = pick from the shape
 };
 
 void launch_conv_gemm(hipStream_t st, const ConvArgs& a);
+int conv_pick_wk(const ConvArgs& a);
 
 // packs rows [row_off, row_off+rows) x channels [0, C) of one K-segment.
 struct PackArgs {
@@ -75,6 +83,19 @@ struct GnArgs {
     float* y;                // (B, Ctot, T) contiguous
 };
 void launch_group_norm(hipStream_t st, const GnArgs& a);
+
+// statistics-only forms: the normalisation is applied by the consumer (ConvSeg::xf, S4ConvArgs::aff)
+struct GnStatArgs {
+    NormSeg seg[CONV_MAXSEG];
+    int nseg, Ctot, T, groups, B;
+    const float* gamma; const float* beta;
+    float eps;
+    float* aff;              // out (B, Ctot, 2): {gamma*rstd, beta - mean*gamma*rstd}
+};
+void launch_gn_stats(hipStream_t st, const GnStatArgs& a);
+struct LnStatArgs { const float* x; float* stat; int B, C, T; float eps; };     // stat (B, T, 2): {mean, rstd}
+void launch_ln_stats(hipStream_t st, const LnStatArgs& a);
+void launch_interleave2(hipStream_t st, const float* x, const float* y, float* out, int n);   // out[i] = {x[i], y[i]}
 
 struct LnArgs {              // LayerNorm over C for every (b, t) of a (B, C, T) tensor
     const float* x; float* y; const float* gamma; const float* beta;
@@ -111,9 +132,10 @@ struct S4GenArgs {
 };
 void launch_s4_kernel_gen(hipStream_t st, const S4GenArgs& a);
 
-struct S4ConvArgs {      // y = gelu( causal_conv(k, u) + D*u ),  u,y: (B,H,L), k: (H,L)
+struct S4ConvArgs {      // y = gelu( causal_conv(k, u') + D*u' ),  u,y: (B,H,L), k: (H,L);  u' = u*g + b per (batch, channel) if aff
     const float* u; const float* k; const float* D; float* y;
     int B, H, L;
+    const float* aff;    // null, or (B, H, 2) {g, b}: the GroupNorm in front of the S4 layer (unet.py:86-88)
 };
 void launch_s4_conv(hipStream_t st, const S4ConvArgs& a);
 

@@ -31,6 +31,7 @@ struct Ctx {
     bool own_stream = false;
     std::string last_error;
     bool use_graph = true;
+    bool fuse_norm = true;      // false (MUGD_UNFUSED_NORM=1): materialise GroupNorm / LayerNorm outputs with the stand-alone kernels (A/B + debugging)
 };
 
 class Arena {
@@ -48,7 +49,9 @@ private:
     bool dry_ = true;
 };
 
-struct ConvIn { Tensor x; int taps = 1, dil = 1, stride = 1, pad = 0, ups = 0; };
+// operand transform of one conv input (ConvSeg::xf): the GroupNorm / LayerNorm in front of the conv
+struct Xf { int kind = 0; int act = 0; const float* a = nullptr; const float* b = nullptr; int stride = 0; };
+struct ConvIn { Tensor x; int taps = 1, dil = 1, stride = 1, pad = 0, ups = 0; Xf xf; };
 struct WBlock { std::string name; int seg; int row_off; int ci_off; };
 struct ConvSpec {
     std::string key;
@@ -98,7 +101,9 @@ protected:
     std::map<std::string, float*> baked;          // S4 kernels and other derived device tensors
     std::vector<void*> owned;
     Arena arena;
-    std::vector<Op> ops;
+    std::vector<Op> ops;                          // the per-call (per DDIM step) program
+    std::vector<Op> pre_ops;                      // work that depends only on the conditioning: once per forward()/sample()
+    bool to_pre = false;                          // emit() target
     bool dry = true;
     int Bn = 0;                                   // batch the program is compiled for
 
@@ -108,13 +113,25 @@ protected:
     float* dev_alloc(size_t nfloats, bool zero = false);
     Tensor talloc(int C, int T) { Tensor t; t.C = C; t.T = T; t.p = arena.alloc((size_t)Bn * C * T); return t; }
     void emit(std::function<void(hipStream_t)> f, int kind = OP_SMALL, double flops = 0, const std::string& label = "") {
-        if (!dry) ops.push_back(Op{std::move(f), kind, flops, label});
+        if (!dry) (to_pre ? pre_ops : ops).push_back(Op{std::move(f), kind, flops, label});
     }
     void run_ops(hipStream_t st) { for (auto& o : ops) o.fn(st); }
+    void run_pre_ops(hipStream_t st) { for (auto& o : pre_ops) o.fn(st); }
 
     // layer emitters
-    Tensor group_norm(const std::string& prefix, const std::vector<Tensor>& segs, int groups, bool silu);
+    // GroupNorm statistics of the virtual concat `segs` -> (B, Ctot, 2) {g, b}; normed() turns the segments
+    // into conv inputs that apply it (and SiLU) while staging
+    const float* gn_stats(const std::string& prefix, const std::vector<Tensor>& segs, int groups);
+    static std::vector<ConvIn> normed(const std::vector<Tensor>& segs, const float* aff, bool silu, int taps, int dil, int pad);
+    // GroupNorm(+SiLU) of the virtual concat as conv inputs: statistics kernel + transformed segments (fused), or one
+    // materialised tensor (unfused).  Callers lay their weight blocks out by walking the returned inputs.
+    std::vector<ConvIn> gn_inputs(const std::string& prefix, const std::vector<Tensor>& segs, int groups, bool silu, int taps, int dil, int pad);
+    Tensor group_norm(const std::string& prefix, const std::vector<Tensor>& segs, int groups, bool silu);   // stand-alone kernel
     Tensor layer_norm(const std::string& prefix, const Tensor& x);
+    // LayerNorm over channels: statistics kernel + the {gamma, beta} table -> transform for a 1x1 conv input
+    Xf layer_norm_xf(const std::string& prefix, const Tensor& x);
+    // LayerNorm as a conv input (fused transform, or the materialised tensor)
+    ConvIn ln_input(const std::string& prefix, const Tensor& x);
     Tensor conv(const ConvSpec& s);
     Tensor conv_simple(const std::string& prefix, const Tensor& x, int taps, int dil, int stride, int pad, int ups,
                        int Tout, const Tensor& resid = Tensor(), const Tensor& out = Tensor());

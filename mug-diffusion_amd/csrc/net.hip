@@ -86,6 +86,7 @@ void Net::invalidate() {
     packed.clear();
     baked.clear();
     ops.clear();
+    pre_ops.clear();
 }
 
 const Param& Net::P(const std::string& n) const {
@@ -131,6 +132,83 @@ Tensor Net::layer_norm(const std::string& prefix, const Tensor& x) {
     LnArgs a{x.p, y.p, PF(prefix + ".weight"), PF(prefix + ".bias"), Bn, x.C, x.T, 1e-5f};
     emit([a](hipStream_t st) { launch_layer_norm(st, a); }, OP_LAYER_NORM, 0, prefix + " C=" + std::to_string(x.C) + " T=" + std::to_string(x.T));
     return y;
+}
+
+std::vector<ConvIn> Net::gn_inputs(const std::string& prefix, const std::vector<Tensor>& segs, int groups, bool silu, int taps, int dil, int pad) {
+    if (ctx->fuse_norm) return normed(segs, gn_stats(prefix, segs, groups), silu, taps, dil, pad);
+    return {ConvIn{group_norm(prefix, segs, groups, silu), taps, dil, 1, pad, 0}};
+}
+
+ConvIn Net::ln_input(const std::string& prefix, const Tensor& x) {
+    if (ctx->fuse_norm) {
+        ConvIn in{x};
+        in.xf = layer_norm_xf(prefix, x);
+        return in;
+    }
+    return ConvIn{layer_norm(prefix, x)};
+}
+
+// weight blocks of one tensor laid over consecutive conv inputs [first, first + n)
+static void span_weights(ConvSpec& s, const std::string& wname, size_t first, size_t n, int row_off = 0) {
+    int ci = 0;
+    for (size_t i = first; i < first + n; ++i) {
+        s.w.push_back(WBlock{wname, (int)i, row_off, ci});
+        ci += s.in[i].x.C;
+    }
+}
+
+const float* Net::gn_stats(const std::string& prefix, const std::vector<Tensor>& segs, int groups) {
+    MUGD_CHECK(!segs.empty() && (int)segs.size() <= CONV_MAXSEG, -2, "group_norm: bad segment count");
+    GnStatArgs a{};
+    a.nseg = (int)segs.size();
+    int C = 0;
+    for (int i = 0; i < a.nseg; ++i) {
+        a.seg[i] = NormSeg{segs[i].p, segs[i].C, segs[i].bmod};
+        C += segs[i].C;
+        MUGD_CHECK(segs[i].T == segs[0].T, -2, "group_norm: segment lengths differ at " + prefix);
+    }
+    MUGD_CHECK(P(prefix + ".weight").numel() == C, -2, "group_norm: weight size mismatch at " + prefix);
+    float* aff = arena.alloc((size_t)Bn * C * 2);
+    a.Ctot = C; a.T = segs[0].T; a.groups = groups; a.B = Bn;
+    a.gamma = PF(prefix + ".weight"); a.beta = PF(prefix + ".bias");
+    a.eps = 1e-6f; a.aff = aff;
+    emit([a](hipStream_t st) { launch_gn_stats(st, a); }, OP_GROUP_NORM, 0,
+         prefix + " C=" + std::to_string(C) + " T=" + std::to_string(a.T));
+    return aff;
+}
+
+std::vector<ConvIn> Net::normed(const std::vector<Tensor>& segs, const float* aff, bool silu, int taps, int dil, int pad) {
+    int Ctot = 0;
+    for (auto& t : segs) Ctot += t.C;
+    std::vector<ConvIn> r;
+    int off = 0;
+    for (auto& t : segs) {
+        ConvIn in{t, taps, dil, 1, pad, 0};
+        in.xf.kind = 1; in.xf.act = silu ? 1 : 0; in.xf.a = aff + 2 * (size_t)off; in.xf.stride = 2 * Ctot;
+        r.push_back(in);
+        off += t.C;
+    }
+    return r;
+}
+
+Xf Net::layer_norm_xf(const std::string& prefix, const Tensor& x) {
+    const std::string key = prefix + "#gb";
+    auto it = baked.find(key);
+    float* gb = nullptr;
+    if (it != baked.end()) {
+        gb = it->second;
+    } else {
+        MUGD_CHECK(P(prefix + ".weight").numel() == x.C, -2, "layer_norm: weight size mismatch at " + prefix);
+        gb = dev_alloc((size_t)x.C * 2);
+        launch_interleave2(ctx->stream, PF(prefix + ".weight"), PF(prefix + ".bias"), gb, x.C);
+        baked[key] = gb;
+    }
+    float* stat = arena.alloc((size_t)Bn * x.T * 2);
+    LnStatArgs a{x.p, stat, Bn, x.C, x.T, 1e-5f};
+    emit([a](hipStream_t st) { launch_ln_stats(st, a); }, OP_LAYER_NORM, 0, prefix + " C=" + std::to_string(x.C) + " T=" + std::to_string(x.T));
+    Xf xf;
+    xf.kind = 2; xf.a = stat; xf.b = gb; xf.stride = 2 * x.T;
+    return xf;
 }
 
 const PackedW& Net::get_packed(const ConvSpec& s) {
@@ -180,7 +258,8 @@ Tensor Net::conv(const ConvSpec& s) {
     a.nseg = (int)s.in.size();
     for (int i = 0; i < a.nseg; ++i) {
         const ConvIn& in = s.in[i];
-        a.seg[i] = ConvSeg{in.x.p, in.x.C, in.x.T, in.taps, in.dil, in.stride, in.pad, in.ups, pw.chunk0[i], pw.woff[i], in.x.bmod};
+        a.seg[i] = ConvSeg{in.x.p, in.x.C, in.x.T, in.taps, in.dil, in.stride, in.pad, in.ups, pw.chunk0[i], pw.woff[i], in.x.bmod,
+                           in.xf.kind, in.xf.act, in.xf.a, in.xf.b, in.xf.stride};
     }
     a.wpk = pw.wpk; a.w_mt_stride = pw.mt_stride; a.bias = pw.bias;
     a.rowadd = s.rowadd; a.rowadd_stride = s.rowadd_stride;
@@ -229,53 +308,74 @@ Tensor Net::attention(const std::string& prefix, const Tensor& q, const Tensor& 
 }
 
 // mug/model/attention.py:154-199 (depth 1).  context == nullptr: attn2 is a second self-attention.
+// GroupNorm and the three LayerNorms are statistics kernels + operand transforms of the convs that
+// consume them; the cross-attention K/V projection of the (step-invariant) context goes to pre_ops.
 Tensor Net::transformer(const std::string& prefix, const Tensor& x, const Tensor* context, int heads) {
     const int C = x.C, T = x.T;
     Tensor out = talloc(C, T);
-    const size_t mk = arena.mark();
-    Tensor g = group_norm(prefix + ".norm", {x}, 32, false);
-    Tensor h0 = conv_simple(prefix + ".proj_in", g, 1, 1, 1, 0, 0, T);
     const std::string b = prefix + ".transformer_blocks.0";
-
-    auto self_attn = [&](const std::string& ap, const Tensor& nx) {
+    Tensor kv;
+    if (context) {                                   // computed once per call: must not share the arena with per-step scratch
+        const std::string kk = b + ".attn2.kv#" + std::to_string(Bn) + "x" + std::to_string(context->T);
+        auto it = baked.find(kk);
+        kv.p = it != baked.end() ? it->second : (baked[kk] = dev_alloc((size_t)Bn * 2 * C * context->T));
+        kv.C = 2 * C; kv.T = context->T;
+        const bool save = to_pre;
+        to_pre = true;
+        ConvSpec s;
+        s.key = b + ".attn2.kv";
+        s.in = {ConvIn{*context}};
+        s.w = {WBlock{b + ".attn2.to_k.weight", 0, 0, 0}, WBlock{b + ".attn2.to_v.weight", 0, C, 0}};
+        s.Mrows = s.Mout = 2 * C; s.Tout = context->T; s.out = kv;
+        conv(s);
+        to_pre = save;
+    }
+    const size_t mk = arena.mark();
+    auto lin = [&](const std::string& key, const ConvIn& in, bool bias, const Tensor& resid, const Tensor& dst) {
+        ConvSpec s;
+        s.key = key;
+        s.in = {in};
+        s.w = {WBlock{key + ".weight", 0, 0, 0}};
+        if (bias) s.bias = {{key + ".bias", 0}};
+        s.Mrows = s.Mout = (int)P(key + ".weight").shape[0];
+        s.Tout = T; s.resid = resid; s.out = dst;
+        return conv(s);
+    };
+    auto self_attn = [&](const std::string& ap, const ConvIn& in) {
         ConvSpec s;
         s.key = ap + ".qkv";
-        s.in.push_back(ConvIn{nx});
+        s.in = {in};
         s.w = {WBlock{ap + ".to_q.weight", 0, 0, 0}, WBlock{ap + ".to_k.weight", 0, C, 0}, WBlock{ap + ".to_v.weight", 0, 2 * C, 0}};
         s.Mrows = s.Mout = 3 * C; s.Tout = T;
         Tensor qkv = conv(s);
         return attention(ap, qkv, qkv, qkv, C, heads, 0, C, 2 * C);
     };
 
-    Tensor n1 = layer_norm(b + ".norm1", h0);
-    Tensor a1 = self_attn(b + ".attn1", n1);
-    Tensor h1 = conv_simple(b + ".attn1.to_out.0", a1, 1, 1, 1, 0, 0, T, h0);
-    Tensor n2 = layer_norm(b + ".norm2", h1);
+    Tensor h0 = lin(prefix + ".proj_in", gn_inputs(prefix + ".norm", {x}, 32, false, 1, 1, 0)[0], true, Tensor(), Tensor());
+    Tensor a1 = self_attn(b + ".attn1", ln_input(b + ".norm1", h0));
+    Tensor h1 = lin(b + ".attn1.to_out.0", ConvIn{a1}, true, h0, Tensor());
+    const ConvIn n2 = ln_input(b + ".norm2", h1);
     Tensor a2;
     if (context) {
-        Tensor q2 = conv_simple(b + ".attn2.to_q", n2, 1, 1, 1, 0, 0, T);
-        ConvSpec s;
-        s.key = b + ".attn2.kv";
-        s.in.push_back(ConvIn{*context});
-        s.w = {WBlock{b + ".attn2.to_k.weight", 0, 0, 0}, WBlock{b + ".attn2.to_v.weight", 0, C, 0}};
-        s.Mrows = s.Mout = 2 * C; s.Tout = context->T;
-        Tensor kv = conv(s);
+        Tensor q2 = lin(b + ".attn2.to_q", n2, false, Tensor(), Tensor());
         a2 = attention(b + ".attn2", q2, kv, kv, C, heads, 0, 0, C);
     } else {
         a2 = self_attn(b + ".attn2", n2);
     }
-    Tensor h2 = conv_simple(b + ".attn2.to_out.0", a2, 1, 1, 1, 0, 0, T, h1);
-    Tensor n3 = layer_norm(b + ".norm3", h2);
-    ConvSpec ff;
-    ff.key = b + ".ff.net.0.proj";
-    ff.in.push_back(ConvIn{n3});
-    ff.w = {WBlock{ff.key + ".weight", 0, 0, 0}};
-    ff.bias = {{ff.key + ".bias", 0}};
-    ff.Mrows = (int)P(ff.key + ".weight").shape[0];
-    ff.Mout = ff.Mrows / 2; ff.Tout = T; ff.epi = EPI_GEGLU;
-    Tensor f = conv(ff);
-    Tensor h3 = conv_simple(b + ".ff.net.2", f, 1, 1, 1, 0, 0, T, h2);
-    conv_simple(prefix + ".proj_out", h3, 1, 1, 1, 0, 0, T, x, out);
+    Tensor h2 = lin(b + ".attn2.to_out.0", ConvIn{a2}, true, h1, Tensor());
+    Tensor f;
+    {
+        ConvSpec ff;
+        ff.key = b + ".ff.net.0.proj";
+        ff.in = {ln_input(b + ".norm3", h2)};
+        ff.w = {WBlock{ff.key + ".weight", 0, 0, 0}};
+        ff.bias = {{ff.key + ".bias", 0}};
+        ff.Mrows = (int)P(ff.key + ".weight").shape[0];
+        ff.Mout = ff.Mrows / 2; ff.Tout = T; ff.epi = EPI_GEGLU;
+        f = conv(ff);
+    }
+    Tensor h3 = lin(b + ".ff.net.2", ConvIn{f}, true, h2, Tensor());
+    lin(prefix + ".proj_out", ConvIn{h3}, true, x, out);
     arena.release(mk);
     return out;
 }
@@ -285,21 +385,32 @@ Tensor Net::resnet_block(const std::string& prefix, const Tensor& x, int Cout, i
     const int T = x.T;
     Tensor out = talloc(Cout, T);
     const size_t mk = arena.mark();
-    Tensor n1 = group_norm(prefix + ".norm1", {x}, groups, true);
-    Tensor h1 = conv_simple(prefix + ".conv1", n1, 3, d0, 1, d0, 0, T);
-    Tensor n2 = group_norm(prefix + ".norm2", {h1}, groups, true);
-    if (has(prefix + ".nin_shortcut.weight")) {
+    Tensor h1;
+    {
         ConvSpec s;
+        s.key = prefix + ".conv1";
+        s.in = gn_inputs(prefix + ".norm1", {x}, groups, true, 3, d0, d0);
+        span_weights(s, s.key + ".weight", 0, s.in.size());
+        s.bias = {{s.key + ".bias", 0}};
+        s.Mrows = s.Mout = Cout; s.Tout = T;
+        h1 = conv(s);
+    }
+    ConvSpec s;
+    s.in = gn_inputs(prefix + ".norm2", {h1}, groups, true, 3, d1, d1);
+    span_weights(s, prefix + ".conv2.weight", 0, s.in.size());
+    s.bias = {{prefix + ".conv2.bias", 0}};
+    s.Mrows = s.Mout = Cout; s.Tout = T; s.out = out;
+    if (has(prefix + ".nin_shortcut.weight")) {
         s.key = prefix + ".conv2+nin";
-        s.in = {ConvIn{n2, 3, d1, 1, d1, 0}, ConvIn{x}};
-        s.w = {WBlock{prefix + ".conv2.weight", 0, 0, 0}, WBlock{prefix + ".nin_shortcut.weight", 1, 0, 0}};
-        s.bias = {{prefix + ".conv2.bias", 0}, {prefix + ".nin_shortcut.bias", 0}};
-        s.Mrows = s.Mout = Cout; s.Tout = T; s.out = out;
-        conv(s);
+        s.in.push_back(ConvIn{x});
+        span_weights(s, prefix + ".nin_shortcut.weight", s.in.size() - 1, 1);
+        s.bias.push_back({prefix + ".nin_shortcut.bias", 0});
     } else {
         MUGD_CHECK(x.C == Cout, -2, "resnet_block without shortcut must keep channels: " + prefix);
-        conv_simple(prefix + ".conv2", n2, 3, d1, 1, d1, 0, T, x, out);
+        s.key = prefix + ".conv2";
+        s.resid = x;
     }
+    conv(s);
     arena.release(mk);
     return out;
 }
@@ -337,10 +448,13 @@ Tensor Net::s4_layer(const std::string& prefix, const Tensor& x) {
     const int H = x.C, L = x.T;
     Tensor out = talloc(H, L);
     const size_t mk = arena.mark();
-    Tensor u = group_norm(prefix + ".norm", {x}, 32, false);
+    const float* aff = nullptr;
+    Tensor u = x;
+    if (ctx->fuse_norm) aff = gn_stats(prefix + ".norm", {x}, 32);
+    else u = group_norm(prefix + ".norm", {x}, 32, false);
     const float* k = s4_kernel(prefix + ".s4_model.kernel.kernel", H, L);
     Tensor y = talloc(H, L);
-    S4ConvArgs ca{u.p, k, PF(prefix + ".s4_model.D"), y.p, Bn, H, L};
+    S4ConvArgs ca{u.p, k, PF(prefix + ".s4_model.D"), y.p, Bn, H, L, aff};
     emit([ca](hipStream_t st) { launch_s4_conv(st, ca); }, OP_S4_CONV, 0, prefix + " H=" + std::to_string(H) + " L=" + std::to_string(L));
     ConvSpec gl;
     gl.key = prefix + ".s4_model.output_linear.0";
@@ -398,39 +512,38 @@ void UNet::prepare_emb() {
     rowadd_total = total;
 }
 
-// mug/diffusion/unet.py:212-239
+// mug/diffusion/unet.py:212-239.  Neither the channel concat [h | audio | skip] nor the two
+// GroupNorm+SiLU outputs are materialised: both convs read the raw tensors as K-segments and
+// normalise them while staging.
 Tensor UNet::resblock(const std::string& prefix, const std::vector<Tensor>& segs, int Cout, int rowadd_off) {
     const int T = segs[0].T;
     Tensor out = talloc(Cout, T);
     const size_t mk = arena.mark();
-    Tensor n1 = group_norm(prefix + ".in_layers.0", segs, 32, true);
     ConvSpec c1;
     c1.key = prefix + ".in_layers.2";
-    c1.in.push_back(ConvIn{n1, 3, 1, 1, 1, 0});
-    c1.w = {WBlock{c1.key + ".weight", 0, 0, 0}};
+    c1.in = gn_inputs(prefix + ".in_layers.0", segs, 32, true, 3, 1, 1);
+    span_weights(c1, c1.key + ".weight", 0, c1.in.size());
     c1.bias = {{c1.key + ".bias", 0}};
     c1.Mrows = c1.Mout = Cout; c1.Tout = T;
     c1.rowadd = emb_rowadd + rowadd_off; c1.rowadd_stride = rowadd_total;
     Tensor h1 = conv(c1);
-    Tensor n2 = group_norm(prefix + ".out_layers.0", {h1}, 32, true);
+    ConvSpec s;
+    s.in = gn_inputs(prefix + ".out_layers.0", {h1}, 32, true, 3, 1, 1);
+    span_weights(s, prefix + ".out_layers.3.weight", 0, s.in.size());
+    s.bias = {{prefix + ".out_layers.3.bias", 0}};
+    s.Mrows = s.Mout = Cout; s.Tout = T; s.out = out;
     if (has(prefix + ".skip_connection.weight")) {
-        ConvSpec s;
         s.key = prefix + ".out_layers.3+skip";
-        s.in.push_back(ConvIn{n2, 3, 1, 1, 1, 0});
-        s.w.push_back(WBlock{prefix + ".out_layers.3.weight", 0, 0, 0});
-        int ci = 0;
-        for (size_t i = 0; i < segs.size(); ++i) {
-            s.in.push_back(ConvIn{segs[i]});
-            s.w.push_back(WBlock{prefix + ".skip_connection.weight", (int)i + 1, 0, ci});
-            ci += segs[i].C;
-        }
-        s.bias = {{prefix + ".out_layers.3.bias", 0}, {prefix + ".skip_connection.bias", 0}};
-        s.Mrows = s.Mout = Cout; s.Tout = T; s.out = out;
-        conv(s);
+        const size_t first = s.in.size();
+        for (auto& t : segs) s.in.push_back(ConvIn{t});
+        span_weights(s, prefix + ".skip_connection.weight", first, segs.size());
+        s.bias.push_back({prefix + ".skip_connection.bias", 0});
     } else {
         MUGD_CHECK(segs.size() == 1 && segs[0].C == Cout, -2, "identity skip needs a single input: " + prefix);
-        conv_simple(prefix + ".out_layers.3", n2, 3, 1, 1, 1, 0, T, segs[0], out);
+        s.key = prefix + ".out_layers.3";
+        s.resid = segs[0];
     }
+    conv(s);
     arena.release(mk);
     return out;
 }
@@ -439,6 +552,7 @@ void UNet::build(bool dry_run) {
     dry = dry_run;
     arena.begin(dry_run);
     ops.clear();
+    pre_ops.clear();
     Bn = key.B;
     const int mc = cfg.model_channels, nl = (int)cfg.channel_mult.size(), z = key.z;
     const bool attn_any = !cfg.attention_resolutions.empty();
@@ -534,8 +648,15 @@ void UNet::build(bool dry_run) {
         }
     }
     MUGD_CHECK(ra == rowadd_total, -2, "internal: emb_layers bookkeeping");
-    Tensor n = group_norm("out.0", {h}, 32, true);
-    conv_simple("out.2", n, 3, 1, 1, 1, 0, z, Tensor(), out_eps);
+    {
+        ConvSpec s;
+        s.key = "out.2";
+        s.in = gn_inputs("out.0", {h}, 32, true, 3, 1, 1);
+        s.w = {WBlock{"out.2.weight", 0, 0, 0}};
+        s.bias = {{"out.2.bias", 0}};
+        s.Mrows = s.Mout = cfg.out_channels; s.Tout = z; s.out = out_eps;
+        conv(s);
+    }
 }
 
 void UNet::invalidate() {
@@ -550,6 +671,7 @@ void UNet::drop_programs() {
     if (graph) { hipGraphExecDestroy(graph); graph = nullptr; }
     built = false;
     ops.clear();
+    pre_ops.clear();
 }
 
 void UNet::ensure(int B, int z, int ntok, int bmod) {
@@ -580,6 +702,7 @@ void UNet::forward(const float* x, const long long* t, const float* context, int
     HIP_CHECK(hipMemcpyAsync(in_ctx.p, context, (size_t)B * in_ctx.C * n_tok * sizeof(float), hipMemcpyDeviceToDevice, st));
     for (int l = 0; l < nl; ++l)
         HIP_CHECK(hipMemcpyAsync(in_audio[l].p, audio[l], (size_t)audio_batch * in_audio[l].C * in_audio[l].T * sizeof(float), hipMemcpyDeviceToDevice, st));
+    run_pre_ops(st);
     run_ops(st);
     HIP_CHECK(hipMemcpyAsync(eps, out_eps.p, (size_t)B * out_eps.C * z * sizeof(float), hipMemcpyDeviceToDevice, st));
 }
@@ -644,6 +767,7 @@ void UNet::sample(float* x, const float* c, const float* uc, int n_tok, const fl
     for (int l = 0; l < nl; ++l)
         HIP_CHECK(hipMemcpyAsync(in_audio[l].p, audio[l], (size_t)audio_batch * in_audio[l].C * in_audio[l].T * sizeof(float), hipMemcpyDeviceToDevice, st));
 
+    run_pre_ops(st);                                      // context-only work (cross-attention K/V): once per call, not per step
     const bool wn = noise != nullptr, wp = pred_x0 != nullptr;
     if (ctx->use_graph) {
         if (graph && (graph_cfg != cfg_on || graph_noise != wn || graph_pred != wp || graph_scale != scale)) {
@@ -675,6 +799,7 @@ void VaeDecoder::build(bool dry_run) {
     dry = dry_run;
     arena.begin(dry_run);
     ops.clear();
+    pre_ops.clear();
     Bn = kB;
     const int nres = (int)cfg.channel_mult.size(), g = cfg.num_groups;
     in_z = talloc(cfg.z_channels, kz);
@@ -690,8 +815,15 @@ void VaeDecoder::build(bool dry_run) {
             h = resnet_block("decoder.up." + std::to_string(lvl) + ".block." + std::to_string(ib), h, block_out, g, 1, 1);
         if (lvl != 0) h = upsample("decoder.up." + std::to_string(lvl) + ".upsample", h);
     }
-    Tensor n = group_norm("decoder.norm_out", {h}, g, true);
-    conv_simple("decoder.conv_out", n, 3, 1, 1, 1, 0, h.T, Tensor(), out_x);
+    {
+        ConvSpec s;
+        s.key = "decoder.conv_out";
+        s.in = gn_inputs("decoder.norm_out", {h}, g, true, 3, 1, 1);
+        s.w = {WBlock{"decoder.conv_out.weight", 0, 0, 0}};
+        s.bias = {{"decoder.conv_out.bias", 0}};
+        s.Mrows = s.Mout = cfg.x_channels; s.Tout = h.T; s.out = out_x;
+        conv(s);
+    }
 }
 
 void VaeDecoder::decode(const float* z_lat, float* logits, int B, int z) {
@@ -716,6 +848,7 @@ void WaveEncoder::build(bool dry_run) {
     dry = dry_run;
     arena.begin(dry_run);
     ops.clear();
+    pre_ops.clear();
     Bn = kB;
     const int nres = (int)cfg.channel_mult.size(), g = cfg.num_groups, mid = cfg.middle_channels;
     in_mel = talloc(cfg.n_freq, kT);

@@ -61,6 +61,7 @@ _SIGS = {
     "mugd_op_group_norm": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i],
     "mugd_op_layer_norm": [_p, _p, _p, _p, _p, _i, _i, _i],
     "mugd_op_conv1d": [_p, _p, _p, _p, _p, _p] + [_i] * 11,
+    "mugd_op_norm_conv1d": [_p, _p, _p, _p, _p, _p, _p] + [_i] * 11,
     "mugd_op_attention": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i],
     "mugd_op_s4_kernel": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i],
     "mugd_op_s4_conv": [_p, _p, _p, _p, _p, _i, _i, _i],
@@ -239,6 +240,18 @@ class Lib:
         y = self.empty(B, M // 2 if epi else M, Tout)
         self.check(self.dll.mugd_op_conv1d(self.ctx, _ptr(x), _ptr(w), _ptr(bias), _ptr(resid), _ptr(y),
                                            B, Cc, Tin, M, taps, dil, stride, pad, int(upsample), Tout, epi))
+        return y
+
+    def op_norm_conv1d(self, x, gamma, beta, w, bias=None, dil=1, pad=0, norm=1, groups=32, silu=False, wk=0):
+        x, gamma, beta, w = self.f32(x), self.f32(gamma), self.f32(beta), self.f32(w)
+        if w.dim() == 2:
+            w = w[:, :, None].contiguous()
+        bias = self.f32(bias) if bias is not None else None
+        B, Cc, T = x.shape
+        M, _, taps = w.shape
+        y = self.empty(B, M, T + 2 * pad - dil * (taps - 1))
+        self.check(self.dll.mugd_op_norm_conv1d(self.ctx, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(w), _ptr(bias), _ptr(y),
+                                                B, Cc, T, M, taps, dil, pad, norm, groups, int(silu), wk))
         return y
 
     def op_attention(self, q, k, v, rel, cemb, heads):

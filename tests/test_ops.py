@@ -71,6 +71,41 @@ def test_conv1d(lib, B, C, T, M, taps, dil, stride, pad, ups):
     close(got, ref + resid, 2e-5, what="conv1d")
 
 
+NORM_CONV_CASES = [
+    # B, C, T, M, taps, dil, norm, groups, silu, wk
+    (2, 64, 48, 64, 3, 1, 1, 32, 1, 0),      # GroupNorm+SiLU -> k3 (ResBlock half), fast window path (T % 4 == 0)
+    (2, 64, 48, 64, 3, 1, 1, 32, 1, 1),      # same, one wave owns all of K
+    (2, 64, 48, 64, 3, 1, 1, 32, 1, 2),
+    (1, 128, 40, 32, 3, 1, 1, 32, 1, 4),     # ragged last tile (40 = 32 + 8)
+    (1, 128, 40, 32, 3, 1, 1, 32, 1, 8),
+    (1, 96, 36, 48, 1, 1, 1, 32, 0, 0),      # GroupNorm -> 1x1 (transformer proj_in)
+    (1, 32, 33, 32, 3, 1, 1, 8, 1, 0),       # T % 4 != 0: generic window path
+    (1, 32, 64, 32, 3, 2, 1, 8, 1, 0),       # dilated (wave encoder / VAE ResnetBlock)
+    (1, 32, 64, 32, 3, 4, 1, 8, 1, 0),
+    (1, 32, 72, 32, 3, 8, 1, 8, 1, 2),
+    (2, 64, 40, 96, 1, 1, 2, 0, 0, 0),       # LayerNorm -> Linear (q/k/v, GEGLU projection)
+    (1, 48, 21, 32, 1, 1, 2, 0, 0, 0),       # LayerNorm, generic path
+    (1, 256, 8, 64, 1, 1, 2, 0, 0, 4),       # LayerNorm, short sequence
+]
+
+
+@pytest.mark.parametrize("B,C,T,M,taps,dil,norm,groups,silu,wk", NORM_CONV_CASES)
+def test_norm_conv1d_fused(lib, B, C, T, M, taps, dil, norm, groups, silu, wk):
+    x = rnd(30, B, C, T, scale=2.0) + 0.3
+    g, b = 1 + 0.1 * rnd(31, C), 0.1 * rnd(32, C)
+    w, bias = rnd(33, M, C, taps, scale=1.0 / math.sqrt(C * taps)), 0.1 * rnd(34, M)
+    if norm == 1:
+        n = F.group_norm(x, groups, g, b, eps=1e-6)
+        if silu:
+            n = F.silu(n)
+    else:
+        n = F.layer_norm(x.transpose(1, 2), (C,), g, b, eps=1e-5).transpose(1, 2)
+    pad = dil * (taps - 1) // 2
+    ref = F.conv1d(n, w, bias, 1, pad, dil)
+    got = lib.op_norm_conv1d(x, g, b, w, bias, dil=dil, pad=pad, norm=norm, groups=groups, silu=bool(silu), wk=wk)
+    close(got, ref, 3e-5, what="norm+conv1d")
+
+
 @pytest.mark.parametrize("epi", [1, 2])
 def test_conv1d_gated(lib, epi):
     B, C, T, M = 2, 32, 40, 128
