@@ -78,6 +78,8 @@ int mugd_create(int device, void* stream, mugd_ctx** out) {
         ctx->c.use_graph = !(g && g[0] == '1');
         const char* u = getenv("MUGD_UNFUSED_NORM");
         ctx->c.fuse_norm = !(u && u[0] == '1');
+        const char* fa = getenv("MUGD_FAST_SILU");
+        ctx->c.fast_act = fa && fa[0] == '1';
     });
     if (rc != MUGD_OK) {
         fprintf(stderr, "mugd_create: %s\n", ctx->c.last_error.c_str());

@@ -56,6 +56,10 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// x * sigmoid(x) on the transcendental units: v_exp_f32 + v_rcp_f32 (~1e-6 relative) instead of expf + IEEE divide
+__device__ __forceinline__ float silu_fast(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));
+}
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 

@@ -164,11 +164,16 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
             for (int i = 0; i < 8; ++i) v[i] = (v[i] - mu[i]) * rs8[i] * g + bt;
 #pragma unroll
             for (int j = 0; j < NH; ++j) vh[j] = (vh[j] - muh[j]) * rsh[j] * g + bt;
-            if (act) {
+            if (act == 1) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = silu_f(v[i]);
 #pragma unroll
                 for (int j = 0; j < NH; ++j) vh[j] = silu_f(vh[j]);
+            } else if (act == 2) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = silu_fast(v[i]);
+#pragma unroll
+                for (int j = 0; j < NH; ++j) vh[j] = silu_fast(vh[j]);
             }
         }
         float4 w0, w1;                                  // zero padding AFTER the transform (component selects: no scratch)
@@ -340,6 +345,40 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
     char* smem_bytes = reinterpret_cast<char*>(smem);
     const int wave_base = wave * WAVE_LDS * 4;
 
+    // ---- epilogue operands: the side loads (bias / row term / residual) are issued HERE, before the K loop, from
+    // clamped addresses under wave-uniform conditions, so their latency is off the kernel's critical path.
+    constexpr int EPT = 16 / WK;         // tile rows (accumulator registers) finished by each wave
+    float bv[EPT], bg[EPT], ra[EPT], rsv[EPT];
+    size_t oo[EPT];
+    int mm[EPT];
+    bool valid[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int r = wave * EPT + q;
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int m = mt * 32 + row, t = t0 + n;
+        valid[q] = (m < a.Mout) && (t < a.Tout);
+        mm[q] = m < a.Mout ? m : a.Mout - 1;
+        oo[q] = ((size_t)b * a.Mout + mm[q]) * a.Tout + (t < a.Tout ? t : a.Tout - 1);
+        bv[q] = 0.f; bg[q] = 0.f; ra[q] = 0.f; rsv[q] = 0.f;
+    }
+    constexpr bool PRELOAD = EPT <= 4;   // wide per-wave epilogues (WK 1, 2) load late instead: registers
+    auto load_side = [&]() {
+        if (a.bias) {
+    #pragma unroll
+            for (int q = 0; q < EPT; ++q) { bv[q] = a.bias[mm[q]]; if (DUAL) bg[q] = a.bias[mm[q] + a.Mout]; }
+        }
+        if (a.rowadd) {
+    #pragma unroll
+            for (int q = 0; q < EPT; ++q) ra[q] = a.rowadd[(size_t)b * a.rowadd_stride + mm[q]];
+        }
+        if (a.resid) {
+    #pragma unroll
+            for (int q = 0; q < EPT; ++q) rsv[q] = a.resid[oo[q]];
+        }
+    };
+    if (PRELOAD) load_side();
+
 #pragma unroll
     for (int si = 0; si < CONV_MAXSEG; ++si) {
         if (si < a.nseg) {
@@ -369,7 +408,6 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
     }
 
     // ---- combine the WK K-slices through LDS (the staging windows are dead after this barrier)
-    constexpr int EPT = 16 / WK;         // tile rows (accumulator registers) finished by each wave
     float acc_v[EPT], acc_g[EPT];
     if (WK > 1) {
         __syncthreads();
@@ -395,34 +433,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
         for (int q = 0; q < EPT; ++q) { acc_v[q] = acc[q]; acc_g[q] = acc2[q]; }
     }
 
-    // ---- epilogue: all side loads (bias / row term / residual) are issued together from clamped
-    // addresses under wave-uniform conditions; only the final store is predicated.
-    float bv[EPT], bg[EPT], ra[EPT], rsv[EPT];
-    size_t oo[EPT];
-    int mm[EPT];
-    bool valid[EPT];
-#pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-        const int r = wave * EPT + q;
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int m = mt * 32 + row, t = t0 + n;
-        valid[q] = (m < a.Mout) && (t < a.Tout);
-        mm[q] = m < a.Mout ? m : a.Mout - 1;
-        oo[q] = ((size_t)b * a.Mout + mm[q]) * a.Tout + (t < a.Tout ? t : a.Tout - 1);
-        bv[q] = 0.f; bg[q] = 0.f; ra[q] = 0.f; rsv[q] = 0.f;
-    }
-    if (a.bias) {
-#pragma unroll
-        for (int q = 0; q < EPT; ++q) { bv[q] = a.bias[mm[q]]; if (DUAL) bg[q] = a.bias[mm[q] + a.Mout]; }
-    }
-    if (a.rowadd) {
-#pragma unroll
-        for (int q = 0; q < EPT; ++q) ra[q] = a.rowadd[(size_t)b * a.rowadd_stride + mm[q]];
-    }
-    if (a.resid) {
-#pragma unroll
-        for (int q = 0; q < EPT; ++q) rsv[q] = a.resid[oo[q]];
-    }
+    if (!PRELOAD) load_side();
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
         float v = acc_v[q] + bv[q];

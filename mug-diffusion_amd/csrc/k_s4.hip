@@ -114,6 +114,57 @@ __global__ __launch_bounds__(256) void s4_conv_kernel(const S4ConvArgs a) {
     }
 }
 
+
+// Fast path for L = 64 R, R in {1,2,4,8} (the U-Net levels at z = 512): one wavefront per (batch, feature)
+// row, lane l owns the R consecutive outputs t = l R .. l R + R-1 and keeps the R inputs u[t - s] it
+// needs in a register window that slides by one sample per tap (one LDS read per tap per lane, k[s]
+// read as broadcast vectors), so the inner loop is R FMAs per ~1.25 LDS reads.  The 4 waves of a
+// workgroup take 4 batch rows of the same feature and share its kernel row.  Causality is a
+// zero-filled prefix of the LDS copy of u (branch-free).
+template <int R>
+__global__ __launch_bounds__(256) void s4_conv_fast_kernel(const S4ConvArgs a) {
+    constexpr int L = 64 * R;
+    __shared__ __attribute__((aligned(16))) float ks[L];
+    __shared__ __attribute__((aligned(16))) float us[4][2 * L];
+    const int h = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int b = blockIdx.y * 4 + wave;
+    const bool live = b < a.B;
+    const int bc = live ? b : a.B - 1;
+    for (int t = threadIdx.x; t < L; t += 256) ks[t] = a.k[(size_t)h * L + t];
+    const float* u = a.u + ((size_t)bc * a.H + h) * L + lane * R;
+    float ag = 1.f, ab = 0.f;
+    if (a.aff) { ag = a.aff[2 * ((size_t)bc * a.H + h)]; ab = a.aff[2 * ((size_t)bc * a.H + h) + 1]; }
+    float w[R], acc[R], u0[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        u0[r] = u[r] * ag + ab;
+        w[r] = u0[r];
+        acc[r] = 0.f;
+        us[wave][L + lane * R + r] = u0[r];
+        us[wave][lane * R + r] = 0.f;
+    }
+    __syncthreads();
+    const float* uw = &us[wave][L + lane * R - 1];          // uw[-s] = u[t0 - s - 1]
+    for (int s = 0; s < L; s += R) {
+        float kv[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) kv[j] = ks[s + j];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] += kv[j] * w[(r - j + R) % R];      // w[(r-j) mod R] holds u[t0 + r - (s+j)]
+            w[(2 * R - 1 - j) % R] = uw[-(s + j)];                                   // u[t0 - (s+j) - 1] for the next tap
+        }
+    }
+    if (live) {
+        const float Dh = a.D[h];
+        float* y = a.y + ((size_t)b * a.H + h) * L + lane * R;
+#pragma unroll
+        for (int r = 0; r < R; ++r) y[r] = gelu_erf_f(acc[r] + Dh * u0[r]);
+    }
+}
+
 }  // namespace
 
 void launch_s4_kernel_gen(hipStream_t st, const S4GenArgs& a) {
@@ -124,5 +175,12 @@ void launch_s4_kernel_gen(hipStream_t st, const S4GenArgs& a) {
 
 void launch_s4_conv(hipStream_t st, const S4ConvArgs& a) {
     MUGD_CHECK(a.L <= S4_LMAX, -2, "s4: sequence longer than 4096");
-    hipLaunchKernelGGL(s4_conv_kernel, dim3(a.H, a.B), dim3(256), 0, st, a);
+    const dim3 gf(a.H, cdiv(a.B, 4));
+    switch (a.L) {
+        case 64: hipLaunchKernelGGL((s4_conv_fast_kernel<1>), gf, dim3(256), 0, st, a); break;
+        case 128: hipLaunchKernelGGL((s4_conv_fast_kernel<2>), gf, dim3(256), 0, st, a); break;
+        case 256: hipLaunchKernelGGL((s4_conv_fast_kernel<4>), gf, dim3(256), 0, st, a); break;
+        case 512: hipLaunchKernelGGL((s4_conv_fast_kernel<8>), gf, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL(s4_conv_kernel, dim3(a.H, a.B), dim3(256), 0, st, a);
+    }
 }

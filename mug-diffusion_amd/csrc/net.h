@@ -31,6 +31,7 @@ struct Ctx {
     bool own_stream = false;
     std::string last_error;
     bool use_graph = true;
+    bool fast_act = false;      // MUGD_FAST_SILU=1: SiLU of the fused GroupNorm path on v_exp_f32 / v_rcp_f32 instead of expf + IEEE divide
     bool fuse_norm = true;      // false (MUGD_UNFUSED_NORM=1): materialise GroupNorm / LayerNorm outputs with the stand-alone kernels (A/B + debugging)
 };
 

@@ -135,7 +135,12 @@ Tensor Net::layer_norm(const std::string& prefix, const Tensor& x) {
 }
 
 std::vector<ConvIn> Net::gn_inputs(const std::string& prefix, const std::vector<Tensor>& segs, int groups, bool silu, int taps, int dil, int pad) {
-    if (ctx->fuse_norm) return normed(segs, gn_stats(prefix, segs, groups), silu, taps, dil, pad);
+    if (ctx->fuse_norm) {
+        std::vector<ConvIn> r = normed(segs, gn_stats(prefix, segs, groups), silu, taps, dil, pad);
+        if (ctx->fast_act)
+            for (auto& in : r) if (in.xf.act == 1) in.xf.act = 2;
+        return r;
+    }
     return {ConvIn{group_norm(prefix, segs, groups, silu), taps, dil, 1, pad, 0}};
 }
 

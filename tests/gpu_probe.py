@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--skip-wave", action="store_true")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--quick", action="store_true", help="U-Net forward + per-kernel-class profile + graph DDIM loop only")
+    ap.add_argument("--streams", type=int, default=0, help="experiment: split the batch over N concurrent streams (N contexts)")
     a = ap.parse_args()
     case = cases.FULL
     z, B, S = a.z, a.B, a.S
@@ -66,13 +68,35 @@ def main():
     steps = sampler.ddim_step_scalars(sd["alphas_cumprod"].numpy(), S, 0.0)
     ts_ = [s["t"] for s in steps]
     sched = [[s["a_t"], s["a_prev"], s["sigma"], s["sqrt_1m_at"]] for s in steps]
-    for graph in (True, False):
+    if a.streams > 1:
+        from mug._native import Lib
+        n = a.streams
+        assert B % n == 0
+        ctxs = []
+        for i in range(n):
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                li = Lib()
+                ui = li.unet(case["unet"]); ui.set_params(sd, "model.unet_model.")
+            ctxs.append((st, li, ui))
+        bs = B // n
+
+        def run_all():
+            for i, (st, li, ui) in enumerate(ctxs):
+                with torch.cuda.stream(st):
+                    ui.ddim_sample(x[i * bs:(i + 1) * bs], c[i * bs:(i + 1) * bs], w, ts_, sched)
+        mn, md = timed(run_all, reps=3)
+        res["ddim_streams%d_ms" % n] = md * 1e3
+        print("ddim %d streams x B=%d: %.2f ms total, %.3f ms/step, %.0f sample-steps/s" % (n, bs, md * 1e3, md * 1e3 / len(ts_), B * len(ts_) / md), flush=True)
+    for graph in ((True,) if a.quick else (True, False)):
         lib.set_graph_mode(graph)
         mn, md = timed(lambda: unet.ddim_sample(x, c, w, ts_, sched), reps=3)
         key = "ddim_graph" if graph else "ddim_eager"
         res[key + "_ms"] = md * 1e3
         print("%s S=%d B=%d: %.2f ms total, %.3f ms/step, %.0f sample-steps/s" % (key, len(ts_), B, md * 1e3, md * 1e3 / len(ts_), B * len(ts_) / md), flush=True)
     lib.set_graph_mode(True)
+    if a.quick:
+        return
     uc = cases.context(case, 2, B).to(dev)
     mn, md = timed(lambda: unet.ddim_sample(x, c, w, ts_, sched, uc=uc, scale=5.0), reps=2)
     res["ddim_cfg_ms"] = md * 1e3

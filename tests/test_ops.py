@@ -78,6 +78,7 @@ NORM_CONV_CASES = [
     (2, 64, 48, 64, 3, 1, 1, 32, 1, 2),
     (1, 128, 40, 32, 3, 1, 1, 32, 1, 4),     # ragged last tile (40 = 32 + 8)
     (1, 128, 40, 32, 3, 1, 1, 32, 1, 8),
+    (2, 64, 48, 64, 3, 1, 1, 32, 2, 4),      # silu = 2: SiLU on v_exp_f32 / v_rcp_f32
     (1, 96, 36, 48, 1, 1, 1, 32, 0, 0),      # GroupNorm -> 1x1 (transformer proj_in)
     (1, 32, 33, 32, 3, 1, 1, 8, 1, 0),       # T % 4 != 0: generic window path
     (1, 32, 64, 32, 3, 2, 1, 8, 1, 0),       # dilated (wave encoder / VAE ResnetBlock)
@@ -102,7 +103,7 @@ def test_norm_conv1d_fused(lib, B, C, T, M, taps, dil, norm, groups, silu, wk):
         n = F.layer_norm(x.transpose(1, 2), (C,), g, b, eps=1e-5).transpose(1, 2)
     pad = dil * (taps - 1) // 2
     ref = F.conv1d(n, w, bias, 1, pad, dil)
-    got = lib.op_norm_conv1d(x, g, b, w, bias, dil=dil, pad=pad, norm=norm, groups=groups, silu=bool(silu), wk=wk)
+    got = lib.op_norm_conv1d(x, g, b, w, bias, dil=dil, pad=pad, norm=norm, groups=groups, silu=silu, wk=wk)
     close(got, ref, 3e-5, what="norm+conv1d")
 
 
@@ -164,7 +165,7 @@ def test_s4_kernel(lib, H, Lint, L):
     close(got, ref, 3e-5, what="s4 kernel vs reference arithmetic")
 
 
-@pytest.mark.parametrize("B,H,L", [(2, 32, 40), (1, 48, 300)])
+@pytest.mark.parametrize("B,H,L", [(2, 32, 40), (1, 48, 300), (5, 8, 64), (2, 8, 128), (3, 4, 256), (1, 4, 512)])
 def test_s4_conv(lib, B, H, L):
     u, k, D = rnd(20, B, H, L), rnd(21, H, L, scale=0.2), rnd(22, H)
     ref = F.gelu(s4o.s4_direct_conv(k, u, D).float())
