@@ -50,6 +50,10 @@ const char* mugd_last_error(mugd_ctx* ctx);
 int mugd_synchronize(mugd_ctx* ctx);
 /* 1 (default): replay each DDIM step from a captured hipGraph; 0: launch kernels eagerly. */
 int mugd_set_graph_mode(mugd_ctx* ctx, int enabled);
+/* Tuning / test knob: force the conv_gemm decomposition for networks COMPILED and operators run after the call
+ * (wk: waves splitting K per workgroup, 1|2|4|8; tn: output tile width 16|32; 0 = pick per layer).  Call
+ * mugd_net_invalidate on existing networks to recompile them. */
+int mugd_set_conv_tiling(mugd_ctx* ctx, int wk, int tn);
 const char* mugd_version(void);
 
 /* ---- networks ------------------------------------------------------------------------- */

@@ -109,6 +109,16 @@ int mugd_set_graph_mode(mugd_ctx* ctx, int enabled) {
     return MUGD_OK;
 }
 
+int mugd_set_conv_tiling(mugd_ctx* ctx, int wk, int tn) {
+    if (!ctx) return MUGD_ERR_INVALID;
+    return guarded(ctx, [&] {
+        MUGD_CHECK(wk == 0 || wk == 1 || wk == 2 || wk == 4 || wk == 8, MUGD_ERR_INVALID, "wk must be 0, 1, 2, 4 or 8");
+        MUGD_CHECK(tn == 0 || tn == 16 || tn == 32, MUGD_ERR_INVALID, "tn must be 0, 16 or 32");
+        ctx->c.force_wk = wk;
+        ctx->c.force_tn = tn;
+    });
+}
+
 int mugd_unet_create(mugd_ctx* ctx, const mugd_unet_config* c, mugd_net** out) {
     return guarded(ctx, [&] {
         MUGD_CHECK(c && out, MUGD_ERR_INVALID, "null argument");
@@ -264,14 +274,16 @@ int mugd_op_conv1d(mugd_ctx* ctx, const float* x, const float* w, const float* b
         const int MT = cdiv(M, 32);
         const long long mts = (long long)(C / CONV_CK) * taps * 512;
         float* wpk = sc.get((size_t)MT * mts, true, st);
-        PackArgs pa{wpk, mts, 0, C, taps, w, C * taps, 0, M, 0};
-        launch_pack_weights(st, pa);
         ConvArgs a{};
         a.nseg = 1;
         a.seg[0] = ConvSeg{x, C, Tin, taps, dil, stride, pad, upsample, 0, 0, 0};
         a.wpk = wpk; a.w_mt_stride = mts; a.bias = bias; a.resid = resid; a.y = y;
         a.B = B; a.Mrows = M; a.Mout = epi ? M / 2 : M; a.Tout = Tout; a.nchunk = C / CONV_CK; a.epi = epi;
-        launch_conv_gemm(st, a);
+        a.wk = ctx->c.force_wk;
+        a.tn = ctx->c.force_tn == 16 ? (conv16_supported(a) ? 16 : 32) : ctx->c.force_tn == 32 ? 32 : conv_pick_tn(a);
+        PackArgs pa{wpk, mts, 0, C, taps, w, C * taps, 0, M, 0};
+        if (a.tn == 16) launch_pack_weights16(st, pa); else launch_pack_weights(st, pa);
+        launch_conv(st, a);
         HIP_CHECK(hipStreamSynchronize(st));
     });
 }
@@ -286,8 +298,6 @@ int mugd_op_norm_conv1d(mugd_ctx* ctx, const float* x, const float* gamma, const
         const int MT = cdiv(M, 32);
         const long long mts = (long long)(C / CONV_CK) * taps * 512;
         float* wpk = sc.get((size_t)MT * mts, true, st);
-        PackArgs pa{wpk, mts, 0, C, taps, w, C * taps, 0, M, 0};
-        launch_pack_weights(st, pa);
         ConvArgs a{};
         a.nseg = 1;
         a.seg[0] = ConvSeg{x, C, T, taps, dil, 1, pad, 0, 0, 0, 0};
@@ -307,8 +317,12 @@ int mugd_op_norm_conv1d(mugd_ctx* ctx, const float* x, const float* gamma, const
             a.seg[0].xf = 2; a.seg[0].act = silu; a.seg[0].xf_a = stat; a.seg[0].xf_b = gb; a.seg[0].xf_stride = 2 * T;
         }
         a.wpk = wpk; a.w_mt_stride = mts; a.bias = bias; a.y = y;
-        a.B = B; a.Mrows = M; a.Mout = M; a.Tout = T + 2 * pad - dil * (taps - 1); a.nchunk = C / CONV_CK; a.epi = EPI_NONE; a.wk = wk;
-        launch_conv_gemm(st, a);
+        a.B = B; a.Mrows = M; a.Mout = M; a.Tout = T + 2 * pad - dil * (taps - 1); a.nchunk = C / CONV_CK; a.epi = EPI_NONE;
+        a.wk = wk ? wk : ctx->c.force_wk;
+        a.tn = ctx->c.force_tn == 16 ? (conv16_supported(a) ? 16 : 32) : ctx->c.force_tn == 32 ? 32 : conv_pick_tn(a);
+        PackArgs pa{wpk, mts, 0, C, taps, w, C * taps, 0, M, 0};
+        if (a.tn == 16) launch_pack_weights16(st, pa); else launch_pack_weights(st, pa);
+        launch_conv(st, a);
         HIP_CHECK(hipStreamSynchronize(st));
     });
 }

@@ -50,8 +50,8 @@ __device__ __forceinline__ void load_a(const float* wp, const float* wp2, float4
     }
 }
 
-template <int TAPS, bool DUAL, int NA, int NA2>
-__device__ __forceinline__ void mfma_chunk(const char* smem_bytes, int rb0, int dil, const float4 (&A)[NA], const float4 (&A2)[NA2],
+template <int TAPS, bool DUAL>
+__device__ __forceinline__ void mfma_chunk(const char* smem_bytes, int rb0, int dil, const float4 (&A)[6], const float4 (&A2)[6],
                                            f32x16& acc, f32x16& acc2) {
     float bf[TAPS * 8];
 #pragma unroll
@@ -82,7 +82,7 @@ __device__ __forceinline__ void mfma_chunk(const char* smem_bytes, int rb0, int 
 // ---------------------------------------------------------------------------------------
 // Fast path: stride 1, no upsample, Tin % 4 == 0 (rows are 16-byte aligned).  NH = halo loads per lane.
 // ---------------------------------------------------------------------------------------
-template <int TAPS, bool DUAL, int NH, int RING>
+template <int TAPS, bool DUAL, int NH>
 __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* wseg, const float* wseg2, int lo, int hi,
                                                 int b, int t0, int lane, int h, int n, char* smem_bytes, int wave_base,
                                                 f32x16& acc, f32x16& acc2) {
@@ -141,82 +141,70 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
     const float* wp2 = wseg2 + (size_t)lo * (TAPS * 512);
     const int rb0 = wave_base + (4 * h * RS + HL - s.pad + n) * 4;      // this lane's B-fragment read base (bytes)
 
-    // ---- RING-deep register pipeline.  Slot u holds the operands of chunk (c + u); a slot is refilled with chunk
-    // (c + u + RING) as soon as its registers are free (activations: right after the LDS park; weights: right after
-    // the MFMAs that read them), so RING-1 chunks of matrix work cover the latency of every load.  The weight stream
-    // of a layer is read once per step from HBM (0.4 GB of fp32 weights do not stay on die), activations come from
-    // the previous kernel through the memory-side cache: one chunk of cover is not enough for either.
-    float4 A[RING][TAPS * 2], A2[RING][DUAL ? TAPS * 2 : 1];
-    float4 X0[RING], X1[RING];
-    float XH[RING][NH > 0 ? NH : 1];
-    float2 GB[RING];
-    const int nch = hi - lo;
-    auto issue_a = [&](int u, int cr) {
-        const float* w1 = wp + (size_t)cr * (TAPS * 512);
-        const float* w2 = wp2 + (size_t)cr * (TAPS * 512);
+    float4 Aa[6], Aa2[6], Ab[6], Ab2[6];       // ping-pong weight fragments: no register copies in the loop
+    float4 x0, x1;
+    float xh[NH > 0 ? NH : 1];
+    float2 gbv = make_float2(1.f, 0.f);
+    load_a<TAPS, DUAL>(wp, wp2, Aa, Aa2);
+    x0 = *reinterpret_cast<const float4*>(xb + g0);
+    x1 = *reinterpret_cast<const float4*>(xb + g1);
 #pragma unroll
-        for (int i = 0; i < TAPS * 2; ++i) {
-            A[u][i] = *reinterpret_cast<const float4*>(w1 + i * 256);
-            if (DUAL) A2[u][i] = *reinterpret_cast<const float4*>(w2 + i * 256);
-        }
-    };
-    auto issue_x = [&](int u, int cr) {
-        const char* xq = xb + (size_t)cr * xstep;
-        X0[u] = *reinterpret_cast<const float4*>(xq + g0);
-        X1[u] = *reinterpret_cast<const float4*>(xq + g1);
-#pragma unroll
-        for (int j = 0; j < NH; ++j) XH[u][j] = *reinterpret_cast<const float*>(xq + gh[j]);
-        GB[u] = make_float2(1.f, 0.f);
-        if (xf) GB[u] = *reinterpret_cast<const float2*>(gb + (size_t)cr * (2 * CONV_CK));
-    };
-#pragma unroll
-    for (int u = 0; u < RING; ++u)
-        if (u < nch) { issue_a(u, u); issue_x(u, u); }
+    for (int j = 0; j < NH; ++j) xh[j] = *reinterpret_cast<const float*>(xb + gh[j]);
+    if (xf) gbv = *reinterpret_cast<const float2*>(gb);
 
-    for (int c = 0; c < nch; c += RING) {
+    auto step = [&](const float4 (&A)[6], const float4 (&A2)[6], float4 (&An)[6], float4 (&An2)[6], bool more) {
+        float v[8];
+        float vh[NH > 0 ? NH : 1];
+        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
 #pragma unroll
-        for (int u = 0; u < RING; ++u) {
-            const int cc = c + u;
-            if (cc < nch) {
-                float v[8];
-                float vh[NH > 0 ? NH : 1];
-                v[0] = X0[u].x; v[1] = X0[u].y; v[2] = X0[u].z; v[3] = X0[u].w;
-                v[4] = X1[u].x; v[5] = X1[u].y; v[6] = X1[u].z; v[7] = X1[u].w;
+        for (int j = 0; j < NH; ++j) vh[j] = xh[j];
+        if (xf) {
+            const float g = gbv.x, bt = gbv.y;
 #pragma unroll
-                for (int j = 0; j < NH; ++j) vh[j] = XH[u][j];
-                if (xf) {
-                    const float g = GB[u].x, bt = GB[u].y;
+            for (int i = 0; i < 8; ++i) v[i] = (v[i] - mu[i]) * rs8[i] * g + bt;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = (v[i] - mu[i]) * rs8[i] * g + bt;
+            for (int j = 0; j < NH; ++j) vh[j] = (vh[j] - muh[j]) * rsh[j] * g + bt;
+            if (act == 1) {
 #pragma unroll
-                    for (int j = 0; j < NH; ++j) vh[j] = (vh[j] - muh[j]) * rsh[j] * g + bt;
-                    if (act == 1) {
+                for (int i = 0; i < 8; ++i) v[i] = silu_f(v[i]);
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) v[i] = silu_f(v[i]);
+                for (int j = 0; j < NH; ++j) vh[j] = silu_f(vh[j]);
+            } else if (act == 2) {
 #pragma unroll
-                        for (int j = 0; j < NH; ++j) vh[j] = silu_f(vh[j]);
-                    } else if (act == 2) {
+                for (int i = 0; i < 8; ++i) v[i] = silu_fast(v[i]);
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) v[i] = silu_fast(v[i]);
-#pragma unroll
-                        for (int j = 0; j < NH; ++j) vh[j] = silu_fast(vh[j]);
-                    }
-                }
-                float4 w0, w1;                          // zero padding AFTER the transform (component selects: no scratch)
-                w0.x = ok0 ? v[0] : 0.f; w0.y = ok0 ? v[1] : 0.f; w0.z = ok0 ? v[2] : 0.f; w0.w = ok0 ? v[3] : 0.f;
-                w1.x = ok1 ? v[4] : 0.f; w1.y = ok1 ? v[5] : 0.f; w1.z = ok1 ? v[6] : 0.f; w1.w = ok1 ? v[7] : 0.f;
-                *reinterpret_cast<float4*>(smem_bytes + l0) = w0;
-                *reinterpret_cast<float4*>(smem_bytes + l0 + 16) = w1;
-#pragma unroll
-                for (int j = 0; j < NH; ++j) *reinterpret_cast<float*>(smem_bytes + lh[j]) = okh[j] ? vh[j] : 0.f;
-                wave_sync();
-                const bool more = cc + RING < nch;
-                if (more) issue_x(u, cc + RING);
-                mfma_chunk<TAPS, DUAL, TAPS * 2, (DUAL ? TAPS * 2 : 1)>(smem_bytes, rb0, s.dil, A[u], A2[u], acc, acc2);
-                if (more) issue_a(u, cc + RING);
-                wave_sync();               // all lanes done reading the window before it is overwritten
+                for (int j = 0; j < NH; ++j) vh[j] = silu_fast(vh[j]);
             }
         }
+        float4 w0, w1;                                  // zero padding AFTER the transform (component selects: no scratch)
+        w0.x = ok0 ? v[0] : 0.f; w0.y = ok0 ? v[1] : 0.f; w0.z = ok0 ? v[2] : 0.f; w0.w = ok0 ? v[3] : 0.f;
+        w1.x = ok1 ? v[4] : 0.f; w1.y = ok1 ? v[5] : 0.f; w1.z = ok1 ? v[6] : 0.f; w1.w = ok1 ? v[7] : 0.f;
+        *reinterpret_cast<float4*>(smem_bytes + l0) = w0;
+        *reinterpret_cast<float4*>(smem_bytes + l0 + 16) = w1;
+#pragma unroll
+        for (int j = 0; j < NH; ++j) *reinterpret_cast<float*>(smem_bytes + lh[j]) = okh[j] ? vh[j] : 0.f;
+        wave_sync();
+        if (more) {
+            wp += TAPS * 512;
+            wp2 += TAPS * 512;
+            xb += xstep;
+            load_a<TAPS, DUAL>(wp, wp2, An, An2);
+            x0 = *reinterpret_cast<const float4*>(xb + g0);
+            x1 = *reinterpret_cast<const float4*>(xb + g1);
+#pragma unroll
+            for (int j = 0; j < NH; ++j) xh[j] = *reinterpret_cast<const float*>(xb + gh[j]);
+            if (xf) { gb += 2 * CONV_CK; gbv = *reinterpret_cast<const float2*>(gb); }
+        }
+        mfma_chunk<TAPS, DUAL>(smem_bytes, rb0, s.dil, A, A2, acc, acc2);
+        wave_sync();               // all lanes done reading the window before it is overwritten
+    };
+
+    int c = lo;
+    for (;;) {
+        step(Aa, Aa2, Ab, Ab2, c + 1 < hi);
+        if (++c >= hi) break;
+        step(Ab, Ab2, Aa, Aa2, c + 1 < hi);
+        if (++c >= hi) break;
     }
 }
 
@@ -306,7 +294,7 @@ __device__ __forceinline__ void run_segment_gen(const ConvSeg& s, const float* w
                 for (int k = 0; k < NIT; ++k) gbr[k] = *reinterpret_cast<const float2*>(gb + 2 * rowk[k]);
             }
         }
-        mfma_chunk<TAPS, DUAL, 6, 6>(smem_bytes, rb0, s.dil, A, A2, acc, acc2);
+        mfma_chunk<TAPS, DUAL>(smem_bytes, rb0, s.dil, A, A2, acc, acc2);
         wave_sync();
     };
 
@@ -402,16 +390,14 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
                 const float* w1 = wtile + s.woff;
                 const float* w2 = wtile2 + s.woff;
 #define MUGD_SEG_ARGS s, w1, w2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, acc, acc2
-                if (DUAL) {                                       // gated epilogues only follow 1x1 convs (host-checked)
-                    run_segment_vec<1, DUAL, 0, 4>(MUGD_SEG_ARGS);
-                } else if (LEAN) {
-                    if (s.taps == 3) run_segment_vec<3, DUAL, 1, 3>(MUGD_SEG_ARGS);
-                    else run_segment_vec<1, DUAL, 0, 4>(MUGD_SEG_ARGS);
+                if (LEAN) {
+                    if (s.taps == 3) run_segment_vec<3, DUAL, 1>(MUGD_SEG_ARGS);
+                    else run_segment_vec<1, DUAL, 0>(MUGD_SEG_ARGS);
                 } else if (seg_is_vec(s)) {
-                    if (s.taps == 1) run_segment_vec<1, DUAL, 0, 4>(MUGD_SEG_ARGS);
-                    else if (s.dil <= 2) run_segment_vec<3, DUAL, 1, 3>(MUGD_SEG_ARGS);
-                    else if (s.dil == 4) run_segment_vec<3, DUAL, 2, 2>(MUGD_SEG_ARGS);
-                    else run_segment_vec<3, DUAL, 4, 2>(MUGD_SEG_ARGS);
+                    if (s.taps == 1) run_segment_vec<1, DUAL, 0>(MUGD_SEG_ARGS);
+                    else if (s.dil <= 2) run_segment_vec<3, DUAL, 1>(MUGD_SEG_ARGS);
+                    else if (s.dil == 4) run_segment_vec<3, DUAL, 2>(MUGD_SEG_ARGS);
+                    else run_segment_vec<3, DUAL, 4>(MUGD_SEG_ARGS);
                 } else {
                     if (s.taps == 3) run_segment_gen<3, DUAL, NITG, (NITG <= 9)>(MUGD_SEG_ARGS);
                     else run_segment_gen<1, DUAL, NITG, (NITG <= 9)>(MUGD_SEG_ARGS);
@@ -531,9 +517,7 @@ void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
     const bool dual = a.epi != EPI_NONE;
     if (dual) {
         MUGD_CHECK(a.Mout % 32 == 0 && a.Mrows == 2 * a.Mout, -2, "conv_gemm: gated epilogue needs Mout % 32 == 0");
-        for (int i = 0; i < a.nseg; ++i)
-            MUGD_CHECK(a.seg[i].taps == 1 && a.seg[i].stride == 1 && !a.seg[i].ups && (a.seg[i].Tin & 3) == 0, -2,
-                       "conv_gemm: gated epilogue is implemented for 1x1 convs with T % 4 == 0");
+        for (int i = 0; i < a.nseg; ++i) MUGD_CHECK(a.seg[i].taps == 1, -2, "conv_gemm: gated epilogue is implemented for 1x1 convs");
     }
     else MUGD_CHECK(a.Mrows == a.Mout, -2, "conv_gemm: Mrows != Mout");
     const int gx = cdiv(a.Tout, CONV_TN), gy = cdiv(a.Mout, 32), gz = a.B;

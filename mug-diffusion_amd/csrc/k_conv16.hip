@@ -1,0 +1,367 @@
+// conv_gemm16: the conv_gemm operation (k_conv.hip) on 32(rows) x 16(samples) output tiles with
+// v_mfma_f32_16x16x4_f32, for the layers whose 32x32 tiling gives fewer workgroups than the chip
+// has CUs.  At the U-Net's deep levels the GEMMs are 512 x (B*64) and 384 x (B*128): with batch 4
+// that is 128 / 192 tiles of 32x32 -- half of the 256 CUs would idle whatever the K-split, because
+// a workgroup lives on one CU.  Halving the tile width doubles the workgroup count at the same MFMA
+// rate (two 16x16x4 MFMAs = one 32x32x2: 64 cycles for the same 32 x 16 x 4 MACs... per 4 channels),
+// for twice the weight traffic per FLOP out of L2 (each weight tile now serves 16 columns).
+//
+// Per wave: two accumulators (rows 0..15, 16..31 of the tile) share every B fragment.
+//   A (weights)     : packed per (tap, row half) as [lane = kq*16 + r][kg] = W[16 half + r][4 kg + kq]:
+//                     one dwordx4 per lane feeds the 4 channel groups kg of one (tap, half).
+//   B (activations) : window [16 ch][HL + 16 + halo] in LDS, row stride 48 floats (conflict-free for the
+//                     16-lane x 4-row fragment reads); lane (row = lane/4, quarter = lane%4) stages one
+//                     aligned float4 + halo.  Same fused GroupNorm / LayerNorm / SiLU operand transform.
+// Only the fast window path exists here (stride 1, T % 4 == 0, taps 1|3 with dilation 1): the host
+// falls back to the 32-wide kernel otherwise.
+#include <algorithm>
+#include <cstdlib>
+
+#include "kernels.h"
+
+namespace {
+
+constexpr int RS = 48;                          // LDS row stride (floats); 48 mod 32 = 16
+constexpr int WAVE_LDS = CONV_CK * RS;          // floats per wave window
+constexpr int HL = 8;                           // window column of sample t0
+
+template <int TAPS, bool DUAL>
+__device__ __forceinline__ void load_a16(const float* wp, const float* wp2, float4 (&A)[6], float4 (&A2)[6]) {
+#pragma unroll
+    for (int i = 0; i < TAPS * 2; ++i) {
+        A[i] = *reinterpret_cast<const float4*>(wp + i * 256);
+        if (DUAL) A2[i] = *reinterpret_cast<const float4*>(wp2 + i * 256);
+    }
+}
+
+template <int TAPS, bool DUAL>
+__device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wseg, const float* wseg2, int lo, int hi,
+                                              int b, int t0, int lane, char* smem_bytes, int wave_base,
+                                              f32x4 (&acc)[2], f32x4 (&accg)[2]) {
+    constexpr int NH = TAPS == 3 ? 1 : 0;                  // dilation 1: 2 halo samples per row, one load for lanes q < 2
+    const int r = lane >> 2, q = lane & 3;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int Tin = s.Tin;
+    const int hw = TAPS - 1;
+    const int ti = t0 + 4 * q;
+    const bool ok0 = ti < Tin;
+    const unsigned g0 = (unsigned)(r * Tin + (ok0 ? ti : Tin - 4)) * 4u;
+    const int l0 = wave_base + (r * RS + HL + 4 * q) * 4;
+    unsigned gh = 0;
+    int lh = 0;
+    bool okh = false;
+    if (NH) {
+        const int e = q;
+        const int col = e < s.pad ? e - s.pad : 16 + (e - s.pad);
+        const int t = t0 + col;
+        okh = (e < hw) && (t >= 0) && (t < Tin);
+        int tc = t < 0 ? 0 : t;
+        tc = tc < Tin ? tc : Tin - 1;
+        gh = (unsigned)(r * Tin + tc) * 4u;
+        lh = wave_base + (r * RS + (e < hw ? HL + col : 40 + q)) * 4;      // dead lanes park in columns no tap reads
+    }
+    const int xf = s.xf, act = s.act;
+    float mu[4], rs4[4], muh = 0.f, rsh = 1.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { mu[i] = 0.f; rs4[i] = 1.f; }
+    const float* gb = nullptr;
+    if (xf == 1) {
+        gb = s.xf_a + (size_t)b * s.xf_stride + 2 * ((size_t)lo * CONV_CK + r);
+    } else if (xf == 2) {
+        gb = s.xf_b + 2 * ((size_t)lo * CONV_CK + r);
+        const float* cs = s.xf_a + (size_t)b * s.xf_stride;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int t = ti + i;
+            t = t < Tin ? t : Tin - 1;
+            mu[i] = cs[2 * t]; rs4[i] = cs[2 * t + 1];
+        }
+        if (NH) { const unsigned tc = gh / 4u % (unsigned)Tin; muh = cs[2 * tc]; rsh = cs[2 * tc + 1]; }
+    }
+    const int bb = s.bmod > 0 ? b % s.bmod : b;
+    const char* xb = reinterpret_cast<const char*>(s.x + ((size_t)bb * s.C + (size_t)lo * CONV_CK) * Tin);
+    const size_t xstep = (size_t)CONV_CK * Tin * 4;
+    const float* wp = wseg + (size_t)lo * (TAPS * 512);
+    const float* wp2 = wseg2 + (size_t)lo * (TAPS * 512);
+    const int rb0 = wave_base + (kq * RS + HL - s.pad + l15) * 4;       // B fragment: row 4 kg + kq, column l15 (+ tap)
+
+    float4 Aa[6], Aa2[6], Ab[6], Ab2[6];
+    float4 x0;
+    float xh = 0.f;
+    float2 gbv = make_float2(1.f, 0.f);
+    load_a16<TAPS, DUAL>(wp, wp2, Aa, Aa2);
+    x0 = *reinterpret_cast<const float4*>(xb + g0);
+    if (NH) xh = *reinterpret_cast<const float*>(xb + gh);
+    if (xf) gbv = *reinterpret_cast<const float2*>(gb);
+
+    auto step = [&](const float4 (&A)[6], const float4 (&A2)[6], float4 (&An)[6], float4 (&An2)[6], bool more) {
+        float v[4], vh = xh;
+        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w;
+        if (xf) {
+            const float g = gbv.x, bt = gbv.y;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = (v[i] - mu[i]) * rs4[i] * g + bt;
+            vh = (vh - muh) * rsh * g + bt;
+            if (act == 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = silu_f(v[i]);
+                vh = silu_f(vh);
+            } else if (act == 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = silu_fast(v[i]);
+                vh = silu_fast(vh);
+            }
+        }
+        float4 w0;
+        w0.x = ok0 ? v[0] : 0.f; w0.y = ok0 ? v[1] : 0.f; w0.z = ok0 ? v[2] : 0.f; w0.w = ok0 ? v[3] : 0.f;
+        *reinterpret_cast<float4*>(smem_bytes + l0) = w0;
+        if (NH) *reinterpret_cast<float*>(smem_bytes + lh) = okh ? vh : 0.f;
+        wave_sync();
+        if (more) {
+            wp += TAPS * 512;
+            wp2 += TAPS * 512;
+            xb += xstep;
+            load_a16<TAPS, DUAL>(wp, wp2, An, An2);
+            x0 = *reinterpret_cast<const float4*>(xb + g0);
+            if (NH) xh = *reinterpret_cast<const float*>(xb + gh);
+            if (xf) { gb += 2 * CONV_CK; gbv = *reinterpret_cast<const float2*>(gb); }
+        }
+        float bf[TAPS * 4];
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg)
+                bf[tap * 4 + kg] = *reinterpret_cast<const float*>(smem_bytes + rb0 + (4 * kg * RS + tap) * 4);
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const float4 a0 = A[tap * 2], a1 = A[tap * 2 + 1];
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bf[tap * 4 + 0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bf[tap * 4 + 0], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bf[tap * 4 + 1], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bf[tap * 4 + 1], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bf[tap * 4 + 2], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, bf[tap * 4 + 2], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bf[tap * 4 + 3], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bf[tap * 4 + 3], acc[1], 0, 0, 0);
+            if (DUAL) {
+                const float4 g0v = A2[tap * 2], g1v = A2[tap * 2 + 1];
+                accg[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(g0v.x, bf[tap * 4 + 0], accg[0], 0, 0, 0);
+                accg[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(g1v.x, bf[tap * 4 + 0], accg[1], 0, 0, 0);
+                accg[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(g0v.y, bf[tap * 4 + 1], accg[0], 0, 0, 0);
+                accg[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(g1v.y, bf[tap * 4 + 1], accg[1], 0, 0, 0);
+                accg[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(g0v.z, bf[tap * 4 + 2], accg[0], 0, 0, 0);
+                accg[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(g1v.z, bf[tap * 4 + 2], accg[1], 0, 0, 0);
+                accg[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(g0v.w, bf[tap * 4 + 3], accg[0], 0, 0, 0);
+                accg[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(g1v.w, bf[tap * 4 + 3], accg[1], 0, 0, 0);
+            }
+        }
+        wave_sync();
+    };
+
+    int c = lo;
+    for (;;) {
+        step(Aa, Aa2, Ab, Ab2, c + 1 < hi);
+        if (++c >= hi) break;
+        step(Ab, Ab2, Aa, Aa2, c + 1 < hi);
+        if (++c >= hi) break;
+    }
+}
+
+template <int WK, bool DUAL>
+__global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kernel(const ConvArgs a, int gx, int gy, int gz) {
+    constexpr int RED = WK > 1 ? WK * 8 * 64 : 1;                   // floats for one partial-tile exchange
+    constexpr int WIN = WK * WAVE_LDS;
+    __shared__ __attribute__((aligned(16))) float smem[(DUAL ? 2 * RED : RED) > WIN ? (DUAL ? 2 * RED : RED) : WIN];
+
+    const int nblk = gx * gy * gz;
+    int lid = blockIdx.x;
+    if ((nblk & 7) == 0) lid = (lid & 7) * (nblk >> 3) + (lid >> 3);          // XCD-contiguous row tiles (see k_conv.hip)
+    const int mt = lid / (gx * gz);
+    const int rem = lid - mt * (gx * gz);
+    const int b = rem / gx;
+    const int t0 = (rem - b * gx) * 16;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+
+    const int per = (a.nchunk + WK - 1) / WK;
+    const int g0 = wave * per;
+    const int g1 = (g0 + per < a.nchunk) ? g0 + per : a.nchunk;
+
+    f32x4 acc[2], accg[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; accg[0][i] = 0.f; accg[1][i] = 0.f; }
+
+    const float* wtile = a.wpk + (size_t)mt * a.w_mt_stride + lane * 4;
+    const float* wtile2 = DUAL ? wtile + (size_t)(a.Mout >> 5) * a.w_mt_stride : wtile;
+    char* smem_bytes = reinterpret_cast<char*>(smem);
+    const int wave_base = wave * WAVE_LDS * 4;
+
+    // ---- epilogue operands, issued before the K loop (see k_conv.hip)
+    constexpr int EPT = 8 / WK;          // accumulator registers (tile rows) finished by each wave
+    float bv[EPT], bg[EPT], ra[EPT], rsv[EPT];
+    size_t oo[EPT];
+    int mm[EPT];
+    bool valid[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int r = wave * EPT + q;                       // r = half*4 + i  ->  row 16 half + 4 kq + i, column l15
+        const int row = 16 * (r >> 2) + 4 * kq + (r & 3);
+        const int m = mt * 32 + row, t = t0 + l15;
+        valid[q] = (m < a.Mout) && (t < a.Tout);
+        mm[q] = m < a.Mout ? m : a.Mout - 1;
+        oo[q] = ((size_t)b * a.Mout + mm[q]) * a.Tout + (t < a.Tout ? t : a.Tout - 1);
+        bv[q] = 0.f; bg[q] = 0.f; ra[q] = 0.f; rsv[q] = 0.f;
+    }
+    if (a.bias) {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) { bv[q] = a.bias[mm[q]]; if (DUAL) bg[q] = a.bias[mm[q] + a.Mout]; }
+    }
+    if (a.rowadd) {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) ra[q] = a.rowadd[(size_t)b * a.rowadd_stride + mm[q]];
+    }
+    if (a.resid) {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) rsv[q] = a.resid[oo[q]];
+    }
+
+#pragma unroll
+    for (int si = 0; si < CONV_MAXSEG; ++si) {
+        if (si < a.nseg) {
+            const ConvSeg& s = a.seg[si];
+            const int nch = s.C / CONV_CK;
+            const int lo = (g0 > s.chunk0 ? g0 : s.chunk0) - s.chunk0;
+            const int hi = (g1 < s.chunk0 + nch ? g1 : s.chunk0 + nch) - s.chunk0;
+            if (lo < hi) {
+                const float* w1 = wtile + s.woff;
+                const float* w2 = wtile2 + s.woff;
+                if (!DUAL && s.taps == 3) run_segment16<3, DUAL>(s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, acc, accg);
+                else run_segment16<1, DUAL>(s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, acc, accg);
+            }
+        }
+    }
+
+    float acc_v[EPT], acc_g[EPT];
+    if (WK > 1) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            smem[(wave * 8 + r) * 64 + lane] = acc[r >> 2][r & 3];
+            if (DUAL) smem[RED + (wave * 8 + r) * 64 + lane] = accg[r >> 2][r & 3];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int r = wave * EPT + q;
+            acc_v[q] = 0.f;
+            acc_g[q] = 0.f;
+#pragma unroll
+            for (int w = 0; w < WK; ++w) {
+                acc_v[q] += smem[(w * 8 + r) * 64 + lane];
+                if (DUAL) acc_g[q] += smem[RED + (w * 8 + r) * 64 + lane];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) { acc_v[q] = acc[q >> 2][q & 3]; acc_g[q] = accg[q >> 2][q & 3]; }
+    }
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        float v = acc_v[q] + bv[q];
+        if (DUAL) {
+            const float gte = acc_g[q] + bg[q];
+            v = (a.epi == EPI_GLU) ? v * sigmoid_f(gte) : v * gelu_erf_f(gte);
+        }
+        v = (v + ra[q]) + rsv[q];
+        if (valid[q]) a.y[oo[q]] = v;
+    }
+}
+
+__global__ void pack_weights16_kernel(const PackArgs p) {
+    const long long total = (long long)p.rows * p.C * p.taps;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % p.taps);
+        const long long q = i / p.taps;
+        const int ci = (int)(q % p.C);
+        const int ms = (int)(q / p.C);
+        const int m = ms + p.row_off;
+        const int mt = m >> 5, half = (m >> 4) & 1, r = m & 15;
+        const int chunk = ci >> 4, within = ci & 15;
+        const int kg = within >> 2, kq = within & 3;
+        const int lane = kq * 16 + r;
+        const long long d = (long long)mt * p.w_mt_stride + p.seg_woff + (long long)chunk * (p.taps * 512) +
+                            (tap * 2 + half) * 256 + lane * 4 + kg;
+        p.dst[d] = p.src[(long long)ms * p.src_ld + (long long)(p.src_ci_off + ci) * p.taps + tap];
+    }
+}
+
+template <int WK>
+void launch16_wk(hipStream_t st, const ConvArgs& a, dim3 grid, int gx, int gy, int gz, bool dual) {
+    if (dual) hipLaunchKernelGGL((conv_gemm16_kernel<WK, true>), grid, dim3(WK * 64), 0, st, a, gx, gy, gz);
+    else hipLaunchKernelGGL((conv_gemm16_kernel<WK, false>), grid, dim3(WK * 64), 0, st, a, gx, gy, gz);
+}
+
+}  // namespace
+
+bool conv16_supported(const ConvArgs& a) {
+    for (int i = 0; i < a.nseg; ++i) {
+        const ConvSeg& s = a.seg[i];
+        if (s.stride != 1 || s.ups || (s.Tin & 3) || !(s.taps == 1 || (s.taps == 3 && s.dil == 1)) || s.pad > s.taps - 1) return false;
+        if (a.epi != EPI_NONE && s.taps != 1) return false;
+    }
+    return true;
+}
+
+// 16-wide tiles when the 32-wide tiling cannot give every CU a workgroup (MUGD_CONV_TN=16|32 forces it)
+int conv_pick_tn(const ConvArgs& a) {
+    static const int forced = [] { const char* e = getenv("MUGD_CONV_TN"); return e ? atoi(e) : 0; }();
+    if (!conv16_supported(a)) return 32;
+    if (forced == 16 || forced == 32) return forced;
+    const long long tiles32 = (long long)cdiv(a.Tout, 32) * cdiv(a.Mout, 32) * a.B;
+    return tiles32 < 256 ? 16 : 32;
+}
+
+void launch_conv_gemm16(hipStream_t st, const ConvArgs& a) {
+    MUGD_CHECK(a.nseg >= 1 && a.nseg <= CONV_MAXSEG, -2, "conv_gemm16: bad segment count");
+    MUGD_CHECK(conv16_supported(a), -2, "conv_gemm16: unsupported segment geometry");
+    for (int i = 0; i < a.nseg; ++i) {
+        const ConvSeg& s = a.seg[i];
+        MUGD_CHECK(s.C % CONV_CK == 0, -2, "conv_gemm16: channels must be a multiple of 16");
+        MUGD_CHECK((long long)CONV_CK * s.Tin * 4 < (1ll << 31), -2, "conv_gemm16: sequence too long for 32-bit window offsets");
+        MUGD_CHECK(s.xf >= 0 && s.xf <= 2 && (s.xf == 0 || s.xf_a) && (s.xf != 2 || s.xf_b), -2, "conv_gemm16: bad operand transform");
+    }
+    const bool dual = a.epi != EPI_NONE;
+    if (dual) MUGD_CHECK(a.Mout % 32 == 0 && a.Mrows == 2 * a.Mout, -2, "conv_gemm16: gated epilogue needs Mout % 32 == 0");
+    else MUGD_CHECK(a.Mrows == a.Mout, -2, "conv_gemm16: Mrows != Mout");
+    const int gx = cdiv(a.Tout, 16), gy = cdiv(a.Mout, 32), gz = a.B;
+    const dim3 grid((unsigned)gx * gy * gz);
+    int wk = a.wk;
+    if (wk <= 0) {
+        const long long tiles = (long long)gx * gy * gz;
+        wk = 8;
+        while (wk > 1 && tiles * wk > 2048) wk >>= 1;
+        while (wk > 1 && a.nchunk < 2 * wk) wk >>= 1;
+        if (wk < 2 && tiles < 2048) wk = a.nchunk >= 4 ? 2 : 1;
+    }
+    if (const char* e = getenv("MUGD_CONV_WK")) {
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4 || v == 8) wk = v;
+    }
+    switch (wk) {
+        case 1: launch16_wk<1>(st, a, grid, gx, gy, gz, dual); break;
+        case 2: launch16_wk<2>(st, a, grid, gx, gy, gz, dual); break;
+        case 4: launch16_wk<4>(st, a, grid, gx, gy, gz, dual); break;
+        case 8: launch16_wk<8>(st, a, grid, gx, gy, gz, dual); break;
+        default: MUGD_CHECK(false, -2, "conv_gemm16: K-split must be 1, 2, 4 or 8");
+    }
+}
+
+void launch_pack_weights16(hipStream_t st, const PackArgs& a) {
+    const long long total = (long long)a.rows * a.C * a.taps;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(pack_weights16_kernel, dim3(blocks), dim3(256), 0, st, a);
+}

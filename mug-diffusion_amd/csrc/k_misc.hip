@@ -65,6 +65,55 @@ __global__ void ddim_update_kernel(const DdimArgs a) {
     if (a.pred_x0) a.pred_x0[i] = pred;
 }
 
+// One launch per DDIM step for everything around the U-Net program (ddim.py:139-196 + unet.py:522-523):
+//   mode 1: CFG combine + DDIM update of the state x; the new x is also written into the U-Net's input
+//           buffer (twice, [uncond ; cond], under guidance); the NEXT step's time-embedding rows (from the
+//           table precomputed for all S timesteps: they depend only on the schedule) are broadcast to the
+//           per-batch-row buffer the ResBlock convs add in their epilogue; the device step counter advances.
+//   mode 0: initialisation before the first step (no update: x -> input buffer, embedding rows of step 0).
+// The counter is advanced by the last workgroup to finish (ticket), after every workgroup has read it.
+__global__ __launch_bounds__(256) void ddim_step_kernel(const DdimStepArgs a) {
+    const int step = *a.step_idx;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.n) {
+        float xn = a.x[i];
+        if (a.mode) {
+            const float* sc = a.sched + 4 * step;
+            const float a_t = sc[0], a_prev = sc[1], sigma = sc[2], s1m = sc[3];
+            float e;
+            if (a.cfg) {
+                const float e_uc = a.eps[i], e_c = a.eps[a.n + i];
+                e = e_uc + a.scale * (e_c - e_uc);
+            } else {
+                e = a.eps[i];
+            }
+            const float pred = (xn - s1m * e) / sqrtf(a_t);
+            const float dir = sqrtf(1.0f - a_prev - sigma * sigma) * e;
+            xn = sqrtf(a_prev) * pred + dir;
+            if (a.noise) xn += sigma * a.noise[(size_t)step * a.n + i];
+            a.x[i] = xn;
+            if (a.pred_x0) a.pred_x0[i] = pred;
+        }
+        a.in_x[i] = xn;
+        if (a.cfg) a.in_x[a.n + i] = xn;
+    }
+    const int S = a.step_idx[1];
+    const int nrow = a.mode ? (step + 1 < S ? step + 1 : step) : step;
+    const float* row = a.emb_table + (size_t)nrow * a.emb_total;
+    for (int j = i; j < a.Bnet * a.emb_total; j += gridDim.x * blockDim.x) a.emb_rows[j] = row[j % a.emb_total];
+    if (a.mode) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            if (atomicAdd(a.ticket, 1) == (int)gridDim.x - 1) {
+                *a.ticket = 0;
+                *a.step_idx = step + 1;
+                __threadfence();
+            }
+        }
+    }
+}
+
 // mug/cond/feature.py:15-21: out[b][h][f] = table[ids[b][f]][h]
 __global__ void embed_tokens_kernel(const float* table, const long long* ids, float* out, int B, int ntok, int dim) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -103,6 +152,13 @@ void launch_linear_small(hipStream_t st, const LinSmallArgs& a) {
 }
 void launch_ddim_update(hipStream_t st, const DdimArgs& a) {
     hipLaunchKernelGGL(ddim_update_kernel, dim3(cdiv(a.n, 256)), dim3(256), 0, st, a);
+}
+void launch_ddim_step(hipStream_t st, const DdimStepArgs& a) {
+    const int work = a.n > a.Bnet * a.emb_total ? a.n : a.Bnet * a.emb_total;
+    int blocks = cdiv(work, 256);
+    if (blocks > 256) blocks = 256;
+    if (blocks < cdiv(a.n, 256)) blocks = cdiv(a.n, 256);
+    hipLaunchKernelGGL(ddim_step_kernel, dim3(blocks), dim3(256), 0, st, a);
 }
 void launch_embed_tokens(hipStream_t st, const float* table, const long long* ids, float* out, int B, int ntok, int dim) {
     hipLaunchKernelGGL(embed_tokens_kernel, dim3(cdiv(B * ntok * dim, 256)), dim3(256), 0, st, table, ids, out, B, ntok, dim);

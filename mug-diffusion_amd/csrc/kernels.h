@@ -54,10 +54,15 @@ struct ConvArgs {
     float* y;                // (B, Mout, Tout)
     int B, Mrows, Mout, Tout, nchunk, epi;
     int wk;                  // K-split (waves per workgroup): 1|2|4|8, 0 = pick from the shape
+    int tn;                  // output tile width: 32 (k_conv.hip) | 16 (k_conv16.hip); decides the weight packing
 };
 
-void launch_conv_gemm(hipStream_t st, const ConvArgs& a);
+void launch_conv_gemm(hipStream_t st, const ConvArgs& a);        // 32 x 32 tiles
 int conv_pick_wk(const ConvArgs& a);
+void launch_conv_gemm16(hipStream_t st, const ConvArgs& a);      // 32 x 16 tiles
+bool conv16_supported(const ConvArgs& a);
+int conv_pick_tn(const ConvArgs& a);                             // needs seg[], nseg, epi, B, Mout, Tout
+inline void launch_conv(hipStream_t st, const ConvArgs& a) { if (a.tn == 16) launch_conv_gemm16(st, a); else launch_conv_gemm(st, a); }
 
 // packs rows [row_off, row_off+rows) x channels [0, C) of one K-segment.
 struct PackArgs {
@@ -69,7 +74,8 @@ struct PackArgs {
     int src_ld, src_ci_off;
     int rows, row_off;
 };
-void launch_pack_weights(hipStream_t st, const PackArgs& a);
+void launch_pack_weights(hipStream_t st, const PackArgs& a);        // fragment order of v_mfma_f32_32x32x2_f32
+void launch_pack_weights16(hipStream_t st, const PackArgs& a);      // fragment order of v_mfma_f32_16x16x4_f32 (two row halves)
 
 // ---------------------------------------------------------------------------------------
 // GroupNorm (+ optional SiLU) over a virtual channel concat, LayerNorm over channels
@@ -159,6 +165,18 @@ struct DdimArgs {
 };
 void launch_ddim_update(hipStream_t st, const DdimArgs& a);
 
+struct DdimStepArgs {
+    float* x; const float* eps; const float* noise; float* pred_x0;
+    const float* sched;      // [S][4] = a_t, a_prev, sigma, sqrt(1-a_t) (device)
+    int* step_idx;           // device: [0] the current step (row of sched / noise / emb_table), [1] the number of steps S
+    int* ticket;             // device scalar, zero between launches
+    float* in_x;             // U-Net input buffer (n floats, or 2n under guidance)
+    const float* emb_table;  // [S][emb_total]: the stacked ResBlock emb_layers outputs of every timestep
+    float* emb_rows;         // [Bnet][emb_total]
+    int n, cfg, Bnet, emb_total, mode;
+    float scale;
+};
+void launch_ddim_step(hipStream_t st, const DdimStepArgs& a);
 void launch_embed_tokens(hipStream_t st, const float* table, const long long* ids, float* out, int B, int ntok, int dim);
 void launch_dup_batch(hipStream_t st, const float* src, float* dst, long long n);          // dst = [src ; src]
 void launch_fill_t(hipStream_t st, long long* t_dev, const long long* t_table, const int* step_idx, int B);

@@ -31,6 +31,7 @@ struct Ctx {
     bool own_stream = false;
     std::string last_error;
     bool use_graph = true;
+    int force_wk = 0, force_tn = 0;   // mugd_set_conv_tiling: 0 = pick per layer
     bool fast_act = false;      // MUGD_FAST_SILU=1: SiLU of the fused GroupNorm path on v_exp_f32 / v_rcp_f32 instead of expf + IEEE divide
     bool fuse_norm = true;      // false (MUGD_UNFUSED_NORM=1): materialise GroupNorm / LayerNorm outputs with the stand-alone kernels (A/B + debugging)
 };
@@ -104,7 +105,8 @@ protected:
     Arena arena;
     std::vector<Op> ops;                          // the per-call (per DDIM step) program
     std::vector<Op> pre_ops;                      // work that depends only on the conditioning: once per forward()/sample()
-    bool to_pre = false;                          // emit() target
+    std::vector<Op> emb_ops;                      // U-Net: timestep embedding of a forward() call (the sampler uses a per-schedule table instead)
+    bool to_pre = false, to_emb = false;          // emit() target
     bool dry = true;
     int Bn = 0;                                   // batch the program is compiled for
 
@@ -114,7 +116,7 @@ protected:
     float* dev_alloc(size_t nfloats, bool zero = false);
     Tensor talloc(int C, int T) { Tensor t; t.C = C; t.T = T; t.p = arena.alloc((size_t)Bn * C * T); return t; }
     void emit(std::function<void(hipStream_t)> f, int kind = OP_SMALL, double flops = 0, const std::string& label = "") {
-        if (!dry) (to_pre ? pre_ops : ops).push_back(Op{std::move(f), kind, flops, label});
+        if (!dry) (to_pre ? pre_ops : to_emb ? emb_ops : ops).push_back(Op{std::move(f), kind, flops, label});
     }
     void run_ops(hipStream_t st) { for (auto& o : ops) o.fn(st); }
     void run_pre_ops(hipStream_t st) { for (auto& o : pre_ops) o.fn(st); }
@@ -144,7 +146,7 @@ protected:
     Tensor upsample(const std::string& prefix, const Tensor& x);
     const float* s4_kernel(const std::string& prefix, int H, int L);
     Tensor s4_layer(const std::string& prefix, const Tensor& x);
-    const PackedW& get_packed(const ConvSpec& s);
+    const PackedW& get_packed(const ConvSpec& s, int tn);
 };
 
 // ---------------------------------------------------------------------------------------
@@ -183,6 +185,8 @@ private:
     float* x_state = nullptr;
     float* sched_dev = nullptr; long long* ttab_dev = nullptr; int* step_dev = nullptr; int sched_cap = 0;
     float* noise_dev = nullptr; size_t noise_cap = 0, state_cap = 0;
+    int step_init[2] = {0, 0};
+    float* emb_table = nullptr; float* emb_tmp = nullptr; int* ticket_dev = nullptr;     // [S][rowadd_total] + scratch of its 3 GEMVs
     float* pred_dev = nullptr;
     hipGraphExec_t graph = nullptr; bool graph_cfg = false; bool graph_noise = false; bool graph_pred = false; float graph_scale = 0.f;
 
@@ -191,7 +195,8 @@ private:
     Tensor resblock(const std::string& prefix, const std::vector<Tensor>& segs, int Cout, int rowadd_off);
     void prepare_emb();
     std::vector<std::pair<std::string, int>> resblock_list() const;   // (prefix, Cout) in execution order
-    void step_body(hipStream_t st, bool cfg, float scale, bool with_noise, bool with_pred, int nstate);
+    void step_body(hipStream_t st, bool cfg, float scale, bool with_noise, bool with_pred, int nstate, int S);
+    DdimStepArgs step_args(bool cfg, float scale, bool with_noise, bool with_pred, int nstate, int S, int mode) const;
 };
 
 struct VaeConfig {

@@ -87,6 +87,7 @@ void Net::invalidate() {
     baked.clear();
     ops.clear();
     pre_ops.clear();
+    emb_ops.clear();
 }
 
 const Param& Net::P(const std::string& n) const {
@@ -216,8 +217,9 @@ Xf Net::layer_norm_xf(const std::string& prefix, const Tensor& x) {
     return xf;
 }
 
-const PackedW& Net::get_packed(const ConvSpec& s) {
-    auto it = packed.find(s.key);
+const PackedW& Net::get_packed(const ConvSpec& s, int tn) {
+    const std::string pkey = tn == 16 ? s.key + "#16" : s.key;
+    auto it = packed.find(pkey);
     if (it != packed.end()) return it->second;
     PackedW pw;
     int chunk = 0, woff = 0;
@@ -242,7 +244,8 @@ const PackedW& Net::get_packed(const ConvSpec& s) {
         MUGD_CHECK(tw == in.taps, -2, "conv: kernel width mismatch for " + wb.name);
         MUGD_CHECK(wb.ci_off + in.x.C <= cw && wb.row_off + rows <= s.Mrows, -2, "conv: weight block out of range: " + wb.name);
         PackArgs pa{pw.wpk, pw.mt_stride, pw.woff[wb.seg], in.x.C, in.taps, (const float*)p.ptr, cw * tw, wb.ci_off, rows, wb.row_off};
-        launch_pack_weights(ctx->stream, pa);
+        if (tn == 16) launch_pack_weights16(ctx->stream, pa);
+        else launch_pack_weights(ctx->stream, pa);
     }
     if (!s.bias.empty()) {
         pw.bias = dev_alloc(s.Mrows, true);
@@ -252,30 +255,34 @@ const PackedW& Net::get_packed(const ConvSpec& s) {
             launch_bias_sum(ctx->stream, pw.bias + b.second, (const float*)p.ptr, pw.bias + b.second, (int)p.numel());
         }
     }
-    return packed[s.key] = pw;
+    return packed[pkey] = pw;
 }
 
 Tensor Net::conv(const ConvSpec& s) {
     MUGD_CHECK(!s.in.empty() && (int)s.in.size() <= CONV_MAXSEG, -2, "conv: bad segment count at " + s.key);
-    const PackedW& pw = get_packed(s);
     Tensor y = s.out.p ? s.out : talloc(s.Mout, s.Tout);
     ConvArgs a{};
     a.nseg = (int)s.in.size();
     for (int i = 0; i < a.nseg; ++i) {
         const ConvIn& in = s.in[i];
-        a.seg[i] = ConvSeg{in.x.p, in.x.C, in.x.T, in.taps, in.dil, in.stride, in.pad, in.ups, pw.chunk0[i], pw.woff[i], in.x.bmod,
+        a.seg[i] = ConvSeg{in.x.p, in.x.C, in.x.T, in.taps, in.dil, in.stride, in.pad, in.ups, 0, 0, in.x.bmod,
                            in.xf.kind, in.xf.act, in.xf.a, in.xf.b, in.xf.stride};
     }
+    a.B = Bn; a.Mrows = s.Mrows; a.Mout = s.Mout; a.Tout = s.Tout; a.epi = s.epi;
+    a.wk = ctx->force_wk;
+    a.tn = ctx->force_tn == 16 ? (conv16_supported(a) ? 16 : 32) : ctx->force_tn == 32 ? 32 : conv_pick_tn(a);
+    const PackedW& pw = get_packed(s, a.tn);       // the tile width decides the weight fragment order
+    for (int i = 0; i < a.nseg; ++i) { a.seg[i].chunk0 = pw.chunk0[i]; a.seg[i].woff = pw.woff[i]; }
     a.wpk = pw.wpk; a.w_mt_stride = pw.mt_stride; a.bias = pw.bias;
     a.rowadd = s.rowadd; a.rowadd_stride = s.rowadd_stride;
     a.resid = s.resid.p;
     if (s.resid.p) MUGD_CHECK(s.resid.C == s.Mout && s.resid.T == s.Tout && s.resid.bmod == 0, -2, "conv: residual shape mismatch at " + s.key);
-    a.y = y.p; a.B = Bn; a.Mrows = s.Mrows; a.Mout = s.Mout; a.Tout = s.Tout; a.nchunk = pw.nchunk; a.epi = s.epi;
+    a.y = y.p; a.nchunk = pw.nchunk;
     double kdim = 0;
     for (auto& in : s.in) kdim += (double)in.x.C * in.taps;
-    emit([a](hipStream_t st) { launch_conv_gemm(st, a); }, s.epi ? OP_CONV_GATED : OP_CONV, 2.0 * s.Mrows * kdim * s.Tout * Bn,
+    emit([a](hipStream_t st) { launch_conv(st, a); }, s.epi ? OP_CONV_GATED : OP_CONV, 2.0 * s.Mrows * kdim * s.Tout * Bn,
          s.key + " M=" + std::to_string(s.Mrows) + " K=" + std::to_string((long long)kdim) + " T=" + std::to_string(s.Tout) +
-             " nseg=" + std::to_string(a.nseg));
+             " nseg=" + std::to_string(a.nseg) + " tn=" + std::to_string(a.tn));
     return y;
 }
 
@@ -558,6 +565,7 @@ void UNet::build(bool dry_run) {
     arena.begin(dry_run);
     ops.clear();
     pre_ops.clear();
+    emb_ops.clear();
     Bn = key.B;
     const int mc = cfg.model_channels, nl = (int)cfg.channel_mult.size(), z = key.z;
     const bool attn_any = !cfg.attention_resolutions.empty();
@@ -584,8 +592,10 @@ void UNet::build(bool dry_run) {
     prepare_emb();
     emb_rowadd = arena.alloc((size_t)Bn * rowadd_total);
 
-    // ---- time embedding (unet.py:522-523) + all resblock emb_layers in one GEMV
+    // ---- time embedding (unet.py:522-523) + all resblock emb_layers in one GEMV.  forward() runs these per call (t may
+    // differ per batch row); sample() precomputes the rows of every timestep of the schedule instead (see sample()).
     {
+        to_emb = true;
         long long* tp = t_dev; float* o = temb.p; int B = Bn, dim = mc;
         emit([=](hipStream_t st) { launch_timestep_embedding(st, tp, nullptr, o, B, dim); });
         LinSmallArgs l1{temb.p, PF("time_embed.0.weight"), PF("time_embed.0.bias"), e1.p, Bn, mc, 4 * mc, 0, 1, mc, 4 * mc};
@@ -594,6 +604,7 @@ void UNet::build(bool dry_run) {
         emit([=](hipStream_t st) { launch_linear_small(st, l2); });
         LinSmallArgs l3{emb.p, baked["emb.W"], baked["emb.b"], emb_rowadd, Bn, 4 * mc, rowadd_total, 1, 0, 4 * mc, rowadd_total};
         emit([=](hipStream_t st) { launch_linear_small(st, l3); });
+        to_emb = false;
     }
 
     // ---- down path (unet.py:341-405, 527-535)
@@ -668,7 +679,7 @@ void UNet::invalidate() {
     drop_programs();
     Net::invalidate();
     x_state = pred_dev = noise_dev = sched_dev = nullptr;
-    ttab_dev = nullptr; step_dev = nullptr;
+    ttab_dev = nullptr; step_dev = nullptr; ticket_dev = nullptr; emb_table = emb_tmp = nullptr;
     sched_cap = 0; noise_cap = state_cap = 0;
 }
 
@@ -677,6 +688,7 @@ void UNet::drop_programs() {
     built = false;
     ops.clear();
     pre_ops.clear();
+    emb_ops.clear();
 }
 
 void UNet::ensure(int B, int z, int ntok, int bmod) {
@@ -708,18 +720,24 @@ void UNet::forward(const float* x, const long long* t, const float* context, int
     for (int l = 0; l < nl; ++l)
         HIP_CHECK(hipMemcpyAsync(in_audio[l].p, audio[l], (size_t)audio_batch * in_audio[l].C * in_audio[l].T * sizeof(float), hipMemcpyDeviceToDevice, st));
     run_pre_ops(st);
+    for (auto& o : emb_ops) o.fn(st);
     run_ops(st);
     HIP_CHECK(hipMemcpyAsync(eps, out_eps.p, (size_t)B * out_eps.C * z * sizeof(float), hipMemcpyDeviceToDevice, st));
 }
 
-void UNet::step_body(hipStream_t st, bool cfg_on, float scale, bool with_noise, bool with_pred, int nstate) {
-    launch_fill_t(st, t_dev, ttab_dev, step_dev, key.B);
-    if (cfg_on) launch_dup_batch(st, x_state, in_x.p, nstate);
-    else HIP_CHECK(hipMemcpyAsync(in_x.p, x_state, (size_t)nstate * sizeof(float), hipMemcpyDeviceToDevice, st));
+DdimStepArgs UNet::step_args(bool cfg_on, float scale, bool with_noise, bool with_pred, int nstate, int S, int mode) const {
+    DdimStepArgs d{};
+    d.x = x_state; d.eps = out_eps.p; d.noise = with_noise ? noise_dev : nullptr; d.pred_x0 = with_pred ? pred_dev : nullptr;
+    d.sched = sched_dev; d.step_idx = step_dev; d.ticket = ticket_dev; d.in_x = in_x.p;
+    d.emb_table = emb_table; d.emb_rows = emb_rowadd;
+    d.n = nstate; d.cfg = cfg_on ? 1 : 0; d.Bnet = key.B; d.emb_total = rowadd_total; d.mode = mode; d.scale = scale;
+    return d;
+}
+
+// one DDIM step = the U-Net program + ONE more launch (CFG combine, DDIM update, next input, next time-embedding rows, counter)
+void UNet::step_body(hipStream_t st, bool cfg_on, float scale, bool with_noise, bool with_pred, int nstate, int S) {
     run_ops(st);
-    DdimArgs d{x_state, out_eps.p, with_noise ? noise_dev : nullptr, with_pred ? pred_dev : nullptr, sched_dev, step_dev, nstate, cfg_on ? 1 : 0, scale};
-    launch_ddim_update(st, d);
-    launch_advance(st, step_dev);
+    launch_ddim_step(st, step_args(cfg_on, scale, with_noise, with_pred, nstate, S, 1));
 }
 
 void UNet::sample(float* x, const float* c, const float* uc, int n_tok, const float* const* audio, int audio_batch,
@@ -743,7 +761,10 @@ void UNet::sample(float* x, const float* c, const float* uc, int n_tok, const fl
         sched_cap = std::max(S, 64);
         sched_dev = dev_alloc((size_t)sched_cap * 4);
         ttab_dev = reinterpret_cast<long long*>(dev_alloc((size_t)sched_cap * 2));
-        step_dev = reinterpret_cast<int*>(dev_alloc(4));
+        step_dev = reinterpret_cast<int*>(dev_alloc(4));                  // {step, S}
+        ticket_dev = reinterpret_cast<int*>(dev_alloc(4, true));
+        emb_table = dev_alloc((size_t)sched_cap * rowadd_total);
+        emb_tmp = dev_alloc((size_t)sched_cap * 9 * cfg.model_channels);
     }
     if ((size_t)nstate > state_cap) {                    // sampler state sized for this (B, z)
         drop_graph();
@@ -761,7 +782,8 @@ void UNet::sample(float* x, const float* c, const float* uc, int n_tok, const fl
     }
     HIP_CHECK(hipMemcpyAsync(sched_dev, sched_host, (size_t)S * 4 * sizeof(float), hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(ttab_dev, t_host, (size_t)S * sizeof(long long), hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemsetAsync(step_dev, 0, sizeof(int), st));
+    step_init[0] = 0; step_init[1] = S;                   // member: outlives the asynchronous copy
+    HIP_CHECK(hipMemcpyAsync(step_dev, step_init, sizeof(step_init), hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(x_state, x, (size_t)nstate * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (cfg_on) {                                         // batch order [uncond ; cond]  (ddim.py:173)
         HIP_CHECK(hipMemcpyAsync(in_ctx.p, uc, ctx_n * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -773,7 +795,16 @@ void UNet::sample(float* x, const float* c, const float* uc, int n_tok, const fl
         HIP_CHECK(hipMemcpyAsync(in_audio[l].p, audio[l], (size_t)audio_batch * in_audio[l].C * in_audio[l].T * sizeof(float), hipMemcpyDeviceToDevice, st));
 
     run_pre_ops(st);                                      // context-only work (cross-attention K/V): once per call, not per step
+    {   // time-embedding rows of all S timesteps (unet.py:522-523 + every ResBlock's emb_layers), once per call
+        const int mc = cfg.model_channels;
+        float* temb = emb_tmp; float* e1 = emb_tmp + (size_t)S * mc; float* emb = e1 + (size_t)S * 4 * mc;
+        launch_timestep_embedding(st, ttab_dev, nullptr, temb, S, mc);
+        launch_linear_small(st, LinSmallArgs{temb, PF("time_embed.0.weight"), PF("time_embed.0.bias"), e1, S, mc, 4 * mc, 0, 1, mc, 4 * mc});
+        launch_linear_small(st, LinSmallArgs{e1, PF("time_embed.2.weight"), PF("time_embed.2.bias"), emb, S, 4 * mc, 4 * mc, 0, 0, 4 * mc, 4 * mc});
+        launch_linear_small(st, LinSmallArgs{emb, baked["emb.W"], baked["emb.b"], emb_table, S, 4 * mc, rowadd_total, 1, 0, 4 * mc, rowadd_total});
+    }
     const bool wn = noise != nullptr, wp = pred_x0 != nullptr;
+    launch_ddim_step(st, step_args(cfg_on, scale, wn, wp, nstate, S, 0));      // x_T -> U-Net input, embedding rows of step 0
     if (ctx->use_graph) {
         if (graph && (graph_cfg != cfg_on || graph_noise != wn || graph_pred != wp || graph_scale != scale)) {
             HIP_CHECK(hipStreamSynchronize(st));
@@ -783,7 +814,7 @@ void UNet::sample(float* x, const float* c, const float* uc, int n_tok, const fl
         if (!graph) {
             hipGraph_t g = nullptr;
             HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            step_body(st, cfg_on, scale, wn, wp, nstate);
+            step_body(st, cfg_on, scale, wn, wp, nstate, S);
             HIP_CHECK(hipStreamEndCapture(st, &g));
             HIP_CHECK(hipGraphInstantiate(&graph, g, nullptr, nullptr, 0));
             HIP_CHECK(hipGraphDestroy(g));
@@ -791,7 +822,7 @@ void UNet::sample(float* x, const float* c, const float* uc, int n_tok, const fl
         }
         for (int i = 0; i < S; ++i) HIP_CHECK(hipGraphLaunch(graph, st));
     } else {
-        for (int i = 0; i < S; ++i) step_body(st, cfg_on, scale, wn, wp, nstate);
+        for (int i = 0; i < S; ++i) step_body(st, cfg_on, scale, wn, wp, nstate, S);
     }
     HIP_CHECK(hipMemcpyAsync(x, x_state, (size_t)nstate * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (wp) HIP_CHECK(hipMemcpyAsync(pred_x0, pred_dev, (size_t)nstate * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -805,6 +836,7 @@ void VaeDecoder::build(bool dry_run) {
     arena.begin(dry_run);
     ops.clear();
     pre_ops.clear();
+    emb_ops.clear();
     Bn = kB;
     const int nres = (int)cfg.channel_mult.size(), g = cfg.num_groups;
     in_z = talloc(cfg.z_channels, kz);
@@ -854,6 +886,7 @@ void WaveEncoder::build(bool dry_run) {
     arena.begin(dry_run);
     ops.clear();
     pre_ops.clear();
+    emb_ops.clear();
     Bn = kB;
     const int nres = (int)cfg.channel_mult.size(), g = cfg.num_groups, mid = cfg.middle_channels;
     in_mel = talloc(cfg.n_freq, kT);

@@ -46,6 +46,7 @@ _SIGS = {
     "mugd_create": [_i, _p, C.POINTER(_p)],
     "mugd_synchronize": [_p],
     "mugd_set_graph_mode": [_p, _i],
+    "mugd_set_conv_tiling": [_p, _i, _i],
     "mugd_unet_create": [_p, C.POINTER(UNetConfig), C.POINTER(_p)],
     "mugd_vae_create": [_p, C.POINTER(VaeConfig), C.POINTER(_p)],
     "mugd_wave_create": [_p, C.POINTER(WaveConfig), C.POINTER(_p)],
@@ -136,6 +137,10 @@ class Lib:
 
     def set_graph_mode(self, on):
         self.check(self.dll.mugd_set_graph_mode(self.ctx, 1 if on else 0))
+
+    def set_conv_tiling(self, wk=0, tn=0):
+        """Force the conv_gemm K-split / tile width (0 = per-layer choice); affects networks compiled afterwards."""
+        self.check(self.dll.mugd_set_conv_tiling(self.ctx, wk, tn))
 
     def f32(self, t):
         return t.detach().to(device=self.device, dtype=torch.float32).contiguous()

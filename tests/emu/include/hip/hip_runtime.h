@@ -152,6 +152,7 @@ static inline int __double2hiint(double d) { uint64_t u; std::memcpy(&u, &d, 8);
 static inline double __hiloint2double(int hi, int lo) {
     uint64_t u = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo; double d; std::memcpy(&d, &u, 8); return d;
 }
+static inline void __threadfence() {}
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }

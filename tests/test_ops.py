@@ -107,6 +107,40 @@ def test_norm_conv1d_fused(lib, B, C, T, M, taps, dil, norm, groups, silu, wk):
     close(got, ref, 3e-5, what="norm+conv1d")
 
 
+@pytest.mark.parametrize("tn", [16, 32])
+@pytest.mark.parametrize("B,C,T,M,taps,dil,norm,groups,silu,wk", [c for c in NORM_CONV_CASES if c[2] % 4 == 0 and c[5] == 1])
+def test_norm_conv1d_tile_widths(lib, tn, B, C, T, M, taps, dil, norm, groups, silu, wk):
+    """Both tile shapes (32x32 on v_mfma_f32_32x32x2_f32, 32x16 on v_mfma_f32_16x16x4_f32) give the same conv."""
+    lib.set_conv_tiling(0, tn)
+    try:
+        test_norm_conv1d_fused(lib, B, C, T, M, taps, dil, norm, groups, silu, wk)
+    finally:
+        lib.set_conv_tiling(0, 0)
+
+
+@pytest.mark.parametrize("tn", [16, 32])
+@pytest.mark.parametrize("B,C,T,M,taps,dil,stride,pad,ups", [c for c in CONV_CASES if c[2] % 4 == 0 and c[5] == 1 and c[6] == 1 and not c[8]])
+def test_conv1d_tile_widths(lib, tn, B, C, T, M, taps, dil, stride, pad, ups):
+    lib.set_conv_tiling(0, tn)
+    try:
+        test_conv1d(lib, B, C, T, M, taps, dil, stride, pad, ups)
+        for wk in (1, 2, 4, 8):
+            lib.set_conv_tiling(wk, tn)
+            test_conv1d(lib, B, C, T, M, taps, dil, stride, pad, ups)
+    finally:
+        lib.set_conv_tiling(0, 0)
+
+
+@pytest.mark.parametrize("tn", [16, 32])
+@pytest.mark.parametrize("epi", [1, 2])
+def test_conv1d_gated_tile_widths(lib, tn, epi):
+    lib.set_conv_tiling(0, tn)
+    try:
+        test_conv1d_gated(lib, epi)
+    finally:
+        lib.set_conv_tiling(0, 0)
+
+
 @pytest.mark.parametrize("epi", [1, 2])
 def test_conv1d_gated(lib, epi):
     B, C, T, M = 2, 32, 40, 128
