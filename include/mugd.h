@@ -148,6 +148,10 @@ int mugd_op_conv1d(mugd_ctx* ctx, const float* x, const float* w, const float* b
  * mug/model/attention.py:139-151 LN->Linear).  wk: K-split 1|2|4|8, 0 = heuristic. */
 int mugd_op_norm_conv1d(mugd_ctx* ctx, const float* x, const float* gamma, const float* beta, const float* w, const float* bias,
                         float* y, int B, int C, int T, int M, int taps, int dil, int pad, int norm, int groups, int silu, int wk);
+/* Development micro-benchmark of one conv_gemm launch shape with `copies` weight sets cycled (cold weights, like a layer
+ * inside the U-Net step); mean microseconds per launch. */
+int mugd_dev_bench_conv(mugd_ctx* ctx, int B, int C, int T, int M, int taps, int norm, int gated, int wk, int tn, int copies,
+                        int iters, float* us_out);
 int mugd_op_attention(mugd_ctx* ctx, const float* q, const float* k, const float* v, const float* rel, const float* cemb,
                       float* out, int B, int heads, int d, int Tq, int Tk, int pmax);
 int mugd_op_s4_kernel(mugd_ctx* ctx, const float* C, const float* Bp, const float* P, const float* inv_w_real,

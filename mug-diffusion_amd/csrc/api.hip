@@ -78,8 +78,8 @@ int mugd_create(int device, void* stream, mugd_ctx** out) {
         ctx->c.use_graph = !(g && g[0] == '1');
         const char* u = getenv("MUGD_UNFUSED_NORM");
         ctx->c.fuse_norm = !(u && u[0] == '1');
-        const char* fa = getenv("MUGD_FAST_SILU");
-        ctx->c.fast_act = fa && fa[0] == '1';
+        const char* fa = getenv("MUGD_EXACT_SILU");            // default: SiLU of the fused GroupNorm path on v_exp_f32 / v_rcp_f32
+        ctx->c.fast_act = !(fa && fa[0] == '1');
     });
     if (rc != MUGD_OK) {
         fprintf(stderr, "mugd_create: %s\n", ctx->c.last_error.c_str());
@@ -324,6 +324,53 @@ int mugd_op_norm_conv1d(mugd_ctx* ctx, const float* x, const float* gamma, const
         if (a.tn == 16) launch_pack_weights16(st, pa); else launch_pack_weights(st, pa);
         launch_conv(st, a);
         HIP_CHECK(hipStreamSynchronize(st));
+    });
+}
+
+// Development micro-benchmark of one conv_gemm launch shape (not part of the reference surface): `copies` weight sets are
+// cycled through so that with copies * M * C * taps * 4 bytes > 256 MiB every launch streams its weights from HBM, like a
+// layer inside the U-Net step does (the step's 0.4 GB of fp32 weights do not stay on die).  norm: 0 none | 1 GroupNorm(32)
+// + SiLU fused | 2 LayerNorm fused.  Returns the mean time per launch in microseconds (HIP events over `iters` launches).
+int mugd_dev_bench_conv(mugd_ctx* ctx, int B, int C, int T, int M, int taps, int norm, int gated, int wk, int tn, int copies,
+                        int iters, float* us_out) {
+    return guarded(ctx, [&] {
+        MUGD_CHECK(C % CONV_CK == 0 && copies >= 1 && iters >= 1 && us_out, MUGD_ERR_INVALID, "bad benchmark arguments");
+        hipStream_t st = ctx->c.stream;
+        Scratch sc;
+        const int MT = cdiv(M, 32);
+        const long long mts = (long long)(C / CONV_CK) * taps * 512;
+        float* x = sc.get((size_t)B * C * T, false, st);
+        float* y = sc.get((size_t)B * M * T, false, st);
+        float* aff = sc.get((size_t)B * C * 2 + (size_t)B * T * 2 + 2 * C, false, st);
+        float* wpk = sc.get((size_t)copies * MT * mts, false, st);
+        HIP_CHECK(hipMemsetAsync(x, 0x3c, (size_t)B * C * T * 4, st));           // 0x3c3c3c3c ~ 0.0115: finite, non-zero operands
+        HIP_CHECK(hipMemsetAsync(aff, 0x3c, ((size_t)B * C * 2 + (size_t)B * T * 2 + 2 * C) * 4, st));
+        HIP_CHECK(hipMemsetAsync(wpk, 0x3c, (size_t)copies * MT * mts * 4, st));
+        ConvArgs a{};
+        a.nseg = 1;
+        a.seg[0] = ConvSeg{x, C, T, taps, 1, 1, taps / 2, 0, 0, 0, 0};
+        if (norm == 1) { a.seg[0].xf = 1; a.seg[0].act = ctx->c.fast_act ? 2 : 1; a.seg[0].xf_a = aff; a.seg[0].xf_stride = 2 * C; }
+        if (norm == 2) { a.seg[0].xf = 2; a.seg[0].xf_a = aff; a.seg[0].xf_b = aff + (size_t)B * T * 2; a.seg[0].xf_stride = 2 * T; }
+        a.w_mt_stride = mts; a.y = y;
+        a.B = B; a.Mrows = M; a.Mout = gated ? M / 2 : M; a.Tout = T; a.nchunk = C / CONV_CK; a.epi = gated ? EPI_GEGLU : EPI_NONE;
+        a.wk = wk;
+        a.tn = tn ? tn : conv_pick_tn(a);
+        if (a.tn == 16 && !conv16_supported(a)) a.tn = 32;
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        for (int it = -3; it < iters; ++it) {
+            if (it == 0) HIP_CHECK(hipEventRecord(e0, st));
+            a.wpk = wpk + (size_t)((it + 3) % copies) * MT * mts;
+            launch_conv(st, a);
+        }
+        HIP_CHECK(hipEventRecord(e1, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+        *us_out = ms * 1e3f / iters;
     });
 }
 

@@ -82,7 +82,11 @@ __device__ __forceinline__ void mfma_chunk(const char* smem_bytes, int rb0, int 
 // ---------------------------------------------------------------------------------------
 // Fast path: stride 1, no upsample, Tin % 4 == 0 (rows are 16-byte aligned).  NH = halo loads per lane.
 // ---------------------------------------------------------------------------------------
-template <int TAPS, bool DUAL, int NH>
+// XFK / ACT: the operand transform as compile-time constants (-1: read from the segment at run time).  The transform
+// is the VALU budget of the kernel -- with the exact-division SiLU it issued as many VALU cycles as the MFMAs take
+// (rocprofv3 PMC: SQ_ACTIVE_INST_VALU ~ SQ_VALU_MFMA_BUSY_CYCLES) -- so the hot instantiations carry no branches
+// and the minimal arithmetic: GroupNorm is one fma per sample, SiLU is v_exp_f32 + v_rcp_f32.
+template <int TAPS, bool DUAL, int NH, int XFK = -1, int ACT = -1>
 __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* wseg, const float* wseg2, int lo, int hi,
                                                 int b, int t0, int lane, int h, int n, char* smem_bytes, int wave_base,
                                                 f32x16& acc, f32x16& acc2) {
@@ -111,7 +115,7 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
         lh[j] = wave_base + (r * RS + (e < hw ? HL + col : 60 + q)) * 4;      // dead lanes park in columns no tap reads
     }
     // ---- operand transform constants
-    const int xf = s.xf, act = s.act;
+    const int xf = XFK >= 0 ? XFK : s.xf, act = ACT >= 0 ? ACT : s.act;
     float mu[8], rs8[8];
     float muh[NH > 0 ? NH : 1], rsh[NH > 0 ? NH : 1];
 #pragma unroll
@@ -161,9 +165,9 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
         if (xf) {
             const float g = gbv.x, bt = gbv.y;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = (v[i] - mu[i]) * rs8[i] * g + bt;
+            for (int i = 0; i < 8; ++i) v[i] = (xf == 1) ? v[i] * g + bt : (v[i] - mu[i]) * rs8[i] * g + bt;
 #pragma unroll
-            for (int j = 0; j < NH; ++j) vh[j] = (vh[j] - muh[j]) * rsh[j] * g + bt;
+            for (int j = 0; j < NH; ++j) vh[j] = (xf == 1) ? vh[j] * g + bt : (vh[j] - muh[j]) * rsh[j] * g + bt;
             if (act == 1) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = silu_f(v[i]);
@@ -391,8 +395,19 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
                 const float* w2 = wtile2 + s.woff;
 #define MUGD_SEG_ARGS s, w1, w2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, acc, acc2
                 if (LEAN) {
-                    if (s.taps == 3) run_segment_vec<3, DUAL, 1>(MUGD_SEG_ARGS);
-                    else run_segment_vec<1, DUAL, 0>(MUGD_SEG_ARGS);
+                    // specialise on (transform, activation): branch-free chunk loops
+#define MUGD_SEG_XF(T, NHALO)                                                                     \
+    switch (s.xf * 4 + s.act) {                                                                   \
+        case 0: run_segment_vec<T, DUAL, NHALO, 0, 0>(MUGD_SEG_ARGS); break;                      \
+        case 4: run_segment_vec<T, DUAL, NHALO, 1, 0>(MUGD_SEG_ARGS); break;                      \
+        case 5: run_segment_vec<T, DUAL, NHALO, 1, 1>(MUGD_SEG_ARGS); break;                      \
+        case 6: run_segment_vec<T, DUAL, NHALO, 1, 2>(MUGD_SEG_ARGS); break;                      \
+        case 8: run_segment_vec<T, DUAL, NHALO, 2, 0>(MUGD_SEG_ARGS); break;                      \
+        default: run_segment_vec<T, DUAL, NHALO>(MUGD_SEG_ARGS);                                  \
+    }
+                    if (DUAL || s.taps == 1) { MUGD_SEG_XF(1, 0) }
+                    else { MUGD_SEG_XF(3, 1) }
+#undef MUGD_SEG_XF
                 } else if (seg_is_vec(s)) {
                     if (s.taps == 1) run_segment_vec<1, DUAL, 0>(MUGD_SEG_ARGS);
                     else if (s.dil <= 2) run_segment_vec<3, DUAL, 1>(MUGD_SEG_ARGS);

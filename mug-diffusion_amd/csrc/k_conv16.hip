@@ -34,7 +34,7 @@ __device__ __forceinline__ void load_a16(const float* wp, const float* wp2, floa
     }
 }
 
-template <int TAPS, bool DUAL>
+template <int TAPS, bool DUAL, int XFK = -1, int ACT = -1>       // XFK / ACT: compile-time operand transform, see k_conv.hip
 __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wseg, const float* wseg2, int lo, int hi,
                                               int b, int t0, int lane, char* smem_bytes, int wave_base,
                                               f32x4 (&acc)[2], f32x4 (&accg)[2]) {
@@ -60,7 +60,7 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
         gh = (unsigned)(r * Tin + tc) * 4u;
         lh = wave_base + (r * RS + (e < hw ? HL + col : 40 + q)) * 4;      // dead lanes park in columns no tap reads
     }
-    const int xf = s.xf, act = s.act;
+    const int xf = XFK >= 0 ? XFK : s.xf, act = ACT >= 0 ? ACT : s.act;
     float mu[4], rs4[4], muh = 0.f, rsh = 1.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { mu[i] = 0.f; rs4[i] = 1.f; }
@@ -100,8 +100,8 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
         if (xf) {
             const float g = gbv.x, bt = gbv.y;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = (v[i] - mu[i]) * rs4[i] * g + bt;
-            vh = (vh - muh) * rsh * g + bt;
+            for (int i = 0; i < 4; ++i) v[i] = (xf == 1) ? v[i] * g + bt : (v[i] - mu[i]) * rs4[i] * g + bt;
+            vh = (xf == 1) ? vh * g + bt : (vh - muh) * rsh * g + bt;
             if (act == 1) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = silu_f(v[i]);
@@ -237,8 +237,20 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
             if (lo < hi) {
                 const float* w1 = wtile + s.woff;
                 const float* w2 = wtile2 + s.woff;
-                if (!DUAL && s.taps == 3) run_segment16<3, DUAL>(s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, acc, accg);
-                else run_segment16<1, DUAL>(s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, acc, accg);
+#define MUGD_SEG16_ARGS s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, acc, accg
+#define MUGD_SEG16_XF(T)                                                                  \
+    switch (s.xf * 4 + s.act) {                                                           \
+        case 0: run_segment16<T, DUAL, 0, 0>(MUGD_SEG16_ARGS); break;                     \
+        case 4: run_segment16<T, DUAL, 1, 0>(MUGD_SEG16_ARGS); break;                     \
+        case 5: run_segment16<T, DUAL, 1, 1>(MUGD_SEG16_ARGS); break;                     \
+        case 6: run_segment16<T, DUAL, 1, 2>(MUGD_SEG16_ARGS); break;                     \
+        case 8: run_segment16<T, DUAL, 2, 0>(MUGD_SEG16_ARGS); break;                     \
+        default: run_segment16<T, DUAL>(MUGD_SEG16_ARGS);                                 \
+    }
+                if (DUAL || s.taps == 1) { MUGD_SEG16_XF(1) }
+                else { MUGD_SEG16_XF(3) }
+#undef MUGD_SEG16_XF
+#undef MUGD_SEG16_ARGS
             }
         }
     }
@@ -320,7 +332,7 @@ int conv_pick_tn(const ConvArgs& a) {
     if (!conv16_supported(a)) return 32;
     if (forced == 16 || forced == 32) return forced;
     const long long tiles32 = (long long)cdiv(a.Tout, 32) * cdiv(a.Mout, 32) * a.B;
-    return tiles32 < 256 ? 16 : 32;
+    return tiles32 * 2 <= 256 ? 16 : 32;       // 129..255 tiles: 16-wide tiles would need a second, half-empty round of workgroups
 }
 
 void launch_conv_gemm16(hipStream_t st, const ConvArgs& a) {

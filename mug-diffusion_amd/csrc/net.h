@@ -32,7 +32,7 @@ struct Ctx {
     std::string last_error;
     bool use_graph = true;
     int force_wk = 0, force_tn = 0;   // mugd_set_conv_tiling: 0 = pick per layer
-    bool fast_act = false;      // MUGD_FAST_SILU=1: SiLU of the fused GroupNorm path on v_exp_f32 / v_rcp_f32 instead of expf + IEEE divide
+    bool fast_act = true;       // SiLU of the fused GroupNorm path on v_exp_f32 / v_rcp_f32 (MUGD_EXACT_SILU=1: expf + IEEE divide)
     bool fuse_norm = true;      // false (MUGD_UNFUSED_NORM=1): materialise GroupNorm / LayerNorm outputs with the stand-alone kernels (A/B + debugging)
 };
 

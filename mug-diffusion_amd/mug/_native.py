@@ -63,6 +63,7 @@ _SIGS = {
     "mugd_op_layer_norm": [_p, _p, _p, _p, _p, _i, _i, _i],
     "mugd_op_conv1d": [_p, _p, _p, _p, _p, _p] + [_i] * 11,
     "mugd_op_norm_conv1d": [_p, _p, _p, _p, _p, _p, _p] + [_i] * 11,
+    "mugd_dev_bench_conv": [_p] + [_i] * 11 + [C.POINTER(_f)],
     "mugd_op_attention": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i],
     "mugd_op_s4_kernel": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i],
     "mugd_op_s4_conv": [_p, _p, _p, _p, _p, _i, _i, _i],
@@ -258,6 +259,11 @@ class Lib:
         self.check(self.dll.mugd_op_norm_conv1d(self.ctx, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(w), _ptr(bias), _ptr(y),
                                                 B, Cc, T, M, taps, dil, pad, norm, groups, int(silu), wk))
         return y
+
+    def dev_bench_conv(self, B, Cc, T, M, taps=3, norm=0, gated=False, wk=0, tn=0, copies=1, iters=50):
+        us = _f()
+        self.check(self.dll.mugd_dev_bench_conv(self.ctx, B, Cc, T, M, taps, norm, int(gated), wk, tn, copies, iters, C.byref(us)))
+        return us.value
 
     def op_attention(self, q, k, v, rel, cemb, heads):
         q, k, v, rel, cemb = map(self.f32, (q, k, v, rel, cemb))
