@@ -35,10 +35,15 @@
 
 #include "kernels.h"
 
+#ifndef MUGD_PIPE
+#define MUGD_PIPE true
+#endif
+
 namespace {
 
 constexpr int RS = CONV_RS;
-constexpr int WAVE_LDS = CONV_CK * RS;          // floats per wave window
+constexpr int WIN_LDS = CONV_CK * RS;           // floats per window
+constexpr int WAVE_LDS = 2 * WIN_LDS;           // two windows per wave: the pipelined loops park chunk c+1 while chunk c is on the matrix pipe
 constexpr int HL = 8;                           // fast path: window column of sample t0 (left halo lives in [HL-pad, HL))
 
 template <int TAPS, bool DUAL>
@@ -86,7 +91,7 @@ __device__ __forceinline__ void mfma_chunk(const char* smem_bytes, int rb0, int 
 // is the VALU budget of the kernel -- with the exact-division SiLU it issued as many VALU cycles as the MFMAs take
 // (rocprofv3 PMC: SQ_ACTIVE_INST_VALU ~ SQ_VALU_MFMA_BUSY_CYCLES) -- so the hot instantiations carry no branches
 // and the minimal arithmetic: GroupNorm is one fma per sample, SiLU is v_exp_f32 + v_rcp_f32.
-template <int TAPS, bool DUAL, int NH, int XFK = -1, int ACT = -1>
+template <int TAPS, bool DUAL, int NH, int XFK = -1, int ACT = -1, bool PIPE = false>
 __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* wseg, const float* wseg2, int lo, int hi,
                                                 int b, int t0, int lane, int h, int n, char* smem_bytes, int wave_base,
                                                 f32x16& acc, f32x16& acc2) {
@@ -149,14 +154,9 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
     float4 x0, x1;
     float xh[NH > 0 ? NH : 1];
     float2 gbv = make_float2(1.f, 0.f);
-    load_a<TAPS, DUAL>(wp, wp2, Aa, Aa2);
-    x0 = *reinterpret_cast<const float4*>(xb + g0);
-    x1 = *reinterpret_cast<const float4*>(xb + g1);
-#pragma unroll
-    for (int j = 0; j < NH; ++j) xh[j] = *reinterpret_cast<const float*>(xb + gh[j]);
-    if (xf) gbv = *reinterpret_cast<const float2*>(gb);
 
-    auto step = [&](const float4 (&A)[6], const float4 (&A2)[6], float4 (&An)[6], float4 (&An2)[6], bool more) {
+    // transform the staged samples and park them in window `wofs` (byte offset 0 | WIN_LDS*4)
+    auto park = [&](int wofs) {
         float v[8];
         float vh[NH > 0 ? NH : 1];
         v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
@@ -183,10 +183,75 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
         float4 w0, w1;                                  // zero padding AFTER the transform (component selects: no scratch)
         w0.x = ok0 ? v[0] : 0.f; w0.y = ok0 ? v[1] : 0.f; w0.z = ok0 ? v[2] : 0.f; w0.w = ok0 ? v[3] : 0.f;
         w1.x = ok1 ? v[4] : 0.f; w1.y = ok1 ? v[5] : 0.f; w1.z = ok1 ? v[6] : 0.f; w1.w = ok1 ? v[7] : 0.f;
-        *reinterpret_cast<float4*>(smem_bytes + l0) = w0;
-        *reinterpret_cast<float4*>(smem_bytes + l0 + 16) = w1;
+        *reinterpret_cast<float4*>(smem_bytes + wofs + l0) = w0;
+        *reinterpret_cast<float4*>(smem_bytes + wofs + l0 + 16) = w1;
 #pragma unroll
-        for (int j = 0; j < NH; ++j) *reinterpret_cast<float*>(smem_bytes + lh[j]) = okh[j] ? vh[j] : 0.f;
+        for (int j = 0; j < NH; ++j) *reinterpret_cast<float*>(smem_bytes + wofs + lh[j]) = okh[j] ? vh[j] : 0.f;
+    };
+
+    if (PIPE) {
+        // ---- software-pipelined loop: while chunk c is on the matrix pipe (its fragments come from window c&1) the wave
+        // transforms chunk c+1 and parks it in the other window, then requests chunk c+2.  One straight-line block per
+        // chunk: the VALU / LDS-store / load-issue work sits in the issue slots between the wave's own dependent MFMAs
+        // instead of in a phase of its own (two waves of a SIMD run in lockstep, so separate phases leave the pipe idle).
+        const int nch = hi - lo;
+        auto fetch_x = [&](int cr) {                    // chunk index clamped: the tail re-reads the last chunk, in bounds
+            const int cc = cr < nch ? cr : nch - 1;
+            const char* xq = xb + (size_t)cc * xstep;
+            x0 = *reinterpret_cast<const float4*>(xq + g0);
+            x1 = *reinterpret_cast<const float4*>(xq + g1);
+#pragma unroll
+            for (int j = 0; j < NH; ++j) xh[j] = *reinterpret_cast<const float*>(xq + gh[j]);
+            if (xf) gbv = *reinterpret_cast<const float2*>(gb + (size_t)cc * (2 * CONV_CK));
+        };
+        auto fetch_a = [&](int cr, float4 (&An)[6], float4 (&An2)[6]) {
+            const int cc = cr < nch ? cr : nch - 1;
+            load_a<TAPS, DUAL>(wp + (size_t)cc * (TAPS * 512), wp2 + (size_t)cc * (TAPS * 512), An, An2);
+        };
+        constexpr int W1 = WIN_LDS * 4;
+        // scheduling pattern of one chunk: after every MFMA a few VALU ops (the next chunk's transform / addressing),
+        // so the VALU stream is spread over the matrix pipe's shadow instead of trailing the last MFMA
+        auto interleave = [&]() {
+#pragma unroll
+            for (int i = 0; i < TAPS * 8 * (DUAL ? 2 : 1); ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                if (XFK > 0 && ACT > 0) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // VALU
+                else __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            }
+        };
+        fetch_a(0, Aa, Aa2);
+        fetch_x(0);
+        park(0);
+        fetch_x(1);
+        fetch_a(1, Ab, Ab2);
+        wave_sync();
+        for (int c = 0; c < nch; c += 2) {
+            mfma_chunk<TAPS, DUAL>(smem_bytes, rb0, s.dil, Aa, Aa2, acc, acc2);
+            park(W1);
+            fetch_x(c + 2);
+            fetch_a(c + 2, Aa, Aa2);
+            interleave();
+            wave_sync();
+            if (c + 1 >= nch) break;
+            mfma_chunk<TAPS, DUAL>(smem_bytes + W1, rb0, s.dil, Ab, Ab2, acc, acc2);
+            park(0);
+            fetch_x(c + 3);
+            fetch_a(c + 3, Ab, Ab2);
+            interleave();
+            wave_sync();
+        }
+        return;
+    }
+
+    load_a<TAPS, DUAL>(wp, wp2, Aa, Aa2);
+    x0 = *reinterpret_cast<const float4*>(xb + g0);
+    x1 = *reinterpret_cast<const float4*>(xb + g1);
+#pragma unroll
+    for (int j = 0; j < NH; ++j) xh[j] = *reinterpret_cast<const float*>(xb + gh[j]);
+    if (xf) gbv = *reinterpret_cast<const float2*>(gb);
+
+    auto step = [&](const float4 (&A)[6], const float4 (&A2)[6], float4 (&An)[6], float4 (&An2)[6], bool more) {
+        park(0);
         wave_sync();
         if (more) {
             wp += TAPS * 512;
@@ -313,9 +378,12 @@ __device__ __forceinline__ void run_segment_gen(const ConvSeg& s, const float* w
 
 __device__ __forceinline__ bool seg_is_vec(const ConvSeg& s) { return s.stride == 1 && !s.ups && (s.Tin & 3) == 0 && s.pad <= HL; }
 
-// LEAN: every segment takes the fast path with dilation 1 (the whole U-Net except its 6 resampling
-// convs) -- keeps the hot instantiations small.  NITG: staging passes of the generic path.
-template <int WK, bool DUAL, bool LEAN, int NITG>
+// KIND 0: every segment takes the fast window path with dilation 1 (the whole U-Net except its 6 resampling convs):
+//         chunk loops specialised on the operand transform and software-pipelined.
+// KIND 1: fast window path, any dilation (wave encoder / VAE ResnetBlocks).
+// KIND 2: every segment through the generic window walk (stride 2, nearest-x2 upsample, T % 4 != 0); NITG = its
+//         staging passes.  Separate kernels keep each instantiation's register budget to what it needs.
+template <int WK, bool DUAL, int KIND, int NITG>
 __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel(const ConvArgs a, int gx, int gy, int gz) {
     constexpr int RED = WK > 1 ? WK * 16 * 64 : 1;                  // floats for one partial-tile exchange
     constexpr int WIN = WK * WAVE_LDS;
@@ -394,21 +462,21 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
                 const float* w1 = wtile + s.woff;
                 const float* w2 = wtile2 + s.woff;
 #define MUGD_SEG_ARGS s, w1, w2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, acc, acc2
-                if (LEAN) {
+                if (KIND == 0) {
                     // specialise on (transform, activation): branch-free chunk loops
 #define MUGD_SEG_XF(T, NHALO)                                                                     \
     switch (s.xf * 4 + s.act) {                                                                   \
-        case 0: run_segment_vec<T, DUAL, NHALO, 0, 0>(MUGD_SEG_ARGS); break;                      \
-        case 4: run_segment_vec<T, DUAL, NHALO, 1, 0>(MUGD_SEG_ARGS); break;                      \
-        case 5: run_segment_vec<T, DUAL, NHALO, 1, 1>(MUGD_SEG_ARGS); break;                      \
-        case 6: run_segment_vec<T, DUAL, NHALO, 1, 2>(MUGD_SEG_ARGS); break;                      \
-        case 8: run_segment_vec<T, DUAL, NHALO, 2, 0>(MUGD_SEG_ARGS); break;                      \
+        case 0: run_segment_vec<T, DUAL, NHALO, 0, 0, MUGD_PIPE>(MUGD_SEG_ARGS); break;                      \
+        case 4: run_segment_vec<T, DUAL, NHALO, 1, 0, MUGD_PIPE>(MUGD_SEG_ARGS); break;                      \
+        case 5: run_segment_vec<T, DUAL, NHALO, 1, 1, MUGD_PIPE>(MUGD_SEG_ARGS); break;                      \
+        case 6: run_segment_vec<T, DUAL, NHALO, 1, 2, MUGD_PIPE>(MUGD_SEG_ARGS); break;                      \
+        case 8: run_segment_vec<T, DUAL, NHALO, 2, 0, MUGD_PIPE>(MUGD_SEG_ARGS); break;                      \
         default: run_segment_vec<T, DUAL, NHALO>(MUGD_SEG_ARGS);                                  \
     }
                     if (DUAL || s.taps == 1) { MUGD_SEG_XF(1, 0) }
                     else { MUGD_SEG_XF(3, 1) }
 #undef MUGD_SEG_XF
-                } else if (seg_is_vec(s)) {
+                } else if (KIND == 1) {
                     if (s.taps == 1) run_segment_vec<1, DUAL, 0>(MUGD_SEG_ARGS);
                     else if (s.dil <= 2) run_segment_vec<3, DUAL, 1>(MUGD_SEG_ARGS);
                     else if (s.dil == 4) run_segment_vec<3, DUAL, 2>(MUGD_SEG_ARGS);
@@ -480,11 +548,12 @@ __global__ void pack_weights_kernel(const PackArgs p) {
 }
 
 template <int WK, bool DUAL>
-void launch_wk(hipStream_t st, const ConvArgs& a, dim3 grid, int gx, int gy, int gz, bool lean, int nitg) {
-#define MUGD_CONV_LAUNCH(L, N) hipLaunchKernelGGL((conv_gemm_kernel<WK, DUAL, L, N>), grid, dim3(WK * 64), 0, st, a, gx, gy, gz)
-    if (lean) MUGD_CONV_LAUNCH(true, 1);
-    else if (nitg <= 9) MUGD_CONV_LAUNCH(false, 9);
-    else MUGD_CONV_LAUNCH(false, 17);
+void launch_wk(hipStream_t st, const ConvArgs& a, dim3 grid, int gx, int gy, int gz, int kind, int nitg) {
+#define MUGD_CONV_LAUNCH(K, N) hipLaunchKernelGGL((conv_gemm_kernel<WK, DUAL, K, N>), grid, dim3(WK * 64), 0, st, a, gx, gy, gz)
+    if (kind == 0) MUGD_CONV_LAUNCH(0, 1);
+    else if (kind == 1) MUGD_CONV_LAUNCH(1, 1);
+    else if (nitg <= 9) MUGD_CONV_LAUNCH(2, 9);
+    else MUGD_CONV_LAUNCH(2, 17);
 #undef MUGD_CONV_LAUNCH
 }
 
@@ -503,7 +572,11 @@ int conv_pick_wk(const ConvArgs& a) {
 void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
     MUGD_CHECK(a.nseg >= 1 && a.nseg <= CONV_MAXSEG, -2, "conv_gemm: bad segment count");
     int nitg = 0;                         // staging passes of the generic path: ceil(16 * window / 64) for its widest segment
-    bool lean = true;
+    bool lean = true, all_vec = true;
+    for (int i = 0; i < a.nseg; ++i) {
+        const ConvSeg& s = a.seg[i];
+        if (!(s.stride == 1 && !s.ups && (s.Tin & 3) == 0 && s.pad <= HL)) all_vec = false;
+    }
     for (int i = 0; i < a.nseg; ++i) {
         const ConvSeg& s = a.seg[i];
         MUGD_CHECK(s.C % CONV_CK == 0, -2, "conv_gemm: channels must be a multiple of 16");
@@ -511,8 +584,7 @@ void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
         MUGD_CHECK(s.dil >= 1 && (s.stride == 1 || s.stride == 2), -2, "conv_gemm: bad dilation / stride");
         MUGD_CHECK((long long)CONV_CK * s.Tin * 4 < (1ll << 31), -2, "conv_gemm: sequence too long for 32-bit window offsets");
         MUGD_CHECK(s.xf >= 0 && s.xf <= 2 && (s.xf == 0 || s.xf_a) && (s.xf != 2 || s.xf_b), -2, "conv_gemm: bad operand transform");
-        const bool vec = s.stride == 1 && !s.ups && (s.Tin & 3) == 0 && s.pad <= HL;
-        if (vec) {
+        if (all_vec) {
             const int hw = (s.taps - 1) * s.dil;
             MUGD_CHECK(hw <= 16 && s.pad <= hw && HL + 32 + (hw - s.pad) <= CONV_RS, -2, "conv_gemm: window exceeds LDS row");
             if (s.taps == 3 && s.dil != 1) lean = false;
@@ -527,8 +599,8 @@ void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
     }
     MUGD_CHECK(nitg <= 17, -2, "conv_gemm: window too wide");
     if (nitg > 9)
-        for (int i = 0; i < a.nseg; ++i) MUGD_CHECK(a.seg[i].xf == 0 || (a.seg[i].stride == 1 && !a.seg[i].ups && (a.seg[i].Tin & 3) == 0), -2,
-                                                    "conv_gemm: operand transform next to a strided segment needs T % 4 == 0");
+        for (int i = 0; i < a.nseg; ++i) MUGD_CHECK(a.seg[i].xf == 0, -2, "conv_gemm: no operand transform in a kernel with a strided / widely dilated generic segment");
+    const int kind = all_vec ? (lean ? 0 : 1) : 2;
     const bool dual = a.epi != EPI_NONE;
     if (dual) {
         MUGD_CHECK(a.Mout % 32 == 0 && a.Mrows == 2 * a.Mout, -2, "conv_gemm: gated epilogue needs Mout % 32 == 0");
@@ -544,8 +616,8 @@ void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
     }
 #define MUGD_WK(W)                                                             \
     case W:                                                                    \
-        if (dual) launch_wk<W, true>(st, a, grid, gx, gy, gz, lean, nitg);     \
-        else launch_wk<W, false>(st, a, grid, gx, gy, gz, lean, nitg);         \
+        if (dual) launch_wk<W, true>(st, a, grid, gx, gy, gz, kind, nitg);     \
+        else launch_wk<W, false>(st, a, grid, gx, gy, gz, kind, nitg);         \
         break;
     switch (wk) {
         MUGD_WK(1) MUGD_WK(2) MUGD_WK(4) MUGD_WK(8)

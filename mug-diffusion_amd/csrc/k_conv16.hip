@@ -22,7 +22,8 @@
 namespace {
 
 constexpr int RS = 48;                          // LDS row stride (floats); 48 mod 32 = 16
-constexpr int WAVE_LDS = CONV_CK * RS;          // floats per wave window
+constexpr int WIN_LDS = CONV_CK * RS;           // floats per window
+constexpr int WAVE_LDS = 2 * WIN_LDS;           // two windows per wave (software-pipelined loops, see k_conv.hip)
 constexpr int HL = 8;                           // window column of sample t0
 
 template <int TAPS, bool DUAL>
@@ -34,7 +35,7 @@ __device__ __forceinline__ void load_a16(const float* wp, const float* wp2, floa
     }
 }
 
-template <int TAPS, bool DUAL, int XFK = -1, int ACT = -1>       // XFK / ACT: compile-time operand transform, see k_conv.hip
+template <int TAPS, bool DUAL, int XFK = -1, int ACT = -1, bool PIPE = false>       // XFK / ACT / PIPE: see k_conv.hip
 __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wseg, const float* wseg2, int lo, int hi,
                                               int b, int t0, int lane, char* smem_bytes, int wave_base,
                                               f32x4 (&acc)[2], f32x4 (&accg)[2]) {
@@ -89,12 +90,8 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
     float4 x0;
     float xh = 0.f;
     float2 gbv = make_float2(1.f, 0.f);
-    load_a16<TAPS, DUAL>(wp, wp2, Aa, Aa2);
-    x0 = *reinterpret_cast<const float4*>(xb + g0);
-    if (NH) xh = *reinterpret_cast<const float*>(xb + gh);
-    if (xf) gbv = *reinterpret_cast<const float2*>(gb);
 
-    auto step = [&](const float4 (&A)[6], const float4 (&A2)[6], float4 (&An)[6], float4 (&An2)[6], bool more) {
+    auto park = [&](int wofs) {
         float v[4], vh = xh;
         v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w;
         if (xf) {
@@ -114,24 +111,16 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
         }
         float4 w0;
         w0.x = ok0 ? v[0] : 0.f; w0.y = ok0 ? v[1] : 0.f; w0.z = ok0 ? v[2] : 0.f; w0.w = ok0 ? v[3] : 0.f;
-        *reinterpret_cast<float4*>(smem_bytes + l0) = w0;
-        if (NH) *reinterpret_cast<float*>(smem_bytes + lh) = okh ? vh : 0.f;
-        wave_sync();
-        if (more) {
-            wp += TAPS * 512;
-            wp2 += TAPS * 512;
-            xb += xstep;
-            load_a16<TAPS, DUAL>(wp, wp2, An, An2);
-            x0 = *reinterpret_cast<const float4*>(xb + g0);
-            if (NH) xh = *reinterpret_cast<const float*>(xb + gh);
-            if (xf) { gb += 2 * CONV_CK; gbv = *reinterpret_cast<const float2*>(gb); }
-        }
+        *reinterpret_cast<float4*>(smem_bytes + wofs + l0) = w0;
+        if (NH) *reinterpret_cast<float*>(smem_bytes + wofs + lh) = okh ? vh : 0.f;
+    };
+    auto mfma = [&](int wofs, const float4 (&A)[6], const float4 (&A2)[6]) {
         float bf[TAPS * 4];
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap)
 #pragma unroll
             for (int kg = 0; kg < 4; ++kg)
-                bf[tap * 4 + kg] = *reinterpret_cast<const float*>(smem_bytes + rb0 + (4 * kg * RS + tap) * 4);
+                bf[tap * 4 + kg] = *reinterpret_cast<const float*>(smem_bytes + wofs + rb0 + (4 * kg * RS + tap) * 4);
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const float4 a0 = A[tap * 2], a1 = A[tap * 2 + 1];
@@ -155,6 +144,71 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
                 accg[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(g1v.w, bf[tap * 4 + 3], accg[1], 0, 0, 0);
             }
         }
+    };
+
+    if (PIPE) {            // software-pipelined: chunk c on the matrix pipe, chunk c+1 transformed + parked, chunk c+2 requested
+        const int nch = hi - lo;
+        auto fetch_x = [&](int cr) {
+            const int cc = cr < nch ? cr : nch - 1;
+            const char* xq = xb + (size_t)cc * xstep;
+            x0 = *reinterpret_cast<const float4*>(xq + g0);
+            if (NH) xh = *reinterpret_cast<const float*>(xq + gh);
+            if (xf) gbv = *reinterpret_cast<const float2*>(gb + (size_t)cc * (2 * CONV_CK));
+        };
+        auto fetch_a = [&](int cr, float4 (&An)[6], float4 (&An2)[6]) {
+            const int cc = cr < nch ? cr : nch - 1;
+            load_a16<TAPS, DUAL>(wp + (size_t)cc * (TAPS * 512), wp2 + (size_t)cc * (TAPS * 512), An, An2);
+        };
+        auto interleave = [&]() {
+#pragma unroll
+            for (int i = 0; i < TAPS * 8 * (DUAL ? 2 : 1); ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // VALU of the next chunk's transform / addressing
+            }
+        };
+        constexpr int W1 = WIN_LDS * 4;
+        fetch_a(0, Aa, Aa2);
+        fetch_x(0);
+        park(0);
+        fetch_x(1);
+        fetch_a(1, Ab, Ab2);
+        wave_sync();
+        for (int c = 0; c < nch; c += 2) {
+            mfma(0, Aa, Aa2);
+            park(W1);
+            fetch_x(c + 2);
+            fetch_a(c + 2, Aa, Aa2);
+            interleave();
+            wave_sync();
+            if (c + 1 >= nch) break;
+            mfma(W1, Ab, Ab2);
+            park(0);
+            fetch_x(c + 3);
+            fetch_a(c + 3, Ab, Ab2);
+            interleave();
+            wave_sync();
+        }
+        return;
+    }
+
+    load_a16<TAPS, DUAL>(wp, wp2, Aa, Aa2);
+    x0 = *reinterpret_cast<const float4*>(xb + g0);
+    if (NH) xh = *reinterpret_cast<const float*>(xb + gh);
+    if (xf) gbv = *reinterpret_cast<const float2*>(gb);
+
+    auto step = [&](const float4 (&A)[6], const float4 (&A2)[6], float4 (&An)[6], float4 (&An2)[6], bool more) {
+        park(0);
+        wave_sync();
+        if (more) {
+            wp += TAPS * 512;
+            wp2 += TAPS * 512;
+            xb += xstep;
+            load_a16<TAPS, DUAL>(wp, wp2, An, An2);
+            x0 = *reinterpret_cast<const float4*>(xb + g0);
+            if (NH) xh = *reinterpret_cast<const float*>(xb + gh);
+            if (xf) { gb += 2 * CONV_CK; gbv = *reinterpret_cast<const float2*>(gb); }
+        }
+        mfma(0, A, A2);
         wave_sync();
     };
 
@@ -240,11 +294,11 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
 #define MUGD_SEG16_ARGS s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, acc, accg
 #define MUGD_SEG16_XF(T)                                                                  \
     switch (s.xf * 4 + s.act) {                                                           \
-        case 0: run_segment16<T, DUAL, 0, 0>(MUGD_SEG16_ARGS); break;                     \
-        case 4: run_segment16<T, DUAL, 1, 0>(MUGD_SEG16_ARGS); break;                     \
-        case 5: run_segment16<T, DUAL, 1, 1>(MUGD_SEG16_ARGS); break;                     \
-        case 6: run_segment16<T, DUAL, 1, 2>(MUGD_SEG16_ARGS); break;                     \
-        case 8: run_segment16<T, DUAL, 2, 0>(MUGD_SEG16_ARGS); break;                     \
+        case 0: run_segment16<T, DUAL, 0, 0, true>(MUGD_SEG16_ARGS); break;                     \
+        case 4: run_segment16<T, DUAL, 1, 0, true>(MUGD_SEG16_ARGS); break;                     \
+        case 5: run_segment16<T, DUAL, 1, 1, true>(MUGD_SEG16_ARGS); break;                     \
+        case 6: run_segment16<T, DUAL, 1, 2, true>(MUGD_SEG16_ARGS); break;                     \
+        case 8: run_segment16<T, DUAL, 2, 0, true>(MUGD_SEG16_ARGS); break;                     \
         default: run_segment16<T, DUAL>(MUGD_SEG16_ARGS);                                 \
     }
                 if (DUAL || s.taps == 1) { MUGD_SEG16_XF(1) }

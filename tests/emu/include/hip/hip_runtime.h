@@ -110,6 +110,7 @@ static inline void __builtin_amdgcn_wave_barrier_emu() { emu::wave_barrier(); }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(m, n, id) ((void)0)
 #define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_amdgcn_readfirstlane(x) (x)
 
