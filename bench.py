@@ -180,6 +180,10 @@ def main():
     notes = 0
     for _ in range(a.steps):
         grid, _ = one_step()
+    if world > 1:                       # the job's only data movement between ranks: note grids (8 x T bits per chart) to every rank
+        from mug import shard
+        all_grids = shard.gather_grids(grid, world * B, device=dev)
+        assert all_grids.shape[0] == world * B
     torch.cuda.synchronize()
     ddim_ms.append(ev0.elapsed_time(ev1))
     sync_all()
@@ -211,10 +215,11 @@ def main():
         if not a.no_roofline:
             # the U-Net program compiled for the timed run, replayed once eagerly with a HIP event pair per launch
             prof = unet.native().profile()
-            k = prof["conv_gemm"]
+            k = {f: prof["conv_gemm"][f] + prof["conv_gemm_gated"][f] for f in ("ms", "flops", "launches")}
             achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12
-            out["roofline"] = {"kernel": "conv_gemm_kernel<false,9> (fp32 MFMA implicit-GEMM conv1d/linear)", "bound": "mfma",
-                               "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            out["roofline"] = {"kernel": "conv_gemm_kernel / conv_gemm16_kernel (fp32-MFMA implicit-GEMM conv1d / linear, 32x32 and 32x16 tiles; "
+                                         "all 212 launches of one U-Net evaluation, HIP events around every launch on the library stream)",
+                               "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                                "launches_per_unet_eval": k["launches"], "avg_launch_us": k["ms"] * 1e3 / max(k["launches"], 1),
                                "algorithmic_gflop_per_launch": k["flops"] / 1e9 / max(k["launches"], 1),

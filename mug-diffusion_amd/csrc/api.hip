@@ -397,7 +397,7 @@ int mugd_op_s4_kernel(mugd_ctx* ctx, const float* C, const float* Bp, const floa
 
 int mugd_op_s4_conv(mugd_ctx* ctx, const float* u, const float* k, const float* D, float* y, int B, int H, int L) {
     return guarded(ctx, [&] {
-        S4ConvArgs a{u, k, D, y, B, H, L, nullptr};
+        S4ConvArgs a{u, k, D, y, B, H, L, nullptr, nullptr, nullptr, 0, 0.f};
         launch_s4_conv(ctx->c.stream, a);
     });
 }

@@ -124,8 +124,11 @@ __global__ __launch_bounds__(256) void s4_conv_kernel(const S4ConvArgs a) {
 template <int R>
 __global__ __launch_bounds__(256) void s4_conv_fast_kernel(const S4ConvArgs a) {
     constexpr int L = 64 * R;
+    // lane l reads u[l R + const]: a stride-R walk of the LDS banks.  One pad word per 32 samples
+    // (index i lives at i + i/32) makes that conflict-free for R = 2, 4, 8 and leaves unit-stride accesses alone.
+    constexpr int LP = 2 * L + (2 * L) / 32;
     __shared__ __attribute__((aligned(16))) float ks[L];
-    __shared__ __attribute__((aligned(16))) float us[4][2 * L];
+    __shared__ float us[4][LP];
     const int h = blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int b = blockIdx.y * 4 + wave;
@@ -134,18 +137,43 @@ __global__ __launch_bounds__(256) void s4_conv_fast_kernel(const S4ConvArgs a) {
     for (int t = threadIdx.x; t < L; t += 256) ks[t] = a.k[(size_t)h * L + t];
     const float* u = a.u + ((size_t)bc * a.H + h) * L + lane * R;
     float ag = 1.f, ab = 0.f;
-    if (a.aff) { ag = a.aff[2 * ((size_t)bc * a.H + h)]; ab = a.aff[2 * ((size_t)bc * a.H + h) + 1]; }
+    if (a.aff) {
+        ag = a.aff[2 * ((size_t)bc * a.H + h)]; ab = a.aff[2 * ((size_t)bc * a.H + h) + 1];
+    } else if (a.gn_gamma) {
+        // GroupNorm statistics of (batch row bc, group of channel h), by this wave: cg rows x L samples, one pass, fp64 sums
+        const int cg = a.H / a.gn_groups, c0 = (h / cg) * cg;
+        const float* ug = a.u + ((size_t)bc * a.H + c0) * L + lane * R;
+        double s1 = 0.0, s2 = 0.0;
+        for (int c = 0; c < cg; ++c) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) { const double v = ug[(size_t)c * L + r]; s1 += v; s2 += v * v; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s1 += __hiloint2double(__shfl_xor(__double2hiint(s1), o), __shfl_xor(__double2loint(s1), o));
+            s2 += __hiloint2double(__shfl_xor(__double2hiint(s2), o), __shfl_xor(__double2loint(s2), o));
+        }
+        const double n = (double)cg * (double)L;
+        const double mean_d = s1 / n;
+        double var_d = s2 / n - mean_d * mean_d;
+        var_d = var_d > 0.0 ? var_d : 0.0;
+        const float rstd = (float)(1.0 / sqrt(var_d + (double)a.gn_eps));
+        ag = a.gn_gamma[h] * rstd;
+        ab = a.gn_beta[h] - (float)mean_d * ag;
+    }
     float w[R], acc[R], u0[R];
+    float* uw = us[wave];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         u0[r] = u[r] * ag + ab;
         w[r] = u0[r];
         acc[r] = 0.f;
-        us[wave][L + lane * R + r] = u0[r];
-        us[wave][lane * R + r] = 0.f;
+        const int i1 = L + lane * R + r, i0 = lane * R + r;
+        uw[i1 + (i1 >> 5)] = u0[r];
+        uw[i0 + (i0 >> 5)] = 0.f;                      // causal padding: u[t] = 0 for t < 0
     }
     __syncthreads();
-    const float* uw = &us[wave][L + lane * R - 1];          // uw[-s] = u[t0 - s - 1]
+    const int base = L + lane * R - 1;                     // sample index of u[t0 - 1]
     for (int s = 0; s < L; s += R) {
         float kv[R];
 #pragma unroll
@@ -154,7 +182,8 @@ __global__ __launch_bounds__(256) void s4_conv_fast_kernel(const S4ConvArgs a) {
         for (int j = 0; j < R; ++j) {
 #pragma unroll
             for (int r = 0; r < R; ++r) acc[r] += kv[j] * w[(r - j + R) % R];      // w[(r-j) mod R] holds u[t0 + r - (s+j)]
-            w[(2 * R - 1 - j) % R] = uw[-(s + j)];                                   // u[t0 - (s+j) - 1] for the next tap
+            const int i = base - (s + j);
+            w[(2 * R - 1 - j) % R] = uw[i + (i >> 5)];                               // u[t0 - (s+j) - 1] for the next tap
         }
     }
     if (live) {
@@ -173,8 +202,12 @@ void launch_s4_kernel_gen(hipStream_t st, const S4GenArgs& a) {
     hipLaunchKernelGGL(s4_kernel_gen_kernel, dim3(a.H), dim3(256), 0, st, a);
 }
 
+bool s4_conv_fuses_group_norm(int L) { return L == 64 || L == 128 || L == 256 || L == 512; }
+
 void launch_s4_conv(hipStream_t st, const S4ConvArgs& a) {
     MUGD_CHECK(a.L <= S4_LMAX, -2, "s4: sequence longer than 4096");
+    MUGD_CHECK(!a.gn_gamma || a.aff || (s4_conv_fuses_group_norm(a.L) && a.gn_groups > 0 && a.H % a.gn_groups == 0), -2,
+               "s4: in-kernel GroupNorm needs L in {64,128,256,512}");
     const dim3 gf(a.H, cdiv(a.B, 4));
     switch (a.L) {
         case 64: hipLaunchKernelGGL((s4_conv_fast_kernel<1>), gf, dim3(256), 0, st, a); break;

@@ -142,7 +142,11 @@ struct S4ConvArgs {      // y = gelu( causal_conv(k, u') + D*u' ),  u,y: (B,H,L)
     const float* u; const float* k; const float* D; float* y;
     int B, H, L;
     const float* aff;    // null, or (B, H, 2) {g, b}: the GroupNorm in front of the S4 layer (unet.py:86-88)
+    // or (fast kernel only, aff == null): the GroupNorm itself -- every workgroup reduces its own group (H/groups rows of L
+    // samples per batch row: <= 32 KiB, L2-resident), which costs less than the separate statistics launch it replaces
+    const float* gn_gamma; const float* gn_beta; int gn_groups; float gn_eps;
 };
+bool s4_conv_fuses_group_norm(int L);
 void launch_s4_conv(hipStream_t st, const S4ConvArgs& a);
 
 // ---------------------------------------------------------------------------------------

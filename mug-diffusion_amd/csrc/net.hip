@@ -462,11 +462,13 @@ Tensor Net::s4_layer(const std::string& prefix, const Tensor& x) {
     const size_t mk = arena.mark();
     const float* aff = nullptr;
     Tensor u = x;
-    if (ctx->fuse_norm) aff = gn_stats(prefix + ".norm", {x}, 32);
-    else u = group_norm(prefix + ".norm", {x}, 32, false);
+    const bool in_kernel_gn = ctx->fuse_norm && s4_conv_fuses_group_norm(L) && H % 32 == 0;
+    if (!ctx->fuse_norm) u = group_norm(prefix + ".norm", {x}, 32, false);
+    else if (!in_kernel_gn) aff = gn_stats(prefix + ".norm", {x}, 32);
     const float* k = s4_kernel(prefix + ".s4_model.kernel.kernel", H, L);
     Tensor y = talloc(H, L);
-    S4ConvArgs ca{u.p, k, PF(prefix + ".s4_model.D"), y.p, Bn, H, L, aff};
+    S4ConvArgs ca{u.p, k, PF(prefix + ".s4_model.D"), y.p, Bn, H, L, aff,
+                  in_kernel_gn ? PF(prefix + ".norm.weight") : nullptr, in_kernel_gn ? PF(prefix + ".norm.bias") : nullptr, 32, 1e-6f};
     emit([ca](hipStream_t st) { launch_s4_conv(st, ca); }, OP_S4_CONV, 0, prefix + " H=" + std::to_string(H) + " L=" + std::to_string(L));
     ConvSpec gl;
     gl.key = prefix + ".s4_model.output_linear.0";

@@ -172,3 +172,15 @@ def test_convertor_threshold_contract():
     assert conv.array_to_objects(a, BeatmapMeta(cs=4)) == host.array_to_objects(a, conv.frame_ms)
     gs, gh = conv.note_grid(a)
     assert (gs == (a[0:4] > 0)).all() and (gh == (a[8:12] > 0)).all()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/mug"), reason="needs the reference checkout (authoring container only)")
+def test_non_hot_path_modules_fall_through_to_the_reference():
+    """the drop-in shadows only the hot path; e.g. mug.lr_scheduler / mug.data.utils stay the reference's files."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(1, '/root/reference'); "
+            "import mug.diffusion.unet as u, mug.lr_scheduler as l; print(u.__file__); print(l.__file__)"
+            % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mug-diffusion_amd"))
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True, check=True).stdout.split()
+    assert "mug-diffusion_amd" in out[0] and out[1].startswith("/root/reference/")
