@@ -157,6 +157,10 @@ int mugd_op_attention(mugd_ctx* ctx, const float* q, const float* k, const float
 int mugd_op_s4_kernel(mugd_ctx* ctx, const float* C, const float* Bp, const float* P, const float* inv_w_real,
                       const float* w_imag, const float* log_dt, float* k, int H, int N, int Lint, int L);
 int mugd_op_s4_conv(mugd_ctx* ctx, const float* u, const float* k, const float* D, float* y, int B, int H, int L);
+/* S4Layer front half as the U-Net runs it (unet.py:86-88 + s4.py:1503-1531): y = gelu(causal_conv(k, GroupNorm(u)) + D*GroupNorm(u)),
+ * GroupNorm(groups, eps 1e-6) statistics computed inside the convolution kernel when L is 64, 128, 256 or 512. */
+int mugd_op_gn_s4_conv(mugd_ctx* ctx, const float* u, const float* k, const float* D, const float* gamma, const float* beta,
+                       int groups, float* y, int B, int H, int L);
 int mugd_op_timestep_embedding(mugd_ctx* ctx, const int64_t* t, float* out, int B, int dim);
 
 #ifdef __cplusplus

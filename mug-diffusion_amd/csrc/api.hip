@@ -402,6 +402,27 @@ int mugd_op_s4_conv(mugd_ctx* ctx, const float* u, const float* k, const float* 
     });
 }
 
+int mugd_op_gn_s4_conv(mugd_ctx* ctx, const float* u, const float* k, const float* D, const float* gamma, const float* beta,
+                       int groups, float* y, int B, int H, int L) {
+    return guarded(ctx, [&] {
+        hipStream_t st = ctx->c.stream;
+        Scratch sc;
+        S4ConvArgs a{u, k, D, y, B, H, L, nullptr, nullptr, nullptr, 0, 0.f};
+        if (s4_conv_fuses_group_norm(L) && H % groups == 0) {
+            a.gn_gamma = gamma; a.gn_beta = beta; a.gn_groups = groups; a.gn_eps = 1e-6f;
+        } else {
+            float* aff = sc.get((size_t)B * H * 2, false, st);
+            GnStatArgs g{};
+            g.seg[0] = NormSeg{u, H, 0};
+            g.nseg = 1; g.Ctot = H; g.T = L; g.groups = groups; g.B = B; g.gamma = gamma; g.beta = beta; g.eps = 1e-6f; g.aff = aff;
+            launch_gn_stats(st, g);
+            a.aff = aff;
+        }
+        launch_s4_conv(st, a);
+        HIP_CHECK(hipStreamSynchronize(st));
+    });
+}
+
 int mugd_op_timestep_embedding(mugd_ctx* ctx, const int64_t* t, float* out, int B, int dim) {
     return guarded(ctx, [&] { launch_timestep_embedding(ctx->c.stream, (const long long*)t, nullptr, out, B, dim); });
 }

@@ -120,7 +120,7 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
         lh[j] = wave_base + (r * RS + (e < hw ? HL + col : 60 + q)) * 4;      // dead lanes park in columns no tap reads
     }
     // ---- operand transform constants
-    const int xf = XFK >= 0 ? XFK : s.xf, act = ACT >= 0 ? ACT : s.act;
+    const int xf = XFK >= 0 ? XFK : (s.xf == 3 ? 2 : s.xf), act = ACT >= 0 ? ACT : s.act;
     float mu[8], rs8[8];
     float muh[NH > 0 ? NH : 1], rsh[NH > 0 ? NH : 1];
 #pragma unroll
@@ -132,15 +132,52 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
         gb = s.xf_a + (size_t)b * s.xf_stride + 2 * ((size_t)lo * CONV_CK + r);
     } else if (xf == 2) {
         gb = s.xf_b + 2 * ((size_t)lo * CONV_CK + r);
-        const float* cs = s.xf_a + (size_t)b * s.xf_stride;
+        if (s.xf == 3) {
+            // LayerNorm statistics from the producer's column sums: this lane's 8 samples x xf_np row tiles, all loads in flight
+            const float* ps = s.xf_a + (size_t)b * s.xf_stride;
+            const int tq0 = ok0 ? ti0 : Tin - 4, tq1 = ok1 ? ti1 : Tin - 4;
+            double s1[8], s2[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int t = ti0 + i;
-            t = t < Tin ? t : Tin - 1;
-            mu[i] = cs[2 * t]; rs8[i] = cs[2 * t + 1];
+            for (int i = 0; i < 8; ++i) { s1[i] = 0.0; s2[i] = 0.0; }
+            for (int p0 = 0; p0 < s.xf_np; p0 += 4) {
+                float4 v[4][4];
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+                    const int pc = p0 + pp < s.xf_np ? p0 + pp : s.xf_np - 1;
+                    const float4* row = reinterpret_cast<const float4*>(ps + (size_t)pc * Tin * 2);
+                    v[pp][0] = row[tq0 / 2]; v[pp][1] = row[tq0 / 2 + 1]; v[pp][2] = row[tq1 / 2]; v[pp][3] = row[tq1 / 2 + 1];
+                }
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+                    if (p0 + pp < s.xf_np) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            s1[2 * j] += (double)v[pp][j].x; s2[2 * j] += (double)v[pp][j].y;
+                            s1[2 * j + 1] += (double)v[pp][j].z; s2[2 * j + 1] += (double)v[pp][j].w;
+                        }
+                    }
+                }
+            }
+            const double inv = 1.0 / (double)s.C;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const double m = s1[i] * inv;
+                double var = s2[i] * inv - m * m;
+                var = var > 0.0 ? var : 0.0;
+                mu[i] = (float)m;
+                rs8[i] = (float)(1.0 / sqrt(var + (double)s.xf_eps));
+            }
+        } else {
+            const float* cs = s.xf_a + (size_t)b * s.xf_stride;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int t = ti0 + i;
+                t = t < Tin ? t : Tin - 1;
+                mu[i] = cs[2 * t]; rs8[i] = cs[2 * t + 1];
+            }
+#pragma unroll
+            for (int j = 0; j < NH; ++j) { muh[j] = cs[gh[j] / 4u % (unsigned)Tin * 2]; rsh[j] = cs[gh[j] / 4u % (unsigned)Tin * 2 + 1]; }
         }
-#pragma unroll
-        for (int j = 0; j < NH; ++j) { muh[j] = cs[gh[j] / 4u % (unsigned)Tin * 2]; rsh[j] = cs[gh[j] / 4u % (unsigned)Tin * 2 + 1]; }
     }
 
     const int bb = s.bmod > 0 ? b % s.bmod : b;
@@ -470,7 +507,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
         case 4: run_segment_vec<T, DUAL, NHALO, 1, 0, MUGD_PIPE>(MUGD_SEG_ARGS); break;                      \
         case 5: run_segment_vec<T, DUAL, NHALO, 1, 1, MUGD_PIPE>(MUGD_SEG_ARGS); break;                      \
         case 6: run_segment_vec<T, DUAL, NHALO, 1, 2, MUGD_PIPE>(MUGD_SEG_ARGS); break;                      \
-        case 8: run_segment_vec<T, DUAL, NHALO, 2, 0, MUGD_PIPE>(MUGD_SEG_ARGS); break;                      \
+        case 8: case 12: run_segment_vec<T, DUAL, NHALO, 2, 0, MUGD_PIPE>(MUGD_SEG_ARGS); break;            \
         default: run_segment_vec<T, DUAL, NHALO>(MUGD_SEG_ARGS);                                  \
     }
                     if (DUAL || s.taps == 1) { MUGD_SEG_XF(1, 0) }
@@ -526,6 +563,30 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
         }
         v = (v + ra[q]) + rsv[q];
         if (valid[q]) a.y[oo[q]] = v;
+        acc_v[q] = v;
+    }
+    // ---- optional: {sum, sum of squares} of this tile's final values per column, for the LayerNorm of the consumer
+    if (!DUAL && a.colstat) {
+        __shared__ float cst[2][WK][32];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int r = wave * EPT + q;
+            const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float v = m < a.Mout ? acc_v[q] : 0.f;
+            s1 += v; s2 += v * v;
+        }
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (h == 0) { cst[0][wave][n] = s1; cst[1][wave][n] = s2; }
+        __syncthreads();
+        if (tid < 32 && t0 + tid < a.Tout) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WK; ++w) { t1 += cst[0][w][tid]; t2 += cst[1][w][tid]; }
+            float* o = a.colstat + 2 * (((size_t)b * gy + mt) * a.Tout + t0 + tid);
+            o[0] = t1; o[1] = t2;
+        }
     }
 }
 
@@ -583,7 +644,9 @@ void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
         MUGD_CHECK(s.taps == 1 || s.taps == 3, -2, "conv_gemm: taps must be 1 or 3");
         MUGD_CHECK(s.dil >= 1 && (s.stride == 1 || s.stride == 2), -2, "conv_gemm: bad dilation / stride");
         MUGD_CHECK((long long)CONV_CK * s.Tin * 4 < (1ll << 31), -2, "conv_gemm: sequence too long for 32-bit window offsets");
-        MUGD_CHECK(s.xf >= 0 && s.xf <= 2 && (s.xf == 0 || s.xf_a) && (s.xf != 2 || s.xf_b), -2, "conv_gemm: bad operand transform");
+        MUGD_CHECK(s.xf >= 0 && s.xf <= 3 && (s.xf == 0 || s.xf_a) && (s.xf < 2 || s.xf_b), -2, "conv_gemm: bad operand transform");
+        MUGD_CHECK(s.xf != 3 || (s.taps == 1 && s.stride == 1 && !s.ups && (s.Tin & 3) == 0 && s.xf_np > 0), -2,
+                   "conv_gemm: LayerNorm from producer sums needs a 1x1 fast-path segment");
         if (all_vec) {
             const int hw = (s.taps - 1) * s.dil;
             MUGD_CHECK(hw <= 16 && s.pad <= hw && HL + 32 + (hw - s.pad) <= CONV_RS, -2, "conv_gemm: window exceeds LDS row");
@@ -602,6 +665,7 @@ void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
         for (int i = 0; i < a.nseg; ++i) MUGD_CHECK(a.seg[i].xf == 0, -2, "conv_gemm: no operand transform in a kernel with a strided / widely dilated generic segment");
     const int kind = all_vec ? (lean ? 0 : 1) : 2;
     const bool dual = a.epi != EPI_NONE;
+    MUGD_CHECK(!a.colstat || !dual, -2, "conv_gemm: column sums are not produced by gated epilogues");
     if (dual) {
         MUGD_CHECK(a.Mout % 32 == 0 && a.Mrows == 2 * a.Mout, -2, "conv_gemm: gated epilogue needs Mout % 32 == 0");
         for (int i = 0; i < a.nseg; ++i) MUGD_CHECK(a.seg[i].taps == 1, -2, "conv_gemm: gated epilogue is implemented for 1x1 convs");

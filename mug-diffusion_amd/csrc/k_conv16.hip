@@ -61,7 +61,7 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
         gh = (unsigned)(r * Tin + tc) * 4u;
         lh = wave_base + (r * RS + (e < hw ? HL + col : 40 + q)) * 4;      // dead lanes park in columns no tap reads
     }
-    const int xf = XFK >= 0 ? XFK : s.xf, act = ACT >= 0 ? ACT : s.act;
+    const int xf = XFK >= 0 ? XFK : (s.xf == 3 ? 2 : s.xf), act = ACT >= 0 ? ACT : s.act;
     float mu[4], rs4[4], muh = 0.f, rsh = 1.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { mu[i] = 0.f; rs4[i] = 1.f; }
@@ -70,14 +70,50 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
         gb = s.xf_a + (size_t)b * s.xf_stride + 2 * ((size_t)lo * CONV_CK + r);
     } else if (xf == 2) {
         gb = s.xf_b + 2 * ((size_t)lo * CONV_CK + r);
-        const float* cs = s.xf_a + (size_t)b * s.xf_stride;
+        if (s.xf == 3) {                     // LayerNorm statistics from the producer's column sums (see k_conv.hip)
+            const float* ps = s.xf_a + (size_t)b * s.xf_stride;
+            const int tq = ok0 ? ti : Tin - 4;
+            double s1[4], s2[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int t = ti + i;
-            t = t < Tin ? t : Tin - 1;
-            mu[i] = cs[2 * t]; rs4[i] = cs[2 * t + 1];
+            for (int i = 0; i < 4; ++i) { s1[i] = 0.0; s2[i] = 0.0; }
+            for (int p0 = 0; p0 < s.xf_np; p0 += 4) {
+                float4 v[4][2];
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+                    const int pc = p0 + pp < s.xf_np ? p0 + pp : s.xf_np - 1;
+                    const float4* row = reinterpret_cast<const float4*>(ps + (size_t)pc * Tin * 2);
+                    v[pp][0] = row[tq / 2]; v[pp][1] = row[tq / 2 + 1];
+                }
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+                    if (p0 + pp < s.xf_np) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            s1[2 * j] += (double)v[pp][j].x; s2[2 * j] += (double)v[pp][j].y;
+                            s1[2 * j + 1] += (double)v[pp][j].z; s2[2 * j + 1] += (double)v[pp][j].w;
+                        }
+                    }
+                }
+            }
+            const double inv = 1.0 / (double)s.C;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double m = s1[i] * inv;
+                double var = s2[i] * inv - m * m;
+                var = var > 0.0 ? var : 0.0;
+                mu[i] = (float)m;
+                rs4[i] = (float)(1.0 / sqrt(var + (double)s.xf_eps));
+            }
+        } else {
+            const float* cs = s.xf_a + (size_t)b * s.xf_stride;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int t = ti + i;
+                t = t < Tin ? t : Tin - 1;
+                mu[i] = cs[2 * t]; rs4[i] = cs[2 * t + 1];
+            }
+            if (NH) { const unsigned tc = gh / 4u % (unsigned)Tin; muh = cs[2 * tc]; rsh = cs[2 * tc + 1]; }
         }
-        if (NH) { const unsigned tc = gh / 4u % (unsigned)Tin; muh = cs[2 * tc]; rsh = cs[2 * tc + 1]; }
     }
     const int bb = s.bmod > 0 ? b % s.bmod : b;
     const char* xb = reinterpret_cast<const char*>(s.x + ((size_t)bb * s.C + (size_t)lo * CONV_CK) * Tin);
@@ -298,7 +334,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
         case 4: run_segment16<T, DUAL, 1, 0, true>(MUGD_SEG16_ARGS); break;                     \
         case 5: run_segment16<T, DUAL, 1, 1, true>(MUGD_SEG16_ARGS); break;                     \
         case 6: run_segment16<T, DUAL, 1, 2, true>(MUGD_SEG16_ARGS); break;                     \
-        case 8: run_segment16<T, DUAL, 2, 0, true>(MUGD_SEG16_ARGS); break;                     \
+        case 8: case 12: run_segment16<T, DUAL, 2, 0, true>(MUGD_SEG16_ARGS); break;            \
         default: run_segment16<T, DUAL>(MUGD_SEG16_ARGS);                                 \
     }
                 if (DUAL || s.taps == 1) { MUGD_SEG16_XF(1) }
@@ -342,6 +378,29 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
         }
         v = (v + ra[q]) + rsv[q];
         if (valid[q]) a.y[oo[q]] = v;
+        acc_v[q] = v;
+    }
+    if (!DUAL && a.colstat) {            // per-column {sum, sum of squares} of the tile's final values (see k_conv.hip)
+        __shared__ float cst[2][WK][16];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int r = wave * EPT + q;
+            const int m = mt * 32 + 16 * (r >> 2) + 4 * kq + (r & 3);
+            const float v = m < a.Mout ? acc_v[q] : 0.f;
+            s1 += v; s2 += v * v;
+        }
+        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        if (kq == 0) { cst[0][wave][l15] = s1; cst[1][wave][l15] = s2; }
+        __syncthreads();
+        if (tid < 16 && t0 + tid < a.Tout) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WK; ++w) { t1 += cst[0][w][tid]; t2 += cst[1][w][tid]; }
+            float* o = a.colstat + 2 * (((size_t)b * gy + mt) * a.Tout + t0 + tid);
+            o[0] = t1; o[1] = t2;
+        }
     }
 }
 
@@ -396,9 +455,11 @@ void launch_conv_gemm16(hipStream_t st, const ConvArgs& a) {
         const ConvSeg& s = a.seg[i];
         MUGD_CHECK(s.C % CONV_CK == 0, -2, "conv_gemm16: channels must be a multiple of 16");
         MUGD_CHECK((long long)CONV_CK * s.Tin * 4 < (1ll << 31), -2, "conv_gemm16: sequence too long for 32-bit window offsets");
-        MUGD_CHECK(s.xf >= 0 && s.xf <= 2 && (s.xf == 0 || s.xf_a) && (s.xf != 2 || s.xf_b), -2, "conv_gemm16: bad operand transform");
+        MUGD_CHECK(s.xf >= 0 && s.xf <= 3 && (s.xf == 0 || s.xf_a) && (s.xf < 2 || s.xf_b), -2, "conv_gemm16: bad operand transform");
+        MUGD_CHECK(s.xf != 3 || (s.taps == 1 && s.xf_np > 0), -2, "conv_gemm16: LayerNorm from producer sums needs a 1x1 segment");
     }
     const bool dual = a.epi != EPI_NONE;
+    MUGD_CHECK(!a.colstat || !dual, -2, "conv_gemm16: column sums are not produced by gated epilogues");
     if (dual) MUGD_CHECK(a.Mout % 32 == 0 && a.Mrows == 2 * a.Mout, -2, "conv_gemm16: gated epilogue needs Mout % 32 == 0");
     else MUGD_CHECK(a.Mrows == a.Mout, -2, "conv_gemm16: Mrows != Mout");
     const int gx = cdiv(a.Tout, 16), gy = cdiv(a.Mout, 32), gz = a.B;

@@ -115,82 +115,98 @@ __global__ __launch_bounds__(256) void s4_conv_kernel(const S4ConvArgs a) {
 }
 
 
-// Fast path for L = 64 R, R in {1,2,4,8} (the U-Net levels at z = 512): one wavefront per (batch, feature)
-// row, lane l owns the R consecutive outputs t = l R .. l R + R-1 and keeps the R inputs u[t - s] it
-// needs in a register window that slides by one sample per tap (one LDS read per tap per lane, k[s]
-// read as broadcast vectors), so the inner loop is R FMAs per ~1.25 LDS reads.  The 4 waves of a
-// workgroup take 4 batch rows of the same feature and share its kernel row.  Causality is a
-// zero-filled prefix of the LDS copy of u (branch-free).
+// Fast path for L = 64 R, R in {1,2,4,8} (the U-Net levels at z = 512): one workgroup per (batch, feature) row.
+// The 4 waves split the TAP range (wave w takes taps [w L/4, (w+1) L/4) of every output); inside a wave, lane l owns
+// the R consecutive outputs t = l R .. l R + R-1 and keeps the R inputs u[t - s] it needs in a register window that
+// slides by one sample per tap (one LDS read per tap per lane, k[s] read as broadcast vectors): R FMAs per ~1.25 LDS
+// reads.  Causality is a zero-filled prefix of the LDS copy of u (branch-free); one pad word per 32 samples (index i
+// lives at i + i/32) makes the stride-R window reads conflict-free.  The 4 partial sums per output are combined through
+// LDS in fixed order.  With a.gn_gamma the workgroup also computes the GroupNorm statistics of its (batch row, group)
+// itself (cg rows of L samples: <= 32 KiB, L2-resident) instead of a separate statistics launch.
 template <int R>
 __global__ __launch_bounds__(256) void s4_conv_fast_kernel(const S4ConvArgs a) {
     constexpr int L = 64 * R;
-    // lane l reads u[l R + const]: a stride-R walk of the LDS banks.  One pad word per 32 samples
-    // (index i lives at i + i/32) makes that conflict-free for R = 2, 4, 8 and leaves unit-stride accesses alone.
     constexpr int LP = 2 * L + (2 * L) / 32;
+    constexpr int SEG = L / 4;                       // taps per wave
     __shared__ __attribute__((aligned(16))) float ks[L];
-    __shared__ float us[4][LP];
-    const int h = blockIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int b = blockIdx.y * 4 + wave;
-    const bool live = b < a.B;
-    const int bc = live ? b : a.B - 1;
-    for (int t = threadIdx.x; t < L; t += 256) ks[t] = a.k[(size_t)h * L + t];
-    const float* u = a.u + ((size_t)bc * a.H + h) * L + lane * R;
+    __shared__ float uw[LP];
+    __shared__ float part[4][L];
+    __shared__ double red[2][4];
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const float* u = a.u + ((size_t)b * a.H + h) * L;
+
     float ag = 1.f, ab = 0.f;
     if (a.aff) {
-        ag = a.aff[2 * ((size_t)bc * a.H + h)]; ab = a.aff[2 * ((size_t)bc * a.H + h) + 1];
+        ag = a.aff[2 * ((size_t)b * a.H + h)]; ab = a.aff[2 * ((size_t)b * a.H + h) + 1];
     } else if (a.gn_gamma) {
-        // GroupNorm statistics of (batch row bc, group of channel h), by this wave: cg rows x L samples, one pass, fp64 sums
         const int cg = a.H / a.gn_groups, c0 = (h / cg) * cg;
-        const float* ug = a.u + ((size_t)bc * a.H + c0) * L + lane * R;
+        const float* ug = a.u + ((size_t)b * a.H + c0) * L;
+        const int n = cg * L;                        // multiple of 256
         double s1 = 0.0, s2 = 0.0;
-        for (int c = 0; c < cg; ++c) {
+        for (int base = tid; base < n; base += 256 * 8) {
+            float v[8];
 #pragma unroll
-            for (int r = 0; r < R; ++r) { const double v = ug[(size_t)c * L + r]; s1 += v; s2 += v * v; }
+            for (int j = 0; j < 8; ++j) { const int i = base + j * 256; v[j] = ug[i < n ? i : n - 1]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (base + j * 256 < n) { s1 += (double)v[j]; s2 += (double)v[j] * (double)v[j]; }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             s1 += __hiloint2double(__shfl_xor(__double2hiint(s1), o), __shfl_xor(__double2loint(s1), o));
             s2 += __hiloint2double(__shfl_xor(__double2hiint(s2), o), __shfl_xor(__double2loint(s2), o));
         }
-        const double n = (double)cg * (double)L;
-        const double mean_d = s1 / n;
-        double var_d = s2 / n - mean_d * mean_d;
+        if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+        __syncthreads();
+        const double nn = (double)n;
+        const double mean_d = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / nn;
+        double var_d = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / nn - mean_d * mean_d;
         var_d = var_d > 0.0 ? var_d : 0.0;
         const float rstd = (float)(1.0 / sqrt(var_d + (double)a.gn_eps));
         ag = a.gn_gamma[h] * rstd;
         ab = a.gn_beta[h] - (float)mean_d * ag;
     }
-    float w[R], acc[R], u0[R];
-    float* uw = us[wave];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        u0[r] = u[r] * ag + ab;
-        w[r] = u0[r];
-        acc[r] = 0.f;
-        const int i1 = L + lane * R + r, i0 = lane * R + r;
-        uw[i1 + (i1 >> 5)] = u0[r];
-        uw[i0 + (i0 >> 5)] = 0.f;                      // causal padding: u[t] = 0 for t < 0
+    for (int i = tid; i < L; i += 256) {
+        ks[i] = a.k[(size_t)h * L + i];
+        const int i1 = L + i;
+        uw[i1 + (i1 >> 5)] = u[i] * ag + ab;
+        uw[i + (i >> 5)] = 0.f;                      // causal padding: u[t] = 0 for t < 0
     }
     __syncthreads();
-    const int base = L + lane * R - 1;                     // sample index of u[t0 - 1]
-    for (int s = 0; s < L; s += R) {
+
+    const int t0 = lane * R, s0 = wave * SEG;
+    float w[R], acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = L + t0 + r - s0;
+        w[r] = uw[i + (i >> 5)];
+        acc[r] = 0.f;
+    }
+    const int base = L + t0 - 1 - s0;                // sample index of u[t0 - s0 - 1]
+    constexpr int STEP = R < SEG ? R : SEG;          // R = 1: SEG = 16 taps, one per iteration
+    for (int s = 0; s < SEG; s += STEP) {
         float kv[R];
 #pragma unroll
-        for (int j = 0; j < R; ++j) kv[j] = ks[s + j];
+        for (int j = 0; j < STEP; ++j) kv[j] = ks[s0 + s + j];
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
+        for (int j = 0; j < STEP; ++j) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] += kv[j] * w[(r - j + R) % R];      // w[(r-j) mod R] holds u[t0 + r - (s+j)]
+            for (int r = 0; r < R; ++r) acc[r] += kv[j] * w[(r - j + R) % R];      // w[(r-j) mod R] holds u[t0 + r - (s0+s+j)]
             const int i = base - (s + j);
-            w[(2 * R - 1 - j) % R] = uw[i + (i >> 5)];                               // u[t0 - (s+j) - 1] for the next tap
+            w[(2 * R - 1 - j) % R] = uw[i + (i >> 5)];                               // u[t0 - (s0+s+j) - 1] for the next tap
         }
     }
-    if (live) {
-        const float Dh = a.D[h];
-        float* y = a.y + ((size_t)b * a.H + h) * L + lane * R;
 #pragma unroll
-        for (int r = 0; r < R; ++r) y[r] = gelu_erf_f(acc[r] + Dh * u0[r]);
+    for (int r = 0; r < R; ++r) part[wave][t0 + r] = acc[r];
+    __syncthreads();
+    const float Dh = a.D[h];
+    float* y = a.y + ((size_t)b * a.H + h) * L;
+    for (int i = tid; i < L; i += 256) {
+        const int i1 = L + i;
+        const float conv = ((part[0][i] + part[1][i]) + part[2][i]) + part[3][i];
+        y[i] = gelu_erf_f(conv + Dh * uw[i1 + (i1 >> 5)]);
     }
 }
 
@@ -208,7 +224,7 @@ void launch_s4_conv(hipStream_t st, const S4ConvArgs& a) {
     MUGD_CHECK(a.L <= S4_LMAX, -2, "s4: sequence longer than 4096");
     MUGD_CHECK(!a.gn_gamma || a.aff || (s4_conv_fuses_group_norm(a.L) && a.gn_groups > 0 && a.H % a.gn_groups == 0), -2,
                "s4: in-kernel GroupNorm needs L in {64,128,256,512}");
-    const dim3 gf(a.H, cdiv(a.B, 4));
+    const dim3 gf(a.H, a.B);
     switch (a.L) {
         case 64: hipLaunchKernelGGL((s4_conv_fast_kernel<1>), gf, dim3(256), 0, st, a); break;
         case 128: hipLaunchKernelGGL((s4_conv_fast_kernel<2>), gf, dim3(256), 0, st, a); break;

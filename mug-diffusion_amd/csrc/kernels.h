@@ -34,10 +34,14 @@ struct ConvSeg {
     int bmod;         // >0: read batch row (b % bmod)  (CFG halves share one copy of the audio maps)
     // operand transform applied while the window is staged (GroupNorm / LayerNorm are never materialised):
     int xf;           // 0 none | 1 v = x*g + b with {g,b} per (batch, channel) | 2 v = (x-mean)*rstd*g + b with {mean,rstd} per (batch, sample), {g,b} per channel
+                      // | 3 as 2, but {mean,rstd} are derived in the kernel prologue from the PRODUCER's per-row-tile column sums (ConvArgs::colstat)
     int act;          // 1: SiLU after the transform
     const float* xf_a;    // xf=1: {g,b} of this segment's first channel, batch stride xf_stride | xf=2: {mean,rstd} (B, Tin, 2), batch stride xf_stride
+                          // | xf=3: {sum, sum of squares} (B, xf_np, Tin, 2) over the 32-row tiles of the producer, batch stride xf_stride
     const float* xf_b;    // xf=2: {gamma,beta} (C, 2)
     int xf_stride;        // floats per batch row of xf_a
+    int xf_np;            // xf=3: number of row tiles summed per column
+    float xf_eps;         // xf=3: LayerNorm eps
 };
 
 enum { EPI_NONE = 0, EPI_GLU = 1, EPI_GEGLU = 2 };
@@ -53,6 +57,8 @@ struct ConvArgs {
     const float* resid;      // (B, Mout, Tout) or null
     float* y;                // (B, Mout, Tout)
     int B, Mrows, Mout, Tout, nchunk, epi;
+    float* colstat;          // null, or (B, ceil(Mout/32), Tout, 2): per output tile and column {sum, sum of squares} of the final values over
+                             // the tile's rows -- the LayerNorm statistics of the consumer without a statistics launch (non-gated epilogues)
     int wk;                  // K-split (waves per workgroup): 1|2|4|8, 0 = pick from the shape
     int tn;                  // output tile width: 32 (k_conv.hip) | 16 (k_conv16.hip); decides the weight packing
 };

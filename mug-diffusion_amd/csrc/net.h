@@ -16,6 +16,9 @@ struct Tensor {
     float* p = nullptr;
     int C = 0, T = 0;
     int bmod = 0;     // >0: batch index is taken modulo bmod (CFG shares the audio maps of both halves)
+    // set by the conv that produced this tensor: per 32-row tile and column {sum, sum of squares} (ConvArgs::colstat)
+    float* colstat = nullptr;
+    int colstat_np = 0;
 };
 
 struct Param {
@@ -52,7 +55,7 @@ private:
 };
 
 // operand transform of one conv input (ConvSeg::xf): the GroupNorm / LayerNorm in front of the conv
-struct Xf { int kind = 0; int act = 0; const float* a = nullptr; const float* b = nullptr; int stride = 0; };
+struct Xf { int kind = 0; int act = 0; const float* a = nullptr; const float* b = nullptr; int stride = 0; int np = 0; float eps = 0.f; };
 struct ConvIn { Tensor x; int taps = 1, dil = 1, stride = 1, pad = 0, ups = 0; Xf xf; };
 struct WBlock { std::string name; int seg; int row_off; int ci_off; };
 struct ConvSpec {
@@ -65,6 +68,7 @@ struct ConvSpec {
     int rowadd_stride = 0;
     Tensor resid;
     Tensor out;
+    bool want_colstat = false;    // also emit the per-column sums a following LayerNorm needs (returned in Tensor::colstat)
 };
 
 struct PackedW {

@@ -209,6 +209,11 @@ Xf Net::layer_norm_xf(const std::string& prefix, const Tensor& x) {
         launch_interleave2(ctx->stream, PF(prefix + ".weight"), PF(prefix + ".bias"), gb, x.C);
         baked[key] = gb;
     }
+    if (x.colstat && x.T % 4 == 0) {             // statistics come from the producer conv's epilogue: no launch
+        Xf xf;
+        xf.kind = 3; xf.a = x.colstat; xf.b = gb; xf.stride = 2 * x.colstat_np * x.T; xf.np = x.colstat_np; xf.eps = 1e-5f;
+        return xf;
+    }
     float* stat = arena.alloc((size_t)Bn * x.T * 2);
     LnStatArgs a{x.p, stat, Bn, x.C, x.T, 1e-5f};
     emit([a](hipStream_t st) { launch_ln_stats(st, a); }, OP_LAYER_NORM, 0, prefix + " C=" + std::to_string(x.C) + " T=" + std::to_string(x.T));
@@ -266,7 +271,7 @@ Tensor Net::conv(const ConvSpec& s) {
     for (int i = 0; i < a.nseg; ++i) {
         const ConvIn& in = s.in[i];
         a.seg[i] = ConvSeg{in.x.p, in.x.C, in.x.T, in.taps, in.dil, in.stride, in.pad, in.ups, 0, 0, in.x.bmod,
-                           in.xf.kind, in.xf.act, in.xf.a, in.xf.b, in.xf.stride};
+                           in.xf.kind, in.xf.act, in.xf.a, in.xf.b, in.xf.stride, in.xf.np, in.xf.eps};
     }
     a.B = Bn; a.Mrows = s.Mrows; a.Mout = s.Mout; a.Tout = s.Tout; a.epi = s.epi;
     a.wk = ctx->force_wk;
@@ -278,6 +283,15 @@ Tensor Net::conv(const ConvSpec& s) {
     a.resid = s.resid.p;
     if (s.resid.p) MUGD_CHECK(s.resid.C == s.Mout && s.resid.T == s.Tout && s.resid.bmod == 0, -2, "conv: residual shape mismatch at " + s.key);
     a.y = y.p; a.nchunk = pw.nchunk;
+    if (s.want_colstat && ctx->fuse_norm && s.epi == EPI_NONE && s.Tout % 4 == 0) {
+        bool fast = true;                                   // only the fast-window kernels emit column sums
+        for (auto& in : s.in) fast = fast && in.stride == 1 && !in.ups && in.x.T % 4 == 0 && (in.taps == 1 || in.dil == 1);
+        if (fast) {
+            y.colstat_np = cdiv(s.Mout, 32);
+            y.colstat = arena.alloc((size_t)Bn * y.colstat_np * s.Tout * 2);
+            a.colstat = y.colstat;
+        }
+    }
     double kdim = 0;
     for (auto& in : s.in) kdim += (double)in.x.C * in.taps;
     emit([a](hipStream_t st) { launch_conv(st, a); }, s.epi ? OP_CONV_GATED : OP_CONV, 2.0 * s.Mrows * kdim * s.Tout * Bn,
@@ -343,9 +357,10 @@ Tensor Net::transformer(const std::string& prefix, const Tensor& x, const Tensor
         to_pre = save;
     }
     const size_t mk = arena.mark();
-    auto lin = [&](const std::string& key, const ConvIn& in, bool bias, const Tensor& resid, const Tensor& dst) {
+    auto lin = [&](const std::string& key, const ConvIn& in, bool bias, const Tensor& resid, const Tensor& dst, bool feeds_ln = false) {
         ConvSpec s;
         s.key = key;
+        s.want_colstat = feeds_ln;
         s.in = {in};
         s.w = {WBlock{key + ".weight", 0, 0, 0}};
         if (bias) s.bias = {{key + ".bias", 0}};
@@ -363,9 +378,9 @@ Tensor Net::transformer(const std::string& prefix, const Tensor& x, const Tensor
         return attention(ap, qkv, qkv, qkv, C, heads, 0, C, 2 * C);
     };
 
-    Tensor h0 = lin(prefix + ".proj_in", gn_inputs(prefix + ".norm", {x}, 32, false, 1, 1, 0)[0], true, Tensor(), Tensor());
+    Tensor h0 = lin(prefix + ".proj_in", gn_inputs(prefix + ".norm", {x}, 32, false, 1, 1, 0)[0], true, Tensor(), Tensor(), true);
     Tensor a1 = self_attn(b + ".attn1", ln_input(b + ".norm1", h0));
-    Tensor h1 = lin(b + ".attn1.to_out.0", ConvIn{a1}, true, h0, Tensor());
+    Tensor h1 = lin(b + ".attn1.to_out.0", ConvIn{a1}, true, h0, Tensor(), true);
     const ConvIn n2 = ln_input(b + ".norm2", h1);
     Tensor a2;
     if (context) {
@@ -374,7 +389,7 @@ Tensor Net::transformer(const std::string& prefix, const Tensor& x, const Tensor
     } else {
         a2 = self_attn(b + ".attn2", n2);
     }
-    Tensor h2 = lin(b + ".attn2.to_out.0", ConvIn{a2}, true, h1, Tensor());
+    Tensor h2 = lin(b + ".attn2.to_out.0", ConvIn{a2}, true, h1, Tensor(), true);
     Tensor f;
     {
         ConvSpec ff;

@@ -67,6 +67,7 @@ _SIGS = {
     "mugd_op_attention": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i],
     "mugd_op_s4_kernel": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i],
     "mugd_op_s4_conv": [_p, _p, _p, _p, _p, _i, _i, _i],
+    "mugd_op_gn_s4_conv": [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i],
     "mugd_op_timestep_embedding": [_p, _p, _p, _i, _i],
 }
 EXPORTS = sorted(list(_SIGS) + ["mugd_destroy", "mugd_net_destroy", "mugd_last_error", "mugd_version",
@@ -287,6 +288,13 @@ class Lib:
         B, H, L = u.shape
         y = torch.empty_like(u)
         self.check(self.dll.mugd_op_s4_conv(self.ctx, _ptr(u), _ptr(k), _ptr(D), _ptr(y), B, H, L))
+        return y
+
+    def op_gn_s4_conv(self, u, k, D, gamma, beta, groups):
+        u, k, D, gamma, beta = map(self.f32, (u, k, D, gamma, beta))
+        B, H, L = u.shape
+        y = torch.empty_like(u)
+        self.check(self.dll.mugd_op_gn_s4_conv(self.ctx, _ptr(u), _ptr(k), _ptr(D), _ptr(gamma), _ptr(beta), groups, _ptr(y), B, H, L))
         return y
 
     def op_timestep_embedding(self, t, dim):

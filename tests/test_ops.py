@@ -210,6 +210,16 @@ def test_s4_conv(lib, B, H, L):
     close(lib.op_s4_conv(u, k, D), F.gelu(fft), 5e-5, what="s4 conv vs FFT form")
 
 
+@pytest.mark.parametrize("B,H,L,groups", [(3, 64, 64, 32), (2, 32, 128, 8), (1, 64, 256, 32), (5, 32, 512, 32), (2, 32, 40, 8)])
+def test_gn_s4_conv(lib, B, H, L, groups):
+    """GroupNorm fused into the S4 convolution kernel (in-kernel statistics for L = 64..512, stats kernel + affine otherwise)."""
+    u, k, D = rnd(23, B, H, L, scale=1.5) + 0.4, rnd(24, H, L, scale=0.2), rnd(25, H)
+    g, b = 1 + 0.1 * rnd(26, H), 0.1 * rnd(27, H)
+    n = F.group_norm(u, groups, g, b, eps=1e-6)
+    ref = F.gelu(s4o.s4_direct_conv(k, n, D).float())
+    close(lib.op_gn_s4_conv(u, k, D, g, b, groups), ref, 3e-5, what="GroupNorm + s4 conv")
+
+
 def test_timestep_embedding(lib):
     t = torch.tensor([1, 21, 501, 981], dtype=torch.long)
     ref = nets.timestep_embedding(t, 128)
