@@ -33,6 +33,7 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include "gn_wave.h"
 #include "kernels.h"
 
 #ifndef MUGD_PIPE
@@ -94,7 +95,7 @@ __device__ __forceinline__ void mfma_chunk(const char* smem_bytes, int rb0, int 
 template <int TAPS, bool DUAL, int NH, int XFK = -1, int ACT = -1, bool PIPE = false>
 __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* wseg, const float* wseg2, int lo, int hi,
                                                 int b, int t0, int lane, int h, int n, char* smem_bytes, int wave_base,
-                                                f32x16& acc, f32x16& acc2) {
+                                                f32x16& acc, f32x16& acc2, const float2* gst, float inv_cg) {
     const int r = lane >> 2, q = lane & 3;
     const int Tin = s.Tin;
     const int hw = (TAPS - 1) * s.dil;                     // halo samples per row (left pad + right rest)
@@ -120,7 +121,8 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
         lh[j] = wave_base + (r * RS + (e < hw ? HL + col : 60 + q)) * 4;      // dead lanes park in columns no tap reads
     }
     // ---- operand transform constants
-    const int xf = XFK >= 0 ? XFK : (s.xf == 3 ? 2 : s.xf), act = ACT >= 0 ? ACT : s.act;
+    const int xf = XFK >= 0 ? XFK : (s.xf == 3 ? 2 : s.xf == 4 ? 1 : s.xf), act = ACT >= 0 ? ACT : s.act;
+    const bool gn4 = s.xf == 4;                              // GroupNorm {g, b} from the wave's group table instead of a stats kernel's array
     float mu[8], rs8[8];
     float muh[NH > 0 ? NH : 1], rsh[NH > 0 ? NH : 1];
 #pragma unroll
@@ -129,40 +131,35 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
     for (int j = 0; j < NH; ++j) { muh[j] = 0.f; rsh[j] = 1.f; }
     const float* gb = nullptr;                            // per-channel {g, b} stream, advanced by 32 floats per chunk
     if (xf == 1) {
-        gb = s.xf_a + (size_t)b * s.xf_stride + 2 * ((size_t)lo * CONV_CK + r);
+        if (!gn4) gb = s.xf_a + (size_t)b * s.xf_stride + 2 * ((size_t)lo * CONV_CK + r);
     } else if (xf == 2) {
         gb = s.xf_b + 2 * ((size_t)lo * CONV_CK + r);
         if (s.xf == 3) {
-            // LayerNorm statistics from the producer's column sums: this lane's 8 samples x xf_np row tiles, all loads in flight
+            // LayerNorm statistics from the producer's column sums.  The 16 lanes that share this lane's 8 samples
+            // (same quarter q, rows r = 0..15) split the producer's row tiles between them -- lane r takes tiles r, r+16, ..:
+            // ONE batch of 4 loads per 16 tiles -- and the partial sums are combined with a fixed xor tree.
             const float* ps = s.xf_a + (size_t)b * s.xf_stride;
             const int tq0 = ok0 ? ti0 : Tin - 4, tq1 = ok1 ? ti1 : Tin - 4;
-            double s1[8], s2[8];
+            float s1[8], s2[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { s1[i] = 0.0; s2[i] = 0.0; }
-            for (int p0 = 0; p0 < s.xf_np; p0 += 4) {
-                float4 v[4][4];
+            for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+            for (int p0 = r; p0 < s.xf_np; p0 += 16) {
+                const float4* row = reinterpret_cast<const float4*>(ps + (size_t)p0 * Tin * 2);
+                float4 v[4];
+                v[0] = row[tq0 / 2]; v[1] = row[tq0 / 2 + 1]; v[2] = row[tq1 / 2]; v[3] = row[tq1 / 2 + 1];
 #pragma unroll
-                for (int pp = 0; pp < 4; ++pp) {
-                    const int pc = p0 + pp < s.xf_np ? p0 + pp : s.xf_np - 1;
-                    const float4* row = reinterpret_cast<const float4*>(ps + (size_t)pc * Tin * 2);
-                    v[pp][0] = row[tq0 / 2]; v[pp][1] = row[tq0 / 2 + 1]; v[pp][2] = row[tq1 / 2]; v[pp][3] = row[tq1 / 2 + 1];
-                }
+                for (int j = 0; j < 4; ++j) { s1[2 * j] += v[j].x; s2[2 * j] += v[j].y; s1[2 * j + 1] += v[j].z; s2[2 * j + 1] += v[j].w; }
+            }
 #pragma unroll
-                for (int pp = 0; pp < 4; ++pp) {
-                    if (p0 + pp < s.xf_np) {
+            for (int o = 4; o < 64; o <<= 1) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            s1[2 * j] += (double)v[pp][j].x; s2[2 * j] += (double)v[pp][j].y;
-                            s1[2 * j + 1] += (double)v[pp][j].z; s2[2 * j + 1] += (double)v[pp][j].w;
-                        }
-                    }
-                }
+                for (int i = 0; i < 8; ++i) { s1[i] += __shfl_xor(s1[i], o); s2[i] += __shfl_xor(s2[i], o); }
             }
             const double inv = 1.0 / (double)s.C;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const double m = s1[i] * inv;
-                double var = s2[i] * inv - m * m;
+                const double m = (double)s1[i] * inv;
+                double var = (double)s2[i] * inv - m * m;
                 var = var > 0.0 ? var : 0.0;
                 mu[i] = (float)m;
                 rs8[i] = (float)(1.0 / sqrt(var + (double)s.xf_eps));
@@ -192,6 +189,10 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
     float xh[NH > 0 ? NH : 1];
     float2 gbv = make_float2(1.f, 0.f);
 
+    auto load_gb = [&](int cr) -> float2 {          // per-channel {g, b} of chunk lo + cr for this lane's row
+        if (gn4) return gn_scale_shift(s, gst, s.xf_coff + (lo + cr) * CONV_CK + r, inv_cg);
+        return *reinterpret_cast<const float2*>(gb + (size_t)cr * (2 * CONV_CK));
+    };
     // transform the staged samples and park them in window `wofs` (byte offset 0 | WIN_LDS*4)
     auto park = [&](int wofs) {
         float v[8];
@@ -239,7 +240,7 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
             x1 = *reinterpret_cast<const float4*>(xq + g1);
 #pragma unroll
             for (int j = 0; j < NH; ++j) xh[j] = *reinterpret_cast<const float*>(xq + gh[j]);
-            if (xf) gbv = *reinterpret_cast<const float2*>(gb + (size_t)cc * (2 * CONV_CK));
+            if (xf) gbv = load_gb(cc);
         };
         auto fetch_a = [&](int cr, float4 (&An)[6], float4 (&An2)[6]) {
             const int cc = cr < nch ? cr : nch - 1;
@@ -285,7 +286,8 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
     x1 = *reinterpret_cast<const float4*>(xb + g1);
 #pragma unroll
     for (int j = 0; j < NH; ++j) xh[j] = *reinterpret_cast<const float*>(xb + gh[j]);
-    if (xf) gbv = *reinterpret_cast<const float2*>(gb);
+    int crel = 0;
+    if (xf) gbv = load_gb(0);
 
     auto step = [&](const float4 (&A)[6], const float4 (&A2)[6], float4 (&An)[6], float4 (&An2)[6], bool more) {
         park(0);
@@ -299,7 +301,8 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
             x1 = *reinterpret_cast<const float4*>(xb + g1);
 #pragma unroll
             for (int j = 0; j < NH; ++j) xh[j] = *reinterpret_cast<const float*>(xb + gh[j]);
-            if (xf) { gb += 2 * CONV_CK; gbv = *reinterpret_cast<const float2*>(gb); }
+            ++crel;
+            if (xf) gbv = load_gb(crel);
         }
         mfma_chunk<TAPS, DUAL>(smem_bytes, rb0, s.dil, A, A2, acc, acc2);
         wave_sync();               // all lanes done reading the window before it is overwritten
@@ -454,6 +457,11 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
     char* smem_bytes = reinterpret_cast<char*>(smem);
     const int wave_base = wave * WAVE_LDS * 4;
 
+    // ---- GroupNorm of the leading segments from their producers' row sums: this wave's groups only (gn_wave.h)
+    __shared__ float2 gnst[WK][32];
+    const float gn_inv_cg = a.gn_groups ? 1.0f / (float)a.gn_cg : 0.f;
+    if (a.gn_groups) wave_gn_stats(a, b, lane, g0, g1, gnst[wave]);
+
     // ---- epilogue operands: the side loads (bias / row term / residual) are issued HERE, before the K loop, from
     // clamped addresses under wave-uniform conditions, so their latency is off the kernel's critical path.
     constexpr int EPT = 16 / WK;         // tile rows (accumulator registers) finished by each wave
@@ -499,29 +507,31 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
                 const float* w1 = wtile + s.woff;
                 const float* w2 = wtile2 + s.woff;
 #define MUGD_SEG_ARGS s, w1, w2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, acc, acc2
+#define MUGD_SEG_VARGS MUGD_SEG_ARGS, gnst[wave], gn_inv_cg
                 if (KIND == 0) {
                     // specialise on (transform, activation): branch-free chunk loops
 #define MUGD_SEG_XF(T, NHALO)                                                                     \
     switch (s.xf * 4 + s.act) {                                                                   \
-        case 0: run_segment_vec<T, DUAL, NHALO, 0, 0, MUGD_PIPE>(MUGD_SEG_ARGS); break;                      \
-        case 4: run_segment_vec<T, DUAL, NHALO, 1, 0, MUGD_PIPE>(MUGD_SEG_ARGS); break;                      \
-        case 5: run_segment_vec<T, DUAL, NHALO, 1, 1, MUGD_PIPE>(MUGD_SEG_ARGS); break;                      \
-        case 6: run_segment_vec<T, DUAL, NHALO, 1, 2, MUGD_PIPE>(MUGD_SEG_ARGS); break;                      \
-        case 8: case 12: run_segment_vec<T, DUAL, NHALO, 2, 0, MUGD_PIPE>(MUGD_SEG_ARGS); break;            \
-        default: run_segment_vec<T, DUAL, NHALO>(MUGD_SEG_ARGS);                                  \
+        case 0: run_segment_vec<T, DUAL, NHALO, 0, 0, MUGD_PIPE>(MUGD_SEG_VARGS); break;                      \
+        case 4: case 16: run_segment_vec<T, DUAL, NHALO, 1, 0, MUGD_PIPE>(MUGD_SEG_VARGS); break;            \
+        case 5: case 17: run_segment_vec<T, DUAL, NHALO, 1, 1, MUGD_PIPE>(MUGD_SEG_VARGS); break;            \
+        case 6: case 18: run_segment_vec<T, DUAL, NHALO, 1, 2, MUGD_PIPE>(MUGD_SEG_VARGS); break;            \
+        case 8: case 12: run_segment_vec<T, DUAL, NHALO, 2, 0, MUGD_PIPE>(MUGD_SEG_VARGS); break;            \
+        default: run_segment_vec<T, DUAL, NHALO>(MUGD_SEG_VARGS);                                  \
     }
                     if (DUAL || s.taps == 1) { MUGD_SEG_XF(1, 0) }
                     else { MUGD_SEG_XF(3, 1) }
 #undef MUGD_SEG_XF
                 } else if (KIND == 1) {
-                    if (s.taps == 1) run_segment_vec<1, DUAL, 0>(MUGD_SEG_ARGS);
-                    else if (s.dil <= 2) run_segment_vec<3, DUAL, 1>(MUGD_SEG_ARGS);
-                    else if (s.dil == 4) run_segment_vec<3, DUAL, 2>(MUGD_SEG_ARGS);
-                    else run_segment_vec<3, DUAL, 4>(MUGD_SEG_ARGS);
+                    if (s.taps == 1) run_segment_vec<1, DUAL, 0>(MUGD_SEG_VARGS);
+                    else if (s.dil <= 2) run_segment_vec<3, DUAL, 1>(MUGD_SEG_VARGS);
+                    else if (s.dil == 4) run_segment_vec<3, DUAL, 2>(MUGD_SEG_VARGS);
+                    else run_segment_vec<3, DUAL, 4>(MUGD_SEG_VARGS);
                 } else {
                     if (s.taps == 3) run_segment_gen<3, DUAL, NITG, (NITG <= 9)>(MUGD_SEG_ARGS);
                     else run_segment_gen<1, DUAL, NITG, (NITG <= 9)>(MUGD_SEG_ARGS);
                 }
+#undef MUGD_SEG_VARGS
 #undef MUGD_SEG_ARGS
             }
         }
@@ -564,6 +574,23 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
         v = (v + ra[q]) + rsv[q];
         if (valid[q]) a.y[oo[q]] = v;
         acc_v[q] = v;
+    }
+    // ---- optional: add this tile's {sum, sum of squares} per row to the fp64 row accumulators (GroupNorm of the consumers)
+    if (!DUAL && a.rowstat) {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            float s1 = valid[q] ? acc_v[q] : 0.f;
+            float s2 = s1 * s1;
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+            const int r = wave * EPT + q;
+            const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (n == 0 && m < a.Mout) {
+                double* o = a.rowstat + 2 * ((size_t)b * a.Mout + m);
+                atomicAdd(o, (double)s1);
+                atomicAdd(o + 1, (double)s2);
+            }
+        }
     }
     // ---- optional: {sum, sum of squares} of this tile's final values per column, for the LayerNorm of the consumer
     if (!DUAL && a.colstat) {
@@ -644,7 +671,9 @@ void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
         MUGD_CHECK(s.taps == 1 || s.taps == 3, -2, "conv_gemm: taps must be 1 or 3");
         MUGD_CHECK(s.dil >= 1 && (s.stride == 1 || s.stride == 2), -2, "conv_gemm: bad dilation / stride");
         MUGD_CHECK((long long)CONV_CK * s.Tin * 4 < (1ll << 31), -2, "conv_gemm: sequence too long for 32-bit window offsets");
-        MUGD_CHECK(s.xf >= 0 && s.xf <= 3 && (s.xf == 0 || s.xf_a) && (s.xf < 2 || s.xf_b), -2, "conv_gemm: bad operand transform");
+        MUGD_CHECK(s.xf >= 0 && s.xf <= 4 && (s.xf == 0 || s.xf_a) && (s.xf < 2 || s.xf_b), -2, "conv_gemm: bad operand transform");
+        MUGD_CHECK(s.xf != 4 || (i < a.gn_nseg && a.gn_groups > 0 && a.gn_groups <= 32 && a.gn_cg > 0 && s.stride == 1 && !s.ups && (s.Tin & 3) == 0), -2,
+                   "conv_gemm: GroupNorm from producer sums needs fast-path segments inside the GroupNorm domain");
         MUGD_CHECK(s.xf != 3 || (s.taps == 1 && s.stride == 1 && !s.ups && (s.Tin & 3) == 0 && s.xf_np > 0), -2,
                    "conv_gemm: LayerNorm from producer sums needs a 1x1 fast-path segment");
         if (all_vec) {
@@ -665,7 +694,7 @@ void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
         for (int i = 0; i < a.nseg; ++i) MUGD_CHECK(a.seg[i].xf == 0, -2, "conv_gemm: no operand transform in a kernel with a strided / widely dilated generic segment");
     const int kind = all_vec ? (lean ? 0 : 1) : 2;
     const bool dual = a.epi != EPI_NONE;
-    MUGD_CHECK(!a.colstat || !dual, -2, "conv_gemm: column sums are not produced by gated epilogues");
+    MUGD_CHECK((!a.colstat && !a.rowstat) || !dual, -2, "conv_gemm: row / column sums are not produced by gated epilogues");
     if (dual) {
         MUGD_CHECK(a.Mout % 32 == 0 && a.Mrows == 2 * a.Mout, -2, "conv_gemm: gated epilogue needs Mout % 32 == 0");
         for (int i = 0; i < a.nseg; ++i) MUGD_CHECK(a.seg[i].taps == 1, -2, "conv_gemm: gated epilogue is implemented for 1x1 convs");

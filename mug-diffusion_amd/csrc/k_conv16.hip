@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include "gn_wave.h"
 #include "kernels.h"
 
 namespace {
@@ -38,7 +39,7 @@ __device__ __forceinline__ void load_a16(const float* wp, const float* wp2, floa
 template <int TAPS, bool DUAL, int XFK = -1, int ACT = -1, bool PIPE = false>       // XFK / ACT / PIPE: see k_conv.hip
 __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wseg, const float* wseg2, int lo, int hi,
                                               int b, int t0, int lane, char* smem_bytes, int wave_base,
-                                              f32x4 (&acc)[2], f32x4 (&accg)[2]) {
+                                              f32x4 (&acc)[2], f32x4 (&accg)[2], const float2* gst, float inv_cg) {
     constexpr int NH = TAPS == 3 ? 1 : 0;                  // dilation 1: 2 halo samples per row, one load for lanes q < 2
     const int r = lane >> 2, q = lane & 3;
     const int l15 = lane & 15, kq = lane >> 4;
@@ -61,45 +62,38 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
         gh = (unsigned)(r * Tin + tc) * 4u;
         lh = wave_base + (r * RS + (e < hw ? HL + col : 40 + q)) * 4;      // dead lanes park in columns no tap reads
     }
-    const int xf = XFK >= 0 ? XFK : (s.xf == 3 ? 2 : s.xf), act = ACT >= 0 ? ACT : s.act;
+    const int xf = XFK >= 0 ? XFK : (s.xf == 3 ? 2 : s.xf == 4 ? 1 : s.xf), act = ACT >= 0 ? ACT : s.act;
+    const bool gn4 = s.xf == 4;
     float mu[4], rs4[4], muh = 0.f, rsh = 1.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { mu[i] = 0.f; rs4[i] = 1.f; }
     const float* gb = nullptr;
     if (xf == 1) {
-        gb = s.xf_a + (size_t)b * s.xf_stride + 2 * ((size_t)lo * CONV_CK + r);
+        if (!gn4) gb = s.xf_a + (size_t)b * s.xf_stride + 2 * ((size_t)lo * CONV_CK + r);
     } else if (xf == 2) {
         gb = s.xf_b + 2 * ((size_t)lo * CONV_CK + r);
         if (s.xf == 3) {                     // LayerNorm statistics from the producer's column sums (see k_conv.hip)
             const float* ps = s.xf_a + (size_t)b * s.xf_stride;
             const int tq = ok0 ? ti : Tin - 4;
-            double s1[4], s2[4];
+            float s1[4], s2[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { s1[i] = 0.0; s2[i] = 0.0; }
-            for (int p0 = 0; p0 < s.xf_np; p0 += 4) {
-                float4 v[4][2];
+            for (int i = 0; i < 4; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+            for (int p0 = r; p0 < s.xf_np; p0 += 16) {
+                const float4* row = reinterpret_cast<const float4*>(ps + (size_t)p0 * Tin * 2);
+                const float4 v0 = row[tq / 2], v1 = row[tq / 2 + 1];
+                s1[0] += v0.x; s2[0] += v0.y; s1[1] += v0.z; s2[1] += v0.w;
+                s1[2] += v1.x; s2[2] += v1.y; s1[3] += v1.z; s2[3] += v1.w;
+            }
 #pragma unroll
-                for (int pp = 0; pp < 4; ++pp) {
-                    const int pc = p0 + pp < s.xf_np ? p0 + pp : s.xf_np - 1;
-                    const float4* row = reinterpret_cast<const float4*>(ps + (size_t)pc * Tin * 2);
-                    v[pp][0] = row[tq / 2]; v[pp][1] = row[tq / 2 + 1];
-                }
+            for (int o = 4; o < 64; o <<= 1) {
 #pragma unroll
-                for (int pp = 0; pp < 4; ++pp) {
-                    if (p0 + pp < s.xf_np) {
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            s1[2 * j] += (double)v[pp][j].x; s2[2 * j] += (double)v[pp][j].y;
-                            s1[2 * j + 1] += (double)v[pp][j].z; s2[2 * j + 1] += (double)v[pp][j].w;
-                        }
-                    }
-                }
+                for (int i = 0; i < 4; ++i) { s1[i] += __shfl_xor(s1[i], o); s2[i] += __shfl_xor(s2[i], o); }
             }
             const double inv = 1.0 / (double)s.C;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const double m = s1[i] * inv;
-                double var = s2[i] * inv - m * m;
+                const double m = (double)s1[i] * inv;
+                double var = (double)s2[i] * inv - m * m;
                 var = var > 0.0 ? var : 0.0;
                 mu[i] = (float)m;
                 rs4[i] = (float)(1.0 / sqrt(var + (double)s.xf_eps));
@@ -127,6 +121,10 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
     float xh = 0.f;
     float2 gbv = make_float2(1.f, 0.f);
 
+    auto load_gb = [&](int cr) -> float2 {
+        if (gn4) return gn_scale_shift(s, gst, s.xf_coff + (lo + cr) * CONV_CK + r, inv_cg);
+        return *reinterpret_cast<const float2*>(gb + (size_t)cr * (2 * CONV_CK));
+    };
     auto park = [&](int wofs) {
         float v[4], vh = xh;
         v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w;
@@ -189,7 +187,7 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
             const char* xq = xb + (size_t)cc * xstep;
             x0 = *reinterpret_cast<const float4*>(xq + g0);
             if (NH) xh = *reinterpret_cast<const float*>(xq + gh);
-            if (xf) gbv = *reinterpret_cast<const float2*>(gb + (size_t)cc * (2 * CONV_CK));
+            if (xf) gbv = load_gb(cc);
         };
         auto fetch_a = [&](int cr, float4 (&An)[6], float4 (&An2)[6]) {
             const int cc = cr < nch ? cr : nch - 1;
@@ -230,7 +228,8 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
     load_a16<TAPS, DUAL>(wp, wp2, Aa, Aa2);
     x0 = *reinterpret_cast<const float4*>(xb + g0);
     if (NH) xh = *reinterpret_cast<const float*>(xb + gh);
-    if (xf) gbv = *reinterpret_cast<const float2*>(gb);
+    int crel = 0;
+    if (xf) gbv = load_gb(0);
 
     auto step = [&](const float4 (&A)[6], const float4 (&A2)[6], float4 (&An)[6], float4 (&An2)[6], bool more) {
         park(0);
@@ -242,7 +241,8 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
             load_a16<TAPS, DUAL>(wp, wp2, An, An2);
             x0 = *reinterpret_cast<const float4*>(xb + g0);
             if (NH) xh = *reinterpret_cast<const float*>(xb + gh);
-            if (xf) { gb += 2 * CONV_CK; gbv = *reinterpret_cast<const float2*>(gb); }
+            ++crel;
+            if (xf) gbv = load_gb(crel);
         }
         mfma(0, A, A2);
         wave_sync();
@@ -288,6 +288,11 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
     char* smem_bytes = reinterpret_cast<char*>(smem);
     const int wave_base = wave * WAVE_LDS * 4;
 
+    // ---- GroupNorm of the leading segments from their producers' row sums: this wave's groups only (gn_wave.h)
+    __shared__ float2 gnst[WK][32];
+    const float gn_inv_cg = a.gn_groups ? 1.0f / (float)a.gn_cg : 0.f;
+    if (a.gn_groups) wave_gn_stats(a, b, lane, g0, g1, gnst[wave]);
+
     // ---- epilogue operands, issued before the K loop (see k_conv.hip)
     constexpr int EPT = 8 / WK;          // accumulator registers (tile rows) finished by each wave
     float bv[EPT], bg[EPT], ra[EPT], rsv[EPT];
@@ -327,13 +332,13 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
             if (lo < hi) {
                 const float* w1 = wtile + s.woff;
                 const float* w2 = wtile2 + s.woff;
-#define MUGD_SEG16_ARGS s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, acc, accg
+#define MUGD_SEG16_ARGS s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, acc, accg, gnst[wave], gn_inv_cg
 #define MUGD_SEG16_XF(T)                                                                  \
     switch (s.xf * 4 + s.act) {                                                           \
         case 0: run_segment16<T, DUAL, 0, 0, true>(MUGD_SEG16_ARGS); break;                     \
-        case 4: run_segment16<T, DUAL, 1, 0, true>(MUGD_SEG16_ARGS); break;                     \
-        case 5: run_segment16<T, DUAL, 1, 1, true>(MUGD_SEG16_ARGS); break;                     \
-        case 6: run_segment16<T, DUAL, 1, 2, true>(MUGD_SEG16_ARGS); break;                     \
+        case 4: case 16: run_segment16<T, DUAL, 1, 0, true>(MUGD_SEG16_ARGS); break;            \
+        case 5: case 17: run_segment16<T, DUAL, 1, 1, true>(MUGD_SEG16_ARGS); break;            \
+        case 6: case 18: run_segment16<T, DUAL, 1, 2, true>(MUGD_SEG16_ARGS); break;            \
         case 8: case 12: run_segment16<T, DUAL, 2, 0, true>(MUGD_SEG16_ARGS); break;            \
         default: run_segment16<T, DUAL>(MUGD_SEG16_ARGS);                                 \
     }
@@ -379,6 +384,22 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
         v = (v + ra[q]) + rsv[q];
         if (valid[q]) a.y[oo[q]] = v;
         acc_v[q] = v;
+    }
+    if (!DUAL && a.rowstat) {            // add the tile's per-row {sum, sum of squares} to the fp64 row accumulators (see k_conv.hip)
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            float s1 = valid[q] ? acc_v[q] : 0.f;
+            float s2 = s1 * s1;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+            const int r = wave * EPT + q;
+            const int m = mt * 32 + 16 * (r >> 2) + 4 * kq + (r & 3);
+            if (l15 == 0 && m < a.Mout) {
+                double* o = a.rowstat + 2 * ((size_t)b * a.Mout + m);
+                atomicAdd(o, (double)s1);
+                atomicAdd(o + 1, (double)s2);
+            }
+        }
     }
     if (!DUAL && a.colstat) {            // per-column {sum, sum of squares} of the tile's final values (see k_conv.hip)
         __shared__ float cst[2][WK][16];
@@ -455,11 +476,12 @@ void launch_conv_gemm16(hipStream_t st, const ConvArgs& a) {
         const ConvSeg& s = a.seg[i];
         MUGD_CHECK(s.C % CONV_CK == 0, -2, "conv_gemm16: channels must be a multiple of 16");
         MUGD_CHECK((long long)CONV_CK * s.Tin * 4 < (1ll << 31), -2, "conv_gemm16: sequence too long for 32-bit window offsets");
-        MUGD_CHECK(s.xf >= 0 && s.xf <= 3 && (s.xf == 0 || s.xf_a) && (s.xf < 2 || s.xf_b), -2, "conv_gemm16: bad operand transform");
+        MUGD_CHECK(s.xf >= 0 && s.xf <= 4 && (s.xf == 0 || s.xf_a) && (s.xf < 2 || s.xf_b), -2, "conv_gemm16: bad operand transform");
+        MUGD_CHECK(s.xf != 4 || (i < a.gn_nseg && a.gn_groups > 0 && a.gn_groups <= 32 && a.gn_cg > 0), -2, "conv_gemm16: bad GroupNorm domain");
         MUGD_CHECK(s.xf != 3 || (s.taps == 1 && s.xf_np > 0), -2, "conv_gemm16: LayerNorm from producer sums needs a 1x1 segment");
     }
     const bool dual = a.epi != EPI_NONE;
-    MUGD_CHECK(!a.colstat || !dual, -2, "conv_gemm16: column sums are not produced by gated epilogues");
+    MUGD_CHECK((!a.colstat && !a.rowstat) || !dual, -2, "conv_gemm16: row / column sums are not produced by gated epilogues");
     if (dual) MUGD_CHECK(a.Mout % 32 == 0 && a.Mrows == 2 * a.Mout, -2, "conv_gemm16: gated epilogue needs Mout % 32 == 0");
     else MUGD_CHECK(a.Mrows == a.Mout, -2, "conv_gemm16: Mrows != Mout");
     const int gx = cdiv(a.Tout, 16), gy = cdiv(a.Mout, 32), gz = a.B;

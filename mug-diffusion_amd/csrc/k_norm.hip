@@ -217,6 +217,18 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const LnStatArgs a) {
     }
 }
 
+// one wavefront per row: fp64 {sum, sum of squares}
+__global__ __launch_bounds__(256) void row_sums_kernel(const float* x, double* out, int rows, int T) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* p = x + (size_t)row * T;
+    double s = 0.0, q = 0.0;
+    for (int t = lane; t < T; t += 64) { const double v = p[t]; s += v; q += v * v; }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    if (lane == 0) { out[2 * (size_t)row] = s; out[2 * (size_t)row + 1] = q; }
+}
+
 __global__ void interleave2_kernel(const float* x, const float* y, float* out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { out[2 * i] = x[i]; out[2 * i + 1] = y[i]; }
@@ -253,4 +265,8 @@ void launch_ln_stats(hipStream_t st, const LnStatArgs& a) {
 
 void launch_interleave2(hipStream_t st, const float* x, const float* y, float* out, int n) {
     hipLaunchKernelGGL(interleave2_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, x, y, out, n);
+}
+
+void launch_row_sums(hipStream_t st, const float* x, double* out, int rows, int T) {
+    hipLaunchKernelGGL(row_sums_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, out, rows, T);
 }

@@ -35,13 +35,18 @@ struct ConvSeg {
     // operand transform applied while the window is staged (GroupNorm / LayerNorm are never materialised):
     int xf;           // 0 none | 1 v = x*g + b with {g,b} per (batch, channel) | 2 v = (x-mean)*rstd*g + b with {mean,rstd} per (batch, sample), {g,b} per channel
                       // | 3 as 2, but {mean,rstd} are derived in the kernel prologue from the PRODUCER's per-row-tile column sums (ConvArgs::colstat)
+                      // | 4 GroupNorm: v = x*g + b with {g,b} derived in the kernel from the PRODUCERS' per-row sums
+                      //     (ConvArgs::rowstat) -- each wave reduces the groups its K-slice touches (ConvArgs::gn_*)
     int act;          // 1: SiLU after the transform
     const float* xf_a;    // xf=1: {g,b} of this segment's first channel, batch stride xf_stride | xf=2: {mean,rstd} (B, Tin, 2), batch stride xf_stride
                           // | xf=3: {sum, sum of squares} (B, xf_np, Tin, 2) over the 32-row tiles of the producer, batch stride xf_stride
+                          // | xf=4: fp64 {sum, sum of squares} (B, C, 2) per row (as const double*), batch stride xf_stride DOUBLES;
+                          //         xf_b = {gamma,beta} of the WHOLE GroupNorm (Ctot, 2), indexed by xf_coff + channel
     const float* xf_b;    // xf=2: {gamma,beta} (C, 2)
     int xf_stride;        // floats per batch row of xf_a
     int xf_np;            // xf=3: number of row tiles summed per column
     float xf_eps;         // xf=3: LayerNorm eps
+    int xf_coff;          // xf=4: first channel of this segment inside the normalised concat
 };
 
 enum { EPI_NONE = 0, EPI_GLU = 1, EPI_GEGLU = 2 };
@@ -59,6 +64,12 @@ struct ConvArgs {
     int B, Mrows, Mout, Tout, nchunk, epi;
     float* colstat;          // null, or (B, ceil(Mout/32), Tout, 2): per output tile and column {sum, sum of squares} of the final values over
                              // the tile's rows -- the LayerNorm statistics of the consumer without a statistics launch (non-gated epilogues)
+    double* rowstat;         // null, or (B, Mout, 2) fp64 accumulators, zeroed once per step: every tile ADDS the {sum, sum of squares} of its
+                             // final values per row (fp64 atomics: the summation order only moves bit 53) -- the GroupNorm statistics of the
+                             // consumers without a statistics launch (non-gated epilogues)
+    // GroupNorm domain of the xf == 4 segments (they are the first gn_nseg segments, in concat order)
+    int gn_nseg, gn_groups, gn_cg;
+    float gn_count, gn_eps;  // elements per group (cg * T), eps
     int wk;                  // K-split (waves per workgroup): 1|2|4|8, 0 = pick from the shape
     int tn;                  // output tile width: 32 (k_conv.hip) | 16 (k_conv16.hip); decides the weight packing
 };
@@ -105,6 +116,9 @@ struct GnStatArgs {
     float* aff;              // out (B, Ctot, 2): {gamma*rstd, beta - mean*gamma*rstd}
 };
 void launch_gn_stats(hipStream_t st, const GnStatArgs& a);
+// fp64 {sum, sum of squares} of every (batch, channel) row of a tensor the library did not produce itself (the audio
+// feature maps): the ConvArgs::rowstat of an input.  out (rows, 2).
+void launch_row_sums(hipStream_t st, const float* x, double* out, int rows, int T);
 struct LnStatArgs { const float* x; float* stat; int B, C, T; float eps; };     // stat (B, T, 2): {mean, rstd}
 void launch_ln_stats(hipStream_t st, const LnStatArgs& a);
 void launch_interleave2(hipStream_t st, const float* x, const float* y, float* out, int n);   // out[i] = {x[i], y[i]}

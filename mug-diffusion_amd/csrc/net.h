@@ -19,6 +19,9 @@ struct Tensor {
     // set by the conv that produced this tensor: per 32-row tile and column {sum, sum of squares} (ConvArgs::colstat)
     float* colstat = nullptr;
     int colstat_np = 0;
+    // fp64 {sum, sum of squares} per (batch, channel) row, accumulated by the producing conv (ConvArgs::rowstat) or computed
+    // once per call for network inputs (audio maps): lets a consuming GroupNorm skip its statistics launch
+    double* rowstat = nullptr;
 };
 
 struct Param {
@@ -36,6 +39,7 @@ struct Ctx {
     bool use_graph = true;
     int force_wk = 0, force_tn = 0;   // mugd_set_conv_tiling: 0 = pick per layer
     bool fast_act = true;       // SiLU of the fused GroupNorm path on v_exp_f32 / v_rcp_f32 (MUGD_EXACT_SILU=1: expf + IEEE divide)
+    bool fuse_stats = true;     // false (MUGD_NO_STATS_FUSION=1): always run the GroupNorm / LayerNorm statistics kernels
     bool fuse_norm = true;      // false (MUGD_UNFUSED_NORM=1): materialise GroupNorm / LayerNorm outputs with the stand-alone kernels (A/B + debugging)
 };
 
@@ -55,7 +59,8 @@ private:
 };
 
 // operand transform of one conv input (ConvSeg::xf): the GroupNorm / LayerNorm in front of the conv
-struct Xf { int kind = 0; int act = 0; const float* a = nullptr; const float* b = nullptr; int stride = 0; int np = 0; float eps = 0.f; };
+struct Xf { int kind = 0; int act = 0; const float* a = nullptr; const float* b = nullptr; int stride = 0; int np = 0; float eps = 0.f; int coff = 0; };
+struct GnDomain { int nseg = 0, groups = 0, cg = 0; float count = 0.f, eps = 0.f; };     // ConvArgs::gn_*
 struct ConvIn { Tensor x; int taps = 1, dil = 1, stride = 1, pad = 0, ups = 0; Xf xf; };
 struct WBlock { std::string name; int seg; int row_off; int ci_off; };
 struct ConvSpec {
@@ -69,6 +74,8 @@ struct ConvSpec {
     Tensor resid;
     Tensor out;
     bool want_colstat = false;    // also emit the per-column sums a following LayerNorm needs (returned in Tensor::colstat)
+    bool want_rowstat = false;    // also accumulate the per-row sums a following GroupNorm needs (returned in Tensor::rowstat)
+    GnDomain gn;                  // set by gn_inputs when the leading inputs are normalised from their producers' row sums
 };
 
 struct PackedW {
@@ -133,6 +140,13 @@ protected:
     // GroupNorm(+SiLU) of the virtual concat as conv inputs: statistics kernel + transformed segments (fused), or one
     // materialised tensor (unfused).  Callers lay their weight blocks out by walking the returned inputs.
     std::vector<ConvIn> gn_inputs(const std::string& prefix, const std::vector<Tensor>& segs, int groups, bool silu, int taps, int dil, int pad);
+    // the same, as the leading inputs of `spec`; uses the producers' row sums (no statistics launch) when every segment has them
+    void gn_inputs(ConvSpec& spec, const std::string& prefix, const std::vector<Tensor>& segs, int groups, bool silu, int taps, int dil, int pad);
+    float* norm_table(const std::string& prefix, int C);      // interleaved {weight, bias} of a norm layer, baked once
+    // fp64 row-sum accumulators: one contiguous block per program, zeroed by the first op of every step
+    double* alloc_rowstat(size_t ndoubles);
+    double* rs_base = nullptr; size_t rs_top = 0, rs_cap = 0;
+    void begin_rowstat();                                     // call at the start of build(): emits the per-step memset
     Tensor group_norm(const std::string& prefix, const std::vector<Tensor>& segs, int groups, bool silu);   // stand-alone kernel
     Tensor layer_norm(const std::string& prefix, const Tensor& x);
     // LayerNorm over channels: statistics kernel + the {gamma, beta} table -> transform for a 1x1 conv input

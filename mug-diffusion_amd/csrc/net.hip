@@ -85,6 +85,7 @@ void Net::invalidate() {
     owned.clear();
     packed.clear();
     baked.clear();
+    rs_base = nullptr; rs_cap = 0; rs_top = 0;
     ops.clear();
     pre_ops.clear();
     emb_ops.clear();
@@ -145,6 +146,30 @@ std::vector<ConvIn> Net::gn_inputs(const std::string& prefix, const std::vector<
     return {ConvIn{group_norm(prefix, segs, groups, silu), taps, dil, 1, pad, 0}};
 }
 
+void Net::gn_inputs(ConvSpec& spec, const std::string& prefix, const std::vector<Tensor>& segs, int groups, bool silu, int taps, int dil, int pad) {
+    bool have = ctx->fuse_norm && ctx->fuse_stats && groups <= 32 && segs[0].T % 4 == 0 && (taps == 1 || true);
+    int Ctot = 0;
+    for (auto& t : segs) { have = have && t.rowstat != nullptr; Ctot += t.C; }
+    if (!have || Ctot % groups != 0) {
+        spec.in = gn_inputs(prefix, segs, groups, silu, taps, dil, pad);
+        return;
+    }
+    const float* tab = norm_table(prefix, Ctot);
+    int off = 0;
+    spec.in.clear();
+    for (auto& t : segs) {
+        ConvIn in{t, taps, dil, 1, pad, 0};
+        in.xf.kind = 4; in.xf.act = silu ? (ctx->fast_act ? 2 : 1) : 0;
+        in.xf.a = reinterpret_cast<const float*>(t.rowstat); in.xf.b = tab;
+        in.xf.stride = 2 * t.C;                 // doubles per batch row
+        in.xf.coff = off;
+        spec.in.push_back(in);
+        off += t.C;
+    }
+    spec.gn.nseg = (int)segs.size(); spec.gn.groups = groups; spec.gn.cg = Ctot / groups;
+    spec.gn.count = (float)(Ctot / groups) * (float)segs[0].T; spec.gn.eps = 1e-6f;
+}
+
 ConvIn Net::ln_input(const std::string& prefix, const Tensor& x) {
     if (ctx->fuse_norm) {
         ConvIn in{x};
@@ -197,19 +222,41 @@ std::vector<ConvIn> Net::normed(const std::vector<Tensor>& segs, const float* af
     return r;
 }
 
-Xf Net::layer_norm_xf(const std::string& prefix, const Tensor& x) {
+float* Net::norm_table(const std::string& prefix, int C) {
     const std::string key = prefix + "#gb";
     auto it = baked.find(key);
-    float* gb = nullptr;
-    if (it != baked.end()) {
-        gb = it->second;
-    } else {
-        MUGD_CHECK(P(prefix + ".weight").numel() == x.C, -2, "layer_norm: weight size mismatch at " + prefix);
-        gb = dev_alloc((size_t)x.C * 2);
-        launch_interleave2(ctx->stream, PF(prefix + ".weight"), PF(prefix + ".bias"), gb, x.C);
-        baked[key] = gb;
+    if (it != baked.end()) return it->second;
+    MUGD_CHECK(P(prefix + ".weight").numel() == C, -2, "norm: weight size mismatch at " + prefix);
+    float* gb = dev_alloc((size_t)C * 2);
+    launch_interleave2(ctx->stream, PF(prefix + ".weight"), PF(prefix + ".bias"), gb, C);
+    return baked[key] = gb;
+}
+
+double* Net::alloc_rowstat(size_t nd) {
+    const size_t off = rs_top;
+    rs_top += (nd + 31) / 32 * 32;
+    if (dry) return reinterpret_cast<double*>(256 + off * sizeof(double));      // never dereferenced
+    MUGD_CHECK(rs_top <= rs_cap, -9, "internal: row-sum block overflow");
+    return rs_base + off;
+}
+
+void Net::begin_rowstat() {
+    if (!dry) {                                  // sized by the dry pass that just ran
+        if (rs_top > rs_cap) {
+            rs_cap = rs_top;
+            rs_base = reinterpret_cast<double*>(dev_alloc(rs_cap * 2));
+        }
+        if (rs_cap) {
+            double* p = rs_base; const size_t bytes = rs_top * sizeof(double);
+            emit([p, bytes](hipStream_t st) { HIP_CHECK(hipMemsetAsync(p, 0, bytes, st)); }, OP_SMALL, 0, "zero row-sum accumulators");
+        }
     }
-    if (x.colstat && x.T % 4 == 0) {             // statistics come from the producer conv's epilogue: no launch
+    rs_top = 0;
+}
+
+Xf Net::layer_norm_xf(const std::string& prefix, const Tensor& x) {
+    float* gb = norm_table(prefix, x.C);
+    if (x.colstat && x.T % 4 == 0 && ctx->fuse_stats) {             // statistics come from the producer conv's epilogue: no launch
         Xf xf;
         xf.kind = 3; xf.a = x.colstat; xf.b = gb; xf.stride = 2 * x.colstat_np * x.T; xf.np = x.colstat_np; xf.eps = 1e-5f;
         return xf;
@@ -271,8 +318,9 @@ Tensor Net::conv(const ConvSpec& s) {
     for (int i = 0; i < a.nseg; ++i) {
         const ConvIn& in = s.in[i];
         a.seg[i] = ConvSeg{in.x.p, in.x.C, in.x.T, in.taps, in.dil, in.stride, in.pad, in.ups, 0, 0, in.x.bmod,
-                           in.xf.kind, in.xf.act, in.xf.a, in.xf.b, in.xf.stride, in.xf.np, in.xf.eps};
+                           in.xf.kind, in.xf.act, in.xf.a, in.xf.b, in.xf.stride, in.xf.np, in.xf.eps, in.xf.coff};
     }
+    a.gn_nseg = s.gn.nseg; a.gn_groups = s.gn.groups; a.gn_cg = s.gn.cg; a.gn_count = s.gn.count; a.gn_eps = s.gn.eps;
     a.B = Bn; a.Mrows = s.Mrows; a.Mout = s.Mout; a.Tout = s.Tout; a.epi = s.epi;
     a.wk = ctx->force_wk;
     a.tn = ctx->force_tn == 16 ? (conv16_supported(a) ? 16 : 32) : ctx->force_tn == 32 ? 32 : conv_pick_tn(a);
@@ -283,7 +331,11 @@ Tensor Net::conv(const ConvSpec& s) {
     a.resid = s.resid.p;
     if (s.resid.p) MUGD_CHECK(s.resid.C == s.Mout && s.resid.T == s.Tout && s.resid.bmod == 0, -2, "conv: residual shape mismatch at " + s.key);
     a.y = y.p; a.nchunk = pw.nchunk;
-    if (s.want_colstat && ctx->fuse_norm && s.epi == EPI_NONE && s.Tout % 4 == 0) {
+    if (s.want_rowstat && ctx->fuse_norm && ctx->fuse_stats && s.epi == EPI_NONE) {
+        y.rowstat = alloc_rowstat((size_t)Bn * s.Mout * 2);
+        a.rowstat = y.rowstat;
+    }
+    if (s.want_colstat && ctx->fuse_stats && ctx->fuse_norm && s.epi == EPI_NONE && s.Tout % 4 == 0) {
         bool fast = true;                                   // only the fast-window kernels emit column sums
         for (auto& in : s.in) fast = fast && in.stride == 1 && !in.ups && in.x.T % 4 == 0 && (in.taps == 1 || in.dil == 1);
         if (fast) {
@@ -311,6 +363,7 @@ Tensor Net::conv_simple(const std::string& prefix, const Tensor& x, int taps, in
     s.Tout = Tout;
     s.resid = resid;
     s.out = out;
+    s.want_rowstat = true;               // every plain conv on these paths feeds a GroupNorm (next block / skip connection)
     return conv(s);
 }
 
@@ -357,11 +410,14 @@ Tensor Net::transformer(const std::string& prefix, const Tensor& x, const Tensor
         to_pre = save;
     }
     const size_t mk = arena.mark();
-    auto lin = [&](const std::string& key, const ConvIn& in, bool bias, const Tensor& resid, const Tensor& dst, bool feeds_ln = false) {
+    auto lin = [&](const std::string& key, const ConvIn& in, bool bias, const Tensor& resid, const Tensor& dst, bool feeds_ln = false,
+                   bool feeds_gn = false, const ConvSpec* proto = nullptr) {
         ConvSpec s;
+        if (proto) s = *proto;               // inputs (+ GroupNorm domain) prepared by the caller
+        else s.in = {in};
         s.key = key;
         s.want_colstat = feeds_ln;
-        s.in = {in};
+        s.want_rowstat = feeds_gn;
         s.w = {WBlock{key + ".weight", 0, 0, 0}};
         if (bias) s.bias = {{key + ".bias", 0}};
         s.Mrows = s.Mout = (int)P(key + ".weight").shape[0];
@@ -378,7 +434,9 @@ Tensor Net::transformer(const std::string& prefix, const Tensor& x, const Tensor
         return attention(ap, qkv, qkv, qkv, C, heads, 0, C, 2 * C);
     };
 
-    Tensor h0 = lin(prefix + ".proj_in", gn_inputs(prefix + ".norm", {x}, 32, false, 1, 1, 0)[0], true, Tensor(), Tensor(), true);
+    ConvSpec pin;
+    gn_inputs(pin, prefix + ".norm", {x}, 32, false, 1, 1, 0);
+    Tensor h0 = lin(prefix + ".proj_in", ConvIn{}, true, Tensor(), Tensor(), true, false, &pin);
     Tensor a1 = self_attn(b + ".attn1", ln_input(b + ".norm1", h0));
     Tensor h1 = lin(b + ".attn1.to_out.0", ConvIn{a1}, true, h0, Tensor(), true);
     const ConvIn n2 = ln_input(b + ".norm2", h1);
@@ -402,7 +460,7 @@ Tensor Net::transformer(const std::string& prefix, const Tensor& x, const Tensor
         f = conv(ff);
     }
     Tensor h3 = lin(b + ".ff.net.2", ConvIn{f}, true, h2, Tensor());
-    lin(prefix + ".proj_out", ConvIn{h3}, true, x, out);
+    out = lin(prefix + ".proj_out", ConvIn{h3}, true, x, out, false, true);
     arena.release(mk);
     return out;
 }
@@ -416,17 +474,17 @@ Tensor Net::resnet_block(const std::string& prefix, const Tensor& x, int Cout, i
     {
         ConvSpec s;
         s.key = prefix + ".conv1";
-        s.in = gn_inputs(prefix + ".norm1", {x}, groups, true, 3, d0, d0);
+        gn_inputs(s, prefix + ".norm1", {x}, groups, true, 3, d0, d0);
         span_weights(s, s.key + ".weight", 0, s.in.size());
         s.bias = {{s.key + ".bias", 0}};
-        s.Mrows = s.Mout = Cout; s.Tout = T;
+        s.Mrows = s.Mout = Cout; s.Tout = T; s.want_rowstat = true;
         h1 = conv(s);
     }
     ConvSpec s;
-    s.in = gn_inputs(prefix + ".norm2", {h1}, groups, true, 3, d1, d1);
+    gn_inputs(s, prefix + ".norm2", {h1}, groups, true, 3, d1, d1);
     span_weights(s, prefix + ".conv2.weight", 0, s.in.size());
     s.bias = {{prefix + ".conv2.bias", 0}};
-    s.Mrows = s.Mout = Cout; s.Tout = T; s.out = out;
+    s.Mrows = s.Mout = Cout; s.Tout = T; s.out = out; s.want_rowstat = true;
     if (has(prefix + ".nin_shortcut.weight")) {
         s.key = prefix + ".conv2+nin";
         s.in.push_back(ConvIn{x});
@@ -437,7 +495,7 @@ Tensor Net::resnet_block(const std::string& prefix, const Tensor& x, int Cout, i
         s.key = prefix + ".conv2";
         s.resid = x;
     }
-    conv(s);
+    out = conv(s);
     arena.release(mk);
     return out;
 }
@@ -492,7 +550,7 @@ Tensor Net::s4_layer(const std::string& prefix, const Tensor& x) {
     gl.bias = {{gl.key + ".bias", 0}};
     gl.Mrows = 2 * H; gl.Mout = H; gl.Tout = L; gl.epi = EPI_GLU;
     Tensor g = conv(gl);
-    conv_simple(prefix + ".out_layer", g, 3, 1, 1, 1, 0, L, x, out);
+    out = conv_simple(prefix + ".out_layer", g, 3, 1, 1, 1, 0, L, x, out);
     arena.release(mk);
     return out;
 }
@@ -550,17 +608,17 @@ Tensor UNet::resblock(const std::string& prefix, const std::vector<Tensor>& segs
     const size_t mk = arena.mark();
     ConvSpec c1;
     c1.key = prefix + ".in_layers.2";
-    c1.in = gn_inputs(prefix + ".in_layers.0", segs, 32, true, 3, 1, 1);
+    gn_inputs(c1, prefix + ".in_layers.0", segs, 32, true, 3, 1, 1);
     span_weights(c1, c1.key + ".weight", 0, c1.in.size());
     c1.bias = {{c1.key + ".bias", 0}};
-    c1.Mrows = c1.Mout = Cout; c1.Tout = T;
+    c1.Mrows = c1.Mout = Cout; c1.Tout = T; c1.want_rowstat = true;
     c1.rowadd = emb_rowadd + rowadd_off; c1.rowadd_stride = rowadd_total;
     Tensor h1 = conv(c1);
     ConvSpec s;
-    s.in = gn_inputs(prefix + ".out_layers.0", {h1}, 32, true, 3, 1, 1);
+    gn_inputs(s, prefix + ".out_layers.0", {h1}, 32, true, 3, 1, 1);
     span_weights(s, prefix + ".out_layers.3.weight", 0, s.in.size());
     s.bias = {{prefix + ".out_layers.3.bias", 0}};
-    s.Mrows = s.Mout = Cout; s.Tout = T; s.out = out;
+    s.Mrows = s.Mout = Cout; s.Tout = T; s.out = out; s.want_rowstat = true;
     if (has(prefix + ".skip_connection.weight")) {
         s.key = prefix + ".out_layers.3+skip";
         const size_t first = s.in.size();
@@ -572,7 +630,7 @@ Tensor UNet::resblock(const std::string& prefix, const std::vector<Tensor>& segs
         s.key = prefix + ".out_layers.3";
         s.resid = segs[0];
     }
-    conv(s);
+    out = conv(s);
     arena.release(mk);
     return out;
 }
@@ -583,6 +641,7 @@ void UNet::build(bool dry_run) {
     ops.clear();
     pre_ops.clear();
     emb_ops.clear();
+    begin_rowstat();
     Bn = key.B;
     const int mc = cfg.model_channels, nl = (int)cfg.channel_mult.size(), z = key.z;
     const bool attn_any = !cfg.attention_resolutions.empty();
@@ -599,6 +658,14 @@ void UNet::build(bool dry_run) {
         for (int l = 0; l < nl; ++l) {
             Tensor a = talloc(cfg.audio_channels[l], z >> l);
             a.bmod = key.bmod;
+            if (ctx->fuse_norm && ctx->fuse_stats) {          // row sums of the (step-invariant) audio maps: once per call
+                const int rows = Bn * a.C;
+                a.rowstat = dry ? reinterpret_cast<double*>(256) : reinterpret_cast<double*>(dev_alloc((size_t)rows * 4));
+                const float* xp = a.p; double* rp = a.rowstat; const int T = a.T;
+                to_pre = true;
+                emit([=](hipStream_t st) { launch_row_sums(st, xp, rp, rows, T); }, OP_SMALL, 0, "audio row sums");
+                to_pre = false;
+            }
             in_audio.push_back(a);
         }
         Bn = save;
@@ -684,7 +751,7 @@ void UNet::build(bool dry_run) {
     {
         ConvSpec s;
         s.key = "out.2";
-        s.in = gn_inputs("out.0", {h}, 32, true, 3, 1, 1);
+        gn_inputs(s, "out.0", {h}, 32, true, 3, 1, 1);
         s.w = {WBlock{"out.2.weight", 0, 0, 0}};
         s.bias = {{"out.2.bias", 0}};
         s.Mrows = s.Mout = cfg.out_channels; s.Tout = z; s.out = out_eps;
@@ -854,6 +921,7 @@ void VaeDecoder::build(bool dry_run) {
     ops.clear();
     pre_ops.clear();
     emb_ops.clear();
+    begin_rowstat();
     Bn = kB;
     const int nres = (int)cfg.channel_mult.size(), g = cfg.num_groups;
     in_z = talloc(cfg.z_channels, kz);
@@ -872,7 +940,7 @@ void VaeDecoder::build(bool dry_run) {
     {
         ConvSpec s;
         s.key = "decoder.conv_out";
-        s.in = gn_inputs("decoder.norm_out", {h}, g, true, 3, 1, 1);
+        gn_inputs(s, "decoder.norm_out", {h}, g, true, 3, 1, 1);
         s.w = {WBlock{"decoder.conv_out.weight", 0, 0, 0}};
         s.bias = {{"decoder.conv_out.bias", 0}};
         s.Mrows = s.Mout = cfg.x_channels; s.Tout = h.T; s.out = out_x;
@@ -904,6 +972,7 @@ void WaveEncoder::build(bool dry_run) {
     ops.clear();
     pre_ops.clear();
     emb_ops.clear();
+    begin_rowstat();
     Bn = kB;
     const int nres = (int)cfg.channel_mult.size(), g = cfg.num_groups, mid = cfg.middle_channels;
     in_mel = talloc(cfg.n_freq, kT);

@@ -164,3 +164,4 @@ static inline void sincospif(float x, float* s, float* c) {
 }
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+static inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
