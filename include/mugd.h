@@ -107,10 +107,12 @@ int mugd_unet_forward(mugd_net* unet, const float* x, const int64_t* t, const fl
  * timesteps[S] (host, already in sampling order, i.e. descending) and sched[S][4] =
  * {a_t, a_prev, sigma_t, sqrt(1-a_t)} (host fp32, the values p_sample_ddim puts in torch.full).
  * noise: NULL, or (S,B,in_ch,z) device fp32 consumed as sigma_t * noise[i] (only matters if eta>0).
- * pred_x0: NULL or (B,in_ch,z) receiving the last step's x_0 prediction. */
+ * pred_x0: NULL or (B,in_ch,z) receiving the last step's x_0 prediction.
+ * first: NULL or (2,B,in_ch,z) receiving x and the x_0 prediction after the FIRST step of the call (the intermediates the
+ * reference records at i == 0, ddim.py:154-156), so that a whole sampling run is one call. */
 int mugd_ddim_sample(mugd_net* unet, float* x, const float* c, const float* uc, int n_tok,
                      const float* const* audio, int audio_batch, int B, int z, int S, const int64_t* timesteps,
-                     const float* sched, float scale, const float* noise, float* pred_x0);
+                     const float* sched, float scale, const float* noise, float* pred_x0, float* first);
 
 /* Measurement hook: runs the program last compiled by mugd_unet_forward / mugd_ddim_sample /
  * mugd_vae_decode / mugd_wave_encode ONCE, eagerly, with a HIP event pair around every kernel

@@ -194,12 +194,12 @@ int mugd_unet_forward(mugd_net* net, const float* x, const int64_t* t, const flo
 
 int mugd_ddim_sample(mugd_net* net, float* x, const float* c, const float* uc, int n_tok,
                      const float* const* audio, int audio_batch, int B, int z, int S, const int64_t* timesteps,
-                     const float* sched, float scale, const float* noise, float* pred_x0) {
+                     const float* sched, float scale, const float* noise, float* pred_x0, float* first) {
     if (!net) return MUGD_ERR_INVALID;
     return guarded(net->ctx, [&] {
         MUGD_CHECK(net->kind == 0, MUGD_ERR_INVALID, "not a U-Net handle");
         MUGD_CHECK(x && c && audio && timesteps && sched && B > 0 && z > 0 && S > 0, MUGD_ERR_INVALID, "null/empty argument");
-        static_cast<UNet*>(net->net.get())->sample(x, c, uc, n_tok, audio, audio_batch, B, z, S, (const long long*)timesteps, sched, scale, noise, pred_x0);
+        static_cast<UNet*>(net->net.get())->sample(x, c, uc, n_tok, audio, audio_batch, B, z, S, (const long long*)timesteps, sched, scale, noise, pred_x0, first);
     });
 }
 

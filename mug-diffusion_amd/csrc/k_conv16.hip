@@ -91,12 +91,12 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
             }
             const double inv = 1.0 / (double)s.C;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 4; ++i) {             // E[x^2] - mean^2 in fp64 (cancellation), 1/sqrt in fp32 like torch's LayerNorm
                 const double m = (double)s1[i] * inv;
-                double var = (double)s2[i] * inv - m * m;
-                var = var > 0.0 ? var : 0.0;
+                float var = (float)((double)s2[i] * inv - m * m);
+                var = var > 0.f ? var : 0.f;
                 mu[i] = (float)m;
-                rs4[i] = (float)(1.0 / sqrt(var + (double)s.xf_eps));
+                rs4[i] = 1.0f / sqrtf(var + s.xf_eps);
             }
         } else {
             const float* cs = s.xf_a + (size_t)b * s.xf_stride;

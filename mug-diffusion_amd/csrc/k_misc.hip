@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256) void ddim_step_kernel(const DdimStepArgs a) {
             if (a.noise) xn += sigma * a.noise[(size_t)step * a.n + i];
             a.x[i] = xn;
             if (a.pred_x0) a.pred_x0[i] = pred;
+            if (a.first && step == 0) { a.first[i] = xn; a.first[a.n + i] = pred; }
         }
         a.in_x[i] = xn;
         if (a.cfg) a.in_x[a.n + i] = xn;

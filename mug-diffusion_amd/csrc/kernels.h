@@ -191,6 +191,7 @@ void launch_ddim_update(hipStream_t st, const DdimArgs& a);
 
 struct DdimStepArgs {
     float* x; const float* eps; const float* noise; float* pred_x0;
+    float* first;            // null, or (2, n): x and pred_x0 after step 0 of the call (the reference logs them: ddim.py:154-156)
     const float* sched;      // [S][4] = a_t, a_prev, sigma, sqrt(1-a_t) (device)
     int* step_idx;           // device: [0] the current step (row of sched / noise / emb_table), [1] the number of steps S
     int* ticket;             // device scalar, zero between launches

@@ -184,7 +184,7 @@ public:
     // DDIM loop (mug/diffusion/ddim.py:110-196), x updated in place.
     void sample(float* x, const float* c, const float* uc, int n_tok, const float* const* audio, int audio_batch,
                 int B, int z, int S, const long long* t_host, const float* sched_host, float scale,
-                const float* noise, float* pred_x0);
+                const float* noise, float* pred_x0, float* first);
     void drop_programs();
     void invalidate() override;
     UNetConfig cfg;
@@ -205,16 +205,16 @@ private:
     float* noise_dev = nullptr; size_t noise_cap = 0, state_cap = 0;
     int step_init[2] = {0, 0};
     float* emb_table = nullptr; float* emb_tmp = nullptr; int* ticket_dev = nullptr;     // [S][rowadd_total] + scratch of its 3 GEMVs
-    float* pred_dev = nullptr;
-    hipGraphExec_t graph = nullptr; bool graph_cfg = false; bool graph_noise = false; bool graph_pred = false; float graph_scale = 0.f;
+    float* pred_dev = nullptr; float* first_dev = nullptr;
+    hipGraphExec_t graph = nullptr; bool graph_cfg = false; bool graph_noise = false; bool graph_pred = false; bool graph_first = false; float graph_scale = 0.f;
 
     void ensure(int B, int z, int ntok, int bmod);
     void build(bool dry_run);
     Tensor resblock(const std::string& prefix, const std::vector<Tensor>& segs, int Cout, int rowadd_off);
     void prepare_emb();
     std::vector<std::pair<std::string, int>> resblock_list() const;   // (prefix, Cout) in execution order
-    void step_body(hipStream_t st, bool cfg, float scale, bool with_noise, bool with_pred, int nstate, int S);
-    DdimStepArgs step_args(bool cfg, float scale, bool with_noise, bool with_pred, int nstate, int S, int mode) const;
+    void step_body(hipStream_t st, bool cfg, float scale, bool with_noise, bool with_pred, bool with_first, int nstate, int S);
+    DdimStepArgs step_args(bool cfg, float scale, bool with_noise, bool with_pred, bool with_first, int nstate, int S, int mode) const;
 };
 
 struct VaeConfig {

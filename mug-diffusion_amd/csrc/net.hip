@@ -762,7 +762,7 @@ void UNet::build(bool dry_run) {
 void UNet::invalidate() {
     drop_programs();
     Net::invalidate();
-    x_state = pred_dev = noise_dev = sched_dev = nullptr;
+    x_state = pred_dev = first_dev = noise_dev = sched_dev = nullptr;
     ttab_dev = nullptr; step_dev = nullptr; ticket_dev = nullptr; emb_table = emb_tmp = nullptr;
     sched_cap = 0; noise_cap = state_cap = 0;
 }
@@ -809,9 +809,9 @@ void UNet::forward(const float* x, const long long* t, const float* context, int
     HIP_CHECK(hipMemcpyAsync(eps, out_eps.p, (size_t)B * out_eps.C * z * sizeof(float), hipMemcpyDeviceToDevice, st));
 }
 
-DdimStepArgs UNet::step_args(bool cfg_on, float scale, bool with_noise, bool with_pred, int nstate, int S, int mode) const {
+DdimStepArgs UNet::step_args(bool cfg_on, float scale, bool with_noise, bool with_pred, bool with_first, int nstate, int S, int mode) const {
     DdimStepArgs d{};
-    d.x = x_state; d.eps = out_eps.p; d.noise = with_noise ? noise_dev : nullptr; d.pred_x0 = with_pred ? pred_dev : nullptr;
+    d.x = x_state; d.eps = out_eps.p; d.noise = with_noise ? noise_dev : nullptr; d.pred_x0 = with_pred ? pred_dev : nullptr; d.first = with_first ? first_dev : nullptr;
     d.sched = sched_dev; d.step_idx = step_dev; d.ticket = ticket_dev; d.in_x = in_x.p;
     d.emb_table = emb_table; d.emb_rows = emb_rowadd;
     d.n = nstate; d.cfg = cfg_on ? 1 : 0; d.Bnet = key.B; d.emb_total = rowadd_total; d.mode = mode; d.scale = scale;
@@ -819,14 +819,14 @@ DdimStepArgs UNet::step_args(bool cfg_on, float scale, bool with_noise, bool wit
 }
 
 // one DDIM step = the U-Net program + ONE more launch (CFG combine, DDIM update, next input, next time-embedding rows, counter)
-void UNet::step_body(hipStream_t st, bool cfg_on, float scale, bool with_noise, bool with_pred, int nstate, int S) {
+void UNet::step_body(hipStream_t st, bool cfg_on, float scale, bool with_noise, bool with_pred, bool with_first, int nstate, int S) {
     run_ops(st);
-    launch_ddim_step(st, step_args(cfg_on, scale, with_noise, with_pred, nstate, S, 1));
+    launch_ddim_step(st, step_args(cfg_on, scale, with_noise, with_pred, with_first, nstate, S, 1));
 }
 
 void UNet::sample(float* x, const float* c, const float* uc, int n_tok, const float* const* audio, int audio_batch,
                   int B, int z, int S, const long long* t_host, const float* sched_host, float scale,
-                  const float* noise, float* pred_x0) {
+                  const float* noise, float* pred_x0, float* first) {
     const bool cfg_on = (uc != nullptr) && (scale != 1.0f);       // ddim.py:167
     const int Bnet = cfg_on ? 2 * B : B;
     ensure(Bnet, z, n_tok, audio_bmod(audio_batch, Bnet, B));
@@ -854,6 +854,7 @@ void UNet::sample(float* x, const float* c, const float* uc, int n_tok, const fl
         drop_graph();
         x_state = dev_alloc(nstate);
         pred_dev = dev_alloc(nstate);
+        first_dev = dev_alloc(2 * (size_t)nstate);
         state_cap = nstate;
     }
     if (noise) {
@@ -887,10 +888,10 @@ void UNet::sample(float* x, const float* c, const float* uc, int n_tok, const fl
         launch_linear_small(st, LinSmallArgs{e1, PF("time_embed.2.weight"), PF("time_embed.2.bias"), emb, S, 4 * mc, 4 * mc, 0, 0, 4 * mc, 4 * mc});
         launch_linear_small(st, LinSmallArgs{emb, baked["emb.W"], baked["emb.b"], emb_table, S, 4 * mc, rowadd_total, 1, 0, 4 * mc, rowadd_total});
     }
-    const bool wn = noise != nullptr, wp = pred_x0 != nullptr;
-    launch_ddim_step(st, step_args(cfg_on, scale, wn, wp, nstate, S, 0));      // x_T -> U-Net input, embedding rows of step 0
+    const bool wn = noise != nullptr, wp = pred_x0 != nullptr, wf = first != nullptr;
+    launch_ddim_step(st, step_args(cfg_on, scale, wn, wp, wf, nstate, S, 0));      // x_T -> U-Net input, embedding rows of step 0
     if (ctx->use_graph) {
-        if (graph && (graph_cfg != cfg_on || graph_noise != wn || graph_pred != wp || graph_scale != scale)) {
+        if (graph && (graph_cfg != cfg_on || graph_noise != wn || graph_pred != wp || graph_first != wf || graph_scale != scale)) {
             HIP_CHECK(hipStreamSynchronize(st));
             hipGraphExecDestroy(graph);
             graph = nullptr;
@@ -898,18 +899,19 @@ void UNet::sample(float* x, const float* c, const float* uc, int n_tok, const fl
         if (!graph) {
             hipGraph_t g = nullptr;
             HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            step_body(st, cfg_on, scale, wn, wp, nstate, S);
+            step_body(st, cfg_on, scale, wn, wp, wf, nstate, S);
             HIP_CHECK(hipStreamEndCapture(st, &g));
             HIP_CHECK(hipGraphInstantiate(&graph, g, nullptr, nullptr, 0));
             HIP_CHECK(hipGraphDestroy(g));
-            graph_cfg = cfg_on; graph_noise = wn; graph_pred = wp; graph_scale = scale;
+            graph_cfg = cfg_on; graph_noise = wn; graph_pred = wp; graph_first = wf; graph_scale = scale;
         }
         for (int i = 0; i < S; ++i) HIP_CHECK(hipGraphLaunch(graph, st));
     } else {
-        for (int i = 0; i < S; ++i) step_body(st, cfg_on, scale, wn, wp, nstate, S);
+        for (int i = 0; i < S; ++i) step_body(st, cfg_on, scale, wn, wp, wf, nstate, S);
     }
     HIP_CHECK(hipMemcpyAsync(x, x_state, (size_t)nstate * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (wp) HIP_CHECK(hipMemcpyAsync(pred_x0, pred_dev, (size_t)nstate * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (wf) HIP_CHECK(hipMemcpyAsync(first, first_dev, 2 * (size_t)nstate * sizeof(float), hipMemcpyDeviceToDevice, st));
 }
 
 // =======================================================================================

@@ -53,7 +53,7 @@ _SIGS = {
     "mugd_net_set_param": [_p, C.c_char_p, _p, _i, _i, C.POINTER(C.c_int64)],
     "mugd_net_invalidate": [_p],
     "mugd_unet_forward": [_p, _p, _p, _p, _i, C.POINTER(_p), _i, _p, _i, _i],
-    "mugd_ddim_sample": [_p, _p, _p, _p, _i, C.POINTER(_p), _i, _i, _i, _i, C.POINTER(C.c_int64), C.POINTER(_f), _f, _p, _p],
+    "mugd_ddim_sample": [_p, _p, _p, _p, _i, C.POINTER(_p), _i, _i, _i, _i, C.POINTER(C.c_int64), C.POINTER(_f), _f, _p, _p, _p],
     "mugd_net_profile": [_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)],
     "mugd_vae_decode": [_p, _p, _p, _i, _i],
     "mugd_wave_encode": [_p, _p, C.POINTER(_p), _i, _i],
@@ -363,7 +363,7 @@ class Net:
         return {self.lib.dll.mugd_profile_kind_name(k).decode(): dict(ms=ms[k], flops=fl[k], launches=int(ln[k]))
                 for k in range(PROFILE_KINDS)}
 
-    def ddim_sample(self, x_T, c, audio, timesteps, sched, uc=None, scale=1.0, noise=None, want_pred_x0=False):
+    def ddim_sample(self, x_T, c, audio, timesteps, sched, uc=None, scale=1.0, noise=None, want_pred_x0=False, want_first=False):
         """timesteps: sequence of ints in sampling order; sched: (S,4) float32 rows {a_t, a_prev, sigma, sqrt(1-a_t)}."""
         lib = self.lib
         x = lib.f32(x_T).clone()
@@ -377,8 +377,11 @@ class Net:
         sc = (_f * (4 * S))(*flat)
         noise = lib.f32(noise) if noise is not None else None
         pred = torch.empty_like(x) if want_pred_x0 else None
+        first = torch.empty((2,) + tuple(x.shape), dtype=x.dtype, device=x.device) if want_first else None
         lib.check(lib.dll.mugd_ddim_sample(self.h, _ptr(x), _ptr(c), _ptr(uc), c.shape[2], arr, ab, B, z, S, ts, sc,
-                                           float(scale), _ptr(noise), _ptr(pred)))
+                                           float(scale), _ptr(noise), _ptr(pred), _ptr(first)))
+        if want_first:
+            return x, pred, first
         return (x, pred) if want_pred_x0 else x
 
     # VAE --------------------------------------------------------------------

@@ -4,7 +4,9 @@
 p_sample_ddim, :110-196) runs on the device inside libmugd (`mugd_ddim_sample`: hipGraph replay of the
 U-Net program + fused CFG/DDIM update), in as few native calls as the arguments allow:
 
-* no callbacks / mask:   one call for the first step (the reference logs its x / pred_x0 as an
+* no callbacks / mask, S <= log_every_t:  ONE call (the library also returns the state after the first step, which the
+                         reference logs as an intermediate, :154-156);
+* no callbacks / mask, S > log_every_t:   one call for the first step (the reference logs its x / pred_x0 as an
                          intermediate, :154-156), then one call per stretch between logging points;
 * callback / img_callback / mask / x0:  one native call per step, with the reference's host-side
                          logic (q_sample blend, callbacks) in between.
@@ -92,6 +94,21 @@ class DDIMSampler(object):
         log_after = [i for i in range(total) if (total - i - 1) % log_every_t == 0 or (total - i - 1) == total - 1]
         cuts = sorted(set(range(1, total + 1)) if per_step else set(i + 1 for i in log_after) | {total})
         bar = (tqdm_class or tqdm)(total=total, desc='Charting, using DDIM Sampler')
+        if not per_step and total > 1 and log_after == [0, total - 1]:
+            # the common case (S <= log_every_t, no callbacks): ONE native call for the whole loop; the library hands back the
+            # state after the first step, the only other intermediate the reference records
+            noise = None
+            if eta_on:
+                noise = torch.randn((total,) + tuple(shape), device=device) * temperature
+                if noise_dropout > 0.:
+                    noise = torch.nn.functional.dropout(noise, p=noise_dropout)
+            x, pred, first = net.ddim_sample(x, c, w, steps, rows, uc=uc, scale=float(unconditional_guidance_scale), noise=noise,
+                                             want_pred_x0=True, want_first=True)
+            if hasattr(bar, "update"):
+                bar.update(total)
+            intermediates['x_inter'] += [first[0], x]
+            intermediates['pred_x0'] += [first[1], pred]
+            cuts = []
         start = 0
         for end in cuts:
             n = end - start

@@ -25,14 +25,53 @@ SHAPES = [  # name, B, C, T, M, taps, norm, gated
 ]
 
 
+# (name, B, C, T, M, taps, norm, gated): the distinct hot layer shapes of the shipped U-Net at batch 4
+SWEEP = [
+    ("res3 c1 K4608", 4, 1536, 64, 512, 3, 1, 0), ("res3 c2 K1536", 4, 512, 64, 512, 3, 1, 0),
+    ("res2 c1 K4224", 4, 1408, 128, 384, 3, 1, 0), ("res2 c2 K1152", 4, 384, 128, 384, 3, 1, 0),
+    ("res1 c1 K3456", 4, 1152, 256, 256, 3, 1, 0), ("res1 c2 K768", 4, 256, 256, 256, 3, 1, 0),
+    ("res0 c1 K1920", 4, 640, 512, 128, 3, 1, 0), ("res0 c2 K384", 4, 128, 512, 128, 3, 1, 0),
+    ("qkv3", 4, 512, 64, 1536, 1, 2, 0), ("qkv2", 4, 384, 128, 1152, 1, 2, 0), ("qkv1", 4, 256, 256, 768, 1, 2, 0),
+    ("ff1.3", 4, 512, 64, 4096, 1, 2, 1), ("ff1.2", 4, 384, 128, 3072, 1, 2, 1), ("ff1.1", 4, 256, 256, 2048, 1, 2, 1),
+    ("ff2.3", 4, 2048, 64, 512, 1, 0, 0), ("ff2.2", 4, 1536, 128, 384, 1, 0, 0), ("ff2.1", 4, 1024, 256, 256, 1, 0, 0),
+    ("proj3", 4, 512, 64, 512, 1, 0, 0), ("proj2", 4, 384, 128, 384, 1, 0, 0), ("proj1", 4, 256, 256, 256, 1, 0, 0),
+    ("toq3 ln", 4, 512, 64, 512, 1, 2, 0), ("toq1 ln", 4, 256, 256, 256, 1, 2, 0),
+    ("s4glu3", 4, 512, 64, 1024, 1, 0, 1), ("s4glu0", 4, 128, 512, 256, 1, 0, 1),
+    ("s4out3 K1536", 4, 512, 64, 512, 3, 0, 0), ("s4out0 K384", 4, 128, 512, 128, 3, 0, 0),
+]
+
+
+def sweep(lib):
+    print("%-16s %7s %6s | best (tn,wk) us | auto us | all: tn32 wk1/2/4/8 ; tn16 wk1/2/4/8" % ("shape", "GFLOP", "tiles"))
+    for name, B, C, T, M, taps, norm, gated in SWEEP:
+        gf = 2.0 * M * C * taps * T * B / 1e9
+        Mo = M // 2 if gated else M
+        tiles = ((T + 31) // 32) * ((Mo + 31) // 32) * B
+        copies = max(1, int(300e6 / (M * C * taps * 4)))
+        nch = C // 16
+        res = {}
+        for tn in (32, 16):
+            for wk in (1, 2, 4, 8):
+                if wk > nch:
+                    continue
+                res[(tn, wk)] = lib.dev_bench_conv(B, C, T, M, taps, norm, bool(gated), wk=wk, tn=tn, copies=copies, iters=100)
+        auto = lib.dev_bench_conv(B, C, T, M, taps, norm, bool(gated), wk=0, tn=0, copies=copies, iters=100)
+        best = min(res, key=res.get)
+        row = " ".join("%5.1f" % res.get((32, w), float("nan")) for w in (1, 2, 4, 8)) + " ; " + " ".join("%5.1f" % res.get((16, w), float("nan")) for w in (1, 2, 4, 8))
+        print("%-16s %7.3f %6d | (%2d,%d) %5.1f | %5.1f | %s" % (name, gf, tiles, best[0], best[1], res[best], auto, row), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--sweep", action="store_true")
     ap.add_argument("--pmc", action="store_true")
     ap.add_argument("--shape", type=int, default=0)
     ap.add_argument("--tn", type=int, default=0)
     ap.add_argument("--wk", type=int, default=0)
     a = ap.parse_args()
     lib = get_lib()
+    if a.sweep:
+        return sweep(lib)
     if a.pmc:
         name, B, C, T, M, taps, norm, gated = SHAPES[a.shape]
         copies = max(1, int(300e6 / (M * C * taps * 4)))
