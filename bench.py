@@ -217,10 +217,15 @@ def main():
             prof = unet.native().profile()
             k = {f: prof["conv_gemm"][f] + prof["conv_gemm_gated"][f] for f in ("ms", "flops", "launches")}
             achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12
+            traffic = None                      # HBM bytes per conv_gemm launch from a separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass
+            tpath = os.path.join(ROOT, "profiles", "conv_traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    traffic = json.load(f).get("hbm_bytes_per_launch")
             out["roofline"] = {"kernel": "conv_gemm_kernel / conv_gemm16_kernel (fp32-MFMA implicit-GEMM conv1d / linear, 32x32 and 32x16 tiles; "
                                          "all 212 launches of one U-Net evaluation, HIP events around every launch on the library stream)",
                                "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                               "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                                "launches_per_unet_eval": k["launches"], "avg_launch_us": k["ms"] * 1e3 / max(k["launches"], 1),
                                "algorithmic_gflop_per_launch": k["flops"] / 1e9 / max(k["launches"], 1),
                                "by_kernel_ms": {n: round(v["ms"], 4) for n, v in prof.items()}}

@@ -95,6 +95,7 @@ int mugd_create(int device, void* stream, mugd_ctx** out) {
 void mugd_destroy(mugd_ctx* ctx) {
     if (!ctx) return;
     hipStreamSynchronize(ctx->c.stream);
+    if (ctx->c.scratch) hipFree(ctx->c.scratch);
     if (ctx->c.own_stream) hipStreamDestroy(ctx->c.stream);
     delete ctx;
 }

@@ -155,9 +155,18 @@ void log_mel(Ctx* ctx, const float* pcm, long long n, int sr, int n_fft, int hop
         plan = it->second;
     }
 
-    float *P = nullptr, *M = nullptr;
-    HIP_CHECK(hipMalloc((void**)&P, (size_t)kpad * frames * sizeof(float)));
-    HIP_CHECK(hipMalloc((void**)&M, (size_t)n_mels * frames * sizeof(float)));
+    // power spectrogram (kpad, frames) + mel energies (n_mels, frames) in the context's grow-only scratch: the call
+    // enqueues three kernels and returns (stream order protects the scratch against the next call)
+    const size_t need = ((size_t)kpad + n_mels) * frames + 4096;
+    if (need > ctx->scratch_cap) {
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (ctx->scratch) HIP_CHECK(hipFree(ctx->scratch));
+        ctx->scratch = nullptr; ctx->scratch_cap = 0;
+        HIP_CHECK(hipMalloc((void**)&ctx->scratch, need * sizeof(float)));
+        ctx->scratch_cap = need;
+    }
+    float* P = ctx->scratch;
+    float* M = P + (((size_t)kpad * frames + 63) / 64) * 64;
     hipLaunchKernelGGL(stft_power_kernel, dim3(cdiv(frames, FB)), dim3(256), 0, st, pcm, n, n_fft, log2n, hop, frames, kpad, P);
     ConvArgs a{};
     a.nseg = 1;
@@ -167,7 +176,4 @@ void log_mel(Ctx* ctx, const float* pcm, long long n, int sr, int n_fft, int hop
     launch_conv_gemm(st, a);
     const long long tot = (long long)n_mels * frames;
     hipLaunchKernelGGL(log1p_half_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float*)M, out, tot);
-    HIP_CHECK(hipStreamSynchronize(st));
-    HIP_CHECK(hipFree(P));
-    HIP_CHECK(hipFree(M));
 }

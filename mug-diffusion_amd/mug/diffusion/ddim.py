@@ -34,8 +34,11 @@ class DDIMSampler(object):
 
     def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True):
         """ddim.py:24-53 (only the buffers the sampler reads)."""
-        self.ddim_timesteps = make_ddim_timesteps(ddim_discretize, ddim_num_steps, self.ddpm_num_timesteps, verbose=verbose)
         ac = self.model.alphas_cumprod
+        key = (ddim_discretize, int(ddim_num_steps), float(ddim_eta), ac.data_ptr(), ac._version)
+        if getattr(self, "_sched_key", None) == key:       # same schedule as the last call: no device round trip
+            return
+        self.ddim_timesteps = make_ddim_timesteps(ddim_discretize, ddim_num_steps, self.ddpm_num_timesteps, verbose=verbose)
         assert ac.shape[0] == self.ddpm_num_timesteps, 'alphas have to be defined for each timestep'
         sig, a, ap = make_ddim_sampling_parameters(ac.detach().cpu().numpy(), self.ddim_timesteps, ddim_eta, verbose=verbose)
         self.ddim_sigmas = np.asarray(sig, dtype=np.float64)
@@ -45,6 +48,7 @@ class DDIMSampler(object):
         self.register_buffer('betas', self.model.betas.clone().detach().float())
         self.register_buffer('alphas_cumprod', ac.clone().detach().float())
         self.register_buffer('alphas_cumprod_prev', self.model.alphas_cumprod_prev.clone().detach().float())
+        self._sched_key = key
 
     @torch.no_grad()
     def sample(self, S, c, w, batch_size, shape=None, callback=None, img_callback=None, eta=0., mask=None, x0=None,

@@ -45,12 +45,16 @@ class UNetModel(NativeModule):
     def prepare_length(self, z):
         """The reference grows each S4 kernel lazily inside forward (s4.py:726-730, mutating C and L);
         do the same here, before the native call, for every S4 layer at its level's length."""
-        sd = dict(self.named_parameters())
-        sd.update(dict(self.named_buffers()))
+        sd = dict(self._tensor_list())
+        lbufs = [sd[p + ".s4_model.kernel.kernel.L"] for p in self._s4_ds]
+        key = (int(z), hash(tuple((t.data_ptr(), t._version) for t in lbufs)))
+        if getattr(self, "_len_ok", None) == key:          # lengths already checked for this z and these buffers: no device sync
+            return
         for p, ds in self._s4_ds.items():
             k = p + ".s4_model.kernel.kernel."
             params = {n: sd[k + n] for n in s4host.S4_SUFFIXES}
             s4host.ensure_length_(params, z // ds)
+        self._len_ok = (int(z), hash(tuple((t.data_ptr(), t._version) for t in lbufs)))
 
     @torch.no_grad()
     def forward(self, x, timesteps=None, context=None, *audios):
