@@ -196,3 +196,20 @@ def test_graph_and_eager_agree(lib):
     ref = sampler.ddim_sample(sd, case["unet"], S, c, w, xT, eta=1.0, noise=list(noise))
     d, s = report("ddim eta=1", a, ref)
     assert d < 1e-3 * max(1.0, s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("z,B", [(512, 4), (1632, 1)])
+def test_full_unet_at_benchmark_and_long_lengths_vs_oracle(gpu_lib, z, B):
+    """BASELINE configs[1] (3-min audio, z = 512, batch 4: the shape bench.py times, with every fused path active --
+    GroupNorm / LayerNorm from producer sums, 16-wide tiles, in-kernel S4 GroupNorm) and configs[3] as the reference
+    actually runs it (10-min audio = the whole sequence at z = 1632) against the oracle on the same seeded inputs."""
+    case = cases.FULL
+    sd = state_dict(case, z)
+    x, t = cases.x_T(11, B, z), torch.full((B,), 481, dtype=torch.long)
+    c, w = cases.context(case, 11, B), cases.audio_maps(case, 11, 1, z)
+    ref = nets.unet_forward(sd, case["unet"], x, t, c, [m.repeat(B, 1, 1) for m in w])
+    got = native(gpu_lib, case, z, "unet").forward(x, t, c, w)          # audio maps shared by the batch rows (audio_batch 1)
+    d, s = report("unet full z=%d B=%d vs oracle" % (z, B), got, ref)
+    assert d < 2e-4 * max(1.0, s)
+    _net_cache.clear()
