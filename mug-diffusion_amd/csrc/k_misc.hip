@@ -1,6 +1,6 @@
-// Small kernels around the U-Net: timestep embedding + its MLP (GEMV class), the fused
-// classifier-free-guidance combine + DDIM update, prompt-token gather, batch duplication and
-// the device-side step counter that lets one captured graph be replayed for every DDIM step.
+// Small kernels around the U-Net: timestep embedding + its MLP (GEMV class), the per-step kernel (classifier-free-guidance
+// combine + DDIM update + next input + next time-embedding rows + device-side step counter, which lets one captured graph be
+// replayed for every DDIM step) and the prompt-token gather.
 #include "kernels.h"
 
 namespace {
@@ -41,28 +41,6 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const LinSmallArgs a)
         if (a.act_out) s = silu_f(s);
         a.y[(size_t)b * a.y_stride + m] = s;
     }
-}
-
-// mug/diffusion/ddim.py:170-196 (eta-general; noise may be null when sigma == 0).
-__global__ void ddim_update_kernel(const DdimArgs a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
-    const float* sc = a.sched + 4 * (*a.step_idx);
-    const float a_t = sc[0], a_prev = sc[1], sigma = sc[2], s1m = sc[3];
-    float e;
-    if (a.cfg) {
-        const float e_uc = a.eps[i], e_c = a.eps[a.n + i];
-        e = e_uc + a.scale * (e_c - e_uc);
-    } else {
-        e = a.eps[i];
-    }
-    const float x = a.x[i];
-    const float pred = (x - s1m * e) / sqrtf(a_t);
-    const float dir = sqrtf(1.0f - a_prev - sigma * sigma) * e;
-    float xn = sqrtf(a_prev) * pred + dir;
-    if (a.noise) xn += sigma * a.noise[(size_t)(*a.step_idx) * a.n + i];
-    a.x[i] = xn;
-    if (a.pred_x0) a.pred_x0[i] = pred;
 }
 
 // One launch per DDIM step for everything around the U-Net program (ddim.py:139-196 + unet.py:522-523):
@@ -123,20 +101,6 @@ __global__ void embed_tokens_kernel(const float* table, const long long* ids, fl
     out[i] = table[(size_t)ids[b * ntok + f] * dim + hdim];
 }
 
-__global__ void dup_batch_kernel(const float* src, float* dst, long long n) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { const float v = src[i]; dst[i] = v; dst[n + i] = v; }
-}
-
-__global__ void fill_t_kernel(long long* t_dev, const long long* t_table, const int* step_idx, int B) {
-    const int i = threadIdx.x;
-    if (i < B) t_dev[i] = t_table[*step_idx];
-}
-
-__global__ void advance_kernel(int* step_idx) {
-    if (threadIdx.x == 0) *step_idx += 1;
-}
-
 __global__ void bias_sum_kernel(const float* x, const float* y, float* out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (x ? x[i] : 0.f) + (y ? y[i] : 0.f);
@@ -151,9 +115,6 @@ void launch_timestep_embedding(hipStream_t st, const long long* t, const int* st
 void launch_linear_small(hipStream_t st, const LinSmallArgs& a) {
     hipLaunchKernelGGL(linear_small_kernel, dim3(cdiv(a.M, 4), a.B), dim3(256), 0, st, a);
 }
-void launch_ddim_update(hipStream_t st, const DdimArgs& a) {
-    hipLaunchKernelGGL(ddim_update_kernel, dim3(cdiv(a.n, 256)), dim3(256), 0, st, a);
-}
 void launch_ddim_step(hipStream_t st, const DdimStepArgs& a) {
     const int work = a.n > a.Bnet * a.emb_total ? a.n : a.Bnet * a.emb_total;
     int blocks = cdiv(work, 256);
@@ -163,15 +124,6 @@ void launch_ddim_step(hipStream_t st, const DdimStepArgs& a) {
 }
 void launch_embed_tokens(hipStream_t st, const float* table, const long long* ids, float* out, int B, int ntok, int dim) {
     hipLaunchKernelGGL(embed_tokens_kernel, dim3(cdiv(B * ntok * dim, 256)), dim3(256), 0, st, table, ids, out, B, ntok, dim);
-}
-void launch_dup_batch(hipStream_t st, const float* src, float* dst, long long n) {
-    hipLaunchKernelGGL(dup_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n);
-}
-void launch_fill_t(hipStream_t st, long long* t_dev, const long long* t_table, const int* step_idx, int B) {
-    hipLaunchKernelGGL(fill_t_kernel, dim3(1), dim3(256), 0, st, t_dev, t_table, step_idx, B);
-}
-void launch_advance(hipStream_t st, int* step_idx) {
-    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, st, step_idx);
 }
 void launch_bias_sum(hipStream_t st, const float* a, const float* b, float* out, int n) {
     hipLaunchKernelGGL(bias_sum_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, a, b, out, n);

@@ -179,16 +179,6 @@ void launch_linear_small(hipStream_t st, const LinSmallArgs& a);
 // sinusoidal timestep embedding (mug/model/util.py:156-176): out[b] = [cos(t f) | sin(t f)]
 void launch_timestep_embedding(hipStream_t st, const long long* t, const int* step_idx, float* out, int B, int dim);
 
-// CFG combine + DDIM update (ddim.py:170-196).  eps holds [uncond ; cond] when cfg != 0.
-struct DdimArgs {
-    float* x; const float* eps; const float* noise; float* pred_x0;   // noise: [S][n] indexed by *step_idx
-    const float* sched;      // [S][4] = a_t, a_prev, sigma, sqrt(1-a_t) (device)
-    const int* step_idx;     // device scalar: which row of sched
-    int n;                   // elements per batch half (B*C*T)
-    int cfg; float scale;
-};
-void launch_ddim_update(hipStream_t st, const DdimArgs& a);
-
 struct DdimStepArgs {
     float* x; const float* eps; const float* noise; float* pred_x0;
     float* first;            // null, or (2, n): x and pred_x0 after step 0 of the call (the reference logs them: ddim.py:154-156)
@@ -203,7 +193,4 @@ struct DdimStepArgs {
 };
 void launch_ddim_step(hipStream_t st, const DdimStepArgs& a);
 void launch_embed_tokens(hipStream_t st, const float* table, const long long* ids, float* out, int B, int ntok, int dim);
-void launch_dup_batch(hipStream_t st, const float* src, float* dst, long long n);          // dst = [src ; src]
-void launch_fill_t(hipStream_t st, long long* t_dev, const long long* t_table, const int* step_idx, int B);
-void launch_advance(hipStream_t st, int* step_idx);
 void launch_bias_sum(hipStream_t st, const float* a, const float* b, float* out, int n);

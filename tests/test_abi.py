@@ -37,3 +37,31 @@ def test_product_loader_has_no_cpu_fallback():
         pytest.skip("GPU present")
     with pytest.raises(_native.MugdError):
         _native.Lib()
+
+
+def test_error_paths_return_status_codes_not_exceptions():
+    """Nothing throws across the C boundary: bad arguments come back as negative mugd_status values with a message
+    (include/mugd.h conventions), here through the emulated build (same host code)."""
+    import torch
+    from conftest import emu_lib
+    from mug import _native
+    lib = emu_lib()
+    dll = lib.dll
+    assert dll.mugd_set_conv_tiling(lib.ctx, 3, 0) == -2 and b"wk" in dll.mugd_last_error(lib.ctx)
+    assert dll.mugd_set_conv_tiling(lib.ctx, 0, 24) == -2
+    assert dll.mugd_unet_forward(None, None, None, None, 0, None, 0, None, 0, 0) == -2
+    x = torch.zeros(1, 24, 8)                                   # 24 channels: not a multiple of the 16-channel K-chunk
+    w = torch.zeros(8, 24, 1)
+    with pytest.raises(_native.MugdError, match="multiple of 16"):
+        lib.op_conv1d(x, w)
+    with pytest.raises(_native.MugdError, match="divisible"):
+        lib.op_group_norm(torch.zeros(1, 30, 8), torch.ones(30), torch.zeros(30), 4, 0)
+    cfg = dict(in_channels=16, model_channels=32, out_channels=16, num_res_blocks=1, attention_resolutions=[2], channel_mult=[1, 2],
+               num_heads=2, context_dim=32, audio_channels=[32, 32], s4_layer=False)
+    net = lib.unet(cfg)                                          # no parameters registered
+    with pytest.raises(_native.MugdError, match="missing parameter"):
+        net.forward(torch.zeros(1, 16, 8), torch.zeros(1, dtype=torch.long), torch.zeros(1, 32, 3),
+                    [torch.zeros(1, 32, 8), torch.zeros(1, 32, 4)])
+    with pytest.raises(_native.MugdError, match="divisible"):   # latent length must be a multiple of 2^(levels-1)
+        net.forward(torch.zeros(1, 16, 7), torch.zeros(1, dtype=torch.long), torch.zeros(1, 32, 3),
+                    [torch.zeros(1, 32, 7), torch.zeros(1, 32, 3)])
