@@ -50,11 +50,3 @@ __device__ __forceinline__ void wave_gn_stats(const ConvArgs& a, int b, int lane
     wave_sync();
 }
 
-// {g, b} of concat channel c: gamma * rstd, beta - mean * gamma * rstd
-__device__ __forceinline__ float2 gn_scale_shift(const ConvSeg& s, const float2* gst, int c, float inv_cg) {
-    const int g = (int)(((float)c + 0.5f) * inv_cg);
-    const float2 gm = reinterpret_cast<const float2*>(s.xf_b)[c];
-    const float2 st = gst[g];
-    const float gg = gm.x * st.y;
-    return make_float2(gg, gm.y - st.x * gg);
-}

@@ -95,7 +95,8 @@ __device__ __forceinline__ void mfma_chunk(const char* smem_bytes, int rb0, int 
 template <int TAPS, bool DUAL, int NH, int XFK = -1, int ACT = -1, bool PIPE = false>
 __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* wseg, const float* wseg2, int lo, int hi,
                                                 int b, int t0, int lane, int h, int n, char* smem_bytes, int wave_base,
-                                                f32x16& acc, f32x16& acc2, const float2* gst, float inv_cg) {
+                                                f32x16& acc, f32x16& acc2, float2* gst, float inv_cg,
+                                                const ConvArgs& ka, int kg0, int kg1, bool& gn_pending) {
     const int r = lane >> 2, q = lane & 3;
     const int Tin = s.Tin;
     const int hw = (TAPS - 1) * s.dil;                     // halo samples per row (left pad + right rest)
@@ -135,35 +136,7 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
     } else if (xf == 2) {
         gb = s.xf_b + 2 * ((size_t)lo * CONV_CK + r);
         if (s.xf == 3) {
-            // LayerNorm statistics from the producer's column sums.  The 16 lanes that share this lane's 8 samples
-            // (same quarter q, rows r = 0..15) split the producer's row tiles between them -- lane r takes tiles r, r+16, ..:
-            // ONE batch of 4 loads per 16 tiles -- and the partial sums are combined with a fixed xor tree.
-            const float* ps = s.xf_a + (size_t)b * s.xf_stride;
-            const int tq0 = ok0 ? ti0 : Tin - 4, tq1 = ok1 ? ti1 : Tin - 4;
-            float s1[8], s2[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-            for (int p0 = r; p0 < s.xf_np; p0 += 16) {
-                const float4* row = reinterpret_cast<const float4*>(ps + (size_t)p0 * Tin * 2);
-                float4 v[4];
-                v[0] = row[tq0 / 2]; v[1] = row[tq0 / 2 + 1]; v[2] = row[tq1 / 2]; v[3] = row[tq1 / 2 + 1];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { s1[2 * j] += v[j].x; s2[2 * j] += v[j].y; s1[2 * j + 1] += v[j].z; s2[2 * j + 1] += v[j].w; }
-            }
-#pragma unroll
-            for (int o = 4; o < 64; o <<= 1) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { s1[i] += __shfl_xor(s1[i], o); s2[i] += __shfl_xor(s2[i], o); }
-            }
-            const double inv = 1.0 / (double)s.C;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {             // E[x^2] - mean^2 in fp64 (cancellation), 1/sqrt in fp32 like torch's LayerNorm
-                const double m = (double)s1[i] * inv;
-                float var = (float)((double)s2[i] * inv - m * m);
-                var = var > 0.f ? var : 0.f;
-                mu[i] = (float)m;
-                rs8[i] = 1.0f / sqrtf(var + s.xf_eps);
-            }
+            // statistics from the producer's column sums: computed by finish_ln(), after the first chunk's loads are in flight
         } else {
             const float* cs = s.xf_a + (size_t)b * s.xf_stride;
 #pragma unroll
@@ -177,6 +150,39 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
         }
     }
 
+    auto finish_ln = [&]() {
+        if (s.xf != 3) return;
+        // LayerNorm statistics from the producer's column sums.  The 16 lanes that share this lane's 8 samples
+        // (same quarter q, rows r = 0..15) split the producer's row tiles between them -- lane r takes tiles r, r+16, ..:
+        // ONE batch of 4 loads per 16 tiles -- and the partial sums are combined with a fixed xor tree.
+        const float* ps = s.xf_a + (size_t)b * s.xf_stride;
+        const int tq0 = ok0 ? ti0 : Tin - 4, tq1 = ok1 ? ti1 : Tin - 4;
+        float s1[8], s2[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+        for (int p0 = r; p0 < s.xf_np; p0 += 16) {
+            const float4* row = reinterpret_cast<const float4*>(ps + (size_t)p0 * Tin * 2);
+            float4 v[4];
+            v[0] = row[tq0 / 2]; v[1] = row[tq0 / 2 + 1]; v[2] = row[tq1 / 2]; v[3] = row[tq1 / 2 + 1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s1[2 * j] += v[j].x; s2[2 * j] += v[j].y; s1[2 * j + 1] += v[j].z; s2[2 * j + 1] += v[j].w; }
+        }
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s1[i] += __shfl_xor(s1[i], o); s2[i] += __shfl_xor(s2[i], o); }
+        }
+        const double inv = 1.0 / (double)s.C;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {             // E[x^2] - mean^2 in fp64 (cancellation), 1/sqrt in fp32 like torch's LayerNorm
+            const double m = (double)s1[i] * inv;
+            float var = (float)((double)s2[i] * inv - m * m);
+            var = var > 0.f ? var : 0.f;
+            mu[i] = (float)m;
+            rs8[i] = 1.0f / sqrtf(var + s.xf_eps);
+        }
+    };
+
     const int bb = s.bmod > 0 ? b % s.bmod : b;
     const char* xb = reinterpret_cast<const char*>(s.x + ((size_t)bb * s.C + (size_t)lo * CONV_CK) * Tin);
     const size_t xstep = (size_t)CONV_CK * Tin * 4;
@@ -189,9 +195,18 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
     float xh[NH > 0 ? NH : 1];
     float2 gbv = make_float2(1.f, 0.f);
 
-    auto load_gb = [&](int cr) -> float2 {          // per-channel {g, b} of chunk lo + cr for this lane's row
-        if (gn4) return gn_scale_shift(s, gst, s.xf_coff + (lo + cr) * CONV_CK + r, inv_cg);
+    int gbg = 0;                                    // gn4: GroupNorm group of the channel gbv belongs to
+    auto load_gb = [&](int cr) -> float2 {          // per-channel {g, b} of chunk lo + cr for this lane's row; for gn4 the raw
+        if (gn4) {                                  // {gamma, beta}: the group statistics are folded in when the chunk is parked,
+            const int c = s.xf_coff + (lo + cr) * CONV_CK + r;      // so no load here waits for the group reduction
+            gbg = (int)(((float)c + 0.5f) * inv_cg);
+            return reinterpret_cast<const float2*>(s.xf_b)[c];
+        }
         return *reinterpret_cast<const float2*>(gb + (size_t)cr * (2 * CONV_CK));
+    };
+    // the wave's GroupNorm group table is filled AFTER the first chunk's loads have been issued (one round trip for both)
+    auto finish_stats = [&]() {
+        if (gn_pending) { wave_gn_stats(ka, b, lane, kg0, kg1, gst); gn_pending = false; }
     };
     // transform the staged samples and park them in window `wofs` (byte offset 0 | WIN_LDS*4)
     auto park = [&](int wofs) {
@@ -201,7 +216,8 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
 #pragma unroll
         for (int j = 0; j < NH; ++j) vh[j] = xh[j];
         if (xf) {
-            const float g = gbv.x, bt = gbv.y;
+            float g = gbv.x, bt = gbv.y;
+            if (gn4) { const float2 st = gst[gbg]; g = gbv.x * st.y; bt = gbv.y - st.x * g; }
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = (xf == 1) ? v[i] * g + bt : (v[i] - mu[i]) * rs8[i] * g + bt;
 #pragma unroll
@@ -259,6 +275,8 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
         };
         fetch_a(0, Aa, Aa2);
         fetch_x(0);
+        finish_stats();
+        finish_ln();
         park(0);
         fetch_x(1);
         fetch_a(1, Ab, Ab2);
@@ -288,6 +306,8 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
     for (int j = 0; j < NH; ++j) xh[j] = *reinterpret_cast<const float*>(xb + gh[j]);
     int crel = 0;
     if (xf) gbv = load_gb(0);
+    finish_stats();
+    finish_ln();
 
     auto step = [&](const float4 (&A)[6], const float4 (&A2)[6], float4 (&An)[6], float4 (&An2)[6], bool more) {
         park(0);
@@ -460,7 +480,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
     // ---- GroupNorm of the leading segments from their producers' row sums: this wave's groups only (gn_wave.h)
     __shared__ float2 gnst[WK][32];
     const float gn_inv_cg = a.gn_groups ? 1.0f / (float)a.gn_cg : 0.f;
-    if (a.gn_groups) wave_gn_stats(a, b, lane, g0, g1, gnst[wave]);
+    bool gn_pending = a.gn_groups != 0;          // reduced by the first GroupNorm segment this wave runs, after its first loads are out
 
     // ---- epilogue operands: the side loads (bias / row term / residual) are issued HERE, before the K loop, from
     // clamped addresses under wave-uniform conditions, so their latency is off the kernel's critical path.
@@ -507,7 +527,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
                 const float* w1 = wtile + s.woff;
                 const float* w2 = wtile2 + s.woff;
 #define MUGD_SEG_ARGS s, w1, w2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, acc, acc2
-#define MUGD_SEG_VARGS MUGD_SEG_ARGS, gnst[wave], gn_inv_cg
+#define MUGD_SEG_VARGS MUGD_SEG_ARGS, gnst[wave], gn_inv_cg, a, g0, g1, gn_pending
                 if (KIND == 0) {
                     // specialise on (transform, activation): branch-free chunk loops
 #define MUGD_SEG_XF(T, NHALO)                                                                     \

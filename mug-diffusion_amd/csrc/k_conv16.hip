@@ -39,7 +39,8 @@ __device__ __forceinline__ void load_a16(const float* wp, const float* wp2, floa
 template <int TAPS, bool DUAL, int XFK = -1, int ACT = -1, bool PIPE = false>       // XFK / ACT / PIPE: see k_conv.hip
 __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wseg, const float* wseg2, int lo, int hi,
                                               int b, int t0, int lane, char* smem_bytes, int wave_base,
-                                              f32x4 (&acc)[2], f32x4 (&accg)[2], const float2* gst, float inv_cg) {
+                                              f32x4 (&acc)[2], f32x4 (&accg)[2], float2* gst, float inv_cg,
+                                              const ConvArgs& ka, int kg0, int kg1, bool& gn_pending) {
     constexpr int NH = TAPS == 3 ? 1 : 0;                  // dilation 1: 2 halo samples per row, one load for lanes q < 2
     const int r = lane >> 2, q = lane & 3;
     const int l15 = lane & 15, kq = lane >> 4;
@@ -72,32 +73,8 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
         if (!gn4) gb = s.xf_a + (size_t)b * s.xf_stride + 2 * ((size_t)lo * CONV_CK + r);
     } else if (xf == 2) {
         gb = s.xf_b + 2 * ((size_t)lo * CONV_CK + r);
-        if (s.xf == 3) {                     // LayerNorm statistics from the producer's column sums (see k_conv.hip)
-            const float* ps = s.xf_a + (size_t)b * s.xf_stride;
-            const int tq = ok0 ? ti : Tin - 4;
-            float s1[4], s2[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-            for (int p0 = r; p0 < s.xf_np; p0 += 16) {
-                const float4* row = reinterpret_cast<const float4*>(ps + (size_t)p0 * Tin * 2);
-                const float4 v0 = row[tq / 2], v1 = row[tq / 2 + 1];
-                s1[0] += v0.x; s2[0] += v0.y; s1[1] += v0.z; s2[1] += v0.w;
-                s1[2] += v1.x; s2[2] += v1.y; s1[3] += v1.z; s2[3] += v1.w;
-            }
-#pragma unroll
-            for (int o = 4; o < 64; o <<= 1) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { s1[i] += __shfl_xor(s1[i], o); s2[i] += __shfl_xor(s2[i], o); }
-            }
-            const double inv = 1.0 / (double)s.C;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {             // E[x^2] - mean^2 in fp64 (cancellation), 1/sqrt in fp32 like torch's LayerNorm
-                const double m = (double)s1[i] * inv;
-                float var = (float)((double)s2[i] * inv - m * m);
-                var = var > 0.f ? var : 0.f;
-                mu[i] = (float)m;
-                rs4[i] = 1.0f / sqrtf(var + s.xf_eps);
-            }
+        if (s.xf == 3) {
+            // statistics from the producer's column sums: computed by finish_ln(), after the first chunk's loads are in flight
         } else {
             const float* cs = s.xf_a + (size_t)b * s.xf_stride;
 #pragma unroll
@@ -109,6 +86,36 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
             if (NH) { const unsigned tc = gh / 4u % (unsigned)Tin; muh = cs[2 * tc]; rsh = cs[2 * tc + 1]; }
         }
     }
+    auto finish_ln = [&]() {
+        if (s.xf != 3) return;
+                // LayerNorm statistics from the producer's column sums (see k_conv.hip)
+        const float* ps = s.xf_a + (size_t)b * s.xf_stride;
+        const int tq = ok0 ? ti : Tin - 4;
+        float s1[4], s2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+        for (int p0 = r; p0 < s.xf_np; p0 += 16) {
+            const float4* row = reinterpret_cast<const float4*>(ps + (size_t)p0 * Tin * 2);
+            const float4 v0 = row[tq / 2], v1 = row[tq / 2 + 1];
+            s1[0] += v0.x; s2[0] += v0.y; s1[1] += v0.z; s2[1] += v0.w;
+            s1[2] += v1.x; s2[2] += v1.y; s1[3] += v1.z; s2[3] += v1.w;
+        }
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s1[i] += __shfl_xor(s1[i], o); s2[i] += __shfl_xor(s2[i], o); }
+        }
+        const double inv = 1.0 / (double)s.C;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {             // E[x^2] - mean^2 in fp64 (cancellation), 1/sqrt in fp32 like torch's LayerNorm
+            const double m = (double)s1[i] * inv;
+            float var = (float)((double)s2[i] * inv - m * m);
+            var = var > 0.f ? var : 0.f;
+            mu[i] = (float)m;
+            rs4[i] = 1.0f / sqrtf(var + s.xf_eps);
+        }
+    };
+
     const int bb = s.bmod > 0 ? b % s.bmod : b;
     const char* xb = reinterpret_cast<const char*>(s.x + ((size_t)bb * s.C + (size_t)lo * CONV_CK) * Tin);
     const size_t xstep = (size_t)CONV_CK * Tin * 4;
@@ -121,15 +128,24 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
     float xh = 0.f;
     float2 gbv = make_float2(1.f, 0.f);
 
-    auto load_gb = [&](int cr) -> float2 {
-        if (gn4) return gn_scale_shift(s, gst, s.xf_coff + (lo + cr) * CONV_CK + r, inv_cg);
+    int gbg = 0;
+    auto load_gb = [&](int cr) -> float2 {          // gn4: raw {gamma, beta}; the group statistics are folded in by park() (see k_conv.hip)
+        if (gn4) {
+            const int c = s.xf_coff + (lo + cr) * CONV_CK + r;
+            gbg = (int)(((float)c + 0.5f) * inv_cg);
+            return reinterpret_cast<const float2*>(s.xf_b)[c];
+        }
         return *reinterpret_cast<const float2*>(gb + (size_t)cr * (2 * CONV_CK));
+    };
+    auto finish_stats = [&]() {
+        if (gn_pending) { wave_gn_stats(ka, b, lane, kg0, kg1, gst); gn_pending = false; }
     };
     auto park = [&](int wofs) {
         float v[4], vh = xh;
         v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w;
         if (xf) {
-            const float g = gbv.x, bt = gbv.y;
+            float g = gbv.x, bt = gbv.y;
+            if (gn4) { const float2 st = gst[gbg]; g = gbv.x * st.y; bt = gbv.y - st.x * g; }
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = (xf == 1) ? v[i] * g + bt : (v[i] - mu[i]) * rs4[i] * g + bt;
             vh = (xf == 1) ? vh * g + bt : (vh - muh) * rsh * g + bt;
@@ -203,6 +219,8 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
         constexpr int W1 = WIN_LDS * 4;
         fetch_a(0, Aa, Aa2);
         fetch_x(0);
+        finish_stats();
+        finish_ln();
         park(0);
         fetch_x(1);
         fetch_a(1, Ab, Ab2);
@@ -230,6 +248,8 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
     if (NH) xh = *reinterpret_cast<const float*>(xb + gh);
     int crel = 0;
     if (xf) gbv = load_gb(0);
+    finish_stats();
+    finish_ln();
 
     auto step = [&](const float4 (&A)[6], const float4 (&A2)[6], float4 (&An)[6], float4 (&An2)[6], bool more) {
         park(0);
@@ -291,7 +311,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
     // ---- GroupNorm of the leading segments from their producers' row sums: this wave's groups only (gn_wave.h)
     __shared__ float2 gnst[WK][32];
     const float gn_inv_cg = a.gn_groups ? 1.0f / (float)a.gn_cg : 0.f;
-    if (a.gn_groups) wave_gn_stats(a, b, lane, g0, g1, gnst[wave]);
+    bool gn_pending = a.gn_groups != 0;
 
     // ---- epilogue operands, issued before the K loop (see k_conv.hip)
     constexpr int EPT = 8 / WK;          // accumulator registers (tile rows) finished by each wave
@@ -332,7 +352,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
             if (lo < hi) {
                 const float* w1 = wtile + s.woff;
                 const float* w2 = wtile2 + s.woff;
-#define MUGD_SEG16_ARGS s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, acc, accg, gnst[wave], gn_inv_cg
+#define MUGD_SEG16_ARGS s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, acc, accg, gnst[wave], gn_inv_cg, a, g0, g1, gn_pending
 #define MUGD_SEG16_XF(T)                                                                  \
     switch (s.xf * 4 + s.act) {                                                           \
         case 0: run_segment16<T, DUAL, 0, 0, true>(MUGD_SEG16_ARGS); break;                     \
