@@ -84,6 +84,8 @@ typedef struct {
 int mugd_unet_create(mugd_ctx* ctx, const mugd_unet_config* cfg, mugd_net** out);
 int mugd_vae_create(mugd_ctx* ctx, const mugd_vae_config* cfg, mugd_net** out);
 int mugd_wave_create(mugd_ctx* ctx, const mugd_wave_config* cfg, mugd_net** out);
+/* the Encoder half of AutoencoderKL (mug/firststage/autoencoder.py:196-265), same `ddconfig`; parameter names "encoder.*" */
+int mugd_vae_encoder_create(mugd_ctx* ctx, const mugd_vae_config* cfg, mugd_net** out);
 void mugd_net_destroy(mugd_net* net);
 
 /* Registers one state-dict tensor (name relative to the sub-model, e.g.
@@ -124,6 +126,11 @@ const char* mugd_profile_kind_name(int k);
 
 /* AutoencoderKL.decode (mug/firststage/autoencoder.py:75-77): z (B,z_ch,z) -> logits (B,x_ch,z*2^(n_levels-1)). */
 int mugd_vae_decode(mugd_net* vae, const float* z_lat, float* logits, int B, int z);
+
+/* Encoder.forward as used by AutoencoderKL.encode (autoencoder.py:67-73,244-265) for inpainting (ddim.py:141-144 blends
+ * q_sample(x0) under a mask): x (B,x_ch,T) -> moments (B,2*z_ch,T/2^(n_levels-1)); mean = first half of the channels, logvar =
+ * clamp(second half, -10, 20) (DiagonalGaussianDistribution, :356-362). */
+int mugd_vae_encode(mugd_net* vae_encoder, const float* x, float* moments, int B, int T);
 
 /* MelspectrogramScaleEncoder1D.forward (mug/cond/wave.py:450-464): mel (B,n_freq,Ta) ->
  * outs[l] (B, middle*channel_mult[l], Ta>>l), l < n_levels; a NULL outs[l] skips that copy. */

@@ -11,7 +11,7 @@ struct mugd_ctx {
 };
 struct mugd_net {
     mugd_ctx* ctx;
-    int kind;   // 0 unet, 1 vae, 2 wave
+    int kind;   // 0 unet, 1 vae decoder, 2 wave, 3 vae encoder
     std::unique_ptr<Net> net;
 };
 
@@ -150,6 +150,18 @@ int mugd_vae_create(mugd_ctx* ctx, const mugd_vae_config* c, mugd_net** out) {
     });
 }
 
+int mugd_vae_encoder_create(mugd_ctx* ctx, const mugd_vae_config* c, mugd_net** out) {
+    return guarded(ctx, [&] {
+        MUGD_CHECK(c && out, MUGD_ERR_INVALID, "null argument");
+        VaeConfig v;
+        v.x_channels = c->x_channels; v.middle_channels = c->middle_channels; v.z_channels = c->z_channels;
+        v.num_groups = c->num_groups; v.num_res_blocks = c->num_res_blocks;
+        v.channel_mult = ivec(c->channel_mult, c->n_levels, 8);
+        v.scale = c->scale;
+        *out = new mugd_net{ctx, 3, std::unique_ptr<Net>(new VaeEncoder(&ctx->c, v))};
+    });
+}
+
 int mugd_wave_create(mugd_ctx* ctx, const mugd_wave_config* c, mugd_net** out) {
     return guarded(ctx, [&] {
         MUGD_CHECK(c && out, MUGD_ERR_INVALID, "null argument");
@@ -223,6 +235,15 @@ int mugd_vae_decode(mugd_net* net, const float* z_lat, float* logits, int B, int
         MUGD_CHECK(net->kind == 1, MUGD_ERR_INVALID, "not a VAE handle");
         MUGD_CHECK(z_lat && logits && B > 0 && z > 0, MUGD_ERR_INVALID, "null/empty argument");
         static_cast<VaeDecoder*>(net->net.get())->decode(z_lat, logits, B, z);
+    });
+}
+
+int mugd_vae_encode(mugd_net* net, const float* x, float* moments, int B, int T) {
+    if (!net) return MUGD_ERR_INVALID;
+    return guarded(net->ctx, [&] {
+        MUGD_CHECK(net->kind == 3, MUGD_ERR_INVALID, "not a VAE-encoder handle");
+        MUGD_CHECK(x && moments && B > 0 && T > 0, MUGD_ERR_INVALID, "null/empty argument");
+        static_cast<VaeEncoder*>(net->net.get())->encode(x, moments, B, T);
     });
 }
 

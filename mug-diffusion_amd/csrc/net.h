@@ -236,6 +236,19 @@ private:
     void build(bool dry_run);
 };
 
+class VaeEncoder : public Net {
+public:
+    VaeEncoder(Ctx* c, const VaeConfig& cfg) : Net(c), cfg(cfg) {}
+    // Encoder.forward (autoencoder.py:244-265): x (B, x_ch, T) -> moments (B, 2 z_ch, T >> (levels-1))
+    void encode(const float* x, float* moments, int B, int T);
+    void invalidate() override { Net::invalidate(); built = false; }
+    VaeConfig cfg;
+private:
+    int kB = 0, kT = 0; bool built = false;
+    Tensor in_x, out_m;
+    void build(bool dry_run);
+};
+
 struct WaveConfig {
     int n_freq = 128, middle_channels = 128, num_res_blocks = 2, num_heads = 8, num_groups = 32;
     std::vector<int> channel_mult, attention_resolutions;

@@ -966,6 +966,54 @@ void VaeDecoder::decode(const float* z_lat, float* logits, int B, int z) {
 }
 
 // =======================================================================================
+// VAE encoder  (mug/firststage/autoencoder.py:196-265) -- inpainting / partial regeneration
+// =======================================================================================
+void VaeEncoder::build(bool dry_run) {
+    dry = dry_run;
+    arena.begin(dry_run);
+    ops.clear();
+    pre_ops.clear();
+    emb_ops.clear();
+    begin_rowstat();
+    Bn = kB;
+    const int nres = (int)cfg.channel_mult.size(), g = cfg.num_groups;
+    MUGD_CHECK(kT % (1 << (nres - 1)) == 0, -2, "VAE encoder: length must be divisible by 2^(levels-1)");
+    in_x = talloc(cfg.x_channels, kT);
+    out_m = talloc(2 * cfg.z_channels, kT >> (nres - 1));
+    Tensor h = conv_simple("encoder.conv_in", in_x, 3, 1, 1, 1, 0, kT);
+    for (int lvl = 0; lvl < nres; ++lvl) {
+        const int block_out = cfg.middle_channels * cfg.channel_mult[lvl];
+        for (int ib = 0; ib < cfg.num_res_blocks; ++ib)
+            h = resnet_block("encoder.down." + std::to_string(lvl) + ".block." + std::to_string(ib), h, block_out, g, 1, 1);
+        if (lvl != nres - 1) h = downsample("encoder.down." + std::to_string(lvl) + ".downsample", h);
+    }
+    h = resnet_block("encoder.mid.block_1", h, h.C, g, 1, 1);
+    h = resnet_block("encoder.mid.block_2", h, h.C, g, 1, 1);
+    ConvSpec s;
+    s.key = "encoder.conv_out";
+    gn_inputs(s, "encoder.norm_out", {h}, g, true, 3, 1, 1);
+    s.w = {WBlock{"encoder.conv_out.weight", 0, 0, 0}};
+    s.bias = {{"encoder.conv_out.bias", 0}};
+    s.Mrows = s.Mout = 2 * cfg.z_channels; s.Tout = h.T; s.out = out_m;
+    conv(s);
+}
+
+void VaeEncoder::encode(const float* x, float* moments, int B, int T) {
+    if (!built || B != kB || T != kT) {
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        kB = B; kT = T;
+        build(true);
+        arena.reserve(arena.peak());
+        build(false);
+        built = true;
+    }
+    hipStream_t st = ctx->stream;
+    HIP_CHECK(hipMemcpyAsync(in_x.p, x, (size_t)B * in_x.C * T * sizeof(float), hipMemcpyDeviceToDevice, st));
+    run_ops(st);
+    HIP_CHECK(hipMemcpyAsync(moments, out_m.p, (size_t)B * out_m.C * out_m.T * sizeof(float), hipMemcpyDeviceToDevice, st));
+}
+
+// =======================================================================================
 // wave encoder  (mug/cond/wave.py:398-464)
 // =======================================================================================
 void WaveEncoder::build(bool dry_run) {

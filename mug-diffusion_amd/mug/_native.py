@@ -50,6 +50,8 @@ _SIGS = {
     "mugd_unet_create": [_p, C.POINTER(UNetConfig), C.POINTER(_p)],
     "mugd_vae_create": [_p, C.POINTER(VaeConfig), C.POINTER(_p)],
     "mugd_wave_create": [_p, C.POINTER(WaveConfig), C.POINTER(_p)],
+    "mugd_vae_encoder_create": [_p, C.POINTER(VaeConfig), C.POINTER(_p)],
+    "mugd_vae_encode": [_p, _p, _p, _i, _i],
     "mugd_net_set_param": [_p, C.c_char_p, _p, _i, _i, C.POINTER(C.c_int64)],
     "mugd_net_invalidate": [_p],
     "mugd_unet_forward": [_p, _p, _p, _p, _i, C.POINTER(_p), _i, _p, _i, _i],
@@ -175,7 +177,7 @@ class Lib:
         self._nets.append(n)
         return n
 
-    def vae(self, cfg, scale=1.0):
+    def vae(self, cfg, scale=1.0, encoder=False):
         c = VaeConfig()
         c.x_channels, c.middle_channels, c.z_channels = cfg["x_channels"], cfg["middle_channels"], cfg["z_channels"]
         c.num_groups, c.num_res_blocks = cfg["num_groups"], cfg["num_res_blocks"]
@@ -183,8 +185,8 @@ class Lib:
         _ilist(c.channel_mult, cfg["channel_mult"])
         c.scale = float(scale)
         h = _p()
-        self.check(self.dll.mugd_vae_create(self.ctx, C.byref(c), C.byref(h)))
-        n = Net(self, h, "vae", dict(cfg))
+        self.check((self.dll.mugd_vae_encoder_create if encoder else self.dll.mugd_vae_create)(self.ctx, C.byref(c), C.byref(h)))
+        n = Net(self, h, "vae_encoder" if encoder else "vae", dict(cfg))
         self._nets.append(n)
         return n
 
@@ -392,6 +394,16 @@ class Net:
         up = 2 ** (len(self.cfg["channel_mult"]) - 1)
         out = lib.empty(B, self.cfg["x_channels"], z * up)
         lib.check(lib.dll.mugd_vae_decode(self.h, _ptr(z_lat), _ptr(out), B, z))
+        return out
+
+    def vae_encode(self, x):
+        """Encoder moments (B, 2 z_ch, T / 2^(levels-1)) of a note-grid tensor x (B, x_ch, T)."""
+        lib = self.lib
+        x = lib.f32(x)
+        B, _, T = x.shape
+        down = 2 ** (len(self.cfg["channel_mult"]) - 1)
+        out = lib.empty(B, 2 * self.cfg["z_channels"], T // down)
+        lib.check(lib.dll.mugd_vae_encode(self.h, _ptr(x), _ptr(out), B, T))
         return out
 
     # wave encoder -------------------------------------------------------------

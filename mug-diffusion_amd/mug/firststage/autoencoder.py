@@ -1,6 +1,5 @@
-"""mug.firststage.autoencoder -- AutoencoderKL (mug/firststage/autoencoder.py:13-77).  Only `decode`
-is on the sampling path and runs in libmugd; the encoder's parameters are registered so that the
-reference's checkpoints load with identical keys, but `encode` (training / inpainting) is not built."""
+"""mug.firststage.autoencoder -- AutoencoderKL (mug/firststage/autoencoder.py:13-77).  `decode` (sampling path) and
+`encode` (inpainting / partial regeneration: SURVEY 8f rank 3) run in libmugd; `forward` / losses are training-only."""
 import numpy as np          # noqa: F401
 import shutil               # noqa: F401
 import torch
@@ -46,8 +45,42 @@ class AutoencoderKL(NativeModule):
     def decode(self, z):
         return self.native().decode(z)
 
+    def native_encoder(self):
+        """A second native network over the same parameters (names "encoder.*")."""
+        lib = self.native().lib                      # registers / validates the parameters first
+        if getattr(self, "_native_enc", None) is None or self._native_enc.lib is not lib or self._enc_fp != self._fp:
+            self._native_enc = lib.vae(self._cfg, scale=self.scale, encoder=True)
+            self._native_enc.set_params(dict(self._tensor_list()))
+            self._enc_fp = self._fp
+        return self._native_enc
+
+    @torch.no_grad()
     def encode(self, x):
-        raise NotImplementedError("AutoencoderKL.encode (training / inpainting) is outside the native sampling path")
+        """autoencoder.py:67-73: the posterior over latents of a note-grid tensor (no gradients: inference use only)."""
+        return DiagonalGaussianDistribution(self.native_encoder().vae_encode(x), scale=self.scale)
 
     def forward(self, input, sample_posterior=True):
         raise NotImplementedError("AutoencoderKL.forward needs the encoder (training only)")
+
+
+class DiagonalGaussianDistribution(object):
+    """autoencoder.py:356-388 (the members inference code reads)."""
+
+    def __init__(self, parameters, deterministic=False, scale=1.0, logvar=None):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        if logvar is not None:
+            self.logvar = logvar * torch.ones_like(self.mean)
+        self.logvar = torch.clamp(self.logvar, -10.0, 20.0)
+        self.deterministic = deterministic
+        self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+        self.scale = scale
+        if self.deterministic:
+            self.var = self.std = torch.zeros_like(self.mean)
+
+    def sample(self):
+        return (self.mean + self.std * torch.randn(self.mean.shape).to(device=self.parameters.device)) * self.scale
+
+    def mode(self):
+        return self.mean * self.scale

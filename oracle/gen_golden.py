@@ -248,8 +248,39 @@ def s4_host_goldens():
     print("  s4 host goldens: L %d -> %d -> %d" % (out["init_L"], out["L_after24"], out["L_after40"]))
 
 
+def encode_goldens():
+    """AutoencoderKL.encode of the real reference (inpainting / partial regeneration row) -> *_vaeenc_*.npz."""
+    rep = {}
+    for case, z_list in ((cases.TINY, [32]), (cases.FULL, [96])):
+        model = ref_model(case)
+        man = weights.manifest_of(model.state_dict())
+        for z in z_list:
+            sd = weights.set_s4_lengths(weights.make_state_dict(man, seed=0), case["unet"], z)
+            load(model, sd)
+            up = 2 ** (len(case["vae"]["channel_mult"]) - 1)
+            x = cases.randn(13 + z, 3, (2, case["vae"]["x_channels"], z * up))
+            post = model.model.first_stage_model.encode(x)
+            m_ref = post.parameters
+            m_orc = nets.vae_encode(sd, case["vae"], x)
+            d = maxdiff(m_ref, m_orc)
+            print("  %s vae encode z=%d |oracle-ref|max %.3e  |ref|max %.3f" % (case["name"], z, d, m_ref.abs().max().item()))
+            assert d == 0.0
+            rep["%s vae encode z=%d |oracle-ref|max" % (case["name"], z)] = d
+            np.savez_compressed(os.path.join(G, "%s_vaeenc_z%d.npz" % (case["name"], z)), seed=13 + z, moments=m_ref.numpy(),
+                                mode=post.mode().numpy(), logvar=post.logvar.numpy())
+    path = os.path.join(G, "oracle_vs_reference.json")
+    with open(path) as f:
+        full = json.load(f)
+    full.update(rep)
+    with open(path, "w") as f:
+        json.dump(full, f, indent=1)
+
+
 def main():
     torch.set_num_threads(os.cpu_count())
+    if "--encode-only" in sys.argv:
+        encode_goldens()
+        return
     if "--s4-only" in sys.argv:
         s4_host_goldens()
         return

@@ -290,6 +290,24 @@ def vae_decode(sd, cfg, z, prefix="model.first_stage_model", scale=1.0):
     return conv1d(sd, p + ".conv_out", h, padding=1)
 
 
+def vae_encode(sd, cfg, x, prefix="model.first_stage_model"):
+    """Encoder.forward (mug/firststage/autoencoder.py:244-265) -> the `moments` tensor (B, 2*z_channels, T / 2^(levels-1)) that
+    AutoencoderKL.encode wraps in DiagonalGaussianDistribution (:67-73, 356-362): mean = first half, logvar = clamp(second, -10, 20)."""
+    p = prefix + ".encoder"
+    g = cfg["num_groups"]
+    h = conv1d(sd, p + ".conv_in", x, padding=1)
+    nres = len(cfg["channel_mult"])
+    for lvl in range(nres):
+        for ib in range(cfg["num_res_blocks"]):
+            h = resnet_block(sd, "%s.down.%d.block.%d" % (p, lvl, ib), h, g)
+        if lvl != nres - 1:
+            h = downsample(sd, "%s.down.%d.downsample" % (p, lvl), h)
+    h = resnet_block(sd, p + ".mid.block_1", h, g)
+    h = resnet_block(sd, p + ".mid.block_2", h, g)
+    h = F.silu(group_norm(sd, p + ".norm_out", h, g))
+    return conv1d(sd, p + ".conv_out", h, padding=1)
+
+
 # ----------------------------------------------------------------------------
 # prompt embedding (mug/cond/feature.py:15-21)
 # ----------------------------------------------------------------------------

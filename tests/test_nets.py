@@ -103,6 +103,24 @@ def test_vae_decode_vs_reference_golden(lib, case, z):
 
 
 @pytest.mark.parametrize("case,z", CASES)
+def test_vae_encode_vs_reference_golden(lib, case, z):
+    """AutoencoderKL.encode (inpainting row): moments against the real reference's, and the oracle agrees bit for bit."""
+    lib = lib_for(lib, case)
+    g = golden("%s_vaeenc_z%d.npz" % (case["name"], z))
+    up = 2 ** (len(case["vae"]["channel_mult"]) - 1)
+    x = cases.randn(int(g["seed"]), 3, (2, case["vae"]["x_channels"], z * up))
+    ref = torch.from_numpy(g["moments"])
+    sd = state_dict(case, z)
+    assert torch.equal(nets.vae_encode(sd, case["vae"], x), ref)
+    enc = lib.vae(case["vae"], encoder=True)
+    enc.set_params(sd, "model.first_stage_model.")
+    got = enc.vae_encode(x)
+    d, s = report("vae encode %s" % case["name"], got, ref)
+    assert d < 2e-4 * max(1.0, s)
+    assert np.allclose(got[:, :ref.shape[1] // 2].cpu().numpy(), g["mode"], atol=2e-4 * max(1.0, s))
+
+
+@pytest.mark.parametrize("case,z", CASES)
 def test_wave_encoder_vs_reference_golden(lib, case, z):
     lib = lib_for(lib, case)
     g = golden("%s_wave_z%d.npz" % (case["name"], z))
