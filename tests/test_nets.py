@@ -231,3 +231,27 @@ def test_full_unet_at_benchmark_and_long_lengths_vs_oracle(gpu_lib, z, B):
     d, s = report("unet full z=%d B=%d vs oracle" % (z, B), got, ref)
     assert d < 2e-4 * max(1.0, s)
     _net_cache.clear()
+
+
+def test_one_handle_follows_changing_lengths_and_batches(lib):
+    """webui.py:349-367 mutates z_length per audio and `count` per request: one native handle is recompiled for each
+    (batch, length) and must give the same numbers as a fresh handle (program cache, row-sum block, baked S4 kernels)."""
+    case = cases.TINY
+    zs = [(32, 2), (64, 1), (32, 2), (32, 1)]
+    sd64 = state_dict(case, 64)                      # S4 buffers long enough for both lengths
+    shared = lib.unet(case["unet"])
+    shared.set_params(sd64, "model.unet_model.")
+    first = {}
+    for z, B in zs:
+        x, t = cases.x_T(3, B, z), torch.full((B,), 301, dtype=torch.long)
+        c, w = cases.context(case, 3, B), cases.audio_maps(case, 3, 1, z)
+        got = shared.forward(x, t, c, w).cpu()
+        fresh = lib.unet(case["unet"])
+        fresh.set_params(sd64, "model.unet_model.")
+        ref = fresh.forward(x, t, c, w).cpu()
+        assert torch.equal(got, ref), (z, B)
+        if (z, B) in first:
+            assert torch.equal(got, first[(z, B)])
+        first[(z, B)] = got
+        orc = nets.unet_forward(sd64, case["unet"], x, t, c, [m.repeat(B, 1, 1) for m in w])
+        assert (got - orc).abs().max().item() < 2e-4 * max(1.0, orc.abs().max().item())
