@@ -115,23 +115,24 @@ __global__ __launch_bounds__(256) void s4_conv_kernel(const S4ConvArgs a) {
 }
 
 
-// Fast path for L = 64 R, R in {1,2,4,8} (the U-Net levels at z = 512): one workgroup per (batch, feature) row.
-// The 4 waves split the TAP range (wave w takes taps [w L/4, (w+1) L/4) of every output); inside a wave, lane l owns
-// the R consecutive outputs t = l R .. l R + R-1 and keeps the R inputs u[t - s] it needs in a register window that
-// slides by one sample per tap (one LDS read per tap per lane, k[s] read as broadcast vectors): R FMAs per ~1.25 LDS
-// reads.  Causality is a zero-filled prefix of the LDS copy of u (branch-free); one pad word per 32 samples (index i
-// lives at i + i/32) makes the stride-R window reads conflict-free.  The 4 partial sums per output are combined through
-// LDS in fixed order.  With a.gn_gamma the workgroup also computes the GroupNorm statistics of its (batch row, group)
-// itself (cg rows of L samples: <= 32 KiB, L2-resident) instead of a separate statistics launch.
+// Fast path for any L <= 2048: one workgroup per (batch, feature) row, padded to LP = 64 R samples (R = 1..32, the smallest
+// that covers L).  The 4 waves split the TAP range (wave w takes taps [w LP/4, (w+1) LP/4) of every output); inside a
+// wave, lane l owns the R consecutive outputs t = l R .. l R + R-1 and keeps the R inputs u[t - s] it needs in a register
+// window that slides by one sample per tap (one LDS read per tap per lane, k[s] read as broadcast vectors): R FMAs per
+// ~1.25 LDS reads.  Causality is a zero-filled prefix of the LDS copy of u (branch-free), k and u are zero beyond L; one
+// pad word per 32 samples (index i lives at i + i/32) makes the stride-R window reads conflict-free.  The 4 partial sums
+// per output are combined through LDS in fixed order.  With a.gn_gamma the workgroup also computes the GroupNorm
+// statistics of its (batch row, group) itself (cg rows of L samples, L2-resident) instead of a separate statistics launch.
 template <int R>
 __global__ __launch_bounds__(256) void s4_conv_fast_kernel(const S4ConvArgs a) {
-    constexpr int L = 64 * R;
-    constexpr int LP = 2 * L + (2 * L) / 32;
-    constexpr int SEG = L / 4;                       // taps per wave
-    __shared__ __attribute__((aligned(16))) float ks[L];
-    __shared__ float uw[LP];
-    __shared__ float part[4][L];
+    constexpr int LP = 64 * R;
+    constexpr int LPP = 2 * LP + (2 * LP) / 32;
+    constexpr int SEG = LP / 4;                      // taps per wave
+    __shared__ __attribute__((aligned(16))) float ks[LP];
+    __shared__ float uw[LPP];
+    __shared__ float part[4][LP];
     __shared__ double red[2][4];
+    const int L = a.L;
     const int h = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void s4_conv_fast_kernel(const S4ConvArgs a) {
     } else if (a.gn_gamma) {
         const int cg = a.H / a.gn_groups, c0 = (h / cg) * cg;
         const float* ug = a.u + ((size_t)b * a.H + c0) * L;
-        const int n = cg * L;                        // multiple of 256
+        const int n = cg * L;
         double s1 = 0.0, s2 = 0.0;
         for (int base = tid; base < n; base += 256 * 8) {
             float v[8];
@@ -168,10 +169,11 @@ __global__ __launch_bounds__(256) void s4_conv_fast_kernel(const S4ConvArgs a) {
         ag = a.gn_gamma[h] * rstd;
         ab = a.gn_beta[h] - (float)mean_d * ag;
     }
-    for (int i = tid; i < L; i += 256) {
-        ks[i] = a.k[(size_t)h * L + i];
-        const int i1 = L + i;
-        uw[i1 + (i1 >> 5)] = u[i] * ag + ab;
+    for (int i = tid; i < LP; i += 256) {
+        const bool in = i < L;
+        ks[i] = in ? a.k[(size_t)h * L + i] : 0.f;
+        const int i1 = LP + i;
+        uw[i1 + (i1 >> 5)] = in ? u[i] * ag + ab : 0.f;
         uw[i + (i >> 5)] = 0.f;                      // causal padding: u[t] = 0 for t < 0
     }
     __syncthreads();
@@ -180,13 +182,14 @@ __global__ __launch_bounds__(256) void s4_conv_fast_kernel(const S4ConvArgs a) {
     float w[R], acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int i = L + t0 + r - s0;
+        const int i = LP + t0 + r - s0;
         w[r] = uw[i + (i >> 5)];
         acc[r] = 0.f;
     }
-    const int base = L + t0 - 1 - s0;                // sample index of u[t0 - s0 - 1]
+    const int base = LP + t0 - 1 - s0;               // sample index of u[t0 - s0 - 1]
     constexpr int STEP = R < SEG ? R : SEG;          // R = 1: SEG = 16 taps, one per iteration
-    for (int s = 0; s < SEG; s += STEP) {
+    const int s_end = (L - s0 < SEG) ? (L - s0) : SEG;     // taps >= L are zero: skip whole blocks of them
+    for (int s = 0; s < s_end; s += STEP) {
         float kv[R];
 #pragma unroll
         for (int j = 0; j < STEP; ++j) kv[j] = ks[s0 + s + j];
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(256) void s4_conv_fast_kernel(const S4ConvArgs a) {
     const float Dh = a.D[h];
     float* y = a.y + ((size_t)b * a.H + h) * L;
     for (int i = tid; i < L; i += 256) {
-        const int i1 = L + i;
+        const int i1 = LP + i;
         const float conv = ((part[0][i] + part[1][i]) + part[2][i]) + part[3][i];
         y[i] = gelu_erf_f(conv + Dh * uw[i1 + (i1 >> 5)]);
     }
@@ -218,18 +221,18 @@ void launch_s4_kernel_gen(hipStream_t st, const S4GenArgs& a) {
     hipLaunchKernelGGL(s4_kernel_gen_kernel, dim3(a.H), dim3(256), 0, st, a);
 }
 
-bool s4_conv_fuses_group_norm(int L) { return L == 64 || L == 128 || L == 256 || L == 512; }
+bool s4_conv_fuses_group_norm(int L) { return L >= 1 && L <= 2048; }
 
 void launch_s4_conv(hipStream_t st, const S4ConvArgs& a) {
     MUGD_CHECK(a.L <= S4_LMAX, -2, "s4: sequence longer than 4096");
     MUGD_CHECK(!a.gn_gamma || a.aff || (s4_conv_fuses_group_norm(a.L) && a.gn_groups > 0 && a.H % a.gn_groups == 0), -2,
-               "s4: in-kernel GroupNorm needs L in {64,128,256,512}");
+               "s4: in-kernel GroupNorm needs L <= 2048");
     const dim3 gf(a.H, a.B);
-    switch (a.L) {
-        case 64: hipLaunchKernelGGL((s4_conv_fast_kernel<1>), gf, dim3(256), 0, st, a); break;
-        case 128: hipLaunchKernelGGL((s4_conv_fast_kernel<2>), gf, dim3(256), 0, st, a); break;
-        case 256: hipLaunchKernelGGL((s4_conv_fast_kernel<4>), gf, dim3(256), 0, st, a); break;
-        case 512: hipLaunchKernelGGL((s4_conv_fast_kernel<8>), gf, dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL(s4_conv_kernel, dim3(a.H, a.B), dim3(256), 0, st, a);
-    }
+    if (a.L <= 64) hipLaunchKernelGGL((s4_conv_fast_kernel<1>), gf, dim3(256), 0, st, a);
+    else if (a.L <= 128) hipLaunchKernelGGL((s4_conv_fast_kernel<2>), gf, dim3(256), 0, st, a);
+    else if (a.L <= 256) hipLaunchKernelGGL((s4_conv_fast_kernel<4>), gf, dim3(256), 0, st, a);
+    else if (a.L <= 512) hipLaunchKernelGGL((s4_conv_fast_kernel<8>), gf, dim3(256), 0, st, a);
+    else if (a.L <= 1024) hipLaunchKernelGGL((s4_conv_fast_kernel<16>), gf, dim3(256), 0, st, a);
+    else if (a.L <= 2048) hipLaunchKernelGGL((s4_conv_fast_kernel<32>), gf, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(s4_conv_kernel, dim3(a.H, a.B), dim3(256), 0, st, a);
 }

