@@ -144,6 +144,24 @@ int mugd_cond_embed(mugd_ctx* ctx, const float* table, const int64_t* ids, float
  * `sr` (device) -> log1p(mel power) rounded to fp16 and widened to fp32, (n_mels, 1 + n/hop). */
 int mugd_log_mel(mugd_ctx* ctx, const float* pcm, int64_t n, int sr, int n_fft, int hop, int n_mels, float* out);
 
+/* ---- chart post-processing (the host step that dominates once sampling takes milliseconds) ---- */
+
+/* The candidate sweep of the BPM / offset fit: `test_timing(..., refine=False)` (mug/data/utils.py:16-27,42-43) for
+ * n_candidates (gap, offset) pairs in one launch -- `timing()` (utils.py:46-97) calls it ~7500 times per chart.
+ * valid_counts[c] = #{ i : |m - rint(m)| < epsilon_ms / gap_ms[c] },  m = (times_ms[i] - offset_ms[c]) / gap_ms[c],
+ * evaluated in IEEE float64 exactly as NumPy does (bit-identical counts); offset_is_f32[c] != 0 makes the subtraction a
+ * float32 one (NumPy's float32 array - float32 scalar: the first-note offset, utils.py:47).  gap = 60000 / (bpm * div).
+ * All pointers are device memory; work is enqueued on the context's stream. */
+int mugd_timing_sweep(mugd_ctx* ctx, const float* times_ms, int n_notes, const double* gap_ms, const double* offset_ms,
+                      const uint8_t* offset_is_f32, int n_candidates, double epsilon_ms, int32_t* valid_counts);
+
+/* remove_intractable_mania_mini_jacks (mug/data/utils.py:140-255) on parsed hit objects -- HOST pointers, host code (the
+ * pass is sequential and data-dependent).  Per note: start_ms = float(field 2), column = int(int(float(field 0)) /
+ * column_width), end_ms = long-note end or NaN (utils.py:7-13).  Outputs: keep[i] = 0 for removed notes; new_x[i] = INT32_MIN, or
+ * the new field-0 value int(round((column + 0.5) * column_width)) of a note moved to another column. */
+int mugd_remove_mini_jacks(int n_notes, const double* start_ms, const int32_t* column, const double* end_ms,
+                           double jack_interval_ms, int column_width, int32_t* new_x, uint8_t* keep);
+
 /* ---- single operators (the kernels behind the networks; used by the parity tests) ------ */
 int mugd_op_group_norm(mugd_ctx* ctx, const float* x, const float* gamma, const float* beta, float* y,
                        int B, int C, int T, int groups, int silu);

@@ -270,6 +270,27 @@ int mugd_log_mel(mugd_ctx* ctx, const float* pcm, int64_t n, int sr, int n_fft, 
     });
 }
 
+// ---------------------------------------------------------------- chart post-processing
+int mugd_timing_sweep(mugd_ctx* ctx, const float* times_ms, int n_notes, const double* gap_ms, const double* offset_ms,
+                      const uint8_t* offset_is_f32, int n_candidates, double epsilon_ms, int32_t* valid_counts) {
+    return guarded(ctx, [&] {
+        MUGD_CHECK(times_ms && gap_ms && offset_ms && offset_is_f32 && valid_counts, MUGD_ERR_INVALID, "null argument");
+        MUGD_CHECK(n_notes > 0 && n_candidates > 0, MUGD_ERR_INVALID, "empty note or candidate list");
+        launch_timing_sweep(ctx->c.stream, TimingSweepArgs{times_ms, n_notes, gap_ms, offset_ms, offset_is_f32, n_candidates,
+                                                           epsilon_ms, valid_counts});
+    });
+}
+
+int mugd_remove_mini_jacks(int n_notes, const double* start_ms, const int32_t* column, const double* end_ms,
+                           double jack_interval_ms, int column_width, int32_t* new_x, uint8_t* keep) {
+    return guarded(nullptr, [&] {
+        MUGD_CHECK(n_notes >= 0 && column_width > 0 && jack_interval_ms >= 0, MUGD_ERR_INVALID, "bad argument");
+        if (n_notes == 0) return;
+        MUGD_CHECK(start_ms && column && end_ms && new_x && keep, MUGD_ERR_INVALID, "null argument");
+        remove_mini_jacks_host(n_notes, start_ms, column, end_ms, jack_interval_ms, column_width, new_x, keep);
+    });
+}
+
 // ---------------------------------------------------------------- single operators
 int mugd_op_group_norm(mugd_ctx* ctx, const float* x, const float* gamma, const float* beta, float* y,
                        int B, int C, int T, int groups, int silu) {

@@ -192,5 +192,16 @@ struct DdimStepArgs {
     float scale;
 };
 void launch_ddim_step(hipStream_t st, const DdimStepArgs& a);
+// chart post-processing (k_timing.hip)
+struct TimingSweepArgs {
+    const float* times; int n;                     // note start times (ms), float32 like the reference's time_list
+    const double* gap; const double* offset;       // per candidate: grid spacing 60000 / (bpm * div) and grid origin (ms)
+    const unsigned char* offset_is_f32;            // per candidate: subtract in float32 (NumPy float32 - float32 scalar)
+    int n_cand; double epsilon; int* counts;
+};
+void launch_timing_sweep(hipStream_t st, const TimingSweepArgs& a);
+void remove_mini_jacks_host(int n, const double* start_ms, const int* column, const double* end_ms, double jack_interval,
+                            int column_width, int* new_x, unsigned char* keep);
+
 void launch_embed_tokens(hipStream_t st, const float* table, const long long* ids, float* out, int B, int ntok, int dim);
 void launch_bias_sum(hipStream_t st, const float* a, const float* b, float* out, int n);

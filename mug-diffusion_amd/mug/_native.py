@@ -12,6 +12,7 @@ CPU emulation of the kernels.  Product code never does.)
 import ctypes as C
 import os
 
+import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -61,6 +62,8 @@ _SIGS = {
     "mugd_wave_encode": [_p, _p, C.POINTER(_p), _i, _i],
     "mugd_cond_embed": [_p, _p, _p, _p, _i, _i, _i],
     "mugd_log_mel": [_p, _p, C.c_int64, _i, _i, _i, _i, _p],
+    "mugd_timing_sweep": [_p, _p, _i, _p, _p, _p, _i, C.c_double, _p],
+    "mugd_remove_mini_jacks": [_i, _p, _p, _p, C.c_double, _i, _p, _p],
     "mugd_op_group_norm": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i],
     "mugd_op_layer_norm": [_p, _p, _p, _p, _p, _i, _i, _i],
     "mugd_op_conv1d": [_p, _p, _p, _p, _p, _p] + [_i] * 11,
@@ -221,6 +224,33 @@ class Lib:
         return out
 
     # ------------------------------------------------------------------ single operators
+    def timing_sweep(self, times, gap, offset, offset_is_f32, epsilon=10.0):
+        """valid-note counts of (gap, offset) grid candidates (mug/data/utils.py:16-27): `times` is a float32 device
+        tensor, the candidate arrays are NumPy (float64, float64, bool); returns an int32 NumPy array."""
+        n_cand = len(gap)
+        g = torch.from_numpy(np.ascontiguousarray(gap, dtype=np.float64)).to(self.device)
+        o = torch.from_numpy(np.ascontiguousarray(offset, dtype=np.float64)).to(self.device)
+        f = torch.from_numpy(np.ascontiguousarray(offset_is_f32, dtype=np.uint8)).to(self.device)
+        counts = torch.empty(n_cand, dtype=torch.int32, device=self.device)
+        self.check(self.dll.mugd_timing_sweep(self.ctx, _ptr(times), times.numel(), _ptr(g), _ptr(o), _ptr(f), n_cand,
+                                              float(epsilon), _ptr(counts)))
+        return counts.cpu().numpy()
+
+    def remove_mini_jacks(self, start_ms, column, end_ms, jack_interval=90, column_width=128):
+        """Host pass (mug/data/utils.py:140-255) on parsed arrays -> (new_x int32 with INT32_MIN = not moved, keep bool)."""
+        n = len(start_ms)
+        st = np.ascontiguousarray(start_ms, dtype=np.float64)
+        co = np.ascontiguousarray(column, dtype=np.int32)
+        en = np.ascontiguousarray(end_ms, dtype=np.float64)
+        new_x = np.full(n, np.iinfo(np.int32).min, dtype=np.int32)
+        keep = np.ones(n, dtype=np.uint8)
+        rc = self.dll.mugd_remove_mini_jacks(n, st.ctypes.data_as(_p), co.ctypes.data_as(_p), en.ctypes.data_as(_p),
+                                             float(jack_interval), int(column_width), new_x.ctypes.data_as(_p),
+                                             keep.ctypes.data_as(_p))
+        if rc != 0:
+            raise MugdError("mugd_remove_mini_jacks failed with status %d" % rc)
+        return new_x, keep.astype(bool)
+
     def op_group_norm(self, x, gamma, beta, groups, silu):
         x, gamma, beta = self.f32(x), self.f32(gamma), self.f32(beta)
         y = torch.empty_like(x)

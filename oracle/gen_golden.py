@@ -276,8 +276,57 @@ def encode_goldens():
         json.dump(full, f, indent=1)
 
 
+def postprocess_goldens():
+    """`gridify` and `remove_intractable_mania_mini_jacks` of the real reference (mug/data/utils.py) on
+    seeded synthetic charts -> tests/golden/postprocess_golden.json.gz.  The module is loaded by file path: it needs numpy and
+    scikit-learn only.  Floats are stored as hex so the comparison is bit-for-bit."""
+    import contextlib
+    import importlib.util
+    import io
+    import sklearn
+    from oracle import postprocess as pp
+    spec = importlib.util.spec_from_file_location("ref_data_utils", os.path.join(refimport.REF, "mug/data/utils.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    specs = [dict(seed=0, beats=40), dict(seed=1, beats=160, bpm=187.0, offset=412.0),
+             dict(seed=2, beats=120, bpm=222.22, offset=35.0, jitter=7.0, ln_p=0.4),
+             dict(seed=3, beats=200, bpm=150.0, offset=1999.0, jitter=2.0, density=0.85, ln_p=0.05),
+             dict(seed=4, beats=64, bpm=271.3, offset=0.0, jitter=12.0),
+             dict(seed=5, beats=700, bpm=174.0, offset=733.0, jitter=3.0)]
+    charts = [dict(spec=sp, objects=pp.synthetic_chart(**sp)) for sp in specs]
+    charts.append(dict(spec="one note", objects=["64,192,1000,1,0,0:0:0:0:"]))
+    charts.append(dict(spec="two notes", objects=["64,192,1000,1,0,0:0:0:0:", "192,192,1400,128,0,1900:0:0:0:0:"]))
+    charts.append(dict(spec="same-time chord", objects=["%d,192,500,1,0,0:0:0:0:" % x for x in (64, 192, 320, 448)]))
+    out = []
+    for ch in charts:
+        ho = ch["objects"]
+        log = io.StringIO()
+        with contextlib.redirect_stdout(log):
+            snapped, bpm, offset = ref.gridify(ho, verbose=True)
+        improvements = log.getvalue().count("[valid")
+        rec = dict(spec=ch["spec"], objects=ho, snapped=snapped, bpm=float(bpm).hex(), offset=float(offset).hex(),
+                   offset_dtype=type(offset).__name__, improvements=improvements, jacks={})
+        # webui.py:401-407 order (snap, then jacks at the UI's interval) and scripts/mapping.py:496-498 order (jacks first)
+        for name, src, interval in (("after_snap_90", snapped, 90), ("raw_90", ho, 90), ("raw_150", ho, 150), ("after_snap_40", snapped, 40)):
+            rec["jacks"][name] = ref.remove_intractable_mania_mini_jacks(src, verbose=False, jack_interval=interval)
+            assert pp.remove_mini_jacks(src, interval) == rec["jacks"][name], (ch["spec"], name)
+        o_snapped, o_bpm, o_offset = pp.gridify(ho)
+        assert o_snapped == snapped and float(o_bpm).hex() == rec["bpm"] and float(o_offset).hex() == rec["offset"], ch["spec"]
+        assert type(o_offset).__name__ == rec["offset_dtype"]
+        print("  postprocess %-40s %5d notes  bpm %.4f offset %.3f  %d refits  jacks -> %d notes"
+              % (str(ch["spec"])[:40], len(ho), bpm, offset, improvements, len(rec["jacks"]["after_snap_90"])))
+        out.append(rec)
+    import gzip
+    with gzip.open(os.path.join(G, "postprocess_golden.json.gz"), "wt", encoding="utf8") as f:
+        json.dump(dict(numpy=np.__version__, sklearn=sklearn.__version__, charts=out), f)
+    print("  postprocess goldens: %d charts, oracle restatement identical" % len(out))
+
+
 def main():
     torch.set_num_threads(os.cpu_count())
+    if "--postprocess-only" in sys.argv:
+        postprocess_goldens()
+        return
     if "--encode-only" in sys.argv:
         encode_goldens()
         return
@@ -286,6 +335,7 @@ def main():
         return
     host_goldens()
     s4_host_goldens()
+    postprocess_goldens()
     run_case(cases.TINY, [32], {32: [(4, 2, 1.0), (4, 2, 5.0)]})
     if "--tiny-only" not in sys.argv:
         run_case(cases.FULL, [96, 512], {96: [(10, 1, 1.0), (10, 1, 5.0)]})

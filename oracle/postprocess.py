@@ -1,0 +1,218 @@
+"""TEST INFRASTRUCTURE -- CPU restatement of the reference's chart post-processing:
+BPM / offset fit + snapping (`gridify`) and mini-jack removal, `mug/data/utils.py:7-273` of the reference.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+(mug-diffusion_amd/mug/data/utils.py + csrc/k_timing.hip + csrc/host_jacks.cpp) never does.
+
+Pinned: tests/golden/postprocess_golden.json.gz holds inputs and outputs of the *real* reference functions run in the
+authoring container (oracle/gen_golden.py --postprocess-only, numpy 2.2.6 / scikit-learn 1.7.2); tests/test_postprocess.py
+checks this restatement against them string-for-string and bit-for-bit (bpm / offset as float hex).
+
+Arithmetic notes (they decide bit-exactness):
+  * `time_list` is float32 (utils.py:120).  `time_list - test_offset` is a float32 subtraction while `test_offset` is
+    the float32 first note time (utils.py:47,57), and a float64 one once the offset comes from a regression intercept or
+    from `np.arange` (NumPy >= 2 promotion: float32 array op float64 scalar -> float64).  The quotient by `gap`
+    (float64) is float64 in both cases.
+  * `np.round` is round-half-even (rint); `valid` is `error < epsilon / gap`, strict.
+  * the refinement is scikit-learn's weighted `LinearRegression` (LAPACK gelsd under scipy.linalg.lstsq): its result is
+    only reproducible by calling it, so this restatement -- like the reference, like the product -- calls scikit-learn.
+"""
+import numpy as np
+
+EPSILON = 10            # utils.py:104 (module level) and :21 (local copy with the same value)
+
+
+def parse_line(line, column_width=128):
+    """utils.py:7-13 -> (start_ms: float, column: int, end_ms: float or None)."""
+    p = line.split(",")
+    column = int(int(float(p[0])) / column_width)
+    end = float(p[5].split(":")[0]) if int(p[3]) == 128 else None
+    return float(p[2]), column, end
+
+
+def candidate_counts(times32, bpm, offset, div=1):
+    """The vectorised half of `test_timing` (utils.py:16-27): which notes sit within EPSILON ms of the grid
+    `offset + k * 60000 / (bpm * div)`; returns (valid int32 mask, rounded meter positions, gap)."""
+    gap = 60 * 1000 / (bpm * div)
+    delta = times32 - offset                     # float32 or float64, see the module docstring
+    meter = delta / gap
+    meter_round = np.round(meter)
+    valid = (np.abs(meter - meter_round) < EPSILON / gap).astype(np.int32)
+    return valid, meter_round, gap
+
+
+def refine(times32, meter_round, valid, bpm, offset):
+    """utils.py:29-40: weighted least squares of time on grid index over the valid notes, bpm folded into [150, 300)."""
+    from sklearn.linear_model import LinearRegression
+    if int(valid.sum()) < 2:
+        return bpm, offset
+    r = LinearRegression(fit_intercept=True)
+    r.fit(meter_round.reshape((-1, 1)), times32, sample_weight=valid)
+    if np.isinf(r.coef_) or np.isnan(r.coef_) or r.coef_[0] == 0:
+        return bpm, offset
+    new_offset = r.intercept_
+    new_bpm = 60000 / r.coef_[0] / 4
+    while new_bpm < 150:
+        new_bpm = new_bpm * 2
+    while new_bpm >= 300:
+        new_bpm = new_bpm / 2
+    return new_bpm, new_offset
+
+
+def timing(times32):
+    """utils.py:46-97: sweep 1500 tempi (150.0 ... 299.9) at the first note's offset and, after each, four quarter-beat
+    shifts of the best offset so far; a candidate that beats the best `valid / bpm` score is refined and becomes the
+    new best.  The two closing calls with div 16 / 6 (utils.py:87-90) do not change the result and are omitted."""
+    first = times32[0]
+    best_bpm, best_offset, best_score = None, None, -1
+    for test_bpm in np.arange(150, 300, 0.1):
+        cur_bpm = test_bpm
+        valid, mr, _ = candidate_counts(times32, test_bpm, first)
+        if valid.sum() / test_bpm > best_score:
+            best_score = valid.sum() / test_bpm
+            best_bpm, best_offset = refine(times32, mr, valid, test_bpm, first)
+            cur_bpm = best_bpm
+        gap = 60000 / cur_bpm
+        for test_offset in np.arange(best_offset, best_offset - gap, -gap / 4):
+            valid, mr, _ = candidate_counts(times32, cur_bpm, test_offset)
+            score = valid.sum() / cur_bpm
+            if score > best_score:
+                best_score = score
+                cur_bpm, best_offset = refine(times32, mr, valid, cur_bpm, test_offset)
+                best_bpm = cur_bpm
+    return best_bpm, best_offset
+
+
+def snap_time(t, bpm, offset):
+    """`format_time` of utils.py:123-131: first divisor in 1,2,4,3,6,8,16,32 whose grid has a line within EPSILON ms."""
+    for div in (1, 2, 4, 3, 6, 8, 16, 32):
+        gap = 60 * 1000 / (bpm * div)
+        meter = (t - offset) / gap
+        k = round(meter)
+        if abs(meter - k) < EPSILON / gap:
+            return str(int(k * gap + offset))
+    return str(int(t))
+
+
+def gridify(hit_objects):
+    """utils.py:106-139 -> (snapped hit objects, bpm, offset)."""
+    times32 = np.asarray([parse_line(l)[0] for l in hit_objects], dtype=np.float32)
+    bpm, offset = timing(times32)
+    out = []
+    for line in hit_objects:
+        e = line.split(",")
+        e[2] = snap_time(int(e[2]), bpm, offset)
+        if int(e[3]) == 128:
+            tail = e[5].split(":")
+            tail[0] = snap_time(int(tail[0]), bpm, offset)
+            e[5] = ":".join(tail)
+        out.append(",".join(e))
+    return out, bpm, offset
+
+
+# ------------------------------------------------------------------------------------------------ mini-jacks
+def remove_mini_jacks(hit_objects, jack_interval=90, column_width=128):
+    """utils.py:140-255 on parsed arrays.  For every note that has a same-column note within `jack_interval` ms before
+    it: leave it if nothing follows within 2 * jack_interval (end of a stream); else try to move it -- or, failing that,
+    the earlier note -- to a column free of jacks and long notes (same hand first); else delete whichever of the two
+    sits in the bigger chord (the later one on ties, unless it is a long note)."""
+    n = len(hit_objects)
+    lines = list(hit_objects)
+    t = [0.0] * n
+    col = [0] * n
+    end = [None] * n
+    for i, l in enumerate(lines):
+        t[i], col[i], end[i] = parse_line(l, column_width)
+    alive = [True] * n
+
+    def near(start, time, interval, column, back, fwd):
+        found = []
+        if back:
+            i = start - 1
+            while i >= 0:
+                if alive[i]:
+                    if abs(t[i] - time) > interval:
+                        break
+                    if column < 0 or col[i] == column:
+                        found.append(i)
+                i -= 1
+        if fwd:
+            i = start + 1
+            while i < n:
+                if alive[i]:
+                    if abs(t[i] - time) > interval:
+                        break
+                    if column < 0 or col[i] == column:
+                        found.append(i)
+                i += 1
+        return found
+
+    def held(start, column, time):
+        i = start - 1
+        while i >= 0:
+            if alive[i] and end[i] is not None and col[i] == column and t[i] <= time:
+                return end[i] >= time - 50
+            i -= 1
+        return False
+
+    for i in range(n):
+        before = near(i, t[i], jack_interval, col[i], True, False)
+        if not before:
+            continue
+        p = before[0]
+        if not any(abs(t[j] - t[i]) >= EPSILON for j in near(i, t[i], jack_interval * 2, -1, False, True)):
+            continue
+        moved = False
+        for idx, is_ln in ((i, end[i] is not None), (p, False)):
+            if is_ln:
+                continue
+            src = col[idx]
+            targets = (1 - src, 2, 3) if src in (0, 1) else (5 - src, 1, 0)
+            for dst in targets:
+                if held(idx, dst, t[idx]):
+                    continue
+                if not near(idx, t[idx], jack_interval, dst, True, True):
+                    x = int(round((dst + 0.5) * column_width))
+                    e = lines[idx].split(",")
+                    e[0] = str(x)
+                    lines[idx] = ",".join(e)
+                    col[idx] = int(x / column_width)
+                    moved = True
+                    break
+            if moved:
+                break
+        if moved:
+            continue
+        chord_i = len(near(i, t[i], 10, -1, True, True)) + 1
+        chord_p = len(near(p, t[p], 10, -1, True, True)) + 1
+        if chord_i > 1 and chord_i >= chord_p and end[i] is None:
+            alive[i] = False
+        elif chord_p > 1 and chord_p >= chord_i:
+            alive[p] = False
+        elif end[i] is not None:
+            alive[p] = False
+        else:
+            alive[i] = False
+    return [lines[i] for i in range(n) if alive[i]]
+
+
+# ------------------------------------------------------------------------------------------------ synthetic charts
+def synthetic_chart(seed, beats=160, bpm=187.0, offset=412.0, jitter=4.0, ln_p=0.15, density=0.55):
+    """Seeded hit objects in the format `array_to_objects` emits (convertor.py:232-264): a quarter-beat stream around
+    `bpm` with Gaussian timing jitter, occasional triplets, chords, long notes and plenty of same-column repeats."""
+    g = np.random.default_rng(seed)
+    gap = 60000 / bpm / 4
+    objs = []
+    for k in range(beats * 4):
+        if g.random() > density:
+            continue
+        pos = k if g.random() < 0.9 else k + g.choice([1 / 3, 0.5, 2 / 3])
+        time = int(round(offset + pos * gap + g.normal(0, jitter)))
+        for c in g.choice(4, size=g.choice([1, 1, 1, 2, 3]), replace=False):
+            x = int(round((c + 0.5) * 128))
+            if g.random() < ln_p:
+                objs.append(("%d,192,%d,128,0,%d:0:0:0:0:" % (x, time, time + int(g.integers(60, 900))), time))
+            else:
+                objs.append(("%d,192,%d,1,0,0:0:0:0:" % (x, time), time))
+    objs.sort(key=lambda r: r[1])
+    return [o[0] for o in objs]

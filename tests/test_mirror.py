@@ -176,7 +176,7 @@ def test_convertor_threshold_contract():
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/mug"), reason="needs the reference checkout (authoring container only)")
 def test_non_hot_path_modules_fall_through_to_the_reference():
-    """the drop-in shadows only the hot path; e.g. mug.lr_scheduler / mug.data.utils stay the reference's files."""
+    """the drop-in shadows only the hot path; e.g. mug.lr_scheduler stays the reference's file."""
     import subprocess
     import sys
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(1, '/root/reference'); "
