@@ -139,29 +139,38 @@ class OsuManiaConvertor(BaseOsuConvertor):
         return self.is_binary_positive(a[..., 0:key_count, :]), self.is_binary_positive(a[..., 2 * key_count:3 * key_count, :])
 
     def array_to_objects(self, note_array: np.ndarray, meta) -> List[str]:
-        """convertor.py:232-264."""
+        """Note grid -> hit-object lines (convertor.py:232-264), one vectorised pass per column: a note starts where
+        channel `column` is positive; it is a long note if the frames right after it are 'holding' (channel column+2K)
+        without a new start, and then ends at the last such frame; sub-frame offsets (channels +K / +3K, clipped to
+        [0, 1]) refine both times.  Sorted by start time (stable, columns in order), like the reference."""
         a = np.asarray(note_array).transpose()
         key_count = int(meta.cs)
         column_width = int(512 / key_count)
-        out = []
         n = len(a)
+        frames = np.arange(n)
+        lines, starts_ms = [], []
         for column in range(key_count):
-            for s in np.where(self.is_binary_positive(a[:, column]))[0]:
-                start = int(round((s + np.clip(a[s, column + key_count], 0, 1)) * self.frame_ms))
-                end = -1
-                if s != n - 1:
-                    i = s + 1
-                    while (i < n and self.is_binary_positive(a[i, column + key_count * 2])
-                           and not self.is_binary_positive(a[i, column])):
-                        i += 1
-                    e = i - 1
-                    if e != s:
-                        end = int(round((e + np.clip(a[e, column + key_count * 3], 0, 1)) * self.frame_ms))
-                x = int(round((column + 0.5) * column_width))
-                line = f"{x},192,{start},1,0,0:0:0:0:" if end == -1 else f"{x},192,{start},128,0,{end}:0:0:0:0:"
-                out.append((line, start))
-        out.sort(key=lambda r: r[1])
-        return [r[0] for r in out]
+            is_start = self.is_binary_positive(a[:, column])
+            s = np.nonzero(is_start)[0]
+            if len(s) == 0:
+                continue
+            held = self.is_binary_positive(a[:, column + key_count * 2]) & ~is_start
+            # first frame >= i that does not continue a hold (n if none): the hold that follows start s ends just before it
+            stop = np.minimum.accumulate(np.where(held, n, frames)[::-1])[::-1]
+            e = np.where(s < n - 1, stop[np.minimum(s + 1, n - 1)] - 1, s)
+            start = np.round((s + np.clip(a[s, column + key_count], 0, 1)) * self.frame_ms).astype(np.int64)
+            end = np.round((e + np.clip(a[e, column + key_count * 3], 0, 1)) * self.frame_ms).astype(np.int64)
+            x = int(round((column + 0.5) * column_width))
+            for k in range(len(s)):
+                if e[k] == s[k]:
+                    lines.append(f"{x},192,{start[k]},1,0,0:0:0:0:")
+                else:
+                    lines.append(f"{x},192,{start[k]},128,0,{end[k]}:0:0:0:0:")
+            starts_ms.append(start)
+        if not lines:
+            return []
+        order = np.argsort(np.concatenate(starts_ms), kind="stable")
+        return [lines[k] for k in order]
 
 
 MOD_CONVERTOR = {3: OsuManiaConvertor}

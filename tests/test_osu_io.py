@@ -97,3 +97,38 @@ def test_audio_fallbacks_and_roundtrip(tmp_path):
     assert meta2.version == "v" and meta2.convertor is None
     assert ho == _gridify(meta.convertor.array_to_objects(_logits(3), meta))[2]
     assert meta2.timing_points[-1].startswith("37,")
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="needs the reference checkout (authoring container only)")
+@pytest.mark.parametrize("from_logits", [True, False])
+def test_array_to_objects_matches_the_reference_on_long_and_edgy_grids(from_logits):
+    """The vectorised note extraction against the reference's per-note loops (convertor.py:232-264): full-length grids,
+    holds that run into the last frame, a start in the last frame, back-to-back starts inside a hold, empty columns."""
+    ref = _reference()
+    params = dict(frame_ms=128 / 22050 * 8 * 1000, max_frame=4096, from_logits=from_logits)
+    r, m = ref.OsuManiaConvertor(**params), mine.OsuManiaConvertor(**params)
+
+    class Meta:
+        cs = 4
+
+    grids = [_logits(seed, T) for seed, T in ((5, 4096), (6, 1000), (7, 1), (8, 2))]
+    edge = _logits(9, 64)
+    hi, lo = (3.0, -3.0) if from_logits else (0.9, 0.1)
+    edge[0:4] = lo
+    edge[8:12] = lo
+    edge[0, [3, 10, 11, 40, 63]] = hi          # column 0: starts, one in the last frame
+    edge[8, 4:10] = hi                          # ... a hold cut by the next start
+    edge[8, 41:64] = hi                         # ... a hold running into the last frame
+    edge[9, :] = hi                             # column 1: holding everywhere but never started
+    edge[2, 62] = hi
+    edge[10, 63] = hi                           # column 2: a 1-frame hold ending in the last frame
+    grids.append(edge)
+    grids.append(np.full((16, 32), lo, dtype=np.float32))       # nothing at all
+    if not from_logits:
+        grids = [1 / (1 + np.exp(-g)) if g is not edge and g.min() < 0 else g for g in grids]
+    total = 0
+    for g in grids:
+        want = r.array_to_objects(g, Meta())
+        assert m.array_to_objects(g, Meta()) == want
+        total += len(want)
+    assert total > 1500
