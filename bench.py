@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--seconds", type=float, default=180.0)
+    ap.add_argument("--audio-sr", type=int, default=44100,
+                    help="sample rate of the synthetic PCM (BASELINE configs[1]: 44.1 kHz); converted to the model's 22.05 kHz on the "
+                         "device inside every timed step.  22050 skips the conversion")
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--cfg-scale", type=float, default=1.0, help="1.0 = no guidance (scripts/mapping.py default); webui default is 5.0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -134,7 +137,8 @@ def main():
     note("model instantiated, seeded and moved to %s" % dev)
 
     B, S, sr, hop = a.batch, a.ddim_steps, SHIPPED["sr"], SHIPPED["n_fft"] // 4
-    pcm = torch.from_numpy(synth_audio(a.seconds, sr, seed=rank)).to(dev)          # resident before the timed region
+    pcm_in = torch.from_numpy(synth_audio(a.seconds, a.audio_sr, seed=rank)).to(dev)   # resident before the timed region
+    pcm = lib.resample_poly(pcm_in, sr, a.audio_sr)                                   # (length rule only; redone in every step)
     with open(FEATURE_YAML) as f:
         fy = yaml.safe_load(f)
     prompts = [{"sr": 4.0, "rank_status": "ranked"}, {"sr": 2.5, "ln_ratio": 0.4}, {"sr": 6.0, "ln": 1}, {"sr": 3.2}]
@@ -149,6 +153,7 @@ def main():
     ddim_ms = []
 
     def one_step():
+        pcm = lib.resample_poly(pcm_in, sr, a.audio_sr) if a.audio_sr != sr else pcm_in     # 44.1 kHz -> 22.05 kHz, polyphase FIR
         mel = lib.log_mel(pcm, sr=sr, n_fft=SHIPPED["n_fft"], hop=hop, n_mels=SHIPPED["n_mels"])   # (128, frames), fp16-rounded
         t = mel.shape[1]
         tgt = z * ratio
@@ -204,9 +209,10 @@ def main():
             "value": charts / elapsed, "unit": "charts/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: %.0f s synthetic 22.05 kHz audio -> z=%d, %d DDIM steps, batch %d, cfg_scale %g, "
+            "config": {"workload": "configs[1]: %.0f s synthetic %.2f kHz audio -> %s z=%d, %d DDIM steps, batch %d, cfg_scale %g, "
                                    "mel + wave-encode (once per song, shared by the seeds) + DDIM + VAE decode + note grid"
-                                   % (a.seconds, z, n_unet_steps, B, a.cfg_scale),
+                                   % (a.seconds, a.audio_sr / 1e3, "22.05 kHz (device polyphase resampler) ->" if a.audio_sr != sr else "",
+                                      z, n_unet_steps, B, a.cfg_scale),
                        "parallelism": "dp%d (independent (audio, seed) units per rank, no data-path collective)" % world,
                        "weights": "seeded synthetic, shipped architecture (151 M params)"},
             "unet_sample_steps_per_s": B * n_unet_steps * (2 if a.cfg_scale != 1.0 else 1) / (ddim_ms[-1] * 1e-3) * world,
@@ -246,7 +252,7 @@ def cpu_baseline(a, z, n_steps):
     nthr = max(1, min(host_threads(), a.cpu_threads))
     env = dict(os.environ, OMP_NUM_THREADS=str(nthr), MKL_NUM_THREADS=str(nthr), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--batch", str(a.batch), "--seconds", str(a.seconds),
-           "--cpu-threads", str(nthr), "--z", str(z), "--n-unet-steps", str(n_steps)]
+           "--audio-sr", str(a.audio_sr), "--cpu-threads", str(nthr), "--z", str(z), "--n-unet-steps", str(n_steps)]
     try:
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=sys.stderr, text=True, timeout=a.cpu_timeout)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -273,10 +279,13 @@ def cpu_baseline_worker(a):
     note("cpu baseline: weights ready (%d threads)" % nthr)
     g = torch.Generator().manual_seed(0)
     t0 = time.perf_counter()
-    y = synth_audio(a.seconds, SHIPPED["sr"], 0)
+    y = synth_audio(a.seconds, a.audio_sr, 0)
+    t0 = time.perf_counter()
+    if a.audio_sr != SHIPPED["sr"]:
+        y = host.resample_poly(y, SHIPPED["sr"], a.audio_sr)
     mel = host.pad_or_trunc_mel(host.log_mel(y).astype(np.float32), z * 64)
     t_mel = time.perf_counter() - t0
-    note("cpu baseline: mel %.2fs" % t_mel)
+    note("cpu baseline: resample + mel %.2fs" % t_mel)
     with torch.no_grad():
         t0 = time.perf_counter()
         w = nets.wave_encode(sd, nets.WAVE_DEFAULT, torch.from_numpy(mel)[None])
@@ -299,7 +308,7 @@ def cpu_baseline_worker(a):
     per_batch = t_mel + t_wave + n_steps * t_unet + t_dec
     print(json.dumps({
         "value": B / per_batch, "unit": "charts/s", "cores": nthr, "kind": "port",
-        "sample": "1 mel (%.2fs) + 1 wave-encode B=1 (%.2fs) + %d U-Net evals B=%d z=%d (%.3fs each, S4 kernels cached) + 1 decode (%.2fs), "
+        "sample": "1 resample+mel (%.2fs) + 1 wave-encode B=1 (%.2fs) + %d U-Net evals B=%d z=%d (%.3fs each, S4 kernels cached) + 1 decode (%.2fs), "
                   "extrapolated to %d steps; PyTorch-CPU fp32, %d threads (host exposes %d)"
                   % (t_mel, t_wave, reps, B, z, t_unet, t_dec, n_steps, nthr, host_threads()),
         "unet_sample_steps_per_s": B / t_unet}), flush=True)

@@ -144,6 +144,14 @@ int mugd_cond_embed(mugd_ctx* ctx, const float* table, const int64_t* ids, float
  * `sr` (device) -> log1p(mel power) rounded to fp16 and widened to fp32, (n_mels, 1 + n/hop). */
 int mugd_log_mel(mugd_ctx* ctx, const float* pcm, int64_t n, int sr, int n_fft, int hop, int n_mels, float* out);
 
+/* Sample-rate conversion in front of mugd_log_mel (the reference resamples on the host inside
+ * librosa.load(sr=22050), mug/util.py:126): polyphase FIR with the specification of scipy.signal.resample_poly(x, up, down)
+ * = librosa.resample(res_type="polyphase") -- Kaiser(5) windowed sinc, 20 max(up, down) + 1 taps rounded to float32, zero
+ * phase, zeros beyond the ends.  pcm_in: n_in mono fp32 samples (device); pcm_out: ceil(n_in up / down) samples (device),
+ * also written to *n_out when n_out != NULL; pcm_out == NULL only queries the length.  44.1 kHz -> 22.05 kHz is up 1,
+ * down 2; 48 kHz -> 22.05 kHz is 147 / 320.  Products are accumulated in float64 and rounded once (scipy: float32). */
+int mugd_resample_poly(mugd_ctx* ctx, const float* pcm_in, int64_t n_in, int up, int down, float* pcm_out, int64_t* n_out);
+
 /* ---- chart post-processing (the host step that dominates once sampling takes milliseconds) ---- */
 
 /* The candidate sweep of the BPM / offset fit: `test_timing(..., refine=False)` (mug/data/utils.py:16-27,42-43) for

@@ -96,6 +96,7 @@ void mugd_destroy(mugd_ctx* ctx) {
     if (!ctx) return;
     hipStreamSynchronize(ctx->c.stream);
     if (ctx->c.scratch) hipFree(ctx->c.scratch);
+    for (auto& kv : ctx->c.resample_taps) hipFree(kv.second);
     if (ctx->c.own_stream) hipStreamDestroy(ctx->c.stream);
     delete ctx;
 }
@@ -267,6 +268,31 @@ int mugd_log_mel(mugd_ctx* ctx, const float* pcm, int64_t n, int sr, int n_fft, 
     return guarded(ctx, [&] {
         MUGD_CHECK(pcm && out && n > 0, MUGD_ERR_INVALID, "null/empty argument");
         log_mel(&ctx->c, pcm, (long long)n, sr, n_fft, hop, n_mels, out);
+    });
+}
+
+int mugd_resample_poly(mugd_ctx* ctx, const float* pcm_in, int64_t n_in, int up, int down, float* pcm_out, int64_t* n_out) {
+    return guarded(ctx, [&] {
+        MUGD_CHECK(up >= 1 && down >= 1 && n_in >= 0, MUGD_ERR_INVALID, "resample: up and down must be >= 1");
+        int a = up, b = down;
+        while (b) { const int t = a % b; a = b; b = t; }
+        up /= a; down /= a;
+        const long long len = resample_poly_out_len(n_in, up, down);
+        if (n_out) *n_out = len;
+        if (!pcm_out) return;                                     // length query
+        MUGD_CHECK(pcm_in && n_in > 0, MUGD_ERR_INVALID, "resample: null/empty input");
+        if (up == 1 && down == 1) {
+            HIP_CHECK(hipMemcpyAsync(pcm_out, pcm_in, (size_t)n_in * sizeof(float), hipMemcpyDeviceToDevice, ctx->c.stream));
+            return;
+        }
+        float*& taps = ctx->c.resample_taps[{up, down}];
+        const std::vector<float> h = resample_poly_taps(up, down);
+        if (!taps) {
+            HIP_CHECK(hipMalloc((void**)&taps, h.size() * sizeof(float)));
+            HIP_CHECK(hipMemcpy(taps, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+        launch_resample_poly(ctx->c.stream, ResampleArgs{pcm_in, (long long)n_in, pcm_out, len, taps, (int)h.size(),
+                                                         (int)(h.size() / 2), up, down});
     });
 }
 

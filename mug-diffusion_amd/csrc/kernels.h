@@ -2,6 +2,7 @@
 // (B, C, T) "channel-major" fp32: T is the fastest axis, so a wavefront's 64 lanes
 // read 256 contiguous bytes of one channel row.
 #pragma once
+#include <vector>
 #include "common.h"
 
 // ---------------------------------------------------------------------------------------
@@ -192,6 +193,15 @@ struct DdimStepArgs {
     float scale;
 };
 void launch_ddim_step(hipStream_t st, const DdimStepArgs& a);
+// audio ingest (k_resample.hip): scipy.signal.resample_poly / librosa res_type="polyphase"
+struct ResampleArgs {
+    const float* x; long long n_in; float* y; long long n_out;
+    const float* taps; int n_taps, half_len, up, down;           // up / down already reduced by their gcd
+};
+std::vector<float> resample_poly_taps(int up, int down);
+long long resample_poly_out_len(long long n_in, int up, int down);
+void launch_resample_poly(hipStream_t st, const ResampleArgs& a);
+
 // chart post-processing (k_timing.hip)
 struct TimingSweepArgs {
     const float* times; int n;                     // note start times (ms), float32 like the reference's time_list

@@ -38,6 +38,7 @@ struct Ctx {
     std::string last_error;
     bool use_graph = true;
     float* scratch = nullptr; size_t scratch_cap = 0;   // grow-only device scratch of the context-level operators (log_mel): no malloc / sync per call
+    std::map<std::pair<int, int>, float*> resample_taps;   // device copies of the polyphase filters, per reduced (up, down)
     int force_wk = 0, force_tn = 0;   // mugd_set_conv_tiling: 0 = pick per layer
     bool fast_act = true;       // SiLU of the fused GroupNorm path on v_exp_f32 / v_rcp_f32 (MUGD_EXACT_SILU=1: expf + IEEE divide)
     bool fuse_stats = true;     // false (MUGD_NO_STATS_FUSION=1): always run the GroupNorm / LayerNorm statistics kernels

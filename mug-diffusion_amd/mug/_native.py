@@ -62,6 +62,7 @@ _SIGS = {
     "mugd_wave_encode": [_p, _p, C.POINTER(_p), _i, _i],
     "mugd_cond_embed": [_p, _p, _p, _p, _i, _i, _i],
     "mugd_log_mel": [_p, _p, C.c_int64, _i, _i, _i, _i, _p],
+    "mugd_resample_poly": [_p, _p, C.c_int64, _i, _i, _p, C.POINTER(C.c_int64)],
     "mugd_timing_sweep": [_p, _p, _i, _p, _p, _p, _i, C.c_double, _p],
     "mugd_remove_mini_jacks": [_i, _p, _p, _p, C.c_double, _i, _p, _p],
     "mugd_op_group_norm": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i],
@@ -224,6 +225,15 @@ class Lib:
         return out
 
     # ------------------------------------------------------------------ single operators
+    def resample_poly(self, pcm, up, down):
+        """scipy.signal.resample_poly(pcm, up, down) / librosa res_type="polyphase" on the device: mono fp32 -> fp32."""
+        pcm = self.f32(pcm).reshape(-1)
+        n_out = C.c_int64(0)
+        self.check(self.dll.mugd_resample_poly(self.ctx, _p(None), pcm.numel(), int(up), int(down), _p(None), C.byref(n_out)))
+        out = self.empty(n_out.value)
+        self.check(self.dll.mugd_resample_poly(self.ctx, _ptr(pcm), pcm.numel(), int(up), int(down), _ptr(out), None))
+        return out
+
     def timing_sweep(self, times, gap, offset, offset_is_f32, epsilon=10.0):
         """valid-note counts of (gap, offset) grid candidates (mug/data/utils.py:16-27): `times` is a float32 device
         tensor, the candidate arrays are NumPy (float64, float64, bool); returns an int32 NumPy array."""

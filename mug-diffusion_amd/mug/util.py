@@ -91,8 +91,10 @@ def load_dict_from_batch(dict_data, i):
 
 
 def _decode_audio(audio_path, sr, max_duration):
-    """Decoding + resampling to `sr` stay on the host, as in the reference (librosa.load through
-    audioread/soundfile, mug/util.py:120-131).  Uses whichever decoder is installed."""
+    """Decoding stays on the host, as in the reference (librosa.load through audioread/soundfile,
+    mug/util.py:120-131), with whichever decoder is installed.  With librosa the call is the reference's own
+    (its resampler included); without it the file is decoded at its native rate and converted to `sr` on the
+    device (mugd_resample_poly = librosa's res_type="polyphase"), and the result is a device tensor."""
     try:
         import librosa
         y, _ = librosa.load(audio_path, sr=sr, duration=max_duration)
@@ -108,9 +110,8 @@ def _decode_audio(audio_path, sr, max_duration):
     if max_duration is not None:
         y = y[: int(max_duration * file_sr)]
     if file_sr != sr:
-        from scipy.signal import resample_poly
-        g = math.gcd(int(sr), int(file_sr))
-        y = resample_poly(y, sr // g, file_sr // g).astype(np.float32)
+        from mug._native import get_lib
+        return get_lib().resample_poly(torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32)), int(sr), int(file_sr))
     return y
 
 
@@ -120,7 +121,8 @@ def pcm_to_log_mel(y, n_mels, audio_hop_length, n_fft, sr):
     like the reference."""
     from mug._native import get_lib
     lib = get_lib()
-    mel = lib.log_mel(torch.as_tensor(np.asarray(y, dtype=np.float32)), sr=sr, n_fft=n_fft, hop=audio_hop_length, n_mels=n_mels)
+    pcm = y if isinstance(y, torch.Tensor) else torch.as_tensor(np.asarray(y, dtype=np.float32))
+    mel = lib.log_mel(pcm, sr=sr, n_fft=n_fft, hop=audio_hop_length, n_mels=n_mels)
     return mel.cpu().numpy().astype(np.float16)
 
 
