@@ -455,8 +455,9 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
     const int nblk = gx * gy * gz;
     int lid = blockIdx.x;
     if ((nblk & 7) == 0) lid = (lid & 7) * (nblk >> 3) + (lid >> 3);
-    const int mt = lid / (gx * gz);
-    const int rem = lid - mt * (gx * gz);
+    int mt, rem;
+    if (a.xcd_cols) { rem = lid / gy; mt = lid - rem * gy; }       // row tile fastest: an XCD's slab is a range of column tiles
+    else { mt = lid / (gx * gz); rem = lid - mt * (gx * gz); }
     const int b = rem / gx;
     const int t0 = (rem - b * gx) * CONV_TN;
 

@@ -286,8 +286,9 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
     const int nblk = gx * gy * gz;
     int lid = blockIdx.x;
     if ((nblk & 7) == 0) lid = (lid & 7) * (nblk >> 3) + (lid >> 3);          // XCD-contiguous row tiles (see k_conv.hip)
-    const int mt = lid / (gx * gz);
-    const int rem = lid - mt * (gx * gz);
+    int mt, rem;
+    if (a.xcd_cols) { rem = lid / gy; mt = lid - rem * gy; }       // row tile fastest: an XCD's slab is a range of column tiles
+    else { mt = lid / (gx * gz); rem = lid - mt * (gx * gz); }
     const int b = rem / gx;
     const int t0 = (rem - b * gx) * 16;
 
@@ -487,6 +488,25 @@ int conv_pick_tn(const ConvArgs& a) {
     if (forced == 16 || forced == 32) return forced;
     const long long tiles32 = (long long)cdiv(a.Tout, 32) * cdiv(a.Mout, 32) * a.B;
     return tiles32 * 2 <= 256 ? 16 : 32;       // 129..255 tiles: 16-wide tiles would need a second, half-empty round of workgroups
+}
+
+// Which operand should be the one every XCD re-reads?  With row-tile-major order the weights are fetched once and the
+// activations by up to 8 private L2s; with row-tile-fastest order it is the other way round.  Bytes moved into L2s:
+//   row major: W max(1, 8 / row_tiles) + X min(8, row_tiles)      col major: W min(8, col_tiles) + X max(1, 8 / col_tiles)
+// (MUGD_XCD_ORDER=row|col forces one; grids that are not a multiple of 8 are not renumbered at all.)
+int conv_pick_order(const ConvArgs& a) {
+    static const int forced = [] { const char* e = getenv("MUGD_XCD_ORDER"); return !e ? -1 : (e[0] == 'c' ? 1 : (e[0] == 'r' ? 0 : -1)); }();
+    if (forced >= 0) return forced;
+    const double row_tiles = cdiv(a.Mout, 32), col_tiles = (double)cdiv(a.Tout, a.tn == 16 ? 16 : 32) * a.B;
+    double W = 0, X = 0;
+    for (int i = 0; i < a.nseg; ++i) {
+        const ConvSeg& s = a.seg[i];
+        W += (double)a.Mrows * s.C * s.taps;
+        X += (double)s.C * s.Tin * (s.bmod > 0 ? std::min(s.bmod, a.B) : a.B);
+    }
+    const double row_major = W * std::max(1.0, 8.0 / row_tiles) + X * std::min(8.0, row_tiles);
+    const double col_major = W * std::min(8.0, col_tiles) + X * std::max(1.0, 8.0 / col_tiles);
+    return col_major < row_major ? 1 : 0;
 }
 
 void launch_conv_gemm16(hipStream_t st, const ConvArgs& a) {

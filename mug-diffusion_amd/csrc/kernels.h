@@ -73,6 +73,9 @@ struct ConvArgs {
     float gn_count, gn_eps;  // elements per group (cg * T), eps
     int wk;                  // K-split (waves per workgroup): 1|2|4|8, 0 = pick from the shape
     int tn;                  // output tile width: 32 (k_conv.hip) | 16 (k_conv16.hip); decides the weight packing
+    int xcd_cols;            // workgroup order inside an XCD's slab: 0 = row tile major (a weight tile lives in one L2, every XCD reads
+                             // the activations), 1 = row tile fastest (a column tile lives in one L2, every XCD reads the weights);
+                             // set per launch by conv_pick_order() to whichever moves fewer bytes
 };
 
 void launch_conv_gemm(hipStream_t st, const ConvArgs& a);        // 32 x 32 tiles
@@ -80,7 +83,12 @@ int conv_pick_wk(const ConvArgs& a);
 void launch_conv_gemm16(hipStream_t st, const ConvArgs& a);      // 32 x 16 tiles
 bool conv16_supported(const ConvArgs& a);
 int conv_pick_tn(const ConvArgs& a);                             // needs seg[], nseg, epi, B, Mout, Tout
-inline void launch_conv(hipStream_t st, const ConvArgs& a) { if (a.tn == 16) launch_conv_gemm16(st, a); else launch_conv_gemm(st, a); }
+int conv_pick_order(const ConvArgs& a);                          // ConvArgs::xcd_cols for this launch (needs tn)
+inline void launch_conv(hipStream_t st, const ConvArgs& a0) {
+    ConvArgs a = a0;
+    a.xcd_cols = conv_pick_order(a);
+    if (a.tn == 16) launch_conv_gemm16(st, a); else launch_conv_gemm(st, a);
+}
 
 // packs rows [row_off, row_off+rows) x channels [0, C) of one K-segment.
 struct PackArgs {
