@@ -316,9 +316,36 @@ def postprocess_goldens():
         print("  postprocess %-40s %5d notes  bpm %.4f offset %.3f  %d refits  jacks -> %d notes"
               % (str(ch["spec"])[:40], len(ho), bpm, offset, improvements, len(rec["jacks"]["after_snap_90"])))
         out.append(rec)
+    # whole files: note grid -> save_osu_file with the web UI's post-processing (webui.py:401-407,431-445), real reference
+    spec = importlib.util.spec_from_file_location("ref_convertor_golden", os.path.join(refimport.REF, "mug/data/convertor.py"))
+    conv = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = conv
+    spec.loader.exec_module(conv)
+    import tempfile
+    files = []
+    with tempfile.TemporaryDirectory() as tmp:
+        osu = os.path.join(tmp, "template.osu")
+        with open(osu, "w", encoding="utf8") as f:
+            f.write(pp.TEMPLATE_OSU)
+        open(os.path.join(tmp, "audio.mp3"), "wb").close()
+        params = dict(frame_ms=128 / 22050 * 8 * 1000, max_frame=4096, from_logits=True)
+        _, meta = conv.parse_osu_file(osu, dict(params))
+
+        def ui_gridify(objs):
+            snapped, bpm, offset = ref.gridify(objs, verbose=False)
+            return bpm, offset, ref.remove_intractable_mania_mini_jacks(snapped, verbose=False, jack_interval=90)
+
+        for seed, frames in ((21, 512), (22, 4096)):
+            grid = pp.synthetic_note_grid(seed, frames)
+            path = os.path.join(tmp, "out%d.osu" % seed)
+            conv.save_osu_file(meta, grid, path=path, override={"Version": "AI v%d" % seed, "Creator": "golden"}, gridify=ui_gridify)
+            with open(path, encoding="utf8") as f:
+                text = f.read()
+            files.append(dict(seed=seed, frames=frames, text=text))
+            print("  chart file seed %d: %d frames -> %d lines" % (seed, frames, text.count("\n")))
     import gzip
     with gzip.open(os.path.join(G, "postprocess_golden.json.gz"), "wt", encoding="utf8") as f:
-        json.dump(dict(numpy=np.__version__, sklearn=sklearn.__version__, charts=out), f)
+        json.dump(dict(numpy=np.__version__, sklearn=sklearn.__version__, charts=out, files=files), f)
     print("  postprocess goldens: %d charts, oracle restatement identical" % len(out))
 
 

@@ -216,3 +216,56 @@ def synthetic_chart(seed, beats=160, bpm=187.0, offset=412.0, jitter=4.0, ln_p=0
                 objs.append(("%d,192,%d,1,0,0:0:0:0:" % (x, time), time))
     objs.sort(key=lambda r: r[1])
     return [o[0] for o in objs]
+
+
+TEMPLATE_OSU = """osu file format v14
+
+[General]
+AudioFilename: audio.mp3
+AudioLeadIn: 0
+Mode: 3
+
+[Metadata]
+Title:Golden
+Creator:someone
+Version:4K template
+BeatmapSetID:-1
+
+[Difficulty]
+HPDrainRate:8
+CircleSize:4
+OverallDifficulty:8
+
+[TimingPoints]
+0,333.333,4,2,1,40,1,0
+
+[HitObjects]
+64,192,1000,1,0,0:0:0:0:
+"""
+
+
+def synthetic_note_grid(seed, frames, bpm=181.0):
+    """A (16, frames) logit grid in the decoder's layout (convertor.py:212-216: is_start x4, start offset x4, holding x4,
+    end offset x4) whose notes follow a tempo, so the post-processing has something to find; float32."""
+    g = np.random.default_rng(seed)
+    frame_ms = 128 / 22050 * 8 * 1000
+    a = np.full((16, frames), -4.0, dtype=np.float32)
+    a[4:8] = g.random((4, frames))
+    a[12:16] = g.random((4, frames))
+    gap = 60000 / bpm / 4
+    k = 0
+    while True:
+        t = 300.0 + k * gap + g.normal(0, 3.0)
+        k += 1
+        f = int(t / frame_ms)
+        if f >= frames - 1:
+            break
+        if g.random() > 0.6:
+            continue
+        for c in g.choice(4, size=g.choice([1, 1, 2]), replace=False):
+            a[c, f] = 3.0
+            a[4 + c, f] = t / frame_ms - f
+            if g.random() < 0.2:
+                hold = int(g.integers(2, 12))
+                a[8 + c, f + 1:f + 1 + hold] = 2.0
+    return a

@@ -172,3 +172,29 @@ def test_mini_jack_abi_rejects_bad_arguments(lib):
 def test_gridify_of_an_empty_chart_raises_like_the_reference(lib):
     with pytest.raises(IndexError):
         product.gridify([], verbose=False, lib=lib)
+
+
+# ------------------------------------------------------------------------------------------------ whole chart files
+def golden_files():
+    with gzip.open(GOLDEN, "rt", encoding="utf8") as f:
+        return json.load(f)["files"]
+
+
+@pytest.mark.parametrize("gold", golden_files(), ids=lambda g: "frames%d" % g["frames"])
+def test_chart_file_is_byte_identical_to_the_reference(lib, tmp_path, gold):
+    """Note grid -> .osu through the drop-in only (parse_osu_file, array_to_objects, gridify, mini-jacks, save_osu_file,
+    wired like webui.py:401-407,431-445) == the file the real reference wrote for the same grid."""
+    from mug.data import convertor
+    osu = tmp_path / "template.osu"
+    osu.write_text(oracle.TEMPLATE_OSU, encoding="utf8")
+    (tmp_path / "audio.mp3").write_bytes(b"")
+    _, meta = convertor.parse_osu_file(str(osu), dict(frame_ms=128 / 22050 * 8 * 1000, max_frame=4096, from_logits=True))
+
+    def ui_gridify(objs):
+        snapped, bpm, offset = product.gridify(objs, verbose=False, lib=lib)
+        return bpm, offset, product.remove_intractable_mania_mini_jacks(snapped, verbose=False, jack_interval=90, lib=lib)
+
+    out = tmp_path / "out.osu"
+    convertor.save_osu_file(meta, oracle.synthetic_note_grid(gold["seed"], gold["frames"]), path=str(out),
+                            override={"Version": "AI v%d" % gold["seed"], "Creator": "golden"}, gridify=ui_gridify)
+    assert out.read_text(encoding="utf8") == gold["text"]
