@@ -240,6 +240,40 @@ def test_full_unet_at_benchmark_and_long_lengths_vs_oracle(gpu_lib, z, B):
     _net_cache.clear()
 
 
+@pytest.mark.gpu
+def test_headline_workload_end_to_end_vs_oracle(gpu_lib):
+    """BASELINE configs[1] in full: 3-minute audio (32768 mel frames, z = 512), 50 DDIM steps, batch 4, no guidance --
+    wave encoder -> the whole DDIM loop (one native call, graph replay) -> VAE decode -> note grid, against the oracle
+    on the same seeded weights and inputs (the oracle needs ~10 s of the box's host cores for its 50 U-Net evaluations)."""
+    case, z, S, B = cases.FULL, 512, 50, 4
+    sd = state_dict(case, z)
+    fy = cases.feature_yaml()
+    prompts = [{"sr": 4.0, "rank_status": "ranked"}, {"sr": 2.5, "ln_ratio": 0.4}, {"sr": 6.0}, {}]
+    ids = torch.tensor([host.feature_ids(p, fy) for p in prompts], dtype=torch.float32)
+    c = nets.cond_embed(sd, ids)
+    mel = cases.mel_input(case, 29, 1, z * case["audio_ratio"])
+    xT = cases.x_T(29, B, z)
+    nl = len(case["unet"]["channel_mult"])
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, threads))           # the oracle's small-tensor ops collapse on a 256-thread pool
+    try:
+        w_ref = nets.wave_encode(sd, case["wave"], mel)[-nl:]
+        lat_ref = sampler.ddim_sample(sd, case["unet"], S, c, [m.repeat(B, 1, 1) for m in w_ref], xT)
+        logits_ref = nets.vae_decode(sd, case["vae"], lat_ref)
+    finally:
+        torch.set_num_threads(threads)
+    w = native(gpu_lib, case, z, "wave").encode(mel)[-nl:]
+    steps = sampler.ddim_step_scalars(sd["alphas_cumprod"].numpy(), S, 0.0)
+    lat = native(gpu_lib, case, z, "unet").ddim_sample(xT, c, w, [s["t"] for s in steps],
+                                                       [[s["a_t"], s["a_prev"], s["sigma"], s["sqrt_1m_at"]] for s in steps])
+    logits = native(gpu_lib, case, z, "vae").decode(lat)
+    d, s = report("headline ddim z=512 S=50 B=4 latent", lat, lat_ref)
+    assert d < 2e-3 * max(1.0, s)
+    flips = grid_check(logits, logits_ref.numpy())
+    print("headline workload: %d of %d note cells differ" % (flips, B * 8 * z * 8))
+    _net_cache.clear()
+
+
 def test_one_handle_follows_changing_lengths_and_batches(lib):
     """webui.py:349-367 mutates z_length per audio and `count` per request: one native handle is recompiled for each
     (batch, length) and must give the same numbers as a fresh handle (program cache, row-sum block, baked S4 kernels)."""
