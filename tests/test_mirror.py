@@ -220,3 +220,30 @@ def test_sampler_call_paths_agree_and_inpainting_round_trip(as_default_lib):
     torch.manual_seed(0)
     full, _ = sampler.sample(mask=torch.ones_like(one), x0=x0, **kw)
     assert full.shape == one.shape and torch.isfinite(full).all() and not close_(full, one)
+
+
+def test_audio_ingest_resamples_on_the_device_when_only_soundfile_is_present(as_default_lib, monkeypatch, tmp_path):
+    """mug.util.load_audio_without_cache (mug/util.py:133-144 of the reference) without librosa: the file is decoded by
+    soundfile at its native rate (stereo 44.1 kHz here), mixed down, cut to max_duration, converted to 22.05 kHz by
+    mugd_resample_poly and turned into the fp16 log-mel by mugd_log_mel -- equal to the oracle's host pipeline."""
+    import sys
+    import types
+    import mug.util as U
+    sr_file, seconds = 44100, 1.5
+    g = np.random.default_rng(3)
+    t = np.arange(int(sr_file * seconds)) / sr_file
+    stereo = np.stack([0.4 * np.sin(2 * np.pi * 440 * t) + 0.05 * g.standard_normal(len(t)),
+                       0.3 * np.sin(2 * np.pi * 1320 * t)], axis=1).astype(np.float32)
+    fake = types.ModuleType("soundfile")
+    fake.read = lambda path, dtype="float32", always_2d=True: (stereo.copy(), sr_file)
+    monkeypatch.setitem(sys.modules, "soundfile", fake)
+    monkeypatch.setitem(sys.modules, "librosa", None)            # `import librosa` raises ImportError
+    got = U.load_audio_without_cache(str(tmp_path / "song.ogg"), n_mels=128, audio_hop_length=128, n_fft=512, sr=22050,
+                                     max_duration=1.0)
+    mono = stereo.mean(axis=1)[: int(1.0 * sr_file)]
+    want = host.log_mel(host.resample_poly(mono, 22050, sr_file))
+    assert got.dtype == np.float16 and got.shape == want.shape == (128, 1 + (len(mono) // 2) // 128)
+    # fp16 log-mel bins may round differently where the fp32 value sits on a rounding boundary: allow 1 fp16 ulp on <= 2 % of bins (as tests/test_ops.py::test_log_mel)
+    diff = np.abs(got.astype(np.float32) - want.astype(np.float32))
+    ulp = np.spacing(np.abs(want).astype(np.float16)).astype(np.float32)
+    assert (diff <= ulp).all() and (diff > 0).mean() < 0.02, (diff.max(), (diff > 0).mean())
