@@ -467,9 +467,26 @@ class Net:
 _default = None
 
 
+def _build_in_tree():
+    """libmugd.so is a build product (git-ignored): on a checkout where nobody ran the build yet, compile it now with hipcc
+    (about a minute).  This is still the HIP path -- without hipcc the loader raises as before."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("mugd_build", os.path.join(os.path.dirname(_HERE), "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    print("mug._native: %s is missing, building it with hipcc ..." % LIB_PATH, file=sys.stderr, flush=True)
+    b.build(verbose=False)
+
+
 def get_lib():
     """The process-wide library instance on the current GPU.  Raises if the HIP build or a GPU is missing."""
     global _default
     if _default is None:
+        if not os.path.exists(LIB_PATH) and torch.cuda.is_available():
+            try:
+                _build_in_tree()
+            except Exception as e:          # no hipcc / compile error: Lib() below reports the missing library
+                raise MugdError("libmugd.so is missing and could not be built: %s" % e) from e
         _default = Lib()
     return _default
