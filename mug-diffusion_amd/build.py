@@ -15,6 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmugd.so")
+TL_DIR = os.path.join(ROOT, "tests", "tl")
+TL_LIB = os.path.join(TL_DIR, "libmugd_tl.so")
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
 EMU_LIB = os.path.join(EMU_DIR, "libmugd_emu.so")
 
@@ -41,16 +43,22 @@ def _run(cmd):
     return r.stdout
 
 
-def build(force=False, verbose=True):
-    """hipcc --offload-arch=gfx950 for every csrc/*.hip, linked into libmugd.so next to this file."""
+def build(force=False, verbose=True, timeline=False):
+    """hipcc --offload-arch=gfx950 for every csrc/*.hip, linked into libmugd.so next to this file.
+
+    timeline=True builds the DEVELOPMENT variant instead (same sources with -DMUGD_TL: per-wave phase stamps in the
+    conv_gemm kernels, csrc/common.h) into tests/tl/libmugd_tl.so; only tests/gpu_timeline.py loads it."""
+    LIB = TL_LIB if timeline else globals()["LIB"]
     if not force and not _stale(LIB, _deps()):
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: libmugd.so cannot be built (there is no CPU fallback)")
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(TL_DIR, "build") if timeline else os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+    if timeline:
+        flags.append("-DMUGD_TL=1")
 
     def cc(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
@@ -93,5 +101,7 @@ def build_emulated(force=False, verbose=True):
 if __name__ == "__main__":
     if "--emu" in sys.argv:
         build_emulated(force="--force" in sys.argv)
+    elif "--tl" in sys.argv:
+        build(force="--force" in sys.argv, timeline=True)
     else:
         build(force="--force" in sys.argv)

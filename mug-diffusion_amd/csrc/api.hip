@@ -230,6 +230,14 @@ int mugd_net_profile(mugd_net* net, double* ms, double* flops, int64_t* launches
 
 const char* mugd_profile_kind_name(int k) { return op_kind_name(k); }
 
+#ifdef MUGD_TL
+// development build only (tests/tl/libmugd_tl.so): not part of include/mugd.h
+int mugd_dev_timeline(mugd_net* net, const char* csv_path, const char* raw_path, int raw_op) {
+    if (!net) return MUGD_ERR_INVALID;
+    return guarded(net->ctx, [&] { net->net->timeline_program(csv_path, raw_path, raw_op); });
+}
+#endif
+
 int mugd_vae_decode(mugd_net* net, const float* z_lat, float* logits, int B, int z) {
     if (!net) return MUGD_ERR_INVALID;
     return guarded(net->ctx, [&] {

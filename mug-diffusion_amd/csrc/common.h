@@ -64,3 +64,44 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------
+// Phase timeline (development build only: `python build.py --tl` compiles the same sources with -DMUGD_TL into
+// tests/tl/libmugd_tl.so; the product library carries none of this).  Every wave of an instrumented kernel stamps
+// s_memtime (shader cycles) at fixed points into an LDS record and dumps it at kernel end; tests/gpu_timeline.py
+// reduces the records to a per-launch phase table (profiles/).
+// ---------------------------------------------------------------------------------------
+constexpr int TL_WORDS = 12;        // per wave: [0..6] s_memtime stamps, [7] s_memrealtime at entry, [8] at exit, [9] HW_ID | XCC_ID << 32, [10] chunks, [11] spare
+#if defined(MUGD_TL) && !defined(MUGD_EMULATED)
+#define TL_DECL __shared__ unsigned long long tl_lds[8][TL_WORDS];
+#define TL_BEGIN()                                                                                          \
+    do {                                                                                                    \
+        if ((threadIdx.x & 63) == 0) {                                                                      \
+            unsigned long long* r_ = tl_lds[threadIdx.x >> 6];                                              \
+            for (int i_ = 0; i_ < TL_WORDS; ++i_) r_[i_] = 0;                                               \
+            r_[7] = __builtin_amdgcn_s_memrealtime();                                                       \
+            r_[9] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |                         \
+                    ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);                 \
+            r_[0] = __builtin_readcyclecounter();                                                           \
+        }                                                                                                   \
+    } while (0)
+#define TL_STAMP(i) do { if ((threadIdx.x & 63) == 0) tl_lds[threadIdx.x >> 6][i] = __builtin_readcyclecounter(); } while (0)
+#define TL_STAMP_ONCE(i) do { if ((threadIdx.x & 63) == 0 && tl_lds[threadIdx.x >> 6][i] == 0) tl_lds[threadIdx.x >> 6][i] = __builtin_readcyclecounter(); } while (0)
+#define TL_SET(i, v) do { if ((threadIdx.x & 63) == 0) tl_lds[threadIdx.x >> 6][i] = (unsigned long long)(v); } while (0)
+#define TL_END(dst, nwaves)                                                                                 \
+    do {                                                                                                    \
+        if ((dst) && (threadIdx.x & 63) == 0) {                                                             \
+            unsigned long long* r_ = tl_lds[threadIdx.x >> 6];                                              \
+            r_[8] = __builtin_amdgcn_s_memrealtime();                                                       \
+            unsigned long long* o_ = (dst) + ((size_t)blockIdx.x * (nwaves) + (threadIdx.x >> 6)) * TL_WORDS; \
+            for (int i_ = 0; i_ < TL_WORDS; ++i_) o_[i_] = r_[i_];                                          \
+        }                                                                                                   \
+    } while (0)
+#else
+#define TL_DECL
+#define TL_BEGIN() do {} while (0)
+#define TL_STAMP(i) do {} while (0)
+#define TL_STAMP_ONCE(i) do {} while (0)
+#define TL_SET(i, v) do {} while (0)
+#define TL_END(dst, nwaves) do {} while (0)
+#endif

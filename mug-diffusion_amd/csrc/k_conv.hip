@@ -42,6 +42,8 @@
 
 namespace {
 
+TL_DECL
+
 constexpr int RS = CONV_RS;
 constexpr int WIN_LDS = CONV_CK * RS;           // floats per window
 constexpr int WAVE_LDS = 2 * WIN_LDS;           // two windows per wave: the pipelined loops park chunk c+1 while chunk c is on the matrix pipe
@@ -281,6 +283,7 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
         fetch_x(1);
         fetch_a(1, Ab, Ab2);
         wave_sync();
+        TL_STAMP_ONCE(2);
         for (int c = 0; c < nch; c += 2) {
             mfma_chunk<TAPS, DUAL>(smem_bytes, rb0, s.dil, Aa, Aa2, acc, acc2);
             park(W1);
@@ -448,6 +451,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
     constexpr int RED = WK > 1 ? WK * 16 * 64 : 1;                  // floats for one partial-tile exchange
     constexpr int WIN = WK * WAVE_LDS;
     __shared__ __attribute__((aligned(16))) float smem[(DUAL ? 2 * RED : RED) > WIN ? (DUAL ? 2 * RED : RED) : WIN];
+    TL_BEGIN();
 
     // ---- XCD-aware renumbering: hardware deals consecutive workgroup ids round-robin to the 8 XCDs;
     // give each XCD a contiguous slab of the (row tile major) tile order so a weight tile is pulled
@@ -516,6 +520,8 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
         }
     };
     if (PRELOAD) load_side();
+    TL_STAMP(1);
+    TL_SET(10, g1 - g0);
 
 #pragma unroll
     for (int si = 0; si < CONV_MAXSEG; ++si) {
@@ -559,6 +565,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
     }
 
     // ---- combine the WK K-slices through LDS (the staging windows are dead after this barrier)
+    TL_STAMP(3);
     float acc_v[EPT], acc_g[EPT];
     if (WK > 1) {
         __syncthreads();
@@ -584,6 +591,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
         for (int q = 0; q < EPT; ++q) { acc_v[q] = acc[q]; acc_g[q] = acc2[q]; }
     }
 
+    TL_STAMP(4);
     if (!PRELOAD) load_side();
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
@@ -596,6 +604,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
         if (valid[q]) a.y[oo[q]] = v;
         acc_v[q] = v;
     }
+    TL_STAMP(5);
     // ---- optional: add this tile's {sum, sum of squares} per row to the fp64 row accumulators (GroupNorm of the consumers)
     if (!DUAL && a.rowstat) {
 #pragma unroll
@@ -636,6 +645,8 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
             o[0] = t1; o[1] = t2;
         }
     }
+    TL_STAMP(6);
+    TL_END(a.tl, WK);
 }
 
 __global__ void pack_weights_kernel(const PackArgs p) {
@@ -657,7 +668,9 @@ __global__ void pack_weights_kernel(const PackArgs p) {
 }
 
 template <int WK, bool DUAL>
-void launch_wk(hipStream_t st, const ConvArgs& a, dim3 grid, int gx, int gy, int gz, int kind, int nitg) {
+void launch_wk(hipStream_t st, const ConvArgs& a0, dim3 grid, int gx, int gy, int gz, int kind, int nitg) {
+    ConvArgs a = a0;
+    a.tl = tl_claim((int)grid.x, WK, 32);
 #define MUGD_CONV_LAUNCH(K, N) hipLaunchKernelGGL((conv_gemm_kernel<WK, DUAL, K, N>), grid, dim3(WK * 64), 0, st, a, gx, gy, gz)
     if (kind == 0) MUGD_CONV_LAUNCH(0, 1);
     else if (kind == 1) MUGD_CONV_LAUNCH(1, 1);

@@ -22,6 +22,8 @@
 
 namespace {
 
+TL_DECL
+
 constexpr int RS = 48;                          // LDS row stride (floats); 48 mod 32 = 16
 constexpr int WIN_LDS = CONV_CK * RS;           // floats per window
 constexpr int WAVE_LDS = 2 * WIN_LDS;           // two windows per wave (software-pipelined loops, see k_conv.hip)
@@ -225,6 +227,7 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
         fetch_x(1);
         fetch_a(1, Ab, Ab2);
         wave_sync();
+        TL_STAMP_ONCE(2);
         for (int c = 0; c < nch; c += 2) {
             mfma(0, Aa, Aa2);
             park(W1);
@@ -282,6 +285,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
     constexpr int RED = WK > 1 ? WK * 8 * 64 : 1;                   // floats for one partial-tile exchange
     constexpr int WIN = WK * WAVE_LDS;
     __shared__ __attribute__((aligned(16))) float smem[(DUAL ? 2 * RED : RED) > WIN ? (DUAL ? 2 * RED : RED) : WIN];
+    TL_BEGIN();
 
     const int nblk = gx * gy * gz;
     int lid = blockIdx.x;
@@ -342,6 +346,8 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
 #pragma unroll
         for (int q = 0; q < EPT; ++q) rsv[q] = a.resid[oo[q]];
     }
+    TL_STAMP(1);
+    TL_SET(10, g1 - g0);
 
 #pragma unroll
     for (int si = 0; si < CONV_MAXSEG; ++si) {
@@ -371,6 +377,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
         }
     }
 
+    TL_STAMP(3);
     float acc_v[EPT], acc_g[EPT];
     if (WK > 1) {
         __syncthreads();
@@ -395,6 +402,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
 #pragma unroll
         for (int q = 0; q < EPT; ++q) { acc_v[q] = acc[q >> 2][q & 3]; acc_g[q] = accg[q >> 2][q & 3]; }
     }
+    TL_STAMP(4);
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
         float v = acc_v[q] + bv[q];
@@ -406,6 +414,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
         if (valid[q]) a.y[oo[q]] = v;
         acc_v[q] = v;
     }
+    TL_STAMP(5);
     if (!DUAL && a.rowstat) {            // add the tile's per-row {sum, sum of squares} to the fp64 row accumulators (see k_conv.hip)
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
@@ -444,6 +453,8 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
             o[0] = t1; o[1] = t2;
         }
     }
+    TL_STAMP(6);
+    TL_END(a.tl, WK);
 }
 
 __global__ void pack_weights16_kernel(const PackArgs p) {
@@ -465,7 +476,9 @@ __global__ void pack_weights16_kernel(const PackArgs p) {
 }
 
 template <int WK>
-void launch16_wk(hipStream_t st, const ConvArgs& a, dim3 grid, int gx, int gy, int gz, bool dual) {
+void launch16_wk(hipStream_t st, const ConvArgs& a0, dim3 grid, int gx, int gy, int gz, bool dual) {
+    ConvArgs a = a0;
+    a.tl = tl_claim((int)grid.x, WK, 16);
     if (dual) hipLaunchKernelGGL((conv_gemm16_kernel<WK, true>), grid, dim3(WK * 64), 0, st, a, gx, gy, gz);
     else hipLaunchKernelGGL((conv_gemm16_kernel<WK, false>), grid, dim3(WK * 64), 0, st, a, gx, gy, gz);
 }

@@ -76,7 +76,22 @@ struct ConvArgs {
     int xcd_cols;            // workgroup order inside an XCD's slab: 0 = row tile major (a weight tile lives in one L2, every XCD reads
                              // the activations), 1 = row tile fastest (a column tile lives in one L2, every XCD reads the weights);
                              // set per launch by conv_pick_order() to whichever moves fewer bytes
+    unsigned long long* tl;  // development build (-DMUGD_TL) only: per-wave phase records [blocks][waves][TL_WORDS]; null otherwise
 };
+
+// development build (-DMUGD_TL): where instrumented launches put their phase records (common.h)
+struct TlLaunch { size_t off; int nblk, nwaves, tn; };
+struct TlSink { unsigned long long* buf = nullptr; size_t cap = 0, used = 0; std::vector<TlLaunch> launches; };
+extern TlSink g_tl;
+inline unsigned long long* tl_claim(int nblk, int nwaves, int tn) {
+    if (!g_tl.buf) return nullptr;
+    const size_t n = (size_t)nblk * nwaves * TL_WORDS;
+    if (g_tl.used + n > g_tl.cap) return nullptr;
+    unsigned long long* p = g_tl.buf + g_tl.used;
+    g_tl.launches.push_back(TlLaunch{g_tl.used, nblk, nwaves, tn});
+    g_tl.used += n;
+    return p;
+}
 
 void launch_conv_gemm(hipStream_t st, const ConvArgs& a);        // 32 x 32 tiles
 int conv_pick_wk(const ConvArgs& a);

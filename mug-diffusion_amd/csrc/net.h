@@ -108,6 +108,9 @@ public:
     virtual void invalidate();       // parameters changed: drop packed weights / baked kernels / programs
     // runs the currently compiled program once, eagerly, with a HIP event pair around every launch
     void profile_program(ProfileRow* rows /*[OP_KINDS]*/);
+#ifdef MUGD_TL
+    void timeline_program(const char* path, const char* raw_path, int raw_op);     // development build: per-launch phase table (common.h)
+#endif
 
 protected:
     Ctx* ctx;

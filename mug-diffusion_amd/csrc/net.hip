@@ -79,6 +79,75 @@ void Net::profile_program(ProfileRow* rows) {
     for (auto& e : ev) hipEventDestroy(e);
 }
 
+TlSink g_tl;
+
+#ifdef MUGD_TL
+// Development build only: runs the compiled program once (eagerly) with every conv_gemm launch writing its per-wave phase
+// records, reduces them per launch and appends one CSV row per launch to `path`.  Columns: cycles are s_memtime ticks (shader
+// clock); *_ns come from s_memrealtime (100 MHz, device-global), so they also order waves of different CUs / XCDs.
+void Net::timeline_program(const char* path, const char* raw_path, int raw_op) {
+    hipStream_t st = ctx->stream;
+    const size_t cap = (size_t)48 << 20;                     // 48 M words = 384 MB: a U-Net evaluation at batch 4 needs ~ 15 M
+    unsigned long long* buf = nullptr;
+    HIP_CHECK(hipMalloc((void**)&buf, cap * 8));
+    HIP_CHECK(hipMemsetAsync(buf, 0, cap * 8, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    g_tl.buf = buf; g_tl.cap = cap; g_tl.used = 0; g_tl.launches.clear();
+    std::vector<size_t> first(ops.size() + 1, 0);
+    for (size_t i = 0; i < ops.size(); ++i) {
+        first[i] = g_tl.launches.size();
+        ops[i].fn(st);
+    }
+    first[ops.size()] = g_tl.launches.size();
+    HIP_CHECK(hipStreamSynchronize(st));
+    g_tl.buf = nullptr;
+    std::vector<unsigned long long> h(g_tl.used);
+    HIP_CHECK(hipMemcpy(h.data(), buf, g_tl.used * 8, hipMemcpyDeviceToHost));
+    hipFree(buf);
+    FILE* f = fopen(path, "a");
+    MUGD_CHECK(f != nullptr, -2, std::string("timeline: cannot open ") + path);
+    FILE* fr = raw_path ? fopen(raw_path, "a") : nullptr;
+    const char* raw_label = getenv("MUGD_TL_RAW_LABEL");          // raw per-wave records of the launches whose label contains this
+    fprintf(f, "op,kind,gflop,tn,wk,blocks,waves,span_ns,start_skew_ns,first_end_ns,mhz,chunks_med,"
+               "setup_med,setup_max,first_med,first_max,loop_med,loop_max,cyc_per_chunk,combine_med,combine_max,store_med,store_max,tail_med,tail_max,total_med,total_max,label\n");
+    auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+    auto mx = [](const std::vector<double>& v) { double m = 0; for (double x : v) m = std::max(m, x); return m; };
+    for (size_t i = 0; i < ops.size(); ++i) {
+        for (size_t li = first[i]; li < first[i + 1]; ++li) {
+            const TlLaunch& L = g_tl.launches[li];
+            const size_t nw = (size_t)L.nblk * L.nwaves;
+            unsigned long long r0 = ~0ull, r1 = 0, r0max = 0, r1min = ~0ull;
+            std::vector<double> ph[7], chunks, mhz;
+            for (size_t w = 0; w < nw; ++w) {
+                const unsigned long long* r = &h[L.off + w * TL_WORDS];
+                if (r[0] == 0) continue;
+                r0 = std::min(r0, r[7]); r0max = std::max(r0max, r[7]); r1 = std::max(r1, r[8]); r1min = std::min(r1min, r[8]);
+                // stamp 2 (first chunk parked) is missing on the non-pipelined paths: fold it into the loop phase
+                const unsigned long long t2 = r[2] ? r[2] : r[1];
+                ph[0].push_back((double)(r[1] - r[0])); ph[1].push_back((double)(t2 - r[1])); ph[2].push_back((double)(r[3] - t2));
+                ph[3].push_back((double)(r[4] - r[3])); ph[4].push_back((double)(r[5] - r[4])); ph[5].push_back((double)(r[6] - r[5]));
+                ph[6].push_back((double)(r[6] - r[0]));
+                chunks.push_back((double)r[10]);
+                if (r[8] > r[7]) mhz.push_back((double)(r[6] - r[0]) / ((double)(r[8] - r[7]) * 10.0) * 1e3);
+                if (fr && ((int)i == raw_op || raw_op == -1 || (raw_label && ops[i].label.find(raw_label) != std::string::npos)))
+                    fprintf(fr, "%zu,%zu,%zu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu\n", i, w / L.nwaves, w % L.nwaves,
+                            r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[10]);
+            }
+            const double cm = med(chunks), lm = med(ph[2]);
+            fprintf(f, "%zu,%s,%.4f,%d,%d,%d,%zu,%llu,%llu,%llu,%.0f,%.0f", i, op_kind_name(ops[i].kind), ops[i].flops / 1e9, L.tn, L.nwaves, L.nblk,
+                    nw, (r1 - r0) * 10ull, (r0max - r0) * 10ull, (r1min - r0) * 10ull, med(mhz), cm);
+            for (int k = 0; k < 6; ++k) {
+                fprintf(f, ",%.0f,%.0f", med(ph[k]), mx(ph[k]));
+                if (k == 2) fprintf(f, ",%.0f", cm > 0 ? lm / cm : 0.0);
+            }
+            fprintf(f, ",%.0f,%.0f,%s\n", med(ph[6]), mx(ph[6]), ops[i].label.c_str());
+        }
+    }
+    fclose(f);
+    if (fr) fclose(fr);
+}
+#endif
+
 void Net::invalidate() {
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (void* p : owned) hipFree(p);
