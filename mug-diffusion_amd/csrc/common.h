@@ -65,6 +65,18 @@ __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f +
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// n / d for n, d < 65536 with m = ceil(2^32 / d) precomputed on the host (conv_fastdiv_mul); d == 1 is encoded as m == 0
+__device__ __forceinline__ int fastdiv(int n, unsigned m) { return m ? (int)__umulhi((unsigned)n, m) : n; }
+
+// Kernel arguments are fetched by scalar loads the compiler places lazily, one dependent round trip per first use: the conv_gemm
+// prologue paid ~25 of them in series (profiles/r2_timeline_*: 0.8-1.2 us "setup").  KARG_PIN forces the listed values into SGPRs
+// at one point, so their loads are issued back to back and waited for once.
+#ifdef MUGD_EMULATED
+#define KARG_PIN4(a, b, c, d) do {} while (0)
+#else
+#define KARG_PIN4(a, b, c, d) asm volatile("" ::"s"(a), "s"(b), "s"(c), "s"(d))
+#endif
+
 // ---------------------------------------------------------------------------------------
 // Phase timeline (development build only: `python build.py --tl` compiles the same sources with -DMUGD_TL into
 // tests/tl/libmugd_tl.so; the product library carries none of this).  Every wave of an instrumented kernel stamps

@@ -1,0 +1,142 @@
+// GroupNorm / LayerNorm statistics inside a conv_gemm workgroup (ConvSeg::xf == 4 / 3), shared by k_conv.hip and k_conv16.hip.
+//
+// The producers of a normalised tensor left partial sums behind (fp64 {sum, sum of squares} per row: ConvArgs::rowstat;
+// fp32 {sum, sum of squares} per 32-row tile and column: ConvArgs::colstat).  The consuming workgroup turns them into
+// {mean, rstd} ONCE, cooperatively, with a single memory round trip:
+//   issue()   first thing in the kernel: every thread requests its share of the partial sums (<= 3 rows of one GroupNorm
+//             group, or <= 4 row tiles of one column) -- the loads are in flight while the wave computes its tile addresses
+//             and requests its epilogue operands;
+//   finish()  in front of the K loop, by every wave: lane-group reduction (GroupNorm: the 16 / 8 / 4 / 2 lanes of a group
+//             sit in one wave) or an exchange through LDS (LayerNorm: the row tiles of a column are spread over the waves),
+//             then one / two workgroup barriers; the tables live in LDS for the rest of the kernel.
+// (Keeping the requested sums in registers across the first chunk's loads as well costs 40 VGPRs in the K loop and more than
+// it hides: measured, profiles/README.md.)
+// The round-2 phase timeline (profiles/r2_timeline_before_*.txt) showed the previous per-wave version -- each wave reduced the
+// groups of its own K-slice with dependent fp64 loads, division and sqrt -- at 2-6 us of every normalised launch.
+#pragma once
+#include "kernels.h"
+
+__device__ __forceinline__ double shfl_xor_d(double v, int o) {
+    return __hiloint2double(__shfl_xor(__double2hiint(v), o), __shfl_xor(__double2loint(v), o));
+}
+
+template <int WK, int TN>
+struct WgStats {
+    static constexpr int NTHR = WK * 64;
+    static constexpr int LPG = NTHR / 32;                 // lanes per GroupNorm group (32 groups per pass): 16 | 8 | 4 | 2
+    static constexpr int NG = 3;                          // rows per lane requested up front (covers 48 channels per group at WK = 8)
+    static constexpr int NPART = NTHR / TN;               // LayerNorm: row tiles summed in parallel
+    static constexpr int NLN = NPART >= 16 ? 1 : (NPART >= 8 ? 2 : 4);      // row tiles per thread requested up front
+
+    struct Lds {
+        float2 gnst[32];                                  // GroupNorm {mean, rstd} per group
+        float2 lnst[TN];                                  // LayerNorm {mean, rstd} per tile column
+        float2 lnred[NTHR];                               // LayerNorm exchange [part][column]
+    };
+
+    bool pending = false;
+    bool ln = false;
+    double2 gv[NG];
+    float2 lv[NLN];
+
+    // fp64 {sum, sum of squares} of channel c of the normalised concat (segments 0 .. gn_nseg-1), batch row b; zero if !ok.
+    // One predicated load per segment with COMPILE-TIME segment indices: a per-lane segment index would turn the kernarg
+    // accesses into vector loads of the argument block -- a second dependent round trip in front of the sums themselves.
+    static __device__ __forceinline__ double2 row_load(const ConvArgs& a, int b, int c, bool ok) {
+        double2 v = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int si = 0; si < CONV_MAXSEG; ++si) {
+            if (si < a.gn_nseg) {
+                const ConvSeg& s = a.seg[si];
+                if (ok && c >= 0 && c < s.C) {
+                    const int bb = s.bmod > 0 ? b % s.bmod : b;
+                    v = *reinterpret_cast<const double2*>(reinterpret_cast<const double*>(s.xf_a) + (size_t)bb * s.xf_stride + 2 * (size_t)c);
+                }
+                c -= s.C;
+            }
+        }
+        return v;
+    }
+
+    __device__ __forceinline__ void issue(const ConvArgs& a, int b, int t0, int tid) {
+        ln = a.seg[0].xf == 3;
+        pending = ln || a.gn_groups != 0;
+        if (a.gn_groups) {
+            const int g = tid / LPG, j = tid % LPG, cg = a.gn_cg;
+#pragma unroll
+            for (int u = 0; u < NG; ++u) {
+                const int cc = j + u * LPG;
+                gv[u] = row_load(a, b, g * cg + cc, g < a.gn_groups && cc < cg);
+            }
+        }
+        if (ln) {
+            const ConvSeg& s = a.seg[0];
+            const int col = tid % TN, part = tid / TN;
+            int t = t0 + col;
+            t = t < s.Tin ? t : s.Tin - 1;
+            const float2* ps = reinterpret_cast<const float2*>(s.xf_a + (size_t)b * s.xf_stride) + t;
+#pragma unroll
+            for (int u = 0; u < NLN; ++u) {
+                const int p = part + u * NPART;
+                lv[u] = ps[(size_t)(p < s.xf_np ? p : 0) * s.Tin];
+            }
+        }
+    }
+
+    __device__ __forceinline__ void finish(const ConvArgs& a, int b, int t0, int tid, Lds& l) {
+        if (!pending) return;
+        pending = false;
+        if (a.gn_groups) {
+            const int g = tid / LPG, j = tid % LPG, cg = a.gn_cg;
+            const bool active = g < a.gn_groups;
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int u = 0; u < NG; ++u)
+                if (active && j + u * LPG < cg) { s1 += gv[u].x; s2 += gv[u].y; }
+            for (int cc = j + NG * LPG; active && cc < cg; cc += LPG) {         // groups wider than NG * LPG channels (not in the shipped nets at WK = 8)
+                const double2 v = row_load(a, b, g * cg + cc, true);
+                s1 += v.x; s2 += v.y;
+            }
+#pragma unroll
+            for (int o = 1; o < LPG; o <<= 1) { s1 += shfl_xor_d(s1, o); s2 += shfl_xor_d(s2, o); }
+            if (active && j == 0) {
+                const double inv = 1.0 / (double)a.gn_count;
+                const double mean = s1 * inv;
+                double var = s2 * inv - mean * mean;
+                var = var > 0.0 ? var : 0.0;
+                l.gnst[g] = make_float2((float)mean, 1.0f / sqrtf((float)var + a.gn_eps));
+            }
+        }
+        if (ln) {
+            const ConvSeg& s = a.seg[0];
+            const int col = tid % TN, part = tid / TN;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int u = 0; u < NLN; ++u)
+                if (part + u * NPART < s.xf_np) { s1 += lv[u].x; s2 += lv[u].y; }
+            if (s.xf_np > NPART * NLN) {                                          // more row tiles than requested up front
+                int t = t0 + col;
+                t = t < s.Tin ? t : s.Tin - 1;
+                const float2* ps = reinterpret_cast<const float2*>(s.xf_a + (size_t)b * s.xf_stride) + t;
+                for (int p = part + NLN * NPART; p < s.xf_np; p += NPART) { const float2 v = ps[(size_t)p * s.Tin]; s1 += v.x; s2 += v.y; }
+            }
+            l.lnred[part * TN + col] = make_float2(s1, s2);
+        }
+        __syncthreads();
+        if (ln) {
+            const ConvSeg& s = a.seg[0];
+            if (tid < TN) {
+                float s1 = 0.f, s2 = 0.f;
+                const int np = s.xf_np < NPART ? s.xf_np : NPART;
+                for (int p = 0; p < np; ++p) { const float2 v = l.lnred[p * TN + tid]; s1 += v.x; s2 += v.y; }
+                // E[x^2] - mean^2 in fp64 (cancellation), 1/sqrt in fp32 like torch's LayerNorm
+                const double inv = 1.0 / (double)s.C;
+                const double m = (double)s1 * inv;
+                float var = (float)((double)s2 * inv - m * m);
+                var = var > 0.f ? var : 0.f;
+                l.lnst[tid] = make_float2((float)m, 1.0f / sqrtf(var + s.xf_eps));
+            }
+            __syncthreads();
+        }
+    }
+};

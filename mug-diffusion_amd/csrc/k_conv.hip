@@ -33,7 +33,7 @@
 #include <algorithm>
 #include <cstdlib>
 
-#include "gn_wave.h"
+#include "conv_stats.h"
 #include "kernels.h"
 
 #ifndef MUGD_PIPE
@@ -97,8 +97,7 @@ __device__ __forceinline__ void mfma_chunk(const char* smem_bytes, int rb0, int 
 template <int TAPS, bool DUAL, int NH, int XFK = -1, int ACT = -1, bool PIPE = false>
 __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* wseg, const float* wseg2, int lo, int hi,
                                                 int b, int t0, int lane, int h, int n, char* smem_bytes, int wave_base,
-                                                f32x16& acc, f32x16& acc2, float2* gst, float inv_cg,
-                                                const ConvArgs& ka, int kg0, int kg1, bool& gn_pending) {
+                                                f32x16& acc, f32x16& acc2, const float2* gst, const float2* lnst, float inv_cg) {
     const int r = lane >> 2, q = lane & 3;
     const int Tin = s.Tin;
     const int hw = (TAPS - 1) * s.dil;                     // halo samples per row (left pad + right rest)
@@ -152,37 +151,11 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
         }
     }
 
+    // LayerNorm statistics from the producer's column sums: reduced once per workgroup (conv_stats.h), read back from LDS here
     auto finish_ln = [&]() {
         if (s.xf != 3) return;
-        // LayerNorm statistics from the producer's column sums.  The 16 lanes that share this lane's 8 samples
-        // (same quarter q, rows r = 0..15) split the producer's row tiles between them -- lane r takes tiles r, r+16, ..:
-        // ONE batch of 4 loads per 16 tiles -- and the partial sums are combined with a fixed xor tree.
-        const float* ps = s.xf_a + (size_t)b * s.xf_stride;
-        const int tq0 = ok0 ? ti0 : Tin - 4, tq1 = ok1 ? ti1 : Tin - 4;
-        float s1[8], s2[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-        for (int p0 = r; p0 < s.xf_np; p0 += 16) {
-            const float4* row = reinterpret_cast<const float4*>(ps + (size_t)p0 * Tin * 2);
-            float4 v[4];
-            v[0] = row[tq0 / 2]; v[1] = row[tq0 / 2 + 1]; v[2] = row[tq1 / 2]; v[3] = row[tq1 / 2 + 1];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { s1[2 * j] += v[j].x; s2[2 * j] += v[j].y; s1[2 * j + 1] += v[j].z; s2[2 * j + 1] += v[j].w; }
-        }
-#pragma unroll
-        for (int o = 4; o < 64; o <<= 1) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { s1[i] += __shfl_xor(s1[i], o); s2[i] += __shfl_xor(s2[i], o); }
-        }
-        const double inv = 1.0 / (double)s.C;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {             // E[x^2] - mean^2 in fp64 (cancellation), 1/sqrt in fp32 like torch's LayerNorm
-            const double m = (double)s1[i] * inv;
-            float var = (float)((double)s2[i] * inv - m * m);
-            var = var > 0.f ? var : 0.f;
-            mu[i] = (float)m;
-            rs8[i] = 1.0f / sqrtf(var + s.xf_eps);
-        }
+        for (int i = 0; i < 8; ++i) { const float2 st = lnst[8 * q + i]; mu[i] = st.x; rs8[i] = st.y; }
     };
 
     const int bb = s.bmod > 0 ? b % s.bmod : b;
@@ -198,28 +171,26 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
     float2 gbv = make_float2(1.f, 0.f);
 
     int gbg = 0;                                    // gn4: GroupNorm group of the channel gbv belongs to
-    auto load_gb = [&](int cr) -> float2 {          // per-channel {g, b} of chunk lo + cr for this lane's row; for gn4 the raw
+    auto load_gb2 = [&](int cr, int& gg) -> float2 {   // per-channel {g, b} of chunk lo + cr for this lane's row; for gn4 the raw
         if (gn4) {                                  // {gamma, beta}: the group statistics are folded in when the chunk is parked,
             const int c = s.xf_coff + (lo + cr) * CONV_CK + r;      // so no load here waits for the group reduction
-            gbg = (int)(((float)c + 0.5f) * inv_cg);
+            gg = (int)(((float)c + 0.5f) * inv_cg);
             return reinterpret_cast<const float2*>(s.xf_b)[c];
         }
         return *reinterpret_cast<const float2*>(gb + (size_t)cr * (2 * CONV_CK));
     };
-    // the wave's GroupNorm group table is filled AFTER the first chunk's loads have been issued (one round trip for both)
-    auto finish_stats = [&]() {
-        if (gn_pending) { wave_gn_stats(ka, b, lane, kg0, kg1, gst); gn_pending = false; }
-    };
+    auto load_gb = [&](int cr) -> float2 { return load_gb2(cr, gbg); };
+    auto finish_stats = [&]() {};           // the workgroup's statistics tables were completed before the K loop (conv_stats.h)
     // transform the staged samples and park them in window `wofs` (byte offset 0 | WIN_LDS*4)
-    auto park = [&](int wofs) {
+    auto park_v = [&](int wofs, const float4& xa, const float4& xb4, const float (&xhh)[NH > 0 ? NH : 1], const float2 gbq, const int ggq) {
         float v[8];
         float vh[NH > 0 ? NH : 1];
-        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+        v[0] = xa.x; v[1] = xa.y; v[2] = xa.z; v[3] = xa.w; v[4] = xb4.x; v[5] = xb4.y; v[6] = xb4.z; v[7] = xb4.w;
 #pragma unroll
-        for (int j = 0; j < NH; ++j) vh[j] = xh[j];
+        for (int j = 0; j < NH; ++j) vh[j] = xhh[j];
         if (xf) {
-            float g = gbv.x, bt = gbv.y;
-            if (gn4) { const float2 st = gst[gbg]; g = gbv.x * st.y; bt = gbv.y - st.x * g; }
+            float g = gbq.x, bt = gbq.y;
+            if (gn4) { const float2 st = gst[ggq]; g = gbq.x * st.y; bt = gbq.y - st.x * g; }
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = (xf == 1) ? v[i] * g + bt : (v[i] - mu[i]) * rs8[i] * g + bt;
 #pragma unroll
@@ -244,69 +215,72 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
 #pragma unroll
         for (int j = 0; j < NH; ++j) *reinterpret_cast<float*>(smem_bytes + wofs + lh[j]) = okh[j] ? vh[j] : 0.f;
     };
+    auto park = [&](int wofs) { park_v(wofs, x0, x1, xh, gbv, gbg); };
 
     if (PIPE) {
-        // ---- software-pipelined loop: while chunk c is on the matrix pipe (its fragments come from window c&1) the wave
-        // transforms chunk c+1 and parks it in the other window, then requests chunk c+2.  One straight-line block per
-        // chunk: the VALU / LDS-store / load-issue work sits in the issue slots between the wave's own dependent MFMAs
-        // instead of in a phase of its own (two waves of a SIMD run in lockstep, so separate phases leave the pipe idle).
+        // ---- software-pipelined loop over a register RING of D chunks.  Chunk k's weights and raw window live in ring stage
+        // k % D from the moment they are requested; while chunk c is on the matrix pipe (fragments from LDS window c & 1) the
+        // wave transforms chunk c+1 into the other window and re-requests the two stages it has just drained (weights of chunk
+        // c+D, window of chunk c+1+D).  A wave's K-slice of a 1x1 layer is only 2..8 chunks long and every chunk's operands
+        // come from another XCD's write-back or from HBM (~1.3 us each at kernel start): with D = 4 the whole slice of the short
+        // layers is in flight before the first MFMA (the phase timeline of the 2-deep version showed one exposed round trip per
+        // pair of chunks: profiles/r2_timeline_*).  3-tap chunks carry 3x the weights per chunk: D = 2.
+        constexpr int D = (TAPS == 1 && !DUAL) ? 4 : 2;
         const int nch = hi - lo;
-        auto fetch_x = [&](int cr) {                    // chunk index clamped: the tail re-reads the last chunk, in bounds
-            const int cc = cr < nch ? cr : nch - 1;
-            const char* xq = xb + (size_t)cc * xstep;
-            x0 = *reinterpret_cast<const float4*>(xq + g0);
-            x1 = *reinterpret_cast<const float4*>(xq + g1);
+        float4 RA[D][6], RA2[D][6];
+        float4 RX0[D], RX1[D];
+        float RXH[D][NH > 0 ? NH : 1];
+        float2 RGB[D];
+        int RGG[D];
 #pragma unroll
-            for (int j = 0; j < NH; ++j) xh[j] = *reinterpret_cast<const float*>(xq + gh[j]);
-            if (xf) gbv = load_gb(cc);
+        for (int d = 0; d < D; ++d) { RGB[d] = make_float2(1.f, 0.f); RGG[d] = 0; }
+        auto fetch_x = [&](int cr, int d) {
+            const char* xq = xb + (size_t)cr * xstep;
+            RX0[d] = *reinterpret_cast<const float4*>(xq + g0);
+            RX1[d] = *reinterpret_cast<const float4*>(xq + g1);
+#pragma unroll
+            for (int j = 0; j < NH; ++j) RXH[d][j] = *reinterpret_cast<const float*>(xq + gh[j]);
+            if (xf) RGB[d] = load_gb2(cr, RGG[d]);
         };
-        auto fetch_a = [&](int cr, float4 (&An)[6], float4 (&An2)[6]) {
-            const int cc = cr < nch ? cr : nch - 1;
-            load_a<TAPS, DUAL>(wp + (size_t)cc * (TAPS * 512), wp2 + (size_t)cc * (TAPS * 512), An, An2);
+        auto fetch_a = [&](int cr, int d) {
+            load_a<TAPS, DUAL>(wp + (size_t)cr * (TAPS * 512), wp2 + (size_t)cr * (TAPS * 512), RA[d], RA2[d]);
         };
         constexpr int W1 = WIN_LDS * 4;
-        // scheduling pattern of one chunk: after every MFMA a few VALU ops (the next chunk's transform / addressing),
-        // so the VALU stream is spread over the matrix pipe's shadow instead of trailing the last MFMA
-        auto interleave = [&]() {
 #pragma unroll
-            for (int i = 0; i < TAPS * 8 * (DUAL ? 2 : 1); ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-                if (XFK > 0 && ACT > 0) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // VALU
-                else __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-            }
-        };
-        fetch_a(0, Aa, Aa2);
-        fetch_x(0);
-        finish_stats();
+        for (int d = 0; d < D; ++d)
+            if (d < nch) fetch_x(d, d);                 // the windows are needed first: their loads go ahead of the weights
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (d < nch) fetch_a(d, d);
         finish_ln();
-        park(0);
-        fetch_x(1);
-        fetch_a(1, Ab, Ab2);
+        park_v(0, RX0[0], RX1[0], RXH[0], RGB[0], RGG[0]);
+        if (D < nch) fetch_x(D, 0);
         wave_sync();
         TL_STAMP_ONCE(2);
-        for (int c = 0; c < nch; c += 2) {
-            mfma_chunk<TAPS, DUAL>(smem_bytes, rb0, s.dil, Aa, Aa2, acc, acc2);
-            park(W1);
-            fetch_x(c + 2);
-            fetch_a(c + 2, Aa, Aa2);
-            interleave();
-            wave_sync();
-            if (c + 1 >= nch) break;
-            mfma_chunk<TAPS, DUAL>(smem_bytes + W1, rb0, s.dil, Ab, Ab2, acc, acc2);
-            park(0);
-            fetch_x(c + 3);
-            fetch_a(c + 3, Ab, Ab2);
-            interleave();
-            wave_sync();
+        for (int c = 0; c < nch; c += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int cc = c + d;
+                if (cc < nch) {
+                    const int dn = (d + 1) % D;
+                    mfma_chunk<TAPS, DUAL>(smem_bytes + (d & 1) * W1, rb0, s.dil, RA[d], RA2[d], acc, acc2);
+                    if (cc + 1 < nch) {
+                        park_v(((d + 1) & 1) * W1, RX0[dn], RX1[dn], RXH[dn], RGB[dn], RGG[dn]);
+                        if (cc + 1 + D < nch) fetch_x(cc + 1 + D, dn);
+                    }
+                    if (cc + D < nch) fetch_a(cc + D, d);
+                    wave_sync();
+                }
+            }
         }
         return;
     }
 
-    load_a<TAPS, DUAL>(wp, wp2, Aa, Aa2);
     x0 = *reinterpret_cast<const float4*>(xb + g0);
     x1 = *reinterpret_cast<const float4*>(xb + g1);
 #pragma unroll
     for (int j = 0; j < NH; ++j) xh[j] = *reinterpret_cast<const float*>(xb + gh[j]);
+    load_a<TAPS, DUAL>(wp, wp2, Aa, Aa2);
     int crel = 0;
     if (xf) gbv = load_gb(0);
     finish_stats();
@@ -447,11 +421,25 @@ __device__ __forceinline__ bool seg_is_vec(const ConvSeg& s) { return s.stride =
 // KIND 2: every segment through the generic window walk (stride 2, nearest-x2 upsample, T % 4 != 0); NITG = its
 //         staging passes.  Separate kernels keep each instantiation's register budget to what it needs.
 template <int WK, bool DUAL, int KIND, int NITG>
-__global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel(const ConvArgs a, int gx, int gy, int gz) {
-    constexpr int RED = WK > 1 ? WK * 16 * 64 : 1;                  // floats for one partial-tile exchange
+__global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel(const ConvArgs a) {
+    constexpr int RED = WK > 1 ? WK * 16 * 64 : 0;                  // floats for one partial-tile exchange
     constexpr int WIN = WK * WAVE_LDS;
-    __shared__ __attribute__((aligned(16))) float smem[(DUAL ? 2 * RED : RED) > WIN ? (DUAL ? 2 * RED : RED) : WIN];
+    // staging windows, then the partial-tile exchange in a region of its own: a wave that has finished its K-slice parks its
+    // accumulators without waiting for the slower waves to leave their windows (ONE barrier per combine instead of two)
+    __shared__ __attribute__((aligned(16))) float smem[WIN + (DUAL ? 2 * RED : RED) + 4];
+    typedef WgStats<WK, CONV_TN> Stats;
+    __shared__ typename Stats::Lds stl;
     TL_BEGIN();
+
+    // ---- kernel arguments of the prologue in one batch (common.h: KARG_PIN)
+    const int gx = a.gx, gy = a.gy, gz = a.gz;
+    KARG_PIN4(gx, gy, gz, a.xcd_cols);
+    KARG_PIN4(a.mgx, a.mgy, a.mgxz, a.nseg);
+    KARG_PIN4(a.gn_groups, a.gn_cg, a.gn_nseg, a.Mout);
+    KARG_PIN4(a.wpk, a.w_mt_stride, a.Tout, a.nchunk);
+    KARG_PIN4(a.seg[0].x, a.seg[0].C, a.seg[0].Tin, a.seg[0].xf);
+    KARG_PIN4(a.seg[0].xf_a, a.seg[0].xf_stride, a.seg[0].bmod, a.seg[0].xf_np);
+    KARG_PIN4(a.bias, a.rowadd, a.resid, a.rowadd_stride);
 
     // ---- XCD-aware renumbering: hardware deals consecutive workgroup ids round-robin to the 8 XCDs;
     // give each XCD a contiguous slab of the (row tile major) tile order so a weight tile is pulled
@@ -460,18 +448,25 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
     int lid = blockIdx.x;
     if ((nblk & 7) == 0) lid = (lid & 7) * (nblk >> 3) + (lid >> 3);
     int mt, rem;
-    if (a.xcd_cols) { rem = lid / gy; mt = lid - rem * gy; }       // row tile fastest: an XCD's slab is a range of column tiles
-    else { mt = lid / (gx * gz); rem = lid - mt * (gx * gz); }
-    const int b = rem / gx;
+    if (a.xcd_cols) { rem = fastdiv(lid, a.mgy); mt = lid - rem * gy; }       // row tile fastest: an XCD's slab is a range of column tiles
+    else { mt = fastdiv(lid, a.mgxz); rem = lid - mt * (gx * gz); }
+    const int b = fastdiv(rem, a.mgx);
     const int t0 = (rem - b * gx) * CONV_TN;
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, h = lane >> 5, n = lane & 31;
 
-    const int per = (a.nchunk + WK - 1) / WK;
-    const int g0 = wave * per;
-    const int g1 = (g0 + per < a.nchunk) ? g0 + per : a.nchunk;
+    // ---- GroupNorm / LayerNorm statistics of the normalised inputs: partial sums requested NOW, reduced once per workgroup
+    // after the first chunk's loads are out (conv_stats.h)
+    Stats stats;
+    stats.issue(a, b, t0, tid);
+
+    // K-slice of this wave: chunk boundaries balanced by cost on the host (a 3-tap chunk is ~2x a 1x1 chunk)
+    int g0 = a.kb[0], g1 = a.kb[1];          // constant kernarg offsets + selects: no dependent scalar load
+#pragma unroll
+    for (int w = 1; w < WK; ++w)
+        if (wave == w) { g0 = a.kb[w]; g1 = a.kb[w + 1]; }
 
     f32x16 acc, acc2;
 #pragma unroll
@@ -482,10 +477,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
     char* smem_bytes = reinterpret_cast<char*>(smem);
     const int wave_base = wave * WAVE_LDS * 4;
 
-    // ---- GroupNorm of the leading segments from their producers' row sums: this wave's groups only (gn_wave.h)
-    __shared__ float2 gnst[WK][32];
     const float gn_inv_cg = a.gn_groups ? 1.0f / (float)a.gn_cg : 0.f;
-    bool gn_pending = a.gn_groups != 0;          // reduced by the first GroupNorm segment this wave runs, after its first loads are out
 
     // ---- epilogue operands: the side loads (bias / row term / residual) are issued HERE, before the K loop, from
     // clamped addresses under wave-uniform conditions, so their latency is off the kernel's critical path.
@@ -520,6 +512,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
         }
     };
     if (PRELOAD) load_side();
+    stats.finish(a, b, t0, tid, stl);      // reduce + workgroup barrier(s): the requests went out before the index math above
     TL_STAMP(1);
     TL_SET(10, g1 - g0);
 
@@ -534,7 +527,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
                 const float* w1 = wtile + s.woff;
                 const float* w2 = wtile2 + s.woff;
 #define MUGD_SEG_ARGS s, w1, w2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, acc, acc2
-#define MUGD_SEG_VARGS MUGD_SEG_ARGS, gnst[wave], gn_inv_cg, a, g0, g1, gn_pending
+#define MUGD_SEG_VARGS MUGD_SEG_ARGS, stl.gnst, stl.lnst, gn_inv_cg
                 if (KIND == 0) {
                     // specialise on (transform, activation): branch-free chunk loops
 #define MUGD_SEG_XF(T, NHALO)                                                                     \
@@ -564,15 +557,15 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
         }
     }
 
-    // ---- combine the WK K-slices through LDS (the staging windows are dead after this barrier)
+    // ---- combine the WK K-slices through LDS (exchange region behind the staging windows)
     TL_STAMP(3);
     float acc_v[EPT], acc_g[EPT];
     if (WK > 1) {
-        __syncthreads();
+        float* ex = smem + WIN;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            smem[(wave * 16 + r) * 64 + lane] = acc[r];
-            if (DUAL) smem[RED + (wave * 16 + r) * 64 + lane] = acc2[r];
+            ex[(wave * 16 + r) * 64 + lane] = acc[r];
+            if (DUAL) ex[RED + (wave * 16 + r) * 64 + lane] = acc2[r];
         }
         __syncthreads();
 #pragma unroll
@@ -582,15 +575,14 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
             acc_g[q] = 0.f;
 #pragma unroll
             for (int w = 0; w < WK; ++w) {
-                acc_v[q] += smem[(w * 16 + r) * 64 + lane];
-                if (DUAL) acc_g[q] += smem[RED + (w * 16 + r) * 64 + lane];
+                acc_v[q] += ex[(w * 16 + r) * 64 + lane];
+                if (DUAL) acc_g[q] += ex[RED + (w * 16 + r) * 64 + lane];
             }
         }
     } else {
 #pragma unroll
         for (int q = 0; q < EPT; ++q) { acc_v[q] = acc[q]; acc_g[q] = acc2[q]; }
     }
-
     TL_STAMP(4);
     if (!PRELOAD) load_side();
 #pragma unroll
@@ -670,8 +662,10 @@ __global__ void pack_weights_kernel(const PackArgs p) {
 template <int WK, bool DUAL>
 void launch_wk(hipStream_t st, const ConvArgs& a0, dim3 grid, int gx, int gy, int gz, int kind, int nitg) {
     ConvArgs a = a0;
+    conv_split_k(a, WK);
+    conv_set_grid(a, gx, gy, gz);
     a.tl = tl_claim((int)grid.x, WK, 32);
-#define MUGD_CONV_LAUNCH(K, N) hipLaunchKernelGGL((conv_gemm_kernel<WK, DUAL, K, N>), grid, dim3(WK * 64), 0, st, a, gx, gy, gz)
+#define MUGD_CONV_LAUNCH(K, N) hipLaunchKernelGGL((conv_gemm_kernel<WK, DUAL, K, N>), grid, dim3(WK * 64), 0, st, a)
     if (kind == 0) MUGD_CONV_LAUNCH(0, 1);
     else if (kind == 1) MUGD_CONV_LAUNCH(1, 1);
     else if (nitg <= 9) MUGD_CONV_LAUNCH(2, 9);

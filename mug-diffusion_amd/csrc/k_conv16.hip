@@ -17,7 +17,7 @@
 #include <algorithm>
 #include <cstdlib>
 
-#include "gn_wave.h"
+#include "conv_stats.h"
 #include "kernels.h"
 
 namespace {
@@ -41,8 +41,7 @@ __device__ __forceinline__ void load_a16(const float* wp, const float* wp2, floa
 template <int TAPS, bool DUAL, int XFK = -1, int ACT = -1, bool PIPE = false>       // XFK / ACT / PIPE: see k_conv.hip
 __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wseg, const float* wseg2, int lo, int hi,
                                               int b, int t0, int lane, char* smem_bytes, int wave_base,
-                                              f32x4 (&acc)[2], f32x4 (&accg)[2], float2* gst, float inv_cg,
-                                              const ConvArgs& ka, int kg0, int kg1, bool& gn_pending) {
+                                              f32x4 (&acc)[2], f32x4 (&accg)[2], const float2* gst, const float2* lnst, float inv_cg) {
     constexpr int NH = TAPS == 3 ? 1 : 0;                  // dilation 1: 2 halo samples per row, one load for lanes q < 2
     const int r = lane >> 2, q = lane & 3;
     const int l15 = lane & 15, kq = lane >> 4;
@@ -88,34 +87,11 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
             if (NH) { const unsigned tc = gh / 4u % (unsigned)Tin; muh = cs[2 * tc]; rsh = cs[2 * tc + 1]; }
         }
     }
+    // LayerNorm statistics from the producer's column sums: reduced once per workgroup (conv_stats.h), read back from LDS here
     auto finish_ln = [&]() {
         if (s.xf != 3) return;
-                // LayerNorm statistics from the producer's column sums (see k_conv.hip)
-        const float* ps = s.xf_a + (size_t)b * s.xf_stride;
-        const int tq = ok0 ? ti : Tin - 4;
-        float s1[4], s2[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-        for (int p0 = r; p0 < s.xf_np; p0 += 16) {
-            const float4* row = reinterpret_cast<const float4*>(ps + (size_t)p0 * Tin * 2);
-            const float4 v0 = row[tq / 2], v1 = row[tq / 2 + 1];
-            s1[0] += v0.x; s2[0] += v0.y; s1[1] += v0.z; s2[1] += v0.w;
-            s1[2] += v1.x; s2[2] += v1.y; s1[3] += v1.z; s2[3] += v1.w;
-        }
-#pragma unroll
-        for (int o = 4; o < 64; o <<= 1) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { s1[i] += __shfl_xor(s1[i], o); s2[i] += __shfl_xor(s2[i], o); }
-        }
-        const double inv = 1.0 / (double)s.C;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {             // E[x^2] - mean^2 in fp64 (cancellation), 1/sqrt in fp32 like torch's LayerNorm
-            const double m = (double)s1[i] * inv;
-            float var = (float)((double)s2[i] * inv - m * m);
-            var = var > 0.f ? var : 0.f;
-            mu[i] = (float)m;
-            rs4[i] = 1.0f / sqrtf(var + s.xf_eps);
-        }
+        for (int i = 0; i < 4; ++i) { const float2 st = lnst[4 * q + i]; mu[i] = st.x; rs4[i] = st.y; }
     };
 
     const int bb = s.bmod > 0 ? b % s.bmod : b;
@@ -131,23 +107,22 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
     float2 gbv = make_float2(1.f, 0.f);
 
     int gbg = 0;
-    auto load_gb = [&](int cr) -> float2 {          // gn4: raw {gamma, beta}; the group statistics are folded in by park() (see k_conv.hip)
+    auto load_gb2 = [&](int cr, int& gg) -> float2 {   // gn4: raw {gamma, beta}; the group statistics are folded in by park() (see k_conv.hip)
         if (gn4) {
             const int c = s.xf_coff + (lo + cr) * CONV_CK + r;
-            gbg = (int)(((float)c + 0.5f) * inv_cg);
+            gg = (int)(((float)c + 0.5f) * inv_cg);
             return reinterpret_cast<const float2*>(s.xf_b)[c];
         }
         return *reinterpret_cast<const float2*>(gb + (size_t)cr * (2 * CONV_CK));
     };
-    auto finish_stats = [&]() {
-        if (gn_pending) { wave_gn_stats(ka, b, lane, kg0, kg1, gst); gn_pending = false; }
-    };
-    auto park = [&](int wofs) {
-        float v[4], vh = xh;
-        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w;
+    auto load_gb = [&](int cr) -> float2 { return load_gb2(cr, gbg); };
+    auto finish_stats = [&]() {};           // the workgroup's statistics tables were completed before the K loop (conv_stats.h)
+    auto park_v = [&](int wofs, const float4& xa, const float xhq, const float2 gbq, const int ggq) {
+        float v[4], vh = xhq;
+        v[0] = xa.x; v[1] = xa.y; v[2] = xa.z; v[3] = xa.w;
         if (xf) {
-            float g = gbv.x, bt = gbv.y;
-            if (gn4) { const float2 st = gst[gbg]; g = gbv.x * st.y; bt = gbv.y - st.x * g; }
+            float g = gbq.x, bt = gbq.y;
+            if (gn4) { const float2 st = gst[ggq]; g = gbq.x * st.y; bt = gbq.y - st.x * g; }
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = (xf == 1) ? v[i] * g + bt : (v[i] - mu[i]) * rs4[i] * g + bt;
             vh = (xf == 1) ? vh * g + bt : (vh - muh) * rsh * g + bt;
@@ -166,6 +141,7 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
         *reinterpret_cast<float4*>(smem_bytes + wofs + l0) = w0;
         if (NH) *reinterpret_cast<float*>(smem_bytes + wofs + lh) = okh ? vh : 0.f;
     };
+    auto park = [&](int wofs) { park_v(wofs, x0, xh, gbv, gbg); };
     auto mfma = [&](int wofs, const float4 (&A)[6], const float4 (&A2)[6]) {
         float bf[TAPS * 4];
 #pragma unroll
@@ -198,57 +174,59 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
         }
     };
 
-    if (PIPE) {            // software-pipelined: chunk c on the matrix pipe, chunk c+1 transformed + parked, chunk c+2 requested
+    if (PIPE) {            // software-pipelined over a register ring of D chunks (see k_conv.hip)
+        constexpr int D = (TAPS == 1 && !DUAL) ? 4 : 2;
         const int nch = hi - lo;
-        auto fetch_x = [&](int cr) {
-            const int cc = cr < nch ? cr : nch - 1;
-            const char* xq = xb + (size_t)cc * xstep;
-            x0 = *reinterpret_cast<const float4*>(xq + g0);
-            if (NH) xh = *reinterpret_cast<const float*>(xq + gh);
-            if (xf) gbv = load_gb(cc);
-        };
-        auto fetch_a = [&](int cr, float4 (&An)[6], float4 (&An2)[6]) {
-            const int cc = cr < nch ? cr : nch - 1;
-            load_a16<TAPS, DUAL>(wp + (size_t)cc * (TAPS * 512), wp2 + (size_t)cc * (TAPS * 512), An, An2);
-        };
-        auto interleave = [&]() {
+        float4 RA[D][6], RA2[D][6];
+        float4 RX0[D];
+        float RXH[D];
+        float2 RGB[D];
+        int RGG[D];
 #pragma unroll
-            for (int i = 0; i < TAPS * 8 * (DUAL ? 2 : 1); ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // VALU of the next chunk's transform / addressing
-            }
+        for (int d = 0; d < D; ++d) { RGB[d] = make_float2(1.f, 0.f); RGG[d] = 0; RXH[d] = 0.f; }
+        auto fetch_x = [&](int cr, int d) {
+            const char* xq = xb + (size_t)cr * xstep;
+            RX0[d] = *reinterpret_cast<const float4*>(xq + g0);
+            if (NH) RXH[d] = *reinterpret_cast<const float*>(xq + gh);
+            if (xf) RGB[d] = load_gb2(cr, RGG[d]);
+        };
+        auto fetch_a = [&](int cr, int d) {
+            load_a16<TAPS, DUAL>(wp + (size_t)cr * (TAPS * 512), wp2 + (size_t)cr * (TAPS * 512), RA[d], RA2[d]);
         };
         constexpr int W1 = WIN_LDS * 4;
-        fetch_a(0, Aa, Aa2);
-        fetch_x(0);
-        finish_stats();
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (d < nch) fetch_x(d, d);
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (d < nch) fetch_a(d, d);
         finish_ln();
-        park(0);
-        fetch_x(1);
-        fetch_a(1, Ab, Ab2);
+        park_v(0, RX0[0], RXH[0], RGB[0], RGG[0]);
+        if (D < nch) fetch_x(D, 0);
         wave_sync();
         TL_STAMP_ONCE(2);
-        for (int c = 0; c < nch; c += 2) {
-            mfma(0, Aa, Aa2);
-            park(W1);
-            fetch_x(c + 2);
-            fetch_a(c + 2, Aa, Aa2);
-            interleave();
-            wave_sync();
-            if (c + 1 >= nch) break;
-            mfma(W1, Ab, Ab2);
-            park(0);
-            fetch_x(c + 3);
-            fetch_a(c + 3, Ab, Ab2);
-            interleave();
-            wave_sync();
+        for (int c = 0; c < nch; c += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int cc = c + d;
+                if (cc < nch) {
+                    const int dn = (d + 1) % D;
+                    mfma((d & 1) * W1, RA[d], RA2[d]);
+                    if (cc + 1 < nch) {
+                        park_v(((d + 1) & 1) * W1, RX0[dn], RXH[dn], RGB[dn], RGG[dn]);
+                        if (cc + 1 + D < nch) fetch_x(cc + 1 + D, dn);
+                    }
+                    if (cc + D < nch) fetch_a(cc + D, d);
+                    wave_sync();
+                }
+            }
         }
         return;
     }
 
-    load_a16<TAPS, DUAL>(wp, wp2, Aa, Aa2);
     x0 = *reinterpret_cast<const float4*>(xb + g0);
     if (NH) xh = *reinterpret_cast<const float*>(xb + gh);
+    load_a16<TAPS, DUAL>(wp, wp2, Aa, Aa2);
     int crel = 0;
     if (xf) gbv = load_gb(0);
     finish_stats();
@@ -281,28 +259,46 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
 }
 
 template <int WK, bool DUAL>
-__global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kernel(const ConvArgs a, int gx, int gy, int gz) {
-    constexpr int RED = WK > 1 ? WK * 8 * 64 : 1;                   // floats for one partial-tile exchange
+__global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kernel(const ConvArgs a) {
+    constexpr int RED = WK > 1 ? WK * 8 * 64 : 0;                   // floats for one partial-tile exchange
     constexpr int WIN = WK * WAVE_LDS;
-    __shared__ __attribute__((aligned(16))) float smem[(DUAL ? 2 * RED : RED) > WIN ? (DUAL ? 2 * RED : RED) : WIN];
+    // staging windows + a partial-tile exchange region of its own (one barrier per combine, see k_conv.hip)
+    __shared__ __attribute__((aligned(16))) float smem[WIN + (DUAL ? 2 * RED : RED) + 4];
+    typedef WgStats<WK, 16> Stats;
+    __shared__ typename Stats::Lds stl;
     TL_BEGIN();
+
+    // ---- kernel arguments of the prologue in one batch (common.h: KARG_PIN)
+    const int gx = a.gx, gy = a.gy, gz = a.gz;
+    KARG_PIN4(gx, gy, gz, a.xcd_cols);
+    KARG_PIN4(a.mgx, a.mgy, a.mgxz, a.nseg);
+    KARG_PIN4(a.gn_groups, a.gn_cg, a.gn_nseg, a.Mout);
+    KARG_PIN4(a.wpk, a.w_mt_stride, a.Tout, a.nchunk);
+    KARG_PIN4(a.seg[0].x, a.seg[0].C, a.seg[0].Tin, a.seg[0].xf);
+    KARG_PIN4(a.seg[0].xf_a, a.seg[0].xf_stride, a.seg[0].bmod, a.seg[0].xf_np);
+    KARG_PIN4(a.bias, a.rowadd, a.resid, a.rowadd_stride);
 
     const int nblk = gx * gy * gz;
     int lid = blockIdx.x;
     if ((nblk & 7) == 0) lid = (lid & 7) * (nblk >> 3) + (lid >> 3);          // XCD-contiguous row tiles (see k_conv.hip)
     int mt, rem;
-    if (a.xcd_cols) { rem = lid / gy; mt = lid - rem * gy; }       // row tile fastest: an XCD's slab is a range of column tiles
-    else { mt = lid / (gx * gz); rem = lid - mt * (gx * gz); }
-    const int b = rem / gx;
+    if (a.xcd_cols) { rem = fastdiv(lid, a.mgy); mt = lid - rem * gy; }       // row tile fastest: an XCD's slab is a range of column tiles
+    else { mt = fastdiv(lid, a.mgxz); rem = lid - mt * (gx * gz); }
+    const int b = fastdiv(rem, a.mgx);
     const int t0 = (rem - b * gx) * 16;
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
 
-    const int per = (a.nchunk + WK - 1) / WK;
-    const int g0 = wave * per;
-    const int g1 = (g0 + per < a.nchunk) ? g0 + per : a.nchunk;
+    // ---- GroupNorm / LayerNorm statistics: partial sums requested now, reduced once per workgroup (conv_stats.h)
+    Stats stats;
+    stats.issue(a, b, t0, tid);
+
+    int g0 = a.kb[0], g1 = a.kb[1];      // this wave's K-slice (cost-balanced on the host: conv_split_k); constant kernarg offsets + selects
+#pragma unroll
+    for (int w = 1; w < WK; ++w)
+        if (wave == w) { g0 = a.kb[w]; g1 = a.kb[w + 1]; }
 
     f32x4 acc[2], accg[2];
 #pragma unroll
@@ -313,10 +309,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
     char* smem_bytes = reinterpret_cast<char*>(smem);
     const int wave_base = wave * WAVE_LDS * 4;
 
-    // ---- GroupNorm of the leading segments from their producers' row sums: this wave's groups only (gn_wave.h)
-    __shared__ float2 gnst[WK][32];
     const float gn_inv_cg = a.gn_groups ? 1.0f / (float)a.gn_cg : 0.f;
-    bool gn_pending = a.gn_groups != 0;
 
     // ---- epilogue operands, issued before the K loop (see k_conv.hip)
     constexpr int EPT = 8 / WK;          // accumulator registers (tile rows) finished by each wave
@@ -346,6 +339,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
 #pragma unroll
         for (int q = 0; q < EPT; ++q) rsv[q] = a.resid[oo[q]];
     }
+    stats.finish(a, b, t0, tid, stl);      // reduce + workgroup barrier(s): the requests went out before the index math above
     TL_STAMP(1);
     TL_SET(10, g1 - g0);
 
@@ -359,7 +353,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
             if (lo < hi) {
                 const float* w1 = wtile + s.woff;
                 const float* w2 = wtile2 + s.woff;
-#define MUGD_SEG16_ARGS s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, acc, accg, gnst[wave], gn_inv_cg, a, g0, g1, gn_pending
+#define MUGD_SEG16_ARGS s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, acc, accg, stl.gnst, stl.lnst, gn_inv_cg
 #define MUGD_SEG16_XF(T)                                                                  \
     switch (s.xf * 4 + s.act) {                                                           \
         case 0: run_segment16<T, DUAL, 0, 0, true>(MUGD_SEG16_ARGS); break;                     \
@@ -380,11 +374,11 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
     TL_STAMP(3);
     float acc_v[EPT], acc_g[EPT];
     if (WK > 1) {
-        __syncthreads();
+        float* ex = smem + WIN;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            smem[(wave * 8 + r) * 64 + lane] = acc[r >> 2][r & 3];
-            if (DUAL) smem[RED + (wave * 8 + r) * 64 + lane] = accg[r >> 2][r & 3];
+            ex[(wave * 8 + r) * 64 + lane] = acc[r >> 2][r & 3];
+            if (DUAL) ex[RED + (wave * 8 + r) * 64 + lane] = accg[r >> 2][r & 3];
         }
         __syncthreads();
 #pragma unroll
@@ -394,8 +388,8 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
             acc_g[q] = 0.f;
 #pragma unroll
             for (int w = 0; w < WK; ++w) {
-                acc_v[q] += smem[(w * 8 + r) * 64 + lane];
-                if (DUAL) acc_g[q] += smem[RED + (w * 8 + r) * 64 + lane];
+                acc_v[q] += ex[(w * 8 + r) * 64 + lane];
+                if (DUAL) acc_g[q] += ex[RED + (w * 8 + r) * 64 + lane];
             }
         }
     } else {
@@ -478,9 +472,11 @@ __global__ void pack_weights16_kernel(const PackArgs p) {
 template <int WK>
 void launch16_wk(hipStream_t st, const ConvArgs& a0, dim3 grid, int gx, int gy, int gz, bool dual) {
     ConvArgs a = a0;
+    conv_split_k(a, WK);
+    conv_set_grid(a, gx, gy, gz);
     a.tl = tl_claim((int)grid.x, WK, 16);
-    if (dual) hipLaunchKernelGGL((conv_gemm16_kernel<WK, true>), grid, dim3(WK * 64), 0, st, a, gx, gy, gz);
-    else hipLaunchKernelGGL((conv_gemm16_kernel<WK, false>), grid, dim3(WK * 64), 0, st, a, gx, gy, gz);
+    if (dual) hipLaunchKernelGGL((conv_gemm16_kernel<WK, true>), grid, dim3(WK * 64), 0, st, a);
+    else hipLaunchKernelGGL((conv_gemm16_kernel<WK, false>), grid, dim3(WK * 64), 0, st, a);
 }
 
 }  // namespace

@@ -76,6 +76,9 @@ struct ConvArgs {
     int xcd_cols;            // workgroup order inside an XCD's slab: 0 = row tile major (a weight tile lives in one L2, every XCD reads
                              // the activations), 1 = row tile fastest (a column tile lives in one L2, every XCD reads the weights);
                              // set per launch by conv_pick_order() to whichever moves fewer bytes
+    int gx, gy, gz;          // grid decomposition (column tiles, row tiles, batch rows), set by the launcher together with the
+    unsigned mgx, mgy, mgxz; // reciprocal multipliers of gx, gy, gx*gz: q = n / d as __umulhi(n, m) for n, d < 65536 (d == 1: q = n)
+    int kb[9];               // K-split: wave w of a workgroup reduces the global chunks [kb[w], kb[w+1]); filled by conv_split_k()
     unsigned long long* tl;  // development build (-DMUGD_TL) only: per-wave phase records [blocks][waves][TL_WORDS]; null otherwise
 };
 
@@ -93,6 +96,32 @@ inline unsigned long long* tl_claim(int nblk, int nwaves, int tn) {
     return p;
 }
 
+// Chunk boundaries of the wk K-slices, balanced by cost: the waves of a workgroup meet at the combine barrier, so a slice made of
+// 3-tap chunks (24 MFMAs + a 6 KiB weight fragment each) must hold fewer chunks than one made of 1x1 chunks (8 MFMAs, 2 KiB).
+// Measured per chunk (profiles/r2_timeline_before_*): ~2750 vs ~1300 cycles on 16-wide tiles, ~4300 vs ~1500 on 32-wide ones.
+inline void conv_split_k(ConvArgs& a, int wk) {
+    long long total = 0;
+    for (int i = 0; i < a.nseg; ++i) total += (long long)(a.seg[i].C / CONV_CK) * (a.seg[i].taps == 3 ? 2 : 1);
+    int w = 1, chunk = 0;
+    long long cum = 0;
+    a.kb[0] = 0;
+    for (int i = 0; i < a.nseg && w < wk; ++i) {
+        const int cost = a.seg[i].taps == 3 ? 2 : 1, n = a.seg[i].C / CONV_CK;
+        for (int c = 0; c < n && w < wk; ++c) {
+            // boundary w sits in front of the first chunk whose start reaches w/wk of the total cost
+            while (w < wk && cum * wk >= total * w) a.kb[w++] = chunk;
+            cum += cost;
+            ++chunk;
+        }
+    }
+    while (w < wk) a.kb[w++] = a.nchunk;
+    for (int i = wk; i <= 8; ++i) a.kb[i] = a.nchunk;
+}
+inline unsigned conv_fastdiv_mul(unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }
+inline void conv_set_grid(ConvArgs& a, int gx, int gy, int gz) {
+    a.gx = gx; a.gy = gy; a.gz = gz;
+    a.mgx = conv_fastdiv_mul((unsigned)gx); a.mgy = conv_fastdiv_mul((unsigned)gy); a.mgxz = conv_fastdiv_mul((unsigned)(gx * gz));
+}
 void launch_conv_gemm(hipStream_t st, const ConvArgs& a);        // 32 x 32 tiles
 int conv_pick_wk(const ConvArgs& a);
 void launch_conv_gemm16(hipStream_t st, const ConvArgs& a);      // 32 x 16 tiles

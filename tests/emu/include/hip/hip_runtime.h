@@ -40,10 +40,12 @@ extern EmuIdx threadIdx, blockIdx, blockDim, gridDim;
 // ---------------------------------------------------------------- vector types
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
+struct double2 { double x, y; };
 struct int2 { int x, y; };
 struct int4 { int x, y, z, w; };
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline double2 make_double2(double x, double y) { return double2{x, y}; }
 
 // ---------------------------------------------------------------- runtime API
 typedef int hipError_t;
@@ -154,6 +156,7 @@ static inline double __hiloint2double(int hi, int lo) {
     uint64_t u = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo; double d; std::memcpy(&d, &u, 8); return d;
 }
 static inline void __threadfence() {}
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * b) >> 32); }
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
