@@ -140,3 +140,47 @@ struct WgStats {
         }
     }
 };
+
+// EPI_XSOFTMAX epilogue (kernels.h): `xs` holds the tile's raw scores [32 key rows][TN query columns] (row stride TN + 1).
+// The NTHR / TN lanes of a column sit in one wave: they split the key rows, reduce max / sum with xor shuffles and write
+// softmax(..) * Cemb for the real keys and zeros for the padding rows (the consumer's K axis is all 32 rows of every head).
+template <int WK, int TN>
+__device__ __forceinline__ void xsoftmax_epilogue(const ConvArgs& a, const float* xs, int head, int b, int t0, int tid) {
+    constexpr int NTHR = WK * 64;
+    constexpr int LPC = NTHR / TN >= 32 ? 32 : NTHR / TN;          // lanes per column (power of two, <= 32 <= wave)
+    constexpr int NR = 32 / LPC;                                   // key rows per lane
+    const int P = a.xs_pmax, ntok = a.xs_ntok;
+    const float sl2 = a.xs_scale * 1.44269504088896340736f;        // softmax in base 2
+    for (int col = tid / LPC; col < TN; col += NTHR / LPC) {       // one pass when NTHR == TN * LPC
+        const int jj = tid % LPC;
+        const int i = t0 + col;                                    // query position
+        float sv[NR], gate[NR];
+        float m = -1e30f;
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const int j = jj + u * LPC;
+            int rel = j - i;
+            rel = rel < -P ? -P : (rel > P ? P : rel);
+            const bool ok = j < ntok;
+            const float r0 = ok ? a.xs_rel[(size_t)(rel + P) * a.xs_heads + head] : 0.f;
+            gate[u] = ok ? a.xs_cemb[(size_t)(rel + P) * a.xs_heads + head] : 0.f;
+            sv[u] = ok ? (xs[j * (TN + 1) + col] + r0) * sl2 : -1e30f;
+            m = fmaxf(m, sv[u]);
+        }
+#pragma unroll
+        for (int o = 1; o < LPC; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float l = 0.f;
+#pragma unroll
+        for (int u = 0; u < NR; ++u) { sv[u] = __builtin_amdgcn_exp2f(sv[u] - m); l += sv[u]; }      // padding rows: 2^(-1e30 - m) = 0
+#pragma unroll
+        for (int o = 1; o < LPC; o <<= 1) l += __shfl_xor(l, o);
+        const float inv = 1.0f / l;
+        if (i < a.Tout) {
+#pragma unroll
+            for (int u = 0; u < NR; ++u) {
+                const int j = jj + u * LPC;
+                a.y[((size_t)b * a.Mout + head * 32 + j) * a.Tout + i] = sv[u] * inv * gate[u];
+            }
+        }
+    }
+}

@@ -472,7 +472,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; }
 
-    const float* wtile = a.wpk + (size_t)mt * a.w_mt_stride + lane * 4;
+    const float* wtile = a.wpk + (size_t)b * a.w_b_stride + (size_t)mt * a.w_mt_stride + lane * 4;
     const float* wtile2 = DUAL ? wtile + (size_t)(a.Mout >> 5) * a.w_mt_stride : wtile;
     char* smem_bytes = reinterpret_cast<char*>(smem);
     const int wave_base = wave * WAVE_LDS * 4;
@@ -584,6 +584,20 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
         for (int q = 0; q < EPT; ++q) { acc_v[q] = acc[q]; acc_g[q] = acc2[q]; }
     }
     TL_STAMP(4);
+    if (!DUAL && a.epi == EPI_XSOFTMAX) {          // folded cross-attention: the tile is one head's key scores (conv_stats.h)
+        __shared__ float xs[32 * (CONV_TN + 1)];
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int r = wave * EPT + q;
+            xs[((r & 3) + 8 * (r >> 2) + 4 * h) * (CONV_TN + 1) + n] = acc_v[q];
+        }
+        __syncthreads();
+        xsoftmax_epilogue<WK, CONV_TN>(a, xs, mt, b, t0, tid);
+        TL_STAMP(5);
+        TL_STAMP(6);
+        TL_END(a.tl, WK);
+        return;
+    }
     if (!PRELOAD) load_side();
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
@@ -721,7 +735,10 @@ void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
     if (nitg > 9)
         for (int i = 0; i < a.nseg; ++i) MUGD_CHECK(a.seg[i].xf == 0, -2, "conv_gemm: no operand transform in a kernel with a strided / widely dilated generic segment");
     const int kind = all_vec ? (lean ? 0 : 1) : 2;
-    const bool dual = a.epi != EPI_NONE;
+    const bool dual = a.epi == EPI_GLU || a.epi == EPI_GEGLU;
+    if (a.epi == EPI_XSOFTMAX)
+        MUGD_CHECK(a.xs_rel && a.xs_cemb && a.xs_heads > 0 && a.Mout == 32 * a.xs_heads && a.xs_ntok >= 1 && a.xs_ntok <= 32 && !a.rowstat && !a.colstat &&
+                       a.nseg == 1 && a.seg[0].taps == 1, -2, "conv_gemm: bad cross-attention score epilogue");
     MUGD_CHECK((!a.colstat && !a.rowstat) || !dual, -2, "conv_gemm: row / column sums are not produced by gated epilogues");
     if (dual) {
         MUGD_CHECK(a.Mout % 32 == 0 && a.Mrows == 2 * a.Mout, -2, "conv_gemm: gated epilogue needs Mout % 32 == 0");

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
 #pragma unroll
     for (int i = 0; i < 4; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; accg[0][i] = 0.f; accg[1][i] = 0.f; }
 
-    const float* wtile = a.wpk + (size_t)mt * a.w_mt_stride + lane * 4;
+    const float* wtile = a.wpk + (size_t)b * a.w_b_stride + (size_t)mt * a.w_mt_stride + lane * 4;
     const float* wtile2 = DUAL ? wtile + (size_t)(a.Mout >> 5) * a.w_mt_stride : wtile;
     char* smem_bytes = reinterpret_cast<char*>(smem);
     const int wave_base = wave * WAVE_LDS * 4;
@@ -397,6 +397,20 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
         for (int q = 0; q < EPT; ++q) { acc_v[q] = acc[q >> 2][q & 3]; acc_g[q] = accg[q >> 2][q & 3]; }
     }
     TL_STAMP(4);
+    if (!DUAL && a.epi == EPI_XSOFTMAX) {          // folded cross-attention: the tile is one head's key scores (conv_stats.h)
+        __shared__ float xs[32 * 17];
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int r = wave * EPT + q;
+            xs[(16 * (r >> 2) + 4 * kq + (r & 3)) * 17 + l15] = acc_v[q];
+        }
+        __syncthreads();
+        xsoftmax_epilogue<WK, 16>(a, xs, mt, b, t0, tid);
+        TL_STAMP(5);
+        TL_STAMP(6);
+        TL_END(a.tl, WK);
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
         float v = acc_v[q] + bv[q];
@@ -529,7 +543,10 @@ void launch_conv_gemm16(hipStream_t st, const ConvArgs& a) {
         MUGD_CHECK(s.xf != 4 || (i < a.gn_nseg && a.gn_groups > 0 && a.gn_groups <= 32 && a.gn_cg > 0), -2, "conv_gemm16: bad GroupNorm domain");
         MUGD_CHECK(s.xf != 3 || (s.taps == 1 && s.xf_np > 0), -2, "conv_gemm16: LayerNorm from producer sums needs a 1x1 segment");
     }
-    const bool dual = a.epi != EPI_NONE;
+    const bool dual = a.epi == EPI_GLU || a.epi == EPI_GEGLU;
+    if (a.epi == EPI_XSOFTMAX)
+        MUGD_CHECK(a.xs_rel && a.xs_cemb && a.xs_heads > 0 && a.Mout == 32 * a.xs_heads && a.xs_ntok >= 1 && a.xs_ntok <= 32 && !a.rowstat && !a.colstat &&
+                       a.nseg == 1 && a.seg[0].taps == 1, -2, "conv_gemm: bad cross-attention score epilogue");
     MUGD_CHECK((!a.colstat && !a.rowstat) || !dual, -2, "conv_gemm16: row / column sums are not produced by gated epilogues");
     if (dual) MUGD_CHECK(a.Mout % 32 == 0 && a.Mrows == 2 * a.Mout, -2, "conv_gemm16: gated epilogue needs Mout % 32 == 0");
     else MUGD_CHECK(a.Mrows == a.Mout, -2, "conv_gemm16: Mrows != Mout");

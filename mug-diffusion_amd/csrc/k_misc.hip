@@ -1,6 +1,8 @@
 // Small kernels around the U-Net: timestep embedding + its MLP (GEMV class), the per-step kernel (classifier-free-guidance
 // combine + DDIM update + next input + next time-embedding rows + device-side step counter, which lets one captured graph be
 // replayed for every DDIM step) and the prompt-token gather.
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace {
@@ -106,7 +108,37 @@ __global__ void bias_sum_kernel(const float* x, const float* y, float* out, int 
     if (i < n) out[i] = (x ? x[i] : 0.f) + (y ? y[i] : 0.f);
 }
 
+// see kernels.h: XattnFoldArgs.  One thread per output element; the d-long sums are tiny and run once per sampling call.
+__global__ void xattn_fold_kernel(const XattnFoldArgs a) {
+    const int C = a.C, R = a.heads * 32;
+    const long long nG = (long long)a.B * R * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * nG; i += (long long)gridDim.x * blockDim.x) {
+        const bool isU = i >= nG;
+        const long long e = isU ? i - nG : i;
+        int b, row, c;
+        if (!isU) { c = (int)(e % C); row = (int)((e / C) % R); b = (int)(e / ((long long)C * R)); }       // G[b][row][c]
+        else { row = (int)(e % R); c = (int)((e / R) % C); b = (int)(e / ((long long)C * R)); }            // U[b][c][row]
+        const int h = row >> 5, j = row & 31;
+        double acc = 0.0;
+        if (j < a.ntok) {
+            const float* kvb = a.kv + (size_t)b * 2 * C * a.ntok + (isU ? (size_t)C * a.ntok : 0);
+            for (int dd = 0; dd < a.d; ++dd) {
+                const int ch = h * a.d + dd;
+                const float w = isU ? a.wo[(size_t)c * C + ch] : a.wq[(size_t)ch * C + c];
+                acc += (double)w * (double)kvb[(size_t)ch * a.ntok + j];
+            }
+        }
+        (isU ? a.U : a.G)[e] = (float)acc;
+    }
+}
+
 }  // namespace
+
+void launch_xattn_fold(hipStream_t st, const XattnFoldArgs& a) {
+    const long long total = 2ll * a.B * a.heads * 32 * a.C;
+    int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(xattn_fold_kernel, dim3(blocks), dim3(256), 0, st, a);
+}
 
 void launch_timestep_embedding(hipStream_t st, const long long* t, const int* step_idx, float* out, int B, int dim) {
     const int n = B * (dim / 2);

@@ -50,13 +50,17 @@ struct ConvSeg {
     int xf_coff;          // xf=4: first channel of this segment inside the normalised concat
 };
 
-enum { EPI_NONE = 0, EPI_GLU = 1, EPI_GEGLU = 2 };
+// EPI_XSOFTMAX: the tile's 32 rows are the key scores of ONE attention head for the tile's query columns (row j < xs_ntok = key
+// j, the rest padding): (dot + Rel[clamp(j - i)]) * scale -> softmax over the keys -> * Cemb[clamp(j - i)]  (attention.py:103-123).
+// Used by the folded cross-attention (net.hip: transformer()), whose key / value sides are step-invariant.
+enum { EPI_NONE = 0, EPI_GLU = 1, EPI_GEGLU = 2, EPI_XSOFTMAX = 3 };
 
 struct ConvArgs {
     ConvSeg seg[CONV_MAXSEG];
     int nseg;
     const float* wpk;        // packed weights [MT][w_mt_stride]
     long long w_mt_stride;   // floats per 32-row tile
+    long long w_b_stride;    // floats between the weight sets of consecutive batch rows (0: one set for all -- every layer but the folded cross-attention)
     const float* bias;       // [Mrows] or null
     const float* rowadd;     // [B][rowadd_stride] or null: added per (b, m) after gating
     int rowadd_stride;
@@ -78,6 +82,9 @@ struct ConvArgs {
                              // set per launch by conv_pick_order() to whichever moves fewer bytes
     int gx, gy, gz;          // grid decomposition (column tiles, row tiles, batch rows), set by the launcher together with the
     unsigned mgx, mgy, mgxz; // reciprocal multipliers of gx, gy, gx*gz: q = n / d as __umulhi(n, m) for n, d < 65536 (d == 1: q = n)
+    // EPI_XSOFTMAX: relative-position tables (2 pmax + 1, heads), head = row tile, keys, softmax scale
+    const float* xs_rel; const float* xs_cemb;
+    int xs_heads, xs_pmax, xs_ntok; float xs_scale;
     int kb[9];               // K-split: wave w of a workgroup reduces the global chunks [kb[w], kb[w+1]); filled by conv_split_k()
     unsigned long long* tl;  // development build (-DMUGD_TL) only: per-wave phase records [blocks][waves][TL_WORDS]; null otherwise
 };
@@ -264,6 +271,15 @@ struct TimingSweepArgs {
 void launch_timing_sweep(hipStream_t st, const TimingSweepArgs& a);
 void remove_mini_jacks_host(int n, const double* start_ms, const int* column, const double* end_ms, double jack_interval,
                             int column_width, int* new_x, unsigned char* keep);
+
+// Folded cross-attention (net.hip: transformer()): with the key / value side fixed for a whole sampling call,
+//   q_i . k_j = LN(x)_i . (Wq_h^T k_j)        and        to_out(sum_j p_ij v_j) = sum_j p_ij (Wo_h v_j),
+// so per batch row b the query projection and the output projection collapse into two small weight sets
+//   G[b][32 h + j][c] = sum_dd Wq[h d + dd][c] K[b][h d + dd][j]        (score rows: 32 per head, rows >= ntok are zero)
+//   U[b][c][32 h + j] = sum_dd Wo[c][h d + dd] V[b][h d + dd][j]
+// computed once per call (fp64 accumulation, rounded to fp32 once).  kv: (B, 2 C, ntok) = [K ; V].
+struct XattnFoldArgs { const float* wq; const float* wo; const float* kv; float* G; float* U; int B, C, heads, d, ntok; };
+void launch_xattn_fold(hipStream_t st, const XattnFoldArgs& a);
 
 void launch_embed_tokens(hipStream_t st, const float* table, const long long* ids, float* out, int B, int ntok, int dim);
 void launch_bias_sum(hipStream_t st, const float* a, const float* b, float* out, int n);

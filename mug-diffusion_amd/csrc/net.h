@@ -42,6 +42,7 @@ struct Ctx {
     int force_wk = 0, force_tn = 0;   // mugd_set_conv_tiling: 0 = pick per layer
     bool fast_act = true;       // SiLU of the fused GroupNorm path on v_exp_f32 / v_rcp_f32 (MUGD_EXACT_SILU=1: expf + IEEE divide)
     bool fuse_stats = true;     // false (MUGD_NO_STATS_FUSION=1): always run the GroupNorm / LayerNorm statistics kernels
+    bool fold_xattn = true;     // false (MUGD_NO_XATTN_FOLD=1): cross-attention as to_q -> attention kernel -> to_out instead of the folded two-GEMM form
     bool fuse_norm = true;      // false (MUGD_UNFUSED_NORM=1): materialise GroupNorm / LayerNorm outputs with the stand-alone kernels (A/B + debugging)
 };
 
@@ -78,6 +79,12 @@ struct ConvSpec {
     bool want_colstat = false;    // also emit the per-column sums a following LayerNorm needs (returned in Tensor::colstat)
     bool want_rowstat = false;    // also accumulate the per-row sums a following GroupNorm needs (returned in Tensor::rowstat)
     GnDomain gn;                  // set by gn_inputs when the leading inputs are normalised from their producers' row sums
+    // weights that are NOT parameters but derived per call and per batch row (folded cross-attention): the caller owns `ext_plain`
+    // (B, Mrows, K) row-major, refreshed by a pre-op; conv() allocates the packed copy, emits the per-call packing and returns
+    // nothing else differently.  One input segment, 1x1.
+    const float* ext_plain = nullptr;
+    // EPI_XSOFTMAX parameters (kernels.h)
+    const float* xs_rel = nullptr; const float* xs_cemb = nullptr; int xs_heads = 0, xs_pmax = 0, xs_ntok = 0; float xs_scale = 0.f;
 };
 
 struct PackedW {
@@ -170,6 +177,7 @@ protected:
     const float* s4_kernel(const std::string& prefix, int H, int L);
     Tensor s4_layer(const std::string& prefix, const Tensor& x);
     const PackedW& get_packed(const ConvSpec& s, int tn);
+    const PackedW& get_packed_ext(const ConvSpec& s, int tn);
 };
 
 // ---------------------------------------------------------------------------------------

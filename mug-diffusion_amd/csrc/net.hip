@@ -379,6 +379,47 @@ const PackedW& Net::get_packed(const ConvSpec& s, int tn) {
     return packed[pkey] = pw;
 }
 
+// Per-call, per-batch-row weights (ConvSpec::ext_plain): the packed copy is library-owned and re-filled by a pre-op on every call.
+const PackedW& Net::get_packed_ext(const ConvSpec& s, int tn) {
+    MUGD_CHECK(s.in.size() == 1 && s.in[0].taps == 1, -2, "conv: external weights need a single 1x1 input at " + s.key);
+    const std::string pkey = s.key + "#ext" + std::to_string(Bn) + (tn == 16 ? "#16" : "");
+    auto it = packed.find(pkey);
+    if (it == packed.end()) {
+        PackedW pw;
+        const int K = s.in[0].x.C;
+        MUGD_CHECK(K % CONV_CK == 0, -2, "conv: channel count not a multiple of 16 at " + s.key);
+        pw.chunk0 = {0}; pw.woff = {0};
+        pw.nchunk = K / CONV_CK;
+        pw.mt_stride = (long long)pw.nchunk * 512;
+        pw.wpk = dev_alloc((size_t)Bn * cdiv(s.Mrows, 32) * pw.mt_stride, true);
+        if (!s.bias.empty()) {
+            pw.bias = dev_alloc(s.Mrows, true);
+            for (auto& b : s.bias) {
+                const Param& p = P(b.first);
+                MUGD_CHECK(b.second + p.numel() <= s.Mrows, -2, "conv: bias out of range: " + b.first);
+                launch_bias_sum(ctx->stream, pw.bias + b.second, (const float*)p.ptr, pw.bias + b.second, (int)p.numel());
+            }
+        }
+        it = packed.emplace(pkey, pw).first;
+    }
+    const PackedW& pw = it->second;
+    {   // per call: (re)pack every batch row's weight set
+        const int K = s.in[0].x.C, M = s.Mrows, B = Bn;
+        const float* src = s.ext_plain; float* dst = pw.wpk; const long long mts = pw.mt_stride;
+        const long long bstride = (long long)cdiv(M, 32) * mts;
+        const bool save = to_pre;
+        to_pre = true;
+        emit([=](hipStream_t st) {
+            for (int b = 0; b < B; ++b) {
+                PackArgs pa{dst + (size_t)b * bstride, mts, 0, K, 1, src + (size_t)b * M * K, K, 0, M, 0};
+                if (tn == 16) launch_pack_weights16(st, pa); else launch_pack_weights(st, pa);
+            }
+        }, OP_SMALL, 0, s.key + " pack per-call weights");
+        to_pre = save;
+    }
+    return pw;
+}
+
 Tensor Net::conv(const ConvSpec& s) {
     MUGD_CHECK(!s.in.empty() && (int)s.in.size() <= CONV_MAXSEG, -2, "conv: bad segment count at " + s.key);
     Tensor y = s.out.p ? s.out : talloc(s.Mout, s.Tout);
@@ -393,9 +434,11 @@ Tensor Net::conv(const ConvSpec& s) {
     a.B = Bn; a.Mrows = s.Mrows; a.Mout = s.Mout; a.Tout = s.Tout; a.epi = s.epi;
     a.wk = ctx->force_wk;
     a.tn = ctx->force_tn == 16 ? (conv16_supported(a) ? 16 : 32) : ctx->force_tn == 32 ? 32 : conv_pick_tn(a);
-    const PackedW& pw = get_packed(s, a.tn);       // the tile width decides the weight fragment order
+    a.xs_rel = s.xs_rel; a.xs_cemb = s.xs_cemb; a.xs_heads = s.xs_heads; a.xs_pmax = s.xs_pmax; a.xs_ntok = s.xs_ntok; a.xs_scale = s.xs_scale;
+    const PackedW& pw = s.ext_plain ? get_packed_ext(s, a.tn) : get_packed(s, a.tn);       // the tile width decides the weight fragment order
     for (int i = 0; i < a.nseg; ++i) { a.seg[i].chunk0 = pw.chunk0[i]; a.seg[i].woff = pw.woff[i]; }
     a.wpk = pw.wpk; a.w_mt_stride = pw.mt_stride; a.bias = pw.bias;
+    a.w_b_stride = s.ext_plain ? (long long)cdiv(s.Mrows, 32) * pw.mt_stride : 0;
     a.rowadd = s.rowadd; a.rowadd_stride = s.rowadd_stride;
     a.resid = s.resid.p;
     if (s.resid.p) MUGD_CHECK(s.resid.C == s.Mout && s.resid.T == s.Tout && s.resid.bmod == 0, -2, "conv: residual shape mismatch at " + s.key);
@@ -415,7 +458,7 @@ Tensor Net::conv(const ConvSpec& s) {
     }
     double kdim = 0;
     for (auto& in : s.in) kdim += (double)in.x.C * in.taps;
-    emit([a](hipStream_t st) { launch_conv(st, a); }, s.epi ? OP_CONV_GATED : OP_CONV, 2.0 * s.Mrows * kdim * s.Tout * Bn,
+    emit([a](hipStream_t st) { launch_conv(st, a); }, (s.epi == EPI_GLU || s.epi == EPI_GEGLU) ? OP_CONV_GATED : OP_CONV, 2.0 * s.Mrows * kdim * s.Tout * Bn,
          s.key + " M=" + std::to_string(s.Mrows) + " K=" + std::to_string((long long)kdim) + " T=" + std::to_string(s.Tout) +
              " nseg=" + std::to_string(a.nseg) + " tn=" + std::to_string(a.tn));
     return y;
@@ -509,14 +552,53 @@ Tensor Net::transformer(const std::string& prefix, const Tensor& x, const Tensor
     Tensor a1 = self_attn(b + ".attn1", ln_input(b + ".norm1", h0));
     Tensor h1 = lin(b + ".attn1.to_out.0", ConvIn{a1}, true, h0, Tensor(), true);
     const ConvIn n2 = ln_input(b + ".norm2", h1);
-    Tensor a2;
-    if (context) {
-        Tensor q2 = lin(b + ".attn2.to_q", n2, false, Tensor(), Tensor());
-        a2 = attention(b + ".attn2", q2, kv, kv, C, heads, 0, 0, C);
+    Tensor a2, h2;
+    const bool fold = context && ctx->fold_xattn && context->T <= 32 && C % heads == 0 &&
+                      P(b + ".attn2.to_q.weight").numel() == (long long)C * C && P(b + ".attn2.to_out.0.weight").numel() == (long long)C * C;
+    if (fold) {
+        // Folded cross-attention (kernels.h: XattnFoldArgs, EPI_XSOFTMAX): the key / value side is fixed for the whole call, so
+        // to_q and to_out collapse into per-batch-row weight sets G (32 heads x C) and U (C x 32 heads), refreshed by a pre-op:
+        //   P = softmax_j((G LN(h1) + Rel) scale) * Cemb      one conv_gemm launch, M = 32 per head
+        //   h2 = U P + bias + h1                              one conv_gemm launch, K = 32 per head
+        // instead of to_q -> attention kernel -> to_out (3 launches; at C = 512 also half the multiply-adds).
+        const int R = 32 * heads, ntok = context->T;
+        const std::string gk = b + ".attn2.fold#" + std::to_string(Bn) + "x" + std::to_string(ntok);
+        auto it = baked.find(gk);
+        float* GU = it != baked.end() ? it->second : (baked[gk] = dev_alloc((size_t)Bn * R * C * 2));
+        float* G = GU; float* U = GU + (size_t)Bn * R * C;
+        {
+            XattnFoldArgs fa{PF(b + ".attn2.to_q.weight"), PF(b + ".attn2.to_out.0.weight"), kv.p, G, U, Bn, C, heads, C / heads, ntok};
+            to_pre = true;
+            emit([fa](hipStream_t st) { launch_xattn_fold(st, fa); }, OP_SMALL, 0, b + ".attn2 fold K/V into the projections");
+            to_pre = false;
+        }
+        const Param& rel = P(b + ".attn2.relative_position_embedding");
+        MUGD_CHECK((int)rel.shape[1] == heads, -2, "attention: head count mismatch at " + b + ".attn2");
+        ConvSpec sc;
+        sc.key = b + ".attn2.scores";
+        sc.in = {n2};
+        sc.ext_plain = G;
+        sc.Mrows = sc.Mout = R; sc.Tout = T; sc.epi = EPI_XSOFTMAX;
+        sc.xs_rel = (const float*)rel.ptr; sc.xs_cemb = PF(b + ".attn2.C_embedding");
+        sc.xs_heads = heads; sc.xs_pmax = (int)(rel.shape[0] - 1) / 2; sc.xs_ntok = ntok;
+        sc.xs_scale = 1.0f / sqrtf((float)(C / heads));
+        Tensor pc = conv(sc);
+        ConvSpec so;
+        so.key = b + ".attn2.to_out.0";
+        so.in = {ConvIn{pc}};
+        so.ext_plain = U;
+        so.bias = {{so.key + ".bias", 0}};
+        so.Mrows = so.Mout = C; so.Tout = T; so.resid = h1; so.want_colstat = true;
+        h2 = conv(so);
     } else {
-        a2 = self_attn(b + ".attn2", n2);
+        if (context) {
+            Tensor q2 = lin(b + ".attn2.to_q", n2, false, Tensor(), Tensor());
+            a2 = attention(b + ".attn2", q2, kv, kv, C, heads, 0, 0, C);
+        } else {
+            a2 = self_attn(b + ".attn2", n2);
+        }
+        h2 = lin(b + ".attn2.to_out.0", ConvIn{a2}, true, h1, Tensor(), true);
     }
-    Tensor h2 = lin(b + ".attn2.to_out.0", ConvIn{a2}, true, h1, Tensor(), true);
     Tensor f;
     {
         ConvSpec ff;

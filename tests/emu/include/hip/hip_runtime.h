@@ -156,6 +156,7 @@ static inline double __hiloint2double(int hi, int lo) {
     uint64_t u = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo; double d; std::memcpy(&d, &u, 8); return d;
 }
 static inline void __threadfence() {}
+static inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * b) >> 32); }
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
