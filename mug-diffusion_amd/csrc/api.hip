@@ -82,6 +82,8 @@ int mugd_create(int device, void* stream, mugd_ctx** out) {
         ctx->c.fuse_stats = !(ns && ns[0] == '1');
         const char* xf = getenv("MUGD_NO_XATTN_FOLD");
         ctx->c.fold_xattn = !(xf && xf[0] == '1');
+        const char* pf = getenv("MUGD_NO_PROJ_FOLD");
+        ctx->c.fold_proj_out = !(pf && pf[0] == '1');
         const char* fa = getenv("MUGD_EXACT_SILU");            // default: SiLU of the fused GroupNorm path on v_exp_f32 / v_rcp_f32
         ctx->c.fast_act = !(fa && fa[0] == '1');
     });

@@ -108,6 +108,16 @@ __global__ void bias_sum_kernel(const float* x, const float* y, float* out, int 
     if (i < n) out[i] = (x ? x[i] : 0.f) + (y ? y[i] : 0.f);
 }
 
+__global__ void derive_matmul_kernel(const DeriveMatmulArgs a) {
+    const long long total = (long long)a.M * a.N;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % a.N), m = (int)(i / a.N);
+        double acc = a.add ? (double)a.add[(size_t)m * a.add_ld + n] : 0.0;
+        for (int k = 0; k < a.K; ++k) acc += (double)a.A[(size_t)m * a.lda + k] * (double)a.B[(size_t)k * a.ldb + n];
+        a.C[(size_t)m * a.ldc + n] = (float)acc;
+    }
+}
+
 // see kernels.h: XattnFoldArgs.  One thread per output element; the d-long sums are tiny and run once per sampling call.
 __global__ void xattn_fold_kernel(const XattnFoldArgs a) {
     const int C = a.C, R = a.heads * 32;
@@ -133,6 +143,12 @@ __global__ void xattn_fold_kernel(const XattnFoldArgs a) {
 }
 
 }  // namespace
+
+void launch_derive_matmul(hipStream_t st, const DeriveMatmulArgs& a) {
+    const long long total = (long long)a.M * a.N;
+    int blocks = (int)std::min<long long>((total + 255) / 256, 16384);
+    hipLaunchKernelGGL(derive_matmul_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, a);
+}
 
 void launch_xattn_fold(hipStream_t st, const XattnFoldArgs& a) {
     const long long total = 2ll * a.B * a.heads * 32 * a.C;

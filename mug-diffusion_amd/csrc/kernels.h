@@ -281,5 +281,10 @@ void remove_mini_jacks_host(int n, const double* start_ms, const int* column, co
 struct XattnFoldArgs { const float* wq; const float* wo; const float* kv; float* G; float* U; int B, C, heads, d, ntok; };
 void launch_xattn_fold(hipStream_t st, const XattnFoldArgs& a);
 
+// C[m][n] = (add ? add[m * add_ld + n] : 0) + sum_k A[m][k] B[k][n], fp64 accumulation, rounded to fp32 once: derived weights
+// (products of two layers' matrices, computed once when the parameters are set).  Row-major with leading dimensions.
+struct DeriveMatmulArgs { const float* A; int lda; const float* B; int ldb; const float* add; int add_ld; float* C; int ldc; int M, N, K; };
+void launch_derive_matmul(hipStream_t st, const DeriveMatmulArgs& a);
+
 void launch_embed_tokens(hipStream_t st, const float* table, const long long* ids, float* out, int B, int ntok, int dim);
 void launch_bias_sum(hipStream_t st, const float* a, const float* b, float* out, int n);

@@ -42,6 +42,7 @@ struct Ctx {
     int force_wk = 0, force_tn = 0;   // mugd_set_conv_tiling: 0 = pick per layer
     bool fast_act = true;       // SiLU of the fused GroupNorm path on v_exp_f32 / v_rcp_f32 (MUGD_EXACT_SILU=1: expf + IEEE divide)
     bool fuse_stats = true;     // false (MUGD_NO_STATS_FUSION=1): always run the GroupNorm / LayerNorm statistics kernels
+    bool fold_proj_out = true;  // false (MUGD_NO_PROJ_FOLD=1): ff.net.2 and the transformer's proj_out as two launches instead of one with pre-multiplied weights
     bool fold_xattn = true;     // false (MUGD_NO_XATTN_FOLD=1): cross-attention as to_q -> attention kernel -> to_out instead of the folded two-GEMM form
     bool fuse_norm = true;      // false (MUGD_UNFUSED_NORM=1): materialise GroupNorm / LayerNorm outputs with the stand-alone kernels (A/B + debugging)
 };
@@ -124,6 +125,7 @@ protected:
     std::map<std::string, Param> params;
     std::map<std::string, PackedW> packed;
     std::map<std::string, float*> baked;          // S4 kernels and other derived device tensors
+    std::map<std::string, Param> derived;         // derived weight tensors (products of two layers' matrices), looked up like parameters; dropped by invalidate()
     std::vector<void*> owned;
     Arena arena;
     std::vector<Op> ops;                          // the per-call (per DDIM step) program
@@ -134,6 +136,9 @@ protected:
     int Bn = 0;                                   // batch the program is compiled for
 
     bool has(const std::string& n) const { return params.count(n) != 0; }
+    // name of the derived tensor W = A B (+ bias form: name of A b + c), computed on first use
+    std::string derive_product(const std::string& a_name, const std::string& b_name);
+    std::string derive_bias(const std::string& a_name, const std::string& b_name, const std::string& c_name);
     const Param& P(const std::string& n) const;
     const float* PF(const std::string& n) const { return (const float*)P(n).ptr; }
     float* dev_alloc(size_t nfloats, bool zero = false);

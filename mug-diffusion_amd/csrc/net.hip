@@ -154,6 +154,7 @@ void Net::invalidate() {
     owned.clear();
     packed.clear();
     baked.clear();
+    derived.clear();
     rs_base = nullptr; rs_cap = 0; rs_top = 0;
     ops.clear();
     pre_ops.clear();
@@ -162,8 +163,43 @@ void Net::invalidate() {
 
 const Param& Net::P(const std::string& n) const {
     auto it = params.find(n);
-    MUGD_CHECK(it != params.end(), -5, "missing parameter: " + n);
+    if (it == params.end()) {
+        it = derived.find(n);
+        MUGD_CHECK(it != derived.end(), -5, "missing parameter: " + n);
+    }
     return it->second;
+}
+
+// W = A B for two weight matrices (trailing unit kernel-width axes ignored): A (M, K), B (K, N) -> (M, N)
+std::string Net::derive_product(const std::string& a_name, const std::string& b_name) {
+    const std::string key = a_name + "*" + b_name;
+    if (derived.count(key)) return key;
+    const Param& A = P(a_name);
+    const Param& B = P(b_name);
+    MUGD_CHECK(A.dtype == 0 && B.dtype == 0 && A.shape.size() >= 2 && B.shape.size() >= 2, -2, "derive_product: bad operands " + key);
+    const int M = (int)A.shape[0], K = (int)(A.numel() / A.shape[0]), N = (int)(B.numel() / B.shape[0]);
+    MUGD_CHECK((int)B.shape[0] == K, -2, "derive_product: inner dimensions differ for " + key);
+    float* C = dev_alloc((size_t)M * N);
+    launch_derive_matmul(ctx->stream, DeriveMatmulArgs{(const float*)A.ptr, K, (const float*)B.ptr, N, nullptr, 0, C, N, M, N, K});
+    Param p; p.ptr = C; p.dtype = 0; p.shape = {M, N};
+    derived[key] = p;
+    return key;
+}
+
+// A b + c for a weight matrix A (M, K) and two bias vectors
+std::string Net::derive_bias(const std::string& a_name, const std::string& b_name, const std::string& c_name) {
+    const std::string key = a_name + "*" + b_name + "+" + c_name;
+    if (derived.count(key)) return key;
+    const Param& A = P(a_name);
+    const Param& b = P(b_name);
+    const Param& c = P(c_name);
+    const int M = (int)A.shape[0], K = (int)(A.numel() / A.shape[0]);
+    MUGD_CHECK((int)b.numel() == K && (int)c.numel() == M, -2, "derive_bias: shape mismatch for " + key);
+    float* out = dev_alloc(M);
+    launch_derive_matmul(ctx->stream, DeriveMatmulArgs{(const float*)A.ptr, K, (const float*)b.ptr, 1, (const float*)c.ptr, 1, out, 1, M, 1, K});
+    Param p; p.ptr = out; p.dtype = 0; p.shape = {M};
+    derived[key] = p;
+    return key;
 }
 
 float* Net::dev_alloc(size_t nfloats, bool zero) {
@@ -610,8 +646,20 @@ Tensor Net::transformer(const std::string& prefix, const Tensor& x, const Tensor
         ff.Mout = ff.Mrows / 2; ff.Tout = T; ff.epi = EPI_GEGLU;
         f = conv(ff);
     }
-    Tensor h3 = lin(b + ".ff.net.2", ConvIn{f}, true, h2, Tensor());
-    out = lin(prefix + ".proj_out", ConvIn{h3}, true, x, out, false, true);
+    if (ctx->fold_proj_out) {
+        // out = x + Wp (h2 + W2 f + b2) + bp = x + (Wp W2) f + Wp h2 + (Wp b2 + bp): ONE launch over the K-segments [f | h2] with the
+        // product matrix computed once (fp64 accumulation) when the parameters are packed, instead of ff.net.2 and proj_out
+        ConvSpec s;
+        s.key = prefix + ".proj_out*ff.net.2";
+        s.in = {ConvIn{f}, ConvIn{h2}};
+        s.w = {WBlock{derive_product(prefix + ".proj_out.weight", b + ".ff.net.2.weight"), 0, 0, 0}, WBlock{prefix + ".proj_out.weight", 1, 0, 0}};
+        s.bias = {{derive_bias(prefix + ".proj_out.weight", b + ".ff.net.2.bias", prefix + ".proj_out.bias"), 0}};
+        s.Mrows = s.Mout = C; s.Tout = T; s.resid = x; s.out = out; s.want_rowstat = true;
+        out = conv(s);
+    } else {
+        Tensor h3 = lin(b + ".ff.net.2", ConvIn{f}, true, h2, Tensor());
+        out = lin(prefix + ".proj_out", ConvIn{h3}, true, x, out, false, true);
+    }
     arena.release(mk);
     return out;
 }
