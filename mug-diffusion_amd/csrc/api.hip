@@ -480,7 +480,7 @@ int mugd_op_s4_kernel(mugd_ctx* ctx, const float* C, const float* Bp, const floa
 
 int mugd_op_s4_conv(mugd_ctx* ctx, const float* u, const float* k, const float* D, float* y, int B, int H, int L) {
     return guarded(ctx, [&] {
-        S4ConvArgs a{u, k, D, y, B, H, L, nullptr, nullptr, nullptr, 0, 0.f};
+        S4ConvArgs a{u, k, D, y, B, H, L, nullptr, nullptr, nullptr, 0, 0.f, nullptr};
         launch_s4_conv(ctx->c.stream, a);
     });
 }
@@ -490,7 +490,7 @@ int mugd_op_gn_s4_conv(mugd_ctx* ctx, const float* u, const float* k, const floa
     return guarded(ctx, [&] {
         hipStream_t st = ctx->c.stream;
         Scratch sc;
-        S4ConvArgs a{u, k, D, y, B, H, L, nullptr, nullptr, nullptr, 0, 0.f};
+        S4ConvArgs a{u, k, D, y, B, H, L, nullptr, nullptr, nullptr, 0, 0.f, nullptr};
         if (s4_conv_fuses_group_norm(L) && H % groups == 0) {
             a.gn_gamma = gamma; a.gn_beta = beta; a.gn_groups = groups; a.gn_eps = 1e-6f;
         } else {

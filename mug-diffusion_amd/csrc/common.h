@@ -83,7 +83,7 @@ __device__ __forceinline__ int fastdiv(int n, unsigned m) { return m ? (int)__um
 // s_memtime (shader cycles) at fixed points into an LDS record and dumps it at kernel end; tests/gpu_timeline.py
 // reduces the records to a per-launch phase table (profiles/).
 // ---------------------------------------------------------------------------------------
-constexpr int TL_WORDS = 12;        // per wave: [0..6] s_memtime stamps, [7] s_memrealtime at entry, [8] at exit, [9] HW_ID | XCC_ID << 32, [10] chunks, [11] spare
+constexpr int TL_WORDS = 16;        // per wave: [0..6] s_memtime stamps, [7] s_memrealtime at entry, [8] at exit, [9] HW_ID | XCC_ID << 32, [10] chunks, [11..13] prologue detail: statistics requested / epilogue operands requested / statistics sums arrived
 #if defined(MUGD_TL) && !defined(MUGD_EMULATED)
 #define TL_DECL __shared__ unsigned long long tl_lds[8][TL_WORDS];
 #define TL_BEGIN()                                                                                          \

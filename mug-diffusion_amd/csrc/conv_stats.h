@@ -16,6 +16,8 @@
 #pragma once
 #include "kernels.h"
 
+TL_DECL          // development build: the per-wave phase records of this translation unit's kernels (common.h)
+
 __device__ __forceinline__ double shfl_xor_d(double v, int o) {
     return __hiloint2double(__shfl_xor(__double2hiint(v), o), __shfl_xor(__double2loint(v), o));
 }
@@ -97,6 +99,7 @@ struct WgStats {
                 const double2 v = row_load(a, b, g * cg + cc, true);
                 s1 += v.x; s2 += v.y;
             }
+            TL_STAMP(13);
 #pragma unroll
             for (int o = 1; o < LPG; o <<= 1) { s1 += shfl_xor_d(s1, o); s2 += shfl_xor_d(s2, o); }
             if (active && j == 0) {
@@ -120,6 +123,7 @@ struct WgStats {
                 const float2* ps = reinterpret_cast<const float2*>(s.xf_a + (size_t)b * s.xf_stride) + t;
                 for (int p = part + NLN * NPART; p < s.xf_np; p += NPART) { const float2 v = ps[(size_t)p * s.Tin]; s1 += v.x; s2 += v.y; }
             }
+            TL_STAMP(13);
             l.lnred[part * TN + col] = make_float2(s1, s2);
         }
         __syncthreads();

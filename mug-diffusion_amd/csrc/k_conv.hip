@@ -42,8 +42,6 @@
 
 namespace {
 
-TL_DECL
-
 constexpr int RS = CONV_RS;
 constexpr int WIN_LDS = CONV_CK * RS;           // floats per window
 constexpr int WAVE_LDS = 2 * WIN_LDS;           // two windows per wave: the pipelined loops park chunk c+1 while chunk c is on the matrix pipe
@@ -97,7 +95,7 @@ __device__ __forceinline__ void mfma_chunk(const char* smem_bytes, int rb0, int 
 template <int TAPS, bool DUAL, int NH, int XFK = -1, int ACT = -1, bool PIPE = false>
 __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* wseg, const float* wseg2, int lo, int hi,
                                                 int b, int t0, int lane, int h, int n, char* smem_bytes, int wave_base,
-                                                f32x16& acc, f32x16& acc2, const float2* gst, const float2* lnst, float inv_cg) {
+                                                f32x16& acc, f32x16& acc2, const float2* gst, const float2* lnst, float inv_cg, int rot_seed) {
     const int r = lane >> 2, q = lane & 3;
     const int Tin = s.Tin;
     const int hw = (TAPS - 1) * s.dil;                     // halo samples per row (left pad + right rest)
@@ -234,7 +232,14 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
         int RGG[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) { RGB[d] = make_float2(1.f, 0.f); RGG[d] = 0; }
-        auto fetch_x = [&](int cr, int d) {
+        // Workgroups that share a weight row tile (the column tiles of one XCD slab) walk a LONG K-slice from different starting
+        // chunks, wrapping around: a weight line is then first touched by one workgroup and found in L2 by the others later,
+        // instead of 16 requests piling up on one pending miss (tests/gpu_l2bw.hip: 22-28 -> 33-34 B/clk/CU on a cold K = 4608
+        // panel, no effect on short ones).  fp32 sums are order-dependent: the result stays deterministic, per column tile.
+        const int rot = nch >= 8 ? rot_seed % nch : 0;
+        auto fetch_x = [&](int cr0, int d) {
+            int cr = cr0 + rot;
+            cr = cr >= nch ? cr - nch : cr;
             const char* xq = xb + (size_t)cr * xstep;
             RX0[d] = *reinterpret_cast<const float4*>(xq + g0);
             RX1[d] = *reinterpret_cast<const float4*>(xq + g1);
@@ -242,16 +247,15 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
             for (int j = 0; j < NH; ++j) RXH[d][j] = *reinterpret_cast<const float*>(xq + gh[j]);
             if (xf) RGB[d] = load_gb2(cr, RGG[d]);
         };
-        auto fetch_a = [&](int cr, int d) {
+        auto fetch_a = [&](int cr0, int d) {
+            int cr = cr0 + rot;
+            cr = cr >= nch ? cr - nch : cr;
             load_a<TAPS, DUAL>(wp + (size_t)cr * (TAPS * 512), wp2 + (size_t)cr * (TAPS * 512), RA[d], RA2[d]);
         };
         constexpr int W1 = WIN_LDS * 4;
 #pragma unroll
-        for (int d = 0; d < D; ++d)
-            if (d < nch) fetch_x(d, d);                 // the windows are needed first: their loads go ahead of the weights
-#pragma unroll
-        for (int d = 0; d < D; ++d)
-            if (d < nch) fetch_a(d, d);
+        for (int d = 0; d < D; ++d)                     // requested chunk by chunk (window first): the memory system serves a cold
+            if (d < nch) { fetch_x(d, d); fetch_a(d, d); }      // burst roughly in order, so chunk 0 is complete after 1/D of it
         finish_ln();
         park_v(0, RX0[0], RX1[0], RXH[0], RGB[0], RGG[0]);
         if (D < nch) fetch_x(D, 0);
@@ -461,6 +465,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
     // after the first chunk's loads are out (conv_stats.h)
     Stats stats;
     stats.issue(a, b, t0, tid);
+    TL_STAMP(11);
 
     // K-slice of this wave: chunk boundaries balanced by cost on the host (a 3-tap chunk is ~2x a 1x1 chunk)
     int g0 = a.kb[0], g1 = a.kb[1];          // constant kernarg offsets + selects: no dependent scalar load
@@ -512,6 +517,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
         }
     };
     if (PRELOAD) load_side();
+    TL_STAMP(12);
     stats.finish(a, b, t0, tid, stl);      // reduce + workgroup barrier(s): the requests went out before the index math above
     TL_STAMP(1);
     TL_SET(10, g1 - g0);
@@ -527,7 +533,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
                 const float* w1 = wtile + s.woff;
                 const float* w2 = wtile2 + s.woff;
 #define MUGD_SEG_ARGS s, w1, w2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, acc, acc2
-#define MUGD_SEG_VARGS MUGD_SEG_ARGS, stl.gnst, stl.lnst, gn_inv_cg
+#define MUGD_SEG_VARGS MUGD_SEG_ARGS, stl.gnst, stl.lnst, gn_inv_cg, rem
                 if (KIND == 0) {
                     // specialise on (transform, activation): branch-free chunk loops
 #define MUGD_SEG_XF(T, NHALO)                                                                     \
@@ -694,7 +700,7 @@ int conv_pick_wk(const ConvArgs& a) {
     const long long tiles = (long long)cdiv(a.Tout, CONV_TN) * cdiv(a.Mout, 32) * a.B;
     int wk = 8;
     while (wk > 1 && tiles * wk > 2048) wk >>= 1;
-    while (wk > 1 && a.nchunk < 2 * wk) wk >>= 1;
+    while (wk > 1 && a.nchunk < wk) wk >>= 1;
     if (wk < 2 && tiles < 2048) wk = a.nchunk >= 4 ? 2 : 1;
     return wk;
 }

@@ -22,8 +22,6 @@
 
 namespace {
 
-TL_DECL
-
 constexpr int RS = 48;                          // LDS row stride (floats); 48 mod 32 = 16
 constexpr int WIN_LDS = CONV_CK * RS;           // floats per window
 constexpr int WAVE_LDS = 2 * WIN_LDS;           // two windows per wave (software-pipelined loops, see k_conv.hip)
@@ -41,7 +39,7 @@ __device__ __forceinline__ void load_a16(const float* wp, const float* wp2, floa
 template <int TAPS, bool DUAL, int XFK = -1, int ACT = -1, bool PIPE = false>       // XFK / ACT / PIPE: see k_conv.hip
 __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wseg, const float* wseg2, int lo, int hi,
                                               int b, int t0, int lane, char* smem_bytes, int wave_base,
-                                              f32x4 (&acc)[2], f32x4 (&accg)[2], const float2* gst, const float2* lnst, float inv_cg) {
+                                              f32x4 (&acc)[2], f32x4 (&accg)[2], const float2* gst, const float2* lnst, float inv_cg, int rot_seed) {
     constexpr int NH = TAPS == 3 ? 1 : 0;                  // dilation 1: 2 halo samples per row, one load for lanes q < 2
     const int r = lane >> 2, q = lane & 3;
     const int l15 = lane & 15, kq = lane >> 4;
@@ -184,22 +182,28 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
         int RGG[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) { RGB[d] = make_float2(1.f, 0.f); RGG[d] = 0; RXH[d] = 0.f; }
-        auto fetch_x = [&](int cr, int d) {
+        // Workgroups that share a weight row tile (the column tiles of one XCD slab) walk a LONG K-slice from different starting
+        // chunks, wrapping around: a weight line is then first touched by one workgroup and found in L2 by the others later,
+        // instead of 16 requests piling up on one pending miss (tests/gpu_l2bw.hip: 22-28 -> 33-34 B/clk/CU on a cold K = 4608
+        // panel, no effect on short ones).  fp32 sums are order-dependent: the result stays deterministic, per column tile.
+        const int rot = nch >= 8 ? rot_seed % nch : 0;
+        auto fetch_x = [&](int cr0, int d) {
+            int cr = cr0 + rot;
+            cr = cr >= nch ? cr - nch : cr;
             const char* xq = xb + (size_t)cr * xstep;
             RX0[d] = *reinterpret_cast<const float4*>(xq + g0);
             if (NH) RXH[d] = *reinterpret_cast<const float*>(xq + gh);
             if (xf) RGB[d] = load_gb2(cr, RGG[d]);
         };
-        auto fetch_a = [&](int cr, int d) {
+        auto fetch_a = [&](int cr0, int d) {
+            int cr = cr0 + rot;
+            cr = cr >= nch ? cr - nch : cr;
             load_a16<TAPS, DUAL>(wp + (size_t)cr * (TAPS * 512), wp2 + (size_t)cr * (TAPS * 512), RA[d], RA2[d]);
         };
         constexpr int W1 = WIN_LDS * 4;
 #pragma unroll
-        for (int d = 0; d < D; ++d)
-            if (d < nch) fetch_x(d, d);
-#pragma unroll
-        for (int d = 0; d < D; ++d)
-            if (d < nch) fetch_a(d, d);
+        for (int d = 0; d < D; ++d)                     // requested chunk by chunk (window first): the memory system serves a cold
+            if (d < nch) { fetch_x(d, d); fetch_a(d, d); }      // burst roughly in order, so chunk 0 is complete after 1/D of it
         finish_ln();
         park_v(0, RX0[0], RXH[0], RGB[0], RGG[0]);
         if (D < nch) fetch_x(D, 0);
@@ -294,6 +298,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
     // ---- GroupNorm / LayerNorm statistics: partial sums requested now, reduced once per workgroup (conv_stats.h)
     Stats stats;
     stats.issue(a, b, t0, tid);
+    TL_STAMP(11);
 
     int g0 = a.kb[0], g1 = a.kb[1];      // this wave's K-slice (cost-balanced on the host: conv_split_k); constant kernarg offsets + selects
 #pragma unroll
@@ -339,6 +344,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
 #pragma unroll
         for (int q = 0; q < EPT; ++q) rsv[q] = a.resid[oo[q]];
     }
+    TL_STAMP(12);
     stats.finish(a, b, t0, tid, stl);      // reduce + workgroup barrier(s): the requests went out before the index math above
     TL_STAMP(1);
     TL_SET(10, g1 - g0);
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
             if (lo < hi) {
                 const float* w1 = wtile + s.woff;
                 const float* w2 = wtile2 + s.woff;
-#define MUGD_SEG16_ARGS s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, acc, accg, stl.gnst, stl.lnst, gn_inv_cg
+#define MUGD_SEG16_ARGS s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, acc, accg, stl.gnst, stl.lnst, gn_inv_cg, rem
 #define MUGD_SEG16_XF(T)                                                                  \
     switch (s.xf * 4 + s.act) {                                                           \
         case 0: run_segment16<T, DUAL, 0, 0, true>(MUGD_SEG16_ARGS); break;                     \
@@ -557,7 +563,7 @@ void launch_conv_gemm16(hipStream_t st, const ConvArgs& a) {
         const long long tiles = (long long)gx * gy * gz;
         wk = 8;
         while (wk > 1 && tiles * wk > 2048) wk >>= 1;
-        while (wk > 1 && a.nchunk < 2 * wk) wk >>= 1;
+        while (wk > 1 && a.nchunk < wk) wk >>= 1;
         if (wk < 2 && tiles < 2048) wk = a.nchunk >= 4 ? 2 : 1;
     }
     if (const char* e = getenv("MUGD_CONV_WK")) {

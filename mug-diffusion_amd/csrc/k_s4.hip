@@ -138,9 +138,40 @@ __global__ __launch_bounds__(256) void s4_conv_fast_kernel(const S4ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const float* u = a.u + ((size_t)b * a.H + h) * L;
 
+    // k and u rows requested before the statistics: their round trip overlaps the GroupNorm reduction
+    constexpr int NE = (LP + 255) / 256;
+    float kreg[NE], ureg[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int i = tid + e * 256;
+        const int ic = i < L ? i : L - 1;
+        kreg[e] = a.k[(size_t)h * L + ic];
+        ureg[e] = u[ic];
+    }
+
     float ag = 1.f, ab = 0.f;
     if (a.aff) {
         ag = a.aff[2 * ((size_t)b * a.H + h)]; ab = a.aff[2 * ((size_t)b * a.H + h) + 1];
+    } else if (a.gn_gamma && a.rowstat) {
+        // GroupNorm statistics from the producer's fp64 row sums: every wave reduces the group's cg rows itself (no barrier)
+        const int cg = a.H / a.gn_groups, c0 = (h / cg) * cg;
+        double s1 = 0.0, s2 = 0.0;
+        for (int c = lane; c < cg; c += 64) {
+            const double* p = a.rowstat + 2 * ((size_t)b * a.H + c0 + c);
+            s1 += p[0]; s2 += p[1];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s1 += __hiloint2double(__shfl_xor(__double2hiint(s1), o), __shfl_xor(__double2loint(s1), o));
+            s2 += __hiloint2double(__shfl_xor(__double2hiint(s2), o), __shfl_xor(__double2loint(s2), o));
+        }
+        const double inv = 1.0 / ((double)cg * (double)L);
+        const double mean_d = s1 * inv;
+        double var_d = s2 * inv - mean_d * mean_d;
+        var_d = var_d > 0.0 ? var_d : 0.0;
+        const float rstd = 1.0f / sqrtf((float)var_d + a.gn_eps);
+        ag = a.gn_gamma[h] * rstd;
+        ab = a.gn_beta[h] - (float)mean_d * ag;
     } else if (a.gn_gamma) {
         const int cg = a.H / a.gn_groups, c0 = (h / cg) * cg;
         const float* ug = a.u + ((size_t)b * a.H + c0) * L;
@@ -169,12 +200,16 @@ __global__ __launch_bounds__(256) void s4_conv_fast_kernel(const S4ConvArgs a) {
         ag = a.gn_gamma[h] * rstd;
         ab = a.gn_beta[h] - (float)mean_d * ag;
     }
-    for (int i = tid; i < LP; i += 256) {
-        const bool in = i < L;
-        ks[i] = in ? a.k[(size_t)h * L + i] : 0.f;
-        const int i1 = LP + i;
-        uw[i1 + (i1 >> 5)] = in ? u[i] * ag + ab : 0.f;
-        uw[i + (i >> 5)] = 0.f;                      // causal padding: u[t] = 0 for t < 0
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int i = tid + e * 256;
+        if (i < LP) {
+            const bool in = i < L;
+            ks[i] = in ? kreg[e] : 0.f;
+            const int i1 = LP + i;
+            uw[i1 + (i1 >> 5)] = in ? ureg[e] * ag + ab : 0.f;
+            uw[i + (i >> 5)] = 0.f;                  // causal padding: u[t] = 0 for t < 0
+        }
     }
     __syncthreads();
 

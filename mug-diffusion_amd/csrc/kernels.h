@@ -225,6 +225,10 @@ struct S4ConvArgs {      // y = gelu( causal_conv(k, u') + D*u' ),  u,y: (B,H,L)
     // or (fast kernel only, aff == null): the GroupNorm itself -- every workgroup reduces its own group (H/groups rows of L
     // samples per batch row: <= 32 KiB, L2-resident), which costs less than the separate statistics launch it replaces
     const float* gn_gamma; const float* gn_beta; int gn_groups; float gn_eps;
+    // or (fast kernel, gn_gamma set): the fp64 {sum, sum of squares} per (batch, channel) row the PRODUCER of u accumulated
+    // (ConvArgs::rowstat): the workgroup sums its group's H / groups rows -- one short load next to the k / u loads instead
+    // of a pass over the group's samples and a barrier
+    const double* rowstat;
 };
 bool s4_conv_fuses_group_norm(int L);
 void launch_s4_conv(hipStream_t st, const S4ConvArgs& a);

@@ -109,7 +109,7 @@ void Net::timeline_program(const char* path, const char* raw_path, int raw_op) {
     FILE* fr = raw_path ? fopen(raw_path, "a") : nullptr;
     const char* raw_label = getenv("MUGD_TL_RAW_LABEL");          // raw per-wave records of the launches whose label contains this
     fprintf(f, "op,kind,gflop,tn,wk,blocks,waves,span_ns,start_skew_ns,first_end_ns,mhz,chunks_med,"
-               "setup_med,setup_max,first_med,first_max,loop_med,loop_max,cyc_per_chunk,combine_med,combine_max,store_med,store_max,tail_med,tail_max,total_med,total_max,label\n");
+               "su_issue,su_side,su_wait,su_reduce,setup_med,setup_max,first_med,first_max,loop_med,loop_max,cyc_per_chunk,combine_med,combine_max,store_med,store_max,tail_med,tail_max,total_med,total_max,label\n");
     auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
     auto mx = [](const std::vector<double>& v) { double m = 0; for (double x : v) m = std::max(m, x); return m; };
     for (size_t i = 0; i < ops.size(); ++i) {
@@ -117,7 +117,7 @@ void Net::timeline_program(const char* path, const char* raw_path, int raw_op) {
             const TlLaunch& L = g_tl.launches[li];
             const size_t nw = (size_t)L.nblk * L.nwaves;
             unsigned long long r0 = ~0ull, r1 = 0, r0max = 0, r1min = ~0ull;
-            std::vector<double> ph[7], chunks, mhz;
+            std::vector<double> ph[7], chunks, mhz, su[4];
             for (size_t w = 0; w < nw; ++w) {
                 const unsigned long long* r = &h[L.off + w * TL_WORDS];
                 if (r[0] == 0) continue;
@@ -128,6 +128,11 @@ void Net::timeline_program(const char* path, const char* raw_path, int raw_op) {
                 ph[3].push_back((double)(r[4] - r[3])); ph[4].push_back((double)(r[5] - r[4])); ph[5].push_back((double)(r[6] - r[5]));
                 ph[6].push_back((double)(r[6] - r[0]));
                 chunks.push_back((double)r[10]);
+                if (r[11] && r[12]) {
+                    const unsigned long long t13 = r[13] ? r[13] : r[12];
+                    su[0].push_back((double)(r[11] - r[0])); su[1].push_back((double)(r[12] - r[11]));
+                    su[2].push_back((double)(t13 - r[12])); su[3].push_back((double)(r[1] - t13));
+                }
                 if (r[8] > r[7]) mhz.push_back((double)(r[6] - r[0]) / ((double)(r[8] - r[7]) * 10.0) * 1e3);
                 if (fr && ((int)i == raw_op || raw_op == -1 || (raw_label && ops[i].label.find(raw_label) != std::string::npos)))
                     fprintf(fr, "%zu,%zu,%zu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu\n", i, w / L.nwaves, w % L.nwaves,
@@ -136,6 +141,7 @@ void Net::timeline_program(const char* path, const char* raw_path, int raw_op) {
             const double cm = med(chunks), lm = med(ph[2]);
             fprintf(f, "%zu,%s,%.4f,%d,%d,%d,%zu,%llu,%llu,%llu,%.0f,%.0f", i, op_kind_name(ops[i].kind), ops[i].flops / 1e9, L.tn, L.nwaves, L.nblk,
                     nw, (r1 - r0) * 10ull, (r0max - r0) * 10ull, (r1min - r0) * 10ull, med(mhz), cm);
+            fprintf(f, ",%.0f,%.0f,%.0f,%.0f", med(su[0]), med(su[1]), med(su[2]), med(su[3]));
             for (int k = 0; k < 6; ++k) {
                 fprintf(f, ",%.0f,%.0f", med(ph[k]), mx(ph[k]));
                 if (k == 2) fprintf(f, ",%.0f", cm > 0 ? lm / cm : 0.0);
@@ -740,7 +746,8 @@ Tensor Net::s4_layer(const std::string& prefix, const Tensor& x) {
     const float* k = s4_kernel(prefix + ".s4_model.kernel.kernel", H, L);
     Tensor y = talloc(H, L);
     S4ConvArgs ca{u.p, k, PF(prefix + ".s4_model.D"), y.p, Bn, H, L, aff,
-                  in_kernel_gn ? PF(prefix + ".norm.weight") : nullptr, in_kernel_gn ? PF(prefix + ".norm.bias") : nullptr, 32, 1e-6f};
+                  in_kernel_gn ? PF(prefix + ".norm.weight") : nullptr, in_kernel_gn ? PF(prefix + ".norm.bias") : nullptr, 32, 1e-6f,
+                  (in_kernel_gn && ctx->fuse_stats && x.bmod == 0) ? x.rowstat : nullptr};
     emit([ca](hipStream_t st) { launch_s4_conv(st, ca); }, OP_S4_CONV, 0, prefix + " H=" + std::to_string(H) + " L=" + std::to_string(L));
     ConvSpec gl;
     gl.key = prefix + ".s4_model.output_linear.0";

@@ -47,10 +47,11 @@ def summarise(path, out):
     skew = sum(f(r, "start_skew_ns") for r in rows)
     print("sum of start skews (last wave's entry - first wave's entry): %.1f us" % (skew / 1e3), file=out)
     # MFMA-ideal loop time: cycles per chunk if the SIMD's matrix pipe were the only limit
-    print("\nper launch (us at the median clock): span | setup first loop combine store tail | cyc/chunk | label", file=out)
+    print("\nper launch (us at the median clock): span | setup (= statistics requested + epilogue operands requested + wait for the sums + reduce / barrier) first loop combine store tail | cyc/chunk | label", file=out)
     for r in rows:
-        print("%4s tn%-2s wk%s blk%-5s %6.2f | %5.2f %5.2f %6.2f %5.2f %5.2f %5.2f | %6.0f | %s" % (
-            r["op"], r["tn"], r["wk"], r["blocks"], f(r, "span_ns") / 1e3, f(r, "setup_med") / mhz, f(r, "first_med") / mhz,
+        print("%4s tn%-2s wk%s blk%-5s %6.2f | %5.2f (%4.2f %4.2f %4.2f %4.2f) %5.2f %6.2f %5.2f %5.2f %5.2f | %6.0f | %s" % (
+            r["op"], r["tn"], r["wk"], r["blocks"], f(r, "span_ns") / 1e3, f(r, "setup_med") / mhz,
+            f(r, "su_issue") / mhz, f(r, "su_side") / mhz, f(r, "su_wait") / mhz, f(r, "su_reduce") / mhz, f(r, "first_med") / mhz,
             f(r, "loop_med") / mhz, f(r, "combine_med") / mhz, f(r, "store_med") / mhz, f(r, "tail_med") / mhz,
             f(r, "cyc_per_chunk"), r["label"]), file=out)
 
