@@ -48,6 +48,13 @@ int mugd_create(int device, void* stream, mugd_ctx** out);
 void mugd_destroy(mugd_ctx* ctx);
 const char* mugd_last_error(mugd_ctx* ctx);
 int mugd_synchronize(mugd_ctx* ctx);
+/* Stream ordering against a caller that works on OTHER streams (PyTorch: torch.cuda.current_stream(), which may be the legacy
+ * NULL stream, a `with torch.cuda.stream(s)` stream or a per-thread default stream).  mugd_order_after makes everything the
+ * library enqueues from now on wait for the work already enqueued on `other`; mugd_order_before makes `other` wait for the
+ * library's work enqueued so far.  Bracket a call with the two and the caller's tensors are ordered both ways without any
+ * host synchronisation (the Python binding does this around every entry point).  other == the context's own stream: no-op. */
+int mugd_order_after(mugd_ctx* ctx, void* other_stream);
+int mugd_order_before(mugd_ctx* ctx, void* other_stream);
 /* 1 (default): replay each DDIM step from a captured hipGraph; 0: launch kernels eagerly. */
 int mugd_set_graph_mode(mugd_ctx* ctx, int enabled);
 /* Tuning / test knob: force the conv_gemm decomposition for networks COMPILED and operators run after the call

@@ -68,7 +68,9 @@ def build(force=False, verbose=True, timeline=False):
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(cc, _sources()))
-    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
+    tmp = LIB + ".tmp.%d" % os.getpid()              # never expose a half-linked library to a concurrent loader
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp])
+    os.replace(tmp, LIB)
     if verbose:
         print("built", LIB)
     return LIB

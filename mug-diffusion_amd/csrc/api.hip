@@ -99,6 +99,7 @@ int mugd_create(int device, void* stream, mugd_ctx** out) {
 void mugd_destroy(mugd_ctx* ctx) {
     if (!ctx) return;
     hipStreamSynchronize(ctx->c.stream);
+    if (ctx->c.order_event) hipEventDestroy(ctx->c.order_event);
     if (ctx->c.scratch) hipFree(ctx->c.scratch);
     for (auto& kv : ctx->c.resample_taps) hipFree(kv.second);
     if (ctx->c.own_stream) hipStreamDestroy(ctx->c.stream);
@@ -110,6 +111,19 @@ const char* mugd_last_error(mugd_ctx* ctx) { return ctx ? ctx->c.last_error.c_st
 int mugd_synchronize(mugd_ctx* ctx) {
     return guarded(ctx, [&] { HIP_CHECK(hipStreamSynchronize(ctx->c.stream)); });
 }
+
+// torch.cuda.current_stream() is not necessarily the stream the library was created on (and the legacy NULL stream cannot
+// be captured into a graph at all): order the two with an event instead of relying on implicit NULL-stream synchronisation
+static int order_streams(mugd_ctx* ctx, hipStream_t first, hipStream_t then) {
+    return guarded(ctx, [&] {
+        if (first == then) return;
+        if (!ctx->c.order_event) HIP_CHECK(hipEventCreateWithFlags(&ctx->c.order_event, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(ctx->c.order_event, first));
+        HIP_CHECK(hipStreamWaitEvent(then, ctx->c.order_event, 0));
+    });
+}
+int mugd_order_after(mugd_ctx* ctx, void* other) { return ctx ? order_streams(ctx, (hipStream_t)other, ctx->c.stream) : MUGD_ERR_INVALID; }
+int mugd_order_before(mugd_ctx* ctx, void* other) { return ctx ? order_streams(ctx, ctx->c.stream, (hipStream_t)other) : MUGD_ERR_INVALID; }
 
 int mugd_set_graph_mode(mugd_ctx* ctx, int enabled) {
     if (!ctx) return MUGD_ERR_INVALID;

@@ -35,6 +35,7 @@ struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipEvent_t order_event = nullptr;     // mugd_order_after / mugd_order_before
     std::string last_error;
     bool use_graph = true;
     float* scratch = nullptr; size_t scratch_cap = 0;   // grow-only device scratch of the context-level operators (log_mel): no malloc / sync per call

@@ -866,7 +866,10 @@ void UNet::build(bool dry_run) {
             a.bmod = key.bmod;
             if (ctx->fuse_norm && ctx->fuse_stats) {          // row sums of the (step-invariant) audio maps: once per call
                 const int rows = Bn * a.C;
-                a.rowstat = dry ? reinterpret_cast<double*>(256) : reinterpret_cast<double*>(dev_alloc((size_t)rows * 4));
+                // library-owned, kept across recompilations for other (batch, length) keys: keyed like the K/V and S4 buffers
+                const std::string rk = "audio.rowstat#" + std::to_string(l) + "x" + std::to_string(rows);
+                if (!dry && !baked.count(rk)) baked[rk] = dev_alloc((size_t)rows * 4);
+                a.rowstat = dry ? reinterpret_cast<double*>(256) : reinterpret_cast<double*>(baked[rk]);
                 const float* xp = a.p; double* rp = a.rowstat; const int T = a.T;
                 to_pre = true;
                 emit([=](hipStream_t st) { launch_row_sums(st, xp, rp, rows, T); }, OP_SMALL, 0, "audio row sums");

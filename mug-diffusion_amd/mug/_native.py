@@ -1,7 +1,10 @@
 """ctypes binding of libmugd.so (the C ABI in include/mugd.h).
 
 PyTorch is used only as the owner of device memory: every call passes raw
-``tensor.data_ptr()`` values and enqueues on torch's current HIP stream.  There
+``tensor.data_ptr()`` values.  The library works on a stream of its own (the legacy NULL stream
+cannot be captured into a hipGraph) and every call is bracketed by event waits against
+``torch.cuda.current_stream()`` (`mugd_order_after` / `mugd_order_before`), so torch ops before and
+after a call are ordered with it on whatever stream the caller uses -- no host synchronisation.  There
 is NO CPU fallback: if the in-tree HIP library is missing or no GPU is visible,
 ``get_lib()`` raises.
 
@@ -46,6 +49,8 @@ class WaveConfig(C.Structure):
 _SIGS = {
     "mugd_create": [_i, _p, C.POINTER(_p)],
     "mugd_synchronize": [_p],
+    "mugd_order_after": [_p, _p],
+    "mugd_order_before": [_p, _p],
     "mugd_set_graph_mode": [_p, _i],
     "mugd_set_conv_tiling": [_p, _i, _i],
     "mugd_unet_create": [_p, C.POINTER(UNetConfig), C.POINTER(_p)],
@@ -94,6 +99,36 @@ class MugdError(RuntimeError):
     pass
 
 
+_UNORDERED = {"mugd_create", "mugd_destroy", "mugd_net_destroy", "mugd_last_error", "mugd_version", "mugd_profile_kind_name",
+              "mugd_order_after", "mugd_order_before", "mugd_set_graph_mode", "mugd_set_conv_tiling", "mugd_remove_mini_jacks"}
+
+
+class _OrderedDll:
+    """The ctypes library with every enqueueing entry point bracketed by stream-ordering calls against torch's current
+    stream (see the module docstring).  `.raw` is the plain CDLL."""
+
+    def __init__(self, raw, lib):
+        self.raw, self._lib, self._cache = raw, lib, {}
+
+    def __getattr__(self, name):
+        fn = getattr(self.raw, name)
+        if name in _UNORDERED or not name.startswith("mugd_"):
+            return fn
+        if name not in self._cache:
+            lib, raw = self._lib, self.raw
+
+            def ordered(*args):
+                if lib.device.type != "cuda" or not lib.ctx:
+                    return fn(*args)
+                cur = _p(torch.cuda.current_stream(lib.device).cuda_stream)
+                raw.mugd_order_after(lib.ctx, cur)
+                rc = fn(*args)
+                raw.mugd_order_before(lib.ctx, cur)
+                return rc
+            self._cache[name] = ordered
+        return self._cache[name]
+
+
 class Lib:
     def __init__(self, path=None, device=None):
         path = path or LIB_PATH
@@ -101,32 +136,31 @@ class Lib:
             raise MugdError("%s not found: build it with `python mug-diffusion_amd/build.py` "
                             "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
         self.path = path
-        self.dll = C.CDLL(path)
+        self.dll = _OrderedDll(C.CDLL(path), self)
         for name, args in _SIGS.items():
-            fn = getattr(self.dll, name)
+            fn = getattr(self.dll.raw, name)
             fn.argtypes = args
             fn.restype = _i
-        self.dll.mugd_last_error.argtypes = [_p]
-        self.dll.mugd_last_error.restype = C.c_char_p
-        self.dll.mugd_version.restype = C.c_char_p
-        self.dll.mugd_profile_kind_name.argtypes = [_i]
-        self.dll.mugd_profile_kind_name.restype = C.c_char_p
-        self.dll.mugd_destroy.argtypes = [_p]
-        self.dll.mugd_destroy.restype = None
-        self.dll.mugd_net_destroy.argtypes = [_p]
-        self.dll.mugd_net_destroy.restype = None
+        raw = self.dll.raw
+        raw.mugd_last_error.argtypes = [_p]
+        raw.mugd_last_error.restype = C.c_char_p
+        raw.mugd_version.restype = C.c_char_p
+        raw.mugd_profile_kind_name.argtypes = [_i]
+        raw.mugd_profile_kind_name.restype = C.c_char_p
+        raw.mugd_destroy.argtypes = [_p]
+        raw.mugd_destroy.restype = None
+        raw.mugd_net_destroy.argtypes = [_p]
+        raw.mugd_net_destroy.restype = None
         if device is None:
             if not torch.cuda.is_available():
                 raise MugdError("no GPU visible to torch: libmugd.so needs an MI355X (no CPU fallback)")
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = torch.device(device)
-        stream = None
         index = 0
         if self.device.type == "cuda":
             index = self.device.index or 0
-            stream = torch.cuda.current_stream(self.device).cuda_stream
         self.ctx = _p()
-        rc = self.dll.mugd_create(index, _p(stream), C.byref(self.ctx))
+        rc = raw.mugd_create(index, _p(None), C.byref(self.ctx))          # NULL: the library creates its own stream
         if rc != 0:
             raise MugdError("mugd_create failed with status %d" % rc)
         self._nets = []
@@ -475,8 +509,17 @@ def _build_in_tree():
     spec = importlib.util.spec_from_file_location("mugd_build", os.path.join(os.path.dirname(_HERE), "build.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
-    print("mug._native: %s is missing, building it with hipcc ..." % LIB_PATH, file=sys.stderr, flush=True)
-    b.build(verbose=False)
+    # one process per GPU (mug/shard.py): every rank lands here at once on a fresh checkout -- serialise the build with a
+    # file lock and re-check under it; build.py links to a temporary name and renames it into place
+    import fcntl
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not os.path.exists(LIB_PATH):
+                print("mug._native: %s is missing, building it with hipcc ..." % LIB_PATH, file=sys.stderr, flush=True)
+                b.build(verbose=False)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def get_lib():

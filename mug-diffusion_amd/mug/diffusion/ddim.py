@@ -97,19 +97,33 @@ class DDIMSampler(object):
         # iterations after which the reference records an intermediate (ddim.py:154-156)
         log_after = [i for i in range(total) if (total - i - 1) % log_every_t == 0 or (total - i - 1) == total - 1]
         cuts = sorted(set(range(1, total + 1)) if per_step else set(i + 1 for i in log_after) | {total})
-        bar = (tqdm_class or tqdm)(total=total, desc='Charting, using DDIM Sampler')
+        # the reference's call shape (ddim.py:133-135): an iterable first, then desc / total -- gradio.Progress().tqdm, which
+        # webui.py:388 passes in, requires the iterable and has no usable update() / close(); the bar is advanced by pulling
+        # from its iterator, n items per native call
+        bar_it = iter((tqdm_class or tqdm)(range(total), desc='Charting, using DDIM Sampler', total=total))
+
+        def advance(n):
+            for _ in range(n):
+                next(bar_it, None)
+
+        def draw_noise(n):
+            # one randn(shape) per step, in step order, exactly as p_sample_ddim does (ddim.py:192) -- also when eta == 0, where
+            # the reference still draws (and discards: sigma = 0) the noise, so that a later sample in the same process starts
+            # from the same generator state as in the reference (scripts/mapping.py's n_samples loop)
+            z = torch.stack([torch.randn(tuple(shape), device=device) for _ in range(n)])
+            if not eta_on:
+                return None
+            z = z * temperature
+            if noise_dropout > 0.:
+                z = torch.nn.functional.dropout(z, p=noise_dropout)
+            return z
         if not per_step and total > 1 and log_after == [0, total - 1]:
             # the common case (S <= log_every_t, no callbacks): ONE native call for the whole loop; the library hands back the
             # state after the first step, the only other intermediate the reference records
-            noise = None
-            if eta_on:
-                noise = torch.randn((total,) + tuple(shape), device=device) * temperature
-                if noise_dropout > 0.:
-                    noise = torch.nn.functional.dropout(noise, p=noise_dropout)
+            noise = draw_noise(total)
             x, pred, first = net.ddim_sample(x, c, w, steps, rows, uc=uc, scale=float(unconditional_guidance_scale), noise=noise,
                                              want_pred_x0=True, want_first=True)
-            if hasattr(bar, "update"):
-                bar.update(total)
+            advance(total)
             intermediates['x_inter'] += [first[0], x]
             intermediates['pred_x0'] += [first[1], pred]
             cuts = []
@@ -120,15 +134,10 @@ class DDIMSampler(object):
                 assert x0 is not None
                 ts = torch.full((b,), steps[start], device=device, dtype=torch.long)
                 x = self.model.q_sample(x0, ts) * mask + (1. - mask) * x
-            noise = None
-            if eta_on:
-                noise = torch.randn((n,) + tuple(shape), device=device) * temperature
-                if noise_dropout > 0.:
-                    noise = torch.nn.functional.dropout(noise, p=noise_dropout)
+            noise = draw_noise(n)
             x, pred = net.ddim_sample(x, c, w, steps[start:end], rows[start:end], uc=uc,
                                       scale=float(unconditional_guidance_scale), noise=noise, want_pred_x0=True)
-            if hasattr(bar, "update"):
-                bar.update(n)
+            advance(n)
             for i in range(start, end):
                 if callback:
                     callback(i)
@@ -138,6 +147,5 @@ class DDIMSampler(object):
                 intermediates['x_inter'].append(x)
                 intermediates['pred_x0'].append(pred)
             start = end
-        if hasattr(bar, "close"):
-            bar.close()
+        advance(1)          # exhausts the iterator: tqdm closes its bar on StopIteration
         return x, intermediates

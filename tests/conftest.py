@@ -36,7 +36,12 @@ def emu_lib():
 
 
 def real_lib():
+    """The HIP build on the GPU.  Without a GPU the `gpu`-marked tests SKIP (a plain `pytest tests` in the authoring
+    container stays green); on a GPU box a missing / unloadable library is an error, never a skip."""
     if "gpu" not in _libs:
+        import torch
+        if not torch.cuda.is_available():
+            pytest.skip("needs a real MI355X (no GPU visible to torch)")
         from mug._native import get_lib
         _libs["gpu"] = get_lib()
     return _libs["gpu"]

@@ -76,6 +76,9 @@ hipError_t hipStreamCreate(hipStream_t*);
 hipError_t hipStreamDestroy(hipStream_t);
 hipError_t hipStreamSynchronize(hipStream_t);
 hipError_t hipEventCreate(hipEvent_t*);
+enum { hipEventDisableTiming = 2 };
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }   // the emulation is synchronous
 hipError_t hipEventDestroy(hipEvent_t);
 hipError_t hipEventRecord(hipEvent_t, hipStream_t);
 hipError_t hipEventSynchronize(hipEvent_t);

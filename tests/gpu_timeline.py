@@ -66,8 +66,8 @@ def main():
     if not os.path.exists(TL_LIB):
         raise SystemExit("build the timeline library first: python mug-diffusion_amd/build.py --tl")
     lib = Lib(path=TL_LIB)
-    lib.dll.mugd_dev_timeline.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int]
-    lib.dll.mugd_dev_timeline.restype = C.c_int
+    lib.dll.raw.mugd_dev_timeline.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int]
+    lib.dll.raw.mugd_dev_timeline.restype = C.c_int
     case = cases.FULL
     man = weights.load_manifest(os.path.join(cases.GOLDEN, case["manifest"]))
     sd = weights.set_s4_lengths(weights.make_state_dict(man, 0), case["unet"], a.z)

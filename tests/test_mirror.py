@@ -136,25 +136,40 @@ def test_python_surface_end_to_end_tiny(as_default_lib, scale):
     samples, inter = sampler.sample(S=S, c=c, w=w, batch_size=B, shape=None, verbose=False, eta=0.0,
                                     x_T=cases.x_T(int(g["seed"]), B, z).to(lib.device),
                                     unconditional_guidance_scale=scale, unconditional_conditioning=uc,
-                                    tqdm_class=lambda *a, **k: _Bar(seen))
+                                    tqdm_class=_GradioShapedTqdm(seen))
     logits = model.model.decode(samples)
     d = (samples.cpu() - torch.from_numpy(g["latent"])).abs().max().item()
     assert d < 1e-3 * max(1.0, float(np.abs(g["latent"]).max())), d
     gs, gh = host.note_grid(logits.cpu().numpy())
     rs, rh = host.note_grid(g["logits"])
     assert (gs == rs).all() and (gh == rh).all()
-    assert sum(seen) == S and len(inter["x_inter"]) == 3 and len(inter["pred_x0"]) == 3
+    assert seen == ["open %d" % S] + ["step"] * S + ["closed"] and len(inter["x_inter"]) == 3 and len(inter["pred_x0"]) == 3
 
 
-class _Bar:
+class _GradioShapedTqdm:
+    """Stands in for `gradio.Progress().tqdm` (webui.py:388): signature tqdm(iterable, desc=None, total=None, ...) with the
+    iterable REQUIRED, and the returned object is only iterated -- there is no update(), and close() needs an argument.
+    Records how the sampler drives it."""
+
     def __init__(self, seen):
         self.seen = seen
 
-    def update(self, n):
-        self.seen.append(n)
+    def __call__(self, iterable, desc=None, total=None, unit="steps"):
+        seen = self.seen
+        items = list(iterable)
+        seen.append("open %d" % (total if total is not None else len(items)))
 
-    def close(self):
-        pass
+        class _It:
+            def __iter__(self_inner):
+                for _ in items:
+                    seen.append("step")
+                    yield _
+                seen.append("closed")
+
+            def close(self_inner, _tqdm):            # gradio's signature: unusable without the argument
+                raise AssertionError("close() must not be called on a foreign progress object")
+
+        return _It()
 
 
 def test_native_module_refuses_wrong_device(as_default_lib):
@@ -204,7 +219,7 @@ def test_sampler_call_paths_agree_and_inpainting_round_trip(as_default_lib):
     model.z_length = z
     sampler = DDIMSampler(model)
     xT = cases.x_T(int(g["seed"]), B, z).to(lib.device)
-    kw = dict(S=S, c=c, w=w, batch_size=B, verbose=False, eta=0.0, x_T=xT, tqdm_class=lambda *a, **k: _Bar([]))
+    kw = dict(S=S, c=c, w=w, batch_size=B, verbose=False, eta=0.0, x_T=xT, tqdm_class=_GradioShapedTqdm([]))
     one, _ = sampler.sample(**kw)
     steps_seen = []
     per, inter = sampler.sample(callback=steps_seen.append, **kw)
@@ -220,6 +235,16 @@ def test_sampler_call_paths_agree_and_inpainting_round_trip(as_default_lib):
     torch.manual_seed(0)
     full, _ = sampler.sample(mask=torch.ones_like(one), x0=x0, **kw)
     assert full.shape == one.shape and torch.isfinite(full).all() and not close_(full, one)
+    # generator state after a sample: the reference's p_sample_ddim draws randn(shape) on every step even with eta = 0
+    # (ddim.py:192), so a following x_T = None sample starts from the state "S draws later" -- reproduce that
+    dev = one.device
+    torch.manual_seed(123)
+    sampler.sample(**kw)
+    after = torch.randn(4, device=dev)
+    torch.manual_seed(123)
+    for _ in range(S):
+        torch.randn(tuple(one.shape), device=dev)
+    assert torch.equal(after, torch.randn(4, device=dev))
 
 
 def test_audio_ingest_resamples_on_the_device_when_only_soundfile_is_present(as_default_lib, monkeypatch, tmp_path):
