@@ -61,6 +61,12 @@ int mugd_set_graph_mode(mugd_ctx* ctx, int enabled);
  * (wk: waves splitting K per workgroup, 1|2|4|8; tn: output tile width 16|32; 0 = pick per layer).  Call
  * mugd_net_invalidate on existing networks to recompile them. */
 int mugd_set_conv_tiling(mugd_ctx* ctx, int wk, int tn);
+/* S4 kernel generation (mug/model/s4.py:706-832): which Cauchy backend of the reference to reproduce.  0 (default): cauchy_naive
+ * (s4.py:140-147, the sum over the stored half of the poles -- what the reference runs when neither pykeops nor its CUDA
+ * extension is installed); 1: cauchy_conj / cauchy_mult(symmetric=True) (s4.py:55-77), the sum over both conjugate halves --
+ * what a checkpoint trained with one of those backends expects.  Affects kernels baked afterwards (mugd_net_invalidate
+ * re-bakes existing networks).  Environment default: MUGD_S4_SYMMETRIC=1. */
+int mugd_set_s4_symmetric(mugd_ctx* ctx, int enabled);
 const char* mugd_version(void);
 
 /* ---- networks ------------------------------------------------------------------------- */

@@ -84,6 +84,8 @@ int mugd_create(int device, void* stream, mugd_ctx** out) {
         ctx->c.fold_xattn = !(xf && xf[0] == '1');
         const char* pf = getenv("MUGD_NO_PROJ_FOLD");
         ctx->c.fold_proj_out = !(pf && pf[0] == '1');
+        const char* sy = getenv("MUGD_S4_SYMMETRIC");
+        ctx->c.s4_symmetric = sy && sy[0] == '1';
         const char* fa = getenv("MUGD_EXACT_SILU");            // default: SiLU of the fused GroupNorm path on v_exp_f32 / v_rcp_f32
         ctx->c.fast_act = !(fa && fa[0] == '1');
     });
@@ -128,6 +130,12 @@ int mugd_order_before(mugd_ctx* ctx, void* other) { return ctx ? order_streams(c
 int mugd_set_graph_mode(mugd_ctx* ctx, int enabled) {
     if (!ctx) return MUGD_ERR_INVALID;
     ctx->c.use_graph = enabled != 0;
+    return MUGD_OK;
+}
+
+int mugd_set_s4_symmetric(mugd_ctx* ctx, int enabled) {
+    if (!ctx) return MUGD_ERR_INVALID;
+    ctx->c.s4_symmetric = enabled != 0;
     return MUGD_OK;
 }
 
@@ -487,7 +495,7 @@ int mugd_op_attention(mugd_ctx* ctx, const float* q, const float* k, const float
 int mugd_op_s4_kernel(mugd_ctx* ctx, const float* C, const float* Bp, const float* P, const float* inv_w_real,
                       const float* w_imag, const float* log_dt, float* k, int H, int N, int Lint, int L) {
     return guarded(ctx, [&] {
-        S4GenArgs a{C, Bp, P, inv_w_real, w_imag, log_dt, H, N, Lint, L, nullptr, k};
+        S4GenArgs a{C, Bp, P, inv_w_real, w_imag, log_dt, H, N, Lint, L, nullptr, k, ctx->c.s4_symmetric ? 1 : 0};
         launch_s4_kernel_gen(ctx->c.stream, a);
     });
 }

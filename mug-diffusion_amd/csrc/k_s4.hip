@@ -5,7 +5,8 @@
 // on the weights, so the library bakes it once per (layer, L) instead of regenerating it in
 // every U-Net call like the reference does.  Arithmetic (per feature h, FFT node l):
 //     dt = exp(log_dt);  w_n = (-exp(inv_w_real) + i w_imag) dt;  omega = exp(-2 pi i l / L)
-//     reference:  z = 2(1-omega)/(1+omega);  r_ab = dt * sum_n v_ab,n / (z - w_n)   (32 stored poles only)
+//     reference:  z = 2(1-omega)/(1+omega);  r_ab = dt * sum_n v_ab,n / (z - w_n)   (32 stored poles only: cauchy_naive;
+//                 S4GenArgs::symmetric adds the conjugate half conj(v_ab,n) / (z - conj(w_n)) like cauchy_conj / the CUDA extension)
 //                 k_f = (r00 - r01 r10 / (1 + r11)) * 2/(1+omega);  k = irfft(k_f, L)
 // evaluated here in the algebraically identical Nyquist-safe form (u = 1+omega):
 //     s_ab = dt * sum_n v_ab,n / (2(1-omega) - w_n u);   k_f = 2 (s00 - u s01 s10 / (1 + u s11))
@@ -63,6 +64,15 @@ __global__ __launch_bounds__(256) void s4_kernel_gen_kernel(const S4GenArgs a) {
             s01 = cadd(s01, cmul(pv01[nn], inv));
             s10 = cadd(s10, cmul(pv10[nn], inv));
             s11 = cadd(s11, cmul(pv11[nn], inv));
+            if (a.symmetric) {                  // the conjugate half: conj(v) / (z - conj(w))
+                const cf den2 = csub(a2, cmul(cconj(pw[nn]), u));
+                const float dd2 = den2.x * den2.x + den2.y * den2.y;
+                const cf inv2{den2.x / dd2, -den2.y / dd2};
+                s00 = cadd(s00, cmul(cconj(pv00[nn]), inv2));
+                s01 = cadd(s01, cmul(cconj(pv01[nn]), inv2));
+                s10 = cadd(s10, cmul(cconj(pv10[nn]), inv2));
+                s11 = cadd(s11, cmul(cconj(pv11[nn]), inv2));
+            }
         }
         s00 = cf{s00.x * dt, s00.y * dt}; s01 = cf{s01.x * dt, s01.y * dt};
         s10 = cf{s10.x * dt, s10.y * dt}; s11 = cf{s11.x * dt, s11.y * dt};

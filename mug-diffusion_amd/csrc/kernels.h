@@ -215,6 +215,9 @@ struct S4GenArgs {
     int H, N, Lint, L;
     float* kf;       // workspace (H, Lint/2+1, 2)
     float* k;        // out (H, L)
+    int symmetric;   // 0: Cauchy sum over the N stored poles only (cauchy_naive, s4.py:140-147 -- what the reference runs without
+                     //    pykeops / its CUDA extension); 1: both conjugate halves, sum_n v/(z-w) + conj(v)/(z-conj(w)) (cauchy_conj,
+                     //    s4.py:55-77, and the extension's symmetric=True) -- what a checkpoint trained with either backend expects
 };
 void launch_s4_kernel_gen(hipStream_t st, const S4GenArgs& a);
 

@@ -713,7 +713,7 @@ Tensor Net::upsample(const std::string& prefix, const Tensor& x) {        // mod
 }
 
 const float* Net::s4_kernel(const std::string& kp, int H, int L) {
-    const std::string key = kp + "#" + std::to_string(L);
+    const std::string key = kp + "#" + std::to_string(L) + (ctx->s4_symmetric ? "s" : "");
     auto it = baked.find(key);
     if (it != baked.end()) return it->second;
     const Param& pl = P(kp + ".L");
@@ -728,7 +728,7 @@ const float* Net::s4_kernel(const std::string& kp, int H, int L) {
     MUGD_CHECK(pc.numel() == (long long)H * N * 2, -2, "S4: unexpected C shape at " + kp);
     float* k = dev_alloc((size_t)H * L);
     S4GenArgs a{PF(kp + ".C"), PF(kp + ".B"), PF(kp + ".P"), PF(kp + ".inv_w_real"), PF(kp + ".w_imag"), PF(kp + ".log_dt"),
-                H, N, (int)Lst, L, nullptr, k};
+                H, N, (int)Lst, L, nullptr, k, ctx->s4_symmetric ? 1 : 0};
     launch_s4_kernel_gen(ctx->stream, a);
     return baked[key] = k;
 }

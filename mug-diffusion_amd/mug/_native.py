@@ -53,6 +53,7 @@ _SIGS = {
     "mugd_order_before": [_p, _p],
     "mugd_set_graph_mode": [_p, _i],
     "mugd_set_conv_tiling": [_p, _i, _i],
+    "mugd_set_s4_symmetric": [_p, _i],
     "mugd_unet_create": [_p, C.POINTER(UNetConfig), C.POINTER(_p)],
     "mugd_vae_create": [_p, C.POINTER(VaeConfig), C.POINTER(_p)],
     "mugd_wave_create": [_p, C.POINTER(WaveConfig), C.POINTER(_p)],
@@ -100,7 +101,7 @@ class MugdError(RuntimeError):
 
 
 _UNORDERED = {"mugd_create", "mugd_destroy", "mugd_net_destroy", "mugd_last_error", "mugd_version", "mugd_profile_kind_name",
-              "mugd_order_after", "mugd_order_before", "mugd_set_graph_mode", "mugd_set_conv_tiling", "mugd_remove_mini_jacks"}
+              "mugd_order_after", "mugd_order_before", "mugd_set_graph_mode", "mugd_set_conv_tiling", "mugd_set_s4_symmetric", "mugd_remove_mini_jacks"}
 
 
 class _OrderedDll:
@@ -179,6 +180,11 @@ class Lib:
 
     def set_graph_mode(self, on):
         self.check(self.dll.mugd_set_graph_mode(self.ctx, 1 if on else 0))
+
+    def set_s4_symmetric(self, on):
+        """Cauchy sum over both conjugate halves of the S4 poles (reference: pykeops / CUDA-extension backends) instead of the
+        stored half only (reference: cauchy_naive).  Affects S4 kernels baked afterwards."""
+        self.check(self.dll.mugd_set_s4_symmetric(self.ctx, 1 if on else 0))
 
     def set_conv_tiling(self, wk=0, tn=0):
         """Force the conv_gemm K-split / tile width (0 = per-layer choice); affects networks compiled afterwards."""

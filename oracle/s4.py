@@ -25,7 +25,7 @@ def _omega_ref(L):
     return omega, z
 
 
-def s4_kernel(sd, p, L, mode="reference"):
+def s4_kernel(sd, p, L, mode="reference", symmetric=False):
     """Convolution kernel k (H, L) of the SSM whose parameters live under
     `p` = '<...>.s4_model.kernel.kernel'.
 
@@ -56,6 +56,12 @@ def s4_kernel(sd, p, L, mode="reference"):
         v = Bs.unsqueeze(-3) * Cs.unsqueeze(-4)                # (2,2,H,N)
         # cauchy_naive s4.py:140-147
         r = (v.unsqueeze(-1) / (z.unsqueeze(-2) - wdt.unsqueeze(-1))).sum(dim=-2)   # (2,2,H,Lf)
+        if symmetric:
+            # cauchy_conj (pykeops, s4.py:55-77): 2 sum_n (z Re v - Re(v conj w)) / ((z - w)(z - conj w)), the sum over BOTH
+            # conjugate halves; written out exactly as the Genred expression, in complex64
+            zz, ww, vv = z.unsqueeze(-2), wdt.unsqueeze(-1), v.unsqueeze(-1)
+            num = zz * vv.real - (vv * ww.conj()).real
+            r = 2 * (num / ((zz - ww) * (zz - ww.conj()))).sum(dim=-2)
         r = r * dt[None, None, :, None]
         k_f = r[:-1, :-1] - r[:-1, -1:] * r[-1:, :-1] / (1 + r[-1:, -1:])
         k_f = k_f * 2 / (1 + omega)
@@ -70,8 +76,11 @@ def s4_kernel(sd, p, L, mode="reference"):
     a = 2 * (1 - omega)
     wdt = w * dt[:, None]
     den = a[None, None, :] - wdt[:, :, None] * u[None, None, :]          # (H,N,Lf)
+    den_c = a[None, None, :] - wdt.conj()[:, :, None] * u[None, None, :]
     def S(x, y):
-        return ((x * y)[0][:, :, None] * dt[:, None, None] / den).sum(dim=1)   # (H,Lf)
+        xy = (x * y)[0][:, :, None] * dt[:, None, None]
+        r = (xy / den).sum(dim=1)                                                # (H,Lf)
+        return r + (xy.conj() / den_c).sum(dim=1) if symmetric else r
     s00, s01, s10, s11 = S(Bc, Cc), S(Bc, Pc.conj()), S(Pc, Cc), S(Pc, Pc.conj())
     k_f = 2 * (s00 - u[None] * s01 * s10 / (1 + u[None] * s11))
     k = torch.fft.irfft(k_f, n=Lint)[..., :L]

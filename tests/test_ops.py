@@ -199,6 +199,29 @@ def test_s4_kernel(lib, H, Lint, L):
     close(got, ref, 3e-5, what="s4 kernel vs reference arithmetic")
 
 
+@pytest.mark.parametrize("H,Lint,L", [(32, 32, 32), (64, 96, 96)])
+def test_s4_kernel_symmetric_cauchy(lib, H, Lint, L):
+    """mugd_set_s4_symmetric(1): the Cauchy sum over both conjugate halves of the poles -- the reference's pykeops backend
+    (cauchy_conj, s4.py:55-77: 2 sum (z Re v - Re(v conj w)) / ((z - w)(z - conj w))) written out in torch inside the oracle's
+    reference-arithmetic path, and the fp64 evaluation of the same sum; the default (cauchy_naive) must differ from it."""
+    sd = s4_params(H, Lint)
+    p = "s.kernel.kernel"
+    args = (sd[p + ".C"], sd[p + ".B"], sd[p + ".P"], sd[p + ".inv_w_real"], sd[p + ".w_imag"], sd[p + ".log_dt"], Lint, L)
+    naive = lib.op_s4_kernel(*args).cpu()
+    lib.set_s4_symmetric(True)
+    try:
+        got = lib.op_s4_kernel(*args).cpu()
+    finally:
+        lib.set_s4_symmetric(False)
+    exact = s4o.s4_kernel(sd, p, L, "exact", symmetric=True)
+    ref = s4o.s4_kernel(sd, p, L, "reference", symmetric=True)
+    e_hip, e_ref = (got - exact).abs().max().item(), (ref - exact).abs().max().item()
+    assert e_hip < max(4 * e_ref, 2e-5), (e_hip, e_ref)
+    close(got, ref, 3e-5, what="symmetric s4 kernel vs the pykeops formula")
+    assert (got - naive).abs().max().item() > 1e-3 * naive.abs().max().item()      # the two backends are NOT the same function (SURVEY D10)
+    assert torch.equal(lib.op_s4_kernel(*args).cpu(), naive)                        # switch restored
+
+
 @pytest.mark.parametrize("B,H,L", [(2, 32, 40), (1, 48, 300), (5, 8, 64), (2, 8, 128), (3, 4, 256), (1, 4, 512), (2, 4, 12), (1, 4, 1),
                                    (1, 3, 816), (1, 2, 1632), (1, 2, 2048), (1, 2, 2100)])
 def test_s4_conv(lib, B, H, L):
