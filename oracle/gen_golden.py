@@ -349,8 +349,44 @@ def postprocess_goldens():
     print("  postprocess goldens: %d charts, oracle restatement identical" % len(out))
 
 
+def masked_goldens():
+    """Inpainting / partial regeneration: DDIMSampler.sample(mask=, x0=) of the REAL reference
+    (ddim.py:141-144: x = q_sample(x0, t) * mask + (1 - mask) * x before every step), seeded CPU generator.  The RNG
+    consumption per step is q_sample's randn_like(x0) followed by p_sample_ddim's randn(shape) (drawn although eta = 0)."""
+    from mug.diffusion.ddim import DDIMSampler
+    for case, z, S, B in ((cases.TINY, 32, 4, 2), (cases.FULL, 96, 10, 1)):
+        tag = case["name"]
+        model = ref_model(case)
+        man = weights.load_manifest(os.path.join(G, case["manifest"]))
+        sd = weights.set_s4_lengths(weights.make_state_dict(man, seed=0), case["unet"], z)
+        model.load_state_dict(sd)
+        fy = cases.feature_yaml()
+        prompts = [{"sr": 4.0, "rank_status": "ranked"}, {"sr": 2.5, "ln_ratio": 0.4}][:B]
+        ids = torch.tensor([host.feature_ids(pm, fy) for pm in prompts], dtype=torch.float32)
+        c = model.model.cond_stage_model(ids)
+        mel = cases.mel_input(case, 11 + z, 1, z * case["audio_ratio"])
+        wl = [wi.repeat(B, 1, 1) for wi in model.model.wave_model(mel)]
+        seed = 900 + z
+        xT = cases.x_T(seed, B, z)
+        x0 = cases.randn(seed, 5, (B, 16, z))
+        mask = torch.zeros(B, 16, z)
+        mask[:, :, : z // 2] = 1.0                                   # keep the first half of the chart, regenerate the rest
+        model.z_length = z
+        torch.manual_seed(seed)
+        lat, _ = DDIMSampler(model).sample(S=S, c=c, w=wl, batch_size=B, eta=0.0, verbose=False, x_T=xT, mask=mask, x0=x0,
+                                           tqdm_class=lambda it, **k: it)
+        dec = model.model.decode(lat)
+        note("%s masked ddim z=%d S=%d latent |ref|max" % (tag, z, S), lat.abs().max().item())
+        np.savez_compressed(os.path.join(G, "%s_ddim_masked_z%d_S%d_B%d.npz" % (tag, z, S, B)), seed=seed, ids=ids.numpy(),
+                            latent=lat.numpy(), logits=dec.numpy(), mel_seed=11 + z)
+        del model
+
+
 def main():
     torch.set_num_threads(os.cpu_count())
+    if "--masked-only" in sys.argv:
+        masked_goldens()
+        return
     if "--postprocess-only" in sys.argv:
         postprocess_goldens()
         return
@@ -363,6 +399,7 @@ def main():
     host_goldens()
     s4_host_goldens()
     postprocess_goldens()
+    masked_goldens()
     run_case(cases.TINY, [32], {32: [(4, 2, 1.0), (4, 2, 5.0)]})
     if "--tiny-only" not in sys.argv:
         run_case(cases.FULL, [96, 512], {96: [(10, 1, 1.0), (10, 1, 5.0)]})

@@ -247,6 +247,49 @@ def test_sampler_call_paths_agree_and_inpainting_round_trip(as_default_lib):
     assert torch.equal(after, torch.randn(4, device=dev))
 
 
+@pytest.mark.parametrize("which", ["tiny", pytest.param("full", marks=pytest.mark.gpu)])
+def test_masked_sampling_vs_reference_golden(as_default_lib, monkeypatch, which):
+    """Inpainting path (ddim.py:141-144) against the REAL reference's DDIMSampler.sample(mask=, x0=) output (oracle/gen_golden.py
+    --masked-only): same seed, same generator consumption (q_sample's randn_like, then the step's randn, every step).  The
+    reference drew from the CPU generator; on the GPU the draws are routed through it too so the streams coincide."""
+    from mug.diffusion.ddim import DDIMSampler
+    lib = as_default_lib
+    case, z, S, B = (cases.TINY, 32, 4, 2) if which == "tiny" else (cases.FULL, 96, 10, 1)
+    if which == "full" and lib.device.type != "cuda":
+        pytest.skip("the full-size networks only run on the GPU build")
+    g = np.load(os.path.join(G, "%s_ddim_masked_z%d_S%d_B%d.npz" % (case["name"], z, S, B)))
+    model = build(case)
+    man = weights.load_manifest(os.path.join(G, case["manifest"]))
+    model.load_state_dict(weights.set_s4_lengths(weights.make_state_dict(man, seed=0), case["unet"], z))
+    model = model.to(lib.device)
+    dev = lib.device
+    if dev.type == "cuda":
+        real_randn, real_like = torch.randn, torch.randn_like
+        monkeypatch.setattr(torch, "randn", lambda *a, device=None, **k: real_randn(*a, **k).to(device) if device is not None else real_randn(*a, **k))
+        monkeypatch.setattr(torch, "randn_like", lambda t, **k: real_randn(t.shape, dtype=t.dtype).to(t.device))
+    c = model.model.cond_stage_model(torch.from_numpy(g["ids"]).to(dev))
+    mel = cases.mel_input(case, int(g["mel_seed"]), 1, z * case["audio_ratio"]).to(dev)
+    w = model.model.wave_model(mel)
+    seed = int(g["seed"])
+    xT, x0 = cases.x_T(seed, B, z).to(dev), cases.randn(seed, 5, (B, 16, z)).to(dev)
+    mask = torch.zeros(B, 16, z, device=dev)
+    mask[:, :, : z // 2] = 1.0
+    model.z_length = z
+    torch.manual_seed(seed)
+    lat, _ = DDIMSampler(model).sample(S=S, c=c, w=w, batch_size=B, eta=0.0, verbose=False, x_T=xT, mask=mask, x0=x0,
+                                       tqdm_class=lambda it, **k: it)
+    ref = torch.from_numpy(g["latent"])
+    d = (lat.cpu() - ref).abs().max().item()
+    print("masked ddim %s: latent max|diff| %.3e (ref max %.3e)" % (which, d, ref.abs().max().item()))
+    assert d < 2e-3 * max(1.0, ref.abs().max().item())
+    logits = model.model.decode(lat).cpu().numpy()
+    gs, gh = host.note_grid(logits)
+    rs, rh = host.note_grid(g["logits"])
+    flips = np.concatenate([(gs != rs).ravel(), (gh != rh).ravel()])
+    refv = np.concatenate([g["logits"][..., 0:4, :].ravel(), g["logits"][..., 8:12, :].ravel()])
+    assert not flips.any() or np.abs(refv[flips]).max() < 2e-3
+
+
 def test_audio_ingest_resamples_on_the_device_when_only_soundfile_is_present(as_default_lib, monkeypatch, tmp_path):
     """mug.util.load_audio_without_cache (mug/util.py:133-144 of the reference) without librosa: the file is decoded by
     soundfile at its native rate (stereo 44.1 kHz here), mixed down, cut to max_duration, converted to 22.05 kHz by
