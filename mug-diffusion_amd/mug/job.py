@@ -1,0 +1,170 @@
+"""Headless sampling job: what scripts/mapping.py:444-505 of the reference does for one audio and `n_samples`
+seeds, generalised to a work list of independent (audio, seed, prompt) UNITS spread over the GPUs of a node
+(BASELINE configs[2]).
+
+    units  -> shard.partition by rank (units of one audio stay adjacent: its mel + wave-encode run once per rank)
+           -> per audio: length rule (webui.py:349-356), pad / truncate the mel (:358-367), wave encoder (batch 1)
+           -> per launch: up to `batch` seeds; with `pack_songs` = 2, two audios of the same latent length share ONE
+              batch-2N launch (rows interleaved so that row b reads audio map b % 2: ConvSeg::bmod) -- the DDIM loop
+              is launch-latency bound at batch 4, so a batch-8 launch costs ~1.4x a batch-4 one
+           -> DDIM (one native call) -> VAE decode -> note grid (logit > 0)
+           -> optional: gridify / mini-jack pass / .osu files (mug.data, the reference's own order: mapping.py:496-499)
+           -> one all_gather of the bit-packed note grids at the end (the job's only collective)
+
+No CPU fallback anywhere: the networks are the libmugd-backed mirror classes.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import shard
+
+
+def z_length_for(frames, max_audio_frame=32768, z_length=512):
+    """webui.py:349-356: ratio = max_audio_frame // z_length (64 mel frames per latent step);
+    z = (int(frames / ratio / 32) + 1) * 32 -- the next multiple of 32 STRICTLY above frames / ratio."""
+    ratio = max_audio_frame // z_length
+    return (int(frames / ratio / 32) + 1) * 32
+
+
+def fit_mel(mel, z, ratio=64):
+    """webui.py:358-367: zero-pad or truncate the (n_mels, frames) log-mel to z * ratio frames."""
+    t, tgt = mel.shape[-1], z * ratio
+    if t < tgt:
+        return torch.nn.functional.pad(mel, (0, tgt - t))
+    return mel[..., :tgt]
+
+
+def note_grid(logits):
+    """convertor.py:212-216: channels 0..3 = note starts, 8..11 = holds; a cell is on where its logit is > 0."""
+    return torch.cat([logits[:, 0:4] > 0, logits[:, 8:12] > 0], dim=1)
+
+
+class Unit(dict):
+    """One chart to generate: audio (key into the job's audio table), seed, prompt (feature dict)."""
+
+
+def make_units(n_audio, seeds_per_audio, prompts=None, seed0=0):
+    prompts = prompts or [{}]
+    return [Unit(audio=a, seed=seed0 + a * seeds_per_audio + s, prompt=prompts[(a * seeds_per_audio + s) % len(prompts)])
+            for a in range(n_audio) for s in range(seeds_per_audio)]
+
+
+def _x_T(seed, z, channels=16):
+    return torch.randn((channels, z), generator=torch.Generator(device="cpu").manual_seed(int(seed)))
+
+
+def run_job(model, sampler, units, mel_of, feature_yaml, steps=50, scale=1.0, eta=0.0, batch=4, pack_songs=1,
+            max_audio_frame=32768, z_length_cfg=512, group=None, gather=True, on_chart=None, tqdm_class=None):
+    """Runs this rank's share of `units` and returns (grids, stats).
+
+    model / sampler : the drop-in DDPM and its DDIMSampler (mug.diffusion)
+    mel_of(audio)   : -> (n_mels, frames) fp32 device tensor, the log-mel of that audio (mug.util.pcm_to_log_mel / file loader)
+    grids           : list over ALL units (gather=True, every rank) or this rank's units: bool (8, 8 z) tensors
+    on_chart(unit_index, unit, logits_row) : optional sink for post-processing / file writing (runs on the owning rank)
+    """
+    from .util import feature_dict_to_embedding_ids
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    mine = list(shard.partition(len(units), world, rank))
+    dev = next(model.parameters()).device
+    ratio = max_audio_frame // z_length_cfg
+    # ---- per audio: mel -> z -> wave-encoder maps (batch 1), once per rank
+    audio_of = {}
+    for u in mine:
+        a = units[u]["audio"]
+        if a not in audio_of:
+            mel = mel_of(a)
+            z = z_length_for(mel.shape[-1], max_audio_frame, z_length_cfg)
+            w = model.model.wave_model(fit_mel(mel, z, ratio)[None].to(dev))
+            audio_of[a] = dict(z=z, w=w, units=[])
+        audio_of[a]["units"].append(u)
+    # ---- launches: chunks of <= batch seeds per audio; pairs of equal-length audios packed into one launch
+    chunks = []
+    for a, rec in audio_of.items():
+        for i in range(0, len(rec["units"]), batch):
+            chunks.append((a, rec["units"][i:i + batch]))
+    launches, used = [], [False] * len(chunks)
+    for i, (a, us) in enumerate(chunks):
+        if used[i]:
+            continue
+        used[i] = True
+        group_ = [(a, us)]
+        if pack_songs > 1:
+            for j in range(i + 1, len(chunks)):
+                b, vs = chunks[j]
+                if len(group_) < pack_songs and not used[j] and b != a and len(vs) == len(us) and audio_of[b]["z"] == audio_of[a]["z"] \
+                        and all(b != g[0] for g in group_):
+                    used[j] = True
+                    group_.append((b, vs))
+        launches.append(group_)
+    grids = {}
+    n_launch = 0
+    for group_ in launches:
+        z = audio_of[group_[0][0]]["z"]
+        ns, per = len(group_), len(group_[0][1])
+        # batch row r = seed (r // ns) of song (r % ns): the U-Net reads audio map row b % ns
+        order = [group_[r % ns][1][r // ns] for r in range(ns * per)]
+        w = [torch.cat([audio_of[a]["w"][l] for a, _ in group_], dim=0) for l in range(len(audio_of[group_[0][0]]["w"]))]
+        ids = torch.tensor([feature_dict_to_embedding_ids(units[u]["prompt"], feature_yaml) for u in order], dtype=torch.float32, device=dev)
+        c = model.model.cond_stage_model(ids)
+        uc = None
+        if scale != 1.0:
+            uc = model.model.cond_stage_model(torch.tensor([feature_dict_to_embedding_ids({}, feature_yaml)] * len(order),
+                                                           dtype=torch.float32, device=dev))
+        x_T = torch.stack([_x_T(units[u]["seed"], z) for u in order]).to(dev)
+        model.z_length = z
+        lat, _ = sampler.sample(S=steps, c=c, w=w, batch_size=len(order), eta=eta, verbose=False, x_T=x_T,
+                                unconditional_guidance_scale=scale, unconditional_conditioning=uc,
+                                tqdm_class=tqdm_class or (lambda it, **k: it))
+        logits = model.model.decode(lat)
+        g = note_grid(logits)
+        for r, u in enumerate(order):
+            grids[u] = g[r]
+            if on_chart is not None:
+                on_chart(u, units[u], logits[r])
+        n_launch += 1
+    stats = dict(rank=rank, world=world, units=len(mine), audios=len(audio_of), launches=n_launch)
+    if not gather or world == 1:
+        return [grids[u].cpu() for u in mine] if world > 1 else [grids[u].cpu() for u in range(len(units))], stats
+    # ---- end of job: every rank gets every chart's grid.  Lengths differ per audio: gather them first (one int per unit),
+    # pad the bit-packed rows to the longest, gather once
+    T_local = torch.tensor([grids[u].shape[-1] for u in mine], dtype=torch.int64)
+    per = -(-len(units) // world)
+    tb = torch.zeros(per, dtype=torch.int64)
+    tb[: len(mine)] = T_local
+    backend_dev = dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    tl = [torch.empty_like(tb, device=backend_dev) for _ in range(world)]
+    dist.all_gather(tl, tb.to(backend_dev), group=group)
+    T_all = torch.cat([tl[r][: len(shard.partition(len(units), world, r))].cpu() for r in range(world)])
+    Tmax = int(T_all.max().item()) if len(units) else 0
+    local = torch.zeros((len(mine), 8, Tmax), dtype=torch.bool)
+    for i, u in enumerate(mine):
+        local[i, :, : grids[u].shape[-1]] = grids[u].cpu()
+    full = shard.gather_grids(local, len(units), group=group, device=backend_dev if backend_dev.type == "cuda" else None)
+    return [full[u, :, : int(T_all[u])] for u in range(len(units))], stats
+
+
+def chart_writer(outdir, template_osu, frame_ms, max_frame, audio_path=None, creator="MuG Diffusion", jack_interval=90, lib=None):
+    """on_chart sink: logits -> hit objects -> mini-jack pass -> gridify -> .osu next to a copy of the audio, in the
+    reference CLI's order (scripts/mapping.py:487-505).  Returns (callback, written_paths)."""
+    from .data import convertor, utils as du
+    os.makedirs(outdir, exist_ok=True)
+    written = []
+
+    def custom_gridify(hit_objects):
+        hit_objects = du.remove_intractable_mania_mini_jacks(hit_objects, verbose=False, jack_interval=jack_interval, lib=lib)
+        hit_objects, bpm, offset = du.gridify(hit_objects, verbose=False, lib=lib)
+        return bpm, offset, hit_objects
+
+    def on_chart(index, unit, logits_row):
+        params = dict(frame_ms=frame_ms, max_frame=max_frame, from_logits=True)
+        _, meta = convertor.parse_osu_file(template_osu, params)
+        path = os.path.join(outdir, "chart_%04d_seed%d.osu" % (index, unit["seed"]))
+        convertor.save_osu_file(meta, logits_row.detach().cpu().numpy(), path=path,
+                                override={"Version": "AI v%d" % (index + 1), "Creator": creator}, gridify=custom_gridify)
+        written.append(path)
+
+    return on_chart, written
