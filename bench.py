@@ -95,6 +95,10 @@ def main():
                          "device inside every timed step.  22050 skips the conversion")
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--cfg-scale", type=float, default=1.0, help="1.0 = no guidance (scripts/mapping.py default); webui default is 5.0")
+    ap.add_argument("--audios-per-rank", type=int, default=1, help="audios per rank and step (each with --batch seeds): 2 with --pack-songs 2 = the throughput mode; "
+                                                                    "--gpus 8 --audios-per-rank 2 = BASELINE configs[2] (64 units)")
+    ap.add_argument("--pack-songs", type=int, default=1, help="2: two audios of equal length share one batch-2B U-Net launch (mug/job.py)")
+    ap.add_argument("--no-throughput-mode", action="store_true", help="skip the extra 2-songs-per-launch measurement (N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (torch scales badly past ~16 on these small tensors)")
@@ -136,40 +140,45 @@ def main():
     sampler = DDIMSampler(model)
     note("model instantiated, seeded and moved to %s" % dev)
 
+    from mug import job, shard
     B, S, sr, hop = a.batch, a.ddim_steps, SHIPPED["sr"], SHIPPED["n_fft"] // 4
-    pcm_in = torch.from_numpy(synth_audio(a.seconds, a.audio_sr, seed=rank)).to(dev)   # resident before the timed region
-    pcm = lib.resample_poly(pcm_in, sr, a.audio_sr)                                   # (length rule only; redone in every step)
     with open(FEATURE_YAML) as f:
         fy = yaml.safe_load(f)
     prompts = [{"sr": 4.0, "rank_status": "ranked"}, {"sr": 2.5, "ln_ratio": 0.4}, {"sr": 6.0, "ln": 1}, {"sr": 3.2}]
-    ids = torch.tensor([feature_dict_to_embedding_ids(prompts[i % 4], fy) for i in range(B)], dtype=torch.float32, device=dev)
-    uc_ids = torch.tensor([feature_dict_to_embedding_ids({}, fy)] * B, dtype=torch.float32, device=dev)
-    ratio = SHIPPED["max_audio_frame"] // z_cfg
-    frames = 1 + pcm.numel() // hop
-    z = (int(frames / ratio / 32) + 1) * 32                     # webui.py:349-356
-    model.z_length = z
-    gens = [torch.Generator(device="cpu").manual_seed(1000 * rank + i) for i in range(B)]
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ddim_ms = []
+    # The work list (BASELINE configs[2] shape): `units_per_rank` (audio, seed) units per rank, B seeds per audio, partitioned
+    # by mug/shard.py so that the seeds of one audio stay on one rank.  Default = one audio x B seeds per rank and step
+    # (configs[1] on every GPU: weak scaling).  Every rank's PCM is resident in HBM before the timed region.
+    n_audio = world * a.audios_per_rank
+    units = job.make_units(n_audio, B, prompts=prompts, seed0=1000)
+    mine = shard.partition(len(units), world, rank)
+    my_audios = sorted(set(units[u]["audio"] for u in mine))
+    pcm_in = {au: torch.from_numpy(synth_audio(a.seconds, a.audio_sr, seed=au)).to(dev) for au in my_audios}
 
-    def one_step():
-        pcm = lib.resample_poly(pcm_in, sr, a.audio_sr) if a.audio_sr != sr else pcm_in     # 44.1 kHz -> 22.05 kHz, polyphase FIR
-        mel = lib.log_mel(pcm, sr=sr, n_fft=SHIPPED["n_fft"], hop=hop, n_mels=SHIPPED["n_mels"])   # (128, frames), fp16-rounded
-        t = mel.shape[1]
-        tgt = z * ratio
-        mel = torch.nn.functional.pad(mel, (0, tgt - t)) if t < tgt else mel[:, :tgt]               # webui.py:358-367
-        w = model.model.wave_model(mel[None])                    # once per song; the B seeds share the maps
-        c = model.model.cond_stage_model(ids)
-        uc = model.model.cond_stage_model(uc_ids) if a.cfg_scale != 1.0 else None
-        x_T = torch.stack([torch.randn((16, z), generator=g) for g in gens]).to(dev)
-        ev0.record()
-        lat, _ = sampler.sample(S=S, c=c, w=w, batch_size=B, eta=0.0, verbose=False, x_T=x_T,
-                                unconditional_guidance_scale=a.cfg_scale, unconditional_conditioning=uc,
-                                tqdm_class=lambda *aa, **kk: None)
-        ev1.record()
-        logits = model.model.decode(lat)
-        grid = torch.cat([logits[:, 0:4] > 0, logits[:, 8:12] > 0], dim=1)       # convertor.py:212-216
-        return grid, (ev0, ev1)
+    def mel_of(au):
+        pcm = lib.resample_poly(pcm_in[au], sr, a.audio_sr) if a.audio_sr != sr else pcm_in[au]    # 44.1 kHz -> 22.05 kHz, polyphase FIR
+        return lib.log_mel(pcm, sr=sr, n_fft=SHIPPED["n_fft"], hop=hop, n_mels=SHIPPED["n_mels"])     # (128, frames), fp16-rounded
+
+    z = job.z_length_for(1 + int(round(a.seconds * sr)) // hop, SHIPPED["max_audio_frame"], z_cfg)   # webui.py:349-356
+    ddim_ms, ev = [], [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+
+    class _Timed:        # the DDIM loop alone (sampler.sample) for the U-Net steps/s figure: events on torch's stream around it
+        def __init__(self, inner):
+            self.inner = inner
+            self.ddim_timesteps = None
+
+        def sample(self, **kw):
+            ev[0].record()
+            r = self.inner.sample(**kw)
+            ev[1].record()
+            self.ddim_timesteps = self.inner.ddim_timesteps
+            return r
+
+    timed = _Timed(sampler)
+
+    def one_step(pack=1):
+        grids, stats = job.run_job(model, timed, units, mel_of, fy, steps=S, scale=a.cfg_scale, eta=0.0, batch=B, pack_songs=pack,
+                                   max_audio_frame=SHIPPED["max_audio_frame"], z_length_cfg=z_cfg, gather=False)
+        return grids, stats
 
     def sync_all():
         if world > 1:
@@ -177,33 +186,32 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(a.warmup):
-        one_step()
+        one_step(a.pack_songs)
         torch.cuda.synchronize()
         note("warmup step %d done" % i)
     sync_all()
     t0 = time.perf_counter()
-    notes = 0
     for _ in range(a.steps):
-        grid, _ = one_step()
+        grids, stats = one_step(a.pack_songs)
     if world > 1:                       # the job's only data movement between ranks: note grids (8 x T bits per chart) to every rank
-        from mug import shard
-        all_grids = shard.gather_grids(grid, world * B, device=dev)
-        assert all_grids.shape[0] == world * B
+        all_grids = shard.gather_grids(torch.stack(grids), len(units), device=dev)
+        assert all_grids.shape[0] == len(units)
     torch.cuda.synchronize()
-    ddim_ms.append(ev0.elapsed_time(ev1))
+    ddim_ms.append(ev[0].elapsed_time(ev[1]))
     sync_all()
     elapsed = time.perf_counter() - t0
-    note("timed region done: %.1f ms per step" % (elapsed / a.steps * 1e3))
-    notes = int(grid.sum().item())
+    note("timed region done: %.1f ms per step (%d launches per rank and step)" % (elapsed / a.steps * 1e3, stats["launches"]))
+    notes = int(sum(int(g.sum()) for g in grids))
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    Bl = B * (a.pack_songs if a.audios_per_rank >= a.pack_songs else 1)      # charts per U-Net launch
 
     out = None
     if rank == 0:
         n_unet_steps = len(sampler.ddim_timesteps)
-        charts = world * B * a.steps
+        charts = len(units) * a.steps
         out = {
             "metric": "charts_per_sec (3-min audio, %d DDIM steps, batch %d)" % (S, B),
             "value": charts / elapsed, "unit": "charts/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -213,9 +221,11 @@ def main():
                                    "mel + wave-encode (once per song, shared by the seeds) + DDIM + VAE decode + note grid"
                                    % (a.seconds, a.audio_sr / 1e3, "22.05 kHz (device polyphase resampler) ->" if a.audio_sr != sr else "",
                                       z, n_unet_steps, B, a.cfg_scale),
-                       "parallelism": "dp%d (independent (audio, seed) units per rank, no data-path collective)" % world,
+                       "parallelism": "dp%d: %d (audio, seed) units = %d audio(s) x %d seeds per rank, partitioned by mug/shard.py through the job driver "
+                                      "(mug/job.py); no data-path collective, one bit-packed all_gather of the note grids at the end" % (world, len(units), a.audios_per_rank, B),
+                       "songs_per_launch": a.pack_songs if a.audios_per_rank >= a.pack_songs else 1,
                        "weights": "seeded synthetic, shipped architecture (151 M params)"},
-            "unet_sample_steps_per_s": B * n_unet_steps * (2 if a.cfg_scale != 1.0 else 1) / (ddim_ms[-1] * 1e-3) * world,
+            "unet_sample_steps_per_s": Bl * n_unet_steps * (2 if a.cfg_scale != 1.0 else 1) / (ddim_ms[-1] * 1e-3) * world,
             "ddim_loop_ms": ddim_ms[-1], "notes_in_last_batch": notes,
         }
         if not a.no_roofline:
@@ -231,16 +241,22 @@ def main():
             gap_ms = max(0.0, (eager_ms - graph_ms) / max(launches, 1))
             conv_ms = k["ms"] - k["launches"] * gap_ms
             achieved = k["flops"] / (conv_ms * 1e-3) / 1e12
-            traffic = None                      # HBM bytes per conv_gemm launch from a separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass
+            # HBM-side bytes per conv_gemm launch cannot be measured from inside this process: they come from separate rocprofv3
+            # --pmc FETCH_SIZE / WRITE_SIZE passes over tests/gpu_unet_once.py (same program, same box class), whose summary is
+            # committed as profiles/conv_traffic.json -- reported with its source, not as a live figure
+            traffic, traffic_source = None, None
             tpath = os.path.join(ROOT, "profiles", "conv_traffic.json")
             if os.path.exists(tpath):
                 with open(tpath) as f:
-                    traffic = json.load(f).get("hbm_bytes_per_launch")
+                    tj = json.load(f)
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = "profiles/conv_traffic.json (%s): separate rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled " \
+                                 "per MI355X_MICROARCH.md; not measured by this run" % tj.get("round", "round 1 tree")
             out["roofline"] = {"kernel": "conv_gemm_kernel / conv_gemm16_kernel (fp32-MFMA implicit-GEMM conv1d / linear, 32x32 and 32x16 tiles; "
                                          "all %d launches of one U-Net evaluation, HIP events around every launch on the library stream, "
                                          "minus the calibrated inter-launch gap)" % k["launches"],
                                "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                               "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                                "launches_per_unet_eval": k["launches"], "avg_launch_us": conv_ms * 1e3 / max(k["launches"], 1),
                                "avg_launch_us_event_bracketed": k["ms"] * 1e3 / max(k["launches"], 1),
                                "event_gap_us_per_launch": gap_ms * 1e3,
@@ -248,6 +264,28 @@ def main():
                                "algorithmic_gflop_per_launch": k["flops"] / 1e9 / max(k["launches"], 1),
                                "by_kernel_ms": {n: round(v["ms"], 4) for n, v in prof.items()}}
         note("roofline probe done")
+        if world == 1 and not a.no_throughput_mode and a.pack_songs == 1 and a.audios_per_rank == 1:
+            # throughput mode, reported NEXT TO the batch-4 headline: two songs x B seeds share one batch-2B launch (the DDIM loop is
+            # launch-latency bound at batch 4).  Same pipeline through the same job driver, 2 timed passes.
+            units2 = job.make_units(2, B, prompts=prompts, seed0=1000)
+            pcm_in[1] = torch.from_numpy(synth_audio(a.seconds, a.audio_sr, seed=1)).to(dev)
+
+            def packed():
+                return job.run_job(model, timed, units2, mel_of, fy, steps=S, scale=a.cfg_scale, eta=0.0, batch=B, pack_songs=2,
+                                   max_audio_frame=SHIPPED["max_audio_frame"], z_length_cfg=z_cfg, gather=False)
+            packed()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            reps = 2
+            for _ in range(reps):
+                g2, st2 = packed()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / reps
+            out["throughput_mode"] = {"what": "2 songs x %d seeds per batch-%d U-Net launch (mug/job.py pack_songs=2), same pipeline" % (B, 2 * B),
+                                      "value": 2 * B / dt, "unit": "charts/s", "ms_per_launch_of_%d_charts" % (2 * B): dt * 1e3,
+                                      "ddim_loop_ms": ev[0].elapsed_time(ev[1]),
+                                      "unet_sample_steps_per_s": 2 * B * n_unet_steps / (ev[0].elapsed_time(ev[1]) * 1e-3), "launches": st2["launches"]}
+            note("throughput mode done: %.1f charts/s" % (2 * B / dt))
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a, z, n_unet_steps)
             note("cpu baseline done")
@@ -320,6 +358,9 @@ def cpu_baseline_worker(a):
     per_batch = t_mel + t_wave + n_steps * t_unet + t_dec
     print(json.dumps({
         "value": B / per_batch, "unit": "charts/s", "cores": nthr, "kind": "port",
+        "kind_detail": "oracle/ (PyTorch-CPU fp32 restatement, bit-identical to the reference on the golden fixtures); the GPU box has no "
+                       "/root/reference.  Conservative: the S4 kernels are cached here while the reference regenerates them in every U-Net "
+                       "call (s4.py:706-832); the unmodified reference timed in the authoring container: profiles/r2_reference_cpu_timing.json",
         "sample": "1 resample+mel (%.2fs) + 1 wave-encode B=1 (%.2fs) + %d U-Net evals B=%d z=%d (%.3fs each, S4 kernels cached) + 1 decode (%.2fs), "
                   "extrapolated to %d steps; PyTorch-CPU fp32, %d threads (host exposes %d)"
                   % (t_mel, t_wave, reps, B, z, t_unet, t_dec, n_steps, nthr, host_threads()),

@@ -296,6 +296,44 @@ def test_headline_workload_end_to_end_vs_oracle(gpu_lib):
     _net_cache.clear()
 
 
+@pytest.mark.gpu
+def test_ten_minute_audio_end_to_end_vs_oracle(gpu_lib):
+    """BASELINE configs[3] as the reference actually runs it (no chunking exists -- a 10-minute audio is ONE sequence,
+    webui.py:349-367): 104 448 mel frames -> wave encoder -> z = 1632, 10 DDIM steps, batch 1 -> VAE decode at 13 056 frames ->
+    note grid, against the oracle on the same seeded weights and inputs (long-sequence attention, S4 at L = 1632, every conv at
+    its longest T)."""
+    case, z, S, B = cases.FULL, 1632, 10, 1
+    sd = state_dict(case, z)
+    fy = cases.feature_yaml()
+    ids = torch.tensor([host.feature_ids({"sr": 5.0, "ln_ratio": 0.2}, fy)], dtype=torch.float32)
+    c = nets.cond_embed(sd, ids)
+    mel = cases.mel_input(case, 31, 1, z * case["audio_ratio"])
+    xT = cases.x_T(31, B, z)
+    nl = len(case["unet"]["channel_mult"])
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, threads))
+    try:
+        w_ref = nets.wave_encode(sd, case["wave"], mel)[-nl:]
+        lat_ref = sampler.ddim_sample(sd, case["unet"], S, c, w_ref, xT)
+        logits_ref = nets.vae_decode(sd, case["vae"], lat_ref)
+    finally:
+        torch.set_num_threads(threads)
+    w = native(gpu_lib, case, z, "wave").encode(mel)[-nl:]
+    for i in range(nl):
+        d, s_ = report("10-min wave map -%d" % (nl - i), w[i], w_ref[i])
+        assert d < 3e-4 * max(1.0, s_)
+    steps = sampler.ddim_step_scalars(sd["alphas_cumprod"].numpy(), S, 0.0)
+    lat = native(gpu_lib, case, z, "unet").ddim_sample(xT, c, w, [s["t"] for s in steps],
+                                                       [[s["a_t"], s["a_prev"], s["sigma"], s["sqrt_1m_at"]] for s in steps])
+    logits = native(gpu_lib, case, z, "vae").decode(lat)
+    d, s_ = report("10-min ddim z=1632 S=10 latent", lat, lat_ref)
+    assert d < 2e-3 * max(1.0, s_)
+    assert logits.shape[-1] == 8 * z
+    flips = grid_check(logits, logits_ref.numpy())
+    print("10-minute workload: %d of %d note cells differ" % (flips, 8 * z * 8))
+    _net_cache.clear()
+
+
 def test_one_handle_follows_changing_lengths_and_batches(lib):
     """webui.py:349-367 mutates z_length per audio and `count` per request: one native handle is recompiled for each
     (batch, length) and must give the same numbers as a fresh handle (program cache, row-sum block, baked S4 kernels)."""
