@@ -1,8 +1,9 @@
 // STFT -> mel front-end.  The reference delegates this to the third-party
 // librosa.feature.melspectrogram (mug/util.py:138-143; librosa is unpinned and not vendored);
-// this follows librosa's published algorithm (>= 0.10 defaults): centred frames with zero
-// padding n_fft/2, periodic Hann, power spectrum, Slaney mel filterbank (area-normalised),
-// then the reference's log1p and fp16 rounding.
+// this follows librosa's published algorithm (0.10.x defaults, named once in oracle/host.py: LIBROSA_TARGET): centred frames
+// with zero padding n_fft/2, periodic Hann, power spectrum, Slaney mel filterbank (area-normalised), then the reference's
+// log1p and fp16 rounding -- and librosa's PRECISION path: the window product and the FFT run in float64 (numpy's rfft of a
+// float64 frame), the spectrum is cast to complex64, and the power is |X|^2 formed in float32 as abs(X)**2.
 //
 //   stft_power : one workgroup = 32 consecutive frames; each frame is a radix-2 DIT FFT in LDS
 //                (n_fft/2 butterflies per stage across the 256 threads, twiddles from an LDS
@@ -25,13 +26,13 @@ constexpr int NFFT_MAX = 1024;
 
 __global__ __launch_bounds__(256) void stft_power_kernel(const float* pcm, long long n, int n_fft, int log2n, int hop,
                                                          int frames, int kpad, float* P) {
-    __shared__ float re[NFFT_MAX], im[NFFT_MAX];
-    __shared__ float twc[NFFT_MAX / 2], tws[NFFT_MAX / 2];
+    __shared__ double re[NFFT_MAX], im[NFFT_MAX];
+    __shared__ double twc[NFFT_MAX / 2], tws[NFFT_MAX / 2];
     __shared__ float tile[(NFFT_MAX / 2 + 1) * (FB + 1)];
     const int tid = threadIdx.x, half = n_fft >> 1, nb = half + 1;
     for (int i = tid; i < half; i += 256) {
-        float s, c;
-        sincospif(2.0f * (float)i / (float)n_fft, &s, &c);
+        double s, c;
+        sincospi(2.0 * (double)i / (double)n_fft, &s, &c);
         twc[i] = c;
         tws[i] = -s;                       // e^{-2 pi i k / N}
     }
@@ -42,15 +43,15 @@ __global__ __launch_bounds__(256) void stft_power_kernel(const float* pcm, long 
         // windowed, zero-padded (centred) frame, stored bit-reversed
         for (int i = tid; i < n_fft; i += 256) {
             const long long src = (long long)f * hop + i - half;
-            float v = 0.f;
+            double v = 0.0;
             if (f < frames && src >= 0 && src < n) {
-                float sw, cw;
-                sincospif(2.0f * (float)i / (float)n_fft, &sw, &cw);
-                v = pcm[src] * (0.5f - 0.5f * cw);      // periodic Hann
+                double sw, cw;
+                sincospi(2.0 * (double)i / (double)n_fft, &sw, &cw);
+                v = (double)pcm[src] * (0.5 - 0.5 * cw);      // periodic Hann in float64 (scipy get_window) x float32 sample
             }
             unsigned r = __builtin_bitreverse32((unsigned)i) >> (32 - log2n);
             re[r] = v;
-            im[r] = 0.f;
+            im[r] = 0.0;
         }
         __syncthreads();
         for (int s = 1; s <= log2n; ++s) {
@@ -58,15 +59,18 @@ __global__ __launch_bounds__(256) void stft_power_kernel(const float* pcm, long 
             for (int j = tid; j < half; j += 256) {
                 const int grp = j / mh, pos = j - grp * mh;
                 const int i0 = grp * m + pos, i1 = i0 + mh;
-                const float wr = twc[pos * tstep], wi = tws[pos * tstep];
-                const float xr = re[i1] * wr - im[i1] * wi, xi = re[i1] * wi + im[i1] * wr;
-                const float ur = re[i0], ui = im[i0];
+                const double wr = twc[pos * tstep], wi = tws[pos * tstep];
+                const double xr = re[i1] * wr - im[i1] * wi, xi = re[i1] * wi + im[i1] * wr;
+                const double ur = re[i0], ui = im[i0];
                 re[i0] = ur + xr; im[i0] = ui + xi;
                 re[i1] = ur - xr; im[i1] = ui - xi;
             }
             __syncthreads();
         }
-        for (int k = tid; k < nb; k += 256) tile[k * (FB + 1) + ff] = re[k] * re[k] + im[k] * im[k];
+        for (int k = tid; k < nb; k += 256) {          // complex64 cast, then numpy's abs(complex64) ** 2.0 in float32
+            const float a = hypotf((float)re[k], (float)im[k]);
+            tile[k * (FB + 1) + ff] = a * a;
+        }
     }
     __syncthreads();
     for (int i = tid; i < kpad * FB; i += 256) {

@@ -59,26 +59,36 @@ def mel_filterbank(sr=22050, n_fft=512, n_mels=128, fmin=0.0, fmax=None):
     return w.astype(np.float32)
 
 
+LIBROSA_TARGET = "librosa 0.10.x defaults (stft: center=True, pad_mode='constant', window='hann', dtype complex64; melspectrogram: power=2.0, " \
+                 "norm='slaney', htk=False)"     # the ONE place the restated third-party version is named (requirements.txt:8 does not pin it)
+
+
 def hann_periodic(n):
-    return (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n) / n)).astype(np.float32)
+    """scipy.signal.get_window('hann', n, fftbins=True): float64, periodic."""
+    return 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n) / n)
 
 
 def n_frames(n_samples, hop=128):
     return 1 + n_samples // hop
 
 
-def log_mel(y, sr=22050, n_fft=512, hop=128, n_mels=128, out_dtype=np.float16):
-    """load_audio_without_cache's arithmetic (mug/util.py:138-143) on mono float32 PCM
-    already at `sr`: (n_mels, 1 + len(y)//hop), log1p(power mel) cast to float16."""
+def log_mel(y, sr=22050, n_fft=512, hop=128, n_mels=128, out_dtype=np.float16, pad_mode="constant"):
+    """load_audio_without_cache's arithmetic (mug/util.py:138-143) on mono float32 PCM already at `sr`:
+    (n_mels, 1 + len(y)//hop), log1p(power mel) cast to float16.  PARITY UNPINNED against the reference (librosa is not
+    installed and the reference ships no fixture); restates LIBROSA_TARGET with librosa's own precision path:
+      stft      float64 window x float32 frame -> float64, rfft in double, result CAST to complex64   (librosa/core/spectrum.py: stft)
+      power     np.abs(complex64) ** 2.0 in float32                                                      (_spectrogram)
+      mel       float32 filterbank (filters.mel, Slaney) times float32 power                             (melspectrogram, einsum)
+    pad_mode: librosa >= 0.10 pads the centred frames with zeros ('constant'); 0.9 and older reflected ('reflect')."""
     y = np.asarray(y, dtype=np.float32)
     pad = n_fft // 2
-    yp = np.concatenate([np.zeros(pad, np.float32), y, np.zeros(pad, np.float32)])
+    yp = np.pad(y, (pad, pad), mode=pad_mode)
     nf = n_frames(len(y), hop)
-    win = hann_periodic(n_fft)
+    win = hann_periodic(n_fft)                                             # float64
     idx = np.arange(n_fft)[None, :] + hop * np.arange(nf)[:, None]
-    frames = yp[idx] * win[None, :]
-    spec = np.fft.rfft(frames.astype(np.float32), axis=1)
-    power = (spec.real.astype(np.float32) ** 2 + spec.imag.astype(np.float32) ** 2)
+    frames = yp[idx].astype(np.float64) * win[None, :]
+    spec = np.fft.rfft(frames, axis=1).astype(np.complex64)
+    power = np.abs(spec) ** 2.0                                            # float32
     mel = mel_filterbank(sr, n_fft, n_mels) @ power.T                      # (n_mels, nf) float32
     return np.log1p(mel).astype(out_dtype)
 

@@ -169,6 +169,7 @@ static inline float __fdividef(float a, float b) { return a / b; }
 static inline void sincospif(float x, float* s, float* c) {
     double a = (double)x * 3.14159265358979323846; *s = (float)sin(a); *c = (float)cos(a);
 }
+static inline void sincospi(double x, double* s, double* c) { const double a = x * 3.14159265358979323846; *s = sin(a); *c = cos(a); }
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
