@@ -99,6 +99,9 @@ def main():
                                                                     "--gpus 8 --audios-per-rank 2 = BASELINE configs[2] (64 units)")
     ap.add_argument("--pack-songs", type=int, default=1, help="2: two audios of equal length share one batch-2B U-Net launch (mug/job.py)")
     ap.add_argument("--no-throughput-mode", action="store_true", help="skip the extra 2-songs-per-launch measurement (N = 1 only)")
+    ap.add_argument("--weights", choices=["f32", "bf16"], default="f32", help="bf16: the reduced-precision mode (packed conv / linear weights in bfloat16; "
+                                                                                "NOT the reference's arithmetic) as the timed configuration")
+    ap.add_argument("--no-reduced-mode", action="store_true", help="skip the extra bf16-weight measurement (N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (torch scales badly past ~16 on these small tensors)")
@@ -131,6 +134,8 @@ def main():
     import yaml
 
     lib = get_lib()
+    if a.weights == "bf16":
+        lib.set_weight_precision(True)
     note("library loaded")
     model = instantiate_from_config(model_config()).eval()
     unet = model.model.unet_model
@@ -216,7 +221,8 @@ def main():
             "metric": "charts_per_sec (3-min audio, %d DDIM steps, batch %d)" % (S, B),
             "value": charts / elapsed, "unit": "charts/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if a.weights == "f32" else "bf16 weights, f32 activations / MFMA inputs after widening / accumulation (reduced-precision mode)",
+            "data": "synthetic",
             "config": {"workload": "configs[1]: %.0f s synthetic %.2f kHz audio -> %s z=%d, %d DDIM steps, batch %d, cfg_scale %g, "
                                    "mel + wave-encode (once per song, shared by the seeds) + DDIM + VAE decode + note grid"
                                    % (a.seconds, a.audio_sr / 1e3, "22.05 kHz (device polyphase resampler) ->" if a.audio_sr != sr else "",
@@ -286,6 +292,28 @@ def main():
                                       "ddim_loop_ms": ev[0].elapsed_time(ev[1]),
                                       "unet_sample_steps_per_s": 2 * B * n_unet_steps / (ev[0].elapsed_time(ev[1]) * 1e-3), "launches": st2["launches"]}
             note("throughput mode done: %.1f charts/s" % (2 * B / dt))
+        if world == 1 and not a.no_reduced_mode and a.weights == "f32" and a.pack_songs == 1 and a.audios_per_rank == 1:
+            # reduced-precision mode, reported separately (never the headline: the reference is fp32): bf16 weight storage, fp32 everything
+            # else; same pipeline, networks recompiled with re-packed weights
+            lib.set_weight_precision(True)
+            for m_ in model.modules():
+                if hasattr(m_, "_fp"):
+                    m_._fp = None                           # forces NativeModule.native() to hand the parameters over again (re-pack)
+            one_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            reps = 2
+            for _ in range(reps):
+                one_step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / reps
+            out["reduced_precision_mode"] = {"what": "conv / linear weights packed as bfloat16 (mugd_set_weight_precision), activations / accumulation fp32; "
+                                                     "parity bound: tests/test_nets.py::test_reduced_precision_mode_bf16_weights",
+                                             "dtype": "bf16 weights + f32", "value": len(units) / dt, "unit": "charts/s", "ms_per_step": dt * 1e3,
+                                             "ddim_loop_ms": ev[0].elapsed_time(ev[1]),
+                                             "unet_sample_steps_per_s": Bl * n_unet_steps / (ev[0].elapsed_time(ev[1]) * 1e-3)}
+            lib.set_weight_precision(False)
+            note("reduced-precision mode done: %.1f charts/s" % (len(units) / dt))
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a, z, n_unet_steps)
             note("cpu baseline done")

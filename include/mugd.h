@@ -67,6 +67,12 @@ int mugd_set_conv_tiling(mugd_ctx* ctx, int wk, int tn);
  * what a checkpoint trained with one of those backends expects.  Affects kernels baked afterwards (mugd_net_invalidate
  * re-bakes existing networks).  Environment default: MUGD_S4_SYMMETRIC=1. */
 int mugd_set_s4_symmetric(mugd_ctx* ctx, int enabled);
+/* Reduced-precision mode (NOT the reference's arithmetic -- the reference is fp32 end to end -- and never the default): 1 packs
+ * the conv / linear weights of networks compiled afterwards as bfloat16 (round to nearest even).  Activations, MFMA inputs after
+ * widening, accumulation, norms, softmax and the S4 path stay fp32.  Halves the weight stream of every launch (0.2 GB per U-Net
+ * evaluation: resident in the 256 MB Infinity Cache).  Outputs differ from the fp32 mode by the weight rounding (2^-9 relative
+ * per weight); tests/test_nets.py states the flipped-note-cell bound.  Environment default: MUGD_WEIGHTS_BF16=1. */
+int mugd_set_weight_precision(mugd_ctx* ctx, int bf16);
 const char* mugd_version(void);
 
 /* ---- networks ------------------------------------------------------------------------- */

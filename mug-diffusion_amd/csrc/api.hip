@@ -84,6 +84,8 @@ int mugd_create(int device, void* stream, mugd_ctx** out) {
         ctx->c.fold_xattn = !(xf && xf[0] == '1');
         const char* pf = getenv("MUGD_NO_PROJ_FOLD");
         ctx->c.fold_proj_out = !(pf && pf[0] == '1');
+        const char* wb = getenv("MUGD_WEIGHTS_BF16");
+        ctx->c.weights_bf16 = wb && wb[0] == '1';
         const char* sy = getenv("MUGD_S4_SYMMETRIC");
         ctx->c.s4_symmetric = sy && sy[0] == '1';
         const char* fa = getenv("MUGD_EXACT_SILU");            // default: SiLU of the fused GroupNorm path on v_exp_f32 / v_rcp_f32
@@ -130,6 +132,12 @@ int mugd_order_before(mugd_ctx* ctx, void* other) { return ctx ? order_streams(c
 int mugd_set_graph_mode(mugd_ctx* ctx, int enabled) {
     if (!ctx) return MUGD_ERR_INVALID;
     ctx->c.use_graph = enabled != 0;
+    return MUGD_OK;
+}
+
+int mugd_set_weight_precision(mugd_ctx* ctx, int bf16) {
+    if (!ctx) return MUGD_ERR_INVALID;
+    ctx->c.weights_bf16 = bf16 != 0;
     return MUGD_OK;
 }
 
@@ -386,7 +394,7 @@ int mugd_op_conv1d(mugd_ctx* ctx, const float* x, const float* w, const float* b
         a.B = B; a.Mrows = M; a.Mout = epi ? M / 2 : M; a.Tout = Tout; a.nchunk = C / CONV_CK; a.epi = epi;
         a.wk = ctx->c.force_wk;
         a.tn = ctx->c.force_tn == 16 ? (conv16_supported(a) ? 16 : 32) : ctx->c.force_tn == 32 ? 32 : conv_pick_tn(a);
-        PackArgs pa{wpk, mts, 0, C, taps, w, C * taps, 0, M, 0};
+        PackArgs pa{wpk, mts, 0, C, taps, w, C * taps, 0, M, 0, 0};
         if (a.tn == 16) launch_pack_weights16(st, pa); else launch_pack_weights(st, pa);
         launch_conv(st, a);
         HIP_CHECK(hipStreamSynchronize(st));
@@ -425,7 +433,7 @@ int mugd_op_norm_conv1d(mugd_ctx* ctx, const float* x, const float* gamma, const
         a.B = B; a.Mrows = M; a.Mout = M; a.Tout = T + 2 * pad - dil * (taps - 1); a.nchunk = C / CONV_CK; a.epi = EPI_NONE;
         a.wk = wk ? wk : ctx->c.force_wk;
         a.tn = ctx->c.force_tn == 16 ? (conv16_supported(a) ? 16 : 32) : ctx->c.force_tn == 32 ? 32 : conv_pick_tn(a);
-        PackArgs pa{wpk, mts, 0, C, taps, w, C * taps, 0, M, 0};
+        PackArgs pa{wpk, mts, 0, C, taps, w, C * taps, 0, M, 0, 0};
         if (a.tn == 16) launch_pack_weights16(st, pa); else launch_pack_weights(st, pa);
         launch_conv(st, a);
         HIP_CHECK(hipStreamSynchronize(st));

@@ -47,12 +47,22 @@ constexpr int WIN_LDS = CONV_CK * RS;           // floats per window
 constexpr int WAVE_LDS = 2 * WIN_LDS;           // two windows per wave: the pipelined loops park chunk c+1 while chunk c is on the matrix pipe
 constexpr int HL = 8;                           // fast path: window column of sample t0 (left halo lives in [HL-pad, HL))
 
-template <int TAPS, bool DUAL>
-__device__ __forceinline__ void load_a(const float* wp, const float* wp2, float4 (&A)[6], float4 (&A2)[6]) {
+// bfloat16 weight fragments (ConvArgs::w16): 8 bytes per lane instead of 16, widened to fp32 with two shifts / masks per pair
+__device__ __forceinline__ float4 widen_bf16x4(const uint2 r) {
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+}
+
+template <int TAPS, bool DUAL, class WT>
+__device__ __forceinline__ void load_a(const WT* wp, const WT* wp2, float4 (&A)[6], float4 (&A2)[6]) {
 #pragma unroll
     for (int i = 0; i < TAPS * 2; ++i) {
-        A[i] = *reinterpret_cast<const float4*>(wp + i * 256);
-        if (DUAL) A2[i] = *reinterpret_cast<const float4*>(wp2 + i * 256);
+        if (sizeof(WT) == 2) {
+            A[i] = widen_bf16x4(*reinterpret_cast<const uint2*>(wp + i * 256));
+            if (DUAL) A2[i] = widen_bf16x4(*reinterpret_cast<const uint2*>(wp2 + i * 256));
+        } else {
+            A[i] = *reinterpret_cast<const float4*>(wp + i * 256);
+            if (DUAL) A2[i] = *reinterpret_cast<const float4*>(wp2 + i * 256);
+        }
     }
 }
 
@@ -92,8 +102,8 @@ __device__ __forceinline__ void mfma_chunk(const char* smem_bytes, int rb0, int 
 // is the VALU budget of the kernel -- with the exact-division SiLU it issued as many VALU cycles as the MFMAs take
 // (rocprofv3 PMC: SQ_ACTIVE_INST_VALU ~ SQ_VALU_MFMA_BUSY_CYCLES) -- so the hot instantiations carry no branches
 // and the minimal arithmetic: GroupNorm is one fma per sample, SiLU is v_exp_f32 + v_rcp_f32.
-template <int TAPS, bool DUAL, int NH, int XFK = -1, int ACT = -1, bool PIPE = false>
-__device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* wseg, const float* wseg2, int lo, int hi,
+template <int TAPS, bool DUAL, int NH, int XFK = -1, int ACT = -1, bool PIPE = false, class WT = float>
+__device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const WT* wseg, const WT* wseg2, int lo, int hi,
                                                 int b, int t0, int lane, int h, int n, char* smem_bytes, int wave_base,
                                                 f32x16& acc, f32x16& acc2, const float2* gst, const float2* lnst, float inv_cg, int rot_seed) {
     const int r = lane >> 2, q = lane & 3;
@@ -159,8 +169,8 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const float* w
     const int bb = s.bmod > 0 ? b % s.bmod : b;
     const char* xb = reinterpret_cast<const char*>(s.x + ((size_t)bb * s.C + (size_t)lo * CONV_CK) * Tin);
     const size_t xstep = (size_t)CONV_CK * Tin * 4;
-    const float* wp = wseg + (size_t)lo * (TAPS * 512);
-    const float* wp2 = wseg2 + (size_t)lo * (TAPS * 512);
+    const WT* wp = wseg + (size_t)lo * (TAPS * 512);
+    const WT* wp2 = wseg2 + (size_t)lo * (TAPS * 512);
     const int rb0 = wave_base + (4 * h * RS + HL - s.pad + n) * 4;      // this lane's B-fragment read base (bytes)
 
     float4 Aa[6], Aa2[6], Ab[6], Ab2[6];       // ping-pong weight fragments: no register copies in the loop
@@ -424,7 +434,7 @@ __device__ __forceinline__ bool seg_is_vec(const ConvSeg& s) { return s.stride =
 // KIND 1: fast window path, any dilation (wave encoder / VAE ResnetBlocks).
 // KIND 2: every segment through the generic window walk (stride 2, nearest-x2 upsample, T % 4 != 0); NITG = its
 //         staging passes.  Separate kernels keep each instantiation's register budget to what it needs.
-template <int WK, bool DUAL, int KIND, int NITG>
+template <int WK, bool DUAL, int KIND, int NITG, class WT = float>
 __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel(const ConvArgs a) {
     constexpr int RED = WK > 1 ? WK * 16 * 64 : 0;                  // floats for one partial-tile exchange
     constexpr int WIN = WK * WAVE_LDS;
@@ -477,8 +487,8 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; }
 
-    const float* wtile = a.wpk + (size_t)b * a.w_b_stride + (size_t)mt * a.w_mt_stride + lane * 4;
-    const float* wtile2 = DUAL ? wtile + (size_t)(a.Mout >> 5) * a.w_mt_stride : wtile;
+    const WT* wtile = reinterpret_cast<const WT*>(a.wpk) + (size_t)b * a.w_b_stride + (size_t)mt * a.w_mt_stride + lane * 4;
+    const WT* wtile2 = DUAL ? wtile + (size_t)(a.Mout >> 5) * a.w_mt_stride : wtile;
     char* smem_bytes = reinterpret_cast<char*>(smem);
     const int wave_base = wave * WAVE_LDS * 4;
 
@@ -530,8 +540,8 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
             const int lo = (g0 > s.chunk0 ? g0 : s.chunk0) - s.chunk0;
             const int hi = (g1 < s.chunk0 + nch ? g1 : s.chunk0 + nch) - s.chunk0;
             if (lo < hi) {
-                const float* w1 = wtile + s.woff;
-                const float* w2 = wtile2 + s.woff;
+                const WT* w1 = wtile + s.woff;
+                const WT* w2 = wtile2 + s.woff;
 #define MUGD_SEG_ARGS s, w1, w2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, acc, acc2
 #define MUGD_SEG_VARGS MUGD_SEG_ARGS, stl.gnst, stl.lnst, gn_inv_cg, rem
                 if (KIND == 0) {
@@ -554,8 +564,12 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
                     else if (s.dil == 4) run_segment_vec<3, DUAL, 2>(MUGD_SEG_VARGS);
                     else run_segment_vec<3, DUAL, 4>(MUGD_SEG_VARGS);
                 } else {
-                    if (s.taps == 3) run_segment_gen<3, DUAL, NITG, (NITG <= 9)>(MUGD_SEG_ARGS);
-                    else run_segment_gen<1, DUAL, NITG, (NITG <= 9)>(MUGD_SEG_ARGS);
+                    if (sizeof(WT) == 4) {          // the generic windows exist with fp32 weights only
+                        const float* f1 = reinterpret_cast<const float*>(w1);
+                        const float* f2 = reinterpret_cast<const float*>(w2);
+                        if (s.taps == 3) run_segment_gen<3, DUAL, NITG, (NITG <= 9)>(s, f1, f2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, acc, acc2);
+                        else run_segment_gen<1, DUAL, NITG, (NITG <= 9)>(s, f1, f2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, acc, acc2);
+                    }
                 }
 #undef MUGD_SEG_VARGS
 #undef MUGD_SEG_ARGS
@@ -675,7 +689,13 @@ __global__ void pack_weights_kernel(const PackArgs p) {
         const int lane = hh * 32 + r;
         const long long d = (long long)mt * p.w_mt_stride + p.seg_woff + (long long)chunk * (p.taps * 512) +
                             (tap * 2 + g8) * 256 + lane * 4 + j;
-        p.dst[d] = p.src[(long long)ms * p.src_ld + (long long)(p.src_ci_off + ci) * p.taps + tap];
+        const float wv = p.src[(long long)ms * p.src_ld + (long long)(p.src_ci_off + ci) * p.taps + tap];
+        if (p.w16) {
+            const unsigned u = __float_as_uint(wv);
+            reinterpret_cast<unsigned short*>(p.dst)[d] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);      // round to nearest even
+        } else {
+            p.dst[d] = wv;
+        }
     }
 }
 
@@ -686,7 +706,10 @@ void launch_wk(hipStream_t st, const ConvArgs& a0, dim3 grid, int gx, int gy, in
     conv_set_grid(a, gx, gy, gz);
     a.tl = tl_claim((int)grid.x, WK, 32);
 #define MUGD_CONV_LAUNCH(K, N) hipLaunchKernelGGL((conv_gemm_kernel<WK, DUAL, K, N>), grid, dim3(WK * 64), 0, st, a)
-    if (kind == 0) MUGD_CONV_LAUNCH(0, 1);
+    if (a.w16) {
+        MUGD_CHECK(kind == 0, -2, "conv_gemm: bfloat16 weights exist for the plain fast-window kernels only");
+        hipLaunchKernelGGL((conv_gemm_kernel<WK, DUAL, 0, 1, unsigned short>), grid, dim3(WK * 64), 0, st, a);
+    } else if (kind == 0) MUGD_CONV_LAUNCH(0, 1);
     else if (kind == 1) MUGD_CONV_LAUNCH(1, 1);
     else if (nitg <= 9) MUGD_CONV_LAUNCH(2, 9);
     else MUGD_CONV_LAUNCH(2, 17);
@@ -694,6 +717,17 @@ void launch_wk(hipStream_t st, const ConvArgs& a0, dim3 grid, int gx, int gy, in
 }
 
 }  // namespace
+
+// bfloat16 weight fragments: the 16-wide kernels always, the 32-wide ones on the plain fast-window path (KIND 0)
+bool conv_w16_supported(const ConvArgs& a) {
+    if (a.tn == 16) return conv16_supported(a);
+    for (int i = 0; i < a.nseg; ++i) {
+        const ConvSeg& s = a.seg[i];
+        if (!(s.stride == 1 && !s.ups && (s.Tin & 3) == 0 && s.pad <= HL)) return false;
+        if (s.taps == 3 && s.dil != 1) return false;
+    }
+    return true;
+}
 
 int conv_pick_wk(const ConvArgs& a) {
     // ~2 waves on each of the 1024 SIMDs, every wave with at least 2 chunks of work where K allows

@@ -27,17 +27,26 @@ constexpr int WIN_LDS = CONV_CK * RS;           // floats per window
 constexpr int WAVE_LDS = 2 * WIN_LDS;           // two windows per wave (software-pipelined loops, see k_conv.hip)
 constexpr int HL = 8;                           // window column of sample t0
 
-template <int TAPS, bool DUAL>
-__device__ __forceinline__ void load_a16(const float* wp, const float* wp2, float4 (&A)[6], float4 (&A2)[6]) {
+__device__ __forceinline__ float4 widen16_bf16x4(const uint2 r) {       // see k_conv.hip
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+}
+
+template <int TAPS, bool DUAL, class WT>
+__device__ __forceinline__ void load_a16(const WT* wp, const WT* wp2, float4 (&A)[6], float4 (&A2)[6]) {
 #pragma unroll
     for (int i = 0; i < TAPS * 2; ++i) {
-        A[i] = *reinterpret_cast<const float4*>(wp + i * 256);
-        if (DUAL) A2[i] = *reinterpret_cast<const float4*>(wp2 + i * 256);
+        if (sizeof(WT) == 2) {
+            A[i] = widen16_bf16x4(*reinterpret_cast<const uint2*>(wp + i * 256));
+            if (DUAL) A2[i] = widen16_bf16x4(*reinterpret_cast<const uint2*>(wp2 + i * 256));
+        } else {
+            A[i] = *reinterpret_cast<const float4*>(wp + i * 256);
+            if (DUAL) A2[i] = *reinterpret_cast<const float4*>(wp2 + i * 256);
+        }
     }
 }
 
-template <int TAPS, bool DUAL, int XFK = -1, int ACT = -1, bool PIPE = false>       // XFK / ACT / PIPE: see k_conv.hip
-__device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wseg, const float* wseg2, int lo, int hi,
+template <int TAPS, bool DUAL, int XFK = -1, int ACT = -1, bool PIPE = false, class WT = float>       // XFK / ACT / PIPE: see k_conv.hip
+__device__ __forceinline__ void run_segment16(const ConvSeg& s, const WT* wseg, const WT* wseg2, int lo, int hi,
                                               int b, int t0, int lane, char* smem_bytes, int wave_base,
                                               f32x4 (&acc)[2], f32x4 (&accg)[2], const float2* gst, const float2* lnst, float inv_cg, int rot_seed) {
     constexpr int NH = TAPS == 3 ? 1 : 0;                  // dilation 1: 2 halo samples per row, one load for lanes q < 2
@@ -95,8 +104,8 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
     const int bb = s.bmod > 0 ? b % s.bmod : b;
     const char* xb = reinterpret_cast<const char*>(s.x + ((size_t)bb * s.C + (size_t)lo * CONV_CK) * Tin);
     const size_t xstep = (size_t)CONV_CK * Tin * 4;
-    const float* wp = wseg + (size_t)lo * (TAPS * 512);
-    const float* wp2 = wseg2 + (size_t)lo * (TAPS * 512);
+    const WT* wp = wseg + (size_t)lo * (TAPS * 512);
+    const WT* wp2 = wseg2 + (size_t)lo * (TAPS * 512);
     const int rb0 = wave_base + (kq * RS + HL - s.pad + l15) * 4;       // B fragment: row 4 kg + kq, column l15 (+ tap)
 
     float4 Aa[6], Aa2[6], Ab[6], Ab2[6];
@@ -262,7 +271,7 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const float* wse
     }
 }
 
-template <int WK, bool DUAL>
+template <int WK, bool DUAL, class WT = float>
 __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kernel(const ConvArgs a) {
     constexpr int RED = WK > 1 ? WK * 8 * 64 : 0;                   // floats for one partial-tile exchange
     constexpr int WIN = WK * WAVE_LDS;
@@ -309,8 +318,8 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
 #pragma unroll
     for (int i = 0; i < 4; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; accg[0][i] = 0.f; accg[1][i] = 0.f; }
 
-    const float* wtile = a.wpk + (size_t)b * a.w_b_stride + (size_t)mt * a.w_mt_stride + lane * 4;
-    const float* wtile2 = DUAL ? wtile + (size_t)(a.Mout >> 5) * a.w_mt_stride : wtile;
+    const WT* wtile = reinterpret_cast<const WT*>(a.wpk) + (size_t)b * a.w_b_stride + (size_t)mt * a.w_mt_stride + lane * 4;
+    const WT* wtile2 = DUAL ? wtile + (size_t)(a.Mout >> 5) * a.w_mt_stride : wtile;
     char* smem_bytes = reinterpret_cast<char*>(smem);
     const int wave_base = wave * WAVE_LDS * 4;
 
@@ -357,8 +366,8 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
             const int lo = (g0 > s.chunk0 ? g0 : s.chunk0) - s.chunk0;
             const int hi = (g1 < s.chunk0 + nch ? g1 : s.chunk0 + nch) - s.chunk0;
             if (lo < hi) {
-                const float* w1 = wtile + s.woff;
-                const float* w2 = wtile2 + s.woff;
+                const WT* w1 = wtile + s.woff;
+                const WT* w2 = wtile2 + s.woff;
 #define MUGD_SEG16_ARGS s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, acc, accg, stl.gnst, stl.lnst, gn_inv_cg, rem
 #define MUGD_SEG16_XF(T)                                                                  \
     switch (s.xf * 4 + s.act) {                                                           \
@@ -485,7 +494,13 @@ __global__ void pack_weights16_kernel(const PackArgs p) {
         const int lane = kq * 16 + r;
         const long long d = (long long)mt * p.w_mt_stride + p.seg_woff + (long long)chunk * (p.taps * 512) +
                             (tap * 2 + half) * 256 + lane * 4 + kg;
-        p.dst[d] = p.src[(long long)ms * p.src_ld + (long long)(p.src_ci_off + ci) * p.taps + tap];
+        const float wv = p.src[(long long)ms * p.src_ld + (long long)(p.src_ci_off + ci) * p.taps + tap];
+        if (p.w16) {
+            const unsigned u = __float_as_uint(wv);
+            reinterpret_cast<unsigned short*>(p.dst)[d] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);      // round to nearest even
+        } else {
+            p.dst[d] = wv;
+        }
     }
 }
 
@@ -495,7 +510,10 @@ void launch16_wk(hipStream_t st, const ConvArgs& a0, dim3 grid, int gx, int gy, 
     conv_split_k(a, WK);
     conv_set_grid(a, gx, gy, gz);
     a.tl = tl_claim((int)grid.x, WK, 16);
-    if (dual) hipLaunchKernelGGL((conv_gemm16_kernel<WK, true>), grid, dim3(WK * 64), 0, st, a);
+    if (a.w16) {
+        if (dual) hipLaunchKernelGGL((conv_gemm16_kernel<WK, true, unsigned short>), grid, dim3(WK * 64), 0, st, a);
+        else hipLaunchKernelGGL((conv_gemm16_kernel<WK, false, unsigned short>), grid, dim3(WK * 64), 0, st, a);
+    } else if (dual) hipLaunchKernelGGL((conv_gemm16_kernel<WK, true>), grid, dim3(WK * 64), 0, st, a);
     else hipLaunchKernelGGL((conv_gemm16_kernel<WK, false>), grid, dim3(WK * 64), 0, st, a);
 }
 

@@ -150,7 +150,7 @@ void log_mel(Ctx* ctx, const float* pcm, long long n, int sr, int n_fft, int hop
             const int MT = cdiv(n_mels, 32);
             HIP_CHECK(hipMalloc((void**)&p.wpk, (size_t)MT * p.mts * sizeof(float) + 8192));
             HIP_CHECK(hipMemsetAsync(p.wpk, 0, (size_t)MT * p.mts * sizeof(float) + 8192, st));
-            PackArgs pa{p.wpk, p.mts, 0, kpad, 1, wd, kpad, 0, n_mels, 0};
+            PackArgs pa{p.wpk, p.mts, 0, kpad, 1, wd, kpad, 0, n_mels, 0, 0};
             launch_pack_weights(st, pa);
             HIP_CHECK(hipStreamSynchronize(st));
             HIP_CHECK(hipFree(wd));

@@ -60,6 +60,9 @@ struct ConvArgs {
     int nseg;
     const float* wpk;        // packed weights [MT][w_mt_stride]
     long long w_mt_stride;   // floats per 32-row tile
+    int w16;                 // 1: the packed weights are bfloat16 (same fragment order, 2 bytes per element; strides still count ELEMENTS):
+                             // the reduced-precision mode -- half the weight bytes per launch (0.2 GB per step: fits the 256 MB
+                             // Infinity Cache), widened to fp32 in registers, fp32 MFMA and accumulation unchanged
     long long w_b_stride;    // floats between the weight sets of consecutive batch rows (0: one set for all -- every layer but the folded cross-attention)
     const float* bias;       // [Mrows] or null
     const float* rowadd;     // [B][rowadd_stride] or null: added per (b, m) after gating
@@ -133,6 +136,7 @@ void launch_conv_gemm(hipStream_t st, const ConvArgs& a);        // 32 x 32 tile
 int conv_pick_wk(const ConvArgs& a);
 void launch_conv_gemm16(hipStream_t st, const ConvArgs& a);      // 32 x 16 tiles
 bool conv16_supported(const ConvArgs& a);
+bool conv_w16_supported(const ConvArgs& a);                      // bf16 weight variant exists for this launch shape (needs tn)
 int conv_pick_tn(const ConvArgs& a);                             // needs seg[], nseg, epi, B, Mout, Tout
 int conv_pick_order(const ConvArgs& a);                          // ConvArgs::xcd_cols for this launch (needs tn)
 inline void launch_conv(hipStream_t st, const ConvArgs& a0) {
@@ -150,6 +154,7 @@ struct PackArgs {
     const float* src;        // weight tensor [rows][src_ld]: element (m, ci, tap) at m*src_ld + (src_ci_off+ci)*taps + tap
     int src_ld, src_ci_off;
     int rows, row_off;
+    int w16;                 // 1: dst holds bfloat16 (round to nearest even)
 };
 void launch_pack_weights(hipStream_t st, const PackArgs& a);        // fragment order of v_mfma_f32_32x32x2_f32
 void launch_pack_weights16(hipStream_t st, const PackArgs& a);      // fragment order of v_mfma_f32_16x16x4_f32 (two row halves)

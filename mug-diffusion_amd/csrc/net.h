@@ -43,6 +43,7 @@ struct Ctx {
     int force_wk = 0, force_tn = 0;   // mugd_set_conv_tiling: 0 = pick per layer
     bool fast_act = true;       // SiLU of the fused GroupNorm path on v_exp_f32 / v_rcp_f32 (MUGD_EXACT_SILU=1: expf + IEEE divide)
     bool fuse_stats = true;     // false (MUGD_NO_STATS_FUSION=1): always run the GroupNorm / LayerNorm statistics kernels
+    bool weights_bf16 = false;  // mugd_set_weight_precision / MUGD_WEIGHTS_BF16=1: packed conv / linear weights in bfloat16 (reduced-precision mode)
     bool s4_symmetric = false;  // mugd_set_s4_symmetric / MUGD_S4_SYMMETRIC=1: Cauchy sum over both conjugate halves (kernels.h: S4GenArgs)
     bool fold_proj_out = true;  // false (MUGD_NO_PROJ_FOLD=1): ff.net.2 and the transformer's proj_out as two launches instead of one with pre-multiplied weights
     bool fold_xattn = true;     // false (MUGD_NO_XATTN_FOLD=1): cross-attention as to_q -> attention kernel -> to_out instead of the folded two-GEMM form
@@ -183,7 +184,7 @@ protected:
     Tensor upsample(const std::string& prefix, const Tensor& x);
     const float* s4_kernel(const std::string& prefix, int H, int L);
     Tensor s4_layer(const std::string& prefix, const Tensor& x);
-    const PackedW& get_packed(const ConvSpec& s, int tn);
+    const PackedW& get_packed(const ConvSpec& s, int tn, bool w16 = false);
     const PackedW& get_packed_ext(const ConvSpec& s, int tn);
 };
 

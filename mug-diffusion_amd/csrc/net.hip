@@ -380,8 +380,8 @@ Xf Net::layer_norm_xf(const std::string& prefix, const Tensor& x) {
     return xf;
 }
 
-const PackedW& Net::get_packed(const ConvSpec& s, int tn) {
-    const std::string pkey = tn == 16 ? s.key + "#16" : s.key;
+const PackedW& Net::get_packed(const ConvSpec& s, int tn, bool w16) {
+    const std::string pkey = (tn == 16 ? s.key + "#16" : s.key) + (w16 ? "#bf16" : "");
     auto it = packed.find(pkey);
     if (it != packed.end()) return it->second;
     PackedW pw;
@@ -396,7 +396,7 @@ const PackedW& Net::get_packed(const ConvSpec& s, int tn) {
     pw.nchunk = chunk;
     pw.mt_stride = woff;
     const int MT = cdiv(s.Mrows, 32);
-    pw.wpk = dev_alloc((size_t)MT * pw.mt_stride, true);
+    pw.wpk = dev_alloc(w16 ? ((size_t)MT * pw.mt_stride + 1) / 2 : (size_t)MT * pw.mt_stride, true);       // bf16: half the bytes
     for (auto& wb : s.w) {
         const Param& p = P(wb.name);
         MUGD_CHECK(p.dtype == 0 && p.shape.size() >= 2, -2, "conv: bad weight tensor " + wb.name);
@@ -406,7 +406,7 @@ const PackedW& Net::get_packed(const ConvSpec& s, int tn) {
         const int tw = p.shape.size() > 2 ? (int)p.shape[2] : 1;
         MUGD_CHECK(tw == in.taps, -2, "conv: kernel width mismatch for " + wb.name);
         MUGD_CHECK(wb.ci_off + in.x.C <= cw && wb.row_off + rows <= s.Mrows, -2, "conv: weight block out of range: " + wb.name);
-        PackArgs pa{pw.wpk, pw.mt_stride, pw.woff[wb.seg], in.x.C, in.taps, (const float*)p.ptr, cw * tw, wb.ci_off, rows, wb.row_off};
+        PackArgs pa{pw.wpk, pw.mt_stride, pw.woff[wb.seg], in.x.C, in.taps, (const float*)p.ptr, cw * tw, wb.ci_off, rows, wb.row_off, w16 ? 1 : 0};
         if (tn == 16) launch_pack_weights16(ctx->stream, pa);
         else launch_pack_weights(ctx->stream, pa);
     }
@@ -453,7 +453,7 @@ const PackedW& Net::get_packed_ext(const ConvSpec& s, int tn) {
         to_pre = true;
         emit([=](hipStream_t st) {
             for (int b = 0; b < B; ++b) {
-                PackArgs pa{dst + (size_t)b * bstride, mts, 0, K, 1, src + (size_t)b * M * K, K, 0, M, 0};
+                PackArgs pa{dst + (size_t)b * bstride, mts, 0, K, 1, src + (size_t)b * M * K, K, 0, M, 0, 0};
                 if (tn == 16) launch_pack_weights16(st, pa); else launch_pack_weights(st, pa);
             }
         }, OP_SMALL, 0, s.key + " pack per-call weights");
@@ -477,7 +477,8 @@ Tensor Net::conv(const ConvSpec& s) {
     a.wk = ctx->force_wk;
     a.tn = ctx->force_tn == 16 ? (conv16_supported(a) ? 16 : 32) : ctx->force_tn == 32 ? 32 : conv_pick_tn(a);
     a.xs_rel = s.xs_rel; a.xs_cemb = s.xs_cemb; a.xs_heads = s.xs_heads; a.xs_pmax = s.xs_pmax; a.xs_ntok = s.xs_ntok; a.xs_scale = s.xs_scale;
-    const PackedW& pw = s.ext_plain ? get_packed_ext(s, a.tn) : get_packed(s, a.tn);       // the tile width decides the weight fragment order
+    a.w16 = (ctx->weights_bf16 && !s.ext_plain && conv_w16_supported(a)) ? 1 : 0;
+    const PackedW& pw = s.ext_plain ? get_packed_ext(s, a.tn) : get_packed(s, a.tn, a.w16 != 0);       // the tile width decides the weight fragment order
     for (int i = 0; i < a.nseg; ++i) { a.seg[i].chunk0 = pw.chunk0[i]; a.seg[i].woff = pw.woff[i]; }
     a.wpk = pw.wpk; a.w_mt_stride = pw.mt_stride; a.bias = pw.bias;
     a.w_b_stride = s.ext_plain ? (long long)cdiv(s.Mrows, 32) * pw.mt_stride : 0;

@@ -54,6 +54,7 @@ _SIGS = {
     "mugd_set_graph_mode": [_p, _i],
     "mugd_set_conv_tiling": [_p, _i, _i],
     "mugd_set_s4_symmetric": [_p, _i],
+    "mugd_set_weight_precision": [_p, _i],
     "mugd_unet_create": [_p, C.POINTER(UNetConfig), C.POINTER(_p)],
     "mugd_vae_create": [_p, C.POINTER(VaeConfig), C.POINTER(_p)],
     "mugd_wave_create": [_p, C.POINTER(WaveConfig), C.POINTER(_p)],
@@ -101,7 +102,7 @@ class MugdError(RuntimeError):
 
 
 _UNORDERED = {"mugd_create", "mugd_destroy", "mugd_net_destroy", "mugd_last_error", "mugd_version", "mugd_profile_kind_name",
-              "mugd_order_after", "mugd_order_before", "mugd_set_graph_mode", "mugd_set_conv_tiling", "mugd_set_s4_symmetric", "mugd_remove_mini_jacks"}
+              "mugd_order_after", "mugd_order_before", "mugd_set_graph_mode", "mugd_set_conv_tiling", "mugd_set_s4_symmetric", "mugd_set_weight_precision", "mugd_remove_mini_jacks"}
 
 
 class _OrderedDll:
@@ -180,6 +181,11 @@ class Lib:
 
     def set_graph_mode(self, on):
         self.check(self.dll.mugd_set_graph_mode(self.ctx, 1 if on else 0))
+
+    def set_weight_precision(self, bf16):
+        """Reduced-precision mode: networks compiled afterwards keep their packed conv / linear weights in bfloat16
+        (include/mugd.h).  Call Net.set_params / invalidate to recompile existing ones."""
+        self.check(self.dll.mugd_set_weight_precision(self.ctx, 1 if bf16 else 0))
 
     def set_s4_symmetric(self, on):
         """Cauchy sum over both conjugate halves of the S4 poles (reference: pykeops / CUDA-extension backends) instead of the

@@ -41,6 +41,7 @@ extern EmuIdx threadIdx, blockIdx, blockDim, gridDim;
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 struct double2 { double x, y; };
+struct uint2 { unsigned x, y; };
 struct int2 { int x, y; };
 struct int4 { int x, y, z, w; };
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
@@ -160,6 +161,7 @@ static inline double __hiloint2double(int hi, int lo) {
 }
 static inline void __threadfence() {}
 static inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * b) >> 32); }
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
