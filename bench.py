@@ -123,7 +123,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    grouped = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)      # under torch.distributed.run also at N = 1: the same
+    if grouped:                                                                          # RCCL code path (init, barrier, gather) then runs on one GPU
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)          # RCCL over xGMI; only barriers / final gather use it
 
@@ -186,7 +187,7 @@ def main():
         return grids, stats
 
     def sync_all():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -198,7 +199,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         grids, stats = one_step(a.pack_songs)
-    if world > 1:                       # the job's only data movement between ranks: note grids (8 x T bits per chart) to every rank
+    if grouped:                         # the job's only data movement between ranks: note grids (8 x T bits per chart) to every rank
         all_grids = shard.gather_grids(torch.stack(grids), len(units), device=dev)
         assert all_grids.shape[0] == len(units)
     torch.cuda.synchronize()
@@ -207,7 +208,7 @@ def main():
     elapsed = time.perf_counter() - t0
     note("timed region done: %.1f ms per step (%d launches per rank and step)" % (elapsed / a.steps * 1e3, stats["launches"]))
     notes = int(sum(int(g.sum()) for g in grids))
-    if world > 1:
+    if grouped:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -318,7 +319,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a, z, n_unet_steps)
             note("cpu baseline done")
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -168,3 +168,99 @@ def chart_writer(outdir, template_osu, frame_ms, max_frame, audio_path=None, cre
         written.append(path)
 
     return on_chart, written
+
+
+def load_model(config_path, ckpt_path=None, device="cuda", seed_synthetic=None):
+    """webui.py:42-58 / scripts/mapping.py:429-431: instantiate `model` from a YAML (configs/mug/mug_diffusion.yaml layout) and
+    load the checkpoint's state dict (strict=False, like the reference).  ckpt_path=None + seed_synthetic: seeded synthetic
+    weights of that architecture (benchmarks / smoke runs; no checkpoint ships offline)."""
+    import yaml
+    from .util import instantiate_from_config
+    with open(config_path) as f:
+        cfg = yaml.safe_load(f)
+    model = instantiate_from_config(cfg["model"] if "model" in cfg else cfg).eval()
+    if ckpt_path is not None:
+        sd = torch.load(ckpt_path, map_location="cpu")
+        sd = sd.get("state_dict", sd)
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        if missing or unexpected:
+            print("load_model: %d missing, %d unexpected keys" % (len(missing), len(unexpected)))
+    elif seed_synthetic is not None:
+        from .model.paramtree import seed_all_parameters
+        unet = model.model.unet_model
+        z_cfg = int(cfg.get("model", cfg)["params"].get("z_length", 512))
+        seed_all_parameters(model, seed=seed_synthetic, s4_length_of=lambda k: unet.s4_length_of(k[len("model.unet_model."):], z_cfg))
+    return model.to(device), cfg
+
+
+def main(argv=None):
+    """`python -m mug.job`: the reference's headless entry (scripts/mapping.py:308-522) on the drop-in, for one audio or a list.
+
+        python -m mug.job --config models/ckpt/model.yaml --ckpt models/ckpt/model.ckpt --audio song.wav \\
+               --template_beatmap data/template.osu --outdir outputs/beatmaps --n_samples 4 --ddim_steps 200 --scale 1.0
+
+    Under `python -m torch.distributed.run --nproc-per-node N -m mug.job ... --audio a.wav b.wav ...` the (audio, sample) units are
+    partitioned over the N GPUs; every rank writes the charts it generated."""
+    import argparse
+    import yaml
+    from .diffusion.ddim import DDIMSampler
+    from .util import load_audio_without_cache
+    ap = argparse.ArgumentParser(prog="python -m mug.job", description=main.__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--config", required=True, help="model YAML (configs/mug/mug_diffusion.yaml / models/ckpt/model.yaml)")
+    ap.add_argument("--ckpt", default=None, help="checkpoint with a state_dict in the reference's key layout; omit with --synthetic-seed")
+    ap.add_argument("--synthetic-seed", type=int, default=None, help="seeded synthetic weights instead of a checkpoint")
+    ap.add_argument("--audio", nargs="+", required=True)
+    ap.add_argument("--feature_yaml", default="configs/mug/mania_beatmap_features.yaml")
+    ap.add_argument("--prompt_dir", default=None, help="directory with feature_<i>.yaml per sample (scripts/mapping.py:422-425)")
+    ap.add_argument("--template_beatmap", default=None, help=".osu template; without it only the note grids are produced")
+    ap.add_argument("--outdir", default="outputs/beatmaps")
+    ap.add_argument("--n_samples", type=int, default=4)
+    ap.add_argument("--ddim_steps", type=int, default=200)
+    ap.add_argument("--ddim_eta", type=float, default=0.0)
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--pack_songs", type=int, default=1)
+    a = ap.parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("mug.job needs an MI355X: libmugd has no CPU path")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    model, cfg = load_model(a.config, a.ckpt, device=torch.device("cuda", local), seed_synthetic=a.synthetic_seed)
+    common = (cfg.get("data", {}).get("params", {}).get("common_params", {})) if isinstance(cfg, dict) else {}
+    sr, n_fft, n_mels = int(common.get("sr", 22050)), int(common.get("n_fft", 512)), int(common.get("n_mels", 128))
+    max_audio_frame = int(common.get("max_audio_frame", 32768))
+    ratio_note = int(common.get("audio_note_window_ratio", 8))
+    z_cfg = int(cfg.get("model", cfg)["params"].get("z_length", 512))
+    with open(a.feature_yaml) as f:
+        fy = yaml.safe_load(f)
+    prompts = [{}]
+    if a.prompt_dir:
+        prompts = [yaml.safe_load(open(os.path.join(a.prompt_dir, "feature_%d.yaml" % (i + 1)))) for i in range(a.n_samples)]
+    units = [Unit(audio=ai, seed=a.seed + ai * a.n_samples + s, prompt=prompts[s % len(prompts)])
+             for ai in range(len(a.audio)) for s in range(a.n_samples)]
+    hop = n_fft // 4
+
+    def mel_of(ai):
+        mel = load_audio_without_cache(a.audio[ai], n_mels, hop, n_fft, sr, None)       # fp16 (n_mels, frames), like the reference
+        return torch.from_numpy(mel.astype(np.float32))
+
+    on_chart, written = None, []
+    if a.template_beatmap:
+        frame_ms = hop / sr * ratio_note * 1000
+        on_chart, written = chart_writer(a.outdir, a.template_beatmap, frame_ms, 1 << 30)
+    grids, stats = run_job(model, DDIMSampler(model), units, mel_of, fy, steps=a.ddim_steps, scale=a.scale, eta=a.ddim_eta,
+                           batch=a.n_samples, pack_songs=a.pack_songs, max_audio_frame=max_audio_frame, z_length_cfg=z_cfg,
+                           on_chart=on_chart, gather=world > 1)
+    print("rank %d: %d units, %d launches, %d charts written to %s" % (stats["rank"], stats["units"], stats["launches"], len(written), a.outdir))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return grids
+
+
+if __name__ == "__main__":
+    main()

@@ -105,7 +105,10 @@ def _decode_audio(audio_path, sr, max_duration):
         import soundfile
         y, file_sr = soundfile.read(audio_path, dtype="float32", always_2d=True)
     except ImportError as e:
-        raise RuntimeError("no audio decoder available (install librosa or soundfile)") from e
+        if str(audio_path).lower().endswith((".wav", ".wave")):
+            y, file_sr = _read_wav(audio_path)          # RIFF PCM needs no third-party decoder
+        else:
+            raise RuntimeError("no audio decoder available for %s (install librosa or soundfile; .wav files are read natively)" % audio_path) from e
     y = y.mean(axis=1)
     if max_duration is not None:
         y = y[: int(max_duration * file_sr)]
@@ -113,6 +116,48 @@ def _decode_audio(audio_path, sr, max_duration):
         from mug._native import get_lib
         return get_lib().resample_poly(torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32)), int(sr), int(file_sr))
     return y
+
+
+def _read_wav(path):
+    """RIFF/WAVE PCM (8 / 16 / 24 / 32-bit integer or 32-bit float) -> (float32 (frames, channels) in [-1, 1), sample rate),
+    with the standard library only: the fallback decoder when neither librosa nor soundfile is installed.  Scaling follows
+    libsndfile's float conversion (integer / 2^(bits-1)), which is what soundfile / librosa would return."""
+    import struct
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise RuntimeError("%s is not a RIFF/WAVE file" % path)
+    pos, fmt, pcm = 12, None, None
+    while pos + 8 <= len(data):
+        cid, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
+        body = data[pos + 8:pos + 8 + size]
+        if cid == b"fmt ":
+            fmt = struct.unpack("<HHIIHH", body[:16])
+            if fmt[0] == 0xFFFE and len(body) >= 26:          # WAVE_FORMAT_EXTENSIBLE: the real format tag is in the sub-format GUID
+                fmt = (struct.unpack("<H", body[24:26])[0],) + fmt[1:]
+        elif cid == b"data":
+            pcm = body
+        pos += 8 + size + (size & 1)
+    if fmt is None or pcm is None:
+        raise RuntimeError("%s: missing fmt / data chunk" % path)
+    tag, ch, rate, _, _, bits = fmt
+    if tag == 3 and bits == 32:
+        y = np.frombuffer(pcm, dtype="<f4").astype(np.float32)
+    elif tag == 1 and bits == 16:
+        y = np.frombuffer(pcm, dtype="<i2").astype(np.float32) / 32768.0
+    elif tag == 1 and bits == 8:
+        y = (np.frombuffer(pcm, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+    elif tag == 1 and bits == 32:
+        y = (np.frombuffer(pcm, dtype="<i4").astype(np.float64) / 2147483648.0).astype(np.float32)
+    elif tag == 1 and bits == 24:
+        b = np.frombuffer(pcm[: len(pcm) // 3 * 3], dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        v = np.where(v & 0x800000, v - 0x1000000, v)
+        y = (v.astype(np.float64) / 8388608.0).astype(np.float32)
+    else:
+        raise RuntimeError("%s: unsupported WAVE format (tag %d, %d bits)" % (path, tag, bits))
+    n = len(y) // ch
+    return y[: n * ch].reshape(n, ch), int(rate)
 
 
 def pcm_to_log_mel(y, n_mels, audio_hop_length, n_fft, sr):

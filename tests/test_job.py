@@ -144,3 +144,66 @@ def test_two_rank_job_equals_single_rank():
         assert len(grids) == len(want)
         for g, w in zip(grids, want):
             assert g.shape == tuple(w.shape) and (g == w.numpy()).all(), rank
+
+
+def test_wav_fallback_decoder(tmp_path):
+    """mug.util._read_wav: the stdlib RIFF reader used when neither librosa nor soundfile is installed (libsndfile scaling)."""
+    import struct
+    import wave
+    from mug.util import _read_wav
+    x = (np.sin(np.arange(999) / 7.0) * 20000).astype(np.int16)
+    p = str(tmp_path / "s16.wav")
+    with wave.open(p, "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(44100)
+        w.writeframes(np.stack([x, -x], 1).tobytes())
+    y, sr = _read_wav(p)
+    assert sr == 44100 and y.shape == (999, 2) and y.dtype == np.float32
+    assert np.array_equal(y[:, 0], x.astype(np.float32) / 32768.0) and np.array_equal(y[:, 1], -x.astype(np.float32) / 32768.0)
+    # 24-bit and float32 payloads written by hand
+    v24 = np.array([0, 1, -1, 8388607, -8388608], dtype=np.int64)
+    raw = b"".join(struct.pack("<i", int(v))[:3] for v in v24)
+    hdr = lambda fmt, bits, payload: (b"RIFF" + struct.pack("<I", 36 + len(payload)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, fmt, 1, 22050, 22050 * bits // 8, bits // 8, bits)
+                                      + b"data" + struct.pack("<I", len(payload)) + payload)
+    p24 = tmp_path / "s24.wav"
+    p24.write_bytes(hdr(1, 24, raw))
+    y, sr = _read_wav(str(p24))
+    assert sr == 22050 and np.allclose(y[:, 0], v24 / 8388608.0, atol=0)
+    f = np.array([0.0, 0.5, -1.0, 0.25], dtype="<f4")
+    pf = tmp_path / "f32.wav"
+    pf.write_bytes(hdr(3, 32, f.tobytes()))
+    y, _ = _read_wav(str(pf))
+    assert np.array_equal(y[:, 0], f)
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end_on_the_gpu(tmp_path):
+    """`python -m mug.job` (the reference's scripts/mapping.py flow): tiny architecture YAML + seeded synthetic weights, one 44.1 kHz WAV,
+    two samples -> two .osu files next to the template's metadata, through decode (stdlib WAV) -> device resampler -> log-mel -> wave
+    encoder -> DDIM -> VAE decode -> mini-jack pass -> gridify -> save_osu_file."""
+    import subprocess
+    import sys
+    import wave
+    import yaml
+    from oracle import host, postprocess as pp
+    case = cases.TINY
+    cfg = dict(model=_model_config(case), data=dict(params=dict(common_params=dict(sr=22050, n_fft=512, n_mels=case["wave"]["n_freq"],
+               max_audio_frame=32 * case["audio_ratio"], audio_note_window_ratio=2 ** (len(case["vae"]["channel_mult"]) - 1)))))
+    cfg["model"]["params"]["z_length"] = 32
+    (tmp_path / "model.yaml").write_text(yaml.safe_dump(cfg))
+    (tmp_path / "template.osu").write_text(pp.TEMPLATE_OSU, encoding="utf8")
+    (tmp_path / "audio.mp3").write_bytes(b"")
+    pcm = (host.synth_audio(0.9, sr=44100, seed=5) * 32767).astype(np.int16)
+    with wave.open(str(tmp_path / "song.wav"), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(44100)
+        w.writeframes(pcm.tobytes())
+    out = tmp_path / "out"
+    env = dict(os.environ, PYTHONPATH=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mug-diffusion_amd"))
+    r = subprocess.run([sys.executable, "-m", "mug.job", "--config", str(tmp_path / "model.yaml"), "--synthetic-seed", "0",
+                        "--audio", str(tmp_path / "song.wav"), "--feature_yaml", os.path.join(G, "mania_beatmap_features.yaml"),
+                        "--template_beatmap", str(tmp_path / "template.osu"), "--outdir", str(out), "--n_samples", "2", "--ddim_steps", "4"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    files = sorted(os.listdir(out))
+    assert len(files) == 2 and all(f.endswith(".osu") for f in files), (files, r.stdout[-1000:])
+    text = (out / files[0]).read_text(encoding="utf8")
+    assert "[HitObjects]" in text and "AI v1" in text
