@@ -217,6 +217,29 @@ int mugd_op_gn_s4_conv(mugd_ctx* ctx, const float* u, const float* k, const floa
                        int groups, float* y, int B, int H, int L);
 int mugd_op_timestep_embedding(mugd_ctx* ctx, const int64_t* t, float* out, int B, int dim);
 
+/* ---- training slice (FIRST STEP: not yet a training loop for the whole U-Net) ------------------------------ */
+/* mug/diffusion/diffusion.py:326-333 q_sample: out = sqrt_alphas_cumprod[t_b] x0 + sqrt_one_minus_alphas_cumprod[t_b] noise.
+ * x0 / noise / out: (B, n) fp32; t: (B) int64; the two schedule buffers: the model's registered buffers (fp32, 1000 entries). */
+int mugd_train_q_sample(mugd_ctx* ctx, const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac, const float* sqrt_1mac,
+                        float* out, int B, int64_t n);
+/* diffusion.py:341-354,386 get_loss('smooth_l1', mean=False).mean(dim=[1,2]): loss[b] = mean smooth_l1(target - pred; beta) + add;
+ * grad (nullable): d(mean_b loss[b]) / d pred, (B, n). */
+int mugd_train_smooth_l1(mugd_ctx* ctx, const float* pred, const float* target, float beta, float add, float* loss, float* grad, int B, int64_t n);
+/* mug/diffusion/unet.py:212-239 TimestepResBlock._forward and its backward.  Parameter / gradient blocks use the module's own tensor
+ * layouts (conv weights (Cout, Cin, 3), emb_layers.1 (Cout, Kemb), skip_connection (Cout, Cin, 1) or NULL for the identity skip). */
+typedef struct {
+    const float *gn1_w, *gn1_b, *conv1_w, *conv1_b, *emb_w, *emb_b, *gn2_w, *gn2_b, *conv2_w, *conv2_b, *skip_w, *skip_b;
+} mugd_resblock_params;
+typedef struct {
+    float *gn1_w, *gn1_b, *conv1_w, *conv1_b, *emb_w, *emb_b, *gn2_w, *gn2_b, *conv2_w, *conv2_b, *skip_w, *skip_b;
+} mugd_resblock_grads;
+/* y = block(x, emb) (B, Cout, T); given dy: dx (B, Cin, T), demb (B, Kemb) and every parameter gradient.  Synchronises. */
+int mugd_train_resblock(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x, const float* emb, const float* dy, float* y, float* dx,
+                        float* demb, const mugd_resblock_grads* g, int B, int Cin, int Cout, int T, int Kemb, int groups);
+/* torch.optim.AdamW step (decoupled weight decay) on a flat parameter block; step counts from 1. */
+int mugd_train_adamw(mugd_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int step);
+
 #ifdef __cplusplus
 }
 #endif

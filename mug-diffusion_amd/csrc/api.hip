@@ -6,9 +6,7 @@
 #include "mel.h"
 #include "net.h"
 
-struct mugd_ctx {
-    Ctx c;
-};
+#include "ctx.h"
 struct mugd_net {
     mugd_ctx* ctx;
     int kind;   // 0 unet, 1 vae decoder, 2 wave, 3 vae encoder

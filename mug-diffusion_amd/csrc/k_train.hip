@@ -1,0 +1,304 @@
+// Training slice (BASELINE configs[4]) -- FIRST STEP, not yet a training loop for the whole U-Net:
+// the DDPM noise-prediction loss around the network (mug/diffusion/diffusion.py:326-354: q_sample, smooth-L1(beta) + 0.01)
+// and the backward pass of the block that makes up most of the U-Net's launches, TimestepResBlock._forward
+// (mug/diffusion/unet.py:212-239): GroupNorm -> SiLU -> conv3 (+ time-embedding row) -> GroupNorm -> SiLU -> conv3 (+ skip).
+//
+//   forward (training form: the two normalised + activated tensors are materialised, backward needs them)
+//       a1 = silu(GN1(x));  h = conv3(a1; W1) + b1 + E[b, :];  E = We silu(emb) + be
+//       a2 = silu(GN2(h));  y = conv3(a2; W2) + b2 + skip(x)          skip = identity | 1x1 conv (Ws, bs)
+//   backward (dy given)
+//       conv data gradients  : the SAME implicit-GEMM kernel (conv_gemm) on the transposed, tap-flipped weights
+//       conv weight gradients: wgrad_kernel (contraction over batch x time), bias gradients: row sums
+//       GroupNorm + SiLU     : gn_silu_bwd_kernel, one workgroup per group, two passes per batch row, deterministic
+//       time-embedding rows  : sums over time of dh, then the small Linear's backward
+//   optimiser: adamw_kernel (torch.optim.AdamW semantics: decoupled weight decay).
+// Everything fp32 with fp64 accumulation where sums are long (statistics, bias / gamma / beta gradients).
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace {
+
+// x_t = sqrt_ac[t_b] x0 + sqrt_1mac[t_b] noise            (diffusion.py:326-333)
+__global__ void q_sample_kernel(const float* x0, const float* noise, const long long* t, const float* sqrt_ac, const float* sqrt_1mac,
+                                float* out, int B, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)B * n) return;
+    const int b = (int)(i / n);
+    const long long tb = t[b];
+    out[i] = sqrt_ac[tb] * x0[i] + sqrt_1mac[tb] * noise[i];
+}
+
+// loss_b = mean_{c,t} smooth_l1(target - pred; beta) + add ;  grad = d(mean_b loss_b)/d pred          (diffusion.py:341-354, 386)
+// one workgroup per batch row; fp64 accumulation
+__global__ __launch_bounds__(256) void smooth_l1_kernel(const float* pred, const float* target, float beta, float add, float* loss, float* grad,
+                                                        int B, long long n) {
+    __shared__ double red[4];
+    const int b = blockIdx.x;
+    const float* p = pred + (size_t)b * n;
+    const float* q = target + (size_t)b * n;
+    const float gscale = 1.0f / ((float)n * (float)B);
+    double s = 0.0;
+    for (long long i = threadIdx.x; i < n; i += 256) {
+        const float d = q[i] - p[i];
+        const float ad = fabsf(d);
+        s += ad < beta ? 0.5 * (double)d * (double)d / (double)beta : (double)ad - 0.5 * (double)beta;
+        if (grad) grad[(size_t)b * n + i] = (ad < beta ? -d / beta : (d > 0.f ? -1.0f : 1.0f)) * gscale;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        s += __hiloint2double(__shfl_xor(__double2hiint(s), o), __shfl_xor(__double2loint(s), o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[b] = (float)((red[0] + red[1] + red[2] + red[3]) / (double)n) + add;
+}
+
+// dst[ci][m][taps-1-tap] = src[m][ci][tap]: the weights of the data-gradient convolution
+__global__ void transpose_flip_kernel(const float* src, float* dst, int M, int C, int taps) {
+    const long long total = (long long)M * C * taps;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % taps);
+        const int ci = (int)((i / taps) % C);
+        const int m = (int)(i / ((long long)taps * C));
+        dst[((size_t)ci * M + m) * taps + (taps - 1 - tap)] = src[i];
+    }
+}
+
+// out[m] (+)= sum_{b,t} x[b][m][t]   (bias gradients; fp64 accumulation, one wave per row)
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* x, float* out, int B, int M, int T, int accumulate) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + wave;
+    if (m >= M) return;
+    double s = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const float* row = x + ((size_t)b * M + m) * T;
+        for (int t = lane; t < T; t += 64) s += (double)row[t];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        s += __hiloint2double(__shfl_xor(__double2hiint(s), o), __shfl_xor(__double2loint(s), o));
+    if (lane == 0) out[m] = (accumulate ? out[m] : 0.f) + (float)s;
+}
+
+// rows[b][m] = sum_t x[b][m][t]   (gradient of the broadcast time-embedding row)
+__global__ __launch_bounds__(256) void time_sum_kernel(const float* x, float* rows, int BM, int T) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= BM) return;
+    double s = 0.0;
+    for (int t = lane; t < T; t += 64) s += (double)x[(size_t)r * T + t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        s += __hiloint2double(__shfl_xor(__double2hiint(s), o), __shfl_xor(__double2loint(s), o));
+    if (lane == 0) rows[r] = (float)s;
+}
+
+// Weight gradient of conv1d (taps 1 | 3, stride 1, zero padding `pad`):
+//   dW[m][c][tap] = sum_{b,t} dY[b][m][t] A[b][c][t + tap - pad]
+// One workgroup = a 32 (m) x 16 (c) tile, all taps; the (b, t) contraction is walked in 64-sample slabs staged in LDS
+// (dY slab 32 x 64, A slab 16 x (64 + 2)); thread (mi = tid / 8, cq = tid % 8) owns rows mi, channels cq and cq + 8.
+// First version of the training path: VALU fma, not yet on the matrix cores (the contraction axis is time, for which the
+// inference kernels' operand layout has no fragment order).
+__global__ __launch_bounds__(256) void wgrad_kernel(const float* dY, const float* A, float* dW, int B, int M, int C, int T, int taps, int pad) {
+    __shared__ float sy[32][65];
+    __shared__ float sa[16][68];
+    const int m0 = blockIdx.x * 32, c0 = blockIdx.y * 16;
+    const int tid = threadIdx.x, mi = tid >> 3, cq = tid & 7;
+    float acc[2][3];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[j][k] = 0.f;
+    for (int b = 0; b < B; ++b) {
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            __syncthreads();
+            for (int i = tid; i < 32 * 64; i += 256) {
+                const int r = i >> 6, tt = i & 63;
+                const int m = m0 + r, t = t0 + tt;
+                sy[r][tt] = (m < M && t < T) ? dY[((size_t)b * M + m) * T + t] : 0.f;
+            }
+            for (int i = tid; i < 16 * 66; i += 256) {
+                const int r = i / 66, tt = i - r * 66;
+                const int c = c0 + r, t = t0 + tt - pad;
+                sa[r][tt] = (c < C && t >= 0 && t < T) ? A[((size_t)b * C + c) * T + t] : 0.f;
+            }
+            __syncthreads();
+            for (int tt = 0; tt < 64; ++tt) {
+                const float y = sy[mi][tt];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        if (k < taps) acc[j][k] += y * sa[cq + 8 * j][tt + k];
+            }
+        }
+    }
+    const int m = m0 + mi;
+    if (m < M) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = c0 + cq + 8 * j;
+            if (c < C)
+                for (int k = 0; k < taps; ++k) dW[((size_t)m * C + c) * taps + k] = acc[j][k];
+        }
+    }
+}
+
+__device__ __forceinline__ double wg_sum(double v, double* red) {        // 256-thread workgroup sum, result to every thread
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __hiloint2double(__shfl_xor(__double2hiint(v), o), __shfl_xor(__double2loint(v), o));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// Backward of a = silu(GroupNorm(x; gamma, beta)):  given da, returns dx (+= if accumulate) and dgamma / dbeta.
+// One workgroup per group; for every batch row: pass 1 statistics of x, pass 2 the two group means of the normalised-gradient
+// terms, pass 3 dx.  dgamma / dbeta are accumulated over the batch in registers of the owning threads (fp64): deterministic.
+__global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float* x, const float* da, const float* gamma, const float* beta, float eps,
+                                                          float* dx, float* dgamma, float* dbeta, int B, int C, int T, int groups, int accumulate) {
+    __shared__ double red[4];
+    __shared__ double cg_g[64], cg_b[64];          // per channel of the group (cg <= 64)
+    const int g = blockIdx.x, cg = C / groups, tid = threadIdx.x;
+    const long long n = (long long)cg * T;
+    if (tid < cg) { cg_g[tid] = 0.0; cg_b[tid] = 0.0; }
+    for (int b = 0; b < B; ++b) {
+        const float* xg = x + ((size_t)b * C + (size_t)g * cg) * T;
+        const float* ag = da + ((size_t)b * C + (size_t)g * cg) * T;
+        float* dg = dx + ((size_t)b * C + (size_t)g * cg) * T;
+        double s1 = 0.0, s2 = 0.0;
+        for (long long i = tid; i < n; i += 256) { const double v = xg[i]; s1 += v; s2 += v * v; }
+        s1 = wg_sum(s1, red);
+        s2 = wg_sum(s2, red);
+        const double mean = s1 / (double)n;
+        double var = s2 / (double)n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float mu = (float)mean;
+        // pass 2: du = da silu'(u); sums of dxhat = du gamma and dxhat xhat over the group; per-channel dgamma / dbeta
+        double m1 = 0.0, m2 = 0.0;
+        for (int c = 0; c < cg; ++c) {
+            const float gm = gamma[g * cg + c], bt = beta[g * cg + c];
+            double dgm = 0.0, dbt = 0.0;
+            for (int t = tid; t < T; t += 256) {
+                const float xh = (xg[(size_t)c * T + t] - mu) * rstd;
+                const float u = xh * gm + bt;
+                const float sg = 1.0f / (1.0f + expf(-u));
+                const float du = ag[(size_t)c * T + t] * (sg * (1.0f + u * (1.0f - sg)));
+                dgm += (double)du * (double)xh;
+                dbt += (double)du;
+                const float dxh = du * gm;
+                m1 += (double)dxh;
+                m2 += (double)dxh * (double)xh;
+            }
+            dgm = wg_sum(dgm, red);
+            dbt = wg_sum(dbt, red);
+            if (tid == 0) { cg_g[c] += dgm; cg_b[c] += dbt; }
+        }
+        m1 = wg_sum(m1, red) / (double)n;
+        m2 = wg_sum(m2, red) / (double)n;
+        const float fm1 = (float)m1, fm2 = (float)m2;
+        // pass 3: dx = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat))
+        for (int c = 0; c < cg; ++c) {
+            const float gm = gamma[g * cg + c], bt = beta[g * cg + c];
+            for (int t = tid; t < T; t += 256) {
+                const size_t o = (size_t)c * T + t;
+                const float xh = (xg[o] - mu) * rstd;
+                const float u = xh * gm + bt;
+                const float sg = 1.0f / (1.0f + expf(-u));
+                const float dxh = ag[o] * (sg * (1.0f + u * (1.0f - sg))) * gm;
+                const float v = rstd * (dxh - fm1 - xh * fm2);
+                dg[o] = accumulate ? dg[o] + v : v;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < cg) { dgamma[g * cg + tid] = (float)cg_g[tid]; dbeta[g * cg + tid] = (float)cg_b[tid]; }
+}
+
+// Backward of E = We silu(e) + be  (emb_layers, unet.py:184-190):  dWe[m][k] = sum_b dE[b][m] silu(e[b][k]);  dbe[m] = sum_b dE[b][m];
+// de[b][k] = silu'(e[b][k]) sum_m We[m][k] dE[b][m].   grid (ceil(M / 4) + ceil(K / 256)), block 256: the first blocks own rows of dWe,
+// the rest own columns of de.
+__global__ __launch_bounds__(256) void emb_linear_bwd_kernel(const float* e, const float* We, const float* dE, float* dWe, float* dbe, float* de,
+                                                             int B, int K, int M, int row_blocks) {
+    if ((int)blockIdx.x < row_blocks) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int m = blockIdx.x * 4 + wave;
+        if (m >= M) return;
+        for (int k = lane; k < K; k += 64) {
+            float s = 0.f;
+            for (int b = 0; b < B; ++b) { const float v = e[(size_t)b * K + k]; s += dE[(size_t)b * M + m] * (v / (1.0f + expf(-v))); }
+            dWe[(size_t)m * K + k] = s;
+        }
+        if (lane == 0) {
+            float s = 0.f;
+            for (int b = 0; b < B; ++b) s += dE[(size_t)b * M + m];
+            dbe[m] = s;
+        }
+    } else if (de) {
+        const int k = ((int)blockIdx.x - row_blocks) * 256 + threadIdx.x;
+        if (k >= K) return;
+        for (int b = 0; b < B; ++b) {
+            float s = 0.f;
+            for (int m = 0; m < M; ++m) s += We[(size_t)m * K + k] * dE[(size_t)b * M + m];
+            const float v = e[(size_t)b * K + k];
+            const float sg = 1.0f / (1.0f + expf(-v));
+            de[(size_t)b * K + k] = s * (sg * (1.0f + v * (1.0f - sg)));
+        }
+    }
+}
+
+// torch.optim.AdamW (decoupled weight decay), one step; bias corrections passed as scalars
+__global__ void adamw_kernel(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd,
+                             float bc1, float bc2) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float w = p[i];
+    const float gi = g[i];
+    w -= lr * wd * w;
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    w -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+    p[i] = w;
+}
+
+}  // namespace
+
+void launch_q_sample(hipStream_t st, const float* x0, const float* noise, const long long* t, const float* sqrt_ac, const float* sqrt_1mac,
+                     float* out, int B, long long n) {
+    const long long tot = (long long)B * n;
+    hipLaunchKernelGGL(q_sample_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, x0, noise, t, sqrt_ac, sqrt_1mac, out, B, n);
+}
+void launch_smooth_l1(hipStream_t st, const float* pred, const float* target, float beta, float add, float* loss, float* grad, int B, long long n) {
+    hipLaunchKernelGGL(smooth_l1_kernel, dim3(B), dim3(256), 0, st, pred, target, beta, add, loss, grad, B, n);
+}
+void launch_transpose_flip(hipStream_t st, const float* src, float* dst, int M, int C, int taps) {
+    const long long total = (long long)M * C * taps;
+    hipLaunchKernelGGL(transpose_flip_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, st, src, dst, M, C, taps);
+}
+void launch_bias_grad(hipStream_t st, const float* x, float* out, int B, int M, int T, int accumulate) {
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, x, out, B, M, T, accumulate);
+}
+void launch_time_sum(hipStream_t st, const float* x, float* rows, int BM, int T) {
+    hipLaunchKernelGGL(time_sum_kernel, dim3(cdiv(BM, 4)), dim3(256), 0, st, x, rows, BM, T);
+}
+void launch_wgrad(hipStream_t st, const float* dY, const float* A, float* dW, int B, int M, int C, int T, int taps, int pad) {
+    MUGD_CHECK(taps == 1 || taps == 3, -2, "wgrad: taps must be 1 or 3");
+    hipLaunchKernelGGL(wgrad_kernel, dim3(cdiv(M, 32), cdiv(C, 16)), dim3(256), 0, st, dY, A, dW, B, M, C, T, taps, pad);
+}
+void launch_gn_silu_bwd(hipStream_t st, const float* x, const float* da, const float* gamma, const float* beta, float eps, float* dx,
+                        float* dgamma, float* dbeta, int B, int C, int T, int groups, int accumulate) {
+    MUGD_CHECK(C % groups == 0 && C / groups <= 64, -2, "gn_silu_bwd: at most 64 channels per group");
+    hipLaunchKernelGGL(gn_silu_bwd_kernel, dim3(groups), dim3(256), 0, st, x, da, gamma, beta, eps, dx, dgamma, dbeta, B, C, T, groups, accumulate);
+}
+void launch_emb_linear_bwd(hipStream_t st, const float* e, const float* We, const float* dE, float* dWe, float* dbe, float* de, int B, int K, int M) {
+    const int rb = cdiv(M, 4);
+    hipLaunchKernelGGL(emb_linear_bwd_kernel, dim3(rb + cdiv(K, 256)), dim3(256), 0, st, e, We, dE, dWe, dbe, de, B, K, M, rb);
+}
+void launch_adamw(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd, int step) {
+    const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2);
+}

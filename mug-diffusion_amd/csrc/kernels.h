@@ -298,5 +298,20 @@ void launch_xattn_fold(hipStream_t st, const XattnFoldArgs& a);
 struct DeriveMatmulArgs { const float* A; int lda; const float* B; int ldb; const float* add; int add_ld; float* C; int ldc; int M, N, K; };
 void launch_derive_matmul(hipStream_t st, const DeriveMatmulArgs& a);
 
+// ---------------------------------------------------------------------------------------
+// training slice (k_train.hip): DDPM loss pieces and the backward of TimestepResBlock
+// ---------------------------------------------------------------------------------------
+void launch_q_sample(hipStream_t st, const float* x0, const float* noise, const long long* t, const float* sqrt_ac, const float* sqrt_1mac,
+                     float* out, int B, long long n);
+void launch_smooth_l1(hipStream_t st, const float* pred, const float* target, float beta, float add, float* loss, float* grad, int B, long long n);
+void launch_transpose_flip(hipStream_t st, const float* src, float* dst, int M, int C, int taps);
+void launch_bias_grad(hipStream_t st, const float* x, float* out, int B, int M, int T, int accumulate);
+void launch_time_sum(hipStream_t st, const float* x, float* rows, int BM, int T);
+void launch_wgrad(hipStream_t st, const float* dY, const float* A, float* dW, int B, int M, int C, int T, int taps, int pad);
+void launch_gn_silu_bwd(hipStream_t st, const float* x, const float* da, const float* gamma, const float* beta, float eps, float* dx,
+                        float* dgamma, float* dbeta, int B, int C, int T, int groups, int accumulate);
+void launch_emb_linear_bwd(hipStream_t st, const float* e, const float* We, const float* dE, float* dWe, float* dbe, float* de, int B, int K, int M);
+void launch_adamw(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd, int step);
+
 void launch_embed_tokens(hipStream_t st, const float* table, const long long* ids, float* out, int B, int ntok, int dim);
 void launch_bias_sum(hipStream_t st, const float* a, const float* b, float* out, int n);

@@ -82,7 +82,16 @@ _SIGS = {
     "mugd_op_s4_conv": [_p, _p, _p, _p, _p, _i, _i, _i],
     "mugd_op_gn_s4_conv": [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i],
     "mugd_op_timestep_embedding": [_p, _p, _p, _i, _i],
+    "mugd_train_q_sample": [_p, _p, _p, _p, _p, _p, _p, _i, C.c_int64],
+    "mugd_train_smooth_l1": [_p, _p, _p, _f, _f, _p, _p, _i, C.c_int64],
+    "mugd_train_resblock": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i],
+    "mugd_train_adamw": [_p, _p, _p, _p, _p, C.c_int64, _f, _f, _f, _f, _f, _i],
 }
+
+
+class ResBlockPtrs(C.Structure):            # mugd_resblock_params / mugd_resblock_grads (include/mugd.h): 12 pointers
+    NAMES = ("gn1_w", "gn1_b", "conv1_w", "conv1_b", "emb_w", "emb_b", "gn2_w", "gn2_b", "conv2_w", "conv2_b", "skip_w", "skip_b")
+    _fields_ = [(n, _p) for n in NAMES]
 EXPORTS = sorted(list(_SIGS) + ["mugd_destroy", "mugd_net_destroy", "mugd_last_error", "mugd_version",
                                 "mugd_profile_kind_name"])
 PROFILE_KINDS = 7
@@ -384,6 +393,56 @@ class Lib:
         y = torch.empty_like(u)
         self.check(self.dll.mugd_op_gn_s4_conv(self.ctx, _ptr(u), _ptr(k), _ptr(D), _ptr(gamma), _ptr(beta), groups, _ptr(y), B, H, L))
         return y
+
+    # ------------------------------------------------------------------ training slice (include/mugd.h)
+    def train_q_sample(self, x0, noise, t, sqrt_ac, sqrt_1mac):
+        """diffusion.py:326-333."""
+        x0, noise, sqrt_ac, sqrt_1mac = map(self.f32, (x0, noise, sqrt_ac, sqrt_1mac))
+        t = t.to(device=self.device, dtype=torch.int64).contiguous()
+        out = torch.empty_like(x0)
+        B = x0.shape[0]
+        self.check(self.dll.mugd_train_q_sample(self.ctx, _ptr(x0), _ptr(noise), _ptr(t), _ptr(sqrt_ac), _ptr(sqrt_1mac), _ptr(out), B, x0.numel() // B))
+        return out
+
+    def train_smooth_l1(self, pred, target, beta=0.02, add=0.01, want_grad=True):
+        """diffusion.py:341-354,386: per-sample loss (B) and d(mean loss)/d pred."""
+        pred, target = self.f32(pred), self.f32(target)
+        B = pred.shape[0]
+        loss = self.empty(B)
+        grad = torch.empty_like(pred) if want_grad else None
+        self.check(self.dll.mugd_train_smooth_l1(self.ctx, _ptr(pred), _ptr(target), float(beta), float(add), _ptr(loss), _ptr(grad), B, pred.numel() // B))
+        return loss, grad
+
+    def train_resblock(self, params, x, emb, dy, groups=32):
+        """TimestepResBlock forward + backward (unet.py:212-239).  params: dict with the module's tensors
+        (in_layers.0.weight/bias, in_layers.2.weight/bias, emb_layers.1.weight/bias, out_layers.0.weight/bias,
+        out_layers.3.weight/bias, optionally skip_connection.weight/bias).  Returns y, dx, demb, grads (same keys)."""
+        keymap = dict(gn1_w="in_layers.0.weight", gn1_b="in_layers.0.bias", conv1_w="in_layers.2.weight", conv1_b="in_layers.2.bias",
+                      emb_w="emb_layers.1.weight", emb_b="emb_layers.1.bias", gn2_w="out_layers.0.weight", gn2_b="out_layers.0.bias",
+                      conv2_w="out_layers.3.weight", conv2_b="out_layers.3.bias", skip_w="skip_connection.weight", skip_b="skip_connection.bias")
+        x, emb, dy = self.f32(x), self.f32(emb), self.f32(dy)
+        P, G, keep, grads = ResBlockPtrs(), ResBlockPtrs(), [], {}
+        for f, k in keymap.items():
+            if k in params:
+                t = self.f32(params[k])
+                g = torch.zeros_like(t)
+                keep += [t, g]
+                grads[k] = g
+                setattr(P, f, t.data_ptr())
+                setattr(G, f, g.data_ptr())
+        B, Cin, T = x.shape
+        Cout = params["in_layers.2.weight"].shape[0]
+        y = self.empty(B, Cout, T)
+        dx = torch.empty_like(x)
+        demb = torch.empty_like(emb)
+        self.check(self.dll.mugd_train_resblock(self.ctx, C.byref(P), _ptr(x), _ptr(emb), _ptr(dy), _ptr(y), _ptr(dx), _ptr(demb), C.byref(G),
+                                                B, Cin, Cout, T, emb.shape[1], groups))
+        return y, dx, demb, grads
+
+    def train_adamw(self, param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+        """One torch.optim.AdamW step, in place on device tensors."""
+        self.check(self.dll.mugd_train_adamw(self.ctx, _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), float(lr),
+                                             float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step)))
 
     def op_timestep_embedding(self, t, dim):
         t = t.to(device=self.device, dtype=torch.int64).contiguous()

@@ -1,0 +1,151 @@
+"""Training slice (first step): DDPM loss pieces and TimestepResBlock forward + backward through the C ABI,
+against torch autograd on the same fp32 math (GroupNorm eps 1e-6, SiLU, conv1d, Linear, smooth_l1(beta=0.02) + 0.01 --
+mug/diffusion/unet.py:212-239, mug/diffusion/diffusion.py:326-354), an AdamW step against torch.optim.AdamW, and the
+data-parallel gradient all-reduce (2-rank gloo) against the full-batch gradient."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+import torch.multiprocessing as mp
+
+
+def rnd(seed, *shape, scale=1.0):
+    return torch.from_numpy(np.random.default_rng(seed).standard_normal(shape).astype(np.float32)) * scale
+
+
+def resblock_params(Cin, Cout, Kemb, seed=0, skip=None):
+    skip = (Cin != Cout) if skip is None else skip
+    p = {"in_layers.0.weight": 1 + 0.1 * rnd(seed + 1, Cin), "in_layers.0.bias": 0.1 * rnd(seed + 2, Cin),
+         "in_layers.2.weight": rnd(seed + 3, Cout, Cin, 3, scale=(3 * Cin) ** -0.5), "in_layers.2.bias": 0.1 * rnd(seed + 4, Cout),
+         "emb_layers.1.weight": rnd(seed + 5, Cout, Kemb, scale=Kemb ** -0.5), "emb_layers.1.bias": 0.1 * rnd(seed + 6, Cout),
+         "out_layers.0.weight": 1 + 0.1 * rnd(seed + 7, Cout), "out_layers.0.bias": 0.1 * rnd(seed + 8, Cout),
+         "out_layers.3.weight": rnd(seed + 9, Cout, Cout, 3, scale=(3 * Cout) ** -0.5), "out_layers.3.bias": 0.1 * rnd(seed + 10, Cout)}
+    if skip:
+        p["skip_connection.weight"] = rnd(seed + 11, Cout, Cin, 1, scale=Cin ** -0.5)
+        p["skip_connection.bias"] = 0.1 * rnd(seed + 12, Cout)
+    return p
+
+
+def resblock_torch(p, x, emb, groups):
+    """TimestepResBlock._forward (unet.py:212-239) in torch functional ops."""
+    h = F.conv1d(F.silu(F.group_norm(x, groups, p["in_layers.0.weight"], p["in_layers.0.bias"], eps=1e-6)),
+                 p["in_layers.2.weight"], p["in_layers.2.bias"], padding=1)
+    e = F.linear(F.silu(emb), p["emb_layers.1.weight"], p["emb_layers.1.bias"])
+    h = h + e[..., None]
+    h = F.conv1d(F.silu(F.group_norm(h, groups, p["out_layers.0.weight"], p["out_layers.0.bias"], eps=1e-6)),
+                 p["out_layers.3.weight"], p["out_layers.3.bias"], padding=1)
+    skip = F.conv1d(x, p["skip_connection.weight"], p["skip_connection.bias"]) if "skip_connection.weight" in p else x
+    return skip + h
+
+
+def close(a, b, tol, what):
+    a, b = a.detach().cpu(), b.detach().cpu()
+    d, s = (a - b).abs().max().item(), b.abs().max().item()
+    assert a.shape == b.shape and d <= tol * max(1.0, s), "%s: max|diff| %.3e (ref max %.3e)" % (what, d, s)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,Kemb,groups", [(2, 32, 32, 40, 48, 8), (3, 32, 64, 64, 64, 16), (1, 64, 32, 20, 32, 32), (2, 128, 128, 96, 512, 32)])
+def test_resblock_forward_backward_vs_autograd(lib, B, Cin, Cout, T, Kemb, groups):
+    p = resblock_params(Cin, Cout, Kemb)
+    x, emb, dy = rnd(20, B, Cin, T), rnd(21, B, Kemb), rnd(22, B, Cout, T)
+    pt = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xt, et = x.clone().requires_grad_(True), emb.clone().requires_grad_(True)
+    yt = resblock_torch(pt, xt, et, groups)
+    yt.backward(dy)
+    y, dx, demb, grads = lib.train_resblock(p, x, emb, dy, groups=groups)
+    close(y, yt, 2e-5, "forward")
+    close(dx, xt.grad, 5e-5, "dx")
+    close(demb, et.grad, 5e-5, "demb")
+    assert set(grads) == set(p)
+    for k in p:
+        close(grads[k], pt[k].grad, 1e-4, "grad of " + k)
+
+
+def test_q_sample_and_smooth_l1_loss(lib):
+    """diffusion.py:326-354,386: x_t = sqrt(ac_t) x0 + sqrt(1 - ac_t) noise;  loss_b = mean smooth_l1(target, pred, beta=0.02) + 0.01."""
+    B, Cc, T = 3, 16, 50
+    betas = np.linspace(1e-4, 2e-2, 1000, dtype=np.float64)
+    ac = torch.from_numpy(np.cumprod(1 - betas)).float()
+    x0, noise = rnd(1, B, Cc, T), rnd(2, B, Cc, T)
+    t = torch.tensor([0, 481, 999])
+    xt = lib.train_q_sample(x0, noise, t, ac.sqrt(), (1 - ac).sqrt()).cpu()
+    ref = ac.sqrt()[t][:, None, None] * x0 + (1 - ac).sqrt()[t][:, None, None] * noise
+    assert torch.equal(xt, ref) or (xt - ref).abs().max().item() < 1e-6          # one fma per element: contraction may differ in the last bit
+    pred = (noise + 0.03 * rnd(3, B, Cc, T)).requires_grad_(True)                # differences on both sides of beta
+    lt = (F.smooth_l1_loss(noise, pred, beta=0.02, reduction="none") + 0.01).mean(dim=[1, 2])
+    lt.mean().backward()
+    loss, grad = lib.train_smooth_l1(pred.detach(), noise)
+    close(loss, lt, 1e-6, "per-sample loss")
+    close(grad, pred.grad, 1e-6, "loss gradient")
+
+
+def test_adamw_step_matches_torch(lib):
+    n = 1000
+    p0, g1, g2 = rnd(5, n), rnd(6, n), rnd(7, n)
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pt], lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    dev = lib.device
+    p, m, v = p0.clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for step, g in enumerate((g1, g2), start=1):
+        pt.grad = g.clone()
+        opt.step()
+        lib.train_adamw(p, g.to(dev), m, v, step, lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+        close(p, pt, 2e-6, "parameters after step %d" % step)
+
+
+# ------------------------------------------------------------------ data parallel: gradient all-reduce over 2 gloo ranks
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    from conftest import emu_lib
+    from mug import train
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lib = emu_lib()
+        B, Cin, Cout, T, Kemb, groups = 4, 32, 32, 24, 32, 8
+        p = resblock_params(Cin, Cout, Kemb)
+        x, emb, target = rnd(30, B, Cin, T), rnd(31, B, Kemb), rnd(32, B, Cout, T)
+        lo, hi = rank * B // world, (rank + 1) * B // world
+        loss, grads = train.resblock_loss_and_grads(lib, p, x[lo:hi], emb[lo:hi], target[lo:hi], groups)
+        train.allreduce_gradients(grads, average=True)
+        q.put((rank, float(loss), {k: v.cpu().numpy() for k, v in grads.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_gradients_equal_full_batch():
+    """configs[4] in miniature: each of 2 ranks computes loss + gradients of the block on its half of the batch (native kernels on
+    the emulated build), one bucketed all_reduce averages them (gloo here, RCCL on the GPU box): equal to the full-batch gradient."""
+    from conftest import emu_lib
+    from mug import train
+    lib = emu_lib()
+    B, Cin, Cout, T, Kemb, groups = 4, 32, 32, 24, 32, 8
+    p = resblock_params(Cin, Cout, Kemb)
+    x, emb, target = rnd(30, B, Cin, T), rnd(31, B, Kemb), rnd(32, B, Cout, T)
+    _, want = train.resblock_loss_and_grads(lib, p, x, emb, target, groups)
+    # and the full-batch gradient itself is autograd's
+    pt = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    lt = (F.smooth_l1_loss(target, resblock_torch(pt, x, emb, groups), beta=0.02, reduction="none") + 0.01).mean(dim=[1, 2]).mean()
+    lt.backward()
+    for k in p:
+        close(want[k], pt[k].grad, 1e-4, "full-batch grad of " + k)
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = [q.get(timeout=600) for _ in procs]
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    for rank, loss, grads in got:
+        for k in p:
+            close(torch.from_numpy(grads[k]), want[k], 1e-5, "rank %d averaged grad of %s" % (rank, k))
