@@ -8,7 +8,7 @@
 //       a2 = silu(GN2(h));  y = conv3(a2; W2) + b2 + skip(x)          skip = identity | 1x1 conv (Ws, bs)
 //   backward (dy given)
 //       conv data gradients  : the SAME implicit-GEMM kernel (conv_gemm) on the transposed, tap-flipped weights
-//       conv weight gradients: wgrad_kernel (contraction over batch x time), bias gradients: row sums
+//       conv weight gradients: wgrad_mfma_kernel (contraction over batch x time, on the fp32 matrix cores), bias gradients: row sums
 //       GroupNorm + SiLU     : gn_silu_bwd_kernel, one workgroup per group, two passes per batch row, deterministic
 //       time-embedding rows  : sums over time of dh, then the small Linear's backward
 //   optimiser: adamw_kernel (torch.optim.AdamW semantics: decoupled weight decay).
@@ -93,53 +93,69 @@ __global__ __launch_bounds__(256) void time_sum_kernel(const float* x, float* ro
     if (lane == 0) rows[r] = (float)s;
 }
 
-// Weight gradient of conv1d (taps 1 | 3, stride 1, zero padding `pad`):
-//   dW[m][c][tap] = sum_{b,t} dY[b][m][t] A[b][c][t + tap - pad]
-// One workgroup = a 32 (m) x 16 (c) tile, all taps; the (b, t) contraction is walked in 64-sample slabs staged in LDS
-// (dY slab 32 x 64, A slab 16 x (64 + 2)); thread (mi = tid / 8, cq = tid % 8) owns rows mi, channels cq and cq + 8.
-// First version of the training path: VALU fma, not yet on the matrix cores (the contraction axis is time, for which the
-// inference kernels' operand layout has no fragment order).
-__global__ __launch_bounds__(256) void wgrad_kernel(const float* dY, const float* A, float* dW, int B, int M, int C, int T, int taps, int pad) {
-    __shared__ float sy[32][65];
-    __shared__ float sa[16][68];
-    const int m0 = blockIdx.x * 32, c0 = blockIdx.y * 16;
-    const int tid = threadIdx.x, mi = tid >> 3, cq = tid & 7;
-    float acc[2][3];
+// Weight gradient of conv1d (taps 1 | 3, stride 1, zero padding `pad`) on the fp32 matrix cores:
+//   dW[m][c][tap] = sum_{b,t} dY[b][m][t] A[b][c][t + tap - pad]          -- a GEMM whose contraction axis is batch x time.
+// One workgroup = a 32 (m) x 32 (c) tile, all taps (one 32x32 accumulator per tap); its 8 waves split the (b, 32-sample slab)
+// work list, each staging its slab of dY (32 x 32) and of A (32 x (32 + 2)) in a private LDS window and feeding
+// v_mfma_f32_32x32x2_f32 with A-operand = dY[row r][t + h], B-operand = A[col n][t + h + tap - pad]; the 8 partial tiles are
+// summed through LDS in fixed order.  Grid (M / 32, C / 32): 256 workgroups for the 512 x 512 layers.
+constexpr int WG_RS = 36;                            // LDS row stride (floats): 32 samples + 2 halo, padded
+
+__global__ __launch_bounds__(512) void wgrad_mfma_kernel(const float* dY, const float* A, float* dW, int B, int M, int C, int T, int taps, int pad) {
+    __shared__ float sy[8][32 * WG_RS];
+    __shared__ float sa[8][32 * WG_RS];
+    float (*red)[16 * 64] = reinterpret_cast<float (*)[16 * 64]>(&sy[0][0]);          // the combine reuses the dY slabs (8 x 1024 <= 8 x 1152 floats)
+    const int m0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, h = lane >> 5, n = lane & 31;
+    f32x16 acc[3];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int k = 0; k < 3; ++k)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) acc[j][k] = 0.f;
-    for (int b = 0; b < B; ++b) {
-        for (int t0 = 0; t0 < T; t0 += 64) {
-            __syncthreads();
-            for (int i = tid; i < 32 * 64; i += 256) {
-                const int r = i >> 6, tt = i & 63;
-                const int m = m0 + r, t = t0 + tt;
-                sy[r][tt] = (m < M && t < T) ? dY[((size_t)b * M + m) * T + t] : 0.f;
+        for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
+    const int nslab = (T + 31) / 32, total = B * nslab;
+    float* wy = sy[wave];
+    float* wa = sa[wave];
+    for (int s = wave; s < total; s += 8) {
+        const int b = s / nslab, t0 = (s - b * nslab) * 32;
+        // stage dY[m0 + r][t0 .. t0+31] and A[c0 + r][t0 - pad .. t0 + 33 - pad]: lane -> row lane / 2, half-row lane % 2
+        {
+            const int r = lane >> 1, hf = lane & 1;
+            const int m = m0 + r, c = c0 + r;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int tt = hf * 16 + j, t = t0 + tt;
+                wy[r * WG_RS + tt] = (m < M && t < T) ? dY[((size_t)b * M + m) * T + t] : 0.f;
             }
-            for (int i = tid; i < 16 * 66; i += 256) {
-                const int r = i / 66, tt = i - r * 66;
-                const int c = c0 + r, t = t0 + tt - pad;
-                sa[r][tt] = (c < C && t >= 0 && t < T) ? A[((size_t)b * C + c) * T + t] : 0.f;
-            }
-            __syncthreads();
-            for (int tt = 0; tt < 64; ++tt) {
-                const float y = sy[mi][tt];
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int k = 0; k < 3; ++k)
-                        if (k < taps) acc[j][k] += y * sa[cq + 8 * j][tt + k];
+            for (int j = 0; j < 17; ++j) {
+                const int tt = hf * 17 + j, t = t0 + tt - pad;
+                wa[r * WG_RS + tt] = (c < C && t >= 0 && t < T) ? A[((size_t)b * C + c) * T + t] : 0.f;
             }
         }
-    }
-    const int m = m0 + mi;
-    if (m < M) {
+        wave_sync();
+#pragma unroll 4
+        for (int k = 0; k < 32; k += 2) {
+            const float a = wy[n * WG_RS + k + h];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int c = c0 + cq + 8 * j;
-            if (c < C)
-                for (int k = 0; k < taps; ++k) dW[((size_t)m * C + c) * taps + k] = acc[j][k];
+            for (int tap = 0; tap < 3; ++tap)
+                if (tap < taps) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wa[n * WG_RS + k + h + tap], acc[tap], 0, 0, 0);
+        }
+        wave_sync();
+    }
+    // combine the 8 partial tiles, tap by tap (fixed order), and store: accumulator register i of lane (h, n) is row (i & 3) + 8 (i >> 2) + 4 h, column n
+    for (int tap = 0; tap < taps; ++tap) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[wave][i * 64 + lane] = acc[tap][i];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = wave * 2 + q;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += red[w][i * 64 + lane];
+            const int m = m0 + (i & 3) + 8 * (i >> 2) + 4 * h, c = c0 + n;
+            if (m < M && c < C) dW[((size_t)m * C + c) * taps + tap] = v;
         }
     }
 }
@@ -287,7 +303,7 @@ void launch_time_sum(hipStream_t st, const float* x, float* rows, int BM, int T)
 }
 void launch_wgrad(hipStream_t st, const float* dY, const float* A, float* dW, int B, int M, int C, int T, int taps, int pad) {
     MUGD_CHECK(taps == 1 || taps == 3, -2, "wgrad: taps must be 1 or 3");
-    hipLaunchKernelGGL(wgrad_kernel, dim3(cdiv(M, 32), cdiv(C, 16)), dim3(256), 0, st, dY, A, dW, B, M, C, T, taps, pad);
+    hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(cdiv(M, 32), cdiv(C, 32)), dim3(512), 0, st, dY, A, dW, B, M, C, T, taps, pad);
 }
 void launch_gn_silu_bwd(hipStream_t st, const float* x, const float* da, const float* gamma, const float* beta, float eps, float* dx,
                         float* dgamma, float* dbeta, int B, int C, int T, int groups, int accumulate) {

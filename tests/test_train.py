@@ -47,7 +47,7 @@ def close(a, b, tol, what):
     assert a.shape == b.shape and d <= tol * max(1.0, s), "%s: max|diff| %.3e (ref max %.3e)" % (what, d, s)
 
 
-@pytest.mark.parametrize("B,Cin,Cout,T,Kemb,groups", [(2, 32, 32, 40, 48, 8), (3, 32, 64, 64, 64, 16), (1, 64, 32, 20, 32, 32), (2, 128, 128, 96, 512, 32)])
+@pytest.mark.parametrize("B,Cin,Cout,T,Kemb,groups", [(2, 32, 32, 40, 48, 8), (3, 32, 64, 64, 64, 16), (1, 64, 32, 20, 32, 32), (2, 128, 128, 96, 512, 32), (4, 256, 512, 64, 512, 32)])
 def test_resblock_forward_backward_vs_autograd(lib, B, Cin, Cout, T, Kemb, groups):
     p = resblock_params(Cin, Cout, Kemb)
     x, emb, dy = rnd(20, B, Cin, T), rnd(21, B, Kemb), rnd(22, B, Cout, T)
