@@ -4,6 +4,8 @@
 // pass (sum and sum of squares accumulated in fp64, so E[x^2]-mean^2 keeps fp32-level accuracy),
 // reductions are wavefront shuffles + one LDS exchange, then one normalise-and-write pass that
 // re-reads the (L1/L2-hot) rows.
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace {
@@ -229,6 +231,35 @@ __global__ __launch_bounds__(256) void row_sums_kernel(const float* x, double* o
     if (lane == 0) { out[2 * (size_t)row] = s; out[2 * (size_t)row + 1] = q; }
 }
 
+// long rows: grid (rows, nsplit), each workgroup sums one T / nsplit stretch of a row in fp64 and ADDS it to the (zeroed)
+// accumulators -- nsplit atomics per address.  Used where a producing conv has so many column tiles per row that their
+// per-tile atomics would queue up on one address (wave encoder / VAE decoder: 128..1024 tiles per row, ~0.2 us each).
+__global__ __launch_bounds__(256) void row_sums_split_kernel(const float* x, double* out, int rows, int T, int nsplit) {
+    __shared__ double red[2][4];
+    const int row = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
+    const int per = ((T + nsplit - 1) / nsplit + 3) & ~3;
+    const int lo = part * per, hi = lo + per < T ? lo + per : T;
+    const float* p = x + (size_t)row * T;
+    double s = 0.0, q = 0.0;
+    if ((T & 3) == 0) {
+        for (int t = lo + 4 * tid; t < hi; t += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(p + t);
+            s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+            q += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+        }
+    } else {
+        for (int t = lo + tid; t < hi; t += 256) { const double v = p[t]; s += v; q += v * v; }
+    }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s; red[1][tid >> 6] = q; }
+    __syncthreads();
+    if (tid == 0) {
+        atomicAdd(out + 2 * (size_t)row, (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+        atomicAdd(out + 2 * (size_t)row + 1, (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+    }
+}
+
 __global__ void interleave2_kernel(const float* x, const float* y, float* out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { out[2 * i] = x[i]; out[2 * i + 1] = y[i]; }
@@ -265,6 +296,11 @@ void launch_ln_stats(hipStream_t st, const LnStatArgs& a) {
 
 void launch_interleave2(hipStream_t st, const float* x, const float* y, float* out, int n) {
     hipLaunchKernelGGL(interleave2_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, x, y, out, n);
+}
+
+void launch_row_sums_add(hipStream_t st, const float* x, double* out, int rows, int T) {
+    const int nsplit = std::max(1, std::min(32, T / 2048));
+    hipLaunchKernelGGL(row_sums_split_kernel, dim3(rows, nsplit), dim3(256), 0, st, x, out, rows, T, nsplit);
 }
 
 void launch_row_sums(hipStream_t st, const float* x, double* out, int rows, int T) {

@@ -184,6 +184,11 @@ void launch_gn_stats(hipStream_t st, const GnStatArgs& a);
 // fp64 {sum, sum of squares} of every (batch, channel) row of a tensor the library did not produce itself (the audio
 // feature maps): the ConvArgs::rowstat of an input.  out (rows, 2).
 void launch_row_sums(hipStream_t st, const float* x, double* out, int rows, int T);
+// the same sums ADDED to zeroed accumulators, long rows split over several workgroups (see Net::conv: layers whose column-tile
+// count per row would serialise the producing conv's per-tile atomics)
+void launch_row_sums_add(hipStream_t st, const float* x, double* out, int rows, int T);
+// column tiles per output row above which a conv's row sums come from launch_row_sums_add instead of per-tile atomics
+constexpr int CONV_ROWSTAT_MAX_TILES = 64;
 struct LnStatArgs { const float* x; float* stat; int B, C, T; float eps; };     // stat (B, T, 2): {mean, rstd}
 void launch_ln_stats(hipStream_t st, const LnStatArgs& a);
 void launch_interleave2(hipStream_t st, const float* x, const float* y, float* out, int n);   // out[i] = {x[i], y[i]}

@@ -1,6 +1,7 @@
 #include "net.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 // =======================================================================================
@@ -486,9 +487,16 @@ Tensor Net::conv(const ConvSpec& s) {
     a.resid = s.resid.p;
     if (s.resid.p) MUGD_CHECK(s.resid.C == s.Mout && s.resid.T == s.Tout && s.resid.bmod == 0, -2, "conv: residual shape mismatch at " + s.key);
     a.y = y.p; a.nchunk = pw.nchunk;
+    bool rowstat_pass = false;
     if (s.want_rowstat && ctx->fuse_norm && ctx->fuse_stats && s.epi == EPI_NONE) {
         y.rowstat = alloc_rowstat((size_t)Bn * s.Mout * 2);
-        a.rowstat = y.rowstat;
+        // Every tile ADDS its rows' sums with fp64 atomics: cdiv(T, tn) of them queue on each address (~0.2 us apiece across
+        // the XCDs).  16 per address in the U-Net -- hidden under the other tiles; 128..1024 in the wave encoder and the VAE
+        // decoder, where they WERE the layer's duration (T = 32768: 213 us for 21 us of MFMA work).  Long rows take one more
+        // pass over the output instead.
+        static const int max_tiles = getenv("MUGD_ROWSTAT_MAX_TILES") ? atoi(getenv("MUGD_ROWSTAT_MAX_TILES")) : CONV_ROWSTAT_MAX_TILES;
+        rowstat_pass = cdiv(s.Tout, a.tn) > max_tiles;
+        a.rowstat = rowstat_pass ? nullptr : y.rowstat;
     }
     if (s.want_colstat && ctx->fuse_stats && ctx->fuse_norm && s.epi == EPI_NONE && s.Tout % 4 == 0) {
         bool fast = true;                                   // only the fast-window kernels emit column sums
@@ -504,6 +512,10 @@ Tensor Net::conv(const ConvSpec& s) {
     emit([a](hipStream_t st) { launch_conv(st, a); }, (s.epi == EPI_GLU || s.epi == EPI_GEGLU) ? OP_CONV_GATED : OP_CONV, 2.0 * s.Mrows * kdim * s.Tout * Bn,
          s.key + " M=" + std::to_string(s.Mrows) + " K=" + std::to_string((long long)kdim) + " T=" + std::to_string(s.Tout) +
              " nseg=" + std::to_string(a.nseg) + " tn=" + std::to_string(a.tn));
+    if (rowstat_pass) {
+        const float* yp = y.p; double* rp = y.rowstat; const int rows = Bn * s.Mout, T = s.Tout;
+        emit([=](hipStream_t st) { launch_row_sums_add(st, yp, rp, rows, T); }, OP_SMALL, 0, s.key + " row sums");
+    }
     return y;
 }
 
