@@ -236,6 +236,19 @@ typedef struct {
 /* y = block(x, emb) (B, Cout, T); given dy: dx (B, Cin, T), demb (B, Kemb) and every parameter gradient.  Synchronises. */
 int mugd_train_resblock(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x, const float* emb, const float* dy, float* y, float* dx,
                         float* demb, const mugd_resblock_grads* g, int B, int Cin, int Cout, int T, int Kemb, int groups);
+/* mug/model/attention.py:154-199 ContextualTransformer (depth 1) forward and backward.  params / grads: MUGD_TF_NPARAMS pointers in the
+ * order of the enum below, every tensor in the module's own layout (Linear weights (out, in), proj_in / proj_out (C, C, 1), the two
+ * attention tables (2 pmax + 1, heads)).  x, dy, y, dx: (B, C, T).  context (B, Cc, Tk) channel-major, or NULL: attn2 is then a second
+ * self-attention (wave encoder) and dcontext is ignored.  dcontext (nullable): (B, Cc, Tk).  Synchronises. */
+enum {
+    MUGD_TF_NORM_W, MUGD_TF_NORM_B, MUGD_TF_PROJ_IN_W, MUGD_TF_PROJ_IN_B,
+    MUGD_TF_LN1_W, MUGD_TF_LN1_B, MUGD_TF_A1_Q, MUGD_TF_A1_K, MUGD_TF_A1_V, MUGD_TF_A1_OUT_W, MUGD_TF_A1_OUT_B, MUGD_TF_A1_REL, MUGD_TF_A1_CEMB,
+    MUGD_TF_LN2_W, MUGD_TF_LN2_B, MUGD_TF_A2_Q, MUGD_TF_A2_K, MUGD_TF_A2_V, MUGD_TF_A2_OUT_W, MUGD_TF_A2_OUT_B, MUGD_TF_A2_REL, MUGD_TF_A2_CEMB,
+    MUGD_TF_LN3_W, MUGD_TF_LN3_B, MUGD_TF_FF0_W, MUGD_TF_FF0_B, MUGD_TF_FF2_W, MUGD_TF_FF2_B, MUGD_TF_PROJ_OUT_W, MUGD_TF_PROJ_OUT_B,
+    MUGD_TF_NPARAMS
+};
+int mugd_train_transformer(mugd_ctx* ctx, const float* const* params, const float* x, const float* context, const float* dy, float* y, float* dx,
+                           float* dcontext, float* const* grads, int B, int C, int T, int Cc, int Tk, int heads, int groups, int pmax);
 /* torch.optim.AdamW step (decoupled weight decay) on a flat parameter block; step counts from 1. */
 int mugd_train_adamw(mugd_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                      float beta2, float eps, float weight_decay, int step);

@@ -173,6 +173,7 @@ __device__ __forceinline__ double wg_sum(double v, double* red) {        // 256-
 // Backward of a = silu(GroupNorm(x; gamma, beta)):  given da, returns dx (+= if accumulate) and dgamma / dbeta.
 // One workgroup per group; for every batch row: pass 1 statistics of x, pass 2 the two group means of the normalised-gradient
 // terms, pass 3 dx.  dgamma / dbeta are accumulated over the batch in registers of the owning threads (fp64): deterministic.
+template <bool SILU>
 __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float* x, const float* da, const float* gamma, const float* beta, float eps,
                                                           float* dx, float* dgamma, float* dbeta, int B, int C, int T, int groups, int accumulate) {
     __shared__ double red[4];
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float* x, const 
                 const float xh = (xg[(size_t)c * T + t] - mu) * rstd;
                 const float u = xh * gm + bt;
                 const float sg = 1.0f / (1.0f + expf(-u));
-                const float du = ag[(size_t)c * T + t] * (sg * (1.0f + u * (1.0f - sg)));
+                const float du = ag[(size_t)c * T + t] * (SILU ? sg * (1.0f + u * (1.0f - sg)) : 1.0f);
                 dgm += (double)du * (double)xh;
                 dbt += (double)du;
                 const float dxh = du * gm;
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float* x, const 
                 const float xh = (xg[o] - mu) * rstd;
                 const float u = xh * gm + bt;
                 const float sg = 1.0f / (1.0f + expf(-u));
-                const float dxh = ag[o] * (sg * (1.0f + u * (1.0f - sg))) * gm;
+                const float dxh = ag[o] * (SILU ? sg * (1.0f + u * (1.0f - sg)) : 1.0f) * gm;
                 const float v = rstd * (dxh - fm1 - xh * fm2);
                 dg[o] = accumulate ? dg[o] + v : v;
             }
@@ -307,8 +308,13 @@ void launch_wgrad(hipStream_t st, const float* dY, const float* A, float* dW, in
 }
 void launch_gn_silu_bwd(hipStream_t st, const float* x, const float* da, const float* gamma, const float* beta, float eps, float* dx,
                         float* dgamma, float* dbeta, int B, int C, int T, int groups, int accumulate) {
-    MUGD_CHECK(C % groups == 0 && C / groups <= 64, -2, "gn_silu_bwd: at most 64 channels per group");
-    hipLaunchKernelGGL(gn_silu_bwd_kernel, dim3(groups), dim3(256), 0, st, x, da, gamma, beta, eps, dx, dgamma, dbeta, B, C, T, groups, accumulate);
+    launch_gn_bwd(st, x, da, gamma, beta, eps, dx, dgamma, dbeta, B, C, T, groups, accumulate, 1);
+}
+void launch_gn_bwd(hipStream_t st, const float* x, const float* da, const float* gamma, const float* beta, float eps, float* dx,
+                   float* dgamma, float* dbeta, int B, int C, int T, int groups, int accumulate, int silu) {
+    MUGD_CHECK(C % groups == 0 && C / groups <= 64, -2, "gn_bwd: at most 64 channels per group");
+    if (silu) hipLaunchKernelGGL(gn_silu_bwd_kernel<true>, dim3(groups), dim3(256), 0, st, x, da, gamma, beta, eps, dx, dgamma, dbeta, B, C, T, groups, accumulate);
+    else hipLaunchKernelGGL(gn_silu_bwd_kernel<false>, dim3(groups), dim3(256), 0, st, x, da, gamma, beta, eps, dx, dgamma, dbeta, B, C, T, groups, accumulate);
 }
 void launch_emb_linear_bwd(hipStream_t st, const float* e, const float* We, const float* dE, float* dWe, float* dbe, float* de, int B, int K, int M) {
     const int rb = cdiv(M, 4);

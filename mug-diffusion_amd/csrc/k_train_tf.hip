@@ -1,0 +1,256 @@
+// Training slice, second block type: the backward kernels of ContextualTransformer (mug/model/attention.py:91-199) that the
+// conv kernels do not already provide -- LayerNorm over channels, the relative-position attention, GEGLU.  All tensors stay
+// channel-major (B, C, T) like the inference path (a Linear over the last dim of (B, T, C) is a 1x1 conv here).
+//
+//   attention (attention.py:91-126), per (batch row, head), queries i, keys j, idx = clamp(j - i, -pmax, pmax) + pmax:
+//       sim = (q.k + Rel[idx]) scale ;  S = softmax_j(sim) ;  A = S * Cemb[idx] ;  o = A v
+//   backward, given do:
+//       dA = do.v ;  dCemb[idx] += dA S ;  dS = dA Cemb[idx] ;  dsim = S (dS - sum_j dS S) ;  dRel[idx] += scale dsim
+//       dq = scale dsim k ;  dk = scale dsim^T q ;  dv = A^T do
+//   First version: A, dsim and dA*S are MATERIALISED per (batch row, head) ((Tq, Tk) each; T <= 256 in the U-Net), row kernel ->
+//   column kernel -> table kernel, VALU arithmetic, fixed summation orders (deterministic).  Not tuned.
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ double wave_sum_dd(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __hiloint2double(__shfl_xor(__double2hiint(v), o), __shfl_xor(__double2loint(v), o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum_ff(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max_ff(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ---- LayerNorm over C of a (B, C, T) tensor, backward.  grid (ceil(T / 64), B), block 256 = 64 columns x 4 channel partitions.
+// dx (+)= rstd (g dy - mean_c(g dy) - xhat mean_c(g dy xhat));  stat (B, T, 2) = {mean, rstd} for the parameter-gradient kernel.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* x, const float* dy, const float* gamma, float eps, float* dx, float* stat,
+                                                     int B, int C, int T, int accumulate) {
+    __shared__ double red[2][4][64];
+    const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + col, b = blockIdx.y;
+    const bool ok = t < T;
+    const int tc = ok ? t : T - 1;
+    const float* xb = x + (size_t)b * C * T + tc;
+    const float* db = dy + (size_t)b * C * T + tc;
+    double s1 = 0.0, s2 = 0.0;
+    for (int c = part; c < C; c += 4) { const double v = xb[(size_t)c * T]; s1 += v; s2 += v * v; }
+    red[0][part][col] = s1; red[1][part][col] = s2;
+    __syncthreads();
+    s1 = (red[0][0][col] + red[0][1][col]) + (red[0][2][col] + red[0][3][col]);
+    s2 = (red[1][0][col] + red[1][1][col]) + (red[1][2][col] + red[1][3][col]);
+    __syncthreads();
+    const double mean = s1 / (double)C;
+    double var = s2 / (double)C - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps)), mu = (float)mean;
+    double a1 = 0.0, a2 = 0.0;
+    for (int c = part; c < C; c += 4) {
+        const float xh = (xb[(size_t)c * T] - mu) * rstd;
+        const float gd = gamma[c] * db[(size_t)c * T];
+        a1 += (double)gd; a2 += (double)gd * (double)xh;
+    }
+    red[0][part][col] = a1; red[1][part][col] = a2;
+    __syncthreads();
+    a1 = (red[0][0][col] + red[0][1][col]) + (red[0][2][col] + red[0][3][col]);
+    a2 = (red[1][0][col] + red[1][1][col]) + (red[1][2][col] + red[1][3][col]);
+    const float m1 = (float)(a1 / (double)C), m2 = (float)(a2 / (double)C);
+    if (ok) {
+        float* ob = dx + (size_t)b * C * T + t;
+        for (int c = part; c < C; c += 4) {
+            const float xh = (xb[(size_t)c * T] - mu) * rstd;
+            const float v = rstd * (gamma[c] * db[(size_t)c * T] - m1 - xh * m2);
+            ob[(size_t)c * T] = accumulate ? ob[(size_t)c * T] + v : v;
+        }
+        if (part == 0) { stat[2 * ((size_t)b * T + t)] = mu; stat[2 * ((size_t)b * T + t) + 1] = rstd; }
+    }
+}
+
+// dgamma[c] = sum_{b,t} dy xhat ; dbeta[c] = sum_{b,t} dy.  One wave per channel, fp64.
+__global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* x, const float* dy, const float* stat, float* dgamma, float* dbeta,
+                                                            int B, int C, int T) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= C) return;
+    double g = 0.0, bsum = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const float* xr = x + ((size_t)b * C + c) * T;
+        const float* dr = dy + ((size_t)b * C + c) * T;
+        const float* st = stat + 2 * (size_t)b * T;
+        for (int t = lane; t < T; t += 64) {
+            const float xh = (xr[t] - st[2 * t]) * st[2 * t + 1];
+            g += (double)dr[t] * (double)xh;
+            bsum += (double)dr[t];
+        }
+    }
+    g = wave_sum_dd(g);
+    bsum = wave_sum_dd(bsum);
+    if (lane == 0) { dgamma[c] = (float)g; dbeta[c] = (float)bsum; }
+}
+
+// ---- GEGLU (attention.py:38-47): u (B, 2 Ch, T), rows [0, Ch) = a, rows [Ch, 2 Ch) = gate;  f = a gelu_erf(gate)
+__global__ void geglu_fwd_kernel(const float* u, float* f, int B, int Ch, int T) {
+    const long long n = (long long)B * Ch * T;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / ((long long)Ch * T), r = i - b * (long long)Ch * T;
+        const float a = u[b * 2 * Ch * T + r], g = u[b * 2 * Ch * T + (long long)Ch * T + r];
+        f[i] = a * (0.5f * g * (1.0f + erff(g * 0.70710678118654752f)));
+    }
+}
+__global__ void geglu_bwd_kernel(const float* u, const float* df, float* du, int B, int Ch, int T) {
+    const long long n = (long long)B * Ch * T;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / ((long long)Ch * T), r = i - b * (long long)Ch * T;
+        const long long ia = b * 2 * Ch * T + r, ig = ia + (long long)Ch * T;
+        const float a = u[ia], g = u[ig], d = df[i];
+        const float Phi = 0.5f * (1.0f + erff(g * 0.70710678118654752f));
+        const float phi = 0.3989422804014327f * expf(-0.5f * g * g);
+        du[ia] = d * (g * Phi);
+        du[ig] = d * a * (Phi + g * phi);
+    }
+}
+
+// ---- attention backward, row kernel: one wave per query row.  grid (ceil(Tq / 4), heads, B), block 256.
+constexpr int ATB_TK = 1024;            // keys per row held in LDS
+__global__ __launch_bounds__(256) void attn_bwd_rows_kernel(const AttnBwdArgs a) {
+    __shared__ float qs[4][64], dos[4][64];
+    __shared__ float srow[4][ATB_TK], drow[4][ATB_TK];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave, h = blockIdx.y, b = blockIdx.z;
+    const int d = a.d, Tq = a.Tq, Tk = a.Tk;
+    if (i >= Tq) return;                                   // whole wave; no workgroup barrier below
+    const float* q = a.q + (size_t)b * a.q_bstride + (size_t)h * d * Tq;
+    const float* k = a.k + (size_t)b * a.k_bstride + (size_t)h * d * Tk;
+    const float* v = a.v + (size_t)b * a.v_bstride + (size_t)h * d * Tk;
+    const float* dO = a.dout + (size_t)b * a.o_bstride + (size_t)h * d * Tq;
+    if (lane < d) { qs[wave][lane] = q[(size_t)lane * Tq + i]; dos[wave][lane] = dO[(size_t)lane * Tq + i]; }
+    wave_sync();
+    float mx = -3.0e38f;
+    for (int j = lane; j < Tk; j += 64) {
+        float dot = 0.f, da = 0.f;
+        for (int e = 0; e < d; ++e) { dot += qs[wave][e] * k[(size_t)e * Tk + j]; da += dos[wave][e] * v[(size_t)e * Tk + j]; }
+        int idx = j - i;
+        idx = (idx < -a.pmax ? -a.pmax : (idx > a.pmax ? a.pmax : idx)) + a.pmax;
+        const float sim = (dot + a.rel[idx * a.heads + h]) * a.scale;
+        srow[wave][j] = sim; drow[wave][j] = da;
+        mx = fmaxf(mx, sim);
+    }
+    mx = wave_max_ff(mx);
+    float sum = 0.f;
+    for (int j = lane; j < Tk; j += 64) { const float e = expf(srow[wave][j] - mx); srow[wave][j] = e; sum += e; }
+    sum = wave_sum_ff(sum);
+    const float inv = 1.0f / sum;
+    float D = 0.f;
+    for (int j = lane; j < Tk; j += 64) {
+        int idx = j - i;
+        idx = (idx < -a.pmax ? -a.pmax : (idx > a.pmax ? a.pmax : idx)) + a.pmax;
+        const float S = srow[wave][j] * inv, G = a.cemb[idx * a.heads + h];
+        srow[wave][j] = S;
+        D += drow[wave][j] * G * S;
+    }
+    D = wave_sum_ff(D);
+    const size_t mrow = (((size_t)b * a.heads + h) * Tq + i) * Tk;
+    for (int j = lane; j < Tk; j += 64) {
+        int idx = j - i;
+        idx = (idx < -a.pmax ? -a.pmax : (idx > a.pmax ? a.pmax : idx)) + a.pmax;
+        const float S = srow[wave][j], G = a.cemb[idx * a.heads + h], dA = drow[wave][j];
+        const float ds = S * (dA * G - D);
+        a.Amat[mrow + j] = S * G;
+        a.dsim[mrow + j] = ds;
+        a.dG[mrow + j] = dA * S;
+        drow[wave][j] = ds;
+    }
+    wave_sync();
+    // dq_i[e] = scale sum_j dsim_j k[e][j]: lane = e
+    if (lane < d) {
+        float s = 0.f;
+        const float* kr = k + (size_t)lane * Tk;
+        for (int j = 0; j < Tk; ++j) s += drow[wave][j] * kr[j];
+        a.dq[(size_t)b * a.q_bstride + ((size_t)h * d + lane) * Tq + i] = s * a.scale;
+    }
+}
+
+// column kernel: one lane per key j.  dk[e][j] = scale sum_i dsim[i][j] q[e][i] ;  dv[e][j] = sum_i A[i][j] do[e][i].  d <= 64.
+__global__ __launch_bounds__(64) void attn_bwd_cols_kernel(const AttnBwdArgs a) {
+    const int j = blockIdx.x * 64 + threadIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int d = a.d, Tq = a.Tq, Tk = a.Tk;
+    const bool ok = j < Tk;
+    const int jc = ok ? j : Tk - 1;
+    const float* q = a.q + (size_t)b * a.q_bstride + (size_t)h * d * Tq;
+    const float* dO = a.dout + (size_t)b * a.o_bstride + (size_t)h * d * Tq;
+    const size_t m0 = ((size_t)b * a.heads + h) * Tq * Tk;
+    float dk[64], dv[64];
+#pragma unroll
+    for (int e = 0; e < 64; ++e) { dk[e] = 0.f; dv[e] = 0.f; }
+    for (int i = 0; i < Tq; ++i) {
+        const float ds = a.dsim[m0 + (size_t)i * Tk + jc], aa = a.Amat[m0 + (size_t)i * Tk + jc];
+#pragma unroll
+        for (int e = 0; e < 64; ++e)
+            if (e < d) { dk[e] += ds * q[(size_t)e * Tq + i]; dv[e] += aa * dO[(size_t)e * Tq + i]; }
+    }
+    if (!ok) return;
+#pragma unroll
+    for (int e = 0; e < 64; ++e)
+        if (e < d) {
+            a.dk[(size_t)b * a.k_bstride + ((size_t)h * d + e) * Tk + j] = dk[e] * a.scale;
+            a.dv[(size_t)b * a.v_bstride + ((size_t)h * d + e) * Tk + j] = dv[e];
+        }
+}
+
+// table kernel: drel[r][h] = scale sum dsim over the cells with idx == r ;  dcemb[r][h] = sum dA S.  grid (2 pmax + 1, heads), block 256
+__global__ __launch_bounds__(256) void attn_bwd_tables_kernel(const AttnBwdArgs a) {
+    __shared__ double red[2][4];
+    const int r = blockIdx.x, h = blockIdx.y, off = r - a.pmax;
+    const int Tq = a.Tq, Tk = a.Tk;
+    double s1 = 0.0, s2 = 0.0;
+    for (int bi = threadIdx.x; bi < a.B * Tq; bi += 256) {
+        const int b = bi / Tq, i = bi - b * Tq;
+        const size_t m0 = (((size_t)b * a.heads + h) * Tq + i) * Tk;
+        int jlo, jhi;                                           // inclusive range of keys with this index
+        if (off == -a.pmax) { jlo = 0; jhi = i - a.pmax; }
+        else if (off == a.pmax) { jlo = i + a.pmax; jhi = Tk - 1; }
+        else { jlo = jhi = i + off; }
+        jlo = jlo < 0 ? 0 : jlo;
+        jhi = jhi > Tk - 1 ? Tk - 1 : jhi;
+        for (int j = jlo; j <= jhi; ++j) { s1 += (double)a.dsim[m0 + j]; s2 += (double)a.dG[m0 + j]; }
+    }
+    s1 = wave_sum_dd(s1);
+    s2 = wave_sum_dd(s2);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.drel[r * a.heads + h] = (float)(((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) * (double)a.scale);
+        a.dcemb[r * a.heads + h] = (float)((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+    }
+}
+
+}  // namespace
+
+void launch_ln_bwd(hipStream_t st, const float* x, const float* dy, const float* gamma, float eps, float* dx, float* stat, float* dgamma,
+                   float* dbeta, int B, int C, int T, int accumulate) {
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(T, 64), B), dim3(256), 0, st, x, dy, gamma, eps, dx, stat, B, C, T, accumulate);
+    hipLaunchKernelGGL(ln_param_grad_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, x, dy, stat, dgamma, dbeta, B, C, T);
+}
+void launch_geglu_fwd(hipStream_t st, const float* u, float* f, int B, int Ch, int T) {
+    const long long n = (long long)B * Ch * T;
+    hipLaunchKernelGGL(geglu_fwd_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 8192)), dim3(256), 0, st, u, f, B, Ch, T);
+}
+void launch_geglu_bwd(hipStream_t st, const float* u, const float* df, float* du, int B, int Ch, int T) {
+    const long long n = (long long)B * Ch * T;
+    hipLaunchKernelGGL(geglu_bwd_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 8192)), dim3(256), 0, st, u, df, du, B, Ch, T);
+}
+void launch_attention_bwd(hipStream_t st, const AttnBwdArgs& a) {
+    MUGD_CHECK(a.d >= 1 && a.d <= 64 && a.Tk >= 1 && a.Tk <= ATB_TK, -2, "attention backward: head dim <= 64, at most 1024 keys");
+    hipLaunchKernelGGL(attn_bwd_rows_kernel, dim3(cdiv(a.Tq, 4), a.heads, a.B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(attn_bwd_cols_kernel, dim3(cdiv(a.Tk, 64), a.heads, a.B), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(attn_bwd_tables_kernel, dim3(2 * a.pmax + 1, a.heads), dim3(256), 0, st, a);
+}

@@ -315,6 +315,24 @@ void launch_time_sum(hipStream_t st, const float* x, float* rows, int BM, int T)
 void launch_wgrad(hipStream_t st, const float* dY, const float* A, float* dW, int B, int M, int C, int T, int taps, int pad);
 void launch_gn_silu_bwd(hipStream_t st, const float* x, const float* da, const float* gamma, const float* beta, float eps, float* dx,
                         float* dgamma, float* dbeta, int B, int C, int T, int groups, int accumulate);
+// GroupNorm backward with (silu = 1) or without (0) the SiLU that follows it
+void launch_gn_bwd(hipStream_t st, const float* x, const float* da, const float* gamma, const float* beta, float eps, float* dx,
+                   float* dgamma, float* dbeta, int B, int C, int T, int groups, int accumulate, int silu);
+// k_train_tf.hip: LayerNorm over channels (stat: (B, T, 2) scratch), GEGLU, relative-position attention
+void launch_ln_bwd(hipStream_t st, const float* x, const float* dy, const float* gamma, float eps, float* dx, float* stat, float* dgamma,
+                   float* dbeta, int B, int C, int T, int accumulate);
+void launch_geglu_fwd(hipStream_t st, const float* u, float* f, int B, int Ch, int T);
+void launch_geglu_bwd(hipStream_t st, const float* u, const float* df, float* du, int B, int Ch, int T);
+struct AttnBwdArgs {         // layouts as AttnArgs; dout = gradient of the attention output
+    const float* q; int q_bstride; const float* k; int k_bstride; const float* v; int v_bstride; const float* dout; int o_bstride;
+    const float* rel; const float* cemb;
+    int B, heads, d, Tq, Tk, pmax;
+    float scale;
+    float* Amat; float* dsim; float* dG;      // scratch, (B, heads, Tq, Tk) each
+    float* dq; float* dk; float* dv;          // same strides as q / k / v
+    float* drel; float* dcemb;                // (2 pmax + 1, heads)
+};
+void launch_attention_bwd(hipStream_t st, const AttnBwdArgs& a);
 void launch_emb_linear_bwd(hipStream_t st, const float* e, const float* We, const float* dE, float* dWe, float* dbe, float* de, int B, int K, int M);
 void launch_adamw(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd, int step);
 

@@ -3,6 +3,8 @@
 // kernel and the kernels of k_train.hip.  Scratch tensors live for the call only.
 #include "../../include/mugd.h"
 
+#include <algorithm>
+#include <cmath>
 #include <vector>
 
 #include "ctx.h"
@@ -62,9 +64,130 @@ void run_group_norm_silu(Ctx& c, const float* x, const float* gamma, const float
     launch_group_norm(c.stream, a);
 }
 
+void run_group_norm_plain(Ctx& c, const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T, int groups) {
+    GnArgs a{};
+    a.seg[0] = NormSeg{x, C, 0};
+    a.nseg = 1; a.Ctot = C; a.T = T; a.groups = groups; a.B = B; a.silu = 0;
+    a.gamma = gamma; a.beta = beta; a.eps = 1e-6f; a.y = y;
+    launch_group_norm(c.stream, a);
+}
+
+// Linear over channels (a 1x1 conv) and its backward pieces; w is the module's (M, K[, 1]) tensor
+struct Lin {
+    Ctx& c; Scratch& sc; int B, T;
+    void fwd(const float* x, const float* w, const float* bias, const float* resid, float* y, int K, int M) {
+        run_conv(c, sc, x, w, bias, nullptr, 0, resid, y, B, K, T, M, 1, 0);
+    }
+    // dx (+= if acc) = W^T dy ;  dW = dy x^T ;  db = row sums of dy
+    void bwd(const float* x, const float* w, const float* dy, float* dx, bool acc, float* dW, float* db, int K, int M, float* wt) {
+        if (dW) launch_wgrad(c.stream, dy, x, dW, B, M, K, T, 1, 0);
+        if (db) launch_bias_grad(c.stream, dy, db, B, M, T, 0);
+        if (dx) {
+            launch_transpose_flip(c.stream, w, wt, M, K, 1);
+            run_conv(c, sc, dy, wt, nullptr, nullptr, 0, acc ? dx : nullptr, dx, B, M, T, K, 1, 0);
+        }
+    }
+};
+
 }  // namespace
 
 extern "C" {
+
+int mugd_train_transformer(mugd_ctx* ctx, const float* const* P, const float* x, const float* context, const float* dy, float* y, float* dx,
+                           float* dcontext, float* const* G, int B, int C, int T, int Cc, int Tk, int heads, int groups, int pmax) {
+    return guarded(ctx, [&] {
+        MUGD_CHECK(P && G && x && dy && y && dx && B > 0 && T > 0 && heads > 0, MUGD_ERR_INVALID, "null/empty argument");
+        MUGD_CHECK(C % heads == 0 && C / heads <= 64 && C % groups == 0, MUGD_ERR_INVALID, "bad head / group split");
+        for (int i = 0; i < MUGD_TF_NPARAMS; ++i) MUGD_CHECK(P[i] && G[i], MUGD_ERR_INVALID, "null parameter / gradient pointer");
+        if (!context) { Cc = C; Tk = T; }
+        MUGD_CHECK(Cc % CONV_CK == 0 && Tk > 0, MUGD_ERR_INVALID, "context channels must be a multiple of 16");
+        Ctx& c = ctx->c;
+        hipStream_t st = c.stream;
+        Scratch sc;
+        const int d = C / heads, Ch = 4 * C;
+        const float scale = 1.0f / sqrtf((float)d);
+        const size_t n = (size_t)B * C * T, nk = (size_t)B * C * Tk;
+        auto buf = [&](size_t k) { return sc.get(k, false, st); };
+        Lin lt{c, sc, B, T}, lk{c, sc, B, Tk};
+        // ---- forward (attention.py:186-199, :148-152), every intermediate kept
+        float *n0 = buf(n), *h0 = buf(n), *l1 = buf(n), *q1 = buf(n), *k1 = buf(n), *v1 = buf(n), *o1 = buf(n), *h1 = buf(n);
+        float *l2 = buf(n), *q2 = buf(n), *k2 = buf(nk), *v2 = buf(nk), *o2 = buf(n), *h2 = buf(n);
+        float *l3 = buf(n), *u = buf(2 * (size_t)B * Ch * T), *f = buf((size_t)B * Ch * T), *h3 = buf(n);
+        auto attn = [&](const float* q, const float* k, const float* v, float* o, int tk, const float* rel, const float* cemb) {
+            AttnArgs a{};
+            a.q = q; a.q_bstride = C * T; a.k = k; a.k_bstride = C * tk; a.v = v; a.v_bstride = C * tk; a.out = o; a.o_bstride = C * T;
+            a.rel = rel; a.cemb = cemb; a.B = B; a.heads = heads; a.d = d; a.Tq = T; a.Tk = tk; a.pmax = pmax; a.scale = scale;
+            launch_attention(st, a);
+        };
+        run_group_norm_plain(c, x, P[MUGD_TF_NORM_W], P[MUGD_TF_NORM_B], n0, B, C, T, groups);
+        lt.fwd(n0, P[MUGD_TF_PROJ_IN_W], P[MUGD_TF_PROJ_IN_B], nullptr, h0, C, C);
+        launch_layer_norm(st, LnArgs{h0, l1, P[MUGD_TF_LN1_W], P[MUGD_TF_LN1_B], B, C, T, 1e-5f});
+        lt.fwd(l1, P[MUGD_TF_A1_Q], nullptr, nullptr, q1, C, C);
+        lt.fwd(l1, P[MUGD_TF_A1_K], nullptr, nullptr, k1, C, C);
+        lt.fwd(l1, P[MUGD_TF_A1_V], nullptr, nullptr, v1, C, C);
+        attn(q1, k1, v1, o1, T, P[MUGD_TF_A1_REL], P[MUGD_TF_A1_CEMB]);
+        lt.fwd(o1, P[MUGD_TF_A1_OUT_W], P[MUGD_TF_A1_OUT_B], h0, h1, C, C);
+        launch_layer_norm(st, LnArgs{h1, l2, P[MUGD_TF_LN2_W], P[MUGD_TF_LN2_B], B, C, T, 1e-5f});
+        const float* ctxp = context ? context : l2;
+        lt.fwd(l2, P[MUGD_TF_A2_Q], nullptr, nullptr, q2, C, C);
+        lk.fwd(ctxp, P[MUGD_TF_A2_K], nullptr, nullptr, k2, Cc, C);
+        lk.fwd(ctxp, P[MUGD_TF_A2_V], nullptr, nullptr, v2, Cc, C);
+        attn(q2, k2, v2, o2, Tk, P[MUGD_TF_A2_REL], P[MUGD_TF_A2_CEMB]);
+        lt.fwd(o2, P[MUGD_TF_A2_OUT_W], P[MUGD_TF_A2_OUT_B], h1, h2, C, C);
+        launch_layer_norm(st, LnArgs{h2, l3, P[MUGD_TF_LN3_W], P[MUGD_TF_LN3_B], B, C, T, 1e-5f});
+        lt.fwd(l3, P[MUGD_TF_FF0_W], P[MUGD_TF_FF0_B], nullptr, u, C, 2 * Ch);
+        launch_geglu_fwd(st, u, f, B, Ch, T);
+        lt.fwd(f, P[MUGD_TF_FF2_W], P[MUGD_TF_FF2_B], h2, h3, Ch, C);
+        lt.fwd(h3, P[MUGD_TF_PROJ_OUT_W], P[MUGD_TF_PROJ_OUT_B], x, y, C, C);
+
+        // ---- backward
+        const size_t wmax = (size_t)2 * Ch * C;
+        float* wt = buf(wmax);
+        float* stat = buf((size_t)B * T * 2);
+        float *dh = buf(n), *da = buf(n), *dq = buf(n), *dk = buf(std::max(n, nk)), *dv = buf(std::max(n, nk)), *dl = buf(n);      // dk / dv serve both attentions
+        float *df = buf((size_t)B * Ch * T), *du = buf(2 * (size_t)B * Ch * T);
+        const size_t nm = (size_t)B * heads * T * std::max(T, Tk);
+        float *Am = buf(nm), *dsm = buf(nm), *dGm = buf(nm);
+        auto attn_bwd = [&](const float* q, const float* k, const float* v, const float* dO, int tk, int rel_i, int cemb_i) {
+            AttnBwdArgs a{};
+            a.q = q; a.q_bstride = C * T; a.k = k; a.k_bstride = C * tk; a.v = v; a.v_bstride = C * tk; a.dout = dO; a.o_bstride = C * T;
+            a.rel = P[rel_i]; a.cemb = P[cemb_i]; a.B = B; a.heads = heads; a.d = d; a.Tq = T; a.Tk = tk; a.pmax = pmax; a.scale = scale;
+            a.Amat = Am; a.dsim = dsm; a.dG = dGm; a.dq = dq; a.dk = dk; a.dv = dv; a.drel = G[rel_i]; a.dcemb = G[cemb_i];
+            launch_attention_bwd(st, a);
+        };
+        // proj_out: y = Wout h3 + b + x
+        lt.bwd(h3, P[MUGD_TF_PROJ_OUT_W], dy, dh, false, G[MUGD_TF_PROJ_OUT_W], G[MUGD_TF_PROJ_OUT_B], C, C, wt);       // dh = d h3
+        // feed-forward: h3 = W2 f + b2 + h2
+        lt.bwd(f, P[MUGD_TF_FF2_W], dh, df, false, G[MUGD_TF_FF2_W], G[MUGD_TF_FF2_B], Ch, C, wt);
+        launch_geglu_bwd(st, u, df, du, B, Ch, T);
+        lt.bwd(l3, P[MUGD_TF_FF0_W], du, dl, false, G[MUGD_TF_FF0_W], G[MUGD_TF_FF0_B], C, 2 * Ch, wt);
+        launch_ln_bwd(st, h2, dl, P[MUGD_TF_LN3_W], 1e-5f, dh, stat, G[MUGD_TF_LN3_W], G[MUGD_TF_LN3_B], B, C, T, 1);      // dh = d h2
+        // attn2: h2 = Wo2 o2 + bo2 + h1
+        lt.bwd(o2, P[MUGD_TF_A2_OUT_W], dh, da, false, G[MUGD_TF_A2_OUT_W], G[MUGD_TF_A2_OUT_B], C, C, wt);
+        attn_bwd(q2, k2, v2, da, Tk, MUGD_TF_A2_REL, MUGD_TF_A2_CEMB);
+        lt.bwd(l2, P[MUGD_TF_A2_Q], dq, dl, false, G[MUGD_TF_A2_Q], nullptr, C, C, wt);
+        if (context) {
+            lk.bwd(ctxp, P[MUGD_TF_A2_K], dk, dcontext, false, G[MUGD_TF_A2_K], nullptr, Cc, C, wt);
+            lk.bwd(ctxp, P[MUGD_TF_A2_V], dv, dcontext, true, G[MUGD_TF_A2_V], nullptr, Cc, C, wt);
+        } else {
+            lt.bwd(l2, P[MUGD_TF_A2_K], dk, dl, true, G[MUGD_TF_A2_K], nullptr, C, C, wt);
+            lt.bwd(l2, P[MUGD_TF_A2_V], dv, dl, true, G[MUGD_TF_A2_V], nullptr, C, C, wt);
+        }
+        launch_ln_bwd(st, h1, dl, P[MUGD_TF_LN2_W], 1e-5f, dh, stat, G[MUGD_TF_LN2_W], G[MUGD_TF_LN2_B], B, C, T, 1);      // dh = d h1
+        // attn1: h1 = Wo o1 + bo + h0
+        lt.bwd(o1, P[MUGD_TF_A1_OUT_W], dh, da, false, G[MUGD_TF_A1_OUT_W], G[MUGD_TF_A1_OUT_B], C, C, wt);
+        attn_bwd(q1, k1, v1, da, T, MUGD_TF_A1_REL, MUGD_TF_A1_CEMB);
+        lt.bwd(l1, P[MUGD_TF_A1_Q], dq, dl, false, G[MUGD_TF_A1_Q], nullptr, C, C, wt);
+        lt.bwd(l1, P[MUGD_TF_A1_K], dk, dl, true, G[MUGD_TF_A1_K], nullptr, C, C, wt);
+        lt.bwd(l1, P[MUGD_TF_A1_V], dv, dl, true, G[MUGD_TF_A1_V], nullptr, C, C, wt);
+        launch_ln_bwd(st, h0, dl, P[MUGD_TF_LN1_W], 1e-5f, dh, stat, G[MUGD_TF_LN1_W], G[MUGD_TF_LN1_B], B, C, T, 1);      // dh = d h0
+        // proj_in and the GroupNorm in front of it
+        lt.bwd(n0, P[MUGD_TF_PROJ_IN_W], dh, da, false, G[MUGD_TF_PROJ_IN_W], G[MUGD_TF_PROJ_IN_B], C, C, wt);
+        launch_gn_bwd(st, x, da, P[MUGD_TF_NORM_W], P[MUGD_TF_NORM_B], 1e-6f, dx, G[MUGD_TF_NORM_W], G[MUGD_TF_NORM_B], B, C, T, groups, 0, 0);
+        launch_bias_sum(st, dx, dy, dx, (int)n);          // + the identity skip
+        HIP_CHECK(hipStreamSynchronize(st));
+    });
+}
 
 int mugd_train_q_sample(mugd_ctx* ctx, const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac, const float* sqrt_1mac,
                         float* out, int B, int64_t n) {

@@ -85,6 +85,7 @@ _SIGS = {
     "mugd_train_q_sample": [_p, _p, _p, _p, _p, _p, _p, _i, C.c_int64],
     "mugd_train_smooth_l1": [_p, _p, _p, _f, _f, _p, _p, _i, C.c_int64],
     "mugd_train_resblock": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i],
+    "mugd_train_transformer": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i],
     "mugd_train_adamw": [_p, _p, _p, _p, _p, C.c_int64, _f, _f, _f, _f, _f, _i],
 }
 
@@ -438,6 +439,44 @@ class Lib:
         self.check(self.dll.mugd_train_resblock(self.ctx, C.byref(P), _ptr(x), _ptr(emb), _ptr(dy), _ptr(y), _ptr(dx), _ptr(demb), C.byref(G),
                                                 B, Cin, Cout, T, emb.shape[1], groups))
         return y, dx, demb, grads
+
+    # include/mugd.h MUGD_TF_*: the ContextualTransformer's tensors in the C ABI's order, by their state-dict names
+    TRANSFORMER_KEYS = (
+        "norm.weight", "norm.bias", "proj_in.weight", "proj_in.bias",
+        "transformer_blocks.0.norm1.weight", "transformer_blocks.0.norm1.bias",
+        "transformer_blocks.0.attn1.to_q.weight", "transformer_blocks.0.attn1.to_k.weight", "transformer_blocks.0.attn1.to_v.weight",
+        "transformer_blocks.0.attn1.to_out.0.weight", "transformer_blocks.0.attn1.to_out.0.bias",
+        "transformer_blocks.0.attn1.relative_position_embedding", "transformer_blocks.0.attn1.C_embedding",
+        "transformer_blocks.0.norm2.weight", "transformer_blocks.0.norm2.bias",
+        "transformer_blocks.0.attn2.to_q.weight", "transformer_blocks.0.attn2.to_k.weight", "transformer_blocks.0.attn2.to_v.weight",
+        "transformer_blocks.0.attn2.to_out.0.weight", "transformer_blocks.0.attn2.to_out.0.bias",
+        "transformer_blocks.0.attn2.relative_position_embedding", "transformer_blocks.0.attn2.C_embedding",
+        "transformer_blocks.0.norm3.weight", "transformer_blocks.0.norm3.bias",
+        "transformer_blocks.0.ff.net.0.proj.weight", "transformer_blocks.0.ff.net.0.proj.bias",
+        "transformer_blocks.0.ff.net.2.weight", "transformer_blocks.0.ff.net.2.bias", "proj_out.weight", "proj_out.bias")
+
+    def train_transformer(self, params, x, context, dy, heads, groups=32):
+        """ContextualTransformer forward + backward (mug/model/attention.py:154-199).  params: dict keyed like the module's state dict
+        (TRANSFORMER_KEYS).  x, dy (B, C, T); context (B, Cc, Tk) or None (attn2 = second self-attention).
+        Returns y, dx, dcontext (None without context), grads (same keys)."""
+        x, dy = self.f32(x), self.f32(dy)
+        ctx = None if context is None else self.f32(context)
+        keep, grads = [], {}
+        PA, GA = (C.c_void_p * len(self.TRANSFORMER_KEYS))(), (C.c_void_p * len(self.TRANSFORMER_KEYS))()
+        for i, k in enumerate(self.TRANSFORMER_KEYS):
+            t = self.f32(params[k])
+            g = torch.zeros_like(t)
+            keep += [t, g]
+            grads[k] = g
+            PA[i], GA[i] = t.data_ptr(), g.data_ptr()
+        B, Cm, T = x.shape
+        pmax = (params["transformer_blocks.0.attn1.relative_position_embedding"].shape[0] - 1) // 2
+        y, dx = torch.empty_like(x), torch.empty_like(x)
+        dctx = None if ctx is None else torch.empty_like(ctx)
+        Cc, Tk = (0, 0) if ctx is None else (ctx.shape[1], ctx.shape[2])
+        self.check(self.dll.mugd_train_transformer(self.ctx, PA, _ptr(x), _ptr(ctx), _ptr(dy), _ptr(y), _ptr(dx), _ptr(dctx), GA,
+                                                   B, Cm, T, Cc, Tk, int(heads), int(groups), int(pmax)))
+        return y, dx, dctx, grads
 
     def train_adamw(self, param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
         """One torch.optim.AdamW step, in place on device tensors."""

@@ -1,9 +1,9 @@
 """Training slice (BASELINE configs[4]) -- FIRST STEP.  What exists natively (include/mugd.h, "training
-slice"): q_sample, the smooth-L1 noise-prediction loss with its gradient, forward + backward of TimestepResBlock (the block
-behind most of the U-Net's launches), an AdamW step; here: the glue that turns them into a data-parallel step on that block and
-the gradient all-reduce every rank of a DDP job runs (one flat bucket, averaged).  The backward of the transformer, S4 and
-resampling layers -- and with them `DDPM.training_step` (mug/diffusion/diffusion.py:356-414) for the whole U-Net -- are not
-built yet.
+slice"): q_sample, the smooth-L1 noise-prediction loss with its gradient, forward + backward of TimestepResBlock and of
+ContextualTransformer (`Lib.train_resblock`, `Lib.train_transformer`), an AdamW step; here: the glue that turns them into a
+data-parallel step on a block and the gradient all-reduce every rank of a DDP job runs (one flat bucket, averaged).  The backward
+of the S4 and resampling layers -- and with them `DDPM.training_step` (mug/diffusion/diffusion.py:356-414) for the whole U-Net --
+are not built yet.
 """
 import torch
 import torch.distributed as dist

@@ -64,6 +64,68 @@ def test_resblock_forward_backward_vs_autograd(lib, B, Cin, Cout, T, Kemb, group
         close(grads[k], pt[k].grad, 1e-4, "grad of " + k)
 
 
+def transformer_params(C, Cc, heads, pmax=64, seed=100):
+    """A ContextualTransformer's tensors (mug/model/attention.py:154-199) with the reference's shapes; the zero-initialised ones
+    (proj_out, relative_position_embedding) and the ones-initialised C_embedding are randomised so every gradient is exercised."""
+    from mug._native import Lib
+    shapes = {"norm.weight": (C,), "norm.bias": (C,), "proj_in.weight": (C, C, 1), "proj_in.bias": (C,), "proj_out.weight": (C, C, 1), "proj_out.bias": (C,)}
+    b = "transformer_blocks.0."
+    for i, kc in ((1, C), (2, Cc)):
+        shapes[b + "norm%d.weight" % i] = (C,); shapes[b + "norm%d.bias" % i] = (C,)
+        shapes[b + "attn%d.to_q.weight" % i] = (C, C); shapes[b + "attn%d.to_k.weight" % i] = (C, kc); shapes[b + "attn%d.to_v.weight" % i] = (C, kc)
+        shapes[b + "attn%d.to_out.0.weight" % i] = (C, C); shapes[b + "attn%d.to_out.0.bias" % i] = (C,)
+        shapes[b + "attn%d.relative_position_embedding" % i] = (2 * pmax + 1, heads); shapes[b + "attn%d.C_embedding" % i] = (2 * pmax + 1, heads)
+    shapes[b + "norm3.weight"] = (C,); shapes[b + "norm3.bias"] = (C,)
+    shapes[b + "ff.net.0.proj.weight"] = (8 * C, C); shapes[b + "ff.net.0.proj.bias"] = (8 * C,)
+    shapes[b + "ff.net.2.weight"] = (C, 4 * C); shapes[b + "ff.net.2.bias"] = (C,)
+    assert set(shapes) == set(Lib.TRANSFORMER_KEYS)
+    p = {}
+    for i, k in enumerate(Lib.TRANSFORMER_KEYS):
+        sh = shapes[k]
+        if k.endswith("norm.weight") or "norm1.weight" in k or "norm2.weight" in k or "norm3.weight" in k:
+            p[k] = 1 + 0.1 * rnd(seed + i, *sh)
+        elif k.endswith("C_embedding"):
+            p[k] = 1 + 0.3 * rnd(seed + i, *sh)
+        elif k.endswith("relative_position_embedding"):
+            p[k] = 0.5 * rnd(seed + i, *sh)
+        elif k.endswith(".bias"):
+            p[k] = 0.1 * rnd(seed + i, *sh)
+        else:
+            p[k] = rnd(seed + i, *sh, scale=sh[1] ** -0.5)
+    return p
+
+
+@pytest.mark.parametrize("B,C,T,Cc,Tk,heads,groups,pmax", [(2, 32, 24, 16, 5, 2, 8, 4), (1, 64, 40, 0, 0, 4, 32, 8), (2, 64, 96, 32, 21, 4, 16, 64),
+                                                           (2, 128, 64, 128, 21, 8, 32, 64)])
+def test_transformer_forward_backward_vs_autograd(lib, B, C, T, Cc, Tk, heads, groups, pmax):
+    """ContextualTransformer (GroupNorm -> proj_in -> [LN, rel-pos self-attention, LN, cross-attention over the prompt tokens, LN,
+    GEGLU feed-forward] -> proj_out -> + x): native forward + backward against torch autograd through the oracle's restatement
+    (oracle/nets.py:contextual_transformer, itself bit-equal to the reference on the goldens).  Cc = 0: attn2 is a second
+    self-attention (the wave encoder's blocks)."""
+    from oracle import nets
+    p = transformer_params(C, Cc if Cc else C, heads, pmax)
+    x, dy = rnd(40, B, C, T), rnd(41, B, C, T)
+    ctx = rnd(42, B, Cc, Tk) if Cc else None
+    pt = {"m." + k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xt = x.clone().requires_grad_(True)
+    ct = None if ctx is None else ctx.clone().requires_grad_(True)
+    real_gn, real_ca = nets.group_norm, nets.cross_attention
+    nets.group_norm = lambda sd, pp, xx, g: real_gn(sd, pp, xx, groups)      # the oracle hard-codes 32 groups / pos_max 64: small shapes
+    nets.cross_attention = lambda sd, pp, xx, cc, hh, pos_max=64: real_ca(sd, pp, xx, cc, hh, pos_max=pmax)
+    try:
+        yt = nets.contextual_transformer(pt, "m", xt, ct, heads)
+    finally:
+        nets.group_norm, nets.cross_attention = real_gn, real_ca
+    yt.backward(dy)
+    y, dx, dctx, grads = lib.train_transformer(p, x, ctx, dy, heads, groups=groups)
+    close(y, yt, 5e-5, "forward")
+    close(dx, xt.grad, 2e-4, "dx")
+    if ctx is not None:
+        close(dctx, ct.grad, 2e-4, "dcontext")
+    for k in p:
+        close(grads[k], pt["m." + k].grad, 3e-4, "grad of " + k)
+
+
 def test_q_sample_and_smooth_l1_loss(lib):
     """diffusion.py:326-354,386: x_t = sqrt(ac_t) x0 + sqrt(1 - ac_t) noise;  loss_b = mean smooth_l1(target, pred, beta=0.02) + 0.01."""
     B, Cc, T = 3, 16, 50
