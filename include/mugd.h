@@ -236,6 +236,13 @@ typedef struct {
 /* y = block(x, emb) (B, Cout, T); given dy: dx (B, Cin, T), demb (B, Kemb) and every parameter gradient.  Synchronises. */
 int mugd_train_resblock(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x, const float* emb, const float* dy, float* y, float* dx,
                         float* demb, const mugd_resblock_grads* g, int B, int Cin, int Cout, int T, int Kemb, int groups);
+/* One conv1d layer forward + backward, optionally behind GroupNorm + SiLU (gn_w / gn_b non-NULL: the U-Net's `out` head, unet.py:489-493).
+ * mode 0: stride 1, padding dil (taps - 1) / 2 (torch padding=dilation for the dilated ResnetBlock convs, models.py:106-122);
+ * mode 1: Downsample (models.py:84-88: pad right by one zero, k = 3, stride 2; Tin even, Tout = Tin / 2);
+ * mode 2: Upsample (models.py:66-70: nearest x2, then k = 3 pad 1; Tout = 2 Tin).
+ * w (Cout, Cin, taps), bias nullable; x / dx (B, Cin, Tin); y / dy (B, Cout, Tout); dw like w; db nullable.  Synchronises. */
+int mugd_train_conv(mugd_ctx* ctx, const float* w, const float* bias, const float* gn_w, const float* gn_b, const float* x, const float* dy, float* y,
+                    float* dx, float* dw, float* db, float* dgn_w, float* dgn_b, int B, int Cin, int Cout, int Tin, int taps, int dil, int mode, int groups);
 /* mug/model/attention.py:154-199 ContextualTransformer (depth 1) forward and backward.  params / grads: MUGD_TF_NPARAMS pointers in the
  * order of the enum below, every tensor in the module's own layout (Linear weights (out, in), proj_in / proj_out (C, C, 1), the two
  * attention tables (2 pmax + 1, heads)).  x, dy, y, dx: (B, C, T).  context (B, Cc, Tk) channel-major, or NULL: attn2 is then a second

@@ -93,18 +93,21 @@ __global__ __launch_bounds__(256) void time_sum_kernel(const float* x, float* ro
     if (lane == 0) rows[r] = (float)s;
 }
 
-// Weight gradient of conv1d (taps 1 | 3, stride 1, zero padding `pad`) on the fp32 matrix cores:
-//   dW[m][c][tap] = sum_{b,t} dY[b][m][t] A[b][c][t + tap - pad]          -- a GEMM whose contraction axis is batch x time.
+// Weight gradient of conv1d (taps 1 | 3; any dilation, stride 1 | 2, optional nearest-x2 upsampled input) on the fp32 matrix cores:
+//   dW[m][c][tap] = sum_{b,t} dY[b][m][t] A[b][c][stride t + tap dil - pad]     -- a GEMM whose contraction axis is batch x time
+//   (A read through the x2 upsample when ups: index >> 1; zero outside [0, Tin (x2))).
 // One workgroup = a 32 (m) x 32 (c) tile, all taps (one 32x32 accumulator per tap); its 8 waves split the (b, 32-sample slab)
-// work list, each staging its slab of dY (32 x 32) and of A (32 x (32 + 2)) in a private LDS window and feeding
-// v_mfma_f32_32x32x2_f32 with A-operand = dY[row r][t + h], B-operand = A[col n][t + h + tap - pad]; the 8 partial tiles are
-// summed through LDS in fixed order.  Grid (M / 32, C / 32): 256 workgroups for the 512 x 512 layers.
-constexpr int WG_RS = 36;                            // LDS row stride (floats): 32 samples + 2 halo, padded
+// work list, each staging its slab of dY (32 x 32) once and the matching 32 x 32 slab of A once PER TAP (L2-hot re-reads keep
+// the LDS window independent of dilation and stride) in a private LDS window and feeding v_mfma_f32_32x32x2_f32 with
+// A-operand = dY[row r][t + h], B-operand = A[col n][.]; the 8 partial tiles are summed through LDS in fixed order.
+// Grid (M / 32, C / 32): 256 workgroups for the 512 x 512 layers.
+constexpr int WG_RS = 33;                            // LDS row stride (floats)
 
-__global__ __launch_bounds__(512) void wgrad_mfma_kernel(const float* dY, const float* A, float* dW, int B, int M, int C, int T, int taps, int pad) {
+__global__ __launch_bounds__(512) void wgrad_mfma_kernel(const float* dY, const float* A, float* dW, int B, int M, int C, int Tout, int Tin, int taps,
+                                                         int pad, int dil, int stride, int ups) {
     __shared__ float sy[8][32 * WG_RS];
     __shared__ float sa[8][32 * WG_RS];
-    float (*red)[16 * 64] = reinterpret_cast<float (*)[16 * 64]>(&sy[0][0]);          // the combine reuses the dY slabs (8 x 1024 <= 8 x 1152 floats)
+    float (*red)[16 * 64] = reinterpret_cast<float (*)[16 * 64]>(&sy[0][0]);          // the combine reuses the slabs (8 x 1024 <= 16 x 1056 floats)
     const int m0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, h = lane >> 5, n = lane & 31;
     f32x16 acc[3];
@@ -112,35 +115,40 @@ __global__ __launch_bounds__(512) void wgrad_mfma_kernel(const float* dY, const 
     for (int k = 0; k < 3; ++k)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
-    const int nslab = (T + 31) / 32, total = B * nslab;
+    const int nslab = (Tout + 31) / 32, total = B * nslab;
+    const int vlen = ups ? 2 * Tin : Tin;
     float* wy = sy[wave];
     float* wa = sa[wave];
+    const int r = lane >> 1, hf = lane & 1;
     for (int s = wave; s < total; s += 8) {
         const int b = s / nslab, t0 = (s - b * nslab) * 32;
-        // stage dY[m0 + r][t0 .. t0+31] and A[c0 + r][t0 - pad .. t0 + 33 - pad]: lane -> row lane / 2, half-row lane % 2
         {
-            const int r = lane >> 1, hf = lane & 1;
-            const int m = m0 + r, c = c0 + r;
+            const int m = m0 + r;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int tt = hf * 16 + j, t = t0 + tt;
-                wy[r * WG_RS + tt] = (m < M && t < T) ? dY[((size_t)b * M + m) * T + t] : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < 17; ++j) {
-                const int tt = hf * 17 + j, t = t0 + tt - pad;
-                wa[r * WG_RS + tt] = (c < C && t >= 0 && t < T) ? A[((size_t)b * C + c) * T + t] : 0.f;
+                wy[r * WG_RS + tt] = (m < M && t < Tout) ? dY[((size_t)b * M + m) * Tout + t] : 0.f;
             }
         }
-        wave_sync();
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            if (tap < taps) {
+                const int c = c0 + r;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int tt = hf * 16 + j;
+                    const int u = stride * (t0 + tt) + tap * dil - pad;
+                    const bool ok = c < C && u >= 0 && u < vlen && t0 + tt < Tout;
+                    const int us = ups ? (u >> 1) : u;
+                    wa[r * WG_RS + tt] = ok ? A[((size_t)b * C + c) * Tin + us] : 0.f;
+                }
+                wave_sync();
 #pragma unroll 4
-        for (int k = 0; k < 32; k += 2) {
-            const float a = wy[n * WG_RS + k + h];
-#pragma unroll
-            for (int tap = 0; tap < 3; ++tap)
-                if (tap < taps) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wa[n * WG_RS + k + h + tap], acc[tap], 0, 0, 0);
+                for (int k = 0; k < 32; k += 2)
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(wy[n * WG_RS + k + h], wa[n * WG_RS + k + h], acc[tap], 0, 0, 0);
+                wave_sync();
+            }
         }
-        wave_sync();
     }
     // combine the 8 partial tiles, tap by tap (fixed order), and store: accumulator register i of lane (h, n) is row (i & 3) + 8 (i >> 2) + 4 h, column n
     for (int tap = 0; tap < taps; ++tap) {
@@ -158,6 +166,30 @@ __global__ __launch_bounds__(512) void wgrad_mfma_kernel(const float* dY, const 
             if (m < M && c < C) dW[((size_t)m * C + c) * taps + tap] = v;
         }
     }
+}
+
+// weights of the stride-2 conv's data gradient (see mugd_train_conv): ev[c][m][0..2] = {w[m][c][2], w[m][c][0], 0}, od[c][m] = w[m][c][1]
+__global__ void down_dgrad_weights_kernel(const float* w, float* ev, float* od, int M, int C) {
+    const long long n = (long long)M * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C), m = (int)(i / C);
+        const float* s = w + i * 3;
+        float* e = ev + ((size_t)c * M + m) * 3;
+        e[0] = s[2]; e[1] = s[0]; e[2] = 0.f;
+        od[(size_t)c * M + m] = s[1];
+    }
+}
+// dst[b][c][2u + par] = src[b][c][u]: interleaves one parity of a x2-longer tensor (data gradient of the stride-2 conv)
+__global__ void interleave_parity_kernel(const float* src, float* dst, long long rows, int T, int par) {
+    const long long n = rows * T;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long rr = i / T; const int u = (int)(i - rr * T);
+        dst[rr * 2 * T + 2 * u + par] = src[i];
+    }
+}
+// dst[b][c][u] = src[b][c][2u] + src[b][c][2u + 1]: data gradient of the nearest x2 upsample
+__global__ void pair_sum_kernel(const float* src, float* dst, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = src[2 * i] + src[2 * i + 1];
 }
 
 __device__ __forceinline__ double wg_sum(double v, double* red) {        // 256-thread workgroup sum, result to every thread
@@ -303,8 +335,23 @@ void launch_time_sum(hipStream_t st, const float* x, float* rows, int BM, int T)
     hipLaunchKernelGGL(time_sum_kernel, dim3(cdiv(BM, 4)), dim3(256), 0, st, x, rows, BM, T);
 }
 void launch_wgrad(hipStream_t st, const float* dY, const float* A, float* dW, int B, int M, int C, int T, int taps, int pad) {
+    launch_wgrad_ex(st, dY, A, dW, B, M, C, T, T, taps, pad, 1, 1, 0);
+}
+void launch_wgrad_ex(hipStream_t st, const float* dY, const float* A, float* dW, int B, int M, int C, int Tout, int Tin, int taps, int pad, int dil,
+                     int stride, int ups) {
     MUGD_CHECK(taps == 1 || taps == 3, -2, "wgrad: taps must be 1 or 3");
-    hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(cdiv(M, 32), cdiv(C, 32)), dim3(512), 0, st, dY, A, dW, B, M, C, T, taps, pad);
+    hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(cdiv(M, 32), cdiv(C, 32)), dim3(512), 0, st, dY, A, dW, B, M, C, Tout, Tin, taps, pad, dil, stride, ups);
+}
+void launch_down_dgrad_weights(hipStream_t st, const float* w, float* ev, float* od, int M, int C) {
+    const long long n = (long long)M * C;
+    hipLaunchKernelGGL(down_dgrad_weights_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, st, w, ev, od, M, C);
+}
+void launch_interleave_parity(hipStream_t st, const float* src, float* dst, long long rows, int T, int par) {
+    const long long n = rows * T;
+    hipLaunchKernelGGL(interleave_parity_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 8192)), dim3(256), 0, st, src, dst, rows, T, par);
+}
+void launch_pair_sum(hipStream_t st, const float* src, float* dst, long long n) {
+    hipLaunchKernelGGL(pair_sum_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 8192)), dim3(256), 0, st, src, dst, n);
 }
 void launch_gn_silu_bwd(hipStream_t st, const float* x, const float* da, const float* gamma, const float* beta, float eps, float* dx,
                         float* dgamma, float* dbeta, int B, int C, int T, int groups, int accumulate) {

@@ -313,6 +313,11 @@ void launch_transpose_flip(hipStream_t st, const float* src, float* dst, int M, 
 void launch_bias_grad(hipStream_t st, const float* x, float* out, int B, int M, int T, int accumulate);
 void launch_time_sum(hipStream_t st, const float* x, float* rows, int BM, int T);
 void launch_wgrad(hipStream_t st, const float* dY, const float* A, float* dW, int B, int M, int C, int T, int taps, int pad);
+void launch_wgrad_ex(hipStream_t st, const float* dY, const float* A, float* dW, int B, int M, int C, int Tout, int Tin, int taps, int pad, int dil,
+                     int stride, int ups);
+void launch_down_dgrad_weights(hipStream_t st, const float* w, float* ev, float* od, int M, int C);
+void launch_interleave_parity(hipStream_t st, const float* src, float* dst, long long rows, int T, int par);
+void launch_pair_sum(hipStream_t st, const float* src, float* dst, long long n);
 void launch_gn_silu_bwd(hipStream_t st, const float* x, const float* da, const float* gamma, const float* beta, float eps, float* dx,
                         float* dgamma, float* dbeta, int B, int C, int T, int groups, int accumulate);
 // GroupNorm backward with (silu = 1) or without (0) the SiLU that follows it

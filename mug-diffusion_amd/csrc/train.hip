@@ -39,7 +39,7 @@ struct Scratch {
 
 // y = conv1d(x; w) (+ bias) (+ rowadd[b][m]) (+ resid): w is a plain (M, C, taps) tensor, packed here
 void run_conv(Ctx& c, Scratch& sc, const float* x, const float* w, const float* bias, const float* rowadd, int rowadd_stride,
-              const float* resid, float* y, int B, int C, int T, int M, int taps, int pad) {
+              const float* resid, float* y, int B, int C, int T, int M, int taps, int pad, int dil = 1, int stride = 1, int ups = 0, int Tout = -1) {
     MUGD_CHECK(C % CONV_CK == 0, MUGD_ERR_INVALID, "training slice: channel counts must be multiples of 16");
     hipStream_t st = c.stream;
     const int MT = cdiv(M, 32);
@@ -47,9 +47,9 @@ void run_conv(Ctx& c, Scratch& sc, const float* x, const float* w, const float* 
     float* wpk = sc.get((size_t)MT * mts, true, st);
     ConvArgs a{};
     a.nseg = 1;
-    a.seg[0] = ConvSeg{x, C, T, taps, 1, 1, pad, 0, 0, 0, 0};
+    a.seg[0] = ConvSeg{x, C, T, taps, dil, stride, pad, ups, 0, 0, 0};
     a.wpk = wpk; a.w_mt_stride = mts; a.bias = bias; a.rowadd = rowadd; a.rowadd_stride = rowadd_stride; a.resid = resid; a.y = y;
-    a.B = B; a.Mrows = M; a.Mout = M; a.Tout = T; a.nchunk = C / CONV_CK; a.epi = EPI_NONE;
+    a.B = B; a.Mrows = M; a.Mout = M; a.Tout = Tout > 0 ? Tout : T; a.nchunk = C / CONV_CK; a.epi = EPI_NONE;
     a.tn = conv_pick_tn(a);
     PackArgs pa{wpk, mts, 0, C, taps, w, C * taps, 0, M, 0, 0};
     if (a.tn == 16) launch_pack_weights16(st, pa); else launch_pack_weights(st, pa);
@@ -92,6 +92,57 @@ struct Lin {
 }  // namespace
 
 extern "C" {
+
+int mugd_train_conv(mugd_ctx* ctx, const float* w, const float* bias, const float* gn_w, const float* gn_b, const float* x, const float* dy, float* y,
+                    float* dx, float* dw, float* db, float* dgn_w, float* dgn_b, int B, int Cin, int Cout, int Tin, int taps, int dil, int mode, int groups) {
+    return guarded(ctx, [&] {
+        MUGD_CHECK(w && x && dy && y && dx && dw && B > 0 && Tin > 0, MUGD_ERR_INVALID, "null/empty argument");
+        MUGD_CHECK((taps == 1 || taps == 3) && dil >= 1 && mode >= 0 && mode <= 2, MUGD_ERR_INVALID, "bad conv geometry");
+        MUGD_CHECK(mode == 0 || (taps == 3 && dil == 1), MUGD_ERR_INVALID, "resampling convs are 3-tap, undilated");
+        MUGD_CHECK(mode != 1 || Tin % 2 == 0, MUGD_ERR_INVALID, "downsample: even input length");
+        MUGD_CHECK(!gn_w || (gn_b && dgn_w && dgn_b && groups > 0 && Cin % groups == 0), MUGD_ERR_INVALID, "bad GroupNorm arguments");
+        Ctx& c = ctx->c;
+        hipStream_t st = c.stream;
+        Scratch sc;
+        const int stride = mode == 1 ? 2 : 1, ups = mode == 2 ? 1 : 0;
+        const int pad = mode == 1 ? 0 : dil * (taps - 1) / 2;
+        const int Tout = mode == 1 ? Tin / 2 : (mode == 2 ? 2 * Tin : Tin);
+        const size_t nin = (size_t)B * Cin * Tin;
+        const float* a = x;
+        if (gn_w) {
+            float* an = sc.get(nin, false, st);
+            run_group_norm_silu(c, x, gn_w, gn_b, an, B, Cin, Tin, groups);
+            a = an;
+        }
+        run_conv(c, sc, a, w, bias, nullptr, 0, nullptr, y, B, Cin, Tin, Cout, taps, pad, dil, stride, ups, Tout);
+        // ---- backward
+        launch_wgrad_ex(st, dy, a, dw, B, Cout, Cin, Tout, Tin, taps, pad, dil, stride, ups);
+        if (db) launch_bias_grad(st, dy, db, B, Cout, Tout, 0);
+        float* da = gn_w ? sc.get(nin, false, st) : dx;
+        float* wt = sc.get((size_t)Cout * Cin * 3, true, st);
+        if (mode == 0) {
+            launch_transpose_flip(st, w, wt, Cout, Cin, taps);
+            run_conv(c, sc, dy, wt, nullptr, nullptr, 0, nullptr, da, B, Cout, Tout, Cin, taps, dil * (taps - 1) - pad, dil);
+        } else if (mode == 1) {
+            // x index s = 2 t + tap:  even s = 2u <- taps 0 (t = u) and 2 (t = u - 1);  odd s = 2u + 1 <- tap 1 (t = u)
+            float* wo = sc.get((size_t)Cout * Cin, false, st);
+            float* ev = sc.get((size_t)B * Cin * Tout, false, st);
+            float* od = sc.get((size_t)B * Cin * Tout, false, st);
+            launch_down_dgrad_weights(st, w, wt, wo, Cout, Cin);
+            run_conv(c, sc, dy, wt, nullptr, nullptr, 0, nullptr, ev, B, Cout, Tout, Cin, 3, 1);
+            run_conv(c, sc, dy, wo, nullptr, nullptr, 0, nullptr, od, B, Cout, Tout, Cin, 1, 0);
+            launch_interleave_parity(st, ev, da, (long long)B * Cin, Tout, 0);
+            launch_interleave_parity(st, od, da, (long long)B * Cin, Tout, 1);
+        } else {
+            float* dxu = sc.get((size_t)B * Cin * Tout, false, st);
+            launch_transpose_flip(st, w, wt, Cout, Cin, 3);
+            run_conv(c, sc, dy, wt, nullptr, nullptr, 0, nullptr, dxu, B, Cout, Tout, Cin, 3, 1);
+            launch_pair_sum(st, dxu, da, (long long)nin);
+        }
+        if (gn_w) launch_gn_bwd(st, x, da, gn_w, gn_b, 1e-6f, dx, dgn_w, dgn_b, B, Cin, Tin, groups, 0, 1);
+        HIP_CHECK(hipStreamSynchronize(st));
+    });
+}
 
 int mugd_train_transformer(mugd_ctx* ctx, const float* const* P, const float* x, const float* context, const float* dy, float* y, float* dx,
                            float* dcontext, float* const* G, int B, int C, int T, int Cc, int Tk, int heads, int groups, int pmax) {

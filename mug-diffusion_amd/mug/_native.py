@@ -85,6 +85,7 @@ _SIGS = {
     "mugd_train_q_sample": [_p, _p, _p, _p, _p, _p, _p, _i, C.c_int64],
     "mugd_train_smooth_l1": [_p, _p, _p, _f, _f, _p, _p, _i, C.c_int64],
     "mugd_train_resblock": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i],
+    "mugd_train_conv": [_p] * 13 + [_i] * 8,
     "mugd_train_transformer": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i],
     "mugd_train_adamw": [_p, _p, _p, _p, _p, C.c_int64, _f, _f, _f, _f, _f, _i],
 }
@@ -439,6 +440,24 @@ class Lib:
         self.check(self.dll.mugd_train_resblock(self.ctx, C.byref(P), _ptr(x), _ptr(emb), _ptr(dy), _ptr(y), _ptr(dx), _ptr(demb), C.byref(G),
                                                 B, Cin, Cout, T, emb.shape[1], groups))
         return y, dx, demb, grads
+
+    def train_conv(self, weight, bias, x, dy, dil=1, mode=0, gn=None, groups=32):
+        """conv1d forward + backward; mode 0 plain (padding = dil (k - 1) / 2), 1 Downsample, 2 Upsample (models.py:55-91);
+        gn = (weight, bias): GroupNorm + SiLU in front (the U-Net's out head).  Returns y, dx, dw, db, (dgn_w, dgn_b) or None."""
+        w, x, dy = self.f32(weight), self.f32(x), self.f32(dy)
+        b = None if bias is None else self.f32(bias)
+        B, Cin, Tin = x.shape
+        Cout, _, taps = w.shape
+        Tout = Tin // 2 if mode == 1 else (2 * Tin if mode == 2 else Tin)
+        y, dx, dw = self.empty(B, Cout, Tout), torch.empty_like(x), torch.zeros_like(w)
+        db = None if b is None else torch.zeros_like(b)
+        gw = gb = dgw = dgb = None
+        if gn is not None:
+            gw, gb = self.f32(gn[0]), self.f32(gn[1])
+            dgw, dgb = torch.zeros_like(gw), torch.zeros_like(gb)
+        self.check(self.dll.mugd_train_conv(self.ctx, _ptr(w), _ptr(b), _ptr(gw), _ptr(gb), _ptr(x), _ptr(dy), _ptr(y), _ptr(dx), _ptr(dw), _ptr(db),
+                                            _ptr(dgw), _ptr(dgb), B, Cin, Cout, Tin, taps, int(dil), int(mode), int(groups)))
+        return y, dx, dw, db, (None if gn is None else (dgw, dgb))
 
     # include/mugd.h MUGD_TF_*: the ContextualTransformer's tensors in the C ABI's order, by their state-dict names
     TRANSFORMER_KEYS = (

@@ -64,6 +64,35 @@ def test_resblock_forward_backward_vs_autograd(lib, B, Cin, Cout, T, Kemb, group
         close(grads[k], pt[k].grad, 1e-4, "grad of " + k)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,T,taps,dil,mode,gn", [(2, 32, 48, 40, 3, 1, 0, False), (2, 32, 32, 64, 3, 4, 0, False), (1, 48, 32, 50, 3, 8, 0, False),
+                                                           (2, 32, 64, 36, 1, 1, 0, False), (2, 32, 48, 40, 3, 1, 1, False), (2, 48, 32, 26, 3, 1, 2, False),
+                                                           (2, 64, 16, 40, 3, 1, 0, True)])
+def test_conv_layer_forward_backward_vs_autograd(lib, B, Cin, Cout, T, taps, dil, mode, gn):
+    """Plain / dilated conv (ResnetBlock, models.py:106-122), Downsample (pad right + stride 2, models.py:84-88), Upsample (nearest x2 +
+    conv, models.py:66-70) and the GroupNorm + SiLU + conv head (unet.py:489-493): forward, dx, dw, db vs torch autograd."""
+    w, b = rnd(50, Cout, Cin, taps, scale=(taps * Cin) ** -0.5), 0.1 * rnd(51, Cout)
+    x = rnd(52, B, Cin, T)
+    gw, gb = 1 + 0.1 * rnd(53, Cin), 0.1 * rnd(54, Cin)
+    wt, bt, xt, gwt, gbt = [v.clone().requires_grad_(True) for v in (w, b, x, gw, gb)]
+    a = F.silu(F.group_norm(xt, 8, gwt, gbt, eps=1e-6)) if gn else xt
+    if mode == 0:
+        yt = F.conv1d(a, wt, bt, padding=dil * (taps - 1) // 2, dilation=dil)
+    elif mode == 1:
+        yt = F.conv1d(F.pad(a, (0, 1)), wt, bt, stride=2)
+    else:
+        yt = F.conv1d(a.repeat_interleave(2, dim=-1), wt, bt, padding=1)
+    dy = rnd(55, *yt.shape)
+    yt.backward(dy)
+    y, dx, dw, db, dg = lib.train_conv(w, b, x, dy, dil=dil, mode=mode, gn=(gw, gb) if gn else None, groups=8)
+    close(y, yt, 2e-5, "forward")
+    close(dx, xt.grad, 5e-5, "dx")
+    close(dw, wt.grad, 1e-4, "dw")
+    close(db, bt.grad, 1e-4, "db")
+    if gn:
+        close(dg[0], gwt.grad, 1e-4, "d gamma")
+        close(dg[1], gbt.grad, 1e-4, "d beta")
+
+
 def transformer_params(C, Cc, heads, pmax=64, seed=100):
     """A ContextualTransformer's tensors (mug/model/attention.py:154-199) with the reference's shapes; the zero-initialised ones
     (proj_out, relative_position_embedding) and the ones-initialised C_embedding are randomised so every gradient is exercised."""
