@@ -256,6 +256,16 @@ enum {
 };
 int mugd_train_transformer(mugd_ctx* ctx, const float* const* params, const float* x, const float* context, const float* dy, float* y, float* dx,
                            float* dcontext, float* const* grads, int B, int C, int T, int Cc, int Tk, int heads, int groups, int pmax);
+/* mug/diffusion/unet.py:76-91 S4Layer (GroupNorm -> S4 (s4.py:1471-1541: NPLR kernel, causal long conv + D u, GELU, Conv1d(H -> 2H) + GLU)
+ * -> conv3 -> + x) forward and backward, INCLUDING the gradients of the kernel generator's parameters (C, B, P as (H, N, 2) real views,
+ * inv_w_real / w_imag (H, N), log_dt (H)).  Lint = the stored kernel.L buffer (>= T; C is the stored, already length-adapted tensor).
+ * params / grads: MUGD_S4_NPARAMS pointers in the order of the enum.  cauchy_naive kernel form only.  x, dy, y, dx: (B, H, T).  Synchronises. */
+enum {
+    MUGD_S4_NORM_W, MUGD_S4_NORM_B, MUGD_S4_K_C, MUGD_S4_K_B, MUGD_S4_K_P, MUGD_S4_K_INV_W_REAL, MUGD_S4_K_W_IMAG, MUGD_S4_K_LOG_DT, MUGD_S4_D,
+    MUGD_S4_OUT_LIN_W, MUGD_S4_OUT_LIN_B, MUGD_S4_OUT_LAYER_W, MUGD_S4_OUT_LAYER_B, MUGD_S4_NPARAMS
+};
+int mugd_train_s4layer(mugd_ctx* ctx, const float* const* params, const float* x, const float* dy, float* y, float* dx, float* const* grads,
+                       int B, int H, int T, int N, int Lint, int groups);
 /* torch.optim.AdamW step (decoupled weight decay) on a flat parameter block; step counts from 1. */
 int mugd_train_adamw(mugd_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                      float beta2, float eps, float weight_decay, int step);

@@ -338,6 +338,20 @@ struct AttnBwdArgs {         // layouts as AttnArgs; dout = gradient of the atte
     float* drel; float* dcemb;                // (2 pmax + 1, heads)
 };
 void launch_attention_bwd(hipStream_t st, const AttnBwdArgs& a);
+// k_train_s4.hip: S4 layer backward pieces
+struct S4GenBwdArgs {        // gradient of launch_s4_kernel_gen's output k (H, L) w.r.t. its parameters (cauchy_naive form)
+    const float* C; const float* Bp; const float* P; const float* inv_w_real; const float* w_imag; const float* log_dt;
+    int H, N, Lint, L;
+    const float* dk;         // (H, L)
+    float* dC; float* dB; float* dP; float* d_inv_w_real; float* d_w_imag; float* d_log_dt;
+};
+void launch_s4_kernel_gen_bwd(hipStream_t st, const S4GenBwdArgs& a);
+void launch_s4_conv_train_fwd(hipStream_t st, const float* n, const float* k, const float* D, float* pre, float* g, int B, int H, int L);
+void launch_s4_conv_train_bwd(hipStream_t st, const float* n, const float* k, const float* D, const float* dpre, float* dn, float* dk, float* dD,
+                              int B, int H, int L);
+void launch_gelu_bwd(hipStream_t st, const float* pre, const float* dg, float* dpre, long long n);
+void launch_glu_fwd(hipStream_t st, const float* v, float* f, int B, int Ch, int T);
+void launch_glu_bwd(hipStream_t st, const float* v, const float* df, float* dv, int B, int Ch, int T);
 void launch_emb_linear_bwd(hipStream_t st, const float* e, const float* We, const float* dE, float* dWe, float* dbe, float* de, int B, int K, int M);
 void launch_adamw(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd, int step);
 

@@ -144,6 +144,48 @@ int mugd_train_conv(mugd_ctx* ctx, const float* w, const float* bias, const floa
     });
 }
 
+int mugd_train_s4layer(mugd_ctx* ctx, const float* const* P, const float* x, const float* dy, float* y, float* dx, float* const* G,
+                       int B, int H, int T, int N, int Lint, int groups) {
+    return guarded(ctx, [&] {
+        MUGD_CHECK(P && G && x && dy && y && dx && B > 0 && T > 0 && N > 0, MUGD_ERR_INVALID, "null/empty argument");
+        for (int i = 0; i < MUGD_S4_NPARAMS; ++i) MUGD_CHECK(P[i] && G[i], MUGD_ERR_INVALID, "null parameter / gradient pointer");
+        MUGD_CHECK(H % groups == 0 && H % CONV_CK == 0 && Lint >= T, MUGD_ERR_INVALID, "bad S4 layer geometry (stored kernel length < T?)");
+        Ctx& c = ctx->c;
+        MUGD_CHECK(!c.s4_symmetric, MUGD_ERR_INVALID, "S4 training gradients exist for the cauchy_naive kernel form only");
+        hipStream_t st = c.stream;
+        Scratch sc;
+        const size_t n = (size_t)B * H * T;
+        auto buf = [&](size_t k) { return sc.get(k, false, st); };
+        Lin lt{c, sc, B, T};
+        // ---- forward (unet.py:86-91, s4.py:1471-1541)
+        float *k = buf((size_t)H * T), *kf = buf((size_t)H * (Lint / 2 + 1) * 2);
+        float *nrm = buf(n), *pre = buf(n), *g = buf(n), *v = buf(2 * n), *f = buf(n);
+        S4GenArgs ga{P[MUGD_S4_K_C], P[MUGD_S4_K_B], P[MUGD_S4_K_P], P[MUGD_S4_K_INV_W_REAL], P[MUGD_S4_K_W_IMAG], P[MUGD_S4_K_LOG_DT], H, N, Lint, T, kf, k, 0};
+        launch_s4_kernel_gen(st, ga);
+        run_group_norm_plain(c, x, P[MUGD_S4_NORM_W], P[MUGD_S4_NORM_B], nrm, B, H, T, groups);
+        launch_s4_conv_train_fwd(st, nrm, k, P[MUGD_S4_D], pre, g, B, H, T);
+        lt.fwd(g, P[MUGD_S4_OUT_LIN_W], P[MUGD_S4_OUT_LIN_B], nullptr, v, H, 2 * H);
+        launch_glu_fwd(st, v, f, B, H, T);
+        run_conv(c, sc, f, P[MUGD_S4_OUT_LAYER_W], P[MUGD_S4_OUT_LAYER_B], nullptr, 0, x, y, B, H, T, H, 3, 1);
+        // ---- backward
+        float *wt = buf((size_t)2 * H * H * 3), *df = buf(n), *dv = buf(2 * n), *dg = buf(n), *dpre = buf(n), *dn = buf(n), *dk = buf((size_t)H * T);
+        launch_wgrad(st, dy, f, G[MUGD_S4_OUT_LAYER_W], B, H, H, T, 3, 1);
+        launch_bias_grad(st, dy, G[MUGD_S4_OUT_LAYER_B], B, H, T, 0);
+        launch_transpose_flip(st, P[MUGD_S4_OUT_LAYER_W], wt, H, H, 3);
+        run_conv(c, sc, dy, wt, nullptr, nullptr, 0, nullptr, df, B, H, T, H, 3, 1);
+        launch_glu_bwd(st, v, df, dv, B, H, T);
+        lt.bwd(g, P[MUGD_S4_OUT_LIN_W], dv, dg, false, G[MUGD_S4_OUT_LIN_W], G[MUGD_S4_OUT_LIN_B], H, 2 * H, wt);
+        launch_gelu_bwd(st, pre, dg, dpre, (long long)n);
+        launch_s4_conv_train_bwd(st, nrm, k, P[MUGD_S4_D], dpre, dn, dk, G[MUGD_S4_D], B, H, T);
+        S4GenBwdArgs gb{P[MUGD_S4_K_C], P[MUGD_S4_K_B], P[MUGD_S4_K_P], P[MUGD_S4_K_INV_W_REAL], P[MUGD_S4_K_W_IMAG], P[MUGD_S4_K_LOG_DT], H, N, Lint, T, dk,
+                        G[MUGD_S4_K_C], G[MUGD_S4_K_B], G[MUGD_S4_K_P], G[MUGD_S4_K_INV_W_REAL], G[MUGD_S4_K_W_IMAG], G[MUGD_S4_K_LOG_DT]};
+        launch_s4_kernel_gen_bwd(st, gb);
+        launch_gn_bwd(st, x, dn, P[MUGD_S4_NORM_W], P[MUGD_S4_NORM_B], 1e-6f, dx, G[MUGD_S4_NORM_W], G[MUGD_S4_NORM_B], B, H, T, groups, 0, 0);
+        launch_bias_sum(st, dx, dy, dx, (int)n);          // + the identity skip
+        HIP_CHECK(hipStreamSynchronize(st));
+    });
+}
+
 int mugd_train_transformer(mugd_ctx* ctx, const float* const* P, const float* x, const float* context, const float* dy, float* y, float* dx,
                            float* dcontext, float* const* G, int B, int C, int T, int Cc, int Tk, int heads, int groups, int pmax) {
     return guarded(ctx, [&] {

@@ -86,6 +86,7 @@ _SIGS = {
     "mugd_train_smooth_l1": [_p, _p, _p, _f, _f, _p, _p, _i, C.c_int64],
     "mugd_train_resblock": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i],
     "mugd_train_conv": [_p] * 13 + [_i] * 8,
+    "mugd_train_s4layer": [_p] * 7 + [_i] * 6,
     "mugd_train_transformer": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i],
     "mugd_train_adamw": [_p, _p, _p, _p, _p, C.c_int64, _f, _f, _f, _f, _f, _i],
 }
@@ -458,6 +459,31 @@ class Lib:
         self.check(self.dll.mugd_train_conv(self.ctx, _ptr(w), _ptr(b), _ptr(gw), _ptr(gb), _ptr(x), _ptr(dy), _ptr(y), _ptr(dx), _ptr(dw), _ptr(db),
                                             _ptr(dgw), _ptr(dgb), B, Cin, Cout, Tin, taps, int(dil), int(mode), int(groups)))
         return y, dx, dw, db, (None if gn is None else (dgw, dgb))
+
+    # include/mugd.h MUGD_S4_*: the S4Layer's tensors in the C ABI's order, by their state-dict names
+    S4LAYER_KEYS = ("norm.weight", "norm.bias", "s4_model.kernel.kernel.C", "s4_model.kernel.kernel.B", "s4_model.kernel.kernel.P",
+                    "s4_model.kernel.kernel.inv_w_real", "s4_model.kernel.kernel.w_imag", "s4_model.kernel.kernel.log_dt", "s4_model.D",
+                    "s4_model.output_linear.0.weight", "s4_model.output_linear.0.bias", "out_layer.weight", "out_layer.bias")
+
+    def train_s4layer(self, params, x, dy, groups=32):
+        """S4Layer forward + backward (unet.py:76-91, s4.py:1471-1541, kernel gradients included).  params: dict keyed like the module's
+        state dict (S4LAYER_KEYS + 's4_model.kernel.kernel.L', the stored internal length).  Returns y, dx, grads."""
+        x, dy = self.f32(x), self.f32(dy)
+        n = len(self.S4LAYER_KEYS)
+        keep, grads = [], {}
+        PA, GA = (C.c_void_p * n)(), (C.c_void_p * n)()
+        for i, k in enumerate(self.S4LAYER_KEYS):
+            t = self.f32(params[k])
+            g = torch.zeros_like(t)
+            keep += [t, g]
+            grads[k] = g
+            PA[i], GA[i] = t.data_ptr(), g.data_ptr()
+        B, H, T = x.shape
+        N = params["s4_model.kernel.kernel.inv_w_real"].shape[-1]
+        Lint = int(params["s4_model.kernel.kernel.L"])
+        y, dx = torch.empty_like(x), torch.empty_like(x)
+        self.check(self.dll.mugd_train_s4layer(self.ctx, PA, _ptr(x), _ptr(dy), _ptr(y), _ptr(dx), GA, B, H, T, N, Lint, int(groups)))
+        return y, dx, grads
 
     # include/mugd.h MUGD_TF_*: the ContextualTransformer's tensors in the C ABI's order, by their state-dict names
     TRANSFORMER_KEYS = (

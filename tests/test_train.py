@@ -155,6 +155,44 @@ def test_transformer_forward_backward_vs_autograd(lib, B, C, T, Cc, Tk, heads, g
         close(grads[k], pt["m." + k].grad, 3e-4, "grad of " + k)
 
 
+def s4layer_params(H, N, L, seed=200):
+    """An S4Layer's tensors with the reference's shapes (state-dict names relative to the layer) in a trained-checkpoint-like
+    state: stored kernel length L, poles spread along the imaginary axis, dt in [1e-3, 1e-1]."""
+    rng = np.random.default_rng(seed)
+    p = {"norm.weight": 1 + 0.1 * rnd(seed + 1, H), "norm.bias": 0.1 * rnd(seed + 2, H),
+         "s4_model.kernel.kernel.C": rnd(seed + 3, 1, H, N, 2, scale=0.7), "s4_model.kernel.kernel.B": rnd(seed + 4, 1, H, N, 2, scale=0.7),
+         "s4_model.kernel.kernel.P": rnd(seed + 5, 1, H, N, 2, scale=0.3),
+         "s4_model.kernel.kernel.inv_w_real": torch.from_numpy(np.log(0.5 + 0.2 * rng.random((H, N))).astype(np.float32)),
+         "s4_model.kernel.kernel.w_imag": torch.from_numpy((np.pi * np.arange(N)[None] + 0.3 * rng.standard_normal((H, N))).astype(np.float32)),
+         "s4_model.kernel.kernel.log_dt": torch.from_numpy(rng.uniform(np.log(1e-3), np.log(1e-1), H).astype(np.float32)),
+         "s4_model.D": rnd(seed + 6, 1, H),
+         "s4_model.output_linear.0.weight": rnd(seed + 7, 2 * H, H, 1, scale=H ** -0.5), "s4_model.output_linear.0.bias": 0.1 * rnd(seed + 8, 2 * H),
+         "out_layer.weight": rnd(seed + 9, H, H, 3, scale=(3 * H) ** -0.5), "out_layer.bias": 0.1 * rnd(seed + 10, H)}
+    p["s4_model.kernel.kernel.L"] = torch.tensor(L, dtype=torch.int64)
+    return p
+
+
+@pytest.mark.parametrize("B,H,T,N,Lint,groups", [(2, 32, 32, 8, 32, 8), (2, 32, 48, 32, 64, 16), (1, 64, 128, 32, 128, 32)])
+def test_s4layer_forward_backward_vs_autograd(lib, B, H, T, N, Lint, groups):
+    """S4Layer (unet.py:76-91): GroupNorm -> NPLR kernel (s4.py:706-832) -> causal long conv + D u -> GELU -> Conv1d(H->2H) + GLU ->
+    conv3 -> + x.  Native forward + backward, INCLUDING the kernel generator's parameter gradients (C, B, P, inv_w_real, w_imag,
+    log_dt), against torch autograd through the oracle's restatement in its float64 'exact' mode (the same Nyquist-safe formula the
+    device evaluates; the complex64 'reference' mode differs from it by fp32 rounding only: tests/test_ops.py::test_s4_kernel)."""
+    from oracle import s4 as s4o
+    p = s4layer_params(H, N, Lint)
+    x, dy = rnd(60, B, H, T), rnd(61, B, H, T)
+    pt = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 else v) for k, v in p.items()}
+    xt = x.clone().requires_grad_(True)
+    u = F.group_norm(xt, groups, pt["norm.weight"], pt["norm.bias"], eps=1e-6)
+    yt = xt + F.conv1d(s4o.s4_forward(pt, "s4_model", u, None, mode="exact"), pt["out_layer.weight"], pt["out_layer.bias"], padding=1)
+    yt.backward(dy)
+    y, dx, grads = lib.train_s4layer(p, x, dy, groups=groups)
+    close(y, yt, 1e-4, "forward")
+    close(dx, xt.grad, 3e-4, "dx")
+    for k in grads:
+        close(grads[k], pt[k].grad, 5e-4, "grad of " + k)
+
+
 def test_q_sample_and_smooth_l1_loss(lib):
     """diffusion.py:326-354,386: x_t = sqrt(ac_t) x0 + sqrt(1 - ac_t) noise;  loss_b = mean smooth_l1(target, pred, beta=0.02) + 0.01."""
     B, Cc, T = 3, 16, 50
