@@ -233,9 +233,20 @@ typedef struct {
 typedef struct {
     float *gn1_w, *gn1_b, *conv1_w, *conv1_b, *emb_w, *emb_b, *gn2_w, *gn2_b, *conv2_w, *conv2_b, *skip_w, *skip_b;
 } mugd_resblock_grads;
-/* y = block(x, emb) (B, Cout, T); given dy: dx (B, Cin, T), demb (B, Kemb) and every parameter gradient.  Synchronises. */
+/* y = block(x, emb) (B, Cout, T); given dy: dx (B, Cin, T), demb (B, Kemb) and every parameter gradient.  Synchronises.
+ * Every mugd_train_* block entry point runs FORWARD ONLY when dy is NULL (dx / gradient pointers are then ignored): a training step
+ * keeps the block inputs of its forward sweep and calls the block again with dy in the backward sweep (block-level checkpointing). */
 int mugd_train_resblock(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x, const float* emb, const float* dy, float* y, float* dx,
                         float* demb, const mugd_resblock_grads* g, int B, int Cin, int Cout, int T, int Kemb, int groups);
+/* mug/model/models.py:142-159 ResnetBlock (wave encoder / VAE: no time embedding, dilated convs with padding = dilation, 1x1
+ * nin_shortcut = skip_w / skip_b): the emb_* members of the parameter / gradient blocks are ignored. */
+int mugd_train_resnet_block(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x, const float* dy, float* y, float* dx,
+                            const mugd_resblock_grads* g, int B, int Cin, int Cout, int T, int groups, int dil1, int dil2);
+/* unet.py:334-339 time_embed: emb (B, M) = W2 silu(W1 temb + b1) + b2 with temb (B, K) the sinusoidal embedding; backward when demb != NULL. */
+int mugd_train_time_embed(mugd_ctx* ctx, const float* w1, const float* b1, const float* w2, const float* b2, const float* temb, const float* demb,
+                          float* emb, float* dw1, float* db1, float* dw2, float* db2, int B, int K, int M);
+/* cond/feature.py:15-21 BeatmapFeatureEmbedder backward: dtable (rows, dim) = scatter-add of dcontext (B, dim, ntok) by ids (B, ntok). */
+int mugd_train_embedding_bwd(mugd_ctx* ctx, const int64_t* ids, const float* dcontext, float* dtable, int B, int ntok, int dim, int rows);
 /* One conv1d layer forward + backward, optionally behind GroupNorm + SiLU (gn_w / gn_b non-NULL: the U-Net's `out` head, unet.py:489-493).
  * mode 0: stride 1, padding dil (taps - 1) / 2 (torch padding=dilation for the dilated ResnetBlock convs, models.py:106-122);
  * mode 1: Downsample (models.py:84-88: pad right by one zero, k = 3, stride 2; Tin even, Tout = Tin / 2);

@@ -270,6 +270,7 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float* x, const 
 // Backward of E = We silu(e) + be  (emb_layers, unet.py:184-190):  dWe[m][k] = sum_b dE[b][m] silu(e[b][k]);  dbe[m] = sum_b dE[b][m];
 // de[b][k] = silu'(e[b][k]) sum_m We[m][k] dE[b][m].   grid (ceil(M / 4) + ceil(K / 256)), block 256: the first blocks own rows of dWe,
 // the rest own columns of de.
+template <bool SILU>
 __global__ __launch_bounds__(256) void emb_linear_bwd_kernel(const float* e, const float* We, const float* dE, float* dWe, float* dbe, float* de,
                                                              int B, int K, int M, int row_blocks) {
     if ((int)blockIdx.x < row_blocks) {
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(256) void emb_linear_bwd_kernel(const float* e, con
         if (m >= M) return;
         for (int k = lane; k < K; k += 64) {
             float s = 0.f;
-            for (int b = 0; b < B; ++b) { const float v = e[(size_t)b * K + k]; s += dE[(size_t)b * M + m] * (v / (1.0f + expf(-v))); }
+            for (int b = 0; b < B; ++b) { const float v = e[(size_t)b * K + k]; s += dE[(size_t)b * M + m] * (SILU ? v / (1.0f + expf(-v)) : v); }
             dWe[(size_t)m * K + k] = s;
         }
         if (lane == 0) {
@@ -294,8 +295,20 @@ __global__ __launch_bounds__(256) void emb_linear_bwd_kernel(const float* e, con
             for (int m = 0; m < M; ++m) s += We[(size_t)m * K + k] * dE[(size_t)b * M + m];
             const float v = e[(size_t)b * K + k];
             const float sg = 1.0f / (1.0f + expf(-v));
-            de[(size_t)b * K + k] = s * (sg * (1.0f + v * (1.0f - sg)));
+            de[(size_t)b * K + k] = SILU ? s * (sg * (1.0f + v * (1.0f - sg))) : s;
         }
+    }
+}
+
+// dtable[r][c] = sum over the (b, j) with ids[b][j] == r of dctx[b][c][j].  One workgroup per table row: deterministic.
+__global__ __launch_bounds__(128) void embedding_bwd_kernel(const long long* ids, const float* dctx, float* dtable, int B, int ntok, int dim) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < dim; c += 128) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b)
+            for (int j = 0; j < ntok; ++j)
+                if (ids[(size_t)b * ntok + j] == r) s += dctx[((size_t)b * dim + c) * ntok + j];
+        dtable[(size_t)r * dim + c] = s;
     }
 }
 
@@ -365,7 +378,15 @@ void launch_gn_bwd(hipStream_t st, const float* x, const float* da, const float*
 }
 void launch_emb_linear_bwd(hipStream_t st, const float* e, const float* We, const float* dE, float* dWe, float* dbe, float* de, int B, int K, int M) {
     const int rb = cdiv(M, 4);
-    hipLaunchKernelGGL(emb_linear_bwd_kernel, dim3(rb + cdiv(K, 256)), dim3(256), 0, st, e, We, dE, dWe, dbe, de, B, K, M, rb);
+    hipLaunchKernelGGL(emb_linear_bwd_kernel<true>, dim3(rb + cdiv(K, 256)), dim3(256), 0, st, e, We, dE, dWe, dbe, de, B, K, M, rb);
+}
+// the same for a plain Linear (no activation in front): dWe = dE^T e, dbe, de (nullable) = dE We
+void launch_emb_linear_bwd_plain(hipStream_t st, const float* e, const float* We, const float* dE, float* dWe, float* dbe, float* de, int B, int K, int M) {
+    const int rb = cdiv(M, 4);
+    hipLaunchKernelGGL(emb_linear_bwd_kernel<false>, dim3(rb + cdiv(K, 256)), dim3(256), 0, st, e, We, dE, dWe, dbe, de, B, K, M, rb);
+}
+void launch_embedding_bwd(hipStream_t st, const long long* ids, const float* dctx, float* dtable, int B, int ntok, int dim, int rows) {
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(rows), dim3(128), 0, st, ids, dctx, dtable, B, ntok, dim);
 }
 void launch_adamw(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd, int step) {
     const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);

@@ -353,6 +353,8 @@ void launch_gelu_bwd(hipStream_t st, const float* pre, const float* dg, float* d
 void launch_glu_fwd(hipStream_t st, const float* v, float* f, int B, int Ch, int T);
 void launch_glu_bwd(hipStream_t st, const float* v, const float* df, float* dv, int B, int Ch, int T);
 void launch_emb_linear_bwd(hipStream_t st, const float* e, const float* We, const float* dE, float* dWe, float* dbe, float* de, int B, int K, int M);
+void launch_emb_linear_bwd_plain(hipStream_t st, const float* e, const float* We, const float* dE, float* dWe, float* dbe, float* de, int B, int K, int M);
+void launch_embedding_bwd(hipStream_t st, const long long* ids, const float* dctx, float* dtable, int B, int ntok, int dim, int rows);
 void launch_adamw(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd, int step);
 
 void launch_embed_tokens(hipStream_t st, const float* table, const long long* ids, float* out, int B, int ntok, int dim);

@@ -89,6 +89,67 @@ struct Lin {
     }
 };
 
+// TimestepResBlock (unet.py:212-239; emb given, dilations 1) and ResnetBlock (models.py:142-159; no emb, dilations d1 / d2, the
+// 1x1 shortcut is the same tensor under another name): forward, and backward when dy is given
+void resblock_impl(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x, const float* emb, const float* dy, float* y, float* dx,
+                   float* demb, const mugd_resblock_grads* g, int B, int Cin, int Cout, int T, int Kemb, int groups, int d1, int d2) {
+    MUGD_CHECK(p && x && y && B > 0 && T > 0 && d1 >= 1 && d2 >= 1, MUGD_ERR_INVALID, "null/empty argument");
+    MUGD_CHECK(!dy || (g && dx), MUGD_ERR_INVALID, "backward needs dx and the gradient block");
+    MUGD_CHECK(Cin % groups == 0 && Cout % groups == 0, MUGD_ERR_INVALID, "channels must be divisible by the group count");
+    MUGD_CHECK((p->skip_w != nullptr) || Cin == Cout, MUGD_ERR_INVALID, "identity skip needs Cin == Cout");
+    MUGD_CHECK(!emb || (p->emb_w && p->emb_b), MUGD_ERR_INVALID, "time embedding given without emb_layers");
+    Ctx& c = ctx->c;
+    hipStream_t st = c.stream;
+    Scratch sc;
+    const size_t nin = (size_t)B * Cin * T, nout = (size_t)B * Cout * T;
+    // ---- forward, training form
+    float* a1 = sc.get(nin, false, st);
+    float* E = emb ? sc.get((size_t)B * Cout, false, st) : nullptr;
+    float* h = sc.get(nout, false, st);
+    float* a2 = sc.get(nout, false, st);
+    run_group_norm_silu(c, x, p->gn1_w, p->gn1_b, a1, B, Cin, T, groups);
+    if (emb) launch_linear_small(st, LinSmallArgs{emb, p->emb_w, p->emb_b, E, B, Kemb, Cout, 1, 0, Kemb, Cout});
+    run_conv(c, sc, a1, p->conv1_w, p->conv1_b, E, Cout, nullptr, h, B, Cin, T, Cout, 3, d1, d1);
+    run_group_norm_silu(c, h, p->gn2_w, p->gn2_b, a2, B, Cout, T, groups);
+    if (p->skip_w) {
+        run_conv(c, sc, x, p->skip_w, p->skip_b, nullptr, 0, nullptr, y, B, Cin, T, Cout, 1, 0);
+        run_conv(c, sc, a2, p->conv2_w, p->conv2_b, nullptr, 0, y, y, B, Cout, T, Cout, 3, d2, d2);
+    } else {
+        run_conv(c, sc, a2, p->conv2_w, p->conv2_b, nullptr, 0, x, y, B, Cout, T, Cout, 3, d2, d2);
+    }
+    if (dy) {
+        float* da2 = sc.get(nout, false, st);
+        float* dh = sc.get(nout, false, st);
+        float* da1 = sc.get(nin, false, st);
+        float* wt = sc.get((size_t)Cout * std::max(Cin, Cout) * 3, false, st);
+        // out_layers conv: dW2, db2, da2 = conv3(dy; W2 transposed + flipped)
+        launch_wgrad_ex(st, dy, a2, g->conv2_w, B, Cout, Cout, T, T, 3, d2, d2, 1, 0);
+        launch_bias_grad(st, dy, g->conv2_b, B, Cout, T, 0);
+        launch_transpose_flip(st, p->conv2_w, wt, Cout, Cout, 3);
+        run_conv(c, sc, dy, wt, nullptr, nullptr, 0, nullptr, da2, B, Cout, T, Cout, 3, d2, d2);
+        launch_gn_silu_bwd(st, h, da2, p->gn2_w, p->gn2_b, 1e-6f, dh, g->gn2_w, g->gn2_b, B, Cout, T, groups, 0);
+        if (emb) {          // h = conv1 + b1 + E: time-embedding branch
+            float* dE = sc.get((size_t)B * Cout, false, st);
+            launch_time_sum(st, dh, dE, B * Cout, T);
+            launch_emb_linear_bwd(st, emb, p->emb_w, dE, g->emb_w, g->emb_b, demb, B, Kemb, Cout);
+        }
+        launch_wgrad_ex(st, dh, a1, g->conv1_w, B, Cout, Cin, T, T, 3, d1, d1, 1, 0);
+        launch_bias_grad(st, dh, g->conv1_b, B, Cout, T, 0);
+        launch_transpose_flip(st, p->conv1_w, wt, Cout, Cin, 3);
+        run_conv(c, sc, dh, wt, nullptr, nullptr, 0, nullptr, da1, B, Cout, T, Cin, 3, d1, d1);
+        launch_gn_silu_bwd(st, x, da1, p->gn1_w, p->gn1_b, 1e-6f, dx, g->gn1_w, g->gn1_b, B, Cin, T, groups, 0);
+        if (p->skip_w) {
+            launch_wgrad(st, dy, x, g->skip_w, B, Cout, Cin, T, 1, 0);
+            launch_bias_grad(st, dy, g->skip_b, B, Cout, T, 0);
+            launch_transpose_flip(st, p->skip_w, wt, Cout, Cin, 1);
+            run_conv(c, sc, dy, wt, nullptr, nullptr, 0, dx, dx, B, Cout, T, Cin, 1, 0);
+        } else {
+            launch_bias_sum(st, dx, dy, dx, (int)nin);          // dx += dy
+        }
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+}
+
 }  // namespace
 
 extern "C" {
@@ -96,11 +157,11 @@ extern "C" {
 int mugd_train_conv(mugd_ctx* ctx, const float* w, const float* bias, const float* gn_w, const float* gn_b, const float* x, const float* dy, float* y,
                     float* dx, float* dw, float* db, float* dgn_w, float* dgn_b, int B, int Cin, int Cout, int Tin, int taps, int dil, int mode, int groups) {
     return guarded(ctx, [&] {
-        MUGD_CHECK(w && x && dy && y && dx && dw && B > 0 && Tin > 0, MUGD_ERR_INVALID, "null/empty argument");
+        MUGD_CHECK(w && x && y && B > 0 && Tin > 0 && (!dy || (dx && dw)), MUGD_ERR_INVALID, "null/empty argument");
         MUGD_CHECK((taps == 1 || taps == 3) && dil >= 1 && mode >= 0 && mode <= 2, MUGD_ERR_INVALID, "bad conv geometry");
         MUGD_CHECK(mode == 0 || (taps == 3 && dil == 1), MUGD_ERR_INVALID, "resampling convs are 3-tap, undilated");
         MUGD_CHECK(mode != 1 || Tin % 2 == 0, MUGD_ERR_INVALID, "downsample: even input length");
-        MUGD_CHECK(!gn_w || (gn_b && dgn_w && dgn_b && groups > 0 && Cin % groups == 0), MUGD_ERR_INVALID, "bad GroupNorm arguments");
+        MUGD_CHECK(!gn_w || (gn_b && (!dy || (dgn_w && dgn_b)) && groups > 0 && Cin % groups == 0), MUGD_ERR_INVALID, "bad GroupNorm arguments");
         Ctx& c = ctx->c;
         hipStream_t st = c.stream;
         Scratch sc;
@@ -115,6 +176,7 @@ int mugd_train_conv(mugd_ctx* ctx, const float* w, const float* bias, const floa
             a = an;
         }
         run_conv(c, sc, a, w, bias, nullptr, 0, nullptr, y, B, Cin, Tin, Cout, taps, pad, dil, stride, ups, Tout);
+        if (!dy) { HIP_CHECK(hipStreamSynchronize(st)); return; }
         // ---- backward
         launch_wgrad_ex(st, dy, a, dw, B, Cout, Cin, Tout, Tin, taps, pad, dil, stride, ups);
         if (db) launch_bias_grad(st, dy, db, B, Cout, Tout, 0);
@@ -147,8 +209,8 @@ int mugd_train_conv(mugd_ctx* ctx, const float* w, const float* bias, const floa
 int mugd_train_s4layer(mugd_ctx* ctx, const float* const* P, const float* x, const float* dy, float* y, float* dx, float* const* G,
                        int B, int H, int T, int N, int Lint, int groups) {
     return guarded(ctx, [&] {
-        MUGD_CHECK(P && G && x && dy && y && dx && B > 0 && T > 0 && N > 0, MUGD_ERR_INVALID, "null/empty argument");
-        for (int i = 0; i < MUGD_S4_NPARAMS; ++i) MUGD_CHECK(P[i] && G[i], MUGD_ERR_INVALID, "null parameter / gradient pointer");
+        MUGD_CHECK(P && x && y && B > 0 && T > 0 && N > 0 && (!dy || (G && dx)), MUGD_ERR_INVALID, "null/empty argument");
+        for (int i = 0; i < MUGD_S4_NPARAMS; ++i) MUGD_CHECK(P[i] && (!dy || G[i]), MUGD_ERR_INVALID, "null parameter / gradient pointer");
         MUGD_CHECK(H % groups == 0 && H % CONV_CK == 0 && Lint >= T, MUGD_ERR_INVALID, "bad S4 layer geometry (stored kernel length < T?)");
         Ctx& c = ctx->c;
         MUGD_CHECK(!c.s4_symmetric, MUGD_ERR_INVALID, "S4 training gradients exist for the cauchy_naive kernel form only");
@@ -167,6 +229,7 @@ int mugd_train_s4layer(mugd_ctx* ctx, const float* const* P, const float* x, con
         lt.fwd(g, P[MUGD_S4_OUT_LIN_W], P[MUGD_S4_OUT_LIN_B], nullptr, v, H, 2 * H);
         launch_glu_fwd(st, v, f, B, H, T);
         run_conv(c, sc, f, P[MUGD_S4_OUT_LAYER_W], P[MUGD_S4_OUT_LAYER_B], nullptr, 0, x, y, B, H, T, H, 3, 1);
+        if (!dy) { HIP_CHECK(hipStreamSynchronize(st)); return; }
         // ---- backward
         float *wt = buf((size_t)2 * H * H * 3), *df = buf(n), *dv = buf(2 * n), *dg = buf(n), *dpre = buf(n), *dn = buf(n), *dk = buf((size_t)H * T);
         launch_wgrad(st, dy, f, G[MUGD_S4_OUT_LAYER_W], B, H, H, T, 3, 1);
@@ -189,9 +252,9 @@ int mugd_train_s4layer(mugd_ctx* ctx, const float* const* P, const float* x, con
 int mugd_train_transformer(mugd_ctx* ctx, const float* const* P, const float* x, const float* context, const float* dy, float* y, float* dx,
                            float* dcontext, float* const* G, int B, int C, int T, int Cc, int Tk, int heads, int groups, int pmax) {
     return guarded(ctx, [&] {
-        MUGD_CHECK(P && G && x && dy && y && dx && B > 0 && T > 0 && heads > 0, MUGD_ERR_INVALID, "null/empty argument");
+        MUGD_CHECK(P && x && y && B > 0 && T > 0 && heads > 0 && (!dy || (G && dx)), MUGD_ERR_INVALID, "null/empty argument");
         MUGD_CHECK(C % heads == 0 && C / heads <= 64 && C % groups == 0, MUGD_ERR_INVALID, "bad head / group split");
-        for (int i = 0; i < MUGD_TF_NPARAMS; ++i) MUGD_CHECK(P[i] && G[i], MUGD_ERR_INVALID, "null parameter / gradient pointer");
+        for (int i = 0; i < MUGD_TF_NPARAMS; ++i) MUGD_CHECK(P[i] && (!dy || G[i]), MUGD_ERR_INVALID, "null parameter / gradient pointer");
         if (!context) { Cc = C; Tk = T; }
         MUGD_CHECK(Cc % CONV_CK == 0 && Tk > 0, MUGD_ERR_INVALID, "context channels must be a multiple of 16");
         Ctx& c = ctx->c;
@@ -232,6 +295,7 @@ int mugd_train_transformer(mugd_ctx* ctx, const float* const* P, const float* x,
         launch_geglu_fwd(st, u, f, B, Ch, T);
         lt.fwd(f, P[MUGD_TF_FF2_W], P[MUGD_TF_FF2_B], h2, h3, Ch, C);
         lt.fwd(h3, P[MUGD_TF_PROJ_OUT_W], P[MUGD_TF_PROJ_OUT_B], x, y, C, C);
+        if (!dy) { HIP_CHECK(hipStreamSynchronize(st)); return; }
 
         // ---- backward
         const size_t wmax = (size_t)2 * Ch * C;
@@ -308,61 +372,43 @@ int mugd_train_adamw(mugd_ctx* ctx, float* param, const float* grad, float* exp_
 int mugd_train_resblock(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x, const float* emb, const float* dy, float* y, float* dx,
                         float* demb, const mugd_resblock_grads* g, int B, int Cin, int Cout, int T, int Kemb, int groups) {
     return guarded(ctx, [&] {
-        MUGD_CHECK(p && g && x && emb && dy && y && dx && B > 0 && T > 0, MUGD_ERR_INVALID, "null/empty argument");
-        MUGD_CHECK(Cin % groups == 0 && Cout % groups == 0, MUGD_ERR_INVALID, "channels must be divisible by the group count");
-        MUGD_CHECK((p->skip_w != nullptr) || Cin == Cout, MUGD_ERR_INVALID, "identity skip needs Cin == Cout");
+        MUGD_CHECK(emb && (!dy || demb), MUGD_ERR_INVALID, "null/empty argument");
+        resblock_impl(ctx, p, x, emb, dy, y, dx, demb, g, B, Cin, Cout, T, Kemb, groups, 1, 1);
+    });
+}
+
+int mugd_train_resnet_block(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x, const float* dy, float* y, float* dx,
+                            const mugd_resblock_grads* g, int B, int Cin, int Cout, int T, int groups, int dil1, int dil2) {
+    return guarded(ctx, [&] { resblock_impl(ctx, p, x, nullptr, dy, y, dx, nullptr, g, B, Cin, Cout, T, 0, groups, dil1, dil2); });
+}
+
+// time_embed (unet.py:334-339): emb = W2 silu(W1 temb + b1) + b2; backward when demb is given
+int mugd_train_time_embed(mugd_ctx* ctx, const float* w1, const float* b1, const float* w2, const float* b2, const float* temb, const float* demb,
+                          float* emb, float* dw1, float* db1, float* dw2, float* db2, int B, int K, int M) {
+    return guarded(ctx, [&] {
+        MUGD_CHECK(w1 && b1 && w2 && b2 && temb && emb && B > 0, MUGD_ERR_INVALID, "null/empty argument");
         Ctx& c = ctx->c;
         hipStream_t st = c.stream;
         Scratch sc;
-        const size_t nin = (size_t)B * Cin * T, nout = (size_t)B * Cout * T;
-        // ---- forward (unet.py:212-239), training form
-        float* a1 = sc.get(nin, false, st);
-        float* E = sc.get((size_t)B * Cout, false, st);
-        float* h = sc.get(nout, false, st);
-        float* a2 = sc.get(nout, false, st);
-        run_group_norm_silu(c, x, p->gn1_w, p->gn1_b, a1, B, Cin, T, groups);
-        launch_linear_small(st, LinSmallArgs{emb, p->emb_w, p->emb_b, E, B, Kemb, Cout, 1, 0, Kemb, Cout});
-        run_conv(c, sc, a1, p->conv1_w, p->conv1_b, E, Cout, nullptr, h, B, Cin, T, Cout, 3, 1);
-        run_group_norm_silu(c, h, p->gn2_w, p->gn2_b, a2, B, Cout, T, groups);
-        if (p->skip_w) {
-            run_conv(c, sc, x, p->skip_w, p->skip_b, nullptr, 0, nullptr, y, B, Cin, T, Cout, 1, 0);
-            run_conv(c, sc, a2, p->conv2_w, p->conv2_b, nullptr, 0, y, y, B, Cout, T, Cout, 3, 1);
-        } else {
-            run_conv(c, sc, a2, p->conv2_w, p->conv2_b, nullptr, 0, x, y, B, Cout, T, Cout, 3, 1);
-        }
-        // ---- backward
-        float* da2 = sc.get(nout, false, st);
-        float* dh = sc.get(nout, false, st);
-        float* da1 = sc.get(nin, false, st);
-        float* dE = sc.get((size_t)B * Cout, false, st);
-        float* wt = sc.get((size_t)Cout * std::max(Cin, Cout) * 3, false, st);
-        // out_layers conv: dW2, db2, da2 = conv3(dy; W2 transposed + flipped)
-        launch_wgrad(st, dy, a2, g->conv2_w, B, Cout, Cout, T, 3, 1);
-        launch_bias_grad(st, dy, g->conv2_b, B, Cout, T, 0);
-        launch_transpose_flip(st, p->conv2_w, wt, Cout, Cout, 3);
-        run_conv(c, sc, dy, wt, nullptr, nullptr, 0, nullptr, da2, B, Cout, T, Cout, 3, 1);
-        // GroupNorm + SiLU of out_layers
-        launch_gn_silu_bwd(st, h, da2, p->gn2_w, p->gn2_b, 1e-6f, dh, g->gn2_w, g->gn2_b, B, Cout, T, groups, 0);
-        // h = conv1 + b1 + E: time-embedding branch
-        launch_time_sum(st, dh, dE, B * Cout, T);
-        launch_emb_linear_bwd(st, emb, p->emb_w, dE, g->emb_w, g->emb_b, demb, B, Kemb, Cout);
-        // in_layers conv
-        launch_wgrad(st, dh, a1, g->conv1_w, B, Cout, Cin, T, 3, 1);
-        launch_bias_grad(st, dh, g->conv1_b, B, Cout, T, 0);
-        launch_transpose_flip(st, p->conv1_w, wt, Cout, Cin, 3);
-        run_conv(c, sc, dh, wt, nullptr, nullptr, 0, nullptr, da1, B, Cout, T, Cin, 3, 1);
-        // GroupNorm + SiLU of in_layers -> dx
-        launch_gn_silu_bwd(st, x, da1, p->gn1_w, p->gn1_b, 1e-6f, dx, g->gn1_w, g->gn1_b, B, Cin, T, groups, 0);
-        // skip connection
-        if (p->skip_w) {
-            launch_wgrad(st, dy, x, g->skip_w, B, Cout, Cin, T, 1, 0);
-            launch_bias_grad(st, dy, g->skip_b, B, Cout, T, 0);
-            launch_transpose_flip(st, p->skip_w, wt, Cout, Cin, 1);
-            run_conv(c, sc, dy, wt, nullptr, nullptr, 0, dx, dx, B, Cout, T, Cin, 1, 0);
-        } else {
-            launch_bias_sum(st, dx, dy, dx, (int)nin);          // dx += dy
+        float* e1 = sc.get((size_t)B * M, false, st);
+        launch_linear_small(st, LinSmallArgs{temb, w1, b1, e1, B, K, M, 0, 0, K, M});
+        launch_linear_small(st, LinSmallArgs{e1, w2, b2, emb, B, M, M, 1, 0, M, M});
+        if (demb) {
+            MUGD_CHECK(dw1 && db1 && dw2 && db2, MUGD_ERR_INVALID, "null gradient pointer");
+            float* de1 = sc.get((size_t)B * M, false, st);
+            launch_emb_linear_bwd(st, e1, w2, demb, dw2, db2, de1, B, M, M);
+            launch_emb_linear_bwd_plain(st, temb, w1, de1, dw1, db1, nullptr, B, K, M);
         }
         HIP_CHECK(hipStreamSynchronize(st));
+    });
+}
+
+// BeatmapFeatureEmbedder backward (cond/feature.py:15-21): dtable[ids[b][j]][:] += dcontext[b][:][j]
+int mugd_train_embedding_bwd(mugd_ctx* ctx, const int64_t* ids, const float* dcontext, float* dtable, int B, int ntok, int dim, int rows) {
+    return guarded(ctx, [&] {
+        MUGD_CHECK(ids && dcontext && dtable && B > 0 && ntok > 0 && dim > 0 && rows > 0, MUGD_ERR_INVALID, "null/empty argument");
+        launch_embedding_bwd(ctx->c.stream, (const long long*)ids, dcontext, dtable, B, ntok, dim, rows);
+        HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
     });
 }
 

@@ -86,6 +86,9 @@ _SIGS = {
     "mugd_train_smooth_l1": [_p, _p, _p, _f, _f, _p, _p, _i, C.c_int64],
     "mugd_train_resblock": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i],
     "mugd_train_conv": [_p] * 13 + [_i] * 8,
+    "mugd_train_resnet_block": [_p] * 7 + [_i] * 7,
+    "mugd_train_time_embed": [_p] * 12 + [_i] * 3,
+    "mugd_train_embedding_bwd": [_p] * 4 + [_i] * 4,
     "mugd_train_s4layer": [_p] * 7 + [_i] * 6,
     "mugd_train_transformer": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i],
     "mugd_train_adamw": [_p, _p, _p, _p, _p, C.c_int64, _f, _f, _f, _f, _f, _i],
@@ -416,49 +419,98 @@ class Lib:
         self.check(self.dll.mugd_train_smooth_l1(self.ctx, _ptr(pred), _ptr(target), float(beta), float(add), _ptr(loss), _ptr(grad), B, pred.numel() // B))
         return loss, grad
 
-    def train_resblock(self, params, x, emb, dy, groups=32):
-        """TimestepResBlock forward + backward (unet.py:212-239).  params: dict with the module's tensors
-        (in_layers.0.weight/bias, in_layers.2.weight/bias, emb_layers.1.weight/bias, out_layers.0.weight/bias,
-        out_layers.3.weight/bias, optionally skip_connection.weight/bias).  Returns y, dx, demb, grads (same keys)."""
-        keymap = dict(gn1_w="in_layers.0.weight", gn1_b="in_layers.0.bias", conv1_w="in_layers.2.weight", conv1_b="in_layers.2.bias",
-                      emb_w="emb_layers.1.weight", emb_b="emb_layers.1.bias", gn2_w="out_layers.0.weight", gn2_b="out_layers.0.bias",
-                      conv2_w="out_layers.3.weight", conv2_b="out_layers.3.bias", skip_w="skip_connection.weight", skip_b="skip_connection.bias")
-        x, emb, dy = self.f32(x), self.f32(emb), self.f32(dy)
+    _RESBLOCK_KEYS = dict(gn1_w="in_layers.0.weight", gn1_b="in_layers.0.bias", conv1_w="in_layers.2.weight", conv1_b="in_layers.2.bias",
+                          emb_w="emb_layers.1.weight", emb_b="emb_layers.1.bias", gn2_w="out_layers.0.weight", gn2_b="out_layers.0.bias",
+                          conv2_w="out_layers.3.weight", conv2_b="out_layers.3.bias", skip_w="skip_connection.weight", skip_b="skip_connection.bias")
+    _RESNET_KEYS = dict(gn1_w="norm1.weight", gn1_b="norm1.bias", conv1_w="conv1.weight", conv1_b="conv1.bias", gn2_w="norm2.weight",
+                        gn2_b="norm2.bias", conv2_w="conv2.weight", conv2_b="conv2.bias", skip_w="nin_shortcut.weight", skip_b="nin_shortcut.bias")
+
+    def _resblock_ptrs(self, keymap, params, want_grads):
         P, G, keep, grads = ResBlockPtrs(), ResBlockPtrs(), [], {}
         for f, k in keymap.items():
             if k in params:
                 t = self.f32(params[k])
-                g = torch.zeros_like(t)
-                keep += [t, g]
-                grads[k] = g
+                keep.append(t)
                 setattr(P, f, t.data_ptr())
-                setattr(G, f, g.data_ptr())
+                if want_grads:
+                    g = torch.zeros_like(t)
+                    keep.append(g)
+                    grads[k] = g
+                    setattr(G, f, g.data_ptr())
+        return P, G, keep, grads
+
+    def train_resblock(self, params, x, emb, dy, groups=32):
+        """TimestepResBlock forward + backward (unet.py:212-239).  params: dict with the module's tensors
+        (in_layers.0.weight/bias, in_layers.2.weight/bias, emb_layers.1.weight/bias, out_layers.0.weight/bias,
+        out_layers.3.weight/bias, optionally skip_connection.weight/bias).  Returns y, dx, demb, grads (same keys);
+        dy None: forward only (dx, demb None, grads empty)."""
+        x, emb = self.f32(x), self.f32(emb)
+        dy = None if dy is None else self.f32(dy)
+        P, G, keep, grads = self._resblock_ptrs(self._RESBLOCK_KEYS, params, dy is not None)
         B, Cin, T = x.shape
         Cout = params["in_layers.2.weight"].shape[0]
         y = self.empty(B, Cout, T)
-        dx = torch.empty_like(x)
-        demb = torch.empty_like(emb)
+        dx = None if dy is None else torch.empty_like(x)
+        demb = None if dy is None else torch.empty_like(emb)
         self.check(self.dll.mugd_train_resblock(self.ctx, C.byref(P), _ptr(x), _ptr(emb), _ptr(dy), _ptr(y), _ptr(dx), _ptr(demb), C.byref(G),
                                                 B, Cin, Cout, T, emb.shape[1], groups))
         return y, dx, demb, grads
 
+    def train_resnet_block(self, params, x, dy, groups=32, dilations=(1, 1)):
+        """ResnetBlock forward + backward (mug/model/models.py:142-159: norm1/conv1/norm2/conv2/nin_shortcut, dilated convs)."""
+        x = self.f32(x)
+        dy = None if dy is None else self.f32(dy)
+        P, G, keep, grads = self._resblock_ptrs(self._RESNET_KEYS, params, dy is not None)
+        B, Cin, T = x.shape
+        Cout = params["conv1.weight"].shape[0]
+        y = self.empty(B, Cout, T)
+        dx = None if dy is None else torch.empty_like(x)
+        self.check(self.dll.mugd_train_resnet_block(self.ctx, C.byref(P), _ptr(x), _ptr(dy), _ptr(y), _ptr(dx), C.byref(G), B, Cin, Cout, T, groups,
+                                                    int(dilations[0]), int(dilations[1])))
+        return y, dx, grads
+
+    def train_time_embed(self, params, temb, demb):
+        """time_embed (unet.py:334-339): params '0.weight', '0.bias', '2.weight', '2.bias'; temb (B, K).  Returns emb, grads."""
+        temb = self.f32(temb)
+        demb = None if demb is None else self.f32(demb)
+        w1, b1, w2, b2 = (self.f32(params[k]) for k in ("0.weight", "0.bias", "2.weight", "2.bias"))
+        B, K = temb.shape
+        M = w1.shape[0]
+        emb = self.empty(B, M)
+        g = [torch.zeros_like(t) for t in (w1, b1, w2, b2)] if demb is not None else [None] * 4
+        self.check(self.dll.mugd_train_time_embed(self.ctx, _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(temb), _ptr(demb), _ptr(emb),
+                                                  _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), B, K, M))
+        return emb, ({} if demb is None else {"0.weight": g[0], "0.bias": g[1], "2.weight": g[2], "2.bias": g[3]})
+
+    def train_embedding_bwd(self, ids, dcontext, rows):
+        """BeatmapFeatureEmbedder backward: gradient of the (rows, dim) table from dcontext (B, dim, ntok)."""
+        ids = ids.to(device=self.device, dtype=torch.int64).contiguous()
+        dc = self.f32(dcontext)
+        B, dim, ntok = dc.shape
+        dt = self.empty(rows, dim)
+        self.check(self.dll.mugd_train_embedding_bwd(self.ctx, _ptr(ids), _ptr(dc), _ptr(dt), B, ntok, dim, rows))
+        return dt
+
     def train_conv(self, weight, bias, x, dy, dil=1, mode=0, gn=None, groups=32):
         """conv1d forward + backward; mode 0 plain (padding = dil (k - 1) / 2), 1 Downsample, 2 Upsample (models.py:55-91);
         gn = (weight, bias): GroupNorm + SiLU in front (the U-Net's out head).  Returns y, dx, dw, db, (dgn_w, dgn_b) or None."""
-        w, x, dy = self.f32(weight), self.f32(x), self.f32(dy)
+        w, x = self.f32(weight), self.f32(x)
+        dy = None if dy is None else self.f32(dy)
         b = None if bias is None else self.f32(bias)
         B, Cin, Tin = x.shape
         Cout, _, taps = w.shape
         Tout = Tin // 2 if mode == 1 else (2 * Tin if mode == 2 else Tin)
-        y, dx, dw = self.empty(B, Cout, Tout), torch.empty_like(x), torch.zeros_like(w)
-        db = None if b is None else torch.zeros_like(b)
+        y = self.empty(B, Cout, Tout)
+        dx, dw = (None, None) if dy is None else (torch.empty_like(x), torch.zeros_like(w))
+        db = None if (b is None or dy is None) else torch.zeros_like(b)
         gw = gb = dgw = dgb = None
         if gn is not None:
             gw, gb = self.f32(gn[0]), self.f32(gn[1])
-            dgw, dgb = torch.zeros_like(gw), torch.zeros_like(gb)
+            if dy is not None:
+                dgw, dgb = torch.zeros_like(gw), torch.zeros_like(gb)
         self.check(self.dll.mugd_train_conv(self.ctx, _ptr(w), _ptr(b), _ptr(gw), _ptr(gb), _ptr(x), _ptr(dy), _ptr(y), _ptr(dx), _ptr(dw), _ptr(db),
                                             _ptr(dgw), _ptr(dgb), B, Cin, Cout, Tin, taps, int(dil), int(mode), int(groups)))
-        return y, dx, dw, db, (None if gn is None else (dgw, dgb))
+        return y, dx, dw, db, (None if (gn is None or dy is None) else (dgw, dgb))
 
     # include/mugd.h MUGD_S4_*: the S4Layer's tensors in the C ABI's order, by their state-dict names
     S4LAYER_KEYS = ("norm.weight", "norm.bias", "s4_model.kernel.kernel.C", "s4_model.kernel.kernel.B", "s4_model.kernel.kernel.P",
@@ -468,20 +520,24 @@ class Lib:
     def train_s4layer(self, params, x, dy, groups=32):
         """S4Layer forward + backward (unet.py:76-91, s4.py:1471-1541, kernel gradients included).  params: dict keyed like the module's
         state dict (S4LAYER_KEYS + 's4_model.kernel.kernel.L', the stored internal length).  Returns y, dx, grads."""
-        x, dy = self.f32(x), self.f32(dy)
+        x = self.f32(x)
+        dy = None if dy is None else self.f32(dy)
         n = len(self.S4LAYER_KEYS)
         keep, grads = [], {}
         PA, GA = (C.c_void_p * n)(), (C.c_void_p * n)()
         for i, k in enumerate(self.S4LAYER_KEYS):
             t = self.f32(params[k])
-            g = torch.zeros_like(t)
-            keep += [t, g]
-            grads[k] = g
-            PA[i], GA[i] = t.data_ptr(), g.data_ptr()
+            keep.append(t)
+            PA[i] = t.data_ptr()
+            if dy is not None:
+                g = torch.zeros_like(t)
+                keep.append(g)
+                grads[k] = g
+                GA[i] = g.data_ptr()
         B, H, T = x.shape
         N = params["s4_model.kernel.kernel.inv_w_real"].shape[-1]
         Lint = int(params["s4_model.kernel.kernel.L"])
-        y, dx = torch.empty_like(x), torch.empty_like(x)
+        y, dx = torch.empty_like(x), (None if dy is None else torch.empty_like(x))
         self.check(self.dll.mugd_train_s4layer(self.ctx, PA, _ptr(x), _ptr(dy), _ptr(y), _ptr(dx), GA, B, H, T, N, Lint, int(groups)))
         return y, dx, grads
 
@@ -504,20 +560,24 @@ class Lib:
         """ContextualTransformer forward + backward (mug/model/attention.py:154-199).  params: dict keyed like the module's state dict
         (TRANSFORMER_KEYS).  x, dy (B, C, T); context (B, Cc, Tk) or None (attn2 = second self-attention).
         Returns y, dx, dcontext (None without context), grads (same keys)."""
-        x, dy = self.f32(x), self.f32(dy)
+        x = self.f32(x)
+        dy = None if dy is None else self.f32(dy)
         ctx = None if context is None else self.f32(context)
         keep, grads = [], {}
         PA, GA = (C.c_void_p * len(self.TRANSFORMER_KEYS))(), (C.c_void_p * len(self.TRANSFORMER_KEYS))()
         for i, k in enumerate(self.TRANSFORMER_KEYS):
             t = self.f32(params[k])
-            g = torch.zeros_like(t)
-            keep += [t, g]
-            grads[k] = g
-            PA[i], GA[i] = t.data_ptr(), g.data_ptr()
+            keep.append(t)
+            PA[i] = t.data_ptr()
+            if dy is not None:
+                g = torch.zeros_like(t)
+                keep.append(g)
+                grads[k] = g
+                GA[i] = g.data_ptr()
         B, Cm, T = x.shape
         pmax = (params["transformer_blocks.0.attn1.relative_position_embedding"].shape[0] - 1) // 2
-        y, dx = torch.empty_like(x), torch.empty_like(x)
-        dctx = None if ctx is None else torch.empty_like(ctx)
+        y, dx = torch.empty_like(x), (None if dy is None else torch.empty_like(x))
+        dctx = None if (ctx is None or dy is None) else torch.empty_like(ctx)
         Cc, Tk = (0, 0) if ctx is None else (ctx.shape[1], ctx.shape[2])
         self.check(self.dll.mugd_train_transformer(self.ctx, PA, _ptr(x), _ptr(ctx), _ptr(dy), _ptr(y), _ptr(dx), _ptr(dctx), GA,
                                                    B, Cm, T, Cc, Tk, int(heads), int(groups), int(pmax)))

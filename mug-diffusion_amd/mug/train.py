@@ -1,9 +1,13 @@
-"""Training slice (BASELINE configs[4]) -- FIRST STEP.  What exists natively (include/mugd.h, "training
+"""Training (BASELINE configs[4]).  What exists natively (include/mugd.h, "training
 slice"): q_sample, the smooth-L1 noise-prediction loss with its gradient, forward + backward of TimestepResBlock and of
 ContextualTransformer (`Lib.train_resblock`, `Lib.train_transformer`), an AdamW step; here: the glue that turns them into a
 data-parallel step on a block and the gradient all-reduce every rank of a DDP job runs (one flat bucket, averaged).  The backward
 of the S4 and resampling layers -- and with them `DDPM.training_step` (mug/diffusion/diffusion.py:356-414) for the whole U-Net --
-are not built yet.
+are built from these block entry points by `training_step` below: a forward sweep that keeps every block's INPUT, then a backward
+sweep that calls each block again with its upstream gradient (the block recomputes its own forward: block-level checkpointing,
+2 forwards + 1 backward per step, no whole-network activation storage).  All arithmetic is native; torch does the bookkeeping
+(channel concatenation / slicing of skip connections, gradient accumulation).  First version: every block call synchronises and
+allocates its scratch -- correct and gradient-checked against autograd, not yet tuned.
 """
 import torch
 import torch.distributed as dist
@@ -49,3 +53,232 @@ def adamw_step(lib, params, grads, state, step, lr=1e-4, betas=(0.9, 0.999), eps
         m, v = state[k]
         lib.train_adamw(p, grads[k], m, v, step, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
     return params
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# whole-model training step (mug/diffusion/diffusion.py:356-414 DDPM.p_losses / training_step)
+# ------------------------------------------------------------------------------------------------------------------------------
+def _sub(sd, q):
+    n = len(q) + 1
+    return {k[n:]: v for k, v in sd.items() if k.startswith(q + ".")}
+
+
+class _Grads:
+    """Gradients keyed by full state-dict name; a tensor reached twice accumulates."""
+
+    def __init__(self):
+        self.g = {}
+
+    def add(self, prefix, grads):
+        for k, v in grads.items():
+            key = prefix + "." + k if prefix else k
+            self.g[key] = v if key not in self.g else self.g[key] + v
+
+
+def unet_plan(cfg):
+    """The U-Net constructor's module order (mug/diffusion/unet.py:341-487), index-compatible with the state-dict keys:
+    input_blocks = conv_in, then per level [audio concat][num_res_blocks x (res, [attn], [s4])][down]; output_blocks mirrored with
+    one more sequence per level, no S4 in the last one, the upsample appended to it."""
+    mc, mult, nrb, attn_res = cfg["model_channels"], cfg["channel_mult"], cfg["num_res_blocks"], cfg["attention_resolutions"]
+    inp, ds = [("conv_in",)], 1
+    for level in range(len(mult)):
+        inp.append(("audio", level))
+        for _ in range(nrb):
+            inp.append(("seq", ["res"] + (["attn"] if ds in attn_res else []) + (["s4"] if cfg.get("s4_layer", False) else [])))
+        if level != len(mult) - 1:
+            inp.append(("down",))
+            ds *= 2
+    out = []
+    for level in reversed(range(len(mult))):
+        out.append(("audio", level))
+        for i in range(nrb + 1):
+            layers = ["res"] + (["attn"] if ds in attn_res else [])
+            if cfg.get("s4_layer", False) and i != nrb:
+                layers.append("s4")
+            if level and i == nrb:
+                layers.append("up")
+                ds //= 2
+            out.append(("seq", layers))
+    return inp, out
+
+
+class UNetStep:
+    """Forward sweep / backward sweep of UNetModel.forward (unet.py:511-550) over the native block entry points."""
+
+    def __init__(self, lib, sd, cfg, prefix="model.unet_model", groups=32):
+        self.lib, self.sd, self.cfg, self.p, self.groups = lib, sd, cfg, prefix, groups
+
+    def _seq_forward(self, q, layers, h, emb, ctx, tape):
+        lib, heads = self.lib, self.cfg["num_heads"]
+        for j, kind in enumerate(layers):
+            qq = "%s.%d" % (q, j)
+            tape.append((kind, qq, h))
+            if kind == "res":
+                h = lib.train_resblock(_sub(self.sd, qq), h, emb, None, groups=self.groups)[0]
+            elif kind == "attn":
+                h = lib.train_transformer(_sub(self.sd, qq), h, ctx, None, heads, groups=self.groups)[0]
+            elif kind == "s4":
+                h = lib.train_s4layer(_sub(self.sd, qq), h, None, groups=self.groups)[0]
+            else:
+                h = lib.train_conv(self.sd[qq + ".conv.weight"], self.sd[qq + ".conv.bias"], h, None, mode=2)[0]
+        return h
+
+    def forward(self, x, t, context, audios):
+        """x (B, C, z), t (B) long, context (B, Cc, ntok), audios: the wave encoder's maps (the last len(channel_mult) are used)."""
+        lib, sd, cfg, p = self.lib, self.sd, self.cfg, self.p
+        nl = len(cfg["channel_mult"])
+        self.temb = lib.op_timestep_embedding(t, cfg["model_channels"])
+        self.emb, _ = lib.train_time_embed(_sub(sd, p + ".time_embed"), self.temb, None)
+        self.context, self.audios = context, [a.to(lib.device) for a in audios]
+        inp, out = unet_plan(cfg)
+        tape, hs, h, ai = [], [], lib.f32(x), -nl
+        for i, mod in enumerate(inp):
+            q = "%s.input_blocks.%d" % (p, i)
+            if mod[0] == "audio":
+                tape.append(("audio_cat", h.shape[1], ai))
+                h = torch.cat([h, self.audios[ai]], dim=1)
+                ai += 1
+                continue
+            if mod[0] == "conv_in":
+                tape.append(("conv", q + ".0", h, 0))
+                h = lib.train_conv(sd[q + ".0.weight"], sd[q + ".0.bias"], h, None)[0]
+            elif mod[0] == "down":
+                tape.append(("conv", q + ".0.conv", h, 1))
+                h = lib.train_conv(sd[q + ".0.conv.weight"], sd[q + ".0.conv.bias"], h, None, mode=1)[0]
+            else:
+                h = self._seq_forward(q, mod[1], h, self.emb, context, tape)
+            tape.append(("push", len(hs)))
+            hs.append(h)
+        ai = -1
+        q = p + ".middle_block"
+        h = self._seq_forward(q, ["res", "attn", "res"], h, self.emb, context, tape)
+        for i, mod in enumerate(out):
+            q = "%s.output_blocks.%d" % (p, i)
+            if mod[0] == "audio":
+                tape.append(("audio_cat", h.shape[1], ai))
+                h = torch.cat([h, self.audios[ai]], dim=1)
+                ai -= 1
+                continue
+            tape.append(("skip_cat", h.shape[1], len(hs) - 1))
+            h = torch.cat([h, hs.pop()], dim=1)
+            h = self._seq_forward(q, mod[1], h, self.emb, context, tape)
+        tape.append(("out", p + ".out", h))
+        y = lib.train_conv(sd[p + ".out.2.weight"], sd[p + ".out.2.bias"], h, None, gn=(sd[p + ".out.0.weight"], sd[p + ".out.0.bias"]),
+                           groups=self.groups)[0]
+        self.tape = tape
+        return y
+
+    def backward(self, dy, grads):
+        """dy: gradient of the output.  Fills `grads` (_Grads); returns (dx, dcontext, {audio index: gradient})."""
+        lib, sd, heads = self.lib, self.sd, self.cfg["num_heads"]
+        dh, demb, dctx, daud, skips = dy, None, None, {}, {}
+        for rec in reversed(self.tape):
+            kind = rec[0]
+            if kind == "out":
+                _, q, h = rec
+                _, dh, dw, db, dg = lib.train_conv(sd[q + ".2.weight"], sd[q + ".2.bias"], h, dh, gn=(sd[q + ".0.weight"], sd[q + ".0.bias"]), groups=self.groups)
+                grads.add(q, {"2.weight": dw, "2.bias": db, "0.weight": dg[0], "0.bias": dg[1]})
+            elif kind == "conv" or kind == "up":
+                q, h, mode = (rec[1], rec[2], rec[3]) if kind == "conv" else (rec[1] + ".conv", rec[2], 2)
+                _, dh, dw, db, _ = lib.train_conv(sd[q + ".weight"], sd[q + ".bias"], h, dh, mode=mode)
+                grads.add(q, {"weight": dw, "bias": db})
+            elif kind == "res":
+                _, dh, de, g = lib.train_resblock(_sub(sd, rec[1]), rec[2], self.emb, dh, groups=self.groups)
+                demb = de if demb is None else demb + de
+                grads.add(rec[1], g)
+            elif kind == "attn":
+                _, dh, dc, g = lib.train_transformer(_sub(sd, rec[1]), rec[2], self.context, dh, heads, groups=self.groups)
+                if dc is not None:
+                    dctx = dc if dctx is None else dctx + dc
+                grads.add(rec[1], g)
+            elif kind == "s4":
+                _, dh, g = lib.train_s4layer(_sub(sd, rec[1]), rec[2], dh, groups=self.groups)
+                grads.add(rec[1], g)
+            elif kind == "skip_cat":
+                skips[rec[2]] = dh[:, rec[1]:].contiguous()
+                dh = dh[:, :rec[1]].contiguous()
+            elif kind == "audio_cat":
+                da = dh[:, rec[1]:].contiguous()
+                daud[rec[2]] = da if rec[2] not in daud else daud[rec[2]] + da
+                dh = dh[:, :rec[1]].contiguous()
+            elif kind == "push":
+                dh = dh + skips.pop(rec[1])
+        _, g = lib.train_time_embed(_sub(sd, self.p + ".time_embed"), self.temb, demb)
+        grads.add(self.p + ".time_embed", g)
+        return dh, dctx, daud
+
+
+class WaveStep:
+    """MelspectrogramScaleEncoder1D.forward (mug/cond/wave.py:398-464) as a forward / backward sweep."""
+
+    def __init__(self, lib, sd, cfg, prefix="model.wave_model"):
+        self.lib, self.sd, self.cfg, self.p = lib, sd, cfg, prefix
+
+    def forward(self, mel):
+        lib, sd, cfg, p = self.lib, self.sd, self.cfg, self.p
+        g, heads = cfg["num_groups"], cfg["num_heads"]
+        tape, hs, ds = [("conv", p + ".conv_in", lib.f32(mel), 0)], [], 1
+        h = lib.train_conv(sd[p + ".conv_in.weight"], sd[p + ".conv_in.bias"], mel, None)[0]
+        for lvl in range(len(cfg["channel_mult"])):
+            q = "%s.down.%d" % (p, lvl)
+            if lvl != 0:
+                tape.append(("conv", q + ".downsample.conv", h, 1))
+                h = lib.train_conv(sd[q + ".downsample.conv.weight"], sd[q + ".downsample.conv.bias"], h, None, mode=1)[0]
+                ds *= 2
+            for ib in range(cfg["num_res_blocks"]):
+                dil = (1, 2) if ib % 2 == 0 else (4, 8)
+                qq = "%s.block.%d" % (q, ib)
+                tape.append(("resnet", qq, h, dil))
+                h = lib.train_resnet_block(_sub(sd, qq), h, None, groups=g, dilations=dil)[0]
+                if ds in cfg["attention_resolutions"]:
+                    qq = "%s.attn.%d" % (q, ib)
+                    tape.append(("attn", qq, h))
+                    h = lib.train_transformer(_sub(sd, qq), h, None, None, heads, groups=32)[0]
+            tape.append(("emit", lvl))
+            hs.append(h)
+        self.tape = tape
+        return hs
+
+    def backward(self, dhs, grads):
+        """dhs: {level index (negative, as the U-Net addresses them, or non-negative): gradient}."""
+        lib, sd, cfg = self.lib, self.sd, self.cfg
+        nl = len(cfg["channel_mult"])
+        want = {(k % nl): v for k, v in dhs.items()}
+        dh = None
+        for rec in reversed(self.tape):
+            kind = rec[0]
+            if kind == "emit":
+                if rec[1] in want:
+                    dh = want[rec[1]] if dh is None else dh + want[rec[1]]
+            elif dh is None:
+                continue                                    # levels above the last one the U-Net reads get no gradient
+            elif kind == "conv":
+                _, dh, dw, db, _ = lib.train_conv(sd[rec[1] + ".weight"], sd[rec[1] + ".bias"], rec[2], dh, mode=rec[3])
+                grads.add(rec[1], {"weight": dw, "bias": db})
+            elif kind == "resnet":
+                _, dh, g = lib.train_resnet_block(_sub(sd, rec[1]), rec[2], dh, groups=cfg["num_groups"], dilations=rec[3])
+                grads.add(rec[1], g)
+            elif kind == "attn":
+                _, dh, _, g = lib.train_transformer(_sub(sd, rec[1]), rec[2], None, dh, cfg["num_heads"], groups=32)
+                grads.add(rec[1], g)
+        return dh
+
+
+def training_step(lib, sd, unet_cfg, wave_cfg, x0, noise, t, ids, mel, beta=0.02, add=0.01):
+    """One DDPM training step's loss and gradients (diffusion.py:356-414: x_t = q_sample(x0, t, noise); eps = unet(x_t, t,
+    cond(ids), *wave(mel)); loss = mean_b(mean smooth_l1(noise, eps; beta) + add)), for every trainable tensor of the U-Net, the
+    wave encoder and the prompt-feature embedding table.  sd: the model's state dict (full names, device or host tensors).
+    Returns (loss, {state-dict name: gradient})."""
+    grads = _Grads()
+    xt = lib.train_q_sample(x0, noise, t, sd["sqrt_alphas_cumprod"], sd["sqrt_one_minus_alphas_cumprod"])
+    table = lib.f32(sd["model.cond_stage_model.embedding.weight"])
+    context = lib.cond_embed(table, ids)
+    wave = WaveStep(lib, sd, wave_cfg)
+    audios = wave.forward(mel)
+    unet = UNetStep(lib, sd, unet_cfg)
+    pred = unet.forward(xt, t, context, audios)
+    loss, dpred = lib.train_smooth_l1(pred, noise, beta=beta, add=add)
+    _, dctx, daud = unet.backward(dpred, grads)
+    grads.add("", {"model.cond_stage_model.embedding.weight": lib.train_embedding_bwd(ids, dctx, table.shape[0])})
+    wave.backward(daud, grads)
+    return loss.mean(), grads.g

@@ -225,6 +225,48 @@ def test_adamw_step_matches_torch(lib):
         close(p, pt, 2e-6, "parameters after step %d" % step)
 
 
+def test_whole_model_training_step_vs_autograd(lib):
+    """configs[4] in miniature: DDPM.p_losses (diffusion.py:356-414) on the structurally complete `tiny` model -- q_sample, prompt
+    embedding, wave encoder, U-Net (ResBlocks, transformers with cross-attention, S4 layers, down / upsampling, audio and skip
+    concatenations), smooth-L1 loss -- through mug.train.training_step (native block forward / backward entry points, block-level
+    checkpointing), against torch autograd through the oracle's restatement of the same networks: the loss and the gradient of
+    EVERY trainable tensor of the three networks."""
+    from oracle import cases, nets, weights
+    from mug import train
+    case = cases.TINY
+    man = weights.load_manifest(os.path.join(cases.GOLDEN, case["manifest"]))
+    B, z = 2, 32
+    sd = weights.set_s4_lengths(weights.make_state_dict(man, 3), case["unet"], z)
+    x0, noise = rnd(70, B, 16, z), rnd(71, B, 16, z)
+    t = torch.tensor([17, 803])
+    ids = cases.prompt_ids(case, 5, B) if hasattr(cases, "prompt_ids") else torch.from_numpy(np.random.default_rng(5).integers(0, sd["model.cond_stage_model.embedding.weight"].shape[0], (B, case["n_ctx_tok"])))
+    mel = rnd(72, B, case["wave"]["n_freq"], z * case["audio_ratio"]).abs()
+    trainable = [k for k, v in sd.items() if v.dtype == torch.float32 and k.startswith("model.") and not k.startswith("model.first_stage_model")]
+    st = {k: (v.clone().requires_grad_(True) if k in trainable else v) for k, v in sd.items()}
+    xt = st["sqrt_alphas_cumprod"][t][:, None, None] * x0 + st["sqrt_one_minus_alphas_cumprod"][t][:, None, None] * noise
+    ctx = nets.cond_embed(st, ids)
+    w = nets.wave_encode(st, case["wave"], mel)
+    pred = nets.unet_forward(st, case["unet"], xt, t, ctx, w)
+    lt = (F.smooth_l1_loss(noise, pred, beta=0.02, reduction="none") + 0.01).mean(dim=[1, 2]).mean()
+    lt.backward()
+    loss, grads = train.training_step(lib, sd, case["unet"], case["wave"], x0, noise, t, ids, mel)
+    lt = lt.detach()
+    assert abs(float(loss) - float(lt)) <= 1e-5 * max(1.0, abs(float(lt))), (float(loss), float(lt))
+    missing = [k for k in trainable if st[k].grad is not None and k not in grads]
+    assert not missing, "no gradient produced for %d tensors, e.g. %s" % (len(missing), missing[:5])
+    worst = (0.0, None)
+    for k in trainable:
+        if st[k].grad is None:
+            assert k not in grads or float(grads[k].abs().max()) == 0.0, k         # tensors the loss does not reach (wave levels the U-Net does not read)
+            continue
+        a, b = grads[k].detach().cpu().reshape(st[k].shape), st[k].grad
+        d, sc = (a - b).abs().max().item(), b.abs().max().item()
+        rel = d / max(sc, 1e-6)
+        worst = max(worst, (rel, k))
+        assert d <= 2e-3 * max(sc, 1e-4), "gradient of %s: max|diff| %.3e (ref max %.3e)" % (k, d, sc)
+    print("worst relative gradient error %.2e at %s over %d tensors" % (worst[0], worst[1], len(trainable)))
+
+
 # ------------------------------------------------------------------ data parallel: gradient all-reduce over 2 gloo ranks
 def _worker(rank, world, port, q):
     import torch.distributed as dist
