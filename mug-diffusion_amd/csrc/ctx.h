@@ -2,6 +2,34 @@
 #pragma once
 #include "net.h"
 
+#include <vector>
+
+// Scratch blocks of the training entry points, kept across calls (a training step makes several hundred block calls of a few
+// recurring sizes: hipMalloc / hipFree per call -- the latter synchronises the device -- were most of the step's wall time).
+struct TrainPool {
+    struct Block { void* p; size_t bytes; bool used; };
+    std::vector<Block> blocks;
+    void* take(size_t bytes) {
+        int best = -1;
+        for (int i = 0; i < (int)blocks.size(); ++i)
+            if (!blocks[i].used && blocks[i].bytes >= bytes && (best < 0 || blocks[i].bytes < blocks[best].bytes)) best = i;
+        if (best >= 0 && blocks[best].bytes <= 2 * bytes + (1 << 20)) { blocks[best].used = true; return blocks[best].p; }
+        void* p = nullptr;
+        HIP_CHECK(hipMalloc(&p, bytes));
+        blocks.push_back(Block{p, bytes, true});
+        return p;
+    }
+    void give(void* p) {
+        for (auto& b : blocks)
+            if (b.p == p) { b.used = false; return; }
+    }
+    void release() {
+        for (auto& b : blocks) hipFree(b.p);
+        blocks.clear();
+    }
+};
+
 struct mugd_ctx {
     Ctx c;
+    TrainPool pool;
 };

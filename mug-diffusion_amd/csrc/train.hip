@@ -25,16 +25,19 @@ int guarded(mugd_ctx* ctx, F&& f) {
     }
 }
 
+// call-scoped scratch from the context's pool (ctx.h); every entry point synchronises its stream before returning, so the
+// blocks are idle when the destructor hands them back
 struct Scratch {
+    TrainPool& pool;
     std::vector<void*> bufs;
+    explicit Scratch(mugd_ctx* ctx) : pool(ctx->pool) {}
     float* get(size_t nfloats, bool zero, hipStream_t st) {
-        float* p = nullptr;
-        HIP_CHECK(hipMalloc((void**)&p, nfloats * sizeof(float) + 8192));
+        float* p = (float*)pool.take(nfloats * sizeof(float) + 8192);
         if (zero) HIP_CHECK(hipMemsetAsync(p, 0, nfloats * sizeof(float) + 8192, st));
         bufs.push_back(p);
         return p;
     }
-    ~Scratch() { for (void* p : bufs) hipFree(p); }
+    ~Scratch() { for (void* p : bufs) pool.give(p); }
 };
 
 // y = conv1d(x; w) (+ bias) (+ rowadd[b][m]) (+ resid): w is a plain (M, C, taps) tensor, packed here
@@ -100,7 +103,7 @@ void resblock_impl(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x,
     MUGD_CHECK(!emb || (p->emb_w && p->emb_b), MUGD_ERR_INVALID, "time embedding given without emb_layers");
     Ctx& c = ctx->c;
     hipStream_t st = c.stream;
-    Scratch sc;
+    Scratch sc(ctx);
     const size_t nin = (size_t)B * Cin * T, nout = (size_t)B * Cout * T;
     // ---- forward, training form
     float* a1 = sc.get(nin, false, st);
@@ -164,7 +167,7 @@ int mugd_train_conv(mugd_ctx* ctx, const float* w, const float* bias, const floa
         MUGD_CHECK(!gn_w || (gn_b && (!dy || (dgn_w && dgn_b)) && groups > 0 && Cin % groups == 0), MUGD_ERR_INVALID, "bad GroupNorm arguments");
         Ctx& c = ctx->c;
         hipStream_t st = c.stream;
-        Scratch sc;
+        Scratch sc(ctx);
         const int stride = mode == 1 ? 2 : 1, ups = mode == 2 ? 1 : 0;
         const int pad = mode == 1 ? 0 : dil * (taps - 1) / 2;
         const int Tout = mode == 1 ? Tin / 2 : (mode == 2 ? 2 * Tin : Tin);
@@ -215,7 +218,7 @@ int mugd_train_s4layer(mugd_ctx* ctx, const float* const* P, const float* x, con
         Ctx& c = ctx->c;
         MUGD_CHECK(!c.s4_symmetric, MUGD_ERR_INVALID, "S4 training gradients exist for the cauchy_naive kernel form only");
         hipStream_t st = c.stream;
-        Scratch sc;
+        Scratch sc(ctx);
         const size_t n = (size_t)B * H * T;
         auto buf = [&](size_t k) { return sc.get(k, false, st); };
         Lin lt{c, sc, B, T};
@@ -259,7 +262,7 @@ int mugd_train_transformer(mugd_ctx* ctx, const float* const* P, const float* x,
         MUGD_CHECK(Cc % CONV_CK == 0 && Tk > 0, MUGD_ERR_INVALID, "context channels must be a multiple of 16");
         Ctx& c = ctx->c;
         hipStream_t st = c.stream;
-        Scratch sc;
+        Scratch sc(ctx);
         const int d = C / heads, Ch = 4 * C;
         const float scale = 1.0f / sqrtf((float)d);
         const size_t n = (size_t)B * C * T, nk = (size_t)B * C * Tk;
@@ -389,7 +392,7 @@ int mugd_train_time_embed(mugd_ctx* ctx, const float* w1, const float* b1, const
         MUGD_CHECK(w1 && b1 && w2 && b2 && temb && emb && B > 0, MUGD_ERR_INVALID, "null/empty argument");
         Ctx& c = ctx->c;
         hipStream_t st = c.stream;
-        Scratch sc;
+        Scratch sc(ctx);
         float* e1 = sc.get((size_t)B * M, false, st);
         launch_linear_small(st, LinSmallArgs{temb, w1, b1, e1, B, K, M, 0, 0, K, M});
         launch_linear_small(st, LinSmallArgs{e1, w2, b2, emb, B, M, M, 1, 0, M, M});

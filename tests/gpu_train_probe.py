@@ -1,0 +1,51 @@
+"""GPU probe (development tool, run through gpurun): one whole-model training step (mug.train.training_step) of the SHIPPED
+architecture on synthetic data -- loss, gradient sanity, wall time.  python tests/gpu_train_probe.py [--B 4] [--z 512] [--reps 2]"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "mug-diffusion_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from oracle import cases, weights  # noqa: E402
+from mug import train  # noqa: E402
+from mug._native import get_lib  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=4)
+    ap.add_argument("--z", type=int, default=512)
+    ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--tiny", action="store_true")
+    a = ap.parse_args()
+    case = cases.TINY if a.tiny else cases.FULL
+    lib = get_lib()
+    man = weights.load_manifest(os.path.join(cases.GOLDEN, case["manifest"]))
+    sd = weights.set_s4_lengths(weights.make_state_dict(man, 0), case["unet"], a.z)
+    sd = {k: (v.to(lib.device) if v.dtype == torch.float32 else v) for k, v in sd.items()}
+    rng = np.random.default_rng(0)
+    B, z = a.B, a.z
+    x0 = torch.from_numpy(rng.standard_normal((B, 16, z)).astype(np.float32))
+    noise = torch.from_numpy(rng.standard_normal((B, 16, z)).astype(np.float32))
+    t = torch.from_numpy(rng.integers(0, 1000, B))
+    ids = torch.from_numpy(rng.integers(0, sd["model.cond_stage_model.embedding.weight"].shape[0], (B, case["n_ctx_tok"])))
+    mel = torch.from_numpy(np.abs(rng.standard_normal((B, case["wave"]["n_freq"], z * case["audio_ratio"]))).astype(np.float32))
+    for r in range(a.reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss, grads = train.training_step(lib, sd, case["unet"], case["wave"], x0, noise, t, ids, mel)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        bad = [k for k, g in grads.items() if not torch.isfinite(g).all()]
+        gn = float(sum(float((g.double() ** 2).sum()) for g in grads.values()) ** 0.5)
+        print("step %d: loss %.6f  %d gradient tensors (%d non-finite)  |g| %.4e  %.2f s  (%.1f samples/s)" % (r, float(loss), len(grads), len(bad), gn, dt, B / dt), flush=True)
+
+
+if __name__ == "__main__":
+    main()

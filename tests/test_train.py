@@ -267,6 +267,71 @@ def test_whole_model_training_step_vs_autograd(lib):
     print("worst relative gradient error %.2e at %s over %d tensors" % (worst[0], worst[1], len(trainable)))
 
 
+def _tiny_training_inputs(B, z):
+    from oracle import cases, weights
+    case = cases.TINY
+    man = weights.load_manifest(os.path.join(cases.GOLDEN, case["manifest"]))
+    sd = weights.set_s4_lengths(weights.make_state_dict(man, 3), case["unet"], z)
+    x0, noise = rnd(70, B, 16, z), rnd(71, B, 16, z)
+    t = torch.tensor([17, 803, 402, 999][:B])
+    ids = torch.from_numpy(np.random.default_rng(5).integers(0, sd["model.cond_stage_model.embedding.weight"].shape[0], (B, case["n_ctx_tok"])))
+    mel = rnd(72, B, case["wave"]["n_freq"], z * case["audio_ratio"]).abs()
+    return case, sd, x0, noise, t, ids, mel
+
+
+def _step_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from conftest import emu_lib
+    from mug import train
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lib = emu_lib()
+        case, sd, x0, noise, t, ids, mel = _tiny_training_inputs(2, 32)
+        sl = slice(rank, rank + 1)
+        loss, grads = train.training_step(lib, sd, case["unet"], case["wave"], x0[sl], noise[sl], t[sl], ids[sl], mel[sl])
+        train.allreduce_gradients(grads, average=True)
+        q.put((rank, float(loss), {k: v.cpu().numpy() for k, v in grads.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_whole_model_data_parallel_step_equals_full_batch():
+    """configs[4]'s shape in miniature: 2 ranks, one sample each, whole-model training_step on the emulated build, ONE bucketed
+    all_reduce over all 395 gradient tensors (gloo here, RCCL on the GPU box) = the single-rank full-batch gradients; then one AdamW
+    step on every tensor."""
+    from conftest import emu_lib
+    from mug import train
+    lib = emu_lib()
+    case, sd, x0, noise, t, ids, mel = _tiny_training_inputs(2, 32)
+    loss, want = train.training_step(lib, sd, case["unet"], case["wave"], x0, noise, t, ids, mel)
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_step_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = [q.get(timeout=900) for _ in procs]
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    assert abs(sum(g[1] for g in got) / world - float(loss)) < 1e-5
+    for rank, _, grads in got:
+        assert set(grads) == set(want)
+        for k in want:
+            close(torch.from_numpy(grads[k]), want[k], 2e-5, "rank %d averaged grad of %s" % (rank, k))
+    # optimiser: one AdamW step over every tensor leaves finite, changed parameters
+    params = {k: sd[k].clone().to(lib.device) for k in want}
+    before = {k: v.clone() for k, v in params.items()}
+    train.adamw_step(lib, params, want, {}, 1, lr=1e-3)
+    changed = sum(int(not torch.equal(params[k], before[k])) for k in params)
+    assert all(torch.isfinite(v).all() for v in params.values()) and changed > 0.9 * len(params)
+
+
 # ------------------------------------------------------------------ data parallel: gradient all-reduce over 2 gloo ranks
 def _worker(rank, world, port, q):
     import torch.distributed as dist
