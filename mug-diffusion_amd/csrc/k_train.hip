@@ -64,20 +64,26 @@ __global__ void transpose_flip_kernel(const float* src, float* dst, int M, int C
     }
 }
 
-// out[m] (+)= sum_{b,t} x[b][m][t]   (bias gradients; fp64 accumulation, one wave per row)
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float* x, float* out, int B, int M, int T, int accumulate) {
+// part[b][m] = sum_t x[b][m][t]   (bias gradients, stage 1: one wave per (batch row, channel) row, fp64)
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* x, double* part, int B, int M, int T) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int m = blockIdx.x * 4 + wave;
+    const int m = blockIdx.x * 4 + wave, b = blockIdx.y;
     if (m >= M) return;
     double s = 0.0;
-    for (int b = 0; b < B; ++b) {
-        const float* row = x + ((size_t)b * M + m) * T;
-        for (int t = lane; t < T; t += 64) s += (double)row[t];
-    }
+    const float* row = x + ((size_t)b * M + m) * T;
+    for (int t = lane; t < T; t += 64) s += (double)row[t];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
         s += __hiloint2double(__shfl_xor(__double2hiint(s), o), __shfl_xor(__double2loint(s), o));
-    if (lane == 0) out[m] = (accumulate ? out[m] : 0.f) + (float)s;
+    if (lane == 0) part[(size_t)b * M + m] = s;
+}
+// out[i] (+)= sum_b part[b][i], fixed order (stage 2 of the per-batch-row partial sums: bias / gamma / beta gradients)
+__global__ void batch_reduce_kernel(const double* part, float* out, int B, int n, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int b = 0; b < B; ++b) s += part[(size_t)b * n + i];
+    out[i] = (accumulate ? out[i] : 0.f) + (float)s;
 }
 
 // rows[b][m] = sum_t x[b][m][t]   (gradient of the broadcast time-embedding row)
@@ -93,22 +99,25 @@ __global__ __launch_bounds__(256) void time_sum_kernel(const float* x, float* ro
     if (lane == 0) rows[r] = (float)s;
 }
 
-// Weight gradient of conv1d (taps 1 | 3; any dilation, stride 1 | 2, optional nearest-x2 upsampled input) on the fp32 matrix cores:
+// Weight gradient of conv1d (taps 1 | 3; any dilation <= 8, stride 1 | 2, optional nearest-x2 upsampled input) on the fp32 matrix cores:
 //   dW[m][c][tap] = sum_{b,t} dY[b][m][t] A[b][c][stride t + tap dil - pad]     -- a GEMM whose contraction axis is batch x time
 //   (A read through the x2 upsample when ups: index >> 1; zero outside [0, Tin (x2))).
-// One workgroup = a 32 (m) x 32 (c) tile, all taps (one 32x32 accumulator per tap); its 8 waves split the (b, 32-sample slab)
-// work list, each staging its slab of dY (32 x 32) once and the matching 32 x 32 slab of A once PER TAP (L2-hot re-reads keep
-// the LDS window independent of dilation and stride) in a private LDS window and feeding v_mfma_f32_32x32x2_f32 with
-// A-operand = dY[row r][t + h], B-operand = A[col n][.]; the 8 partial tiles are summed through LDS in fixed order.
-// Grid (M / 32, C / 32): 256 workgroups for the 512 x 512 layers.
-constexpr int WG_RS = 33;                            // LDS row stride (floats)
+// One workgroup = a 32 (m) x 32 (c) tile, all taps (one 32x32 accumulator per tap), one of KS slices of the (b, 32-sample slab)
+// list (split-K: the contraction is 10^4..10^6 long while the tile grid is 16..256 workgroups); its 8 waves take slabs round-robin.
+// A wave stages its slab of dY (32 x 32) and the input window that covers ALL taps (32 x (32 + (taps - 1) dil), stride 1) with
+// row-contiguous, coalesced loads into a private LDS window (odd row strides: conflict-free fragment reads) and feeds
+// v_mfma_f32_32x32x2_f32 with A-operand = dY[row r][t + h], B-operand = window[col n][t + h + tap dil].  Strided / upsampled
+// inputs (6 + 9 layers) restage a 32-sample window per tap instead.  The 8 waves' partial tiles are summed through LDS in fixed
+// order; KS > 1 writes partial tiles that wgrad_reduce_kernel adds in fixed order (deterministic).
+constexpr int WG_YS = 33;                            // LDS row stride of the dY slab (floats)
+constexpr int WG_AS = 49;                            // LDS row stride of the input window: 32 + 2 * 8 samples, odd
 
 __global__ __launch_bounds__(512) void wgrad_mfma_kernel(const float* dY, const float* A, float* dW, int B, int M, int C, int Tout, int Tin, int taps,
-                                                         int pad, int dil, int stride, int ups) {
-    __shared__ float sy[8][32 * WG_RS];
-    __shared__ float sa[8][32 * WG_RS];
-    float (*red)[16 * 64] = reinterpret_cast<float (*)[16 * 64]>(&sy[0][0]);          // the combine reuses the slabs (8 x 1024 <= 16 x 1056 floats)
-    const int m0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+                                                         int pad, int dil, int stride, int ups, int KS) {
+    __shared__ float sy[8][32 * WG_YS];
+    __shared__ float sa[8][32 * WG_AS];
+    float (*red)[16 * 64] = reinterpret_cast<float (*)[16 * 64]>(&sa[0][0]);          // the combine reuses the windows (8 x 1024 <= 8 x 1568 floats)
+    const int m0 = blockIdx.x * 32, c0 = blockIdx.y * 32, ks = blockIdx.z;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, h = lane >> 5, n = lane & 31;
     f32x16 acc[3];
 #pragma unroll
@@ -119,38 +128,58 @@ __global__ __launch_bounds__(512) void wgrad_mfma_kernel(const float* dY, const 
     const int vlen = ups ? 2 * Tin : Tin;
     float* wy = sy[wave];
     float* wa = sa[wave];
-    const int r = lane >> 1, hf = lane & 1;
-    for (int s = wave; s < total; s += 8) {
+    const bool wide = stride == 1 && !ups;               // one window serves all taps
+    const int W = 32 + (taps - 1) * dil;
+    for (int s = ks * 8 + wave; s < total; s += 8 * KS) {
         const int b = s / nslab, t0 = (s - b * nslab) * 32;
-        {
-            const int m = m0 + r;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int tt = hf * 16 + j, t = t0 + tt;
-                wy[r * WG_RS + tt] = (m < M && t < Tout) ? dY[((size_t)b * M + m) * Tout + t] : 0.f;
-            }
-        }
-#pragma unroll
-        for (int tap = 0; tap < 3; ++tap) {
-            if (tap < taps) {
-                const int c = c0 + r;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int tt = hf * 16 + j;
-                    const int u = stride * (t0 + tt) + tap * dil - pad;
-                    const bool ok = c < C && u >= 0 && u < vlen && t0 + tt < Tout;
-                    const int us = ups ? (u >> 1) : u;
-                    wa[r * WG_RS + tt] = ok ? A[((size_t)b * C + c) * Tin + us] : 0.f;
-                }
-                wave_sync();
+        // dY slab: two rows per instruction, 32 consecutive samples each
 #pragma unroll 4
-                for (int k = 0; k < 32; k += 2)
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(wy[n * WG_RS + k + h], wa[n * WG_RS + k + h], acc[tap], 0, 0, 0);
-                wave_sync();
+        for (int i = 0; i < 16; ++i) {
+            const int r = 2 * i + h, m = m0 + r, t = t0 + n;
+            wy[r * WG_YS + n] = (m < M && t < Tout) ? dY[((size_t)b * M + m) * Tout + t] : 0.f;
+        }
+        if (wide) {
+            const int u = t0 - pad + lane;
+            const bool oku = lane < W && u >= 0 && u < Tin;
+#pragma unroll 4
+            for (int r = 0; r < 32; ++r) {
+                const int c = c0 + r;
+                const float v = (oku && c < C) ? A[((size_t)b * C + c) * Tin + u] : 0.f;
+                if (lane < W) wa[r * WG_AS + lane] = v;
+            }
+            wave_sync();
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap)
+                if (tap < taps) {
+                    const int o = tap * dil;
+#pragma unroll 4
+                    for (int k = 0; k < 32; k += 2)
+                        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(wy[n * WG_YS + k + h], wa[n * WG_AS + k + h + o], acc[tap], 0, 0, 0);
+                }
+            wave_sync();
+        } else {
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap) {
+                if (tap < taps) {
+#pragma unroll 4
+                    for (int i = 0; i < 16; ++i) {
+                        const int r = 2 * i + h, c = c0 + r;
+                        const int u = stride * (t0 + n) + tap * dil - pad;
+                        const bool ok = c < C && u >= 0 && u < vlen && t0 + n < Tout;
+                        const int us = ups ? (u >> 1) : u;
+                        wa[r * WG_AS + n] = ok ? A[((size_t)b * C + c) * Tin + us] : 0.f;
+                    }
+                    wave_sync();
+#pragma unroll 4
+                    for (int k = 0; k < 32; k += 2)
+                        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(wy[n * WG_YS + k + h], wa[n * WG_AS + k + h], acc[tap], 0, 0, 0);
+                    wave_sync();
+                }
             }
         }
     }
     // combine the 8 partial tiles, tap by tap (fixed order), and store: accumulator register i of lane (h, n) is row (i & 3) + 8 (i >> 2) + 4 h, column n
+    float* out = dW + (size_t)ks * M * C * taps;
     for (int tap = 0; tap < taps; ++tap) {
         __syncthreads();
 #pragma unroll
@@ -163,8 +192,17 @@ __global__ __launch_bounds__(512) void wgrad_mfma_kernel(const float* dY, const 
 #pragma unroll
             for (int w = 0; w < 8; ++w) v += red[w][i * 64 + lane];
             const int m = m0 + (i & 3) + 8 * (i >> 2) + 4 * h, c = c0 + n;
-            if (m < M && c < C) dW[((size_t)m * C + c) * taps + tap] = v;
+            if (m < M && c < C) out[((size_t)m * C + c) * taps + tap] = v;
         }
+    }
+}
+
+// dW[i] = sum_{k < KS} part[k][i], fixed order
+__global__ void wgrad_reduce_kernel(const float* part, float* dW, long long n, int KS) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int k = 0; k < KS; ++k) v += part[(size_t)k * n + i];
+        dW[i] = v;
     }
 }
 
@@ -203,17 +241,19 @@ __device__ __forceinline__ double wg_sum(double v, double* red) {        // 256-
 }
 
 // Backward of a = silu(GroupNorm(x; gamma, beta)):  given da, returns dx (+= if accumulate) and dgamma / dbeta.
-// One workgroup per group; for every batch row: pass 1 statistics of x, pass 2 the two group means of the normalised-gradient
-// terms, pass 3 dx.  dgamma / dbeta are accumulated over the batch in registers of the owning threads (fp64): deterministic.
+// One workgroup per (group, batch row): pass 1 statistics of x, pass 2 the two group means of the normalised-gradient terms,
+// pass 3 dx.  The row's dgamma / dbeta contributions go to part (B, C, 2) in fp64; batch_reduce_kernel sums them over the batch
+// in fixed order: deterministic.
 template <bool SILU>
 __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float* x, const float* da, const float* gamma, const float* beta, float eps,
-                                                          float* dx, float* dgamma, float* dbeta, int B, int C, int T, int groups, int accumulate) {
+                                                          float* dx, double* part, int B, int C, int T, int groups, int accumulate) {
     __shared__ double red[4];
     __shared__ double cg_g[64], cg_b[64];          // per channel of the group (cg <= 64)
     const int g = blockIdx.x, cg = C / groups, tid = threadIdx.x;
     const long long n = (long long)cg * T;
     if (tid < cg) { cg_g[tid] = 0.0; cg_b[tid] = 0.0; }
-    for (int b = 0; b < B; ++b) {
+    const int b = blockIdx.y;
+    {
         const float* xg = x + ((size_t)b * C + (size_t)g * cg) * T;
         const float* ag = da + ((size_t)b * C + (size_t)g * cg) * T;
         float* dg = dx + ((size_t)b * C + (size_t)g * cg) * T;
@@ -264,7 +304,18 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float* x, const 
         }
     }
     __syncthreads();
-    if (tid < cg) { dgamma[g * cg + tid] = (float)cg_g[tid]; dbeta[g * cg + tid] = (float)cg_b[tid]; }
+    if (tid < cg) {
+        part[2 * ((size_t)b * C + g * cg + tid)] = cg_g[tid];
+        part[2 * ((size_t)b * C + g * cg + tid) + 1] = cg_b[tid];
+    }
+}
+// dgamma[c] = sum_b part[b][c][0] ; dbeta[c] = sum_b part[b][c][1]
+__global__ void gn_param_reduce_kernel(const double* part, float* dgamma, float* dbeta, int B, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < B; ++b) { s1 += part[2 * ((size_t)b * C + c)]; s2 += part[2 * ((size_t)b * C + c) + 1]; }
+    dgamma[c] = (float)s1; dbeta[c] = (float)s2;
 }
 
 // Backward of E = We silu(e) + be  (emb_layers, unet.py:184-190):  dWe[m][k] = sum_b dE[b][m] silu(e[b][k]);  dbe[m] = sum_b dE[b][m];
@@ -341,19 +392,31 @@ void launch_transpose_flip(hipStream_t st, const float* src, float* dst, int M, 
     const long long total = (long long)M * C * taps;
     hipLaunchKernelGGL(transpose_flip_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, st, src, dst, M, C, taps);
 }
-void launch_bias_grad(hipStream_t st, const float* x, float* out, int B, int M, int T, int accumulate) {
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, x, out, B, M, T, accumulate);
+void launch_bias_grad(hipStream_t st, const float* x, float* out, int B, int M, int T, int accumulate, double* partial) {
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(cdiv(M, 4), B), dim3(256), 0, st, x, partial, B, M, T);
+    hipLaunchKernelGGL(batch_reduce_kernel, dim3(cdiv(M, 256)), dim3(256), 0, st, partial, out, B, M, accumulate);
 }
 void launch_time_sum(hipStream_t st, const float* x, float* rows, int BM, int T) {
     hipLaunchKernelGGL(time_sum_kernel, dim3(cdiv(BM, 4)), dim3(256), 0, st, x, rows, BM, T);
 }
-void launch_wgrad(hipStream_t st, const float* dY, const float* A, float* dW, int B, int M, int C, int T, int taps, int pad) {
-    launch_wgrad_ex(st, dY, A, dW, B, M, C, T, T, taps, pad, 1, 1, 0);
+// K-slices for a weight-gradient launch: enough workgroups to fill the chip (~1024), every wave with at least 2 slabs
+int wgrad_splits(int B, int M, int C, int Tout) {
+    const long long tiles = (long long)cdiv(M, 32) * cdiv(C, 32), slabs = (long long)B * cdiv(Tout, 32);
+    long long ks = std::max<long long>(1, 1024 / tiles);
+    ks = std::min(ks, std::max<long long>(1, slabs / 16));
+    return (int)std::min<long long>(ks, 256);
 }
 void launch_wgrad_ex(hipStream_t st, const float* dY, const float* A, float* dW, int B, int M, int C, int Tout, int Tin, int taps, int pad, int dil,
-                     int stride, int ups) {
+                     int stride, int ups, float* partial, int KS) {
     MUGD_CHECK(taps == 1 || taps == 3, -2, "wgrad: taps must be 1 or 3");
-    hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(cdiv(M, 32), cdiv(C, 32)), dim3(512), 0, st, dY, A, dW, B, M, C, Tout, Tin, taps, pad, dil, stride, ups);
+    MUGD_CHECK(dil >= 1 && dil <= 8, -2, "wgrad: dilation 1..8");
+    MUGD_CHECK(KS == 1 || partial, -2, "wgrad: split-K needs a partial buffer");
+    hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(cdiv(M, 32), cdiv(C, 32), KS), dim3(512), 0, st, dY, A, KS > 1 ? partial : dW, B, M, C, Tout, Tin, taps, pad,
+                       dil, stride, ups, KS);
+    if (KS > 1) {
+        const long long n = (long long)M * C * taps;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, st, partial, dW, n, KS);
+    }
 }
 void launch_down_dgrad_weights(hipStream_t st, const float* w, float* ev, float* od, int M, int C) {
     const long long n = (long long)M * C;
@@ -366,15 +429,12 @@ void launch_interleave_parity(hipStream_t st, const float* src, float* dst, long
 void launch_pair_sum(hipStream_t st, const float* src, float* dst, long long n) {
     hipLaunchKernelGGL(pair_sum_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 8192)), dim3(256), 0, st, src, dst, n);
 }
-void launch_gn_silu_bwd(hipStream_t st, const float* x, const float* da, const float* gamma, const float* beta, float eps, float* dx,
-                        float* dgamma, float* dbeta, int B, int C, int T, int groups, int accumulate) {
-    launch_gn_bwd(st, x, da, gamma, beta, eps, dx, dgamma, dbeta, B, C, T, groups, accumulate, 1);
-}
 void launch_gn_bwd(hipStream_t st, const float* x, const float* da, const float* gamma, const float* beta, float eps, float* dx,
-                   float* dgamma, float* dbeta, int B, int C, int T, int groups, int accumulate, int silu) {
+                   float* dgamma, float* dbeta, int B, int C, int T, int groups, int accumulate, int silu, double* partial) {
     MUGD_CHECK(C % groups == 0 && C / groups <= 64, -2, "gn_bwd: at most 64 channels per group");
-    if (silu) hipLaunchKernelGGL(gn_silu_bwd_kernel<true>, dim3(groups), dim3(256), 0, st, x, da, gamma, beta, eps, dx, dgamma, dbeta, B, C, T, groups, accumulate);
-    else hipLaunchKernelGGL(gn_silu_bwd_kernel<false>, dim3(groups), dim3(256), 0, st, x, da, gamma, beta, eps, dx, dgamma, dbeta, B, C, T, groups, accumulate);
+    if (silu) hipLaunchKernelGGL(gn_silu_bwd_kernel<true>, dim3(groups, B), dim3(256), 0, st, x, da, gamma, beta, eps, dx, partial, B, C, T, groups, accumulate);
+    else hipLaunchKernelGGL(gn_silu_bwd_kernel<false>, dim3(groups, B), dim3(256), 0, st, x, da, gamma, beta, eps, dx, partial, B, C, T, groups, accumulate);
+    hipLaunchKernelGGL(gn_param_reduce_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, partial, dgamma, dbeta, B, C);
 }
 void launch_emb_linear_bwd(hipStream_t st, const float* e, const float* We, const float* dE, float* dWe, float* dbe, float* de, int B, int K, int M) {
     const int rb = cdiv(M, 4);

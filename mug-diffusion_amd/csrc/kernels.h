@@ -310,19 +310,18 @@ void launch_q_sample(hipStream_t st, const float* x0, const float* noise, const 
                      float* out, int B, long long n);
 void launch_smooth_l1(hipStream_t st, const float* pred, const float* target, float beta, float add, float* loss, float* grad, int B, long long n);
 void launch_transpose_flip(hipStream_t st, const float* src, float* dst, int M, int C, int taps);
-void launch_bias_grad(hipStream_t st, const float* x, float* out, int B, int M, int T, int accumulate);
+void launch_bias_grad(hipStream_t st, const float* x, float* out, int B, int M, int T, int accumulate, double* partial /* B * M */);
 void launch_time_sum(hipStream_t st, const float* x, float* rows, int BM, int T);
-void launch_wgrad(hipStream_t st, const float* dY, const float* A, float* dW, int B, int M, int C, int T, int taps, int pad);
+// conv weight gradient; KS = wgrad_splits(...) K-slices need a partial buffer of KS * M * C * taps floats (KS == 1: none)
+int wgrad_splits(int B, int M, int C, int Tout);
 void launch_wgrad_ex(hipStream_t st, const float* dY, const float* A, float* dW, int B, int M, int C, int Tout, int Tin, int taps, int pad, int dil,
-                     int stride, int ups);
+                     int stride, int ups, float* partial, int KS);
 void launch_down_dgrad_weights(hipStream_t st, const float* w, float* ev, float* od, int M, int C);
 void launch_interleave_parity(hipStream_t st, const float* src, float* dst, long long rows, int T, int par);
 void launch_pair_sum(hipStream_t st, const float* src, float* dst, long long n);
-void launch_gn_silu_bwd(hipStream_t st, const float* x, const float* da, const float* gamma, const float* beta, float eps, float* dx,
-                        float* dgamma, float* dbeta, int B, int C, int T, int groups, int accumulate);
 // GroupNorm backward with (silu = 1) or without (0) the SiLU that follows it
 void launch_gn_bwd(hipStream_t st, const float* x, const float* da, const float* gamma, const float* beta, float eps, float* dx,
-                   float* dgamma, float* dbeta, int B, int C, int T, int groups, int accumulate, int silu);
+                   float* dgamma, float* dbeta, int B, int C, int T, int groups, int accumulate, int silu, double* partial /* B * C * 2 */);
 // k_train_tf.hip: LayerNorm over channels (stat: (B, T, 2) scratch), GEGLU, relative-position attention
 void launch_ln_bwd(hipStream_t st, const float* x, const float* dy, const float* gamma, float eps, float* dx, float* stat, float* dgamma,
                    float* dbeta, int B, int C, int T, int accumulate);

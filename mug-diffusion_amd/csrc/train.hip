@@ -59,6 +59,24 @@ void run_conv(Ctx& c, Scratch& sc, const float* x, const float* w, const float* 
     launch_conv(st, a);
 }
 
+// weight gradient with split-K partials from the call's scratch
+void run_wgrad(Ctx& c, Scratch& sc, const float* dY, const float* A, float* dW, int B, int M, int C, int Tout, int Tin, int taps, int pad, int dil = 1,
+               int stride = 1, int ups = 0) {
+    const int ks = wgrad_splits(B, M, C, Tout);
+    float* part = ks > 1 ? sc.get((size_t)ks * M * C * taps, false, c.stream) : nullptr;
+    launch_wgrad_ex(c.stream, dY, A, dW, B, M, C, Tout, Tin, taps, pad, dil, stride, ups, part, ks);
+}
+
+void run_bias_grad(Ctx& c, Scratch& sc, const float* x, float* out, int B, int M, int T) {
+    double* part = reinterpret_cast<double*>(sc.get((size_t)B * M * 2, false, c.stream));
+    launch_bias_grad(c.stream, x, out, B, M, T, 0, part);
+}
+void run_gn_bwd(Ctx& c, Scratch& sc, const float* x, const float* da, const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta,
+                int B, int C, int T, int groups, int silu) {
+    double* part = reinterpret_cast<double*>(sc.get((size_t)B * C * 4, false, c.stream));
+    launch_gn_bwd(c.stream, x, da, gamma, beta, 1e-6f, dx, dgamma, dbeta, B, C, T, groups, 0, silu, part);
+}
+
 void run_group_norm_silu(Ctx& c, const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T, int groups) {
     GnArgs a{};
     a.seg[0] = NormSeg{x, C, 0};
@@ -83,8 +101,8 @@ struct Lin {
     }
     // dx (+= if acc) = W^T dy ;  dW = dy x^T ;  db = row sums of dy
     void bwd(const float* x, const float* w, const float* dy, float* dx, bool acc, float* dW, float* db, int K, int M, float* wt) {
-        if (dW) launch_wgrad(c.stream, dy, x, dW, B, M, K, T, 1, 0);
-        if (db) launch_bias_grad(c.stream, dy, db, B, M, T, 0);
+        if (dW) run_wgrad(c, sc, dy, x, dW, B, M, K, T, T, 1, 0);
+        if (db) run_bias_grad(c, sc, dy, db, B, M, T);
         if (dx) {
             launch_transpose_flip(c.stream, w, wt, M, K, 1);
             run_conv(c, sc, dy, wt, nullptr, nullptr, 0, acc ? dx : nullptr, dx, B, M, T, K, 1, 0);
@@ -126,24 +144,24 @@ void resblock_impl(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x,
         float* da1 = sc.get(nin, false, st);
         float* wt = sc.get((size_t)Cout * std::max(Cin, Cout) * 3, false, st);
         // out_layers conv: dW2, db2, da2 = conv3(dy; W2 transposed + flipped)
-        launch_wgrad_ex(st, dy, a2, g->conv2_w, B, Cout, Cout, T, T, 3, d2, d2, 1, 0);
-        launch_bias_grad(st, dy, g->conv2_b, B, Cout, T, 0);
+        run_wgrad(c, sc, dy, a2, g->conv2_w, B, Cout, Cout, T, T, 3, d2, d2);
+        run_bias_grad(c, sc, dy, g->conv2_b, B, Cout, T);
         launch_transpose_flip(st, p->conv2_w, wt, Cout, Cout, 3);
         run_conv(c, sc, dy, wt, nullptr, nullptr, 0, nullptr, da2, B, Cout, T, Cout, 3, d2, d2);
-        launch_gn_silu_bwd(st, h, da2, p->gn2_w, p->gn2_b, 1e-6f, dh, g->gn2_w, g->gn2_b, B, Cout, T, groups, 0);
+        run_gn_bwd(c, sc, h, da2, p->gn2_w, p->gn2_b, dh, g->gn2_w, g->gn2_b, B, Cout, T, groups, 1);
         if (emb) {          // h = conv1 + b1 + E: time-embedding branch
             float* dE = sc.get((size_t)B * Cout, false, st);
             launch_time_sum(st, dh, dE, B * Cout, T);
             launch_emb_linear_bwd(st, emb, p->emb_w, dE, g->emb_w, g->emb_b, demb, B, Kemb, Cout);
         }
-        launch_wgrad_ex(st, dh, a1, g->conv1_w, B, Cout, Cin, T, T, 3, d1, d1, 1, 0);
-        launch_bias_grad(st, dh, g->conv1_b, B, Cout, T, 0);
+        run_wgrad(c, sc, dh, a1, g->conv1_w, B, Cout, Cin, T, T, 3, d1, d1);
+        run_bias_grad(c, sc, dh, g->conv1_b, B, Cout, T);
         launch_transpose_flip(st, p->conv1_w, wt, Cout, Cin, 3);
         run_conv(c, sc, dh, wt, nullptr, nullptr, 0, nullptr, da1, B, Cout, T, Cin, 3, d1, d1);
-        launch_gn_silu_bwd(st, x, da1, p->gn1_w, p->gn1_b, 1e-6f, dx, g->gn1_w, g->gn1_b, B, Cin, T, groups, 0);
+        run_gn_bwd(c, sc, x, da1, p->gn1_w, p->gn1_b, dx, g->gn1_w, g->gn1_b, B, Cin, T, groups, 1);
         if (p->skip_w) {
-            launch_wgrad(st, dy, x, g->skip_w, B, Cout, Cin, T, 1, 0);
-            launch_bias_grad(st, dy, g->skip_b, B, Cout, T, 0);
+            run_wgrad(c, sc, dy, x, g->skip_w, B, Cout, Cin, T, T, 1, 0);
+            run_bias_grad(c, sc, dy, g->skip_b, B, Cout, T);
             launch_transpose_flip(st, p->skip_w, wt, Cout, Cin, 1);
             run_conv(c, sc, dy, wt, nullptr, nullptr, 0, dx, dx, B, Cout, T, Cin, 1, 0);
         } else {
@@ -181,8 +199,8 @@ int mugd_train_conv(mugd_ctx* ctx, const float* w, const float* bias, const floa
         run_conv(c, sc, a, w, bias, nullptr, 0, nullptr, y, B, Cin, Tin, Cout, taps, pad, dil, stride, ups, Tout);
         if (!dy) { HIP_CHECK(hipStreamSynchronize(st)); return; }
         // ---- backward
-        launch_wgrad_ex(st, dy, a, dw, B, Cout, Cin, Tout, Tin, taps, pad, dil, stride, ups);
-        if (db) launch_bias_grad(st, dy, db, B, Cout, Tout, 0);
+        run_wgrad(c, sc, dy, a, dw, B, Cout, Cin, Tout, Tin, taps, pad, dil, stride, ups);
+        if (db) run_bias_grad(c, sc, dy, db, B, Cout, Tout);
         float* da = gn_w ? sc.get(nin, false, st) : dx;
         float* wt = sc.get((size_t)Cout * Cin * 3, true, st);
         if (mode == 0) {
@@ -204,7 +222,7 @@ int mugd_train_conv(mugd_ctx* ctx, const float* w, const float* bias, const floa
             run_conv(c, sc, dy, wt, nullptr, nullptr, 0, nullptr, dxu, B, Cout, Tout, Cin, 3, 1);
             launch_pair_sum(st, dxu, da, (long long)nin);
         }
-        if (gn_w) launch_gn_bwd(st, x, da, gn_w, gn_b, 1e-6f, dx, dgn_w, dgn_b, B, Cin, Tin, groups, 0, 1);
+        if (gn_w) run_gn_bwd(c, sc, x, da, gn_w, gn_b, dx, dgn_w, dgn_b, B, Cin, Tin, groups, 1);
         HIP_CHECK(hipStreamSynchronize(st));
     });
 }
@@ -235,8 +253,8 @@ int mugd_train_s4layer(mugd_ctx* ctx, const float* const* P, const float* x, con
         if (!dy) { HIP_CHECK(hipStreamSynchronize(st)); return; }
         // ---- backward
         float *wt = buf((size_t)2 * H * H * 3), *df = buf(n), *dv = buf(2 * n), *dg = buf(n), *dpre = buf(n), *dn = buf(n), *dk = buf((size_t)H * T);
-        launch_wgrad(st, dy, f, G[MUGD_S4_OUT_LAYER_W], B, H, H, T, 3, 1);
-        launch_bias_grad(st, dy, G[MUGD_S4_OUT_LAYER_B], B, H, T, 0);
+        run_wgrad(c, sc, dy, f, G[MUGD_S4_OUT_LAYER_W], B, H, H, T, T, 3, 1);
+        run_bias_grad(c, sc, dy, G[MUGD_S4_OUT_LAYER_B], B, H, T);
         launch_transpose_flip(st, P[MUGD_S4_OUT_LAYER_W], wt, H, H, 3);
         run_conv(c, sc, dy, wt, nullptr, nullptr, 0, nullptr, df, B, H, T, H, 3, 1);
         launch_glu_bwd(st, v, df, dv, B, H, T);
@@ -246,7 +264,7 @@ int mugd_train_s4layer(mugd_ctx* ctx, const float* const* P, const float* x, con
         S4GenBwdArgs gb{P[MUGD_S4_K_C], P[MUGD_S4_K_B], P[MUGD_S4_K_P], P[MUGD_S4_K_INV_W_REAL], P[MUGD_S4_K_W_IMAG], P[MUGD_S4_K_LOG_DT], H, N, Lint, T, dk,
                         G[MUGD_S4_K_C], G[MUGD_S4_K_B], G[MUGD_S4_K_P], G[MUGD_S4_K_INV_W_REAL], G[MUGD_S4_K_W_IMAG], G[MUGD_S4_K_LOG_DT]};
         launch_s4_kernel_gen_bwd(st, gb);
-        launch_gn_bwd(st, x, dn, P[MUGD_S4_NORM_W], P[MUGD_S4_NORM_B], 1e-6f, dx, G[MUGD_S4_NORM_W], G[MUGD_S4_NORM_B], B, H, T, groups, 0, 0);
+        run_gn_bwd(c, sc, x, dn, P[MUGD_S4_NORM_W], P[MUGD_S4_NORM_B], dx, G[MUGD_S4_NORM_W], G[MUGD_S4_NORM_B], B, H, T, groups, 0);
         launch_bias_sum(st, dx, dy, dx, (int)n);          // + the identity skip
         HIP_CHECK(hipStreamSynchronize(st));
     });
@@ -343,7 +361,7 @@ int mugd_train_transformer(mugd_ctx* ctx, const float* const* P, const float* x,
         launch_ln_bwd(st, h0, dl, P[MUGD_TF_LN1_W], 1e-5f, dh, stat, G[MUGD_TF_LN1_W], G[MUGD_TF_LN1_B], B, C, T, 1);      // dh = d h0
         // proj_in and the GroupNorm in front of it
         lt.bwd(n0, P[MUGD_TF_PROJ_IN_W], dh, da, false, G[MUGD_TF_PROJ_IN_W], G[MUGD_TF_PROJ_IN_B], C, C, wt);
-        launch_gn_bwd(st, x, da, P[MUGD_TF_NORM_W], P[MUGD_TF_NORM_B], 1e-6f, dx, G[MUGD_TF_NORM_W], G[MUGD_TF_NORM_B], B, C, T, groups, 0, 0);
+        run_gn_bwd(c, sc, x, da, P[MUGD_TF_NORM_W], P[MUGD_TF_NORM_B], dx, G[MUGD_TF_NORM_W], G[MUGD_TF_NORM_B], B, C, T, groups, 0);
         launch_bias_sum(st, dx, dy, dx, (int)n);          // + the identity skip
         HIP_CHECK(hipStreamSynchronize(st));
     });
