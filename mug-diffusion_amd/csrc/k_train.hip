@@ -339,9 +339,11 @@ __global__ __launch_bounds__(256) void emb_linear_bwd_kernel(const float* e, con
             dbe[m] = s;
         }
     } else if (de) {
-        const int k = ((int)blockIdx.x - row_blocks) * 256 + threadIdx.x;
+        const int kblocks = (K + 255) / 256, idx = (int)blockIdx.x - row_blocks;
+        const int k = (idx % kblocks) * 256 + threadIdx.x;
         if (k >= K) return;
-        for (int b = 0; b < B; ++b) {
+        {
+            const int b = idx / kblocks;
             float s = 0.f;
             for (int m = 0; m < M; ++m) s += We[(size_t)m * K + k] * dE[(size_t)b * M + m];
             const float v = e[(size_t)b * K + k];
@@ -438,12 +440,12 @@ void launch_gn_bwd(hipStream_t st, const float* x, const float* da, const float*
 }
 void launch_emb_linear_bwd(hipStream_t st, const float* e, const float* We, const float* dE, float* dWe, float* dbe, float* de, int B, int K, int M) {
     const int rb = cdiv(M, 4);
-    hipLaunchKernelGGL(emb_linear_bwd_kernel<true>, dim3(rb + cdiv(K, 256)), dim3(256), 0, st, e, We, dE, dWe, dbe, de, B, K, M, rb);
+    hipLaunchKernelGGL(emb_linear_bwd_kernel<true>, dim3(rb + cdiv(K, 256) * B), dim3(256), 0, st, e, We, dE, dWe, dbe, de, B, K, M, rb);
 }
 // the same for a plain Linear (no activation in front): dWe = dE^T e, dbe, de (nullable) = dE We
 void launch_emb_linear_bwd_plain(hipStream_t st, const float* e, const float* We, const float* dE, float* dWe, float* dbe, float* de, int B, int K, int M) {
     const int rb = cdiv(M, 4);
-    hipLaunchKernelGGL(emb_linear_bwd_kernel<false>, dim3(rb + cdiv(K, 256)), dim3(256), 0, st, e, We, dE, dWe, dbe, de, B, K, M, rb);
+    hipLaunchKernelGGL(emb_linear_bwd_kernel<false>, dim3(rb + cdiv(K, 256) * B), dim3(256), 0, st, e, We, dE, dWe, dbe, de, B, K, M, rb);
 }
 void launch_embedding_bwd(hipStream_t st, const long long* ids, const float* dctx, float* dtable, int B, int ntok, int dim, int rows) {
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3(rows), dim3(128), 0, st, ids, dctx, dtable, B, ntok, dim);

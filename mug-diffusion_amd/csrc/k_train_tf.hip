@@ -179,58 +179,78 @@ __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(const AttnBwdArgs a)
     }
 }
 
-// column kernel: one lane per key j.  dk[e][j] = scale sum_i dsim[i][j] q[e][i] ;  dv[e][j] = sum_i A[i][j] do[e][i].  d <= 64.
-__global__ __launch_bounds__(64) void attn_bwd_cols_kernel(const AttnBwdArgs a) {
-    const int j = blockIdx.x * 64 + threadIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int d = a.d, Tq = a.Tq, Tk = a.Tk;
+// column kernel: one lane per key j, the 4 waves of a workgroup split the head dimension (d % 4 == 0, d <= 64).
+// dk[e][j] = scale sum_i dsim[i][j] q[e][i] ;  dv[e][j] = sum_i A[i][j] do[e][i].
+__global__ __launch_bounds__(256) void attn_bwd_cols_kernel(const AttnBwdArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 64 + lane, h = blockIdx.y, b = blockIdx.z;
+    const int d = a.d, Tq = a.Tq, Tk = a.Tk, dq = d >> 2, e0 = wave * dq;
     const bool ok = j < Tk;
     const int jc = ok ? j : Tk - 1;
-    const float* q = a.q + (size_t)b * a.q_bstride + (size_t)h * d * Tq;
-    const float* dO = a.dout + (size_t)b * a.o_bstride + (size_t)h * d * Tq;
+    const float* q = a.q + (size_t)b * a.q_bstride + ((size_t)h * d + e0) * Tq;
+    const float* dO = a.dout + (size_t)b * a.o_bstride + ((size_t)h * d + e0) * Tq;
     const size_t m0 = ((size_t)b * a.heads + h) * Tq * Tk;
-    float dk[64], dv[64];
+    float dk[16], dv[16];
 #pragma unroll
-    for (int e = 0; e < 64; ++e) { dk[e] = 0.f; dv[e] = 0.f; }
+    for (int e = 0; e < 16; ++e) { dk[e] = 0.f; dv[e] = 0.f; }
     for (int i = 0; i < Tq; ++i) {
         const float ds = a.dsim[m0 + (size_t)i * Tk + jc], aa = a.Amat[m0 + (size_t)i * Tk + jc];
 #pragma unroll
-        for (int e = 0; e < 64; ++e)
-            if (e < d) { dk[e] += ds * q[(size_t)e * Tq + i]; dv[e] += aa * dO[(size_t)e * Tq + i]; }
+        for (int e = 0; e < 16; ++e)
+            if (e < dq) { dk[e] += ds * q[(size_t)e * Tq + i]; dv[e] += aa * dO[(size_t)e * Tq + i]; }
     }
     if (!ok) return;
 #pragma unroll
-    for (int e = 0; e < 64; ++e)
-        if (e < d) {
-            a.dk[(size_t)b * a.k_bstride + ((size_t)h * d + e) * Tk + j] = dk[e] * a.scale;
-            a.dv[(size_t)b * a.v_bstride + ((size_t)h * d + e) * Tk + j] = dv[e];
+    for (int e = 0; e < 16; ++e)
+        if (e < dq) {
+            a.dk[(size_t)b * a.k_bstride + ((size_t)h * d + e0 + e) * Tk + j] = dk[e] * a.scale;
+            a.dv[(size_t)b * a.v_bstride + ((size_t)h * d + e0 + e) * Tk + j] = dv[e];
         }
 }
 
-// table kernel: drel[r][h] = scale sum dsim over the cells with idx == r ;  dcemb[r][h] = sum dA S.  grid (2 pmax + 1, heads), block 256
-__global__ __launch_bounds__(256) void attn_bwd_tables_kernel(const AttnBwdArgs a) {
+// table kernel, stage 1: part[b][r][h] = {scale sum dsim, sum dA S} over the cells of batch row b with idx == r.
+// grid (2 pmax + 1, heads, B), block 256; stage 2 sums over b in fixed order.
+__global__ __launch_bounds__(256) void attn_bwd_tables_kernel(const AttnBwdArgs a, double* part) {
     __shared__ double red[2][4];
-    const int r = blockIdx.x, h = blockIdx.y, off = r - a.pmax;
+    const int r = blockIdx.x, h = blockIdx.y, b = blockIdx.z, off = r - a.pmax;
     const int Tq = a.Tq, Tk = a.Tk;
     double s1 = 0.0, s2 = 0.0;
-    for (int bi = threadIdx.x; bi < a.B * Tq; bi += 256) {
-        const int b = bi / Tq, i = bi - b * Tq;
-        const size_t m0 = (((size_t)b * a.heads + h) * Tq + i) * Tk;
-        int jlo, jhi;                                           // inclusive range of keys with this index
-        if (off == -a.pmax) { jlo = 0; jhi = i - a.pmax; }
-        else if (off == a.pmax) { jlo = i + a.pmax; jhi = Tk - 1; }
-        else { jlo = jhi = i + off; }
-        jlo = jlo < 0 ? 0 : jlo;
-        jhi = jhi > Tk - 1 ? Tk - 1 : jhi;
-        for (int j = jlo; j <= jhi; ++j) { s1 += (double)a.dsim[m0 + j]; s2 += (double)a.dG[m0 + j]; }
+    const bool edge = off == -a.pmax || off == a.pmax;
+    if (!edge) {
+        for (int i = threadIdx.x; i < Tq; i += 256) {
+            const int j = i + off;
+            if (j >= 0 && j < Tk) {
+                const size_t m = (((size_t)b * a.heads + h) * Tq + i) * Tk + j;
+                s1 += (double)a.dsim[m]; s2 += (double)a.dG[m];
+            }
+        }
+    } else {
+        // all keys at or beyond the clamp: one wave per query row, lanes over keys
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (int i = wave; i < Tq; i += 4) {
+            const size_t m0 = (((size_t)b * a.heads + h) * Tq + i) * Tk;
+            int jlo = off < 0 ? 0 : i + a.pmax, jhi = off < 0 ? i - a.pmax : Tk - 1;
+            jlo = jlo < 0 ? 0 : jlo;
+            jhi = jhi > Tk - 1 ? Tk - 1 : jhi;
+            for (int j = jlo + lane; j <= jhi; j += 64) { s1 += (double)a.dsim[m0 + j]; s2 += (double)a.dG[m0 + j]; }
+        }
     }
     s1 = wave_sum_dd(s1);
     s2 = wave_sum_dd(s2);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        a.drel[r * a.heads + h] = (float)(((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) * (double)a.scale);
-        a.dcemb[r * a.heads + h] = (float)((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+        const size_t o = 2 * (((size_t)b * (2 * a.pmax + 1) + r) * a.heads + h);
+        part[o] = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) * (double)a.scale;
+        part[o + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     }
+}
+__global__ void attn_tables_reduce_kernel(const double* part, float* drel, float* dcemb, int B, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < B; ++b) { s1 += part[2 * ((size_t)b * n + i)]; s2 += part[2 * ((size_t)b * n + i) + 1]; }
+    drel[i] = (float)s1; dcemb[i] = (float)s2;
 }
 
 }  // namespace
@@ -249,8 +269,11 @@ void launch_geglu_bwd(hipStream_t st, const float* u, const float* df, float* du
     hipLaunchKernelGGL(geglu_bwd_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 8192)), dim3(256), 0, st, u, df, du, B, Ch, T);
 }
 void launch_attention_bwd(hipStream_t st, const AttnBwdArgs& a) {
-    MUGD_CHECK(a.d >= 1 && a.d <= 64 && a.Tk >= 1 && a.Tk <= ATB_TK, -2, "attention backward: head dim <= 64, at most 1024 keys");
+    MUGD_CHECK(a.d >= 4 && a.d <= 64 && a.d % 4 == 0 && a.Tk >= 1 && a.Tk <= ATB_TK, -2, "attention backward: head dim 4..64 (multiple of 4), at most 1024 keys");
+    MUGD_CHECK(a.tab_part, -2, "attention backward: no partial buffer for the table gradients");
     hipLaunchKernelGGL(attn_bwd_rows_kernel, dim3(cdiv(a.Tq, 4), a.heads, a.B), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(attn_bwd_cols_kernel, dim3(cdiv(a.Tk, 64), a.heads, a.B), dim3(64), 0, st, a);
-    hipLaunchKernelGGL(attn_bwd_tables_kernel, dim3(2 * a.pmax + 1, a.heads), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(attn_bwd_cols_kernel, dim3(cdiv(a.Tk, 64), a.heads, a.B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(attn_bwd_tables_kernel, dim3(2 * a.pmax + 1, a.heads, a.B), dim3(256), 0, st, a, a.tab_part);
+    const int n = (2 * a.pmax + 1) * a.heads;
+    hipLaunchKernelGGL(attn_tables_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, a.tab_part, a.drel, a.dcemb, a.B, n);
 }

@@ -335,6 +335,7 @@ struct AttnBwdArgs {         // layouts as AttnArgs; dout = gradient of the atte
     float* Amat; float* dsim; float* dG;      // scratch, (B, heads, Tq, Tk) each
     float* dq; float* dk; float* dv;          // same strides as q / k / v
     float* drel; float* dcemb;                // (2 pmax + 1, heads)
+    double* tab_part;                         // scratch, (B, 2 pmax + 1, heads, 2)
 };
 void launch_attention_bwd(hipStream_t st, const AttnBwdArgs& a);
 // k_train_s4.hip: S4 layer backward pieces

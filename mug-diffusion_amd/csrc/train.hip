@@ -326,11 +326,12 @@ int mugd_train_transformer(mugd_ctx* ctx, const float* const* P, const float* x,
         float *df = buf((size_t)B * Ch * T), *du = buf(2 * (size_t)B * Ch * T);
         const size_t nm = (size_t)B * heads * T * std::max(T, Tk);
         float *Am = buf(nm), *dsm = buf(nm), *dGm = buf(nm);
+        double* tabp = reinterpret_cast<double*>(buf((size_t)B * (2 * pmax + 1) * heads * 4));
         auto attn_bwd = [&](const float* q, const float* k, const float* v, const float* dO, int tk, int rel_i, int cemb_i) {
             AttnBwdArgs a{};
             a.q = q; a.q_bstride = C * T; a.k = k; a.k_bstride = C * tk; a.v = v; a.v_bstride = C * tk; a.dout = dO; a.o_bstride = C * T;
             a.rel = P[rel_i]; a.cemb = P[cemb_i]; a.B = B; a.heads = heads; a.d = d; a.Tq = T; a.Tk = tk; a.pmax = pmax; a.scale = scale;
-            a.Amat = Am; a.dsim = dsm; a.dG = dGm; a.dq = dq; a.dk = dk; a.dv = dv; a.drel = G[rel_i]; a.dcemb = G[cemb_i];
+            a.Amat = Am; a.dsim = dsm; a.dG = dGm; a.dq = dq; a.dk = dk; a.dv = dv; a.drel = G[rel_i]; a.dcemb = G[cemb_i]; a.tab_part = tabp;
             launch_attention_bwd(st, a);
         };
         // proj_out: y = Wout h3 + b + x
