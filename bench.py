@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--audios-per-rank", type=int, default=1, help="audios per rank and step (each with --batch seeds): 2 with --pack-songs 2 = the throughput mode; "
                                                                     "--gpus 8 --audios-per-rank 2 = BASELINE configs[2] (64 units)")
     ap.add_argument("--pack-songs", type=int, default=1, help="2: two audios of equal length share one batch-2B U-Net launch (mug/job.py)")
+    ap.add_argument("--no-training-step", action="store_true", help="skip the extra training-step measurement (configs[4] shape, every N)")
+    ap.add_argument("--train-batch", type=int, default=32, help="per-GPU batch of the training-step measurement (configs[4]: 256 over 8 GPUs)")
     ap.add_argument("--no-throughput-mode", action="store_true", help="skip the extra 2-songs-per-launch measurement (N = 1 only)")
     ap.add_argument("--weights", choices=["f32", "bf16"], default="f32", help="bf16: the reduced-precision mode (packed conv / linear weights in bfloat16; "
                                                                                 "NOT the reference's arithmetic) as the timed configuration")
@@ -214,6 +216,15 @@ def main():
         elapsed = float(tt.item())
     Bl = B * (a.pack_songs if a.audios_per_rank >= a.pack_songs else 1)      # charts per U-Net launch
 
+    train_info = None
+    if not a.no_training_step and a.weights == "f32" and a.pack_songs == 1 and a.audios_per_rank == 1:
+        try:                                                  # an extra: its failure must not take the headline line with it
+            train_info = training_leg(a, lib, model, dev, world, rank, grouped, sync_all)
+            note("training step done: %.1f samples/s" % train_info["value"])
+        except Exception as e:                                # noqa: BLE001
+            train_info = {"error": repr(e)[:400]}
+            note("training step failed: %r" % e)
+
     out = None
     if rank == 0:
         n_unet_steps = len(sampler.ddim_timesteps)
@@ -315,6 +326,8 @@ def main():
                                              "unet_sample_steps_per_s": Bl * n_unet_steps / (ev[0].elapsed_time(ev[1]) * 1e-3)}
             lib.set_weight_precision(False)
             note("reduced-precision mode done: %.1f charts/s" % (len(units) / dt))
+        if train_info is not None:
+            out["training_step"] = train_info
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a, z, n_unet_steps)
             note("cpu baseline done")
@@ -322,6 +335,55 @@ def main():
     if grouped:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def training_leg(a, lib, model, dev, world, rank, grouped, sync_all):
+    """BASELINE configs[4] shape, fp32: one DDPM training step per rank on `--train-batch` synthetic samples (z = 512 latents,
+    32768-frame log-mel, random prompts and timesteps) = q_sample -> wave encoder -> prompt embedding -> U-Net -> smooth-L1 loss ->
+    backward through all three networks (mug/train.py: native block forward / backward entry points, block-level checkpointing) ->
+    ONE bucketed all-reduce of the 1327 gradient tensors (RCCL when N > 1) -> AdamW on every tensor.  1 warm-up + 2 timed steps,
+    barrier + synchronize on both sides, MAX over ranks.  Reported next to the headline, never as it."""
+    import torch.distributed as dist
+    from mug import train
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    Bt, z = a.train_batch, SHIPPED["z_length"]
+    g = torch.Generator().manual_seed(1234 + rank)
+    x0, noise = torch.randn(Bt, 16, z, generator=g), torch.randn(Bt, 16, z, generator=g)
+    t = torch.randint(0, 1000, (Bt,), generator=g)
+    ids = torch.randint(0, sd["model.cond_stage_model.embedding.weight"].shape[0], (Bt, 21), generator=g)
+    mel = torch.randn(Bt, SHIPPED["n_mels"], SHIPPED["max_audio_frame"], generator=g).abs()
+    x0, noise, t, ids, mel = (v.to(dev) for v in (x0, noise, t, ids, mel))
+    state, params = {}, None
+
+    def step(i):
+        nonlocal params
+        loss, grads = train.training_step(lib, sd, SHIPPED["unet"], SHIPPED["wave"], x0, noise, t, ids, mel)
+        if grouped:
+            train.allreduce_gradients(grads, average=True)
+        if params is None:
+            params = {k: sd[k] for k in grads}             # the model's own tensors: updated in place
+        train.adamw_step(lib, params, grads, state, i, lr=1e-6)
+        return loss, grads
+
+    loss, grads = step(1)
+    sync_all()
+    t0 = time.perf_counter()
+    reps = 2
+    for i in range(reps):
+        loss, grads = step(2 + i)
+    sync_all()
+    dt = (time.perf_counter() - t0) / reps
+    if grouped:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    nparam = sum(v.numel() for v in grads.values())
+    return {"what": "configs[4] shape in fp32: DDPM training step (q_sample, wave encoder, prompt embedding, U-Net, smooth-L1, backward through all "
+                    "three networks, one bucketed gradient all-reduce, AdamW), per-GPU batch %d, z = %d, synthetic data; first version: block-level "
+                    "checkpointing (2 forwards + 1 backward), not tuned" % (Bt, z),
+            "value": Bt * world / dt, "unit": "samples/s", "ms_per_step": dt * 1e3, "global_batch": Bt * world, "dtype": "f32",
+            "loss": float(loss), "gradient_tensors": len(grads), "trainable_parameters": int(nparam),
+            "allreduce": ("RCCL, one flat fp32 bucket of %.0f MB per step" % (nparam * 4 / 1e6)) if world > 1 else "none (1 rank)"}
 
 
 def cpu_baseline(a, z, n_steps):
