@@ -148,14 +148,20 @@ __global__ __launch_bounds__(512) void wgrad_mfma_kernel(const float* dY, const 
                 if (lane < W) wa[r * WG_AS + lane] = v;
             }
             wave_sync();
-#pragma unroll
-            for (int tap = 0; tap < 3; ++tap)
-                if (tap < taps) {
-                    const int o = tap * dil;
+            if (taps == 3) {                           // one dY fragment read feeds the three taps
 #pragma unroll 4
-                    for (int k = 0; k < 32; k += 2)
-                        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(wy[n * WG_YS + k + h], wa[n * WG_AS + k + h + o], acc[tap], 0, 0, 0);
+                for (int k = 0; k < 32; k += 2) {
+                    const float ay = wy[n * WG_YS + k + h];
+                    const float* wr = wa + n * WG_AS + k + h;
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay, wr[0], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay, wr[dil], acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay, wr[2 * dil], acc[2], 0, 0, 0);
                 }
+            } else {
+#pragma unroll 4
+                for (int k = 0; k < 32; k += 2)
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wy[n * WG_YS + k + h], wa[n * WG_AS + k + h], acc[0], 0, 0, 0);
+            }
             wave_sync();
         } else {
 #pragma unroll
