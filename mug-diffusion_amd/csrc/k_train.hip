@@ -130,24 +130,47 @@ __global__ __launch_bounds__(512) void wgrad_mfma_kernel(const float* dY, const 
     float* wa = sa[wave];
     const bool wide = stride == 1 && !ups;               // one window serves all taps
     const int W = 32 + (taps - 1) * dil;
-    for (int s = ks * 8 + wave; s < total; s += 8 * KS) {
+    // Register-staged, software-pipelined slab loop: the NEXT slab's 16 + 32 row loads are issued before the current slab's
+    // MFMAs, so the memory round trip (the whole cost of the first version: 12 dependent round trips per slab) hides behind them.
+    float vy[16], va[32];
+    auto load_y = [&](int s) {
         const int b = s / nslab, t0 = (s - b * nslab) * 32;
-        // dY slab: two rows per instruction, 32 consecutive samples each
-#pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            const int r = 2 * i + h, m = m0 + r, t = t0 + n;
-            wy[r * WG_YS + n] = (m < M && t < Tout) ? dY[((size_t)b * M + m) * Tout + t] : 0.f;
-        }
+        const int t = t0 + n;
+        const bool okt = t < Tout;
+        const float* yp = dY + ((size_t)b * M + m0 + h) * Tout + (okt ? t : 0);          // row 2 i + h: uniform stride 2 Tout from here
+#pragma unroll
+        for (int i = 0; i < 16; ++i) vy[i] = (okt && m0 + 2 * i + h < M) ? yp[(size_t)(2 * i) * Tout] : 0.f;
+    };
+    auto load_a_wide = [&](int s) {
+        const int b = s / nslab, t0 = (s - b * nslab) * 32;
+        const int u = t0 - pad + lane;
+        const bool oku = lane < W && u >= 0 && u < Tin;
+        const int uc = oku ? u : 0;
+        const float* ap = A + ((size_t)b * C + c0) * Tin + uc;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) va[r] = (oku && c0 + r < C) ? ap[(size_t)r * Tin] : 0.f;
+    };
+    auto load_a_tap = [&](int s, int tap) {                 // strided / upsampled input: a 32-sample window per tap, two rows per instruction
+        const int b = s / nslab, t0 = (s - b * nslab) * 32;
+        const int u = stride * (t0 + n) + tap * dil - pad;
+        const bool oku = u >= 0 && u < vlen && t0 + n < Tout;
+        const int us = oku ? (ups ? (u >> 1) : u) : 0;
+        const float* ap = A + ((size_t)b * C + c0 + h) * Tin + us;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) va[i] = (oku && c0 + 2 * i + h < C) ? ap[(size_t)(2 * i) * Tin] : 0.f;
+    };
+    const int s_first = ks * 8 + wave, s_step = 8 * KS;
+    if (s_first < total) { load_y(s_first); if (wide) load_a_wide(s_first); }
+    for (int s = s_first; s < total; s += s_step) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wy[(2 * i + h) * WG_YS + n] = vy[i];
         if (wide) {
-            const int u = t0 - pad + lane;
-            const bool oku = lane < W && u >= 0 && u < Tin;
-#pragma unroll 4
-            for (int r = 0; r < 32; ++r) {
-                const int c = c0 + r;
-                const float v = (oku && c < C) ? A[((size_t)b * C + c) * Tin + u] : 0.f;
-                if (lane < W) wa[r * WG_AS + lane] = v;
+            if (lane < W) {
+#pragma unroll
+                for (int r = 0; r < 32; ++r) wa[r * WG_AS + lane] = va[r];
             }
             wave_sync();
+            if (s + s_step < total) { load_y(s + s_step); load_a_wide(s + s_step); }
             if (taps == 3) {                           // one dY fragment read feeds the three taps
 #pragma unroll 4
                 for (int k = 0; k < 32; k += 2) {
@@ -167,14 +190,9 @@ __global__ __launch_bounds__(512) void wgrad_mfma_kernel(const float* dY, const 
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap) {
                 if (tap < taps) {
-#pragma unroll 4
-                    for (int i = 0; i < 16; ++i) {
-                        const int r = 2 * i + h, c = c0 + r;
-                        const int u = stride * (t0 + n) + tap * dil - pad;
-                        const bool ok = c < C && u >= 0 && u < vlen && t0 + n < Tout;
-                        const int us = ups ? (u >> 1) : u;
-                        wa[r * WG_AS + n] = ok ? A[((size_t)b * C + c) * Tin + us] : 0.f;
-                    }
+                    load_a_tap(s, tap);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) wa[(2 * i + h) * WG_AS + n] = va[i];
                     wave_sync();
 #pragma unroll 4
                     for (int k = 0; k < 32; k += 2)
@@ -182,6 +200,7 @@ __global__ __launch_bounds__(512) void wgrad_mfma_kernel(const float* dY, const 
                     wave_sync();
                 }
             }
+            if (s + s_step < total) load_y(s + s_step);
         }
     }
     // combine the 8 partial tiles, tap by tap (fixed order), and store: accumulator register i of lane (h, n) is row (i & 3) + 8 (i >> 2) + 4 h, column n
