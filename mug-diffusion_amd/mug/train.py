@@ -64,15 +64,75 @@ def _sub(sd, q):
 
 
 class _Grads:
-    """Gradients keyed by full state-dict name; a tensor reached twice accumulates."""
+    """Gradients keyed by full state-dict name; a tensor reached twice accumulates.
 
-    def __init__(self):
+    With `reducer` (a BucketedAllReduce) every tensor is handed over the moment its block's backward has produced it: buckets
+    fill in backward order and their all-reduce runs while the sweep continues (every parameter of this model belongs to exactly
+    one block, so a gradient is final when it first appears)."""
+
+    def __init__(self, reducer=None):
         self.g = {}
+        self.reducer = reducer
 
     def add(self, prefix, grads):
         for k, v in grads.items():
             key = prefix + "." + k if prefix else k
-            self.g[key] = v if key not in self.g else self.g[key] + v
+            if key in self.g:
+                assert self.reducer is None, "gradient of %s produced twice: cannot be reduced early" % key
+                self.g[key] = self.g[key] + v
+            else:
+                self.g[key] = v
+                if self.reducer is not None:
+                    self.reducer.push(v)
+
+
+class BucketedAllReduce:
+    """DDP-style gradient reduction overlapped with the backward sweep: gradients are appended to the open bucket as they are
+    produced; a full bucket (`bucket_bytes`) is flattened and all-reduced asynchronously (RCCL over xGMI under the `nccl` backend:
+    the collective runs on RCCL's own stream next to the backward kernels; `gloo` in the CPU tests); `finish()` flushes the last
+    bucket, waits for all of them and writes the averaged values back into the gradient tensors.  Ranks produce gradients in the
+    same order (same model, same sweep), so bucket boundaries agree without negotiation."""
+
+    def __init__(self, bucket_bytes=64 << 20, average=True, group=None):
+        self.bucket_bytes, self.average, self.group = bucket_bytes, average, group
+        self.open, self.open_bytes, self.inflight = [], 0, []
+        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.n_buckets = 0
+
+    def push(self, t):
+        if not self.on:
+            return
+        self.open.append(t)
+        self.open_bytes += t.numel() * t.element_size()
+        if self.open_bytes >= self.bucket_bytes:
+            self._launch()
+
+    def _launch(self):
+        if not self.open:
+            return
+        dev = self.open[0].device
+        backend_dev = dev if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+        flat = torch.cat([t.reshape(-1).to(backend_dev) for t in self.open])
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.inflight.append((work, flat, self.open))
+        self.open, self.open_bytes = [], 0
+        self.n_buckets += 1
+
+    def finish(self):
+        if not self.on:
+            return
+        self._launch()
+        world = dist.get_world_size(self.group)
+        for work, flat, tensors in self.inflight:
+            work.wait()
+            if self.average:
+                flat /= world
+            off = 0
+            for t in tensors:
+                n = t.numel()
+                t.copy_(flat[off:off + n].reshape(t.shape).to(t.device))
+                off += n
+        self.inflight = []
 
 
 def unet_plan(cfg):
@@ -264,12 +324,13 @@ class WaveStep:
         return dh
 
 
-def training_step(lib, sd, unet_cfg, wave_cfg, x0, noise, t, ids, mel, beta=0.02, add=0.01):
+def training_step(lib, sd, unet_cfg, wave_cfg, x0, noise, t, ids, mel, beta=0.02, add=0.01, reducer=None):
     """One DDPM training step's loss and gradients (diffusion.py:356-414: x_t = q_sample(x0, t, noise); eps = unet(x_t, t,
     cond(ids), *wave(mel)); loss = mean_b(mean smooth_l1(noise, eps; beta) + add)), for every trainable tensor of the U-Net, the
     wave encoder and the prompt-feature embedding table.  sd: the model's state dict (full names, device or host tensors).
-    Returns (loss, {state-dict name: gradient})."""
-    grads = _Grads()
+    reducer: a BucketedAllReduce -- the gradients are then all-reduced bucket by bucket WHILE the backward sweep runs and come
+    back averaged over the ranks.  Returns (loss, {state-dict name: gradient})."""
+    grads = _Grads(reducer)
     xt = lib.train_q_sample(x0, noise, t, sd["sqrt_alphas_cumprod"], sd["sqrt_one_minus_alphas_cumprod"])
     table = lib.f32(sd["model.cond_stage_model.embedding.weight"])
     context = lib.cond_embed(table, ids)
@@ -281,4 +342,6 @@ def training_step(lib, sd, unet_cfg, wave_cfg, x0, noise, t, ids, mel, beta=0.02
     _, dctx, daud = unet.backward(dpred, grads)
     grads.add("", {"model.cond_stage_model.embedding.weight": lib.train_embedding_bwd(ids, dctx, table.shape[0])})
     wave.backward(daud, grads)
+    if reducer is not None:
+        reducer.finish()
     return loss.mean(), grads.g

@@ -290,8 +290,12 @@ def _step_worker(rank, world, port, q):
         lib = emu_lib()
         case, sd, x0, noise, t, ids, mel = _tiny_training_inputs(2, 32)
         sl = slice(rank, rank + 1)
-        loss, grads = train.training_step(lib, sd, case["unet"], case["wave"], x0[sl], noise[sl], t[sl], ids[sl], mel[sl])
-        train.allreduce_gradients(grads, average=True)
+        red = train.BucketedAllReduce(bucket_bytes=64 << 10)         # ... vs small buckets overlapped with the backward sweep
+        loss, grads = train.training_step(lib, sd, case["unet"], case["wave"], x0[sl], noise[sl], t[sl], ids[sl], mel[sl], reducer=red)
+        assert red.n_buckets > 3
+        loss2, grads2 = train.training_step(lib, sd, case["unet"], case["wave"], x0[sl], noise[sl], t[sl], ids[sl], mel[sl])
+        train.allreduce_gradients(grads2, average=True)
+        assert set(grads) == set(grads2) and all(torch.equal(grads[k], grads2[k]) for k in grads), "bucketed / overlapped reduction differs"
         q.put((rank, float(loss), {k: v.cpu().numpy() for k, v in grads.items()}))
     finally:
         dist.destroy_process_group()
