@@ -285,25 +285,28 @@ def main():
         if world == 1 and not a.no_throughput_mode and a.pack_songs == 1 and a.audios_per_rank == 1:
             # throughput mode, reported NEXT TO the batch-4 headline: two songs x B seeds share one batch-2B launch (the DDIM loop is
             # launch-latency bound at batch 4).  Same pipeline through the same job driver, 2 timed passes.
-            units2 = job.make_units(2, B, prompts=prompts, seed0=1000)
-            pcm_in[1] = torch.from_numpy(synth_audio(a.seconds, a.audio_sr, seed=1)).to(dev)
+            for npack, key in ((2, "throughput_mode"), (4, "throughput_mode_4_songs")):
+                units2 = job.make_units(npack, B, prompts=prompts, seed0=1000)
+                for au in range(1, npack):
+                    if au not in pcm_in:
+                        pcm_in[au] = torch.from_numpy(synth_audio(a.seconds, a.audio_sr, seed=au)).to(dev)
 
-            def packed():
-                return job.run_job(model, timed, units2, mel_of, fy, steps=S, scale=a.cfg_scale, eta=0.0, batch=B, pack_songs=2,
-                                   max_audio_frame=SHIPPED["max_audio_frame"], z_length_cfg=z_cfg, gather=False)
-            packed()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            reps = 2
-            for _ in range(reps):
-                g2, st2 = packed()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t1) / reps
-            out["throughput_mode"] = {"what": "2 songs x %d seeds per batch-%d U-Net launch (mug/job.py pack_songs=2), same pipeline" % (B, 2 * B),
-                                      "value": 2 * B / dt, "unit": "charts/s", "ms_per_launch_of_%d_charts" % (2 * B): dt * 1e3,
-                                      "ddim_loop_ms": ev[0].elapsed_time(ev[1]),
-                                      "unet_sample_steps_per_s": 2 * B * n_unet_steps / (ev[0].elapsed_time(ev[1]) * 1e-3), "launches": st2["launches"]}
-            note("throughput mode done: %.1f charts/s" % (2 * B / dt))
+                def packed():
+                    return job.run_job(model, timed, units2, mel_of, fy, steps=S, scale=a.cfg_scale, eta=0.0, batch=B, pack_songs=npack,
+                                       max_audio_frame=SHIPPED["max_audio_frame"], z_length_cfg=z_cfg, gather=False)
+                packed()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                reps = 2
+                for _ in range(reps):
+                    g2, st2 = packed()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t1) / reps
+                out[key] = {"what": "%d songs x %d seeds per batch-%d U-Net launch (mug/job.py pack_songs=%d), same pipeline" % (npack, B, npack * B, npack),
+                            "value": npack * B / dt, "unit": "charts/s", "ms_per_launch_of_%d_charts" % (npack * B): dt * 1e3,
+                            "ddim_loop_ms": ev[0].elapsed_time(ev[1]),
+                            "unet_sample_steps_per_s": npack * B * n_unet_steps / (ev[0].elapsed_time(ev[1]) * 1e-3), "launches": st2["launches"]}
+                note("throughput mode (%d songs per launch) done: %.1f charts/s" % (npack, npack * B / dt))
         if world == 1 and not a.no_reduced_mode and a.weights == "f32" and a.pack_songs == 1 and a.audios_per_rank == 1:
             # reduced-precision mode, reported separately (never the headline: the reference is fp32): bf16 weight storage, fp32 everything
             # else; same pipeline, networks recompiled with re-packed weights
