@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <exception>
 #include <vector>
 
 #include "ctx.h"
@@ -29,15 +30,19 @@ int guarded(mugd_ctx* ctx, F&& f) {
 // blocks are idle when the destructor hands them back
 struct Scratch {
     TrainPool& pool;
+    hipStream_t stream;
     std::vector<void*> bufs;
-    explicit Scratch(mugd_ctx* ctx) : pool(ctx->pool) {}
+    explicit Scratch(mugd_ctx* ctx) : pool(ctx->pool), stream(ctx->c.stream) {}
     float* get(size_t nfloats, bool zero, hipStream_t st) {
         float* p = (float*)pool.take(nfloats * sizeof(float) + 8192);
         if (zero) HIP_CHECK(hipMemsetAsync(p, 0, nfloats * sizeof(float) + 8192, st));
         bufs.push_back(p);
         return p;
     }
-    ~Scratch() { for (void* p : bufs) pool.give(p); }
+    ~Scratch() {
+        if (std::uncaught_exceptions() > 0) hipStreamSynchronize(stream);      // error path: queued kernels may still use the blocks
+        for (void* p : bufs) pool.give(p);
+    }
 };
 
 // y = conv1d(x; w) (+ bias) (+ rowadd[b][m]) (+ resid): w is a plain (M, C, taps) tensor, packed here

@@ -193,6 +193,31 @@ def test_s4layer_forward_backward_vs_autograd(lib, B, H, T, N, Lint, groups):
         close(grads[k], pt[k].grad, 5e-4, "grad of " + k)
 
 
+def test_training_entry_points_reject_bad_arguments(lib):
+    """Error behaviour of the training ABI: bad geometry / missing tensors come back as MugdError (a negative status with a message),
+    never as a crash; the context stays usable."""
+    from mug._native import MugdError
+    p = resblock_params(32, 32, 16)
+    x, emb, dy = rnd(1, 2, 32, 16), rnd(2, 2, 16), rnd(3, 2, 32, 16)
+    with pytest.raises(MugdError):
+        lib.train_resblock(p, x, emb, dy, groups=5)                      # channels not divisible by the group count
+    with pytest.raises((MugdError, KeyError)):
+        lib.train_resblock({k: v for k, v in p.items() if k != "emb_layers.1.weight"}, x, emb, dy, groups=8)
+    with pytest.raises(MugdError):
+        lib.train_conv(rnd(4, 32, 32, 3), None, rnd(5, 2, 32, 15), rnd(6, 2, 32, 7), mode=1)      # Downsample needs an even length
+    sp = s4layer_params(32, 8, 16)
+    with pytest.raises(MugdError):
+        lib.train_s4layer(sp, rnd(7, 1, 32, 32), rnd(8, 1, 32, 32), groups=8)                      # stored kernel length 16 < T = 32
+    lib.set_s4_symmetric(True)
+    try:
+        with pytest.raises(MugdError):
+            lib.train_s4layer(s4layer_params(32, 8, 32), rnd(7, 1, 32, 32), rnd(8, 1, 32, 32), groups=8)   # gradients exist for cauchy_naive only
+    finally:
+        lib.set_s4_symmetric(False)
+    y, dx, demb, g = lib.train_resblock(p, x, emb, dy, groups=8)        # still works
+    assert torch.isfinite(y).all() and torch.isfinite(dx).all()
+
+
 def test_q_sample_and_smooth_l1_loss(lib):
     """diffusion.py:326-354,386: x_t = sqrt(ac_t) x0 + sqrt(1 - ac_t) noise;  loss_b = mean smooth_l1(target, pred, beta=0.02) + 0.01."""
     B, Cc, T = 3, 16, 50
