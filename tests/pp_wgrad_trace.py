@@ -1,3 +1,5 @@
+"""Development tool: per-grid-shape totals of wgrad_mfma_kernel dispatches from a rocprofv3 --kernel-trace CSV
+(python tests/pp_wgrad_trace.py <..._kernel_trace.csv>): which layers the weight-gradient time goes to."""
 import csv, sys, collections
 f = sys.argv[1]
 rows = list(csv.DictReader(open(f)))
