@@ -235,13 +235,17 @@ typedef struct {
 } mugd_resblock_grads;
 /* y = block(x, emb) (B, Cout, T); given dy: dx (B, Cin, T), demb (B, Kemb) and every parameter gradient.  Synchronises.
  * Every mugd_train_* block entry point runs FORWARD ONLY when dy is NULL (dx / gradient pointers are then ignored): a training step
- * keeps the block inputs of its forward sweep and calls the block again with dy in the backward sweep (block-level checkpointing). */
+ * keeps the block inputs of its forward sweep and calls the block again with dy in the backward sweep (block-level checkpointing).
+ * `state` (last argument of the five block entry points, nullable): forward-only call with state != NULL -> the block KEEPS its forward
+ * intermediates and writes an id to *state; backward call with that id (same x / emb / context / parameters) -> the forward is not
+ * recomputed, the intermediates are released and *state is cleared.  mugd_train_release_states drops ids that were never consumed. */
+int mugd_train_release_states(mugd_ctx* ctx);
 int mugd_train_resblock(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x, const float* emb, const float* dy, float* y, float* dx,
-                        float* demb, const mugd_resblock_grads* g, int B, int Cin, int Cout, int T, int Kemb, int groups);
+                        float* demb, const mugd_resblock_grads* g, int B, int Cin, int Cout, int T, int Kemb, int groups, int64_t* state);
 /* mug/model/models.py:142-159 ResnetBlock (wave encoder / VAE: no time embedding, dilated convs with padding = dilation, 1x1
  * nin_shortcut = skip_w / skip_b): the emb_* members of the parameter / gradient blocks are ignored. */
 int mugd_train_resnet_block(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x, const float* dy, float* y, float* dx,
-                            const mugd_resblock_grads* g, int B, int Cin, int Cout, int T, int groups, int dil1, int dil2);
+                            const mugd_resblock_grads* g, int B, int Cin, int Cout, int T, int groups, int dil1, int dil2, int64_t* state);
 /* unet.py:334-339 time_embed: emb (B, M) = W2 silu(W1 temb + b1) + b2 with temb (B, K) the sinusoidal embedding; backward when demb != NULL. */
 int mugd_train_time_embed(mugd_ctx* ctx, const float* w1, const float* b1, const float* w2, const float* b2, const float* temb, const float* demb,
                           float* emb, float* dw1, float* db1, float* dw2, float* db2, int B, int K, int M);
@@ -253,7 +257,8 @@ int mugd_train_embedding_bwd(mugd_ctx* ctx, const int64_t* ids, const float* dco
  * mode 2: Upsample (models.py:66-70: nearest x2, then k = 3 pad 1; Tout = 2 Tin).
  * w (Cout, Cin, taps), bias nullable; x / dx (B, Cin, Tin); y / dy (B, Cout, Tout); dw like w; db nullable.  Synchronises. */
 int mugd_train_conv(mugd_ctx* ctx, const float* w, const float* bias, const float* gn_w, const float* gn_b, const float* x, const float* dy, float* y,
-                    float* dx, float* dw, float* db, float* dgn_w, float* dgn_b, int B, int Cin, int Cout, int Tin, int taps, int dil, int mode, int groups);
+                    float* dx, float* dw, float* db, float* dgn_w, float* dgn_b, int B, int Cin, int Cout, int Tin, int taps, int dil, int mode, int groups,
+                    int64_t* state);
 /* mug/model/attention.py:154-199 ContextualTransformer (depth 1) forward and backward.  params / grads: MUGD_TF_NPARAMS pointers in the
  * order of the enum below, every tensor in the module's own layout (Linear weights (out, in), proj_in / proj_out (C, C, 1), the two
  * attention tables (2 pmax + 1, heads)).  x, dy, y, dx: (B, C, T).  context (B, Cc, Tk) channel-major, or NULL: attn2 is then a second
@@ -266,7 +271,7 @@ enum {
     MUGD_TF_NPARAMS
 };
 int mugd_train_transformer(mugd_ctx* ctx, const float* const* params, const float* x, const float* context, const float* dy, float* y, float* dx,
-                           float* dcontext, float* const* grads, int B, int C, int T, int Cc, int Tk, int heads, int groups, int pmax);
+                           float* dcontext, float* const* grads, int B, int C, int T, int Cc, int Tk, int heads, int groups, int pmax, int64_t* state);
 /* mug/diffusion/unet.py:76-91 S4Layer (GroupNorm -> S4 (s4.py:1471-1541: NPLR kernel, causal long conv + D u, GELU, Conv1d(H -> 2H) + GLU)
  * -> conv3 -> + x) forward and backward, INCLUDING the gradients of the kernel generator's parameters (C, B, P as (H, N, 2) real views,
  * inv_w_real / w_imag (H, N), log_dt (H)).  Lint = the stored kernel.L buffer (>= T; C is the stored, already length-adapted tensor).
@@ -276,7 +281,7 @@ enum {
     MUGD_S4_OUT_LIN_W, MUGD_S4_OUT_LIN_B, MUGD_S4_OUT_LAYER_W, MUGD_S4_OUT_LAYER_B, MUGD_S4_NPARAMS
 };
 int mugd_train_s4layer(mugd_ctx* ctx, const float* const* params, const float* x, const float* dy, float* y, float* dx, float* const* grads,
-                       int B, int H, int T, int N, int Lint, int groups);
+                       int B, int H, int T, int N, int Lint, int groups, int64_t* state);
 /* torch.optim.AdamW step (decoupled weight decay) on a flat parameter block; step counts from 1. */
 int mugd_train_adamw(mugd_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                      float beta2, float eps, float weight_decay, int step);

@@ -29,7 +29,13 @@ struct TrainPool {
     }
 };
 
+#include <unordered_map>
+
 struct mugd_ctx {
     Ctx c;
     TrainPool pool;
+    // forward intermediates a training block kept for its backward call (mugd_train_*'s `state` argument): pool blocks in the
+    // block's allocation order
+    std::unordered_map<long long, std::vector<void*>> saved;
+    long long next_state = 1;
 };

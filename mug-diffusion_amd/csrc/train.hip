@@ -45,6 +45,51 @@ struct Scratch {
     }
 };
 
+// The named forward intermediates of one block call.  Three modes, chosen by the entry point's (dy, state) arguments:
+//   plain   (state == NULL)                 : call-scoped like Scratch
+//   save    (dy == NULL, state != NULL)     : the blocks outlive the call under a fresh id written to *state
+//   replay  (dy != NULL, *state != 0)       : get() hands the saved blocks back in the original order; the caller skips its forward
+//                                             launches; the blocks return to the pool at the end of the call and *state is cleared
+struct Inter {
+    mugd_ctx* ctx;
+    int64_t* state;
+    bool replay = false, save = false;
+    std::vector<void*> bufs;
+    size_t next = 0;
+    Inter(mugd_ctx* ctx_, const float* dy, int64_t* state_) : ctx(ctx_), state(state_) {
+        if (state && dy && *state) {
+            auto it = ctx->saved.find((long long)*state);
+            MUGD_CHECK(it != ctx->saved.end(), MUGD_ERR_INVALID, "unknown or already consumed training state");
+            bufs = std::move(it->second);
+            ctx->saved.erase(it);
+            *state = 0;
+            replay = true;
+        } else if (state && !dy) {
+            save = true;
+        }
+    }
+    float* get(size_t nfloats) {
+        if (replay) {
+            MUGD_CHECK(next < bufs.size(), MUGD_ERR_INTERNAL, "training state does not match the block's allocation order");
+            return (float*)bufs[next++];
+        }
+        float* p = (float*)ctx->pool.take(nfloats * sizeof(float) + 8192);
+        bufs.push_back(p);
+        return p;
+    }
+    void keep() {                      // end of a forward-only call in save mode
+        if (!save) return;
+        const long long id = ctx->next_state++;
+        ctx->saved[id] = std::move(bufs);
+        bufs.clear();
+        *state = id;
+    }
+    ~Inter() {
+        if (std::uncaught_exceptions() > 0) hipStreamSynchronize(ctx->c.stream);
+        for (void* p : bufs) ctx->pool.give(p);
+    }
+};
+
 // y = conv1d(x; w) (+ bias) (+ rowadd[b][m]) (+ resid): w is a plain (M, C, taps) tensor, packed here
 void run_conv(Ctx& c, Scratch& sc, const float* x, const float* w, const float* bias, const float* rowadd, int rowadd_stride,
               const float* resid, float* y, int B, int C, int T, int M, int taps, int pad, int dil = 1, int stride = 1, int ups = 0, int Tout = -1) {
@@ -118,7 +163,7 @@ struct Lin {
 // TimestepResBlock (unet.py:212-239; emb given, dilations 1) and ResnetBlock (models.py:142-159; no emb, dilations d1 / d2, the
 // 1x1 shortcut is the same tensor under another name): forward, and backward when dy is given
 void resblock_impl(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x, const float* emb, const float* dy, float* y, float* dx,
-                   float* demb, const mugd_resblock_grads* g, int B, int Cin, int Cout, int T, int Kemb, int groups, int d1, int d2) {
+                   float* demb, const mugd_resblock_grads* g, int B, int Cin, int Cout, int T, int Kemb, int groups, int d1, int d2, int64_t* state) {
     MUGD_CHECK(p && x && y && B > 0 && T > 0 && d1 >= 1 && d2 >= 1, MUGD_ERR_INVALID, "null/empty argument");
     MUGD_CHECK(!dy || (g && dx), MUGD_ERR_INVALID, "backward needs dx and the gradient block");
     MUGD_CHECK(Cin % groups == 0 && Cout % groups == 0, MUGD_ERR_INVALID, "channels must be divisible by the group count");
@@ -127,22 +172,26 @@ void resblock_impl(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x,
     Ctx& c = ctx->c;
     hipStream_t st = c.stream;
     Scratch sc(ctx);
+    Inter in(ctx, dy, state);
     const size_t nin = (size_t)B * Cin * T, nout = (size_t)B * Cout * T;
     // ---- forward, training form
-    float* a1 = sc.get(nin, false, st);
-    float* E = emb ? sc.get((size_t)B * Cout, false, st) : nullptr;
-    float* h = sc.get(nout, false, st);
-    float* a2 = sc.get(nout, false, st);
-    run_group_norm_silu(c, x, p->gn1_w, p->gn1_b, a1, B, Cin, T, groups);
-    if (emb) launch_linear_small(st, LinSmallArgs{emb, p->emb_w, p->emb_b, E, B, Kemb, Cout, 1, 0, Kemb, Cout});
-    run_conv(c, sc, a1, p->conv1_w, p->conv1_b, E, Cout, nullptr, h, B, Cin, T, Cout, 3, d1, d1);
-    run_group_norm_silu(c, h, p->gn2_w, p->gn2_b, a2, B, Cout, T, groups);
-    if (p->skip_w) {
-        run_conv(c, sc, x, p->skip_w, p->skip_b, nullptr, 0, nullptr, y, B, Cin, T, Cout, 1, 0);
-        run_conv(c, sc, a2, p->conv2_w, p->conv2_b, nullptr, 0, y, y, B, Cout, T, Cout, 3, d2, d2);
-    } else {
-        run_conv(c, sc, a2, p->conv2_w, p->conv2_b, nullptr, 0, x, y, B, Cout, T, Cout, 3, d2, d2);
+    float* a1 = in.get(nin);
+    float* E = emb ? in.get((size_t)B * Cout) : nullptr;
+    float* h = in.get(nout);
+    float* a2 = in.get(nout);
+    if (!in.replay) {
+        run_group_norm_silu(c, x, p->gn1_w, p->gn1_b, a1, B, Cin, T, groups);
+        if (emb) launch_linear_small(st, LinSmallArgs{emb, p->emb_w, p->emb_b, E, B, Kemb, Cout, 1, 0, Kemb, Cout});
+        run_conv(c, sc, a1, p->conv1_w, p->conv1_b, E, Cout, nullptr, h, B, Cin, T, Cout, 3, d1, d1);
+        run_group_norm_silu(c, h, p->gn2_w, p->gn2_b, a2, B, Cout, T, groups);
+        if (p->skip_w) {
+            run_conv(c, sc, x, p->skip_w, p->skip_b, nullptr, 0, nullptr, y, B, Cin, T, Cout, 1, 0);
+            run_conv(c, sc, a2, p->conv2_w, p->conv2_b, nullptr, 0, y, y, B, Cout, T, Cout, 3, d2, d2);
+        } else {
+            run_conv(c, sc, a2, p->conv2_w, p->conv2_b, nullptr, 0, x, y, B, Cout, T, Cout, 3, d2, d2);
+        }
     }
+    if (!dy) { HIP_CHECK(hipStreamSynchronize(st)); in.keep(); return; }
     if (dy) {
         float* da2 = sc.get(nout, false, st);
         float* dh = sc.get(nout, false, st);
@@ -181,7 +230,8 @@ void resblock_impl(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x,
 extern "C" {
 
 int mugd_train_conv(mugd_ctx* ctx, const float* w, const float* bias, const float* gn_w, const float* gn_b, const float* x, const float* dy, float* y,
-                    float* dx, float* dw, float* db, float* dgn_w, float* dgn_b, int B, int Cin, int Cout, int Tin, int taps, int dil, int mode, int groups) {
+                    float* dx, float* dw, float* db, float* dgn_w, float* dgn_b, int B, int Cin, int Cout, int Tin, int taps, int dil, int mode, int groups,
+                    int64_t* state) {
     return guarded(ctx, [&] {
         MUGD_CHECK(w && x && y && B > 0 && Tin > 0 && (!dy || (dx && dw)), MUGD_ERR_INVALID, "null/empty argument");
         MUGD_CHECK((taps == 1 || taps == 3) && dil >= 1 && mode >= 0 && mode <= 2, MUGD_ERR_INVALID, "bad conv geometry");
@@ -195,14 +245,15 @@ int mugd_train_conv(mugd_ctx* ctx, const float* w, const float* bias, const floa
         const int pad = mode == 1 ? 0 : dil * (taps - 1) / 2;
         const int Tout = mode == 1 ? Tin / 2 : (mode == 2 ? 2 * Tin : Tin);
         const size_t nin = (size_t)B * Cin * Tin;
+        Inter in(ctx, dy, state);
         const float* a = x;
         if (gn_w) {
-            float* an = sc.get(nin, false, st);
-            run_group_norm_silu(c, x, gn_w, gn_b, an, B, Cin, Tin, groups);
+            float* an = in.get(nin);
+            if (!in.replay) run_group_norm_silu(c, x, gn_w, gn_b, an, B, Cin, Tin, groups);
             a = an;
         }
-        run_conv(c, sc, a, w, bias, nullptr, 0, nullptr, y, B, Cin, Tin, Cout, taps, pad, dil, stride, ups, Tout);
-        if (!dy) { HIP_CHECK(hipStreamSynchronize(st)); return; }
+        if (!in.replay) run_conv(c, sc, a, w, bias, nullptr, 0, nullptr, y, B, Cin, Tin, Cout, taps, pad, dil, stride, ups, Tout);
+        if (!dy) { HIP_CHECK(hipStreamSynchronize(st)); in.keep(); return; }
         // ---- backward
         run_wgrad(c, sc, dy, a, dw, B, Cout, Cin, Tout, Tin, taps, pad, dil, stride, ups);
         if (db) run_bias_grad(c, sc, dy, db, B, Cout, Tout);
@@ -233,7 +284,7 @@ int mugd_train_conv(mugd_ctx* ctx, const float* w, const float* bias, const floa
 }
 
 int mugd_train_s4layer(mugd_ctx* ctx, const float* const* P, const float* x, const float* dy, float* y, float* dx, float* const* G,
-                       int B, int H, int T, int N, int Lint, int groups) {
+                       int B, int H, int T, int N, int Lint, int groups, int64_t* state) {
     return guarded(ctx, [&] {
         MUGD_CHECK(P && x && y && B > 0 && T > 0 && N > 0 && (!dy || (G && dx)), MUGD_ERR_INVALID, "null/empty argument");
         for (int i = 0; i < MUGD_S4_NPARAMS; ++i) MUGD_CHECK(P[i] && (!dy || G[i]), MUGD_ERR_INVALID, "null parameter / gradient pointer");
@@ -246,16 +297,19 @@ int mugd_train_s4layer(mugd_ctx* ctx, const float* const* P, const float* x, con
         auto buf = [&](size_t k) { return sc.get(k, false, st); };
         Lin lt{c, sc, B, T};
         // ---- forward (unet.py:86-91, s4.py:1471-1541)
-        float *k = buf((size_t)H * T), *kf = buf((size_t)H * (Lint / 2 + 1) * 2);
-        float *nrm = buf(n), *pre = buf(n), *g = buf(n), *v = buf(2 * n), *f = buf(n);
-        S4GenArgs ga{P[MUGD_S4_K_C], P[MUGD_S4_K_B], P[MUGD_S4_K_P], P[MUGD_S4_K_INV_W_REAL], P[MUGD_S4_K_W_IMAG], P[MUGD_S4_K_LOG_DT], H, N, Lint, T, kf, k, 0};
-        launch_s4_kernel_gen(st, ga);
-        run_group_norm_plain(c, x, P[MUGD_S4_NORM_W], P[MUGD_S4_NORM_B], nrm, B, H, T, groups);
-        launch_s4_conv_train_fwd(st, nrm, k, P[MUGD_S4_D], pre, g, B, H, T);
-        lt.fwd(g, P[MUGD_S4_OUT_LIN_W], P[MUGD_S4_OUT_LIN_B], nullptr, v, H, 2 * H);
-        launch_glu_fwd(st, v, f, B, H, T);
-        run_conv(c, sc, f, P[MUGD_S4_OUT_LAYER_W], P[MUGD_S4_OUT_LAYER_B], nullptr, 0, x, y, B, H, T, H, 3, 1);
-        if (!dy) { HIP_CHECK(hipStreamSynchronize(st)); return; }
+        Inter in(ctx, dy, state);
+        float *k = in.get((size_t)H * T), *kf = in.get((size_t)H * (Lint / 2 + 1) * 2);
+        float *nrm = in.get(n), *pre = in.get(n), *g = in.get(n), *v = in.get(2 * n), *f = in.get(n);
+        if (!in.replay) {
+            S4GenArgs ga{P[MUGD_S4_K_C], P[MUGD_S4_K_B], P[MUGD_S4_K_P], P[MUGD_S4_K_INV_W_REAL], P[MUGD_S4_K_W_IMAG], P[MUGD_S4_K_LOG_DT], H, N, Lint, T, kf, k, 0};
+            launch_s4_kernel_gen(st, ga);
+            run_group_norm_plain(c, x, P[MUGD_S4_NORM_W], P[MUGD_S4_NORM_B], nrm, B, H, T, groups);
+            launch_s4_conv_train_fwd(st, nrm, k, P[MUGD_S4_D], pre, g, B, H, T);
+            lt.fwd(g, P[MUGD_S4_OUT_LIN_W], P[MUGD_S4_OUT_LIN_B], nullptr, v, H, 2 * H);
+            launch_glu_fwd(st, v, f, B, H, T);
+            run_conv(c, sc, f, P[MUGD_S4_OUT_LAYER_W], P[MUGD_S4_OUT_LAYER_B], nullptr, 0, x, y, B, H, T, H, 3, 1);
+        }
+        if (!dy) { HIP_CHECK(hipStreamSynchronize(st)); in.keep(); return; }
         // ---- backward
         float *wt = buf((size_t)2 * H * H * 3), *df = buf(n), *dv = buf(2 * n), *dg = buf(n), *dpre = buf(n), *dn = buf(n), *dk = buf((size_t)H * T);
         run_wgrad(c, sc, dy, f, G[MUGD_S4_OUT_LAYER_W], B, H, H, T, T, 3, 1);
@@ -276,7 +330,7 @@ int mugd_train_s4layer(mugd_ctx* ctx, const float* const* P, const float* x, con
 }
 
 int mugd_train_transformer(mugd_ctx* ctx, const float* const* P, const float* x, const float* context, const float* dy, float* y, float* dx,
-                           float* dcontext, float* const* G, int B, int C, int T, int Cc, int Tk, int heads, int groups, int pmax) {
+                           float* dcontext, float* const* G, int B, int C, int T, int Cc, int Tk, int heads, int groups, int pmax, int64_t* state) {
     return guarded(ctx, [&] {
         MUGD_CHECK(P && x && y && B > 0 && T > 0 && heads > 0 && (!dy || (G && dx)), MUGD_ERR_INVALID, "null/empty argument");
         MUGD_CHECK(C % heads == 0 && C / heads <= 64 && C % groups == 0, MUGD_ERR_INVALID, "bad head / group split");
@@ -292,36 +346,39 @@ int mugd_train_transformer(mugd_ctx* ctx, const float* const* P, const float* x,
         auto buf = [&](size_t k) { return sc.get(k, false, st); };
         Lin lt{c, sc, B, T}, lk{c, sc, B, Tk};
         // ---- forward (attention.py:186-199, :148-152), every intermediate kept
-        float *n0 = buf(n), *h0 = buf(n), *l1 = buf(n), *q1 = buf(n), *k1 = buf(n), *v1 = buf(n), *o1 = buf(n), *h1 = buf(n);
-        float *l2 = buf(n), *q2 = buf(n), *k2 = buf(nk), *v2 = buf(nk), *o2 = buf(n), *h2 = buf(n);
-        float *l3 = buf(n), *u = buf(2 * (size_t)B * Ch * T), *f = buf((size_t)B * Ch * T), *h3 = buf(n);
+        Inter in(ctx, dy, state);
+        float *n0 = in.get(n), *h0 = in.get(n), *l1 = in.get(n), *q1 = in.get(n), *k1 = in.get(n), *v1 = in.get(n), *o1 = in.get(n), *h1 = in.get(n);
+        float *l2 = in.get(n), *q2 = in.get(n), *k2 = in.get(nk), *v2 = in.get(nk), *o2 = in.get(n), *h2 = in.get(n);
+        float *l3 = in.get(n), *u = in.get(2 * (size_t)B * Ch * T), *f = in.get((size_t)B * Ch * T), *h3 = in.get(n);
         auto attn = [&](const float* q, const float* k, const float* v, float* o, int tk, const float* rel, const float* cemb) {
             AttnArgs a{};
             a.q = q; a.q_bstride = C * T; a.k = k; a.k_bstride = C * tk; a.v = v; a.v_bstride = C * tk; a.out = o; a.o_bstride = C * T;
             a.rel = rel; a.cemb = cemb; a.B = B; a.heads = heads; a.d = d; a.Tq = T; a.Tk = tk; a.pmax = pmax; a.scale = scale;
             launch_attention(st, a);
         };
-        run_group_norm_plain(c, x, P[MUGD_TF_NORM_W], P[MUGD_TF_NORM_B], n0, B, C, T, groups);
-        lt.fwd(n0, P[MUGD_TF_PROJ_IN_W], P[MUGD_TF_PROJ_IN_B], nullptr, h0, C, C);
-        launch_layer_norm(st, LnArgs{h0, l1, P[MUGD_TF_LN1_W], P[MUGD_TF_LN1_B], B, C, T, 1e-5f});
-        lt.fwd(l1, P[MUGD_TF_A1_Q], nullptr, nullptr, q1, C, C);
-        lt.fwd(l1, P[MUGD_TF_A1_K], nullptr, nullptr, k1, C, C);
-        lt.fwd(l1, P[MUGD_TF_A1_V], nullptr, nullptr, v1, C, C);
-        attn(q1, k1, v1, o1, T, P[MUGD_TF_A1_REL], P[MUGD_TF_A1_CEMB]);
-        lt.fwd(o1, P[MUGD_TF_A1_OUT_W], P[MUGD_TF_A1_OUT_B], h0, h1, C, C);
-        launch_layer_norm(st, LnArgs{h1, l2, P[MUGD_TF_LN2_W], P[MUGD_TF_LN2_B], B, C, T, 1e-5f});
         const float* ctxp = context ? context : l2;
-        lt.fwd(l2, P[MUGD_TF_A2_Q], nullptr, nullptr, q2, C, C);
-        lk.fwd(ctxp, P[MUGD_TF_A2_K], nullptr, nullptr, k2, Cc, C);
-        lk.fwd(ctxp, P[MUGD_TF_A2_V], nullptr, nullptr, v2, Cc, C);
-        attn(q2, k2, v2, o2, Tk, P[MUGD_TF_A2_REL], P[MUGD_TF_A2_CEMB]);
-        lt.fwd(o2, P[MUGD_TF_A2_OUT_W], P[MUGD_TF_A2_OUT_B], h1, h2, C, C);
-        launch_layer_norm(st, LnArgs{h2, l3, P[MUGD_TF_LN3_W], P[MUGD_TF_LN3_B], B, C, T, 1e-5f});
-        lt.fwd(l3, P[MUGD_TF_FF0_W], P[MUGD_TF_FF0_B], nullptr, u, C, 2 * Ch);
-        launch_geglu_fwd(st, u, f, B, Ch, T);
-        lt.fwd(f, P[MUGD_TF_FF2_W], P[MUGD_TF_FF2_B], h2, h3, Ch, C);
-        lt.fwd(h3, P[MUGD_TF_PROJ_OUT_W], P[MUGD_TF_PROJ_OUT_B], x, y, C, C);
-        if (!dy) { HIP_CHECK(hipStreamSynchronize(st)); return; }
+        if (!in.replay) {
+            run_group_norm_plain(c, x, P[MUGD_TF_NORM_W], P[MUGD_TF_NORM_B], n0, B, C, T, groups);
+            lt.fwd(n0, P[MUGD_TF_PROJ_IN_W], P[MUGD_TF_PROJ_IN_B], nullptr, h0, C, C);
+            launch_layer_norm(st, LnArgs{h0, l1, P[MUGD_TF_LN1_W], P[MUGD_TF_LN1_B], B, C, T, 1e-5f});
+            lt.fwd(l1, P[MUGD_TF_A1_Q], nullptr, nullptr, q1, C, C);
+            lt.fwd(l1, P[MUGD_TF_A1_K], nullptr, nullptr, k1, C, C);
+            lt.fwd(l1, P[MUGD_TF_A1_V], nullptr, nullptr, v1, C, C);
+            attn(q1, k1, v1, o1, T, P[MUGD_TF_A1_REL], P[MUGD_TF_A1_CEMB]);
+            lt.fwd(o1, P[MUGD_TF_A1_OUT_W], P[MUGD_TF_A1_OUT_B], h0, h1, C, C);
+            launch_layer_norm(st, LnArgs{h1, l2, P[MUGD_TF_LN2_W], P[MUGD_TF_LN2_B], B, C, T, 1e-5f});
+            lt.fwd(l2, P[MUGD_TF_A2_Q], nullptr, nullptr, q2, C, C);
+            lk.fwd(ctxp, P[MUGD_TF_A2_K], nullptr, nullptr, k2, Cc, C);
+            lk.fwd(ctxp, P[MUGD_TF_A2_V], nullptr, nullptr, v2, Cc, C);
+            attn(q2, k2, v2, o2, Tk, P[MUGD_TF_A2_REL], P[MUGD_TF_A2_CEMB]);
+            lt.fwd(o2, P[MUGD_TF_A2_OUT_W], P[MUGD_TF_A2_OUT_B], h1, h2, C, C);
+            launch_layer_norm(st, LnArgs{h2, l3, P[MUGD_TF_LN3_W], P[MUGD_TF_LN3_B], B, C, T, 1e-5f});
+            lt.fwd(l3, P[MUGD_TF_FF0_W], P[MUGD_TF_FF0_B], nullptr, u, C, 2 * Ch);
+            launch_geglu_fwd(st, u, f, B, Ch, T);
+            lt.fwd(f, P[MUGD_TF_FF2_W], P[MUGD_TF_FF2_B], h2, h3, Ch, C);
+            lt.fwd(h3, P[MUGD_TF_PROJ_OUT_W], P[MUGD_TF_PROJ_OUT_B], x, y, C, C);
+        }
+        if (!dy) { HIP_CHECK(hipStreamSynchronize(st)); in.keep(); return; }
 
         // ---- backward
         const size_t wmax = (size_t)2 * Ch * C;
@@ -397,16 +454,25 @@ int mugd_train_adamw(mugd_ctx* ctx, float* param, const float* grad, float* exp_
 }
 
 int mugd_train_resblock(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x, const float* emb, const float* dy, float* y, float* dx,
-                        float* demb, const mugd_resblock_grads* g, int B, int Cin, int Cout, int T, int Kemb, int groups) {
+                        float* demb, const mugd_resblock_grads* g, int B, int Cin, int Cout, int T, int Kemb, int groups, int64_t* state) {
     return guarded(ctx, [&] {
         MUGD_CHECK(emb && (!dy || demb), MUGD_ERR_INVALID, "null/empty argument");
-        resblock_impl(ctx, p, x, emb, dy, y, dx, demb, g, B, Cin, Cout, T, Kemb, groups, 1, 1);
+        resblock_impl(ctx, p, x, emb, dy, y, dx, demb, g, B, Cin, Cout, T, Kemb, groups, 1, 1, state);
     });
 }
 
 int mugd_train_resnet_block(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x, const float* dy, float* y, float* dx,
-                            const mugd_resblock_grads* g, int B, int Cin, int Cout, int T, int groups, int dil1, int dil2) {
-    return guarded(ctx, [&] { resblock_impl(ctx, p, x, nullptr, dy, y, dx, nullptr, g, B, Cin, Cout, T, 0, groups, dil1, dil2); });
+                            const mugd_resblock_grads* g, int B, int Cin, int Cout, int T, int groups, int dil1, int dil2, int64_t* state) {
+    return guarded(ctx, [&] { resblock_impl(ctx, p, x, nullptr, dy, y, dx, nullptr, g, B, Cin, Cout, T, 0, groups, dil1, dil2, state); });
+}
+
+int mugd_train_release_states(mugd_ctx* ctx) {
+    return guarded(ctx, [&] {
+        HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
+        for (auto& kv : ctx->saved)
+            for (void* p : kv.second) ctx->pool.give(p);
+        ctx->saved.clear();
+    });
 }
 
 // time_embed (unet.py:334-339): emb = W2 silu(W1 temb + b1) + b2; backward when demb is given

@@ -84,15 +84,31 @@ _SIGS = {
     "mugd_op_timestep_embedding": [_p, _p, _p, _i, _i],
     "mugd_train_q_sample": [_p, _p, _p, _p, _p, _p, _p, _i, C.c_int64],
     "mugd_train_smooth_l1": [_p, _p, _p, _f, _f, _p, _p, _i, C.c_int64],
-    "mugd_train_resblock": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i],
-    "mugd_train_conv": [_p] * 13 + [_i] * 8,
-    "mugd_train_resnet_block": [_p] * 7 + [_i] * 7,
+    "mugd_train_resblock": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "mugd_train_release_states": [_p],
+    "mugd_train_conv": [_p] * 13 + [_i] * 8 + [_p],
+    "mugd_train_resnet_block": [_p] * 7 + [_i] * 7 + [_p],
     "mugd_train_time_embed": [_p] * 12 + [_i] * 3,
     "mugd_train_embedding_bwd": [_p] * 4 + [_i] * 4,
-    "mugd_train_s4layer": [_p] * 7 + [_i] * 6,
-    "mugd_train_transformer": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i],
+    "mugd_train_s4layer": [_p] * 7 + [_i] * 6 + [_p],
+    "mugd_train_transformer": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "mugd_train_adamw": [_p, _p, _p, _p, _p, C.c_int64, _f, _f, _f, _f, _f, _i],
 }
+
+
+class TrainState:
+    """Handle of the forward intermediates a training block keeps between its forward-only call and its backward call
+    (include/mugd.h: the `state` argument of the block entry points)."""
+
+    def __init__(self):
+        self.v = C.c_longlong(0)
+
+    def ref(self):
+        return C.cast(C.byref(self.v), C.c_void_p)
+
+
+def _sref(state):
+    return _p(None) if state is None else state.ref()
 
 
 class ResBlockPtrs(C.Structure):            # mugd_resblock_params / mugd_resblock_grads (include/mugd.h): 12 pointers
@@ -439,7 +455,10 @@ class Lib:
                     setattr(G, f, g.data_ptr())
         return P, G, keep, grads
 
-    def train_resblock(self, params, x, emb, dy, groups=32):
+    def train_release_states(self):
+        self.check(self.dll.mugd_train_release_states(self.ctx))
+
+    def train_resblock(self, params, x, emb, dy, groups=32, state=None):
         """TimestepResBlock forward + backward (unet.py:212-239).  params: dict with the module's tensors
         (in_layers.0.weight/bias, in_layers.2.weight/bias, emb_layers.1.weight/bias, out_layers.0.weight/bias,
         out_layers.3.weight/bias, optionally skip_connection.weight/bias).  Returns y, dx, demb, grads (same keys);
@@ -453,10 +472,10 @@ class Lib:
         dx = None if dy is None else torch.empty_like(x)
         demb = None if dy is None else torch.empty_like(emb)
         self.check(self.dll.mugd_train_resblock(self.ctx, C.byref(P), _ptr(x), _ptr(emb), _ptr(dy), _ptr(y), _ptr(dx), _ptr(demb), C.byref(G),
-                                                B, Cin, Cout, T, emb.shape[1], groups))
+                                                B, Cin, Cout, T, emb.shape[1], groups, _sref(state)))
         return y, dx, demb, grads
 
-    def train_resnet_block(self, params, x, dy, groups=32, dilations=(1, 1)):
+    def train_resnet_block(self, params, x, dy, groups=32, dilations=(1, 1), state=None):
         """ResnetBlock forward + backward (mug/model/models.py:142-159: norm1/conv1/norm2/conv2/nin_shortcut, dilated convs)."""
         x = self.f32(x)
         dy = None if dy is None else self.f32(dy)
@@ -466,7 +485,7 @@ class Lib:
         y = self.empty(B, Cout, T)
         dx = None if dy is None else torch.empty_like(x)
         self.check(self.dll.mugd_train_resnet_block(self.ctx, C.byref(P), _ptr(x), _ptr(dy), _ptr(y), _ptr(dx), C.byref(G), B, Cin, Cout, T, groups,
-                                                    int(dilations[0]), int(dilations[1])))
+                                                    int(dilations[0]), int(dilations[1]), _sref(state)))
         return y, dx, grads
 
     def train_time_embed(self, params, temb, demb):
@@ -491,7 +510,7 @@ class Lib:
         self.check(self.dll.mugd_train_embedding_bwd(self.ctx, _ptr(ids), _ptr(dc), _ptr(dt), B, ntok, dim, rows))
         return dt
 
-    def train_conv(self, weight, bias, x, dy, dil=1, mode=0, gn=None, groups=32):
+    def train_conv(self, weight, bias, x, dy, dil=1, mode=0, gn=None, groups=32, state=None):
         """conv1d forward + backward; mode 0 plain (padding = dil (k - 1) / 2), 1 Downsample, 2 Upsample (models.py:55-91);
         gn = (weight, bias): GroupNorm + SiLU in front (the U-Net's out head).  Returns y, dx, dw, db, (dgn_w, dgn_b) or None."""
         w, x = self.f32(weight), self.f32(x)
@@ -509,7 +528,7 @@ class Lib:
             if dy is not None:
                 dgw, dgb = torch.zeros_like(gw), torch.zeros_like(gb)
         self.check(self.dll.mugd_train_conv(self.ctx, _ptr(w), _ptr(b), _ptr(gw), _ptr(gb), _ptr(x), _ptr(dy), _ptr(y), _ptr(dx), _ptr(dw), _ptr(db),
-                                            _ptr(dgw), _ptr(dgb), B, Cin, Cout, Tin, taps, int(dil), int(mode), int(groups)))
+                                            _ptr(dgw), _ptr(dgb), B, Cin, Cout, Tin, taps, int(dil), int(mode), int(groups), _sref(state)))
         return y, dx, dw, db, (None if (gn is None or dy is None) else (dgw, dgb))
 
     # include/mugd.h MUGD_S4_*: the S4Layer's tensors in the C ABI's order, by their state-dict names
@@ -517,7 +536,7 @@ class Lib:
                     "s4_model.kernel.kernel.inv_w_real", "s4_model.kernel.kernel.w_imag", "s4_model.kernel.kernel.log_dt", "s4_model.D",
                     "s4_model.output_linear.0.weight", "s4_model.output_linear.0.bias", "out_layer.weight", "out_layer.bias")
 
-    def train_s4layer(self, params, x, dy, groups=32):
+    def train_s4layer(self, params, x, dy, groups=32, state=None):
         """S4Layer forward + backward (unet.py:76-91, s4.py:1471-1541, kernel gradients included).  params: dict keyed like the module's
         state dict (S4LAYER_KEYS + 's4_model.kernel.kernel.L', the stored internal length).  Returns y, dx, grads."""
         x = self.f32(x)
@@ -538,7 +557,7 @@ class Lib:
         N = params["s4_model.kernel.kernel.inv_w_real"].shape[-1]
         Lint = int(params["s4_model.kernel.kernel.L"])
         y, dx = torch.empty_like(x), (None if dy is None else torch.empty_like(x))
-        self.check(self.dll.mugd_train_s4layer(self.ctx, PA, _ptr(x), _ptr(dy), _ptr(y), _ptr(dx), GA, B, H, T, N, Lint, int(groups)))
+        self.check(self.dll.mugd_train_s4layer(self.ctx, PA, _ptr(x), _ptr(dy), _ptr(y), _ptr(dx), GA, B, H, T, N, Lint, int(groups), _sref(state)))
         return y, dx, grads
 
     # include/mugd.h MUGD_TF_*: the ContextualTransformer's tensors in the C ABI's order, by their state-dict names
@@ -556,7 +575,7 @@ class Lib:
         "transformer_blocks.0.ff.net.0.proj.weight", "transformer_blocks.0.ff.net.0.proj.bias",
         "transformer_blocks.0.ff.net.2.weight", "transformer_blocks.0.ff.net.2.bias", "proj_out.weight", "proj_out.bias")
 
-    def train_transformer(self, params, x, context, dy, heads, groups=32):
+    def train_transformer(self, params, x, context, dy, heads, groups=32, state=None):
         """ContextualTransformer forward + backward (mug/model/attention.py:154-199).  params: dict keyed like the module's state dict
         (TRANSFORMER_KEYS).  x, dy (B, C, T); context (B, Cc, Tk) or None (attn2 = second self-attention).
         Returns y, dx, dcontext (None without context), grads (same keys)."""
@@ -580,7 +599,7 @@ class Lib:
         dctx = None if (ctx is None or dy is None) else torch.empty_like(ctx)
         Cc, Tk = (0, 0) if ctx is None else (ctx.shape[1], ctx.shape[2])
         self.check(self.dll.mugd_train_transformer(self.ctx, PA, _ptr(x), _ptr(ctx), _ptr(dy), _ptr(y), _ptr(dx), _ptr(dctx), GA,
-                                                   B, Cm, T, Cc, Tk, int(heads), int(groups), int(pmax)))
+                                                   B, Cm, T, Cc, Tk, int(heads), int(groups), int(pmax), _sref(state)))
         return y, dx, dctx, grads
 
     def train_adamw(self, param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):

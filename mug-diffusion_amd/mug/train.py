@@ -4,8 +4,9 @@ ContextualTransformer (`Lib.train_resblock`, `Lib.train_transformer`), an AdamW 
 data-parallel step on a block and the gradient all-reduce every rank of a DDP job runs (one flat bucket, averaged).  The backward
 of the S4 and resampling layers -- and with them `DDPM.training_step` (mug/diffusion/diffusion.py:356-414) for the whole U-Net --
 are built from these block entry points by `training_step` below: a forward sweep that keeps every block's INPUT, then a backward
-sweep that calls each block again with its upstream gradient (the block recomputes its own forward: block-level checkpointing,
-2 forwards + 1 backward per step, no whole-network activation storage).  All arithmetic is native; torch does the bookkeeping
+sweep that calls each block again with its upstream gradient.  By default the block keeps its forward intermediates between the
+two calls (a `TrainState`); with recompute=True it recomputes its own forward in the backward call instead (block-level
+checkpointing: 2 forwards + 1 backward per step, no whole-network activation storage).  All arithmetic is native; torch does the bookkeeping
 (channel concatenation / slicing of skip connections, gradient accumulation).  First version: every block call synchronises and
 allocates its scratch -- correct and gradient-checked against autograd, not yet tuned.
 """
@@ -165,22 +166,29 @@ def unet_plan(cfg):
 class UNetStep:
     """Forward sweep / backward sweep of UNetModel.forward (unet.py:511-550) over the native block entry points."""
 
-    def __init__(self, lib, sd, cfg, prefix="model.unet_model", groups=32):
-        self.lib, self.sd, self.cfg, self.p, self.groups = lib, sd, cfg, prefix, groups
+    def __init__(self, lib, sd, cfg, prefix="model.unet_model", groups=32, recompute=False):
+        self.lib, self.sd, self.cfg, self.p, self.groups, self.recompute = lib, sd, cfg, prefix, groups, recompute
+
+    def _st(self):
+        """recompute=False: the block keeps its forward intermediates between the two sweeps (a TrainState); True: block-level
+        checkpointing, the backward call recomputes the block's forward."""
+        from ._native import TrainState
+        return None if self.recompute else TrainState()
 
     def _seq_forward(self, q, layers, h, emb, ctx, tape):
         lib, heads = self.lib, self.cfg["num_heads"]
         for j, kind in enumerate(layers):
             qq = "%s.%d" % (q, j)
-            tape.append((kind, qq, h))
+            st = self._st()
+            tape.append((kind, qq, h, st))
             if kind == "res":
-                h = lib.train_resblock(_sub(self.sd, qq), h, emb, None, groups=self.groups)[0]
+                h = lib.train_resblock(_sub(self.sd, qq), h, emb, None, groups=self.groups, state=st)[0]
             elif kind == "attn":
-                h = lib.train_transformer(_sub(self.sd, qq), h, ctx, None, heads, groups=self.groups)[0]
+                h = lib.train_transformer(_sub(self.sd, qq), h, ctx, None, heads, groups=self.groups, state=st)[0]
             elif kind == "s4":
-                h = lib.train_s4layer(_sub(self.sd, qq), h, None, groups=self.groups)[0]
+                h = lib.train_s4layer(_sub(self.sd, qq), h, None, groups=self.groups, state=st)[0]
             else:
-                h = lib.train_conv(self.sd[qq + ".conv.weight"], self.sd[qq + ".conv.bias"], h, None, mode=2)[0]
+                h = lib.train_conv(self.sd[qq + ".conv.weight"], self.sd[qq + ".conv.bias"], h, None, mode=2, state=st)[0]
         return h
 
     def forward(self, x, t, context, audios):
@@ -200,11 +208,13 @@ class UNetStep:
                 ai += 1
                 continue
             if mod[0] == "conv_in":
-                tape.append(("conv", q + ".0", h, 0))
-                h = lib.train_conv(sd[q + ".0.weight"], sd[q + ".0.bias"], h, None)[0]
+                st = self._st()
+                tape.append(("conv", q + ".0", h, 0, st))
+                h = lib.train_conv(sd[q + ".0.weight"], sd[q + ".0.bias"], h, None, state=st)[0]
             elif mod[0] == "down":
-                tape.append(("conv", q + ".0.conv", h, 1))
-                h = lib.train_conv(sd[q + ".0.conv.weight"], sd[q + ".0.conv.bias"], h, None, mode=1)[0]
+                st = self._st()
+                tape.append(("conv", q + ".0.conv", h, 1, st))
+                h = lib.train_conv(sd[q + ".0.conv.weight"], sd[q + ".0.conv.bias"], h, None, mode=1, state=st)[0]
             else:
                 h = self._seq_forward(q, mod[1], h, self.emb, context, tape)
             tape.append(("push", len(hs)))
@@ -222,9 +232,10 @@ class UNetStep:
             tape.append(("skip_cat", h.shape[1], len(hs) - 1))
             h = torch.cat([h, hs.pop()], dim=1)
             h = self._seq_forward(q, mod[1], h, self.emb, context, tape)
-        tape.append(("out", p + ".out", h))
+        st = self._st()
+        tape.append(("out", p + ".out", h, st))
         y = lib.train_conv(sd[p + ".out.2.weight"], sd[p + ".out.2.bias"], h, None, gn=(sd[p + ".out.0.weight"], sd[p + ".out.0.bias"]),
-                           groups=self.groups)[0]
+                           groups=self.groups, state=st)[0]
         self.tape = tape
         return y
 
@@ -235,24 +246,25 @@ class UNetStep:
         for rec in reversed(self.tape):
             kind = rec[0]
             if kind == "out":
-                _, q, h = rec
-                _, dh, dw, db, dg = lib.train_conv(sd[q + ".2.weight"], sd[q + ".2.bias"], h, dh, gn=(sd[q + ".0.weight"], sd[q + ".0.bias"]), groups=self.groups)
+                _, q, h, st = rec
+                _, dh, dw, db, dg = lib.train_conv(sd[q + ".2.weight"], sd[q + ".2.bias"], h, dh, gn=(sd[q + ".0.weight"], sd[q + ".0.bias"]), groups=self.groups,
+                                                   state=st)
                 grads.add(q, {"2.weight": dw, "2.bias": db, "0.weight": dg[0], "0.bias": dg[1]})
             elif kind == "conv" or kind == "up":
                 q, h, mode = (rec[1], rec[2], rec[3]) if kind == "conv" else (rec[1] + ".conv", rec[2], 2)
-                _, dh, dw, db, _ = lib.train_conv(sd[q + ".weight"], sd[q + ".bias"], h, dh, mode=mode)
+                _, dh, dw, db, _ = lib.train_conv(sd[q + ".weight"], sd[q + ".bias"], h, dh, mode=mode, state=rec[-1])
                 grads.add(q, {"weight": dw, "bias": db})
             elif kind == "res":
-                _, dh, de, g = lib.train_resblock(_sub(sd, rec[1]), rec[2], self.emb, dh, groups=self.groups)
+                _, dh, de, g = lib.train_resblock(_sub(sd, rec[1]), rec[2], self.emb, dh, groups=self.groups, state=rec[3])
                 demb = de if demb is None else demb + de
                 grads.add(rec[1], g)
             elif kind == "attn":
-                _, dh, dc, g = lib.train_transformer(_sub(sd, rec[1]), rec[2], self.context, dh, heads, groups=self.groups)
+                _, dh, dc, g = lib.train_transformer(_sub(sd, rec[1]), rec[2], self.context, dh, heads, groups=self.groups, state=rec[3])
                 if dc is not None:
                     dctx = dc if dctx is None else dctx + dc
                 grads.add(rec[1], g)
             elif kind == "s4":
-                _, dh, g = lib.train_s4layer(_sub(sd, rec[1]), rec[2], dh, groups=self.groups)
+                _, dh, g = lib.train_s4layer(_sub(sd, rec[1]), rec[2], dh, groups=self.groups, state=rec[3])
                 grads.add(rec[1], g)
             elif kind == "skip_cat":
                 skips[rec[2]] = dh[:, rec[1]:].contiguous()
@@ -271,29 +283,37 @@ class UNetStep:
 class WaveStep:
     """MelspectrogramScaleEncoder1D.forward (mug/cond/wave.py:398-464) as a forward / backward sweep."""
 
-    def __init__(self, lib, sd, cfg, prefix="model.wave_model"):
-        self.lib, self.sd, self.cfg, self.p = lib, sd, cfg, prefix
+    def __init__(self, lib, sd, cfg, prefix="model.wave_model", recompute=False):
+        self.lib, self.sd, self.cfg, self.p, self.recompute = lib, sd, cfg, prefix, recompute
+
+    def _st(self):
+        from ._native import TrainState
+        return None if self.recompute else TrainState()
 
     def forward(self, mel):
         lib, sd, cfg, p = self.lib, self.sd, self.cfg, self.p
         g, heads = cfg["num_groups"], cfg["num_heads"]
-        tape, hs, ds = [("conv", p + ".conv_in", lib.f32(mel), 0)], [], 1
-        h = lib.train_conv(sd[p + ".conv_in.weight"], sd[p + ".conv_in.bias"], mel, None)[0]
+        st = self._st()
+        tape, hs, ds = [("conv", p + ".conv_in", lib.f32(mel), 0, st)], [], 1
+        h = lib.train_conv(sd[p + ".conv_in.weight"], sd[p + ".conv_in.bias"], mel, None, state=st)[0]
         for lvl in range(len(cfg["channel_mult"])):
             q = "%s.down.%d" % (p, lvl)
             if lvl != 0:
-                tape.append(("conv", q + ".downsample.conv", h, 1))
-                h = lib.train_conv(sd[q + ".downsample.conv.weight"], sd[q + ".downsample.conv.bias"], h, None, mode=1)[0]
+                st = self._st()
+                tape.append(("conv", q + ".downsample.conv", h, 1, st))
+                h = lib.train_conv(sd[q + ".downsample.conv.weight"], sd[q + ".downsample.conv.bias"], h, None, mode=1, state=st)[0]
                 ds *= 2
             for ib in range(cfg["num_res_blocks"]):
                 dil = (1, 2) if ib % 2 == 0 else (4, 8)
                 qq = "%s.block.%d" % (q, ib)
-                tape.append(("resnet", qq, h, dil))
-                h = lib.train_resnet_block(_sub(sd, qq), h, None, groups=g, dilations=dil)[0]
+                st = self._st()
+                tape.append(("resnet", qq, h, dil, st))
+                h = lib.train_resnet_block(_sub(sd, qq), h, None, groups=g, dilations=dil, state=st)[0]
                 if ds in cfg["attention_resolutions"]:
                     qq = "%s.attn.%d" % (q, ib)
-                    tape.append(("attn", qq, h))
-                    h = lib.train_transformer(_sub(sd, qq), h, None, None, heads, groups=32)[0]
+                    st = self._st()
+                    tape.append(("attn", qq, h, st))
+                    h = lib.train_transformer(_sub(sd, qq), h, None, None, heads, groups=32, state=st)[0]
             tape.append(("emit", lvl))
             hs.append(h)
         self.tape = tape
@@ -313,30 +333,33 @@ class WaveStep:
             elif dh is None:
                 continue                                    # levels above the last one the U-Net reads get no gradient
             elif kind == "conv":
-                _, dh, dw, db, _ = lib.train_conv(sd[rec[1] + ".weight"], sd[rec[1] + ".bias"], rec[2], dh, mode=rec[3])
+                _, dh, dw, db, _ = lib.train_conv(sd[rec[1] + ".weight"], sd[rec[1] + ".bias"], rec[2], dh, mode=rec[3], state=rec[4])
                 grads.add(rec[1], {"weight": dw, "bias": db})
             elif kind == "resnet":
-                _, dh, g = lib.train_resnet_block(_sub(sd, rec[1]), rec[2], dh, groups=cfg["num_groups"], dilations=rec[3])
+                _, dh, g = lib.train_resnet_block(_sub(sd, rec[1]), rec[2], dh, groups=cfg["num_groups"], dilations=rec[3], state=rec[4])
                 grads.add(rec[1], g)
             elif kind == "attn":
-                _, dh, _, g = lib.train_transformer(_sub(sd, rec[1]), rec[2], None, dh, cfg["num_heads"], groups=32)
+                _, dh, _, g = lib.train_transformer(_sub(sd, rec[1]), rec[2], None, dh, cfg["num_heads"], groups=32, state=rec[3])
                 grads.add(rec[1], g)
         return dh
 
 
-def training_step(lib, sd, unet_cfg, wave_cfg, x0, noise, t, ids, mel, beta=0.02, add=0.01, reducer=None):
+def training_step(lib, sd, unet_cfg, wave_cfg, x0, noise, t, ids, mel, beta=0.02, add=0.01, reducer=None, recompute=False):
     """One DDPM training step's loss and gradients (diffusion.py:356-414: x_t = q_sample(x0, t, noise); eps = unet(x_t, t,
     cond(ids), *wave(mel)); loss = mean_b(mean smooth_l1(noise, eps; beta) + add)), for every trainable tensor of the U-Net, the
     wave encoder and the prompt-feature embedding table.  sd: the model's state dict (full names, device or host tensors).
     reducer: a BucketedAllReduce -- the gradients are then all-reduced bucket by bucket WHILE the backward sweep runs and come
-    back averaged over the ranks.  Returns (loss, {state-dict name: gradient})."""
+    back averaged over the ranks.  recompute: False -- every block keeps its forward intermediates for its backward call (one forward
+    + one backward; a few GB at batch 32); True -- block-level activation checkpointing (the backward call recomputes the block's
+    forward: only block inputs are stored).  Both give bit-identical gradients.  Returns (loss, {state-dict name: gradient})."""
+    lib.train_release_states()                       # intermediates of a sweep that was abandoned half-way
     grads = _Grads(reducer)
     xt = lib.train_q_sample(x0, noise, t, sd["sqrt_alphas_cumprod"], sd["sqrt_one_minus_alphas_cumprod"])
     table = lib.f32(sd["model.cond_stage_model.embedding.weight"])
     context = lib.cond_embed(table, ids)
-    wave = WaveStep(lib, sd, wave_cfg)
+    wave = WaveStep(lib, sd, wave_cfg, recompute=recompute)
     audios = wave.forward(mel)
-    unet = UNetStep(lib, sd, unet_cfg)
+    unet = UNetStep(lib, sd, unet_cfg, recompute=recompute)
     pred = unet.forward(xt, t, context, audios)
     loss, dpred = lib.train_smooth_l1(pred, noise, beta=beta, add=add)
     _, dctx, daud = unet.backward(dpred, grads)
@@ -344,4 +367,5 @@ def training_step(lib, sd, unet_cfg, wave_cfg, x0, noise, t, ids, mel, beta=0.02
     wave.backward(daud, grads)
     if reducer is not None:
         reducer.finish()
+    lib.train_release_states()                       # wave-encoder levels the U-Net does not read never run their backward
     return loss.mean(), grads.g

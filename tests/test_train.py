@@ -218,6 +218,28 @@ def test_training_entry_points_reject_bad_arguments(lib):
     assert torch.isfinite(y).all() and torch.isfinite(dx).all()
 
 
+def test_block_state_keeps_forward_intermediates(lib):
+    """The `state` argument of the block entry points (include/mugd.h): forward-only call keeps the intermediates, the backward call
+    with the same handle skips the forward and consumes them (bit-identical to the recomputing call); a consumed handle is rejected."""
+    from mug._native import MugdError, TrainState
+    p = resblock_params(32, 64, 16)
+    x, emb, dy = rnd(1, 2, 32, 24), rnd(2, 2, 16), rnd(3, 2, 64, 24)
+    y0, dx0, de0, g0 = lib.train_resblock(p, x, emb, dy, groups=8)
+    st = TrainState()
+    y1 = lib.train_resblock(p, x, emb, None, groups=8, state=st)[0]
+    assert st.v.value != 0 and torch.equal(y0, y1)
+    _, dx1, de1, g1 = lib.train_resblock(p, x, emb, dy, groups=8, state=st)
+    assert st.v.value == 0 and torch.equal(dx0, dx1) and torch.equal(de0, de1) and all(torch.equal(g0[k], g1[k]) for k in g0)
+    st.v.value = 12345
+    with pytest.raises(MugdError):
+        lib.train_resblock(p, x, emb, dy, groups=8, state=st)
+    st2 = TrainState()
+    lib.train_resblock(p, x, emb, None, groups=8, state=st2)
+    lib.train_release_states()                                  # never-consumed handles are dropped
+    with pytest.raises(MugdError):
+        lib.train_resblock(p, x, emb, dy, groups=8, state=st2)
+
+
 def test_q_sample_and_smooth_l1_loss(lib):
     """diffusion.py:326-354,386: x_t = sqrt(ac_t) x0 + sqrt(1 - ac_t) noise;  loss_b = mean smooth_l1(target, pred, beta=0.02) + 0.01."""
     B, Cc, T = 3, 16, 50
@@ -275,6 +297,9 @@ def test_whole_model_training_step_vs_autograd(lib):
     lt = (F.smooth_l1_loss(noise, pred, beta=0.02, reduction="none") + 0.01).mean(dim=[1, 2]).mean()
     lt.backward()
     loss, grads = train.training_step(lib, sd, case["unet"], case["wave"], x0, noise, t, ids, mel)
+    loss_r, grads_r = train.training_step(lib, sd, case["unet"], case["wave"], x0, noise, t, ids, mel, recompute=True)
+    assert float(loss) == float(loss_r) and set(grads) == set(grads_r) and all(torch.equal(grads[k], grads_r[k]) for k in grads), \
+        "kept-intermediates and recompute (checkpointing) sweeps must give identical gradients"
     lt = lt.detach()
     assert abs(float(loss) - float(lt)) <= 1e-5 * max(1.0, abs(float(lt))), (float(loss), float(lt))
     missing = [k for k in trainable if st[k].grad is not None and k not in grads]
