@@ -343,7 +343,7 @@ def main():
 def training_leg(a, lib, model, dev, world, rank, grouped, sync_all):
     """BASELINE configs[4] shape, fp32: one DDPM training step per rank on `--train-batch` synthetic samples (z = 512 latents,
     32768-frame log-mel, random prompts and timesteps) = q_sample -> wave encoder -> prompt embedding -> U-Net -> smooth-L1 loss ->
-    backward through all three networks (mug/train.py: native block forward / backward entry points, block-level checkpointing) ->
+    backward through all three networks (mug/train.py: native block forward / backward entry points; blocks keep their forward intermediates) ->
     bucketed all-reduce of the 1327 gradient tensors overlapped with the backward sweep (RCCL when N > 1) -> AdamW on every tensor.  1 warm-up + 2 timed steps,
     barrier + synchronize on both sides, MAX over ranks.  Reported next to the headline, never as it."""
     import torch.distributed as dist
@@ -381,8 +381,8 @@ def training_leg(a, lib, model, dev, world, rank, grouped, sync_all):
         dt = float(tt.item())
     nparam = sum(v.numel() for v in grads.values())
     return {"what": "configs[4] shape in fp32: DDPM training step (q_sample, wave encoder, prompt embedding, U-Net, smooth-L1, backward through all "
-                    "three networks, one bucketed gradient all-reduce, AdamW), per-GPU batch %d, z = %d, synthetic data; first version: block-level "
-                    "checkpointing (2 forwards + 1 backward), not tuned" % (Bt, z),
+                    "three networks, bucketed gradient all-reduce overlapped with the backward sweep, AdamW), per-GPU batch %d, z = %d, synthetic data; "
+                    "first version, fp32, not tuned" % (Bt, z),
             "value": Bt * world / dt, "unit": "samples/s", "ms_per_step": dt * 1e3, "global_batch": Bt * world, "dtype": "f32",
             "loss": float(loss), "gradient_tensors": len(grads), "trainable_parameters": int(nparam),
             "allreduce": ("RCCL, %.0f MB of fp32 gradients per step in 64 MB buckets, asynchronous, overlapped with the backward sweep"

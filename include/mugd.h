@@ -286,6 +286,10 @@ int mugd_train_s4layer(mugd_ctx* ctx, const float* const* params, const float* x
 int mugd_train_adamw(mugd_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                      float beta2, float eps, float weight_decay, int step);
 
+/* The same step over a list of n tensors (one launch each, no host round trip per tensor): an optimiser step over a whole model. */
+int mugd_train_adamw_multi(mugd_ctx* ctx, int n, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                           const int64_t* sizes, float lr, float beta1, float beta2, float eps, float weight_decay, int step);
+
 #ifdef __cplusplus
 }
 #endif

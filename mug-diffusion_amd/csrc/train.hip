@@ -453,6 +453,17 @@ int mugd_train_adamw(mugd_ctx* ctx, float* param, const float* grad, float* exp_
     });
 }
 
+int mugd_train_adamw_multi(mugd_ctx* ctx, int n, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                           const int64_t* sizes, float lr, float beta1, float beta2, float eps, float weight_decay, int step) {
+    return guarded(ctx, [&] {
+        MUGD_CHECK(n > 0 && params && grads && exp_avg && exp_avg_sq && sizes && step >= 1, MUGD_ERR_INVALID, "null/empty argument");
+        for (int i = 0; i < n; ++i) {
+            MUGD_CHECK(params[i] && grads[i] && exp_avg[i] && exp_avg_sq[i] && sizes[i] > 0, MUGD_ERR_INVALID, "null tensor in the AdamW list");
+            launch_adamw(ctx->c.stream, params[i], grads[i], exp_avg[i], exp_avg_sq[i], (long long)sizes[i], lr, beta1, beta2, eps, weight_decay, step);
+        }
+    });
+}
+
 int mugd_train_resblock(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x, const float* emb, const float* dy, float* y, float* dx,
                         float* demb, const mugd_resblock_grads* g, int B, int Cin, int Cout, int T, int Kemb, int groups, int64_t* state) {
     return guarded(ctx, [&] {

@@ -86,6 +86,7 @@ _SIGS = {
     "mugd_train_smooth_l1": [_p, _p, _p, _f, _f, _p, _p, _i, C.c_int64],
     "mugd_train_resblock": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "mugd_train_release_states": [_p],
+    "mugd_train_adamw_multi": [_p, _i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _f, _i],
     "mugd_train_conv": [_p] * 13 + [_i] * 8 + [_p],
     "mugd_train_resnet_block": [_p] * 7 + [_i] * 7 + [_p],
     "mugd_train_time_embed": [_p] * 12 + [_i] * 3,
@@ -606,6 +607,14 @@ class Lib:
         """One torch.optim.AdamW step, in place on device tensors."""
         self.check(self.dll.mugd_train_adamw(self.ctx, _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), float(lr),
                                              float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step)))
+
+    def train_adamw_multi(self, params, grads, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+        """One AdamW step over lists of device tensors (in place), a single native call."""
+        n = len(params)
+        arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])          # noqa: E731
+        sizes = (C.c_longlong * n)(*[p.numel() for p in params])
+        self.check(self.dll.mugd_train_adamw_multi(self.ctx, n, arr(params), arr(grads), arr(exp_avg), arr(exp_avg_sq), sizes, float(lr),
+                                                   float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step)))
 
     def op_timestep_embedding(self, t, dim):
         t = t.to(device=self.device, dtype=torch.int64).contiguous()

@@ -47,12 +47,16 @@ def allreduce_gradients(grads, average=True, group=None):
 
 
 def adamw_step(lib, params, grads, state, step, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
-    """torch.optim.AdamW semantics on the block's parameter dict, in place on device tensors; `state` holds exp_avg / exp_avg_sq."""
-    for k, p in params.items():
+    """torch.optim.AdamW semantics on a parameter dict, in place on device tensors; `state` holds exp_avg / exp_avg_sq.  One native
+    call for the whole list."""
+    keys = list(params)
+    for k in keys:
         if k not in state:
-            state[k] = (torch.zeros_like(p), torch.zeros_like(p))
-        m, v = state[k]
-        lib.train_adamw(p, grads[k], m, v, step, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+            state[k] = (torch.zeros_like(params[k]), torch.zeros_like(params[k]))
+        assert params[k].is_contiguous() and params[k].dtype == torch.float32, k
+    gs = [lib.f32(grads[k]) for k in keys]
+    lib.train_adamw_multi([params[k] for k in keys], gs, [state[k][0] for k in keys], [state[k][1] for k in keys], step,
+                          lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
     return params
 
 

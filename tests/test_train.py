@@ -384,6 +384,12 @@ def test_whole_model_data_parallel_step_equals_full_batch():
     train.adamw_step(lib, params, want, {}, 1, lr=1e-3)
     changed = sum(int(not torch.equal(params[k], before[k])) for k in params)
     assert all(torch.isfinite(v).all() for v in params.values()) and changed > 0.9 * len(params)
+    for k in list(params)[::97]:                                  # a sample of tensors against torch.optim.AdamW
+        pt = before[k].cpu().clone().requires_grad_(True)
+        opt = torch.optim.AdamW([pt], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+        pt.grad = want[k].cpu().clone()
+        opt.step()
+        close(params[k], pt, 2e-6, "AdamW step of " + k)
 
 
 # ------------------------------------------------------------------ data parallel: gradient all-reduce over 2 gloo ranks
