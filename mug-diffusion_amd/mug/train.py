@@ -63,9 +63,23 @@ def adamw_step(lib, params, grads, state, step, lr=1e-4, betas=(0.9, 0.999), eps
 # ------------------------------------------------------------------------------------------------------------------------------
 # whole-model training step (mug/diffusion/diffusion.py:356-414 DDPM.p_losses / training_step)
 # ------------------------------------------------------------------------------------------------------------------------------
+_SUB_CACHE = {}
+
+
 def _sub(sd, q):
-    n = len(q) + 1
-    return {k[n:]: v for k, v in sd.items() if k.startswith(q + ".")}
+    """The tensors under module prefix q, keyed relative to it.  Memoised per state dict object (a step asks for every block
+    twice; scanning 1515 names each time was a measurable part of a small-batch step)."""
+    key = id(sd)
+    ent = _SUB_CACHE.get(key)
+    if ent is None or ent[0] is not sd:
+        if len(_SUB_CACHE) > 4:
+            _SUB_CACHE.clear()
+        ent = _SUB_CACHE[key] = (sd, {})
+    hit = ent[1].get(q)
+    if hit is None:
+        n = len(q) + 1
+        hit = ent[1][q] = {k[n:]: v for k, v in sd.items() if k.startswith(q + ".")}
+    return hit
 
 
 class _Grads:
