@@ -68,7 +68,8 @@ _SUB_CACHE = {}
 
 def _sub(sd, q):
     """The tensors under module prefix q, keyed relative to it.  Memoised per state dict object (a step asks for every block
-    twice; scanning 1515 names each time was a measurable part of a small-batch step)."""
+    twice; scanning 1515 names each time was a measurable part of a small-batch step).  Tensors must be updated IN PLACE (as
+    adamw_step does): an entry replaced in the dict afterwards is not seen."""
     key = id(sd)
     ent = _SUB_CACHE.get(key)
     if ent is None or ent[0] is not sd:
