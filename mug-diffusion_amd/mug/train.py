@@ -388,3 +388,101 @@ def training_step(lib, sd, unet_cfg, wave_cfg, x0, noise, t, ids, mel, beta=0.02
         reducer.finish()
     lib.train_release_states()                       # wave-encoder levels the U-Net does not read never run their backward
     return loss.mean(), grads.g
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# a minimal training loop over the step (the reference trains through pytorch_lightning: main.py + DDPM.training_step /
+# configure_optimizers, diffusion.py:416-513; its dataset is not available offline -- SURVEY.md 8f rank 4 -- so: synthetic batches)
+# ------------------------------------------------------------------------------------------------------------------------------
+def synthetic_batch(B, z, unet_cfg, wave_cfg, n_ids, ntok, audio_ratio, seed, device):
+    """One synthetic training batch with the shapes of the real one: x0 (B, z_channels, z) latent, mel (B, n_freq, z * audio_ratio)
+    non-negative log-mel, ids (B, ntok) prompt-feature ids."""
+    g = torch.Generator().manual_seed(seed)
+    x0 = torch.randn(B, unet_cfg["in_channels"], z, generator=g)
+    mel = torch.randn(B, wave_cfg["n_freq"], z * audio_ratio, generator=g).abs()
+    ids = torch.randint(0, n_ids, (B, ntok), generator=g)
+    return x0.to(device), mel.to(device), ids.to(device)
+
+
+def fit(lib, sd, unet_cfg, wave_cfg, steps, batch, z, lr=1e-4, weight_decay=0.01, seed=0, fixed_batch=False, audio_ratio=None, ntok=21,
+        log=None, recompute=False):
+    """`steps` optimiser steps of DDPM training (diffusion.py:404-414: t ~ U{0..T-1}, noise ~ N(0, I), p_losses; AdamW(lr) like
+    configure_optimizers :477-499) on synthetic batches, data parallel when torch.distributed is initialised (per-rank batches,
+    gradients averaged by BucketedAllReduce during the backward sweep).  Updates the tensors of `sd` in place.  Returns the per-step
+    losses of this rank."""
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    nl = len(unet_cfg["channel_mult"])
+    if audio_ratio is None:                  # mel frames per latent sample: the wave encoder's level that feeds U-Net level 0
+        audio_ratio = 2 ** (len(wave_cfg["channel_mult"]) - nl)
+    n_ids = sd["model.cond_stage_model.embedding.weight"].shape[0]
+    T = sd["sqrt_alphas_cumprod"].shape[0]
+    dev = lib.device
+    for k, v in list(sd.items()):
+        if v.dtype == torch.float32 and k.startswith("model.") and v.device != dev:
+            sd[k] = v.to(dev)
+    state, params, losses = {}, None, []
+    g = torch.Generator().manual_seed(seed * 1000 + rank)
+    for i in range(steps):
+        bseed = seed * 7919 + (0 if fixed_batch else i) * world + rank
+        x0, mel, ids = synthetic_batch(batch, z, unet_cfg, wave_cfg, n_ids, ntok, audio_ratio, bseed, dev)
+        if fixed_batch:                                   # the same (t, noise) too: a pure overfitting run
+            g = torch.Generator().manual_seed(seed * 1000 + rank)
+        t = torch.randint(0, T, (batch,), generator=g)
+        noise = torch.randn(batch, unet_cfg["in_channels"], z, generator=g).to(dev)
+        red = BucketedAllReduce() if world > 1 else None
+        loss, grads = training_step(lib, sd, unet_cfg, wave_cfg, x0, noise, t, ids, mel, reducer=red, recompute=recompute)
+        if params is None:
+            params = {k: sd[k] for k in grads}
+        adamw_step(lib, params, grads, state, i + 1, lr=lr, weight_decay=weight_decay)
+        losses.append(float(loss))
+        if log is not None and rank == 0:
+            log(i, losses[-1])
+    return losses
+
+
+def main(argv=None):
+    """python -m mug.train --config model.yaml [--ckpt model.ckpt | --synthetic-seed 0] --steps 10 --batch 32
+    (under `python -m torch.distributed.run --nproc-per-node N ...`: data parallel over N GPUs, RCCL)."""
+    import argparse
+    import os
+    import time
+    from . import job
+    from ._native import get_lib
+    ap = argparse.ArgumentParser(prog="python -m mug.train", description=main.__doc__)
+    ap.add_argument("--config", required=True)
+    ap.add_argument("--ckpt", default=None)
+    ap.add_argument("--synthetic-seed", type=int, default=None)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--z", type=int, default=None, help="latent length (default: the config's z_length)")
+    ap.add_argument("--lr", type=float, default=1e-4)
+    ap.add_argument("--recompute", action="store_true", help="block-level activation checkpointing")
+    ap.add_argument("--save", default=None, help="write the trained state dict here (rank 0)")
+    a = ap.parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    lib = get_lib()
+    model, cfg = job.load_model(a.config, a.ckpt, device="cuda", seed_synthetic=a.synthetic_seed if a.ckpt is None else None)
+    mp = (cfg["model"] if "model" in cfg else cfg)["params"]
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    z = a.z or int(mp.get("z_length", 512))
+    t0 = time.perf_counter()
+
+    def log(i, loss):
+        print("step %4d  loss %.6f  %.1f samples/s" % (i, loss, (i + 1) * a.batch * world / (time.perf_counter() - t0)), flush=True)
+
+    fit(lib, sd, mp["unet_config"]["params"], mp["wave_stage_config"]["params"], a.steps, a.batch, z, lr=a.lr, seed=a.synthetic_seed or 0,
+        log=log, recompute=a.recompute)
+    if a.save and (not dist.is_initialized() or dist.get_rank() == 0):
+        torch.save({"state_dict": {k: v.cpu() for k, v in sd.items()}}, a.save)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

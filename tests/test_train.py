@@ -392,6 +392,20 @@ def test_whole_model_data_parallel_step_equals_full_batch():
         close(params[k], pt, 2e-6, "AdamW step of " + k)
 
 
+def test_fit_reduces_the_loss_on_a_fixed_batch(lib):
+    """mug.train.fit: a few AdamW steps of the whole-model training step on one fixed synthetic batch of the tiny model -- the loss
+    goes down (every gradient has the right sign and the optimiser applies it), the parameters stay finite."""
+    from mug import train
+    case, sd, *_ = _tiny_training_inputs(2, 32)
+    sd = {k: v.clone() for k, v in sd.items()}
+    torch.manual_seed(0)
+    losses = train.fit(lib, sd, case["unet"], case["wave"], steps=4, batch=2, z=32, lr=2e-3, seed=1, fixed_batch=True,
+                       audio_ratio=case["audio_ratio"], ntok=case["n_ctx_tok"])
+    print("losses", ["%.4f" % v for v in losses])
+    assert all(np.isfinite(losses)) and losses[-1] < 0.9 * losses[0], losses
+    assert all(torch.isfinite(v).all() for v in sd.values() if v.dtype == torch.float32)
+
+
 # ------------------------------------------------------------------ data parallel: gradient all-reduce over 2 gloo ranks
 def _worker(rank, world, port, q):
     import torch.distributed as dist
