@@ -193,6 +193,54 @@ def test_s4layer_forward_backward_vs_autograd(lib, B, H, T, N, Lint, groups):
         close(grads[k], pt[k].grad, 5e-4, "grad of " + k)
 
 
+@pytest.mark.gpu
+def test_shipped_size_blocks_vs_autograd(gpu_lib):
+    """The three block types at the SHIPPED model's deepest-level shapes (C = 512, T = 64, 8 heads of 64, 21 prompt tokens of 128
+    channels, 32 S4 poles, batch 4) against torch autograd on the host: forward, input gradients and every parameter gradient."""
+    from oracle import nets, s4 as s4o
+    lib = gpu_lib
+    B, Cm, T = 4, 512, 64
+    # TimestepResBlock 1536 -> 512 (the first up-block after the skip concatenation)
+    p = resblock_params(1536, Cm, 512)
+    x, emb, dy = rnd(20, B, 1536, T), rnd(21, B, 512), rnd(22, B, Cm, T)
+    pt = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xt, et = x.clone().requires_grad_(True), emb.clone().requires_grad_(True)
+    yt = resblock_torch(pt, xt, et, 32)
+    yt.backward(dy)
+    y, dx, demb, grads = lib.train_resblock(p, x, emb, dy, groups=32)
+    close(y, yt, 5e-5, "resblock forward")
+    close(dx, xt.grad, 1e-4, "resblock dx")
+    close(demb, et.grad, 1e-4, "resblock demb")
+    for k in p:
+        close(grads[k], pt[k].grad, 2e-4, "resblock grad of " + k)
+    # ContextualTransformer with the prompt context
+    p = transformer_params(Cm, 128, 8, 64)
+    x, dy, ctx = rnd(40, B, Cm, T), rnd(41, B, Cm, T), rnd(42, B, 128, 21)
+    pt = {"m." + k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xt, ct = x.clone().requires_grad_(True), ctx.clone().requires_grad_(True)
+    yt = nets.contextual_transformer(pt, "m", xt, ct, 8)
+    yt.backward(dy)
+    y, dx, dctx, grads = lib.train_transformer(p, x, ctx, dy, 8, groups=32)
+    close(y, yt, 1e-4, "transformer forward")
+    close(dx, xt.grad, 3e-4, "transformer dx")
+    close(dctx, ct.grad, 3e-4, "transformer dcontext")
+    for k in p:
+        close(grads[k], pt["m." + k].grad, 5e-4, "transformer grad of " + k)
+    # S4Layer
+    p = s4layer_params(Cm, 32, T)
+    x, dy = rnd(60, B, Cm, T), rnd(61, B, Cm, T)
+    pt = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 else v) for k, v in p.items()}
+    xt = x.clone().requires_grad_(True)
+    u = F.group_norm(xt, 32, pt["norm.weight"], pt["norm.bias"], eps=1e-6)
+    yt = xt + F.conv1d(s4o.s4_forward(pt, "s4_model", u, None, mode="exact"), pt["out_layer.weight"], pt["out_layer.bias"], padding=1)
+    yt.backward(dy)
+    y, dx, grads = lib.train_s4layer(p, x, dy, groups=32)
+    close(y, yt, 1e-4, "s4 layer forward")
+    close(dx, xt.grad, 3e-4, "s4 layer dx")
+    for k in grads:
+        close(grads[k], pt[k].grad, 1e-3, "s4 layer grad of " + k)
+
+
 def test_training_entry_points_reject_bad_arguments(lib):
     """Error behaviour of the training ABI: bad geometry / missing tensors come back as MugdError (a negative status with a message),
     never as a crash; the context stays usable."""
