@@ -170,44 +170,43 @@ __global__ __launch_bounds__(256) void s4_conv_train_fwd_kernel(const float* n, 
     }
 }
 
-// dn[t'] = sum_{t >= t'} k[t - t'] dpre[t] + D dpre[t'];  dk[s] = sum_b sum_{t >= s} dpre[t] n[t - s];  dD = sum dpre n.   grid (H), block 256
-__global__ __launch_bounds__(256) void s4_conv_train_bwd_kernel(const float* n, const float* k, const float* D, const float* dpre, float* dn, float* dk,
-                                                                float* dD, int B, int H, int L) {
+// dn[t'] = sum_{t >= t'} k[t - t'] dpre[t] + D dpre[t'];  per batch row: pk[b][h][s] = sum_{t >= s} dpre[t] n[t - s], pD[b][h] = sum dpre n.
+// grid (H, B), block 256; s4_conv_bwd_reduce_kernel sums the partials over the batch in fixed order.
+__global__ __launch_bounds__(256) void s4_conv_train_bwd_kernel(const float* n, const float* k, const float* D, const float* dpre, float* dn, float* pk,
+                                                                float* pD, int B, int H, int L) {
     __shared__ float ks[4096], us[4096], ds[4096];
     __shared__ double red[4];
-    const int h = blockIdx.x, tid = threadIdx.x;
-    for (int t = tid; t < L; t += 256) ks[t] = k[(size_t)h * L + t];
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const size_t row = ((size_t)b * H + h) * L;
+    for (int t = tid; t < L; t += 256) { ks[t] = k[(size_t)h * L + t]; us[t] = n[row + t]; ds[t] = dpre[row + t]; }
+    __syncthreads();
     const float Dh = D[h];
-    float kacc[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) kacc[j] = 0.f;
     double dd = 0.0;
-    for (int b = 0; b < B; ++b) {
-        __syncthreads();
-        const size_t row = ((size_t)b * H + h) * L;
-        for (int t = tid; t < L; t += 256) { us[t] = n[row + t]; ds[t] = dpre[row + t]; }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int s = tid + 256 * j;
-            if (s < L) {
-                float a0 = 0.f, a1 = 0.f;                      // a0: dn[s], a1: dk[s]
-                for (int t = s; t < L; ++t) { a0 += ks[t - s] * ds[t]; a1 += ds[t] * us[t - s]; }
-                dn[row + s] = a0 + Dh * ds[s];
-                kacc[j] += a1;
-                dd += (double)ds[s] * (double)us[s];
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int s = tid + 256 * j;
-        if (s < L) dk[(size_t)h * L + s] = kacc[j];
+    for (int s = tid; s < L; s += 256) {
+        float a0 = 0.f, a1 = 0.f;                      // a0: dn[s], a1: dk[s]
+        for (int t = s; t < L; ++t) { a0 += ks[t - s] * ds[t]; a1 += ds[t] * us[t - s]; }
+        dn[row + s] = a0 + Dh * ds[s];
+        pk[row + s] = a1;
+        dd += (double)ds[s] * (double)us[s];
     }
     dd = wave_sum_d2(dd);
     if ((tid & 63) == 0) red[tid >> 6] = dd;
     __syncthreads();
-    if (tid == 0) dD[h] = (float)((red[0] + red[1]) + (red[2] + red[3]));
+    if (tid == 0) pD[(size_t)b * H + h] = (float)((red[0] + red[1]) + (red[2] + red[3]));
+}
+// dk[h][s] = sum_b pk[b][h][s] ; dD[h] = sum_b pD[b][h]
+__global__ void s4_conv_bwd_reduce_kernel(const float* pk, const float* pD, float* dk, float* dD, int B, int H, int L) {
+    const long long n = (long long)H * L;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int b = 0; b < B; ++b) v += pk[(size_t)b * n + i];
+        dk[i] = v;
+        if (i < H) {
+            float w = 0.f;
+            for (int b = 0; b < B; ++b) w += pD[(size_t)b * H + i];
+            dD[i] = w;
+        }
+    }
 }
 
 __global__ void gelu_bwd_kernel(const float* pre, const float* dg, float* dpre, long long n) {
@@ -251,9 +250,12 @@ void launch_s4_conv_train_fwd(hipStream_t st, const float* n, const float* k, co
     hipLaunchKernelGGL(s4_conv_train_fwd_kernel, dim3(H, B), dim3(256), 0, st, n, k, D, pre, g, B, H, L);
 }
 void launch_s4_conv_train_bwd(hipStream_t st, const float* n, const float* k, const float* D, const float* dpre, float* dn, float* dk, float* dD,
-                              int B, int H, int L) {
+                              int B, int H, int L, float* partial) {
     MUGD_CHECK(L <= 4096, -2, "s4: sequence longer than 4096");
-    hipLaunchKernelGGL(s4_conv_train_bwd_kernel, dim3(H), dim3(256), 0, st, n, k, D, dpre, dn, dk, dD, B, H, L);
+    float* pk = partial;
+    float* pD = partial + (size_t)B * H * L;
+    hipLaunchKernelGGL(s4_conv_train_bwd_kernel, dim3(H, B), dim3(256), 0, st, n, k, D, dpre, dn, pk, pD, B, H, L);
+    hipLaunchKernelGGL(s4_conv_bwd_reduce_kernel, dim3(grid1d((long long)H * L)), dim3(256), 0, st, pk, pD, dk, dD, B, H, L);
 }
 void launch_gelu_bwd(hipStream_t st, const float* pre, const float* dg, float* dpre, long long n) {
     hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid1d(n)), dim3(256), 0, st, pre, dg, dpre, n);

@@ -31,42 +31,48 @@ __device__ __forceinline__ float wave_max_ff(float v) {
     return v;
 }
 
-// ---- LayerNorm over C of a (B, C, T) tensor, backward.  grid (ceil(T / 64), B), block 256 = 64 columns x 4 channel partitions.
+// ---- LayerNorm over C of a (B, C, T) tensor, backward.  grid (ceil(T / 16), B), block 256 = 16 columns x 16 channel partitions
+// (T is 64..256 here: narrow column tiles keep > 100 workgroups in flight).
 // dx (+)= rstd (g dy - mean_c(g dy) - xhat mean_c(g dy xhat));  stat (B, T, 2) = {mean, rstd} for the parameter-gradient kernel.
+constexpr int LNB_COLS = 16, LNB_PARTS = 16;
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* x, const float* dy, const float* gamma, float eps, float* dx, float* stat,
                                                      int B, int C, int T, int accumulate) {
-    __shared__ double red[2][4][64];
-    const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int t = blockIdx.x * 64 + col, b = blockIdx.y;
+    __shared__ double red[2][LNB_PARTS][LNB_COLS + 1];
+    const int col = threadIdx.x % LNB_COLS, part = threadIdx.x / LNB_COLS;
+    const int t = blockIdx.x * LNB_COLS + col, b = blockIdx.y;
     const bool ok = t < T;
     const int tc = ok ? t : T - 1;
     const float* xb = x + (size_t)b * C * T + tc;
     const float* db = dy + (size_t)b * C * T + tc;
+    auto colsum = [&](double v, int which) {
+        red[which][part][col] = v;
+        __syncthreads();
+        double s = 0.0;
+#pragma unroll
+        for (int p = 0; p < LNB_PARTS; ++p) s += red[which][p][col];
+        return s;
+    };
     double s1 = 0.0, s2 = 0.0;
-    for (int c = part; c < C; c += 4) { const double v = xb[(size_t)c * T]; s1 += v; s2 += v * v; }
-    red[0][part][col] = s1; red[1][part][col] = s2;
-    __syncthreads();
-    s1 = (red[0][0][col] + red[0][1][col]) + (red[0][2][col] + red[0][3][col]);
-    s2 = (red[1][0][col] + red[1][1][col]) + (red[1][2][col] + red[1][3][col]);
+    for (int c = part; c < C; c += LNB_PARTS) { const double v = xb[(size_t)c * T]; s1 += v; s2 += v * v; }
+    s1 = colsum(s1, 0);
+    s2 = colsum(s2, 1);
     __syncthreads();
     const double mean = s1 / (double)C;
     double var = s2 / (double)C - mean * mean;
     var = var > 0.0 ? var : 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps)), mu = (float)mean;
     double a1 = 0.0, a2 = 0.0;
-    for (int c = part; c < C; c += 4) {
+    for (int c = part; c < C; c += LNB_PARTS) {
         const float xh = (xb[(size_t)c * T] - mu) * rstd;
         const float gd = gamma[c] * db[(size_t)c * T];
         a1 += (double)gd; a2 += (double)gd * (double)xh;
     }
-    red[0][part][col] = a1; red[1][part][col] = a2;
-    __syncthreads();
-    a1 = (red[0][0][col] + red[0][1][col]) + (red[0][2][col] + red[0][3][col]);
-    a2 = (red[1][0][col] + red[1][1][col]) + (red[1][2][col] + red[1][3][col]);
+    a1 = colsum(a1, 0);
+    a2 = colsum(a2, 1);
     const float m1 = (float)(a1 / (double)C), m2 = (float)(a2 / (double)C);
     if (ok) {
         float* ob = dx + (size_t)b * C * T + t;
-        for (int c = part; c < C; c += 4) {
+        for (int c = part; c < C; c += LNB_PARTS) {
             const float xh = (xb[(size_t)c * T] - mu) * rstd;
             const float v = rstd * (gamma[c] * db[(size_t)c * T] - m1 - xh * m2);
             ob[(size_t)c * T] = accumulate ? ob[(size_t)c * T] + v : v;
@@ -257,7 +263,7 @@ __global__ void attn_tables_reduce_kernel(const double* part, float* drel, float
 
 void launch_ln_bwd(hipStream_t st, const float* x, const float* dy, const float* gamma, float eps, float* dx, float* stat, float* dgamma,
                    float* dbeta, int B, int C, int T, int accumulate) {
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(T, 64), B), dim3(256), 0, st, x, dy, gamma, eps, dx, stat, B, C, T, accumulate);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(T, LNB_COLS), B), dim3(256), 0, st, x, dy, gamma, eps, dx, stat, B, C, T, accumulate);
     hipLaunchKernelGGL(ln_param_grad_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, x, dy, stat, dgamma, dbeta, B, C, T);
 }
 void launch_geglu_fwd(hipStream_t st, const float* u, float* f, int B, int Ch, int T) {

@@ -348,7 +348,7 @@ struct S4GenBwdArgs {        // gradient of launch_s4_kernel_gen's output k (H, 
 void launch_s4_kernel_gen_bwd(hipStream_t st, const S4GenBwdArgs& a);
 void launch_s4_conv_train_fwd(hipStream_t st, const float* n, const float* k, const float* D, float* pre, float* g, int B, int H, int L);
 void launch_s4_conv_train_bwd(hipStream_t st, const float* n, const float* k, const float* D, const float* dpre, float* dn, float* dk, float* dD,
-                              int B, int H, int L);
+                              int B, int H, int L, float* partial /* B * H * (L + 1) floats */);
 void launch_gelu_bwd(hipStream_t st, const float* pre, const float* dg, float* dpre, long long n);
 void launch_glu_fwd(hipStream_t st, const float* v, float* f, int B, int Ch, int T);
 void launch_glu_bwd(hipStream_t st, const float* v, const float* df, float* dv, int B, int Ch, int T);

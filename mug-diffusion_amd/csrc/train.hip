@@ -319,7 +319,7 @@ int mugd_train_s4layer(mugd_ctx* ctx, const float* const* P, const float* x, con
         launch_glu_bwd(st, v, df, dv, B, H, T);
         lt.bwd(g, P[MUGD_S4_OUT_LIN_W], dv, dg, false, G[MUGD_S4_OUT_LIN_W], G[MUGD_S4_OUT_LIN_B], H, 2 * H, wt);
         launch_gelu_bwd(st, pre, dg, dpre, (long long)n);
-        launch_s4_conv_train_bwd(st, nrm, k, P[MUGD_S4_D], dpre, dn, dk, G[MUGD_S4_D], B, H, T);
+        launch_s4_conv_train_bwd(st, nrm, k, P[MUGD_S4_D], dpre, dn, dk, G[MUGD_S4_D], B, H, T, buf((size_t)B * H * (T + 1)));
         S4GenBwdArgs gb{P[MUGD_S4_K_C], P[MUGD_S4_K_B], P[MUGD_S4_K_P], P[MUGD_S4_K_INV_W_REAL], P[MUGD_S4_K_W_IMAG], P[MUGD_S4_K_LOG_DT], H, N, Lint, T, dk,
                         G[MUGD_S4_K_C], G[MUGD_S4_K_B], G[MUGD_S4_K_P], G[MUGD_S4_K_INV_W_REAL], G[MUGD_S4_K_W_IMAG], G[MUGD_S4_K_LOG_DT]};
         launch_s4_kernel_gen_bwd(st, gb);
