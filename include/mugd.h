@@ -217,7 +217,8 @@ int mugd_op_gn_s4_conv(mugd_ctx* ctx, const float* u, const float* k, const floa
                        int groups, float* y, int B, int H, int L);
 int mugd_op_timestep_embedding(mugd_ctx* ctx, const int64_t* t, float* out, int B, int dim);
 
-/* ---- training slice (FIRST STEP: not yet a training loop for the whole U-Net) ------------------------------ */
+/* ---- training (BASELINE configs[4]): loss pieces, one forward / backward entry point per block type, AdamW.
+ * mug-diffusion_amd/mug/train.py strings them into the whole-model DDPM training step.  fp32. ------------------ */
 /* mug/diffusion/diffusion.py:326-333 q_sample: out = sqrt_alphas_cumprod[t_b] x0 + sqrt_one_minus_alphas_cumprod[t_b] noise.
  * x0 / noise / out: (B, n) fp32; t: (B) int64; the two schedule buffers: the model's registered buffers (fp32, 1000 entries). */
 int mugd_train_q_sample(mugd_ctx* ctx, const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac, const float* sqrt_1mac,

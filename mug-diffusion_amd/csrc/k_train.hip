@@ -1,4 +1,5 @@
-// Training slice (BASELINE configs[4]) -- FIRST STEP, not yet a training loop for the whole U-Net:
+// Training (BASELINE configs[4]), first kernel file: the pieces shared by all block types and the ResBlock's own
+// (the transformer's are in k_train_tf.hip, the S4 layer's in k_train_s4.hip; train.hip holds the entry points):
 // the DDPM noise-prediction loss around the network (mug/diffusion/diffusion.py:326-354: q_sample, smooth-L1(beta) + 0.01)
 // and the backward pass of the block that makes up most of the U-Net's launches, TimestepResBlock._forward
 // (mug/diffusion/unet.py:212-239): GroupNorm -> SiLU -> conv3 (+ time-embedding row) -> GroupNorm -> SiLU -> conv3 (+ skip).

@@ -1,4 +1,4 @@
-"""Training slice (first step): DDPM loss pieces and TimestepResBlock forward + backward through the C ABI,
+"""Training: DDPM loss pieces, every block type's forward + backward and the whole-model step through the C ABI,
 against torch autograd on the same fp32 math (GroupNorm eps 1e-6, SiLU, conv1d, Linear, smooth_l1(beta=0.02) + 0.01 --
 mug/diffusion/unet.py:212-239, mug/diffusion/diffusion.py:326-354), an AdamW step against torch.optim.AdamW, and the
 data-parallel gradient all-reduce (2-rank gloo) against the full-batch gradient."""
