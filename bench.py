@@ -2,7 +2,8 @@
 """Headline benchmark (BASELINE.json): charts/s for 3-minute audio, 50 DDIM steps, batch 4, on N MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1: either under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`, or as the plain
+   command above -- without WORLD_SIZE in the environment bench.py starts its own N ranks through torch.distributed.run)
 
 One STEP = one batch of `--batch` charts for one synthetic 3-minute 22.05 kHz song, i.e. one full pass of
 the hot path with the PCM already resident in HBM:
@@ -109,6 +110,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (torch scales badly past ~16 on these small tensors)")
     ap.add_argument("--cpu-timeout", type=int, default=150)
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)        # tests/test_bench_launcher.py: the rank plumbing on gloo, no GPU
     ap.add_argument("--z", type=int, default=512, help=argparse.SUPPRESS)
     ap.add_argument("--n-unet-steps", type=int, default=50, help=argparse.SUPPRESS)
     a = ap.parse_args()
@@ -116,10 +118,15 @@ def main():
     if a.cpu_baseline_worker:
         return cpu_baseline_worker(a)
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(a.gpus)                       # plain `python bench.py --gpus N`: start the N ranks ourselves
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == a.gpus, "launch with --nproc-per-node equal to --gpus"
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks (use --nproc-per-node equal to --gpus)" % (a.gpus, world))
+    if a.launcher_selftest:
+        return launcher_selftest(a, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libmugd has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -338,6 +345,52 @@ def main():
     if grouped:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-run this very command line under torch.distributed.run, one rank per GPU
+    of this node (rendezvous on 127.0.0.1, a free port).  The children see WORLD_SIZE and take the normal path; rank 0's JSON
+    line goes to our stdout unchanged; our exit status is the launcher's."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_threads() // n)))
+    note("starting %d ranks: %s" % (n, " ".join(cmd[1:9])))
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        raise SystemExit(rc)
+
+
+def launcher_selftest(a, rank, world):
+    """The rank plumbing of main() -- process group, barrier, K 'steps' bracketed like the timed region, MAX over ranks, one gather,
+    ONE JSON line from rank 0 -- on the gloo backend with a stub body, so the launcher path is testable without GPUs."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    dist.barrier()
+    t0 = time.perf_counter()
+    acc = torch.zeros(4)
+    for i in range(a.steps):
+        acc += torch.arange(4, dtype=torch.float32) * (rank + 1)
+    dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    got = [torch.zeros(4) for _ in range(world)]
+    dist.all_gather(got, acc)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher_selftest", "n_gpus": world, "steps": a.steps, "elapsed_max_s": float(tt.item()),
+                          "gathered": [g.tolist() for g in got]}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def training_leg(a, lib, model, dev, world, rank, grouped, sync_all):
