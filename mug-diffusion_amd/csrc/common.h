@@ -65,8 +65,16 @@ __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f +
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// n / d for n, d < 65536 with m = ceil(2^32 / d) precomputed on the host (conv_fastdiv_mul); d == 1 is encoded as m == 0
-__device__ __forceinline__ int fastdiv(int n, unsigned m) { return m ? (int)__umulhi((unsigned)n, m) : n; }
+// n / d with m = ceil(2^32 / d) precomputed on the host (conv_fastdiv_mul); d == 1 is encoded as m == 0.  The estimate
+// __umulhi(n, m) is floor(n / d) whenever n * d < 2^32 and floor(n / d) + 1 at worst otherwise (m d - 2^32 < d, so the excess
+// n (m d - 2^32) / (d 2^32) stays below 1 for every 32-bit n): one multiply + compare makes the quotient exact for ANY grid
+// (long wave-encoder / VAE launches at large batch pass the n * d < 2^32 range).
+__device__ __forceinline__ int fastdiv(int n, unsigned m, int d) {
+    if (!m) return n;
+    unsigned q = __umulhi((unsigned)n, m);
+    q -= (q * (unsigned)d > (unsigned)n) ? 1u : 0u;
+    return (int)q;
+}
 
 // Kernel arguments are fetched by scalar loads the compiler places lazily, one dependent round trip per first use: the conv_gemm
 // prologue paid ~25 of them in series (profiles/r2_timeline_*: 0.8-1.2 us "setup").  KARG_PIN forces the listed values into SGPRs

@@ -462,9 +462,9 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
     int lid = blockIdx.x;
     if ((nblk & 7) == 0) lid = (lid & 7) * (nblk >> 3) + (lid >> 3);
     int mt, rem;
-    if (a.xcd_cols) { rem = fastdiv(lid, a.mgy); mt = lid - rem * gy; }       // row tile fastest: an XCD's slab is a range of column tiles
-    else { mt = fastdiv(lid, a.mgxz); rem = lid - mt * (gx * gz); }
-    const int b = fastdiv(rem, a.mgx);
+    if (a.xcd_cols) { rem = fastdiv(lid, a.mgy, gy); mt = lid - rem * gy; }       // row tile fastest: an XCD's slab is a range of column tiles
+    else { mt = fastdiv(lid, a.mgxz, gx * gz); rem = lid - mt * (gx * gz); }
+    const int b = fastdiv(rem, a.mgx, gx);
     const int t0 = (rem - b * gx) * CONV_TN;
 
     const int tid = threadIdx.x;

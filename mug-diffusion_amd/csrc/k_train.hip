@@ -477,6 +477,7 @@ void launch_embedding_bwd(hipStream_t st, const long long* ids, const float* dct
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3(rows), dim3(128), 0, st, ids, dctx, dtable, B, ntok, dim);
 }
 void launch_adamw(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd, int step) {
-    const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
+    // bias corrections in double like torch.optim.AdamW (float powf is off by ~6e-5 relative in bc2 at step 1)
+    const float bc1 = (float)(1.0 - pow((double)b1, (double)step)), bc2 = (float)(1.0 - pow((double)b2, (double)step));
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2);
 }

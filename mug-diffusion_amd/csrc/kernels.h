@@ -84,7 +84,7 @@ struct ConvArgs {
                              // the activations), 1 = row tile fastest (a column tile lives in one L2, every XCD reads the weights);
                              // set per launch by conv_pick_order() to whichever moves fewer bytes
     int gx, gy, gz;          // grid decomposition (column tiles, row tiles, batch rows), set by the launcher together with the
-    unsigned mgx, mgy, mgxz; // reciprocal multipliers of gx, gy, gx*gz: q = n / d as __umulhi(n, m) for n, d < 65536 (d == 1: q = n)
+    unsigned mgx, mgy, mgxz; // reciprocal multipliers of gx, gy, gx*gz for fastdiv() (common.h; exact for every 32-bit n; d == 1: q = n)
     // EPI_XSOFTMAX: relative-position tables (2 pmax + 1, heads), head = row tile, keys, softmax scale
     const float* xs_rel; const float* xs_cemb;
     int xs_heads, xs_pmax, xs_ntok; float xs_scale;

@@ -107,22 +107,28 @@ class DDIMSampler(object):
                 next(bar_it, None)
 
         def draw_noise(n):
-            # one randn(shape) per step, in step order, exactly as p_sample_ddim does (ddim.py:192) -- also when eta == 0, where
-            # the reference still draws (and discards: sigma = 0) the noise, so that a later sample in the same process starts
-            # from the same generator state as in the reference (scripts/mapping.py's n_samples loop)
-            z = torch.stack([torch.randn(tuple(shape), device=device) for _ in range(n)])
-            if not eta_on:
-                return None
-            z = z * temperature
-            if noise_dropout > 0.:
-                z = torch.nn.functional.dropout(z, p=noise_dropout)
-            return z
+            # one randn(shape) per step, in step order, exactly as p_sample_ddim does (ddim.py:192-194: randn, then the dropout
+            # draw when noise_dropout > 0) -- also when eta == 0, where the reference still draws (and discards: sigma = 0) the
+            # noise, so that a later sample in the same process starts from the same generator state as in the reference
+            # (scripts/mapping.py's n_samples loop).  With eta == 0 nothing is kept: the draws only advance the generator.
+            keep = []
+            for _ in range(n):
+                z = torch.randn(tuple(shape), device=device)
+                if noise_dropout > 0.:
+                    z = torch.nn.functional.dropout(z * temperature, p=noise_dropout)
+                elif eta_on:
+                    z = z * temperature
+                if eta_on:
+                    keep.append(z)
+            return torch.stack(keep) if eta_on else None
         if not per_step and total > 1 and log_after == [0, total - 1]:
             # the common case (S <= log_every_t, no callbacks): ONE native call for the whole loop; the library hands back the
             # state after the first step, the only other intermediate the reference records
-            noise = draw_noise(total)
+            noise = draw_noise(total) if eta_on else None
             x, pred, first = net.ddim_sample(x, c, w, steps, rows, uc=uc, scale=float(unconditional_guidance_scale), noise=noise,
                                              want_pred_x0=True, want_first=True)
+            if not eta_on:
+                draw_noise(total)          # generator bookkeeping only: issued AFTER the loop is enqueued, hidden behind it
             advance(total)
             intermediates['x_inter'] += [first[0], x]
             intermediates['pred_x0'] += [first[1], pred]

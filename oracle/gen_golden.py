@@ -382,8 +382,130 @@ def masked_goldens():
         del model
 
 
+# tensors whose full gradients the shipped-size fixture keeps (every block type, all three trainable networks; the rest are
+# pinned through their L2 norms)
+TRAIN_FULL_KEEP = [
+    "model.cond_stage_model.embedding.weight",
+    "model.unet_model.time_embed.0.weight", "model.unet_model.time_embed.2.bias",
+    "model.unet_model.input_blocks.0.0.weight",
+    "model.unet_model.input_blocks.2.0.in_layers.2.weight", "model.unet_model.input_blocks.2.0.emb_layers.1.weight",
+    "model.unet_model.input_blocks.2.0.skip_connection.weight", "model.unet_model.input_blocks.2.0.out_layers.0.weight",
+    "model.unet_model.input_blocks.2.1.s4_model.kernel.kernel.C", "model.unet_model.input_blocks.2.1.s4_model.kernel.kernel.log_dt",
+    "model.unet_model.input_blocks.2.1.s4_model.kernel.kernel.inv_w_real", "model.unet_model.input_blocks.2.1.s4_model.D",
+    "model.unet_model.input_blocks.4.0.conv.weight",
+    "model.unet_model.input_blocks.6.1.transformer_blocks.0.attn1.to_q.weight",
+    "model.unet_model.input_blocks.6.1.transformer_blocks.0.attn1.relative_position_embedding",
+    "model.unet_model.input_blocks.6.1.transformer_blocks.0.attn2.to_k.weight",
+    "model.unet_model.input_blocks.6.1.transformer_blocks.0.attn2.C_embedding",
+    "model.unet_model.input_blocks.6.1.transformer_blocks.0.ff.net.0.proj.weight",
+    "model.unet_model.input_blocks.6.1.transformer_blocks.0.norm2.weight",
+    "model.unet_model.middle_block.1.proj_out.weight",
+    "model.unet_model.output_blocks.3.2.conv.weight", "model.unet_model.output_blocks.15.0.out_layers.3.weight",
+    "model.unet_model.out.0.weight", "model.unet_model.out.2.weight",
+    "model.wave_model.conv_in.weight", "model.wave_model.down.6.block.0.conv1.weight", "model.wave_model.down.6.block.1.conv2.weight",
+    "model.wave_model.down.7.block.0.nin_shortcut.weight", "model.wave_model.down.7.downsample.conv.weight",
+    "model.wave_model.down.8.attn.0.transformer_blocks.0.attn2.to_v.weight", "model.wave_model.down.9.block.1.norm2.bias",
+]
+
+
+def train_sample_index(seed, i, n):
+    return np.sort(cases.rng(seed, 9, i).choice(n, size=8192, replace=False))
+
+
+def train_batch(case, seed, B, z):
+    """The training batch of the *_train_* fixtures: note grid tensor, fp16-rounded log-mel, prompt ids (numpy generators)."""
+    up = 2 ** (len(case["vae"]["channel_mult"]) - 1)
+    note_t = cases.randn(seed, 1, (B, case["vae"]["x_channels"], z * up))
+    mel = cases.mel_input(case, seed, B, z * case["audio_ratio"])
+    return note_t, mel
+
+
+def train_goldens():
+    """The training step of the REAL reference (BASELINE configs[4]): `DDPM.forward` (diffusion.py:408-414:
+    frozen `first_stage_model.encode(batch['note'])` -> `.mode()`, t ~ randint(generator), then `p_losses` :356-406: noise ~
+    randn(generator), q_sample, cond / wave encoders with grad, U-Net, smooth_l1(beta 0.02) + 0.01, mean over (C, T) then batch)
+    followed by `loss.backward()`, in train mode, on the tiny and the shipped architecture.  Stored: the batch, the (t, noise)
+    the generator produced, the loss, x_start, the L2 norm of EVERY parameter gradient and the full gradients of a spread of
+    tensors (all of them for the tiny model).  The oracle's autograd restatement of the same step is checked against it here."""
+    import torch.nn.functional as F
+    rep = {}
+    for case, z, B, keep in ((cases.TINY, 32, 2, None), (cases.FULL, 96, 2, TRAIN_FULL_KEEP)):
+        tag = case["name"]
+        model = ref_model(case)
+        man = weights.manifest_of(model.state_dict())
+        sd = weights.set_s4_lengths(weights.make_state_dict(man, seed=0), case["unet"], z)
+        load(model, sd)
+        model.train()                                             # the first stage stays in eval mode (disabled_train, diffusion.py:15-18,36-41)
+        seed = 1300 + z
+        note_t, mel = train_batch(case, seed, B, z)
+        n_ids = sd["model.cond_stage_model.embedding.weight"].shape[0]
+        ids = torch.from_numpy(cases.rng(seed, 2).integers(0, n_ids, (B, case["n_ctx_tok"])))
+        batch = {"note": note_t, "audio": mel, "feature": ids.to(torch.float32)}
+        g = torch.Generator().manual_seed(seed)
+        t0 = time.time()
+        with torch.enable_grad():
+            for p_ in model.parameters():
+                p_.grad = None
+            loss, loss_dict = model(batch, generator=g)
+            loss.backward()
+        t1 = time.time()
+        # what the generator handed out inside forward / p_losses, replayed: randint for t, then randn for the noise
+        g2 = torch.Generator().manual_seed(seed)
+        t = torch.randint(0, model.num_timesteps, (B,), generator=g2).long()
+        x_start = model.model.encode(batch).mode()
+        noise = torch.randn(x_start.size(), generator=g2)
+        grads = {k: p_.grad.detach().clone() for k, p_ in model.named_parameters() if p_.grad is not None}
+        frozen = [k for k, p_ in model.named_parameters() if p_.grad is None]
+        assert all(k.startswith("model.first_stage_model.") or k.startswith("model.wave_model.") for k in frozen), frozen[:5]
+        print("  %s train z=%d B=%d: loss %.6f, %d gradient tensors, %d without gradient (frozen VAE / wave levels the U-Net does not read), %.1fs"
+              % (tag, z, B, float(loss), len(grads), len(frozen), t1 - t0))
+        # ---- the oracle's restatement of the same step through autograd
+        trainable = [k for k in grads]
+        st = {k: (v.clone().requires_grad_(True) if k in trainable else v) for k, v in sd.items()}
+        with torch.enable_grad():
+            x0_o = nets.vae_encode(sd, case["vae"], note_t)[:, :case["z_channels"]]         # mode() of the diagonal Gaussian = its mean
+            assert maxdiff(x0_o, x_start) == 0.0
+            xt = st["sqrt_alphas_cumprod"][t][:, None, None] * x0_o + st["sqrt_one_minus_alphas_cumprod"][t][:, None, None] * noise
+            ctx = nets.cond_embed(st, ids)
+            w = nets.wave_encode(st, case["wave"], mel)
+            pred = nets.unet_forward(st, case["unet"], xt, t, ctx, w)
+            lo = (F.smooth_l1_loss(noise, pred, beta=0.02, reduction="none") + 0.01).mean(dim=[1, 2]).mean()
+            lo.backward()
+        dl = abs(float(lo) - float(loss))
+        worst = max(((st[k].grad - grads[k]).abs().max().item() / max(grads[k].abs().max().item(), 1e-12), k) for k in trainable)
+        note("%s train z=%d loss |oracle-ref|" % (tag, z), dl)
+        note("%s train z=%d worst relative gradient |oracle-ref| (%s)" % (tag, z, worst[1][-40:]), worst[0])
+        rep["%s train z=%d loss |oracle-ref|" % (tag, z)] = dl
+        rep["%s train z=%d worst relative gradient |oracle-ref|" % (tag, z)] = worst[0]
+        names = sorted(grads)
+        full = names if keep is None else keep
+        for k in full:
+            assert k in grads, k
+        # tensors above 8192 elements are kept as a seeded sample of 8192 flat positions (cases.rng(seed, 9, position in `full_names`))
+        kept = {}
+        for i, k in enumerate(full):
+            gk = grads[k].reshape(-1)
+            kept["g%d" % i] = (gk if gk.numel() <= 8192 else gk[torch.from_numpy(train_sample_index(seed, i, gk.numel()))]).numpy()
+        # the batch itself is reproducible from the seed (cases.randn / mel_input / rng: numpy generators); t and the noise came out
+        # of a torch generator and are stored
+        np.savez_compressed(os.path.join(G, "%s_train_z%d_B%d.npz" % (tag, z, B)), seed=seed, t=t.numpy(), noise=noise.numpy(),
+                            x_start=x_start.numpy(), loss=np.float64(float(loss)), loss_simple=np.float64(float(loss_dict["train/loss_simple"])),
+                            names=np.array(names), norms=np.array([float(grads[k].double().norm()) for k in names]),
+                            absmax=np.array([float(grads[k].abs().max()) for k in names]), full_names=np.array(full), **kept)
+        del model
+    path = os.path.join(G, "oracle_vs_reference.json")
+    with open(path) as f:
+        full_rep = json.load(f)
+    full_rep.update(rep)
+    with open(path, "w") as f:
+        json.dump(full_rep, f, indent=1)
+
+
 def main():
     torch.set_num_threads(os.cpu_count())
+    if "--train-only" in sys.argv:
+        train_goldens()
+        return
     if "--masked-only" in sys.argv:
         masked_goldens()
         return
@@ -400,6 +522,7 @@ def main():
     s4_host_goldens()
     postprocess_goldens()
     masked_goldens()
+    train_goldens()
     run_case(cases.TINY, [32], {32: [(4, 2, 1.0), (4, 2, 5.0)]})
     if "--tiny-only" not in sys.argv:
         run_case(cases.FULL, [96, 512], {96: [(10, 1, 1.0), (10, 1, 5.0)]})

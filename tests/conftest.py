@@ -14,6 +14,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """Every `gpu`-marked item skips when no GPU is visible to torch (a plain `pytest tests` in the authoring container stays
+    green whatever a test forgets to call); on a GPU box nothing is skipped here."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="needs a real MI355X (no GPU visible to torch)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 _libs = {}
 
 
