@@ -55,7 +55,8 @@ int mugd_synchronize(mugd_ctx* ctx);
  * host synchronisation (the Python binding does this around every entry point).  other == the context's own stream: no-op. */
 int mugd_order_after(mugd_ctx* ctx, void* other_stream);
 int mugd_order_before(mugd_ctx* ctx, void* other_stream);
-/* 1 (default): replay each DDIM step from a captured hipGraph; 0: launch kernels eagerly. */
+/* DDIM loop launch mode.  1 (default): replay each DDIM step from a captured hipGraph; 0: launch kernels eagerly;
+ * 2: capture the whole S-step loop into ONE graph (one hipGraphLaunch per sampling call; re-captured when S changes). */
 int mugd_set_graph_mode(mugd_ctx* ctx, int enabled);
 /* Tuning / test knob: force the conv_gemm decomposition for networks COMPILED and operators run after the call
  * (wk: waves splitting K per workgroup, 1|2|4|8; tn: output tile width 16|32; 0 = pick per layer).  Call

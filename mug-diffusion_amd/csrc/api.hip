@@ -73,7 +73,7 @@ int mugd_create(int device, void* stream, mugd_ctx** out) {
             ctx->c.own_stream = true;
         }
         const char* g = getenv("MUGD_NO_GRAPH");
-        ctx->c.use_graph = !(g && g[0] == '1');
+        ctx->c.use_graph = (g && g[0] == '1') ? 0 : 1;
         const char* u = getenv("MUGD_UNFUSED_NORM");
         ctx->c.fuse_norm = !(u && u[0] == '1');
         const char* ns = getenv("MUGD_NO_STATS_FUSION");
@@ -130,7 +130,7 @@ int mugd_order_before(mugd_ctx* ctx, void* other) { return ctx ? order_streams(c
 
 int mugd_set_graph_mode(mugd_ctx* ctx, int enabled) {
     if (!ctx) return MUGD_ERR_INVALID;
-    ctx->c.use_graph = enabled != 0;
+    ctx->c.use_graph = enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled);
     return MUGD_OK;
 }
 

@@ -37,7 +37,7 @@ struct Ctx {
     bool own_stream = false;
     hipEvent_t order_event = nullptr;     // mugd_order_after / mugd_order_before
     std::string last_error;
-    bool use_graph = true;
+    int use_graph = 1;         // DDIM loop: 0 eager launches | 1 one hipGraph per step, replayed S times | 2 the whole S-step loop as ONE graph
     float* scratch = nullptr; size_t scratch_cap = 0;   // grow-only device scratch of the context-level operators (log_mel): no malloc / sync per call
     std::map<std::pair<int, int>, float*> resample_taps;   // device copies of the polyphase filters, per reduced (up, down)
     int force_wk = 0, force_tn = 0;   // mugd_set_conv_tiling: 0 = pick per layer
@@ -227,7 +227,7 @@ private:
     int step_init[2] = {0, 0};
     float* emb_table = nullptr; float* emb_tmp = nullptr; int* ticket_dev = nullptr;     // [S][rowadd_total] + scratch of its 3 GEMVs
     float* pred_dev = nullptr; float* first_dev = nullptr;
-    hipGraphExec_t graph = nullptr; bool graph_cfg = false; bool graph_noise = false; bool graph_pred = false; bool graph_first = false; float graph_scale = 0.f;
+    hipGraphExec_t graph = nullptr; int graph_steps = 0; bool graph_cfg = false; bool graph_noise = false; bool graph_pred = false; bool graph_first = false; float graph_scale = 0.f;
 
     void ensure(int B, int z, int ntok, int bmod);
     void build(bool dry_run);

@@ -1113,7 +1113,8 @@ void UNet::sample(float* x, const float* c, const float* uc, int n_tok, const fl
     const bool wn = noise != nullptr, wp = pred_x0 != nullptr, wf = first != nullptr;
     launch_ddim_step(st, step_args(cfg_on, scale, wn, wp, wf, nstate, S, 0));      // x_T -> U-Net input, embedding rows of step 0
     if (ctx->use_graph) {
-        if (graph && (graph_cfg != cfg_on || graph_noise != wn || graph_pred != wp || graph_first != wf || graph_scale != scale)) {
+        const int per_graph = ctx->use_graph == 2 ? S : 1;        // steps captured into one graph
+        if (graph && (graph_steps != per_graph || graph_cfg != cfg_on || graph_noise != wn || graph_pred != wp || graph_first != wf || graph_scale != scale)) {
             HIP_CHECK(hipStreamSynchronize(st));
             hipGraphExecDestroy(graph);
             graph = nullptr;
@@ -1121,13 +1122,13 @@ void UNet::sample(float* x, const float* c, const float* uc, int n_tok, const fl
         if (!graph) {
             hipGraph_t g = nullptr;
             HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            step_body(st, cfg_on, scale, wn, wp, wf, nstate, S);
+            for (int i = 0; i < per_graph; ++i) step_body(st, cfg_on, scale, wn, wp, wf, nstate, S);
             HIP_CHECK(hipStreamEndCapture(st, &g));
             HIP_CHECK(hipGraphInstantiate(&graph, g, nullptr, nullptr, 0));
             HIP_CHECK(hipGraphDestroy(g));
-            graph_cfg = cfg_on; graph_noise = wn; graph_pred = wp; graph_first = wf; graph_scale = scale;
+            graph_steps = per_graph; graph_cfg = cfg_on; graph_noise = wn; graph_pred = wp; graph_first = wf; graph_scale = scale;
         }
-        for (int i = 0; i < S; ++i) HIP_CHECK(hipGraphLaunch(graph, st));
+        for (int i = 0; i < S / per_graph; ++i) HIP_CHECK(hipGraphLaunch(graph, st));
     } else {
         for (int i = 0; i < S; ++i) step_body(st, cfg_on, scale, wn, wp, wf, nstate, S);
     }

@@ -212,7 +212,8 @@ class Lib:
         self.check(self.dll.mugd_synchronize(self.ctx))
 
     def set_graph_mode(self, on):
-        self.check(self.dll.mugd_set_graph_mode(self.ctx, 1 if on else 0))
+        """True / 1: one hipGraph per DDIM step, replayed S times; False / 0: eager launches; 2: the whole loop as one graph."""
+        self.check(self.dll.mugd_set_graph_mode(self.ctx, int(on)))
 
     def set_weight_precision(self, bf16):
         """Reduced-precision mode: networks compiled afterwards keep their packed conv / linear weights in bfloat16

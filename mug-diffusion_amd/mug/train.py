@@ -390,6 +390,34 @@ def training_step(lib, sd, unet_cfg, wave_cfg, x0, noise, t, ids, mel, beta=0.02
     return loss.mean(), grads.g
 
 
+_VAE_ENC = {}
+
+
+def encode_x0(lib, sd, vae_cfg, note):
+    """The frozen first stage in front of the step, as DDPM.forward does (diffusion.py:408: `x = self.model.encode(batch)`, then
+    p_losses :357 `x_start = x_start_distribution.mode()`): AutoencoderKL.encode (autoencoder.py:67-73) on the native VaeEncoder
+    network; the mode of the diagonal Gaussian is its mean = the first z_channels rows of the moments.  The encoder instance is
+    kept per (library, state dict)."""
+    key = (id(lib), id(sd))
+    ent = _VAE_ENC.get(key)
+    if ent is None or ent[0] is not sd:
+        if len(_VAE_ENC) > 2:
+            _VAE_ENC.clear()
+        enc = lib.vae(vae_cfg, encoder=True)
+        enc.set_params(sd, "model.first_stage_model.")
+        ent = _VAE_ENC[key] = (sd, enc)
+    moments = ent[1].vae_encode(note)
+    return moments[:, :vae_cfg["z_channels"]].contiguous()
+
+
+def training_step_from_batch(lib, sd, unet_cfg, wave_cfg, vae_cfg, batch, t, noise, **kw):
+    """DDPM.forward + p_losses on a reference-shaped batch {'note': (B, x_ch, 8 z), 'audio': (B, n_freq, frames), 'feature': (B, 21) ids}
+    (diffusion.py:356-414) with explicit (t, noise) -- what the reference draws from its generator: the frozen VAE encoder's
+    mode() in front, then `training_step`."""
+    x0 = encode_x0(lib, sd, vae_cfg, batch["note"])
+    return training_step(lib, sd, unet_cfg, wave_cfg, x0, noise, t, batch["feature"].long(), batch["audio"], **kw)
+
+
 # ------------------------------------------------------------------------------------------------------------------------------
 # a minimal training loop over the step (the reference trains through pytorch_lightning: main.py + DDPM.training_step /
 # configure_optimizers, diffusion.py:416-513; its dataset is not available offline -- SURVEY.md 8f rank 4 -- so: synthetic batches)

@@ -66,3 +66,18 @@ def mel_input(case, seed, B, frames):
     n = case["wave"]["n_freq"]
     m = np.abs(rng(seed, 5).standard_normal((B, n, frames))).astype(np.float16).astype(np.float32) * 2.0
     return torch.from_numpy(m.astype(np.float16).astype(np.float32))
+
+
+def train_batch(case, seed, B, z, n_ids):
+    """The training batch of the tests/golden/*_train_* fixtures (oracle/gen_golden.py: train_goldens): note-grid tensor
+    (B, x_channels, 8 z), fp16-rounded log-mel (B, n_freq, z * audio_ratio), prompt ids (B, 21)."""
+    up = 2 ** (len(case["vae"]["channel_mult"]) - 1)
+    note_t = randn(seed, 1, (B, case["vae"]["x_channels"], z * up))
+    mel = mel_input(case, seed, B, z * case["audio_ratio"])
+    ids = torch.from_numpy(rng(seed, 2).integers(0, n_ids, (B, case["n_ctx_tok"])))
+    return note_t, mel, ids
+
+
+def train_sample_index(seed, i, n):
+    """Flat positions kept of the i-th fully stored gradient when it has more than 8192 elements."""
+    return np.sort(rng(seed, 9, i).choice(n, size=8192, replace=False))

@@ -408,18 +408,6 @@ TRAIN_FULL_KEEP = [
 ]
 
 
-def train_sample_index(seed, i, n):
-    return np.sort(cases.rng(seed, 9, i).choice(n, size=8192, replace=False))
-
-
-def train_batch(case, seed, B, z):
-    """The training batch of the *_train_* fixtures: note grid tensor, fp16-rounded log-mel, prompt ids (numpy generators)."""
-    up = 2 ** (len(case["vae"]["channel_mult"]) - 1)
-    note_t = cases.randn(seed, 1, (B, case["vae"]["x_channels"], z * up))
-    mel = cases.mel_input(case, seed, B, z * case["audio_ratio"])
-    return note_t, mel
-
-
 def train_goldens():
     """The training step of the REAL reference (BASELINE configs[4]): `DDPM.forward` (diffusion.py:408-414:
     frozen `first_stage_model.encode(batch['note'])` -> `.mode()`, t ~ randint(generator), then `p_losses` :356-406: noise ~
@@ -437,9 +425,7 @@ def train_goldens():
         load(model, sd)
         model.train()                                             # the first stage stays in eval mode (disabled_train, diffusion.py:15-18,36-41)
         seed = 1300 + z
-        note_t, mel = train_batch(case, seed, B, z)
-        n_ids = sd["model.cond_stage_model.embedding.weight"].shape[0]
-        ids = torch.from_numpy(cases.rng(seed, 2).integers(0, n_ids, (B, case["n_ctx_tok"])))
+        note_t, mel, ids = cases.train_batch(case, seed, B, z, sd["model.cond_stage_model.embedding.weight"].shape[0])
         batch = {"note": note_t, "audio": mel, "feature": ids.to(torch.float32)}
         g = torch.Generator().manual_seed(seed)
         t0 = time.time()
@@ -485,7 +471,7 @@ def train_goldens():
         kept = {}
         for i, k in enumerate(full):
             gk = grads[k].reshape(-1)
-            kept["g%d" % i] = (gk if gk.numel() <= 8192 else gk[torch.from_numpy(train_sample_index(seed, i, gk.numel()))]).numpy()
+            kept["g%d" % i] = (gk if gk.numel() <= 8192 else gk[torch.from_numpy(cases.train_sample_index(seed, i, gk.numel()))]).numpy()
         # the batch itself is reproducible from the seed (cases.randn / mel_input / rng: numpy generators); t and the noise came out
         # of a torch generator and are stored
         np.savez_compressed(os.path.join(G, "%s_train_z%d_B%d.npz" % (tag, z, B)), seed=seed, t=t.numpy(), noise=noise.numpy(),

@@ -507,3 +507,122 @@ def test_data_parallel_gradients_equal_full_batch():
     for rank, loss, grads in got:
         for k in p:
             close(torch.from_numpy(grads[k]), want[k], 1e-5, "rank %d averaged grad of %s" % (rank, k))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the reference's own training step (oracle/gen_golden.py --train-only: DDPM.forward -> p_losses -> backward of the REAL
+# reference): tests/golden/*_train_*.npz
+# ------------------------------------------------------------------------------------------------------------------------------
+def block_type(name):
+    """Which kind of block a state-dict tensor belongs to (for the per-block-type error report)."""
+    rules = (("time_embed", "time_embed"), ("emb_layers", "resblock.emb"), ("cond_stage_model", "prompt embedding"),
+             ("relative_position_embedding", "attention tables"), ("C_embedding", "attention tables"),
+             ("transformer_blocks.0.attn", "attention linears"), ("transformer_blocks.0.ff", "feed-forward"),
+             ("transformer_blocks.0.norm", "layer norms"), ("proj_in", "transformer proj"), ("proj_out", "transformer proj"),
+             ("s4_model.kernel", "s4 kernel generator"), ("s4_model", "s4 D / output_linear"), ("out_layer", "s4 out conv"),
+             ("in_layers", "resblock convs / norms"), ("out_layers", "resblock convs / norms"), ("skip_connection", "resblock convs / norms"),
+             ("nin_shortcut", "resnet block"), ("block.", "resnet block"), ("downsample", "resampling convs"), (".conv.", "resampling convs"),
+             ("conv_in", "plain convs"), ("input_blocks.0.0", "plain convs"), (".out.", "out head"), (".norm.", "group norms"))
+    for pat, kind in rules:
+        if pat in name:
+            return kind
+    return "other"
+
+
+def _load_train_fixture(case, z, B):
+    from oracle import cases, weights
+    g = np.load(os.path.join(cases.GOLDEN, "%s_train_z%d_B%d.npz" % (case["name"], z, B)))
+    man = weights.load_manifest(os.path.join(cases.GOLDEN, case["manifest"]))
+    sd = weights.set_s4_lengths(weights.make_state_dict(man, seed=0), case["unet"], z)
+    seed = int(g["seed"])
+    note_t, mel, ids = cases.train_batch(case, seed, B, z, sd["model.cond_stage_model.embedding.weight"].shape[0])
+    return g, sd, seed, {"note": note_t, "audio": mel, "feature": ids}
+
+
+def _check_against_train_fixture(case, g, seed, loss, grads, tol_norm, tol_elem):
+    """loss, the L2 norm of EVERY gradient tensor and the stored gradients (all of them for the tiny model; a spread over every
+    block type, sampled above 8192 elements, for the shipped one) against the real reference's."""
+    from oracle import cases
+    assert abs(float(loss) - float(g["loss"])) <= 2e-5 * max(1.0, abs(float(g["loss"]))), (float(loss), float(g["loss"]))
+    names = [str(n) for n in g["names"]]
+    assert sorted(grads) == names, "gradient set differs from the reference's: %s" % sorted(set(grads) ^ set(names))[:6]
+    worst = {}
+    gmax = float(np.max(g["absmax"]))
+    ZERO_GRAD = 1e-6 * gmax
+    for n, ref_norm, ref_max in zip(names, g["norms"], g["absmax"]):
+        got = float(grads[n].double().norm())
+        rel = abs(got - ref_norm) / max(ref_norm, 1e-12)
+        if ref_max < ZERO_GRAD:                     # analytically zero (a bias in front of a GroupNorm): rounding noise on both sides
+            assert got <= 1e-4 * gmax * max(1.0, grads[n].numel() ** 0.5), "gradient of %s should vanish: |g| %.3e" % (n, got)
+            continue
+        bt = block_type(n)
+        worst[bt] = max(worst.get(bt, (0.0, "")), (rel, n))
+        assert rel <= tol_norm, "|grad| of %s: %.6e, reference %.6e" % (n, got, ref_norm)
+    print("worst relative error of a gradient NORM per block type (vs the reference's DDPM.p_losses backward):")
+    for bt, (rel, n) in sorted(worst.items()):
+        print("   %-26s %.2e   %s" % (bt, rel, n))
+    worst = {}
+    for i, n in enumerate(str(x) for x in g["full_names"]):
+        ref = torch.from_numpy(g["g%d" % i]).reshape(-1)
+        got = grads[n].detach().cpu().reshape(-1)
+        if got.numel() > 8192:
+            got = got[torch.from_numpy(cases.train_sample_index(seed, i, got.numel()))]
+        d, sc = (got - ref).abs().max().item(), ref.abs().max().item()
+        if sc < ZERO_GRAD:
+            continue
+        bt = block_type(n)
+        worst[bt] = max(worst.get(bt, (0.0, "")), (d / sc, n))
+        assert d <= tol_elem * sc, "gradient of %s: max|diff| %.3e (reference max %.3e)" % (n, d, sc)
+    print("worst element error / max|reference| per block type over the %d stored gradients:" % len(g["full_names"]))
+    for bt, (rel, n) in sorted(worst.items()):
+        print("   %-26s %.2e   %s" % (bt, rel, n))
+
+
+def test_tiny_training_step_vs_reference_golden(lib):
+    """The whole step -- frozen VAE encode -> mode(), q_sample, prompt embedding, wave encoder, U-Net, smooth-L1, backward -- on the
+    tiny model against the REAL reference's DDPM.forward / p_losses / backward (fixture from oracle/gen_golden.py --train-only)."""
+    from oracle import cases
+    from mug import train
+    case, z, B = cases.TINY, 32, 2
+    g, sd, seed, batch = _load_train_fixture(case, z, B)
+    loss, grads = train.training_step_from_batch(lib, sd, case["unet"], case["wave"], case["vae"], batch, torch.from_numpy(g["t"]), torch.from_numpy(g["noise"]))
+    x0 = train.encode_x0(lib, sd, case["vae"], batch["note"]).cpu()
+    assert (x0 - torch.from_numpy(g["x_start"])).abs().max().item() <= 1e-4 * max(1.0, float(np.abs(g["x_start"]).max()))
+    _check_against_train_fixture(case, g, seed, loss, grads, tol_norm=1e-4, tol_elem=3e-4)
+
+
+@pytest.mark.gpu
+def test_shipped_training_step_vs_reference_golden_and_autograd(gpu_lib):
+    """configs[4]'s model: the SHIPPED architecture's whole training step (151 M parameters, 1327 gradient tensors) against
+    (a) the real reference's DDPM.forward / p_losses / backward fixture (loss, every gradient's norm, 31 gradients across all block
+    types) and (b) torch autograd through the oracle's restatement for EVERY tensor, element by element."""
+    from oracle import cases, nets
+    from mug import train
+    lib = gpu_lib
+    case, z, B = cases.FULL, 96, 2
+    g, sd, seed, batch = _load_train_fixture(case, z, B)
+    t, noise = torch.from_numpy(g["t"]), torch.from_numpy(g["noise"])
+    loss, grads = train.training_step_from_batch(lib, sd, case["unet"], case["wave"], case["vae"], batch, t, noise)
+    _check_against_train_fixture(case, g, seed, loss, grads, tol_norm=1e-4, tol_elem=3e-4)
+    # (b) autograd through the oracle, all tensors
+    trainable = [str(n) for n in g["names"]]
+    st = {k: (v.clone().requires_grad_(True) if k in trainable else v) for k, v in sd.items()}
+    x0 = torch.from_numpy(g["x_start"])
+    xt = st["sqrt_alphas_cumprod"][t][:, None, None] * x0 + st["sqrt_one_minus_alphas_cumprod"][t][:, None, None] * noise
+    pred = nets.unet_forward(st, case["unet"], xt, t, nets.cond_embed(st, batch["feature"]), nets.wave_encode(st, case["wave"], batch["audio"]))
+    lt = (F.smooth_l1_loss(noise, pred, beta=0.02, reduction="none") + 0.01).mean(dim=[1, 2]).mean()
+    lt.backward()
+    assert abs(float(lt) - float(g["loss"])) == 0.0 or abs(float(lt) - float(g["loss"])) < 1e-6
+    worst = {}
+    gmax = float(np.max(g["absmax"]))
+    for k in trainable:
+        a, b = grads[k].detach().cpu().reshape(st[k].shape), st[k].grad
+        d, sc = (a - b).abs().max().item(), b.abs().max().item()
+        if sc < 1e-6 * gmax:
+            continue
+        bt = block_type(k)
+        worst[bt] = max(worst.get(bt, (0.0, "")), (d / sc, k))
+        assert d <= 3e-4 * sc, "gradient of %s: max|diff| %.3e (autograd max %.3e)" % (k, d, sc)
+    print("worst element error / max|autograd| per block type over all %d tensors:" % len(trainable))
+    for bt, (rel, n) in sorted(worst.items()):
+        print("   %-26s %.2e   %s" % (bt, rel, n))
