@@ -55,7 +55,8 @@ int mugd_synchronize(mugd_ctx* ctx);
  * host synchronisation (the Python binding does this around every entry point).  other == the context's own stream: no-op. */
 int mugd_order_after(mugd_ctx* ctx, void* other_stream);
 int mugd_order_before(mugd_ctx* ctx, void* other_stream);
-/* DDIM loop launch mode.  1 (default): replay each DDIM step from a captured hipGraph; 0: launch kernels eagerly;
+/* DDIM loop launch mode.  0 (default since round 3: measured 5 % faster, profiles/r3_graph_vs_eager.txt): launch kernels eagerly;
+ * 1: replay each DDIM step from a captured hipGraph;
  * 2: capture the whole S-step loop into ONE graph (one hipGraphLaunch per sampling call; re-captured when S changes). */
 int mugd_set_graph_mode(mugd_ctx* ctx, int enabled);
 /* Tuning / test knob: force the conv_gemm decomposition for networks COMPILED and operators run after the call
@@ -219,7 +220,19 @@ int mugd_op_gn_s4_conv(mugd_ctx* ctx, const float* u, const float* k, const floa
 int mugd_op_timestep_embedding(mugd_ctx* ctx, const int64_t* t, float* out, int B, int dim);
 
 /* ---- training (BASELINE configs[4]): loss pieces, one forward / backward entry point per block type, AdamW.
- * mug-diffusion_amd/mug/train.py strings them into the whole-model DDPM training step.  fp32. ------------------ */
+ * mug-diffusion_amd/mug/train.py strings them into the whole-model DDPM training step.  None of these entry
+ * points synchronises the host: work is enqueued on the context's stream (order it against other streams with mugd_order_*). ---- */
+/* Arithmetic of the training GEMMs (conv / Linear forward, data gradients, weight gradients): 0 (default) fp32-input MFMA -- the
+ * parity mode, bitwise an fp32 fma chain; 1 bf16-input MFMA with fp32 accumulation (BASELINE configs[4]: bf16; replaces what the
+ * reference would get from Lightning's `precision: bf16`, main.py / configs/mug/mug_diffusion.yaml:151): operands are rounded to
+ * bfloat16 on their way into the matrix cores; master weights, activations in memory, norms, softmax, S4 and reductions stay fp32. */
+int mugd_train_set_precision(mugd_ctx* ctx, int bf16);
+/* Channel concatenation of (B, C, T) tensors and its gradient (unet.py:114-118 AudioConcatBlock, :542 skip th.cat):
+ * out = cat([a, b], dim = 1);   split: a (+)= src[:, :Ca], b (+)= src[:, Ca:] (a or b may be NULL; accumulate_x: add instead of store);
+ * add: out = a + b (n elements; out may alias either). */
+int mugd_train_concat(mugd_ctx* ctx, const float* a, const float* b, float* out, int B, int Ca, int Cb, int T);
+int mugd_train_split(mugd_ctx* ctx, const float* src, float* a, float* b, int B, int Ca, int Cb, int T, int accumulate_a, int accumulate_b);
+int mugd_train_add(mugd_ctx* ctx, const float* a, const float* b, float* out, int64_t n);
 /* mug/diffusion/diffusion.py:326-333 q_sample: out = sqrt_alphas_cumprod[t_b] x0 + sqrt_one_minus_alphas_cumprod[t_b] noise.
  * x0 / noise / out: (B, n) fp32; t: (B) int64; the two schedule buffers: the model's registered buffers (fp32, 1000 entries). */
 int mugd_train_q_sample(mugd_ctx* ctx, const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac, const float* sqrt_1mac,
@@ -235,7 +248,7 @@ typedef struct {
 typedef struct {
     float *gn1_w, *gn1_b, *conv1_w, *conv1_b, *emb_w, *emb_b, *gn2_w, *gn2_b, *conv2_w, *conv2_b, *skip_w, *skip_b;
 } mugd_resblock_grads;
-/* y = block(x, emb) (B, Cout, T); given dy: dx (B, Cin, T), demb (B, Kemb) and every parameter gradient.  Synchronises.
+/* y = block(x, emb) (B, Cout, T); given dy: dx (B, Cin, T), demb (B, Kemb) and every parameter gradient.
  * Every mugd_train_* block entry point runs FORWARD ONLY when dy is NULL (dx / gradient pointers are then ignored): a training step
  * keeps the block inputs of its forward sweep and calls the block again with dy in the backward sweep (block-level checkpointing).
  * `state` (last argument of the five block entry points, nullable): forward-only call with state != NULL -> the block KEEPS its forward

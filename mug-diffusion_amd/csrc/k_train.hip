@@ -256,6 +256,27 @@ __global__ void pair_sum_kernel(const float* src, float* dst, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = src[2 * i] + src[2 * i + 1];
 }
 
+// channel concat / split of (B, C, T) tensors (the U-Net's skip and audio concatenations, unet.py:114-118,542, and their gradients):
+// out[b][c][t] = c < Ca ? a[b][c][t] : bsrc[b][c - Ca][t], float4 granules (T % 4 == 0) or scalars
+__global__ void concat2_kernel(const float* a, const float* bsrc, float* out, long long na, long long nb, long long nrow_a, long long nrow_b, int B) {
+    // per batch row: na = Ca * T elements of a, nb = Cb * T of b
+    const long long per = na + nb, total = per * B;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / per, r = i - b * per;
+        out[i] = r < na ? a[b * nrow_a + r] : bsrc[b * nrow_b + (r - na)];
+    }
+}
+// the reverse: a (+)= src[:, :Ca], b (+)= src[:, Ca:]  (either destination may be null)
+__global__ void split2_kernel(const float* src, float* a, float* bdst, long long na, long long nb, int B, int acc_a, int acc_b) {
+    const long long per = na + nb, total = per * B;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / per, r = i - b * per;
+        const float v = src[i];
+        if (r < na) { if (a) { float* d = a + b * na + r; *d = acc_a ? *d + v : v; } }
+        else if (bdst) { float* d = bdst + b * nb + (r - na); *d = acc_b ? *d + v : v; }
+    }
+}
+
 __device__ __forceinline__ double wg_sum(double v, double* red) {        // 256-thread workgroup sum, result to every thread
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
@@ -415,6 +436,14 @@ void launch_q_sample(hipStream_t st, const float* x0, const float* noise, const 
 }
 void launch_smooth_l1(hipStream_t st, const float* pred, const float* target, float beta, float add, float* loss, float* grad, int B, long long n) {
     hipLaunchKernelGGL(smooth_l1_kernel, dim3(B), dim3(256), 0, st, pred, target, beta, add, loss, grad, B, n);
+}
+void launch_concat2(hipStream_t st, const float* a, const float* b, float* out, int B, int Ca, int Cb, int T) {
+    const long long na = (long long)Ca * T, nb = (long long)Cb * T, total = (na + nb) * B;
+    hipLaunchKernelGGL(concat2_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 16384)), dim3(256), 0, st, a, b, out, na, nb, na, nb, B);
+}
+void launch_split2(hipStream_t st, const float* src, float* a, float* b, int B, int Ca, int Cb, int T, int acc_a, int acc_b) {
+    const long long na = (long long)Ca * T, nb = (long long)Cb * T, total = (na + nb) * B;
+    hipLaunchKernelGGL(split2_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 16384)), dim3(256), 0, st, src, a, b, na, nb, B, acc_a, acc_b);
 }
 void launch_transpose_flip(hipStream_t st, const float* src, float* dst, int M, int C, int taps) {
     const long long total = (long long)M * C * taps;

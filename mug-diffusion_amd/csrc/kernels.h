@@ -310,6 +310,8 @@ void launch_q_sample(hipStream_t st, const float* x0, const float* noise, const 
                      float* out, int B, long long n);
 void launch_smooth_l1(hipStream_t st, const float* pred, const float* target, float beta, float add, float* loss, float* grad, int B, long long n);
 void launch_transpose_flip(hipStream_t st, const float* src, float* dst, int M, int C, int taps);
+void launch_concat2(hipStream_t st, const float* a, const float* b, float* out, int B, int Ca, int Cb, int T);            // out = cat([a, b], dim = 1)
+void launch_split2(hipStream_t st, const float* src, float* a, float* b, int B, int Ca, int Cb, int T, int acc_a, int acc_b);   // a (+)= src[:, :Ca]; b (+)= src[:, Ca:]
 void launch_bias_grad(hipStream_t st, const float* x, float* out, int B, int M, int T, int accumulate, double* partial /* B * M */);
 void launch_time_sum(hipStream_t st, const float* x, float* rows, int BM, int T);
 // conv weight gradient; KS = wgrad_splits(...) K-slices need a partial buffer of KS * M * C * taps floats (KS == 1: none)
@@ -356,6 +358,30 @@ void launch_emb_linear_bwd(hipStream_t st, const float* e, const float* We, cons
 void launch_emb_linear_bwd_plain(hipStream_t st, const float* e, const float* We, const float* dE, float* dWe, float* dbe, float* de, int B, int K, int M);
 void launch_embedding_bwd(hipStream_t st, const long long* ids, const float* dctx, float* dtable, int B, int ntok, int dim, int rows);
 void launch_adamw(hipStream_t st, float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd, int step);
+
+// ---------------------------------------------------------------------------------------
+// k_tgemm.hip: the training GEMMs on the bf16 matrix cores (fp32 accumulation; operands rounded to bf16 on their way into the MFMA)
+// ---------------------------------------------------------------------------------------
+struct TConvArgs {           // y[b][m][t] = bias[m] + rowadd[b][m] + resid[b][m][t] + sum_{c,tap} W[m][c][tap] x[b][c][stride t + tap dil - pad]
+    const float* x;                  // (B, C, Tin)
+    const unsigned short* wpk;       // bf16 A fragments from launch_tpack_weights (rows = M, K = C)
+    const float* bias;               // [M] or null
+    const float* rowadd; int rowadd_stride;      // [B][rowadd_stride] or null
+    const float* resid;              // (B, M, Tout) or null (may alias y)
+    float* y;                        // (B, M, Tout)
+    int B, C, Tin, M, Tout, taps, dil, stride, pad, ups;
+    int nkb, gx, gy;                 // set by the launcher
+};
+struct TWgradArgs {          // dW[m][c][tap] = sum_{b,t} dY[b][m][t] X[b][c][stride t + tap dil - pad]
+    const float* dY; const float* X; float* dW;
+    int B, M, C, Tout, Tin, taps, pad, dil, stride, ups, KS;
+};
+size_t tpack_elems(int rows, int K, int taps);               // bf16 elements of the packed form
+// A[row][k][tap] = src[row * s_row + k * s_k + (flip ? taps - 1 - tap : tap)]  ->  bf16 MFMA A-fragment order (zero padded to 32 rows / 16 k)
+void launch_tpack_weights(hipStream_t st, const float* src, unsigned short* dst, int rows, int K, int taps, long long s_row, long long s_k, int flip);
+void launch_tconv_bf16(hipStream_t st, const TConvArgs& a);
+int twgrad_splits(int B, int M, int C, int Tout, int taps);
+void launch_twgrad_bf16(hipStream_t st, const TWgradArgs& a, float* partial /* KS * M * C * taps floats when KS > 1 */);
 
 void launch_embed_tokens(hipStream_t st, const float* table, const long long* ids, float* out, int B, int ntok, int dim);
 void launch_bias_sum(hipStream_t st, const float* a, const float* b, float* out, int n);

@@ -37,7 +37,7 @@ struct Ctx {
     bool own_stream = false;
     hipEvent_t order_event = nullptr;     // mugd_order_after / mugd_order_before
     std::string last_error;
-    int use_graph = 1;         // DDIM loop: 0 eager launches | 1 one hipGraph per step, replayed S times | 2 the whole S-step loop as ONE graph
+    int use_graph = 0;         // DDIM loop: 0 eager launches (default: fastest, profiles/r3_graph_vs_eager.txt) | 1 one hipGraph per step, replayed S times | 2 the whole S-step loop as ONE graph
     float* scratch = nullptr; size_t scratch_cap = 0;   // grow-only device scratch of the context-level operators (log_mel): no malloc / sync per call
     std::map<std::pair<int, int>, float*> resample_taps;   // device copies of the polyphase filters, per reduced (up, down)
     int force_wk = 0, force_tn = 0;   // mugd_set_conv_tiling: 0 = pick per layer
@@ -47,6 +47,7 @@ struct Ctx {
     bool s4_symmetric = false;  // mugd_set_s4_symmetric / MUGD_S4_SYMMETRIC=1: Cauchy sum over both conjugate halves (kernels.h: S4GenArgs)
     bool fold_proj_out = true;  // false (MUGD_NO_PROJ_FOLD=1): ff.net.2 and the transformer's proj_out as two launches instead of one with pre-multiplied weights
     bool fold_xattn = true;     // false (MUGD_NO_XATTN_FOLD=1): cross-attention as to_q -> attention kernel -> to_out instead of the folded two-GEMM form
+    bool train_bf16 = false;    // mugd_train_set_precision: the training GEMMs (conv / Linear forward, data and weight gradients) on the bf16 matrix cores
     bool fuse_norm = true;      // false (MUGD_UNFUSED_NORM=1): materialise GroupNorm / LayerNorm outputs with the stand-alone kernels (A/B + debugging)
 };
 

@@ -1,6 +1,9 @@
-// extern "C" entry points of the training slice (include/mugd.h, "training slice"): the DDPM loss pieces and one
-// TimestepResBlock forward + backward, composed from conv_gemm (forward AND data gradients), the stand-alone GroupNorm
-// kernel and the kernels of k_train.hip.  Scratch tensors live for the call only.
+// extern "C" entry points of the training slice (include/mugd.h, "training slice"): the DDPM loss pieces and the forward + backward
+// of every block type, composed from the conv GEMMs (forward AND data gradients), the weight-gradient GEMM, the stand-alone
+// GroupNorm kernel and the kernels of k_train*.hip.  Two arithmetic modes (mugd_train_set_precision): fp32 (conv_gemm /
+// wgrad_mfma on the fp32 matrix cores: the parity mode) and bf16 (k_tgemm.hip: bf16 MFMA inputs, fp32 accumulation -- BASELINE
+// configs[4]'s precision).  Nothing here synchronises the host: every kernel goes to the context's stream, scratch blocks are
+// recycled in stream order (a block handed back to the pool is only ever reused by later work on the same stream).
 #include "../../include/mugd.h"
 
 #include <algorithm>
@@ -26,8 +29,9 @@ int guarded(mugd_ctx* ctx, F&& f) {
     }
 }
 
-// call-scoped scratch from the context's pool (ctx.h); every entry point synchronises its stream before returning, so the
-// blocks are idle when the destructor hands them back
+// call-scoped scratch from the context's pool (ctx.h).  The blocks go back to the pool when the call returns although its kernels
+// may still be queued: the pool only serves this context, whose work is all on ONE stream, so the next user of a block is
+// ordered behind them
 struct Scratch {
     TrainPool& pool;
     hipStream_t stream;
@@ -90,11 +94,30 @@ struct Inter {
     }
 };
 
-// y = conv1d(x; w) (+ bias) (+ rowadd[b][m]) (+ resid): w is a plain (M, C, taps) tensor, packed here
-void run_conv(Ctx& c, Scratch& sc, const float* x, const float* w, const float* bias, const float* rowadd, int rowadd_stride,
-              const float* resid, float* y, int B, int C, int T, int M, int taps, int pad, int dil = 1, int stride = 1, int ups = 0, int Tout = -1) {
+// y = conv1d(x; w) (+ bias) (+ rowadd[b][m]) (+ resid): w is a plain (M, C, taps) tensor, packed here.
+// wt_src (optional, with `transposed`): the conv runs on the transposed, tap-flipped form of the (C_of_x = rows of w, M = ..., taps)
+// tensor `w` -- the data gradient of a conv: x is the upstream gradient (B, Mw, T), the result has Cw channels.  fp32 mode packs from a
+// transposed copy (transpose_flip_kernel into `wt`), bf16 mode packs straight from w with swapped strides.
+void run_conv_ex(Ctx& c, Scratch& sc, const float* x, const float* w, bool transposed, float* wt, const float* bias, const float* rowadd, int rowadd_stride,
+                 const float* resid, float* y, int B, int C, int T, int M, int taps, int pad, int dil, int stride, int ups, int Tout) {
     MUGD_CHECK(C % CONV_CK == 0, MUGD_ERR_INVALID, "training slice: channel counts must be multiples of 16");
     hipStream_t st = c.stream;
+    if (c.train_bf16) {
+        unsigned short* wpk = reinterpret_cast<unsigned short*>(sc.get((tpack_elems(M, C, taps) + 1) / 2, false, st));
+        // plain: A[m][ci][tap] = w[m][ci][tap];  transposed: w is (C, M, taps) and A[m][ci][tap] = w[ci][m][taps - 1 - tap]
+        if (transposed) launch_tpack_weights(st, w, wpk, M, C, taps, taps, (long long)M * taps, 1);
+        else launch_tpack_weights(st, w, wpk, M, C, taps, (long long)C * taps, taps, 0);
+        TConvArgs a{};
+        a.x = x; a.wpk = wpk; a.bias = bias; a.rowadd = rowadd; a.rowadd_stride = rowadd_stride; a.resid = resid; a.y = y;
+        a.B = B; a.C = C; a.Tin = T; a.M = M; a.Tout = Tout > 0 ? Tout : T; a.taps = taps; a.dil = dil; a.stride = stride; a.pad = pad; a.ups = ups;
+        launch_tconv_bf16(st, a);
+        return;
+    }
+    if (transposed) {
+        MUGD_CHECK(wt, MUGD_ERR_INTERNAL, "transposed conv needs a staging buffer in fp32 mode");
+        launch_transpose_flip(st, w, wt, C, M, taps);            // (C, M, taps) -> (M, C, taps), taps reversed
+        w = wt;
+    }
     const int MT = cdiv(M, 32);
     const long long mts = (long long)(C / CONV_CK) * taps * 512;
     float* wpk = sc.get((size_t)MT * mts, true, st);
@@ -108,10 +131,25 @@ void run_conv(Ctx& c, Scratch& sc, const float* x, const float* w, const float* 
     if (a.tn == 16) launch_pack_weights16(st, pa); else launch_pack_weights(st, pa);
     launch_conv(st, a);
 }
+void run_conv(Ctx& c, Scratch& sc, const float* x, const float* w, const float* bias, const float* rowadd, int rowadd_stride,
+              const float* resid, float* y, int B, int C, int T, int M, int taps, int pad, int dil = 1, int stride = 1, int ups = 0, int Tout = -1) {
+    run_conv_ex(c, sc, x, w, false, nullptr, bias, rowadd, rowadd_stride, resid, y, B, C, T, M, taps, pad, dil, stride, ups, Tout);
+}
+// data gradient of y = conv1d(a; w (Mw, Cw, taps), pad, dil) at stride 1: da (+= resid) = conv1d(dy; w transposed + flipped, pad' = dil (taps - 1) - pad)
+void run_dgrad(Ctx& c, Scratch& sc, const float* dy, const float* w, float* wt, const float* resid, float* da, int B, int Mw, int Cw, int T, int taps, int pad,
+               int dil = 1) {
+    run_conv_ex(c, sc, dy, w, true, wt, nullptr, nullptr, 0, resid, da, B, Mw, T, Cw, taps, dil * (taps - 1) - pad, dil, 1, 0, -1);
+}
 
 // weight gradient with split-K partials from the call's scratch
 void run_wgrad(Ctx& c, Scratch& sc, const float* dY, const float* A, float* dW, int B, int M, int C, int Tout, int Tin, int taps, int pad, int dil = 1,
                int stride = 1, int ups = 0) {
+    if (c.train_bf16) {
+        TWgradArgs a{dY, A, dW, B, M, C, Tout, Tin, taps, pad, dil, stride, ups, twgrad_splits(B, M, C, Tout, taps)};
+        float* part = a.KS > 1 ? sc.get((size_t)a.KS * M * C * taps, false, c.stream) : nullptr;
+        launch_twgrad_bf16(c.stream, a, part);
+        return;
+    }
     const int ks = wgrad_splits(B, M, C, Tout);
     float* part = ks > 1 ? sc.get((size_t)ks * M * C * taps, false, c.stream) : nullptr;
     launch_wgrad_ex(c.stream, dY, A, dW, B, M, C, Tout, Tin, taps, pad, dil, stride, ups, part, ks);
@@ -153,10 +191,7 @@ struct Lin {
     void bwd(const float* x, const float* w, const float* dy, float* dx, bool acc, float* dW, float* db, int K, int M, float* wt) {
         if (dW) run_wgrad(c, sc, dy, x, dW, B, M, K, T, T, 1, 0);
         if (db) run_bias_grad(c, sc, dy, db, B, M, T);
-        if (dx) {
-            launch_transpose_flip(c.stream, w, wt, M, K, 1);
-            run_conv(c, sc, dy, wt, nullptr, nullptr, 0, acc ? dx : nullptr, dx, B, M, T, K, 1, 0);
-        }
+        if (dx) run_dgrad(c, sc, dy, w, wt, acc ? dx : nullptr, dx, B, M, K, T, 1, 0);
     }
 };
 
@@ -191,7 +226,7 @@ void resblock_impl(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x,
             run_conv(c, sc, a2, p->conv2_w, p->conv2_b, nullptr, 0, x, y, B, Cout, T, Cout, 3, d2, d2);
         }
     }
-    if (!dy) { HIP_CHECK(hipStreamSynchronize(st)); in.keep(); return; }
+    if (!dy) { in.keep(); return; }
     if (dy) {
         float* da2 = sc.get(nout, false, st);
         float* dh = sc.get(nout, false, st);
@@ -200,8 +235,7 @@ void resblock_impl(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x,
         // out_layers conv: dW2, db2, da2 = conv3(dy; W2 transposed + flipped)
         run_wgrad(c, sc, dy, a2, g->conv2_w, B, Cout, Cout, T, T, 3, d2, d2);
         run_bias_grad(c, sc, dy, g->conv2_b, B, Cout, T);
-        launch_transpose_flip(st, p->conv2_w, wt, Cout, Cout, 3);
-        run_conv(c, sc, dy, wt, nullptr, nullptr, 0, nullptr, da2, B, Cout, T, Cout, 3, d2, d2);
+        run_dgrad(c, sc, dy, p->conv2_w, wt, nullptr, da2, B, Cout, Cout, T, 3, d2, d2);
         run_gn_bwd(c, sc, h, da2, p->gn2_w, p->gn2_b, dh, g->gn2_w, g->gn2_b, B, Cout, T, groups, 1);
         if (emb) {          // h = conv1 + b1 + E: time-embedding branch
             float* dE = sc.get((size_t)B * Cout, false, st);
@@ -210,19 +244,16 @@ void resblock_impl(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x,
         }
         run_wgrad(c, sc, dh, a1, g->conv1_w, B, Cout, Cin, T, T, 3, d1, d1);
         run_bias_grad(c, sc, dh, g->conv1_b, B, Cout, T);
-        launch_transpose_flip(st, p->conv1_w, wt, Cout, Cin, 3);
-        run_conv(c, sc, dh, wt, nullptr, nullptr, 0, nullptr, da1, B, Cout, T, Cin, 3, d1, d1);
+        run_dgrad(c, sc, dh, p->conv1_w, wt, nullptr, da1, B, Cout, Cin, T, 3, d1, d1);
         run_gn_bwd(c, sc, x, da1, p->gn1_w, p->gn1_b, dx, g->gn1_w, g->gn1_b, B, Cin, T, groups, 1);
         if (p->skip_w) {
             run_wgrad(c, sc, dy, x, g->skip_w, B, Cout, Cin, T, T, 1, 0);
             run_bias_grad(c, sc, dy, g->skip_b, B, Cout, T);
-            launch_transpose_flip(st, p->skip_w, wt, Cout, Cin, 1);
-            run_conv(c, sc, dy, wt, nullptr, nullptr, 0, dx, dx, B, Cout, T, Cin, 1, 0);
+            run_dgrad(c, sc, dy, p->skip_w, wt, dx, dx, B, Cout, Cin, T, 1, 0);
         } else {
             launch_bias_sum(st, dx, dy, dx, (int)nin);          // dx += dy
         }
     }
-    HIP_CHECK(hipStreamSynchronize(st));
 }
 
 }  // namespace
@@ -253,15 +284,14 @@ int mugd_train_conv(mugd_ctx* ctx, const float* w, const float* bias, const floa
             a = an;
         }
         if (!in.replay) run_conv(c, sc, a, w, bias, nullptr, 0, nullptr, y, B, Cin, Tin, Cout, taps, pad, dil, stride, ups, Tout);
-        if (!dy) { HIP_CHECK(hipStreamSynchronize(st)); in.keep(); return; }
+        if (!dy) { in.keep(); return; }
         // ---- backward
         run_wgrad(c, sc, dy, a, dw, B, Cout, Cin, Tout, Tin, taps, pad, dil, stride, ups);
         if (db) run_bias_grad(c, sc, dy, db, B, Cout, Tout);
         float* da = gn_w ? sc.get(nin, false, st) : dx;
         float* wt = sc.get((size_t)Cout * Cin * 3, true, st);
         if (mode == 0) {
-            launch_transpose_flip(st, w, wt, Cout, Cin, taps);
-            run_conv(c, sc, dy, wt, nullptr, nullptr, 0, nullptr, da, B, Cout, Tout, Cin, taps, dil * (taps - 1) - pad, dil);
+            run_dgrad(c, sc, dy, w, wt, nullptr, da, B, Cout, Cin, Tout, taps, pad, dil);
         } else if (mode == 1) {
             // x index s = 2 t + tap:  even s = 2u <- taps 0 (t = u) and 2 (t = u - 1);  odd s = 2u + 1 <- tap 1 (t = u)
             float* wo = sc.get((size_t)Cout * Cin, false, st);
@@ -274,12 +304,10 @@ int mugd_train_conv(mugd_ctx* ctx, const float* w, const float* bias, const floa
             launch_interleave_parity(st, od, da, (long long)B * Cin, Tout, 1);
         } else {
             float* dxu = sc.get((size_t)B * Cin * Tout, false, st);
-            launch_transpose_flip(st, w, wt, Cout, Cin, 3);
-            run_conv(c, sc, dy, wt, nullptr, nullptr, 0, nullptr, dxu, B, Cout, Tout, Cin, 3, 1);
+            run_dgrad(c, sc, dy, w, wt, nullptr, dxu, B, Cout, Cin, Tout, 3, 1);
             launch_pair_sum(st, dxu, da, (long long)nin);
         }
         if (gn_w) run_gn_bwd(c, sc, x, da, gn_w, gn_b, dx, dgn_w, dgn_b, B, Cin, Tin, groups, 1);
-        HIP_CHECK(hipStreamSynchronize(st));
     });
 }
 
@@ -309,13 +337,12 @@ int mugd_train_s4layer(mugd_ctx* ctx, const float* const* P, const float* x, con
             launch_glu_fwd(st, v, f, B, H, T);
             run_conv(c, sc, f, P[MUGD_S4_OUT_LAYER_W], P[MUGD_S4_OUT_LAYER_B], nullptr, 0, x, y, B, H, T, H, 3, 1);
         }
-        if (!dy) { HIP_CHECK(hipStreamSynchronize(st)); in.keep(); return; }
+        if (!dy) { in.keep(); return; }
         // ---- backward
         float *wt = buf((size_t)2 * H * H * 3), *df = buf(n), *dv = buf(2 * n), *dg = buf(n), *dpre = buf(n), *dn = buf(n), *dk = buf((size_t)H * T);
         run_wgrad(c, sc, dy, f, G[MUGD_S4_OUT_LAYER_W], B, H, H, T, T, 3, 1);
         run_bias_grad(c, sc, dy, G[MUGD_S4_OUT_LAYER_B], B, H, T);
-        launch_transpose_flip(st, P[MUGD_S4_OUT_LAYER_W], wt, H, H, 3);
-        run_conv(c, sc, dy, wt, nullptr, nullptr, 0, nullptr, df, B, H, T, H, 3, 1);
+        run_dgrad(c, sc, dy, P[MUGD_S4_OUT_LAYER_W], wt, nullptr, df, B, H, H, T, 3, 1);
         launch_glu_bwd(st, v, df, dv, B, H, T);
         lt.bwd(g, P[MUGD_S4_OUT_LIN_W], dv, dg, false, G[MUGD_S4_OUT_LIN_W], G[MUGD_S4_OUT_LIN_B], H, 2 * H, wt);
         launch_gelu_bwd(st, pre, dg, dpre, (long long)n);
@@ -325,7 +352,6 @@ int mugd_train_s4layer(mugd_ctx* ctx, const float* const* P, const float* x, con
         launch_s4_kernel_gen_bwd(st, gb);
         run_gn_bwd(c, sc, x, dn, P[MUGD_S4_NORM_W], P[MUGD_S4_NORM_B], dx, G[MUGD_S4_NORM_W], G[MUGD_S4_NORM_B], B, H, T, groups, 0);
         launch_bias_sum(st, dx, dy, dx, (int)n);          // + the identity skip
-        HIP_CHECK(hipStreamSynchronize(st));
     });
 }
 
@@ -378,7 +404,7 @@ int mugd_train_transformer(mugd_ctx* ctx, const float* const* P, const float* x,
             lt.fwd(f, P[MUGD_TF_FF2_W], P[MUGD_TF_FF2_B], h2, h3, Ch, C);
             lt.fwd(h3, P[MUGD_TF_PROJ_OUT_W], P[MUGD_TF_PROJ_OUT_B], x, y, C, C);
         }
-        if (!dy) { HIP_CHECK(hipStreamSynchronize(st)); in.keep(); return; }
+        if (!dy) { in.keep(); return; }
 
         // ---- backward
         const size_t wmax = (size_t)2 * Ch * C;
@@ -426,7 +452,6 @@ int mugd_train_transformer(mugd_ctx* ctx, const float* const* P, const float* x,
         lt.bwd(n0, P[MUGD_TF_PROJ_IN_W], dh, da, false, G[MUGD_TF_PROJ_IN_W], G[MUGD_TF_PROJ_IN_B], C, C, wt);
         run_gn_bwd(c, sc, x, da, P[MUGD_TF_NORM_W], P[MUGD_TF_NORM_B], dx, G[MUGD_TF_NORM_W], G[MUGD_TF_NORM_B], B, C, T, groups, 0);
         launch_bias_sum(st, dx, dy, dx, (int)n);          // + the identity skip
-        HIP_CHECK(hipStreamSynchronize(st));
     });
 }
 
@@ -477,6 +502,33 @@ int mugd_train_resnet_block(mugd_ctx* ctx, const mugd_resblock_params* p, const 
     return guarded(ctx, [&] { resblock_impl(ctx, p, x, nullptr, dy, y, dx, nullptr, g, B, Cin, Cout, T, 0, groups, dil1, dil2, state); });
 }
 
+int mugd_train_set_precision(mugd_ctx* ctx, int bf16) {
+    if (!ctx) return MUGD_ERR_INVALID;
+    ctx->c.train_bf16 = bf16 != 0;
+    return MUGD_OK;
+}
+
+int mugd_train_concat(mugd_ctx* ctx, const float* a, const float* b, float* out, int B, int Ca, int Cb, int T) {
+    return guarded(ctx, [&] {
+        MUGD_CHECK(a && b && out && B > 0 && Ca > 0 && Cb > 0 && T > 0, MUGD_ERR_INVALID, "null/empty argument");
+        launch_concat2(ctx->c.stream, a, b, out, B, Ca, Cb, T);
+    });
+}
+
+int mugd_train_split(mugd_ctx* ctx, const float* src, float* a, float* b, int B, int Ca, int Cb, int T, int accumulate_a, int accumulate_b) {
+    return guarded(ctx, [&] {
+        MUGD_CHECK(src && (a || b) && B > 0 && Ca > 0 && Cb > 0 && T > 0, MUGD_ERR_INVALID, "null/empty argument");
+        launch_split2(ctx->c.stream, src, a, b, B, Ca, Cb, T, accumulate_a, accumulate_b);
+    });
+}
+
+int mugd_train_add(mugd_ctx* ctx, const float* a, const float* b, float* out, int64_t n) {
+    return guarded(ctx, [&] {
+        MUGD_CHECK(a && b && out && n > 0 && n < (1ll << 31), MUGD_ERR_INVALID, "null/empty argument");
+        launch_bias_sum(ctx->c.stream, a, b, out, (int)n);
+    });
+}
+
 int mugd_train_release_states(mugd_ctx* ctx) {
     return guarded(ctx, [&] {
         HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
@@ -503,7 +555,6 @@ int mugd_train_time_embed(mugd_ctx* ctx, const float* w1, const float* b1, const
             launch_emb_linear_bwd(st, e1, w2, demb, dw2, db2, de1, B, M, M);
             launch_emb_linear_bwd_plain(st, temb, w1, de1, dw1, db1, nullptr, B, K, M);
         }
-        HIP_CHECK(hipStreamSynchronize(st));
     });
 }
 
@@ -512,7 +563,6 @@ int mugd_train_embedding_bwd(mugd_ctx* ctx, const int64_t* ids, const float* dco
     return guarded(ctx, [&] {
         MUGD_CHECK(ids && dcontext && dtable && B > 0 && ntok > 0 && dim > 0 && rows > 0, MUGD_ERR_INVALID, "null/empty argument");
         launch_embedding_bwd(ctx->c.stream, (const long long*)ids, dcontext, dtable, B, ntok, dim, rows);
-        HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
     });
 }
 

@@ -86,6 +86,10 @@ _SIGS = {
     "mugd_train_smooth_l1": [_p, _p, _p, _f, _f, _p, _p, _i, C.c_int64],
     "mugd_train_resblock": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "mugd_train_release_states": [_p],
+    "mugd_train_set_precision": [_p, _i],
+    "mugd_train_concat": [_p, _p, _p, _p, _i, _i, _i, _i],
+    "mugd_train_split": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i],
+    "mugd_train_add": [_p, _p, _p, _p, C.c_int64],
     "mugd_train_adamw_multi": [_p, _i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _f, _i],
     "mugd_train_conv": [_p] * 13 + [_i] * 8 + [_p],
     "mugd_train_resnet_block": [_p] * 7 + [_i] * 7 + [_p],
@@ -134,7 +138,8 @@ class MugdError(RuntimeError):
 
 
 _UNORDERED = {"mugd_create", "mugd_destroy", "mugd_net_destroy", "mugd_last_error", "mugd_version", "mugd_profile_kind_name",
-              "mugd_order_after", "mugd_order_before", "mugd_set_graph_mode", "mugd_set_conv_tiling", "mugd_set_s4_symmetric", "mugd_set_weight_precision", "mugd_remove_mini_jacks"}
+              "mugd_order_after", "mugd_order_before", "mugd_set_graph_mode", "mugd_set_conv_tiling", "mugd_set_s4_symmetric", "mugd_set_weight_precision", "mugd_remove_mini_jacks",
+              "mugd_train_set_precision"}
 
 
 class _OrderedDll:
@@ -231,6 +236,19 @@ class Lib:
 
     def f32(self, t):
         return t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+
+    # parameter-gradient tensors of the training entry points: zeroed, shaped like the parameter.  A training step installs a
+    # FlatGrads arena (mug/train.py) so that a whole step's 1327 gradient tensors are views of ONE buffer cleared by ONE fill
+    # instead of 1327 allocations + fills; without it every gradient is its own tensor.
+    grad_arena = None
+
+    def zgrad(self, like):
+        ar = self.grad_arena
+        if ar is not None:
+            g = ar.take(like)
+            if g is not None:
+                return g
+        return torch.zeros_like(like)
 
     def empty(self, *shape):
         return torch.empty(*shape, dtype=torch.float32, device=self.device)
@@ -451,7 +469,7 @@ class Lib:
                 keep.append(t)
                 setattr(P, f, t.data_ptr())
                 if want_grads:
-                    g = torch.zeros_like(t)
+                    g = self.zgrad(t)
                     keep.append(g)
                     grads[k] = g
                     setattr(G, f, g.data_ptr())
@@ -459,6 +477,33 @@ class Lib:
 
     def train_release_states(self):
         self.check(self.dll.mugd_train_release_states(self.ctx))
+
+    def train_set_precision(self, bf16):
+        """Training GEMMs on the bf16 matrix cores (fp32 accumulation; BASELINE configs[4]) instead of the fp32-input MFMA parity mode."""
+        self.check(self.dll.mugd_train_set_precision(self.ctx, 1 if bf16 else 0))
+
+    def train_concat(self, a, b):
+        """cat([a, b], dim=1) of (B, C, T) tensors (skip / audio concatenation)."""
+        a, b = self.f32(a), self.f32(b)
+        B, Ca, T = a.shape
+        out = self.empty(B, Ca + b.shape[1], T)
+        self.check(self.dll.mugd_train_concat(self.ctx, _ptr(a), _ptr(b), _ptr(out), B, Ca, b.shape[1], T))
+        return out
+
+    def train_split(self, src, Ca, acc_a=None, acc_b=None):
+        """(src[:, :Ca], src[:, Ca:]) as contiguous tensors; acc_a / acc_b: existing tensors the slice is ADDED to instead."""
+        src = self.f32(src)
+        B, Ct, T = src.shape
+        a = acc_a if acc_a is not None else self.empty(B, Ca, T)
+        b = acc_b if acc_b is not None else self.empty(B, Ct - Ca, T)
+        self.check(self.dll.mugd_train_split(self.ctx, _ptr(src), _ptr(a), _ptr(b), B, Ca, Ct - Ca, T, int(acc_a is not None), int(acc_b is not None)))
+        return a, b
+
+    def train_add(self, a, b, out=None):
+        """a + b natively (out may be a or b)."""
+        out = torch.empty_like(a) if out is None else out
+        self.check(self.dll.mugd_train_add(self.ctx, _ptr(a), _ptr(b), _ptr(out), a.numel()))
+        return out
 
     def train_resblock(self, params, x, emb, dy, groups=32, state=None):
         """TimestepResBlock forward + backward (unet.py:212-239).  params: dict with the module's tensors
@@ -498,7 +543,7 @@ class Lib:
         B, K = temb.shape
         M = w1.shape[0]
         emb = self.empty(B, M)
-        g = [torch.zeros_like(t) for t in (w1, b1, w2, b2)] if demb is not None else [None] * 4
+        g = [self.zgrad(t) for t in (w1, b1, w2, b2)] if demb is not None else [None] * 4
         self.check(self.dll.mugd_train_time_embed(self.ctx, _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(temb), _ptr(demb), _ptr(emb),
                                                   _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), B, K, M))
         return emb, ({} if demb is None else {"0.weight": g[0], "0.bias": g[1], "2.weight": g[2], "2.bias": g[3]})
@@ -508,7 +553,7 @@ class Lib:
         ids = ids.to(device=self.device, dtype=torch.int64).contiguous()
         dc = self.f32(dcontext)
         B, dim, ntok = dc.shape
-        dt = self.empty(rows, dim)
+        dt = self.empty(rows, dim)          # every row is written by the kernel
         self.check(self.dll.mugd_train_embedding_bwd(self.ctx, _ptr(ids), _ptr(dc), _ptr(dt), B, ntok, dim, rows))
         return dt
 
@@ -522,13 +567,13 @@ class Lib:
         Cout, _, taps = w.shape
         Tout = Tin // 2 if mode == 1 else (2 * Tin if mode == 2 else Tin)
         y = self.empty(B, Cout, Tout)
-        dx, dw = (None, None) if dy is None else (torch.empty_like(x), torch.zeros_like(w))
-        db = None if (b is None or dy is None) else torch.zeros_like(b)
+        dx, dw = (None, None) if dy is None else (torch.empty_like(x), self.zgrad(w))
+        db = None if (b is None or dy is None) else self.zgrad(b)
         gw = gb = dgw = dgb = None
         if gn is not None:
             gw, gb = self.f32(gn[0]), self.f32(gn[1])
             if dy is not None:
-                dgw, dgb = torch.zeros_like(gw), torch.zeros_like(gb)
+                dgw, dgb = self.zgrad(gw), self.zgrad(gb)
         self.check(self.dll.mugd_train_conv(self.ctx, _ptr(w), _ptr(b), _ptr(gw), _ptr(gb), _ptr(x), _ptr(dy), _ptr(y), _ptr(dx), _ptr(dw), _ptr(db),
                                             _ptr(dgw), _ptr(dgb), B, Cin, Cout, Tin, taps, int(dil), int(mode), int(groups), _sref(state)))
         return y, dx, dw, db, (None if (gn is None or dy is None) else (dgw, dgb))
@@ -551,7 +596,7 @@ class Lib:
             keep.append(t)
             PA[i] = t.data_ptr()
             if dy is not None:
-                g = torch.zeros_like(t)
+                g = self.zgrad(t)
                 keep.append(g)
                 grads[k] = g
                 GA[i] = g.data_ptr()
@@ -591,7 +636,7 @@ class Lib:
             keep.append(t)
             PA[i] = t.data_ptr()
             if dy is not None:
-                g = torch.zeros_like(t)
+                g = self.zgrad(t)
                 keep.append(g)
                 grads[k] = g
                 GA[i] = g.data_ptr()

@@ -6,9 +6,10 @@ of the S4 and resampling layers -- and with them `DDPM.training_step` (mug/diffu
 are built from these block entry points by `training_step` below: a forward sweep that keeps every block's INPUT, then a backward
 sweep that calls each block again with its upstream gradient.  By default the block keeps its forward intermediates between the
 two calls (a `TrainState`); with recompute=True it recomputes its own forward in the backward call instead (block-level
-checkpointing: 2 forwards + 1 backward per step, no whole-network activation storage).  All arithmetic is native; torch does the bookkeeping
-(channel concatenation / slicing of skip connections, gradient accumulation).  First version: every block call synchronises and
-allocates its scratch -- correct and gradient-checked against autograd, not yet tuned.
+checkpointing: 2 forwards + 1 backward per step, no whole-network activation storage).  All arithmetic is native, including the
+channel concatenation / slicing of the skip and audio connections and the gradient accumulation over them (mugd_train_concat /
+_split / _add); torch owns the tensors.  No entry point synchronises the host: a step is one uninterrupted stream of kernels.
+`lib.train_set_precision(True)` runs the GEMMs on the bf16 matrix cores (BASELINE configs[4]); the default is the fp32 parity mode.
 """
 import torch
 import torch.distributed as dist
@@ -46,6 +47,28 @@ def allreduce_gradients(grads, average=True, group=None):
     return grads
 
 
+def broadcast_parameters(sd, src=0, group=None, bucket_bytes=64 << 20):
+    """What DistributedDataParallel does at construction: every rank takes rank `src`'s trainable tensors (flat buckets, in place),
+    so data-parallel training cannot start from silently different initialisations.  No-op without an initialised process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    keys = [k for k, v in sd.items() if v.dtype == torch.float32 and k.startswith("model.")]
+    nccl = dist.get_backend(group) == "nccl"
+    i = 0
+    while i < len(keys):
+        chunk, nbytes = [], 0
+        while i < len(keys) and (not chunk or nbytes < bucket_bytes):
+            chunk.append(keys[i]); nbytes += sd[keys[i]].numel() * 4; i += 1
+        dev = sd[chunk[0]].device if nccl else torch.device("cpu")
+        flat = torch.cat([sd[k].reshape(-1).to(dev) for k in chunk])
+        dist.broadcast(flat, src=src, group=group)
+        off = 0
+        for k in chunk:
+            n = sd[k].numel()
+            sd[k].copy_(flat[off:off + n].reshape(sd[k].shape).to(sd[k].device))
+            off += n
+
+
 def adamw_step(lib, params, grads, state, step, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
     """torch.optim.AdamW semantics on a parameter dict, in place on device tensors; `state` holds exp_avg / exp_avg_sq.  One native
     call for the whole list."""
@@ -53,7 +76,7 @@ def adamw_step(lib, params, grads, state, step, lr=1e-4, betas=(0.9, 0.999), eps
     for k in keys:
         if k not in state:
             state[k] = (torch.zeros_like(params[k]), torch.zeros_like(params[k]))
-        assert params[k].is_contiguous() and params[k].dtype == torch.float32, k
+        assert params[k].is_contiguous() and params[k].dtype == torch.float32 and params[k].device == lib.device, k
     gs = [lib.f32(grads[k]) for k in keys]
     lib.train_adamw_multi([params[k] for k in keys], gs, [state[k][0] for k in keys], [state[k][1] for k in keys], step,
                           lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
@@ -77,10 +100,42 @@ def _sub(sd, q):
             _SUB_CACHE.clear()
         ent = _SUB_CACHE[key] = (sd, {})
     hit = ent[1].get(q)
+    if hit is not None:
+        n = len(q) + 1
+        for k, v in hit.items():                    # an entry REPLACED in the dict since (sd[k] = v.to(dev), a reload) must not be served stale
+            if sd.get(q + "." + k) is not v:
+                hit = None
+                break
     if hit is None:
         n = len(q) + 1
         hit = ent[1][q] = {k[n:]: v for k, v in sd.items() if k.startswith(q + ".")}
     return hit
+
+
+def invalidate_param_cache(sd=None):
+    """Forget the memoised per-block parameter views (of `sd`, or all)."""
+    if sd is None:
+        _SUB_CACHE.clear()
+    else:
+        _SUB_CACHE.pop(id(sd), None)
+
+
+class FlatGrads:
+    """One zeroed buffer for all parameter gradients of a step; `take(like)` hands out the next slice shaped like a parameter
+    (None when the buffer is exhausted: the caller falls back to its own allocation)."""
+
+    def __init__(self, numel, device):
+        self.buf = torch.zeros(int(numel), dtype=torch.float32, device=device)
+        self.off = 0
+
+    def take(self, like):
+        n = like.numel()
+        n_al = (n + 63) // 64 * 64                     # 256-byte aligned slices
+        if like.dtype != torch.float32 or self.off + n_al > self.buf.numel():
+            return None
+        g = self.buf[self.off:self.off + n].view(like.shape)
+        self.off += n_al
+        return g
 
 
 class _Grads:
@@ -99,7 +154,7 @@ class _Grads:
             key = prefix + "." + k if prefix else k
             if key in self.g:
                 assert self.reducer is None, "gradient of %s produced twice: cannot be reduced early" % key
-                self.g[key] = self.g[key] + v
+                self.g[key] = self.g[key] + v          # never happens in this model (every parameter belongs to one block)
             else:
                 self.g[key] = v
                 if self.reducer is not None:
@@ -223,7 +278,7 @@ class UNetStep:
             q = "%s.input_blocks.%d" % (p, i)
             if mod[0] == "audio":
                 tape.append(("audio_cat", h.shape[1], ai))
-                h = torch.cat([h, self.audios[ai]], dim=1)
+                h = lib.train_concat(h, self.audios[ai])
                 ai += 1
                 continue
             if mod[0] == "conv_in":
@@ -245,11 +300,11 @@ class UNetStep:
             q = "%s.output_blocks.%d" % (p, i)
             if mod[0] == "audio":
                 tape.append(("audio_cat", h.shape[1], ai))
-                h = torch.cat([h, self.audios[ai]], dim=1)
+                h = lib.train_concat(h, self.audios[ai])
                 ai -= 1
                 continue
             tape.append(("skip_cat", h.shape[1], len(hs) - 1))
-            h = torch.cat([h, hs.pop()], dim=1)
+            h = lib.train_concat(h, hs.pop())
             h = self._seq_forward(q, mod[1], h, self.emb, context, tape)
         st = self._st()
         tape.append(("out", p + ".out", h, st))
@@ -275,25 +330,22 @@ class UNetStep:
                 grads.add(q, {"weight": dw, "bias": db})
             elif kind == "res":
                 _, dh, de, g = lib.train_resblock(_sub(sd, rec[1]), rec[2], self.emb, dh, groups=self.groups, state=rec[3])
-                demb = de if demb is None else demb + de
+                demb = de if demb is None else lib.train_add(demb, de, out=demb)
                 grads.add(rec[1], g)
             elif kind == "attn":
                 _, dh, dc, g = lib.train_transformer(_sub(sd, rec[1]), rec[2], self.context, dh, heads, groups=self.groups, state=rec[3])
                 if dc is not None:
-                    dctx = dc if dctx is None else dctx + dc
+                    dctx = dc if dctx is None else lib.train_add(dctx, dc, out=dctx)
                 grads.add(rec[1], g)
             elif kind == "s4":
                 _, dh, g = lib.train_s4layer(_sub(sd, rec[1]), rec[2], dh, groups=self.groups, state=rec[3])
                 grads.add(rec[1], g)
-            elif kind == "skip_cat":
-                skips[rec[2]] = dh[:, rec[1]:].contiguous()
-                dh = dh[:, :rec[1]].contiguous()
-            elif kind == "audio_cat":
-                da = dh[:, rec[1]:].contiguous()
-                daud[rec[2]] = da if rec[2] not in daud else daud[rec[2]] + da
-                dh = dh[:, :rec[1]].contiguous()
-            elif kind == "push":
-                dh = dh + skips.pop(rec[1])
+            elif kind == "skip_cat":                      # gradient of cat([h, skip]): two channel slices
+                dh, skips[rec[2]] = lib.train_split(dh, rec[1])
+            elif kind == "audio_cat":                     # gradient of cat([h, audio map]); a map read on the way down and up accumulates
+                dh, daud[rec[2]] = lib.train_split(dh, rec[1], acc_b=daud.get(rec[2]))
+            elif kind == "push":                          # the tensor went to the next block AND onto the skip stack
+                dh = lib.train_add(dh, skips.pop(rec[1]), out=dh)
         _, g = lib.train_time_embed(_sub(sd, self.p + ".time_embed"), self.temb, demb)
         grads.add(self.p + ".time_embed", g)
         return dh, dctx, daud
@@ -348,7 +400,7 @@ class WaveStep:
             kind = rec[0]
             if kind == "emit":
                 if rec[1] in want:
-                    dh = want[rec[1]] if dh is None else dh + want[rec[1]]
+                    dh = want[rec[1]] if dh is None else lib.train_add(dh, want[rec[1]], out=dh)
             elif dh is None:
                 continue                                    # levels above the last one the U-Net reads get no gradient
             elif kind == "conv":
@@ -373,6 +425,15 @@ def training_step(lib, sd, unet_cfg, wave_cfg, x0, noise, t, ids, mel, beta=0.02
     forward: only block inputs are stored).  Both give bit-identical gradients.  Returns (loss, {state-dict name: gradient})."""
     lib.train_release_states()                       # intermediates of a sweep that was abandoned half-way
     grads = _Grads(reducer)
+    n_train = sum(v.numel() + 64 for k, v in sd.items() if v.dtype == torch.float32 and k.startswith("model.") and not k.startswith("model.first_stage_model."))
+    lib.grad_arena = FlatGrads(n_train, lib.device)      # every parameter gradient of the step: a view of one buffer, one fill
+    try:
+        return _training_step(lib, sd, unet_cfg, wave_cfg, x0, noise, t, ids, mel, beta, add, reducer, recompute, grads)
+    finally:
+        lib.grad_arena = None
+
+
+def _training_step(lib, sd, unet_cfg, wave_cfg, x0, noise, t, ids, mel, beta, add, reducer, recompute, grads):
     xt = lib.train_q_sample(x0, noise, t, sd["sqrt_alphas_cumprod"], sd["sqrt_one_minus_alphas_cumprod"])
     table = lib.f32(sd["model.cond_stage_model.embedding.weight"])
     context = lib.cond_embed(table, ids)
@@ -449,6 +510,8 @@ def fit(lib, sd, unet_cfg, wave_cfg, steps, batch, z, lr=1e-4, weight_decay=0.01
     for k, v in list(sd.items()):
         if v.dtype == torch.float32 and k.startswith("model.") and v.device != dev:
             sd[k] = v.to(dev)
+    invalidate_param_cache(sd)
+    broadcast_parameters(sd)                         # ranks start from rank 0's weights, as under DistributedDataParallel
     state, params, losses = {}, None, []
     g = torch.Generator().manual_seed(seed * 1000 + rank)
     for i in range(steps):
@@ -487,7 +550,10 @@ def main(argv=None):
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--recompute", action="store_true", help="block-level activation checkpointing")
     ap.add_argument("--save", default=None, help="write the trained state dict here (rank 0)")
+    ap.add_argument("--fp32", action="store_true", help="fp32-input MFMA GEMMs (the parity mode) instead of bf16 (BASELINE configs[4])")
     a = ap.parse_args(argv)
+    if a.ckpt is None and a.synthetic_seed is None:
+        ap.error("give --ckpt or --synthetic-seed: every rank must build the same initial weights")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
@@ -495,6 +561,7 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     lib = get_lib()
+    lib.train_set_precision(not a.fp32)
     model, cfg = job.load_model(a.config, a.ckpt, device="cuda", seed_synthetic=a.synthetic_seed if a.ckpt is None else None)
     mp = (cfg["model"] if "model" in cfg else cfg)["params"]
     sd = {k: v.detach() for k, v in model.state_dict().items()}

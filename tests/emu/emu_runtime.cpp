@@ -47,6 +47,7 @@ struct Fiber {
 
 struct WaveScratch {
     float a[64], b[64];
+    float a8[64][8], b8[64][8];       // bf16 MFMA operands, widened
 };
 
 std::vector<Fiber> fibers;
@@ -222,6 +223,23 @@ void mfma_16x16x4(float a, float b, const float* c, float* d) {
         const int row = (l >> 4) * 4 + r;
         float acc = c[r];
         for (int k = 0; k < 4; ++k) acc = fmaf(w.a[row + 16 * k], w.b[col + 16 * k], acc);
+        d[r] = acc;
+    }
+    wave_barrier();
+}
+
+// v_mfma_f32_32x32x16_bf16: lane l holds 8 consecutive k of A row i = l & 31 and of B column j = l & 31, k = 8 (l >> 5) + e;
+// D map as the f32 form.  The hardware's internal summation order is not specified: fp32 accumulation, k ascending here.
+void mfma_32x32x16_bf16(const float* a8, const float* b8, const float* c, float* d) {
+    WaveScratch& w = waves[cur->lin >> 6];
+    const int l = cur->lin & 63;
+    for (int e = 0; e < 8; ++e) { w.a8[l][e] = a8[e]; w.b8[l][e] = b8[e]; }
+    wave_barrier();
+    const int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) acc = fmaf(w.a8[row + 32 * (k >> 3)][k & 7], w.b8[col + 32 * (k >> 3)][k & 7], acc);
         d[r] = acc;
     }
     wave_barrier();

@@ -99,6 +99,7 @@ void wave_barrier();
 float wave_xchg(float v, int src_lane);
 void mfma_32x32x2(float a, float b, const float* c, float* d);
 void mfma_16x16x4(float a, float b, const float* c, float* d);
+void mfma_32x32x16_bf16(const float* a8, const float* b8, const float* c, float* d);
 int lane_id();
 }  // namespace emu
 
@@ -150,6 +151,17 @@ static inline emu_f32x4 emu_mfma16(float a, float b, emu_f32x4 c) {
     for (int i = 0; i < 4; ++i) d[i] = di[i];
     return d;
 }
+typedef __bf16 emu_bf16x8 __attribute__((ext_vector_type(8)));
+static inline emu_f32x16 emu_mfma32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x16 c) {
+    float af[8], bf[8], ci[16], di[16];
+    for (int i = 0; i < 8; ++i) { af[i] = (float)a[i]; bf[i] = (float)b[i]; }
+    for (int i = 0; i < 16; ++i) ci[i] = c[i];
+    emu::mfma_32x32x16_bf16(af, bf, ci, di);
+    emu_f32x16 d;
+    for (int i = 0; i < 16; ++i) d[i] = di[i];
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu_mfma32_bf16((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma32((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu_mfma16((a), (b), (c))
 

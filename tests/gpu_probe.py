@@ -94,7 +94,7 @@ def main():
         key = "ddim_graph" if graph else "ddim_eager"
         res[key + "_ms"] = md * 1e3
         print("%s S=%d B=%d: %.2f ms total, %.3f ms/step, %.0f sample-steps/s" % (key, len(ts_), B, md * 1e3, md * 1e3 / len(ts_), B * len(ts_) / md), flush=True)
-    lib.set_graph_mode(True)
+    lib.set_graph_mode(0)
     if a.quick:
         return
     uc = cases.context(case, 2, B).to(dev)

