@@ -409,15 +409,14 @@ def training_leg(a, lib, model, dev, world, rank, grouped, sync_all):
     ids = torch.randint(0, sd["model.cond_stage_model.embedding.weight"].shape[0], (Bt, 21), generator=g)
     mel = torch.randn(Bt, SHIPPED["n_mels"], SHIPPED["max_audio_frame"], generator=g).abs()
     x0, noise, t, ids, mel = (v.to(dev) for v in (x0, noise, t, ids, mel))
-    state, params = {}, None
+    plan, opt = train.TrainPlan(lib, sd, SHIPPED["unet"], SHIPPED["wave"]), [None]
 
     def step(i):
-        nonlocal params
         red = train.BucketedAllReduce(bucket_bytes=64 << 20) if grouped else None          # 64 MB buckets, reduced while the backward sweep runs
-        loss, grads = train.training_step(lib, sd, SHIPPED["unet"], SHIPPED["wave"], x0, noise, t, ids, mel, reducer=red)
-        if params is None:
-            params = {k: sd[k] for k in grads}             # the model's own tensors: updated in place
-        train.adamw_step(lib, params, grads, state, i, lr=1e-6)
+        loss, grads = plan.step(x0, noise, t, ids, mel, reducer=red)
+        if opt[0] is None:
+            opt[0] = train.AdamW(lib, {k: sd[k] for k in grads}, grads, lr=1e-6)           # the model's own tensors: updated in place
+        opt[0].step()
         return loss, grads
 
     loss, grads = step(1)

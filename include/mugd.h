@@ -53,6 +53,9 @@ int mugd_synchronize(mugd_ctx* ctx);
  * library enqueues from now on wait for the work already enqueued on `other`; mugd_order_before makes `other` wait for the
  * library's work enqueued so far.  Bracket a call with the two and the caller's tensors are ordered both ways without any
  * host synchronisation (the Python binding does this around every entry point).  other == the context's own stream: no-op. */
+/* The hipStream_t all of this context's work is enqueued on (the one given to mugd_create, or the library's own).  A host that puts
+ * its own work on this stream needs no mugd_order_* calls at all (the Python binding's Lib.on_stream() does that for training steps). */
+void* mugd_get_stream(mugd_ctx* ctx);
 int mugd_order_after(mugd_ctx* ctx, void* other_stream);
 int mugd_order_before(mugd_ctx* ctx, void* other_stream);
 /* DDIM loop launch mode.  0 (default since round 3: measured 5 % faster, profiles/r3_graph_vs_eager.txt): launch kernels eagerly;

@@ -115,6 +115,8 @@ void mugd_destroy(mugd_ctx* ctx) {
 
 const char* mugd_last_error(mugd_ctx* ctx) { return ctx ? ctx->c.last_error.c_str() : "null context"; }
 
+void* mugd_get_stream(mugd_ctx* ctx) { return ctx ? (void*)ctx->c.stream : nullptr; }
+
 int mugd_synchronize(mugd_ctx* ctx) {
     return guarded(ctx, [&] { HIP_CHECK(hipStreamSynchronize(ctx->c.stream)); });
 }

@@ -18,7 +18,13 @@
 //     g_B = G00 conj(C) + G01 P;  g_C = G00 conj(B) + G10 conj(P);  g_P = G10 conj(C) + G11 P + conj(G01) B + conj(G11) P
 //     g_wdt,n = sum_ab sum_l g_sab[l] conj(dt v_ab,n u_l q_nl^2);  g_w = dt g_wdt;  d inv_w_real = -exp(inv_w_real) Re g_w;  d w_imag = Im g_w
 //     d dt = sum_n Re(g_wdt,n conj(w_n)) + sum_ab sum_l Re(g_sab[l] conj(s_ab[l])) / dt;   d log_dt = dt d dt
-// Evaluated in float64 (one-off per step and layer, ~H N Lint complex terms).  cauchy_naive form only (S4GenArgs::symmetric = 0).
+// Evaluated in float64 (one-off per step and layer, ~H N Lint complex terms).
+// Symmetric Cauchy form (S4GenBwdArgs::symmetric, the reference's pykeops / CUDA-extension backends, s4.py:55-77: the sum runs over
+// both conjugate halves):  s_ab[l] = dt sum_n ( v_ab,n q_nl + conj(v_ab,n) q'_nl ),  q'_nl = 1 / (a_l - conj(w_n dt) u_l).
+// The second half is anti-holomorphic in v and in w dt, so with the rules above
+//     G_ab,n  += sum_l conj(g_sab[l]) (dt q'_nl)
+//     g_wdt,n += sum_ab sum_l conj(g_sab[l]) (dt conj(v_ab,n) u_l q'_nl^2)
+// and the explicit-dt term keeps its form with the full s_ab.
 #include <algorithm>
 
 #include "kernels.h"
@@ -84,6 +90,11 @@ __global__ __launch_bounds__(256) void s4_kernel_gen_bwd_kernel(const S4GenBwdAr
             const cd q = cinv(csub(a2, cmul(pw[n], u)));
 #pragma unroll
             for (int k = 0; k < 4; ++k) s[k] = cadd(s[k], cmul(pv[k][n], q));
+            if (a.symmetric) {
+                const cd q2 = cinv(csub(a2, cmul(cconj(pw[n]), u)));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s[k] = cadd(s[k], cmul(cconj(pv[k][n]), q2));
+            }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) s[k] = cscale(s[k], dt);
@@ -117,6 +128,17 @@ __global__ __launch_bounds__(256) void s4_kernel_gen_bwd_kernel(const S4GenBwdAr
                 for (int k = 0; k < 4; ++k) {
                     G[k] = cadd(G[k], cmul(gs[k][l], cq));
                     Gw = cadd(Gw, cmul(gs[k][l], cconj(cmul(pv[k][n], uq2))));
+                }
+                if (a.symmetric) {
+                    const cd q2 = cinv(csub(a2, cmul(cconj(pw[n]), u)));
+                    const cd q2dt = cscale(q2, dt);
+                    const cd uq22 = cscale(cmul(u, cmul(q2, q2)), dt);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const cd cg = cconj(gs[k][l]);
+                        G[k] = cadd(G[k], cmul(cg, q2dt));
+                        Gw = cadd(Gw, cmul(cg, cmul(cconj(pv[k][n]), uq22)));
+                    }
                 }
             }
         }

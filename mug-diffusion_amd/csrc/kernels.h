@@ -341,11 +341,12 @@ struct AttnBwdArgs {         // layouts as AttnArgs; dout = gradient of the atte
 };
 void launch_attention_bwd(hipStream_t st, const AttnBwdArgs& a);
 // k_train_s4.hip: S4 layer backward pieces
-struct S4GenBwdArgs {        // gradient of launch_s4_kernel_gen's output k (H, L) w.r.t. its parameters (cauchy_naive form)
+struct S4GenBwdArgs {        // gradient of launch_s4_kernel_gen's output k (H, L) w.r.t. its parameters (either Cauchy form)
     const float* C; const float* Bp; const float* P; const float* inv_w_real; const float* w_imag; const float* log_dt;
     int H, N, Lint, L;
     const float* dk;         // (H, L)
     float* dC; float* dB; float* dP; float* d_inv_w_real; float* d_w_imag; float* d_log_dt;
+    int symmetric;           // as S4GenArgs::symmetric
 };
 void launch_s4_kernel_gen_bwd(hipStream_t st, const S4GenBwdArgs& a);
 void launch_s4_conv_train_fwd(hipStream_t st, const float* n, const float* k, const float* D, float* pre, float* g, int B, int H, int L);

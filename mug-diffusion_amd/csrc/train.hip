@@ -318,7 +318,6 @@ int mugd_train_s4layer(mugd_ctx* ctx, const float* const* P, const float* x, con
         for (int i = 0; i < MUGD_S4_NPARAMS; ++i) MUGD_CHECK(P[i] && (!dy || G[i]), MUGD_ERR_INVALID, "null parameter / gradient pointer");
         MUGD_CHECK(H % groups == 0 && H % CONV_CK == 0 && Lint >= T, MUGD_ERR_INVALID, "bad S4 layer geometry (stored kernel length < T?)");
         Ctx& c = ctx->c;
-        MUGD_CHECK(!c.s4_symmetric, MUGD_ERR_INVALID, "S4 training gradients exist for the cauchy_naive kernel form only");
         hipStream_t st = c.stream;
         Scratch sc(ctx);
         const size_t n = (size_t)B * H * T;
@@ -329,7 +328,7 @@ int mugd_train_s4layer(mugd_ctx* ctx, const float* const* P, const float* x, con
         float *k = in.get((size_t)H * T), *kf = in.get((size_t)H * (Lint / 2 + 1) * 2);
         float *nrm = in.get(n), *pre = in.get(n), *g = in.get(n), *v = in.get(2 * n), *f = in.get(n);
         if (!in.replay) {
-            S4GenArgs ga{P[MUGD_S4_K_C], P[MUGD_S4_K_B], P[MUGD_S4_K_P], P[MUGD_S4_K_INV_W_REAL], P[MUGD_S4_K_W_IMAG], P[MUGD_S4_K_LOG_DT], H, N, Lint, T, kf, k, 0};
+            S4GenArgs ga{P[MUGD_S4_K_C], P[MUGD_S4_K_B], P[MUGD_S4_K_P], P[MUGD_S4_K_INV_W_REAL], P[MUGD_S4_K_W_IMAG], P[MUGD_S4_K_LOG_DT], H, N, Lint, T, kf, k, c.s4_symmetric ? 1 : 0};
             launch_s4_kernel_gen(st, ga);
             run_group_norm_plain(c, x, P[MUGD_S4_NORM_W], P[MUGD_S4_NORM_B], nrm, B, H, T, groups);
             launch_s4_conv_train_fwd(st, nrm, k, P[MUGD_S4_D], pre, g, B, H, T);
@@ -348,7 +347,7 @@ int mugd_train_s4layer(mugd_ctx* ctx, const float* const* P, const float* x, con
         launch_gelu_bwd(st, pre, dg, dpre, (long long)n);
         launch_s4_conv_train_bwd(st, nrm, k, P[MUGD_S4_D], dpre, dn, dk, G[MUGD_S4_D], B, H, T, buf((size_t)B * H * (T + 1)));
         S4GenBwdArgs gb{P[MUGD_S4_K_C], P[MUGD_S4_K_B], P[MUGD_S4_K_P], P[MUGD_S4_K_INV_W_REAL], P[MUGD_S4_K_W_IMAG], P[MUGD_S4_K_LOG_DT], H, N, Lint, T, dk,
-                        G[MUGD_S4_K_C], G[MUGD_S4_K_B], G[MUGD_S4_K_P], G[MUGD_S4_K_INV_W_REAL], G[MUGD_S4_K_W_IMAG], G[MUGD_S4_K_LOG_DT]};
+                        G[MUGD_S4_K_C], G[MUGD_S4_K_B], G[MUGD_S4_K_P], G[MUGD_S4_K_INV_W_REAL], G[MUGD_S4_K_W_IMAG], G[MUGD_S4_K_LOG_DT], c.s4_symmetric ? 1 : 0};
         launch_s4_kernel_gen_bwd(st, gb);
         run_gn_bwd(c, sc, x, dn, P[MUGD_S4_NORM_W], P[MUGD_S4_NORM_B], dx, G[MUGD_S4_NORM_W], G[MUGD_S4_NORM_B], B, H, T, groups, 0);
         launch_bias_sum(st, dx, dy, dx, (int)n);          // + the identity skip

@@ -120,7 +120,7 @@ class ResBlockPtrs(C.Structure):            # mugd_resblock_params / mugd_resblo
     NAMES = ("gn1_w", "gn1_b", "conv1_w", "conv1_b", "emb_w", "emb_b", "gn2_w", "gn2_b", "conv2_w", "conv2_b", "skip_w", "skip_b")
     _fields_ = [(n, _p) for n in NAMES]
 EXPORTS = sorted(list(_SIGS) + ["mugd_destroy", "mugd_net_destroy", "mugd_last_error", "mugd_version",
-                                "mugd_profile_kind_name"])
+                                "mugd_profile_kind_name", "mugd_get_stream"])
 PROFILE_KINDS = 7
 
 
@@ -137,7 +137,7 @@ class MugdError(RuntimeError):
     pass
 
 
-_UNORDERED = {"mugd_create", "mugd_destroy", "mugd_net_destroy", "mugd_last_error", "mugd_version", "mugd_profile_kind_name",
+_UNORDERED = {"mugd_get_stream", "mugd_create", "mugd_destroy", "mugd_net_destroy", "mugd_last_error", "mugd_version", "mugd_profile_kind_name",
               "mugd_order_after", "mugd_order_before", "mugd_set_graph_mode", "mugd_set_conv_tiling", "mugd_set_s4_symmetric", "mugd_set_weight_precision", "mugd_remove_mini_jacks",
               "mugd_train_set_precision"}
 
@@ -159,7 +159,10 @@ class _OrderedDll:
             def ordered(*args):
                 if lib.device.type != "cuda" or not lib.ctx:
                     return fn(*args)
-                cur = _p(torch.cuda.current_stream(lib.device).cuda_stream)
+                cur = torch.cuda.current_stream(lib.device).cuda_stream
+                if cur == lib.stream_ptr:                 # torch already runs on the library's stream (Lib.on_stream()): nothing to order
+                    return fn(*args)
+                cur = _p(cur)
                 raw.mugd_order_after(lib.ctx, cur)
                 rc = fn(*args)
                 raw.mugd_order_before(lib.ctx, cur)
@@ -203,6 +206,34 @@ class Lib:
         if rc != 0:
             raise MugdError("mugd_create failed with status %d" % rc)
         self._nets = []
+        raw.mugd_get_stream.argtypes = [_p]
+        raw.mugd_get_stream.restype = _p
+        self.stream_ptr = raw.mugd_get_stream(self.ctx) or 0
+        self._ext_stream = None
+
+    def on_stream(self):
+        """Context manager: torch's current stream := the library's stream for the duration (tensors torch allocates / fills inside are
+        then ordered with the library's kernels by stream order alone -- no event per call; a training step makes ~700 native calls).
+        The library's stream first waits for what the caller's stream has queued, and the caller's stream waits for it at exit."""
+        import contextlib
+        if self.device.type != "cuda" or not self.stream_ptr:
+            return contextlib.nullcontext()
+        if self._ext_stream is None:
+            self._ext_stream = torch.cuda.ExternalStream(self.stream_ptr, device=self.device)
+        ext = self._ext_stream
+        lib_dev = self.device
+
+        @contextlib.contextmanager
+        def cm():
+            prev = torch.cuda.current_stream(lib_dev)
+            if prev.cuda_stream == ext.cuda_stream:
+                yield
+                return
+            ext.wait_stream(prev)
+            with torch.cuda.stream(ext):
+                yield
+            prev.wait_stream(ext)
+        return cm()
 
     # ------------------------------------------------------------------ plumbing
     def check(self, rc):
@@ -461,19 +492,56 @@ class Lib:
     _RESNET_KEYS = dict(gn1_w="norm1.weight", gn1_b="norm1.bias", conv1_w="conv1.weight", conv1_b="conv1.bias", gn2_w="norm2.weight",
                         gn2_b="norm2.bias", conv2_w="conv2.weight", conv2_b="conv2.bias", skip_w="nin_shortcut.weight", skip_b="nin_shortcut.bias")
 
-    def _resblock_ptrs(self, keymap, params, want_grads):
-        P, G, keep, grads = ResBlockPtrs(), ResBlockPtrs(), [], {}
+    # Argument packs.  A block's parameter pointers (and, with a persistent gradient arena, its gradient pointers) do not change from
+    # step to step (AdamW updates in place): a caller that keeps a `pack` dict per block pays for building the ctypes arrays and the
+    # tensor views ONCE; without a pack everything is rebuilt per call.
+    def _resblock_ptrs(self, keymap, params, want_grads, pack=None):
+        if pack is not None and "P" in pack and (not want_grads or "G" in pack):
+            return pack["P"], pack.get("G") or ResBlockPtrs(), None, (pack["grads"] if want_grads else {})
+        P, keep = ResBlockPtrs(), []
+        ts = {}
         for f, k in keymap.items():
             if k in params:
                 t = self.f32(params[k])
                 keep.append(t)
+                ts[f] = (k, t)
                 setattr(P, f, t.data_ptr())
-                if want_grads:
-                    g = self.zgrad(t)
-                    keep.append(g)
-                    grads[k] = g
-                    setattr(G, f, g.data_ptr())
+        G, grads = ResBlockPtrs(), {}
+        if want_grads:
+            for f, (k, t) in ts.items():
+                g = self.zgrad(t)
+                keep.append(g)
+                grads[k] = g
+                setattr(G, f, g.data_ptr())
+        if pack is not None:
+            pack["P"] = P
+            pack.setdefault("keep", []).extend(keep)
+            if want_grads:
+                pack["G"], pack["grads"] = G, grads
         return P, G, keep, grads
+
+    def _array_ptrs(self, keys, params, want_grads, pack=None):
+        """(pointer array of the parameters in `keys` order, pointer array of their gradients, keep-alive list, grads dict)."""
+        n = len(keys)
+        if pack is not None and "P" in pack and (not want_grads or "G" in pack):
+            return pack["P"], pack.get("G") or (C.c_void_p * n)(), None, (pack["grads"] if want_grads else {})
+        keep, grads = [], {}
+        PA, GA = (C.c_void_p * n)(), (C.c_void_p * n)()
+        for i, k in enumerate(keys):
+            t = self.f32(params[k])
+            keep.append(t)
+            PA[i] = t.data_ptr()
+            if want_grads:
+                g = self.zgrad(t)
+                keep.append(g)
+                grads[k] = g
+                GA[i] = g.data_ptr()
+        if pack is not None:
+            pack["P"] = PA
+            pack.setdefault("keep", []).extend(keep)
+            if want_grads:
+                pack["G"], pack["grads"] = GA, grads
+        return PA, GA, keep, grads
 
     def train_release_states(self):
         self.check(self.dll.mugd_train_release_states(self.ctx))
@@ -505,14 +573,14 @@ class Lib:
         self.check(self.dll.mugd_train_add(self.ctx, _ptr(a), _ptr(b), _ptr(out), a.numel()))
         return out
 
-    def train_resblock(self, params, x, emb, dy, groups=32, state=None):
+    def train_resblock(self, params, x, emb, dy, groups=32, state=None, pack=None):
         """TimestepResBlock forward + backward (unet.py:212-239).  params: dict with the module's tensors
         (in_layers.0.weight/bias, in_layers.2.weight/bias, emb_layers.1.weight/bias, out_layers.0.weight/bias,
         out_layers.3.weight/bias, optionally skip_connection.weight/bias).  Returns y, dx, demb, grads (same keys);
         dy None: forward only (dx, demb None, grads empty)."""
         x, emb = self.f32(x), self.f32(emb)
         dy = None if dy is None else self.f32(dy)
-        P, G, keep, grads = self._resblock_ptrs(self._RESBLOCK_KEYS, params, dy is not None)
+        P, G, keep, grads = self._resblock_ptrs(self._RESBLOCK_KEYS, params, dy is not None, pack)
         B, Cin, T = x.shape
         Cout = params["in_layers.2.weight"].shape[0]
         y = self.empty(B, Cout, T)
@@ -522,11 +590,11 @@ class Lib:
                                                 B, Cin, Cout, T, emb.shape[1], groups, _sref(state)))
         return y, dx, demb, grads
 
-    def train_resnet_block(self, params, x, dy, groups=32, dilations=(1, 1), state=None):
+    def train_resnet_block(self, params, x, dy, groups=32, dilations=(1, 1), state=None, pack=None):
         """ResnetBlock forward + backward (mug/model/models.py:142-159: norm1/conv1/norm2/conv2/nin_shortcut, dilated convs)."""
         x = self.f32(x)
         dy = None if dy is None else self.f32(dy)
-        P, G, keep, grads = self._resblock_ptrs(self._RESNET_KEYS, params, dy is not None)
+        P, G, keep, grads = self._resblock_ptrs(self._RESNET_KEYS, params, dy is not None, pack)
         B, Cin, T = x.shape
         Cout = params["conv1.weight"].shape[0]
         y = self.empty(B, Cout, T)
@@ -557,23 +625,35 @@ class Lib:
         self.check(self.dll.mugd_train_embedding_bwd(self.ctx, _ptr(ids), _ptr(dc), _ptr(dt), B, ntok, dim, rows))
         return dt
 
-    def train_conv(self, weight, bias, x, dy, dil=1, mode=0, gn=None, groups=32, state=None):
+    def train_conv(self, weight, bias, x, dy, dil=1, mode=0, gn=None, groups=32, state=None, pack=None):
         """conv1d forward + backward; mode 0 plain (padding = dil (k - 1) / 2), 1 Downsample, 2 Upsample (models.py:55-91);
         gn = (weight, bias): GroupNorm + SiLU in front (the U-Net's out head).  Returns y, dx, dw, db, (dgn_w, dgn_b) or None."""
-        w, x = self.f32(weight), self.f32(x)
+        x = self.f32(x)
         dy = None if dy is None else self.f32(dy)
-        b = None if bias is None else self.f32(bias)
+        if pack is not None and "w" in pack:
+            w, b, gw, gb = pack["w"], pack["b"], pack["gw"], pack["gb"]
+        else:
+            w = self.f32(weight)
+            b = None if bias is None else self.f32(bias)
+            gw, gb = (self.f32(gn[0]), self.f32(gn[1])) if gn is not None else (None, None)
+            if pack is not None:
+                pack.update(w=w, b=b, gw=gw, gb=gb)
         B, Cin, Tin = x.shape
         Cout, _, taps = w.shape
         Tout = Tin // 2 if mode == 1 else (2 * Tin if mode == 2 else Tin)
         y = self.empty(B, Cout, Tout)
-        dx, dw = (None, None) if dy is None else (torch.empty_like(x), self.zgrad(w))
-        db = None if (b is None or dy is None) else self.zgrad(b)
-        gw = gb = dgw = dgb = None
-        if gn is not None:
-            gw, gb = self.f32(gn[0]), self.f32(gn[1])
-            if dy is not None:
-                dgw, dgb = self.zgrad(gw), self.zgrad(gb)
+        dx = dw = db = dgw = dgb = None
+        if dy is not None:
+            dx = torch.empty_like(x)
+            if pack is not None and "dw" in pack:
+                dw, db, dgw, dgb = pack["dw"], pack["db"], pack["dgw"], pack["dgb"]
+            else:
+                dw = self.zgrad(w)
+                db = None if b is None else self.zgrad(b)
+                if gn is not None:
+                    dgw, dgb = self.zgrad(gw), self.zgrad(gb)
+                if pack is not None:
+                    pack.update(dw=dw, db=db, dgw=dgw, dgb=dgb)
         self.check(self.dll.mugd_train_conv(self.ctx, _ptr(w), _ptr(b), _ptr(gw), _ptr(gb), _ptr(x), _ptr(dy), _ptr(y), _ptr(dx), _ptr(dw), _ptr(db),
                                             _ptr(dgw), _ptr(dgb), B, Cin, Cout, Tin, taps, int(dil), int(mode), int(groups), _sref(state)))
         return y, dx, dw, db, (None if (gn is None or dy is None) else (dgw, dgb))
@@ -583,26 +663,20 @@ class Lib:
                     "s4_model.kernel.kernel.inv_w_real", "s4_model.kernel.kernel.w_imag", "s4_model.kernel.kernel.log_dt", "s4_model.D",
                     "s4_model.output_linear.0.weight", "s4_model.output_linear.0.bias", "out_layer.weight", "out_layer.bias")
 
-    def train_s4layer(self, params, x, dy, groups=32, state=None):
+    def train_s4layer(self, params, x, dy, groups=32, state=None, pack=None):
         """S4Layer forward + backward (unet.py:76-91, s4.py:1471-1541, kernel gradients included).  params: dict keyed like the module's
         state dict (S4LAYER_KEYS + 's4_model.kernel.kernel.L', the stored internal length).  Returns y, dx, grads."""
         x = self.f32(x)
         dy = None if dy is None else self.f32(dy)
-        n = len(self.S4LAYER_KEYS)
-        keep, grads = [], {}
-        PA, GA = (C.c_void_p * n)(), (C.c_void_p * n)()
-        for i, k in enumerate(self.S4LAYER_KEYS):
-            t = self.f32(params[k])
-            keep.append(t)
-            PA[i] = t.data_ptr()
-            if dy is not None:
-                g = self.zgrad(t)
-                keep.append(g)
-                grads[k] = g
-                GA[i] = g.data_ptr()
+        PA, GA, keep, grads = self._array_ptrs(self.S4LAYER_KEYS, params, dy is not None, pack)
         B, H, T = x.shape
         N = params["s4_model.kernel.kernel.inv_w_real"].shape[-1]
-        Lint = int(params["s4_model.kernel.kernel.L"])
+        if pack is not None and "Lint" in pack:
+            Lint = pack["Lint"]
+        else:
+            Lint = int(params["s4_model.kernel.kernel.L"])          # a device-resident buffer costs a host synchronisation here: packs keep the value
+            if pack is not None:
+                pack["Lint"] = Lint
         y, dx = torch.empty_like(x), (None if dy is None else torch.empty_like(x))
         self.check(self.dll.mugd_train_s4layer(self.ctx, PA, _ptr(x), _ptr(dy), _ptr(y), _ptr(dx), GA, B, H, T, N, Lint, int(groups), _sref(state)))
         return y, dx, grads
@@ -622,24 +696,14 @@ class Lib:
         "transformer_blocks.0.ff.net.0.proj.weight", "transformer_blocks.0.ff.net.0.proj.bias",
         "transformer_blocks.0.ff.net.2.weight", "transformer_blocks.0.ff.net.2.bias", "proj_out.weight", "proj_out.bias")
 
-    def train_transformer(self, params, x, context, dy, heads, groups=32, state=None):
+    def train_transformer(self, params, x, context, dy, heads, groups=32, state=None, pack=None):
         """ContextualTransformer forward + backward (mug/model/attention.py:154-199).  params: dict keyed like the module's state dict
         (TRANSFORMER_KEYS).  x, dy (B, C, T); context (B, Cc, Tk) or None (attn2 = second self-attention).
         Returns y, dx, dcontext (None without context), grads (same keys)."""
         x = self.f32(x)
         dy = None if dy is None else self.f32(dy)
         ctx = None if context is None else self.f32(context)
-        keep, grads = [], {}
-        PA, GA = (C.c_void_p * len(self.TRANSFORMER_KEYS))(), (C.c_void_p * len(self.TRANSFORMER_KEYS))()
-        for i, k in enumerate(self.TRANSFORMER_KEYS):
-            t = self.f32(params[k])
-            keep.append(t)
-            PA[i] = t.data_ptr()
-            if dy is not None:
-                g = self.zgrad(t)
-                keep.append(g)
-                grads[k] = g
-                GA[i] = g.data_ptr()
+        PA, GA, keep, grads = self._array_ptrs(self.TRANSFORMER_KEYS, params, dy is not None, pack)
         B, Cm, T = x.shape
         pmax = (params["transformer_blocks.0.attn1.relative_position_embedding"].shape[0] - 1) // 2
         y, dx = torch.empty_like(x), (None if dy is None else torch.empty_like(x))

@@ -1,8 +1,8 @@
 """mug.diffusion.ddim -- DDIMSampler with the reference's interface (mug/diffusion/ddim.py:11-196).
 
 `sample()` keeps the reference's arguments and return value; the loop itself (ddim_sampling +
-p_sample_ddim, :110-196) runs on the device inside libmugd (`mugd_ddim_sample`: hipGraph replay of the
-U-Net program + fused CFG/DDIM update), in as few native calls as the arguments allow:
+p_sample_ddim, :110-196) runs on the device inside libmugd (`mugd_ddim_sample`: the
+U-Net program + fused CFG/DDIM update per step, launched eagerly or replayed from a hipGraph), in as few native calls as the arguments allow:
 
 * no callbacks / mask, S <= log_every_t:  ONE call (the library also returns the state after the first step, which the
                          reference logs as an intermediate, :154-156);

@@ -102,19 +102,25 @@ def run_job(model, sampler, units, mel_of, feature_yaml, steps=50, scale=1.0, et
         launches.append(group_)
     grids = {}
     n_launch = 0
+    # ---- everything a launch needs that does not depend on the GPU: batch order, prompt ids, x_T (one CPU generator per unit:
+    # reproducible per seed wherever the unit runs).  Staged for ALL launches in one go and copied with the stream still short, so
+    # no host-side copy waits behind a DDIM loop later
+    staged = []
     for group_ in launches:
         z = audio_of[group_[0][0]]["z"]
         ns, per = len(group_), len(group_[0][1])
         # batch row r = seed (r // ns) of song (r % ns): the U-Net reads audio map row b % ns
         order = [group_[r % ns][1][r // ns] for r in range(ns * per)]
-        w = [torch.cat([audio_of[a]["w"][l] for a, _ in group_], dim=0) for l in range(len(audio_of[group_[0][0]]["w"]))]
-        ids = torch.tensor([feature_dict_to_embedding_ids(units[u]["prompt"], feature_yaml) for u in order], dtype=torch.float32, device=dev)
+        ids = torch.tensor([feature_dict_to_embedding_ids(units[u]["prompt"], feature_yaml) for u in order], dtype=torch.float32)
+        uids = torch.tensor([feature_dict_to_embedding_ids({}, feature_yaml)] * len(order), dtype=torch.float32) if scale != 1.0 else None
+        x_T = torch.stack([_x_T(units[u]["seed"], z) for u in order])
+        staged.append((order, ids.to(dev, non_blocking=True), None if uids is None else uids.to(dev, non_blocking=True), x_T.to(dev, non_blocking=True)))
+    for group_, (order, ids, uids, x_T) in zip(launches, staged):
+        z = audio_of[group_[0][0]]["z"]
+        w = [torch.cat([audio_of[a]["w"][l] for a, _ in group_], dim=0) for l in range(len(audio_of[group_[0][0]]["w"]))] if len(group_) > 1 \
+            else audio_of[group_[0][0]]["w"]
         c = model.model.cond_stage_model(ids)
-        uc = None
-        if scale != 1.0:
-            uc = model.model.cond_stage_model(torch.tensor([feature_dict_to_embedding_ids({}, feature_yaml)] * len(order),
-                                                           dtype=torch.float32, device=dev))
-        x_T = torch.stack([_x_T(units[u]["seed"], z) for u in order]).to(dev)
+        uc = model.model.cond_stage_model(uids) if uids is not None else None
         model.z_length = z
         lat, _ = sampler.sample(S=steps, c=c, w=w, batch_size=len(order), eta=eta, verbose=False, x_T=x_T,
                                 unconditional_guidance_scale=scale, unconditional_conditioning=uc,
@@ -128,7 +134,11 @@ def run_job(model, sampler, units, mel_of, feature_yaml, steps=50, scale=1.0, et
         n_launch += 1
     stats = dict(rank=rank, world=world, units=len(mine), audios=len(audio_of), launches=n_launch)
     if not gather or world == 1:
-        return [grids[u].cpu() for u in mine] if world > 1 else [grids[u].cpu() for u in range(len(units))], stats
+        keys = mine if world > 1 else list(range(len(units)))
+        if keys and len(set(tuple(grids[u].shape) for u in keys)) == 1:      # equal lengths: ONE device-to-host copy (and one sync)
+            host = torch.stack([grids[u] for u in keys]).cpu()
+            return [host[i] for i in range(len(keys))], stats
+        return [grids[u].cpu() for u in keys], stats
     # ---- end of job: every rank gets every chart's grid.  Lengths differ per audio: gather them first (one int per unit),
     # pad the bit-packed rows to the longest, gather once
     T_local = torch.tensor([grids[u].shape[-1] for u in mine], dtype=torch.int64)

@@ -83,6 +83,32 @@ def adamw_step(lib, params, grads, state, step, lr=1e-4, betas=(0.9, 0.999), eps
     return params
 
 
+class AdamW:
+    """adamw_step with its argument lists built once: for a TrainPlan's stable (parameter, gradient) tensors one optimiser step is a
+    single native call with prebuilt pointer arrays (configure_optimizers, diffusion.py:477-499: AdamW over the trainable tensors)."""
+
+    def __init__(self, lib, params, grads, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+        import ctypes as C
+        self.lib, self.hp = lib, (float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay))
+        self.keys = list(grads)
+        self.tensors = [(params[k], grads[k], torch.zeros_like(params[k]), torch.zeros_like(params[k])) for k in self.keys]
+        for p_, g_, _, _ in self.tensors:
+            assert p_.is_contiguous() and g_.is_contiguous() and p_.dtype == torch.float32 and p_.device == lib.device and p_.shape == g_.shape
+        n = len(self.keys)
+        self.n = n
+        self.arrs = [(C.c_void_p * n)(*[t[i].data_ptr() for t in self.tensors]) for i in range(4)]
+        self.sizes = (C.c_longlong * n)(*[t[0].numel() for t in self.tensors])
+        self.t = 0
+
+    def step(self, lr=None):
+        self.t += 1
+        lr_, b1, b2, eps, wd = self.hp
+        lib = self.lib
+        with lib.on_stream():
+            lib.check(lib.dll.mugd_train_adamw_multi(lib.ctx, self.n, self.arrs[0], self.arrs[1], self.arrs[2], self.arrs[3], self.sizes,
+                                                     float(lr_ if lr is None else lr), b1, b2, eps, wd, self.t))
+
+
 # ------------------------------------------------------------------------------------------------------------------------------
 # whole-model training step (mug/diffusion/diffusion.py:356-414 DDPM.p_losses / training_step)
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -240,8 +266,12 @@ def unet_plan(cfg):
 class UNetStep:
     """Forward sweep / backward sweep of UNetModel.forward (unet.py:511-550) over the native block entry points."""
 
-    def __init__(self, lib, sd, cfg, prefix="model.unet_model", groups=32, recompute=False):
+    def __init__(self, lib, sd, cfg, prefix="model.unet_model", groups=32, recompute=False, packs=None):
         self.lib, self.sd, self.cfg, self.p, self.groups, self.recompute = lib, sd, cfg, prefix, groups, recompute
+        self.packs = packs          # {block name: argument pack} kept across steps by a TrainPlan; None: rebuilt per call
+
+    def _pk(self, q):
+        return None if self.packs is None else self.packs.setdefault(q, {})
 
     def _st(self):
         """recompute=False: the block keeps its forward intermediates between the two sweeps (a TrainState); True: block-level
@@ -256,13 +286,13 @@ class UNetStep:
             st = self._st()
             tape.append((kind, qq, h, st))
             if kind == "res":
-                h = lib.train_resblock(_sub(self.sd, qq), h, emb, None, groups=self.groups, state=st)[0]
+                h = lib.train_resblock(_sub(self.sd, qq), h, emb, None, groups=self.groups, state=st, pack=self._pk(qq))[0]
             elif kind == "attn":
-                h = lib.train_transformer(_sub(self.sd, qq), h, ctx, None, heads, groups=self.groups, state=st)[0]
+                h = lib.train_transformer(_sub(self.sd, qq), h, ctx, None, heads, groups=self.groups, state=st, pack=self._pk(qq))[0]
             elif kind == "s4":
-                h = lib.train_s4layer(_sub(self.sd, qq), h, None, groups=self.groups, state=st)[0]
+                h = lib.train_s4layer(_sub(self.sd, qq), h, None, groups=self.groups, state=st, pack=self._pk(qq))[0]
             else:
-                h = lib.train_conv(self.sd[qq + ".conv.weight"], self.sd[qq + ".conv.bias"], h, None, mode=2, state=st)[0]
+                h = lib.train_conv(self.sd[qq + ".conv.weight"], self.sd[qq + ".conv.bias"], h, None, mode=2, state=st, pack=self._pk(qq + ".conv"))[0]
         return h
 
     def forward(self, x, t, context, audios):
@@ -284,11 +314,11 @@ class UNetStep:
             if mod[0] == "conv_in":
                 st = self._st()
                 tape.append(("conv", q + ".0", h, 0, st))
-                h = lib.train_conv(sd[q + ".0.weight"], sd[q + ".0.bias"], h, None, state=st)[0]
+                h = lib.train_conv(sd[q + ".0.weight"], sd[q + ".0.bias"], h, None, state=st, pack=self._pk(q + ".0"))[0]
             elif mod[0] == "down":
                 st = self._st()
                 tape.append(("conv", q + ".0.conv", h, 1, st))
-                h = lib.train_conv(sd[q + ".0.conv.weight"], sd[q + ".0.conv.bias"], h, None, mode=1, state=st)[0]
+                h = lib.train_conv(sd[q + ".0.conv.weight"], sd[q + ".0.conv.bias"], h, None, mode=1, state=st, pack=self._pk(q + ".0.conv"))[0]
             else:
                 h = self._seq_forward(q, mod[1], h, self.emb, context, tape)
             tape.append(("push", len(hs)))
@@ -309,7 +339,7 @@ class UNetStep:
         st = self._st()
         tape.append(("out", p + ".out", h, st))
         y = lib.train_conv(sd[p + ".out.2.weight"], sd[p + ".out.2.bias"], h, None, gn=(sd[p + ".out.0.weight"], sd[p + ".out.0.bias"]),
-                           groups=self.groups, state=st)[0]
+                           groups=self.groups, state=st, pack=self._pk(p + ".out"))[0]
         self.tape = tape
         return y
 
@@ -322,23 +352,23 @@ class UNetStep:
             if kind == "out":
                 _, q, h, st = rec
                 _, dh, dw, db, dg = lib.train_conv(sd[q + ".2.weight"], sd[q + ".2.bias"], h, dh, gn=(sd[q + ".0.weight"], sd[q + ".0.bias"]), groups=self.groups,
-                                                   state=st)
+                                                   state=st, pack=self._pk(q))
                 grads.add(q, {"2.weight": dw, "2.bias": db, "0.weight": dg[0], "0.bias": dg[1]})
             elif kind == "conv" or kind == "up":
                 q, h, mode = (rec[1], rec[2], rec[3]) if kind == "conv" else (rec[1] + ".conv", rec[2], 2)
-                _, dh, dw, db, _ = lib.train_conv(sd[q + ".weight"], sd[q + ".bias"], h, dh, mode=mode, state=rec[-1])
+                _, dh, dw, db, _ = lib.train_conv(sd[q + ".weight"], sd[q + ".bias"], h, dh, mode=mode, state=rec[-1], pack=self._pk(q))
                 grads.add(q, {"weight": dw, "bias": db})
             elif kind == "res":
-                _, dh, de, g = lib.train_resblock(_sub(sd, rec[1]), rec[2], self.emb, dh, groups=self.groups, state=rec[3])
+                _, dh, de, g = lib.train_resblock(_sub(sd, rec[1]), rec[2], self.emb, dh, groups=self.groups, state=rec[3], pack=self._pk(rec[1]))
                 demb = de if demb is None else lib.train_add(demb, de, out=demb)
                 grads.add(rec[1], g)
             elif kind == "attn":
-                _, dh, dc, g = lib.train_transformer(_sub(sd, rec[1]), rec[2], self.context, dh, heads, groups=self.groups, state=rec[3])
+                _, dh, dc, g = lib.train_transformer(_sub(sd, rec[1]), rec[2], self.context, dh, heads, groups=self.groups, state=rec[3], pack=self._pk(rec[1]))
                 if dc is not None:
                     dctx = dc if dctx is None else lib.train_add(dctx, dc, out=dctx)
                 grads.add(rec[1], g)
             elif kind == "s4":
-                _, dh, g = lib.train_s4layer(_sub(sd, rec[1]), rec[2], dh, groups=self.groups, state=rec[3])
+                _, dh, g = lib.train_s4layer(_sub(sd, rec[1]), rec[2], dh, groups=self.groups, state=rec[3], pack=self._pk(rec[1]))
                 grads.add(rec[1], g)
             elif kind == "skip_cat":                      # gradient of cat([h, skip]): two channel slices
                 dh, skips[rec[2]] = lib.train_split(dh, rec[1])
@@ -354,8 +384,12 @@ class UNetStep:
 class WaveStep:
     """MelspectrogramScaleEncoder1D.forward (mug/cond/wave.py:398-464) as a forward / backward sweep."""
 
-    def __init__(self, lib, sd, cfg, prefix="model.wave_model", recompute=False):
+    def __init__(self, lib, sd, cfg, prefix="model.wave_model", recompute=False, packs=None):
         self.lib, self.sd, self.cfg, self.p, self.recompute = lib, sd, cfg, prefix, recompute
+        self.packs = packs
+
+    def _pk(self, q):
+        return None if self.packs is None else self.packs.setdefault(q, {})
 
     def _st(self):
         from ._native import TrainState
@@ -366,25 +400,25 @@ class WaveStep:
         g, heads = cfg["num_groups"], cfg["num_heads"]
         st = self._st()
         tape, hs, ds = [("conv", p + ".conv_in", lib.f32(mel), 0, st)], [], 1
-        h = lib.train_conv(sd[p + ".conv_in.weight"], sd[p + ".conv_in.bias"], mel, None, state=st)[0]
+        h = lib.train_conv(sd[p + ".conv_in.weight"], sd[p + ".conv_in.bias"], mel, None, state=st, pack=self._pk(p + ".conv_in"))[0]
         for lvl in range(len(cfg["channel_mult"])):
             q = "%s.down.%d" % (p, lvl)
             if lvl != 0:
                 st = self._st()
                 tape.append(("conv", q + ".downsample.conv", h, 1, st))
-                h = lib.train_conv(sd[q + ".downsample.conv.weight"], sd[q + ".downsample.conv.bias"], h, None, mode=1, state=st)[0]
+                h = lib.train_conv(sd[q + ".downsample.conv.weight"], sd[q + ".downsample.conv.bias"], h, None, mode=1, state=st, pack=self._pk(q + ".downsample.conv"))[0]
                 ds *= 2
             for ib in range(cfg["num_res_blocks"]):
                 dil = (1, 2) if ib % 2 == 0 else (4, 8)
                 qq = "%s.block.%d" % (q, ib)
                 st = self._st()
                 tape.append(("resnet", qq, h, dil, st))
-                h = lib.train_resnet_block(_sub(sd, qq), h, None, groups=g, dilations=dil, state=st)[0]
+                h = lib.train_resnet_block(_sub(sd, qq), h, None, groups=g, dilations=dil, state=st, pack=self._pk(qq))[0]
                 if ds in cfg["attention_resolutions"]:
                     qq = "%s.attn.%d" % (q, ib)
                     st = self._st()
                     tape.append(("attn", qq, h, st))
-                    h = lib.train_transformer(_sub(sd, qq), h, None, None, heads, groups=32, state=st)[0]
+                    h = lib.train_transformer(_sub(sd, qq), h, None, None, heads, groups=32, state=st, pack=self._pk(qq))[0]
             tape.append(("emit", lvl))
             hs.append(h)
         self.tape = tape
@@ -404,15 +438,49 @@ class WaveStep:
             elif dh is None:
                 continue                                    # levels above the last one the U-Net reads get no gradient
             elif kind == "conv":
-                _, dh, dw, db, _ = lib.train_conv(sd[rec[1] + ".weight"], sd[rec[1] + ".bias"], rec[2], dh, mode=rec[3], state=rec[4])
+                _, dh, dw, db, _ = lib.train_conv(sd[rec[1] + ".weight"], sd[rec[1] + ".bias"], rec[2], dh, mode=rec[3], state=rec[4], pack=self._pk(rec[1]))
                 grads.add(rec[1], {"weight": dw, "bias": db})
             elif kind == "resnet":
-                _, dh, g = lib.train_resnet_block(_sub(sd, rec[1]), rec[2], dh, groups=cfg["num_groups"], dilations=rec[3], state=rec[4])
+                _, dh, g = lib.train_resnet_block(_sub(sd, rec[1]), rec[2], dh, groups=cfg["num_groups"], dilations=rec[3], state=rec[4], pack=self._pk(rec[1]))
                 grads.add(rec[1], g)
             elif kind == "attn":
-                _, dh, _, g = lib.train_transformer(_sub(sd, rec[1]), rec[2], None, dh, cfg["num_heads"], groups=32, state=rec[3])
+                _, dh, _, g = lib.train_transformer(_sub(sd, rec[1]), rec[2], None, dh, cfg["num_heads"], groups=32, state=rec[3], pack=self._pk(rec[1]))
                 grads.add(rec[1], g)
         return dh
+
+
+class TrainPlan:
+    """Everything about a training step that does not change from step to step, built once: the two sweep objects with one argument
+    pack per block (parameter / gradient pointer arrays, gradient views) and ONE gradient arena all parameter gradients are views of
+    (cleared by a single fill per step).  `step()` returns (loss, grads) where grads are views of the arena: they are overwritten by
+    the next `step()` -- consume them (AdamW, all-reduce) first.  The parameters of `sd` must be updated IN PLACE (adamw_step does);
+    call `invalidate()` after replacing tensors in `sd`."""
+
+    def __init__(self, lib, sd, unet_cfg, wave_cfg, recompute=False):
+        self.lib, self.sd, self.unet_cfg, self.wave_cfg, self.recompute = lib, sd, unet_cfg, wave_cfg, recompute
+        self.invalidate()
+
+    def invalidate(self):
+        sd = self.sd
+        invalidate_param_cache(sd)
+        n_train = sum(v.numel() + 64 for k, v in sd.items() if v.dtype == torch.float32 and k.startswith("model.") and not k.startswith("model.first_stage_model."))
+        self.arena = FlatGrads(n_train, self.lib.device)
+        self.packs = {}
+        self.first = True
+
+    def step(self, x0, noise, t, ids, mel, beta=0.02, add=0.01, reducer=None):
+        lib = self.lib
+        with lib.on_stream():                         # torch's fills / allocations and the library's kernels on ONE stream: no event per call
+            lib.train_release_states()                # intermediates of a sweep that was abandoned half-way
+            if not self.first:
+                self.arena.buf.zero_()                # packs hold views of the arena: clear it, keep the layout
+            self.first = False
+            lib.grad_arena = self.arena
+            try:
+                return _training_step(lib, self.sd, self.unet_cfg, self.wave_cfg, x0, noise, t, ids, mel, beta, add, reducer, self.recompute,
+                                      _Grads(reducer), self.packs)
+            finally:
+                lib.grad_arena = None
 
 
 def training_step(lib, sd, unet_cfg, wave_cfg, x0, noise, t, ids, mel, beta=0.02, add=0.01, reducer=None, recompute=False):
@@ -422,24 +490,18 @@ def training_step(lib, sd, unet_cfg, wave_cfg, x0, noise, t, ids, mel, beta=0.02
     reducer: a BucketedAllReduce -- the gradients are then all-reduced bucket by bucket WHILE the backward sweep runs and come
     back averaged over the ranks.  recompute: False -- every block keeps its forward intermediates for its backward call (one forward
     + one backward; a few GB at batch 32); True -- block-level activation checkpointing (the backward call recomputes the block's
-    forward: only block inputs are stored).  Both give bit-identical gradients.  Returns (loss, {state-dict name: gradient})."""
-    lib.train_release_states()                       # intermediates of a sweep that was abandoned half-way
-    grads = _Grads(reducer)
-    n_train = sum(v.numel() + 64 for k, v in sd.items() if v.dtype == torch.float32 and k.startswith("model.") and not k.startswith("model.first_stage_model."))
-    lib.grad_arena = FlatGrads(n_train, lib.device)      # every parameter gradient of the step: a view of one buffer, one fill
-    try:
-        return _training_step(lib, sd, unet_cfg, wave_cfg, x0, noise, t, ids, mel, beta, add, reducer, recompute, grads)
-    finally:
-        lib.grad_arena = None
+    forward: only block inputs are stored).  Both give bit-identical gradients.  Returns (loss, {state-dict name: gradient}).
+    This functional form builds a throw-away TrainPlan (fresh gradient buffer, nothing cached across calls); loops use TrainPlan.step."""
+    return TrainPlan(lib, sd, unet_cfg, wave_cfg, recompute=recompute).step(x0, noise, t, ids, mel, beta=beta, add=add, reducer=reducer)
 
 
-def _training_step(lib, sd, unet_cfg, wave_cfg, x0, noise, t, ids, mel, beta, add, reducer, recompute, grads):
+def _training_step(lib, sd, unet_cfg, wave_cfg, x0, noise, t, ids, mel, beta, add, reducer, recompute, grads, packs=None):
     xt = lib.train_q_sample(x0, noise, t, sd["sqrt_alphas_cumprod"], sd["sqrt_one_minus_alphas_cumprod"])
     table = lib.f32(sd["model.cond_stage_model.embedding.weight"])
     context = lib.cond_embed(table, ids)
-    wave = WaveStep(lib, sd, wave_cfg, recompute=recompute)
+    wave = WaveStep(lib, sd, wave_cfg, recompute=recompute, packs=packs)
     audios = wave.forward(mel)
-    unet = UNetStep(lib, sd, unet_cfg, recompute=recompute)
+    unet = UNetStep(lib, sd, unet_cfg, recompute=recompute, packs=packs)
     pred = unet.forward(xt, t, context, audios)
     loss, dpred = lib.train_smooth_l1(pred, noise, beta=beta, add=add)
     _, dctx, daud = unet.backward(dpred, grads)
@@ -512,7 +574,7 @@ def fit(lib, sd, unet_cfg, wave_cfg, steps, batch, z, lr=1e-4, weight_decay=0.01
             sd[k] = v.to(dev)
     invalidate_param_cache(sd)
     broadcast_parameters(sd)                         # ranks start from rank 0's weights, as under DistributedDataParallel
-    state, params, losses = {}, None, []
+    plan, opt, losses = TrainPlan(lib, sd, unet_cfg, wave_cfg, recompute=recompute), None, []
     g = torch.Generator().manual_seed(seed * 1000 + rank)
     for i in range(steps):
         bseed = seed * 7919 + (0 if fixed_batch else i) * world + rank
@@ -522,10 +584,10 @@ def fit(lib, sd, unet_cfg, wave_cfg, steps, batch, z, lr=1e-4, weight_decay=0.01
         t = torch.randint(0, T, (batch,), generator=g)
         noise = torch.randn(batch, unet_cfg["in_channels"], z, generator=g).to(dev)
         red = BucketedAllReduce() if world > 1 else None
-        loss, grads = training_step(lib, sd, unet_cfg, wave_cfg, x0, noise, t, ids, mel, reducer=red, recompute=recompute)
-        if params is None:
-            params = {k: sd[k] for k in grads}
-        adamw_step(lib, params, grads, state, i + 1, lr=lr, weight_decay=weight_decay)
+        loss, grads = plan.step(x0, noise, t, ids, mel, reducer=red)
+        if opt is None:                                   # the plan's gradient tensors are the same views every step
+            opt = AdamW(lib, {k: sd[k] for k in grads}, grads, lr=lr, weight_decay=weight_decay)
+        opt.step()
         losses.append(float(loss))
         if log is not None and rank == 0:
             log(i, losses[-1])

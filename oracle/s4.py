@@ -87,15 +87,15 @@ def s4_kernel(sd, p, L, mode="reference", symmetric=False):
     return k.float()
 
 
-def s4_forward(sd, p, u, kernel_cache=None, mode="reference"):
+def s4_forward(sd, p, u, kernel_cache=None, mode="reference", symmetric=False):
     """S4.forward (s4.py:1471-1541): FFT long-conv with the generated kernel,
     + D*u, exact-erf GELU, Conv1d(H->2H,k=1) + GLU over channels.  u: (B,H,L)."""
     L = u.shape[-1]
-    key = (p, L, mode)
+    key = (p, L, mode, symmetric)
     if kernel_cache is not None and key in kernel_cache:
         k = kernel_cache[key]
     else:
-        k = s4_kernel(sd, p + ".kernel.kernel", L, mode)
+        k = s4_kernel(sd, p + ".kernel.kernel", L, mode, symmetric=symmetric)
         if kernel_cache is not None:
             kernel_cache[key] = k
     k_f = torch.fft.rfft(k, n=2 * L)

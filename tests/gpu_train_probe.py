@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--z", type=int, default=512)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--tiny", action="store_true")
+    ap.add_argument("--cprofile", action="store_true", help="cProfile of the host side of the last step")
+    ap.add_argument("--adamw", action="store_true", help="include the optimiser step")
     ap.add_argument("--bf16", action="store_true", help="GEMMs on the bf16 matrix cores (mugd_train_set_precision)")
     a = ap.parse_args()
     case = cases.TINY if a.tiny else cases.FULL
@@ -38,15 +40,35 @@ def main():
     t = torch.from_numpy(rng.integers(0, 1000, B))
     ids = torch.from_numpy(rng.integers(0, sd["model.cond_stage_model.embedding.weight"].shape[0], (B, case["n_ctx_tok"])))
     mel = torch.from_numpy(np.abs(rng.standard_normal((B, case["wave"]["n_freq"], z * case["audio_ratio"]))).astype(np.float32))
+    plan = train.TrainPlan(lib, sd, case["unet"], case["wave"])
+    opt = None
+    prof = None
     for r in range(a.reps):
         torch.cuda.synchronize()
+        if a.cprofile and r == a.reps - 1:
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
         t0 = time.perf_counter()
-        loss, grads = train.training_step(lib, sd, case["unet"], case["wave"], x0, noise, t, ids, mel)
+        loss, grads = plan.step(x0, noise, t, ids, mel)
+        if a.adamw:
+            if opt is None:
+                opt = train.AdamW(lib, {k: sd[k] for k in grads}, grads, lr=1e-6)
+            opt.step()
+        t_host = time.perf_counter() - t0
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        bad = [k for k, g in grads.items() if not torch.isfinite(g).all()]
-        gn = float(sum(float((g.double() ** 2).sum()) for g in grads.values()) ** 0.5)
-        print(("bf16 " if a.bf16 else "fp32 ") + "step %d: loss %.6f  %d gradient tensors (%d non-finite)  |g| %.4e  %.2f s  (%.1f samples/s)" % (r, float(loss), len(grads), len(bad), gn, dt, B / dt), flush=True)
+        if prof is not None:
+            prof.disable()
+        line = ("bf16 " if a.bf16 else "fp32 ") + "step %d: %.3f s wall, host enqueue %.3f s (%.1f samples/s)" % (r, dt, t_host, B / dt)
+        if r == a.reps - 1 or r == 0:
+            bad = [k for k, g in grads.items() if not torch.isfinite(g).all()]
+            gn = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())))
+            line += "  loss %.6f  %d gradient tensors (%d non-finite)  |g| %.4e" % (float(loss), len(grads), len(bad), gn)
+        print(line, flush=True)
+    if prof is not None:
+        import pstats
+        pstats.Stats(prof).sort_stats("cumulative").print_stats(35)
 
 
 if __name__ == "__main__":
