@@ -230,6 +230,10 @@ int mugd_op_timestep_embedding(mugd_ctx* ctx, const int64_t* t, float* out, int 
  * reference would get from Lightning's `precision: bf16`, main.py / configs/mug/mug_diffusion.yaml:151): operands are rounded to
  * bfloat16 on their way into the matrix cores; master weights, activations in memory, norms, softmax, S4 and reductions stay fp32. */
 int mugd_train_set_precision(mugd_ctx* ctx, int bf16);
+/* Measurement hook of the training GEMMs.  enable != 0: from now on every conv / Linear forward + data-gradient GEMM (class 0) and every
+ * weight-gradient GEMM (class 1) launch is bracketed by a HIP event pair on the context's stream.  enable == 0: stop, synchronise, and
+ * (out != NULL) report out[0..1] = elapsed milliseconds, out[2..3] = algorithmic FLOPs (2 M K N), out[4..5] = launches per class. */
+int mugd_train_profile(mugd_ctx* ctx, int enable, double* out);
 /* Channel concatenation of (B, C, T) tensors and its gradient (unet.py:114-118 AudioConcatBlock, :542 skip th.cat):
  * out = cat([a, b], dim = 1);   split: a (+)= src[:, :Ca], b (+)= src[:, Ca:] (a or b may be NULL; accumulate_x: add instead of store);
  * add: out = a + b (n elements; out may alias either). */
@@ -307,6 +311,9 @@ int mugd_train_adamw(mugd_ctx* ctx, float* param, const float* grad, float* exp_
 /* The same step over a list of n tensors (one launch each, no host round trip per tensor): an optimiser step over a whole model. */
 int mugd_train_adamw_multi(mugd_ctx* ctx, int n, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                            const int64_t* sizes, float lr, float beta1, float beta2, float eps, float weight_decay, int step);
+/* The same step over a FIXED tensor list as ONE launch: desc is a DEVICE array of nchunks x 5 int64 {param, grad, exp_avg, exp_avg_sq
+ * addresses, element count <= 4096} -- every tensor cut into runs of <= 4096 elements, one workgroup per run (built once by the host). */
+int mugd_train_adamw_chunks(mugd_ctx* ctx, const int64_t* desc, int nchunks, float lr, float beta1, float beta2, float eps, float weight_decay, int step);
 
 #ifdef __cplusplus
 }

@@ -31,8 +31,24 @@ struct TrainPool {
 
 #include <unordered_map>
 
+// mugd_train_profile: while enabled, every training GEMM launch (conv / Linear forward + data gradient: kind 0; weight gradient: kind 1)
+// is bracketed by a HIP event pair on the context's stream; read() sums the elapsed times and the algorithmic FLOPs.
+struct TrainProfile {
+    struct Rec { hipEvent_t a, b; int kind; double flops; };
+    bool on = false;
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> free_events;
+    hipEvent_t get() {
+        if (!free_events.empty()) { hipEvent_t e = free_events.back(); free_events.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        HIP_CHECK(hipEventCreate(&e));
+        return e;
+    }
+};
+
 struct mugd_ctx {
     Ctx c;
+    TrainProfile tprof;
     TrainPool pool;
     // forward intermediates a training block kept for its backward call (mugd_train_*'s `state` argument): pool blocks in the
     // block's allocation order

@@ -65,7 +65,7 @@ __global__ void tpack_weights_kernel(const float* src, unsigned short* dst, int 
 // ---------------------------------------------------------------------------------------
 constexpr int TC_TN = 64;                 // output samples per workgroup
 constexpr int TC_WINMAX = 144;            // 63 * 2 + 2 * 8 + 1 = 143 window columns at most
-constexpr int TC_BUF = 16 * TC_WINMAX;    // dwords per LDS buffer: 16 pair-rows (3-tap, KC = 32) x 144, or 32 pair-rows (1-tap, KC = 64) x 64 -- both <= 2304
+constexpr int TC_BUF = 16 * TC_WINMAX + 4; // dwords per LDS buffer: 16 pair-rows (3-tap, KC = 32) x 144, or 32 pair-rows (1-tap, KC = 64) x 64 -- both <= 2304 (+ a dead slot)
 
 template <int TAPS>
 __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
@@ -90,7 +90,9 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
     const int u0 = t0 * a.stride - a.pad;
     const int vlen = a.ups ? 2 * a.Tin : a.Tin;
     const float inv_win = 1.0f / (float)WIN;
-    // ---- staging map: element e = tid + 256 i -> (pair-row p, window column col): channels 2p, 2p + 1 of the stage, sample u0 + col
+    // ---- staging map: element e = tid + 256 i -> (pair-row p, window column col): channels 2p, 2p + 1 of the stage, sample u0 + col.
+    // Loads are UNCONDITIONAL from clamped (always valid) addresses and zeroed by a select afterwards: a predicated load makes the
+    // compiler branch around every element (exec-mask juggling + 64-bit address math per element, no batching of the loads).
     unsigned goff[NIT];
     int loff[NIT], pch[NIT];           // pch: first channel of the element's pair inside the stage (2 p)
     bool ok[NIT];
@@ -105,9 +107,9 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
         ok[i] = in && u >= 0 && u < vlen;
         int uc = u < 0 ? 0 : u;
         uc = uc < vlen ? uc : vlen - 1;
-        goff[i] = (unsigned)(2 * p * a.Tin + (a.ups ? (uc >> 1) : uc));
+        goff[i] = (unsigned)(a.ups ? (uc >> 1) : uc);          // sample offset inside a channel row
         pch[i] = 2 * p;
-        loff[i] = in ? p * WIN + col : -1;
+        loff[i] = in ? p * WIN + col : TC_BUF - 1;             // dead elements park in the buffer's last dword (no window reaches it)
     }
     const float* xb = a.x + (size_t)b * a.C * a.Tin;
     const int mtile = mb * 4 + wave;
@@ -119,66 +121,70 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
 
+    // The packed weights hold a whole number of stages (zero blocks behind the last channel block: launch_tpack_weights), so every
+    // stage runs the same straight-line code; activation channels past C are zeroed when they are parked.
+    const int nstage = nkb / KSUB;
     float xlo[NIT], xhi[NIT];
-    u32x4 A[KSUB * TAPS], An[KSUB * TAPS];
-    const int nstage = (nkb + KSUB - 1) / KSUB;
+    u32x4 Aa[KSUB * TAPS], Ab[KSUB * TAPS];          // ping-pong weight fragments: no register copies in the loop
 
+    // raw, unconditional loads of stage s (window samples + weight fragments); nothing here USES a loaded value, so the loads stay in
+    // flight across the MFMAs of the stage before
     auto load_stage = [&](int s, u32x4 (&Ad)[KSUB * TAPS]) {
         const int c0 = s * KSUB * 16;
-        const float* xs = xb + (size_t)c0 * a.Tin;
+        const int cmax = a.C - 2 - c0;                       // last pair of the tensor, relative to the stage (C is a multiple of 16)
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const bool okc = ok[i] && (c0 + pch[i] + 1 < a.C);       // channels past C (the last, partial stage) are zero
-            xlo[i] = okc ? xs[goff[i]] : 0.f;
-            xhi[i] = okc ? xs[goff[i] + a.Tin] : 0.f;
+            const int pc = pch[i] < cmax ? pch[i] : cmax;    // channels past C (the last, partial stage): clamped address, zeroed in park()
+            const float* q = xb + (size_t)(unsigned)((c0 + pc) * a.Tin) + goff[i];
+            xlo[i] = q[0];
+            xhi[i] = q[a.Tin];
         }
 #pragma unroll
-        for (int kk = 0; kk < KSUB; ++kk) {
-            const int kb = s * KSUB + kk;
-            const int kbc = kb < nkb ? kb : nkb - 1;
+        for (int kk = 0; kk < KSUB; ++kk)
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap)
-                Ad[kk * TAPS + tap] = *reinterpret_cast<const u32x4*>(wp + ((size_t)kbc * TAPS + tap) * 512);
+                Ad[kk * TAPS + tap] = *reinterpret_cast<const u32x4*>(wp + ((size_t)(s * KSUB + kk) * TAPS + tap) * 512);
+    };
+    auto park = [&](int s, int buf) {                        // zero padding / channel tail, round to bf16 pairs, store
+        unsigned* w = smem + buf * TC_BUF;
+        const int cmax = a.C - 2 - s * KSUB * 16;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const bool okc = ok[i] && pch[i] <= cmax;
+            w[loff[i]] = pack_bf16(okc ? xlo[i] : 0.f, okc ? xhi[i] : 0.f);
         }
     };
-    auto park = [&](int buf) {
-        unsigned* w = smem + buf * TC_BUF;
+    auto compute = [&](int buf, const u32x4 (&A)[KSUB * TAPS]) {
+        const unsigned* w = smem + buf * TC_BUF;
 #pragma unroll
-        for (int i = 0; i < NIT; ++i)
-            if (loff[i] >= 0) w[loff[i]] = pack_bf16(xlo[i], xhi[i]);
-    };
-
-    load_stage(0, A);
-    park(0);
-    __syncthreads();
-    for (int s = 0; s < nstage; ++s) {
-        const bool more = s + 1 < nstage;
-        if (more) load_stage(s + 1, An);
-        const unsigned* w = smem + (s & 1) * TC_BUF;
-        if (active) {
+        for (int kk = 0; kk < KSUB; ++kk)
 #pragma unroll
-            for (int kk = 0; kk < KSUB; ++kk) {
-                if (s * KSUB + kk < nkb) {
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const bf16x8 af = __builtin_bit_cast(bf16x8, A[kk * TAPS + tap]);
 #pragma unroll
-                    for (int tap = 0; tap < TAPS; ++tap) {
-                        const bf16x8 af = __builtin_bit_cast(bf16x8, A[kk * TAPS + tap]);
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) {
-                            const unsigned* r = w + (kk * 8 + 4 * h) * WIN + (nt * 32 + n) * a.stride + tap * a.dil;
-                            u32x4 bv;
-                            bv[0] = r[0]; bv[1] = r[WIN]; bv[2] = r[2 * WIN]; bv[3] = r[3 * WIN];
-                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bv), acc[nt], 0, 0, 0);
-                        }
-                    }
+                for (int nt = 0; nt < 2; ++nt) {
+                    const unsigned* r = w + (kk * 8 + 4 * h) * WIN + (nt * 32 + n) * a.stride + tap * a.dil;
+                    u32x4 bv;
+                    bv[0] = r[0]; bv[1] = r[WIN]; bv[2] = r[2 * WIN]; bv[3] = r[3 * WIN];
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bv), acc[nt], 0, 0, 0);
                 }
             }
-        }
-        if (more) {
-            park((s + 1) & 1);
-#pragma unroll
-            for (int i = 0; i < KSUB * TAPS; ++i) A[i] = An[i];
-        }
+    };
+    // one stage: next stage's loads out, this stage on the matrix pipe, then the loaded window goes to the other LDS buffer
+    auto step = [&](int s, const u32x4 (&A)[KSUB * TAPS], u32x4 (&An)[KSUB * TAPS]) {
+        const bool more = s + 1 < nstage;
+        if (more) load_stage(s + 1, An);
+        if (active) compute(s & 1, A);
+        if (more) park(s + 1, (s + 1) & 1);
         __syncthreads();
+    };
+
+    load_stage(0, Aa);
+    park(0, 0);
+    __syncthreads();
+    for (int s = 0; s < nstage; s += 2) {
+        step(s, Aa, Ab);
+        if (s + 1 < nstage) step(s + 1, Ab, Aa);
     }
     if (!active) return;
     // ---- epilogue: accumulator register i of lane (h, n) is row (i & 3) + 8 (i >> 2) + 4 h, column n
@@ -229,14 +235,38 @@ __global__ __launch_bounds__(256) void twgrad_bf16_kernel(const TWgradArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
 
+    // raw, unconditional loads of slab s from clamped addresses; the zero padding is applied when the slab is parked (a select right
+    // behind a load would make the wave wait for it before the MFMAs of the slab in front)
     auto load_slab = [&](int s) {
         const int b = s / nslab, t0 = (s - b * nslab) * TW_KT;
+        const float* yb = a.dY + (size_t)b * a.M * a.Tout;
 #pragma unroll
         for (int i = 0; i < NY; ++i) {
             const int e = tid + 256 * i, row = e >> 5, col = e & 31;
             const int m = m0 + row, t = t0 + col;
-            const bool okk = m < a.M && t < a.Tout;
-            vy[i] = okk ? a.dY[((size_t)b * a.M + m) * a.Tout + t] : 0.f;
+            vy[i] = yb[(size_t)(unsigned)((m < a.M ? m : a.M - 1) * a.Tout + (t < a.Tout ? t : a.Tout - 1))];
+        }
+        const int u0 = t0 * a.stride - a.pad;
+        const float* xbp = a.X + (size_t)b * a.C * a.Tin;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            int e = tid + 256 * i;
+            e = e < 64 * W ? e : 0;
+            const int row = (int)(((float)e + 0.5f) * inv_w), col = e - row * W;
+            const int c = c0 + row, u = u0 + col;
+            int uc = u < 0 ? 0 : u;
+            uc = uc < vlen ? uc : vlen - 1;
+            vx[i] = xbp[(size_t)(unsigned)((c < a.C ? c : a.C - 1) * a.Tin + (a.ups ? (uc >> 1) : uc))];
+        }
+    };
+    auto park = [&](int s, int buf) {
+        const int b = s / nslab, t0 = (s - b * nslab) * TW_KT;
+        float* sy = smem + buf * TW_BUF;
+        float* sx = sy + 64 * TW_YS;
+#pragma unroll
+        for (int i = 0; i < NY; ++i) {
+            const int e = tid + 256 * i, row = e >> 5, col = e & 31;
+            sy[row * TW_YS + col] = (m0 + row < a.M && t0 + col < a.Tout) ? vy[i] : 0.f;
         }
         const int u0 = t0 * a.stride - a.pad;
 #pragma unroll
@@ -244,30 +274,15 @@ __global__ __launch_bounds__(256) void twgrad_bf16_kernel(const TWgradArgs a) {
             const int e = tid + 256 * i;
             if (e < 64 * W) {
                 const int row = (int)(((float)e + 0.5f) * inv_w), col = e - row * W;
-                const int c = c0 + row, u = u0 + col;
-                const bool okk = c < a.C && u >= 0 && u < vlen;
-                const int us = okk ? (a.ups ? (u >> 1) : u) : 0;
-                vx[i] = okk ? a.X[((size_t)b * a.C + (okk ? c : 0)) * a.Tin + us] : 0.f;
-            } else {
-                vx[i] = 0.f;
+                const int u = u0 + col;
+                sx[row * TW_XS + col] = (c0 + row < a.C && u >= 0 && u < vlen) ? vx[i] : 0.f;
             }
-        }
-    };
-    auto park = [&](int buf) {
-        float* sy = smem + buf * TW_BUF;
-        float* sx = sy + 64 * TW_YS;
-#pragma unroll
-        for (int i = 0; i < NY; ++i) { const int e = tid + 256 * i; sy[(e >> 5) * TW_YS + (e & 31)] = vy[i]; }
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const int e = tid + 256 * i;
-            if (e < 64 * W) { const int row = (int)(((float)e + 0.5f) * inv_w); sx[row * TW_XS + (e - row * W)] = vx[i]; }
         }
     };
 
     const int s_step = a.KS;
     int s = ks;
-    if (s < total) { load_slab(s); park(0); }
+    if (s < total) { load_slab(s); park(s, 0); }
     __syncthreads();
     int it = 0;
     for (; s < total; s += s_step, ++it) {
@@ -297,7 +312,7 @@ __global__ __launch_bounds__(256) void twgrad_bf16_kernel(const TWgradArgs a) {
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bv), acc[tap], 0, 0, 0);
             }
         }
-        if (more) park((it + 1) & 1);
+        if (more) park(s + s_step, (it + 1) & 1);
         __syncthreads();
     }
     // ---- store: dW (or partial slice ks) [m][c][tap]; accumulator register i of lane (h, n): row (i & 3) + 8 (i >> 2) + 4 h, column n
@@ -321,10 +336,12 @@ __global__ void twgrad_reduce_kernel(const float* part, float* dW, long long n, 
 
 }  // namespace
 
-size_t tpack_elems(int rows, int K, int taps) { return (size_t)cdiv(rows, 32) * cdiv(K, 16) * taps * 512; }
+// 16-channel blocks of the packed form: a whole number of tconv stages (4 blocks per stage for 1x1 layers, 2 for 3-tap ones)
+static int tpack_nkb(int K, int taps) { const int ksub = taps == 1 ? 4 : 2; return cdiv(cdiv(K, 16), ksub) * ksub; }
+size_t tpack_elems(int rows, int K, int taps) { return (size_t)cdiv(rows, 32) * tpack_nkb(K, taps) * taps * 512; }
 
 void launch_tpack_weights(hipStream_t st, const float* src, unsigned short* dst, int rows, int K, int taps, long long s_row, long long s_k, int flip) {
-    const int MT = cdiv(rows, 32), nkb = cdiv(K, 16);
+    const int MT = cdiv(rows, 32), nkb = tpack_nkb(K, taps);
     const long long total = (long long)MT * nkb * taps * 512;
     hipLaunchKernelGGL(tpack_weights_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 8192)), dim3(256), 0, st, src, dst, rows, K, taps, s_row, s_k,
                        flip, MT, nkb);
@@ -337,7 +354,7 @@ void launch_tconv_bf16(hipStream_t st, const TConvArgs& a0) {
     MUGD_CHECK(a.C % 16 == 0, -2, "tconv: channels must be a multiple of 16");
     MUGD_CHECK(a.taps == 3 || a.stride == 1, -2, "tconv: strided 1x1 convs are not used by the model");
     MUGD_CHECK((long long)a.C * a.Tin < (1ll << 31), -2, "tconv: batch row too long for 32-bit offsets");
-    a.nkb = a.C / 16;
+    a.nkb = tpack_nkb(a.C, a.taps);
     a.gx = cdiv(a.Tout, TC_TN);
     a.gy = cdiv(a.M, 128);
     const dim3 grid((unsigned)a.gx * a.gy * a.B);
@@ -352,8 +369,9 @@ int twgrad_splits(int B, int M, int C, int Tout, int taps) {
     long long ks = std::max<long long>(1, 768 / tiles);
     ks = std::min(ks, std::max<long long>(1, slabs / 4));
     const double operand = (double)B * Tout * ((double)M + C);
-    const long long cap = (long long)std::max(1.0, 0.5 * operand / ((double)M * C * taps));
-    ks = std::min(ks, cap);
+    long long cap = (long long)std::max(1.0, 0.5 * operand / ((double)M * C * taps));
+    cap = std::max(cap, std::min<long long>(cdiv(512, (int)tiles), slabs / 8));      // ... but never fewer than ~512 workgroups of >= 8 slabs
+    ks = std::min(ks, std::max<long long>(cap, 1));
     return (int)std::min<long long>(ks, 512);
 }
 

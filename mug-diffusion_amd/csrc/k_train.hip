@@ -427,7 +427,33 @@ __global__ void adamw_kernel(float* p, const float* g, float* m, float* v, long 
     p[i] = w;
 }
 
+// the same update over a whole parameter LIST in one launch: block b handles the contiguous run of elements its descriptor names
+// (desc[b] = {param, grad, exp_avg, exp_avg_sq pointers, element count <= 4096}; built once on the host for a fixed tensor list)
+__global__ __launch_bounds__(256) void adamw_chunks_kernel(const long long* desc, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2) {
+    const long long* d = desc + (size_t)blockIdx.x * 5;
+    float* p = reinterpret_cast<float*>(d[0]);
+    const float* g = reinterpret_cast<const float*>(d[1]);
+    float* m = reinterpret_cast<float*>(d[2]);
+    float* v = reinterpret_cast<float*>(d[3]);
+    const int n = (int)d[4];
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float w = p[i];
+        const float gi = g[i];
+        w -= lr * wd * w;
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        w -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+        p[i] = w;
+    }
+}
+
 }  // namespace
+
+void launch_adamw_chunks(hipStream_t st, const long long* desc, int nchunks, float lr, float b1, float b2, float eps, float wd, int step) {
+    const float bc1 = (float)(1.0 - pow((double)b1, (double)step)), bc2 = (float)(1.0 - pow((double)b2, (double)step));
+    hipLaunchKernelGGL(adamw_chunks_kernel, dim3((unsigned)nchunks), dim3(256), 0, st, desc, lr, b1, b2, eps, wd, bc1, bc2);
+}
 
 void launch_q_sample(hipStream_t st, const float* x0, const float* noise, const long long* t, const float* sqrt_ac, const float* sqrt_1mac,
                      float* out, int B, long long n) {

@@ -384,5 +384,6 @@ void launch_tconv_bf16(hipStream_t st, const TConvArgs& a);
 int twgrad_splits(int B, int M, int C, int Tout, int taps);
 void launch_twgrad_bf16(hipStream_t st, const TWgradArgs& a, float* partial /* KS * M * C * taps floats when KS > 1 */);
 
+void launch_adamw_chunks(hipStream_t st, const long long* desc, int nchunks, float lr, float b1, float b2, float eps, float wd, int step);
 void launch_embed_tokens(hipStream_t st, const float* table, const long long* ids, float* out, int B, int ntok, int dim);
 void launch_bias_sum(hipStream_t st, const float* a, const float* b, float* out, int n);

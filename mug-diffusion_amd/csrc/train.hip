@@ -94,6 +94,18 @@ struct Inter {
     }
 };
 
+// event pair around the GEMM launch(es) of one conv / weight-gradient call while the training profile is on (ctx.h)
+struct ProfScope {
+    TrainProfile* p; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; int kind; double flops;
+    ProfScope(TrainProfile* p_, hipStream_t st_, int kind_, double flops_) : p(p_ && p_->on ? p_ : nullptr), st(st_), kind(kind_), flops(flops_) {
+        if (p) { a = p->get(); b = p->get(); hipEventRecord(a, st); }
+    }
+    ~ProfScope() {
+        if (p) { hipEventRecord(b, st); p->recs.push_back(TrainProfile::Rec{a, b, kind, flops}); }
+    }
+};
+TrainProfile* g_tprof = nullptr;       // the active context's profile (one training context per process: set by mugd_train_profile)
+
 // y = conv1d(x; w) (+ bias) (+ rowadd[b][m]) (+ resid): w is a plain (M, C, taps) tensor, packed here.
 // wt_src (optional, with `transposed`): the conv runs on the transposed, tap-flipped form of the (C_of_x = rows of w, M = ..., taps)
 // tensor `w` -- the data gradient of a conv: x is the upstream gradient (B, Mw, T), the result has Cw channels.  fp32 mode packs from a
@@ -102,6 +114,7 @@ void run_conv_ex(Ctx& c, Scratch& sc, const float* x, const float* w, bool trans
                  const float* resid, float* y, int B, int C, int T, int M, int taps, int pad, int dil, int stride, int ups, int Tout) {
     MUGD_CHECK(C % CONV_CK == 0, MUGD_ERR_INVALID, "training slice: channel counts must be multiples of 16");
     hipStream_t st = c.stream;
+    ProfScope prof(g_tprof, st, 0, 2.0 * M * C * taps * (double)B * (Tout > 0 ? Tout : T));
     if (c.train_bf16) {
         unsigned short* wpk = reinterpret_cast<unsigned short*>(sc.get((tpack_elems(M, C, taps) + 1) / 2, false, st));
         // plain: A[m][ci][tap] = w[m][ci][tap];  transposed: w is (C, M, taps) and A[m][ci][tap] = w[ci][m][taps - 1 - tap]
@@ -144,6 +157,7 @@ void run_dgrad(Ctx& c, Scratch& sc, const float* dy, const float* w, float* wt, 
 // weight gradient with split-K partials from the call's scratch
 void run_wgrad(Ctx& c, Scratch& sc, const float* dY, const float* A, float* dW, int B, int M, int C, int Tout, int Tin, int taps, int pad, int dil = 1,
                int stride = 1, int ups = 0) {
+    ProfScope prof(g_tprof, c.stream, 1, 2.0 * M * C * taps * (double)B * Tout);
     if (c.train_bf16) {
         TWgradArgs a{dY, A, dW, B, M, C, Tout, Tin, taps, pad, dil, stride, ups, twgrad_splits(B, M, C, Tout, taps)};
         float* part = a.KS > 1 ? sc.get((size_t)a.KS * M * C * taps, false, c.stream) : nullptr;
@@ -488,6 +502,13 @@ int mugd_train_adamw_multi(mugd_ctx* ctx, int n, float* const* params, const flo
     });
 }
 
+int mugd_train_adamw_chunks(mugd_ctx* ctx, const int64_t* desc, int nchunks, float lr, float beta1, float beta2, float eps, float weight_decay, int step) {
+    return guarded(ctx, [&] {
+        MUGD_CHECK(desc && nchunks > 0 && step >= 1, MUGD_ERR_INVALID, "null/empty argument");
+        launch_adamw_chunks(ctx->c.stream, (const long long*)desc, nchunks, lr, beta1, beta2, eps, weight_decay, step);
+    });
+}
+
 int mugd_train_resblock(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x, const float* emb, const float* dy, float* y, float* dx,
                         float* demb, const mugd_resblock_grads* g, int B, int Cin, int Cout, int T, int Kemb, int groups, int64_t* state) {
     return guarded(ctx, [&] {
@@ -505,6 +526,33 @@ int mugd_train_set_precision(mugd_ctx* ctx, int bf16) {
     if (!ctx) return MUGD_ERR_INVALID;
     ctx->c.train_bf16 = bf16 != 0;
     return MUGD_OK;
+}
+
+// enable != 0: start (and clear) the GEMM profile; enable == 0 with out != NULL: stop, wait for the stream and report
+// out[0..1] = milliseconds, out[2..3] = algorithmic FLOPs, out[4..5] = launches of {conv / Linear forward + data gradients, weight gradients}
+int mugd_train_profile(mugd_ctx* ctx, int enable, double* out) {
+    return guarded(ctx, [&] {
+        TrainProfile& p = ctx->tprof;
+        if (enable) {
+            for (auto& r : p.recs) { p.free_events.push_back(r.a); p.free_events.push_back(r.b); }
+            p.recs.clear();
+            p.on = true;
+            g_tprof = &p;
+            return;
+        }
+        p.on = false;
+        g_tprof = nullptr;
+        HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        for (auto& r : p.recs) {
+            float ms = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
+            acc[r.kind] += ms; acc[2 + r.kind] += r.flops; acc[4 + r.kind] += 1.0;
+            p.free_events.push_back(r.a); p.free_events.push_back(r.b);
+        }
+        p.recs.clear();
+        if (out) for (int i = 0; i < 6; ++i) out[i] = acc[i];
+    });
 }
 
 int mugd_train_concat(mugd_ctx* ctx, const float* a, const float* b, float* out, int B, int Ca, int Cb, int T) {

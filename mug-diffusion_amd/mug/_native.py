@@ -87,10 +87,12 @@ _SIGS = {
     "mugd_train_resblock": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "mugd_train_release_states": [_p],
     "mugd_train_set_precision": [_p, _i],
+    "mugd_train_profile": [_p, _i, C.POINTER(C.c_double)],
     "mugd_train_concat": [_p, _p, _p, _p, _i, _i, _i, _i],
     "mugd_train_split": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i],
     "mugd_train_add": [_p, _p, _p, _p, C.c_int64],
     "mugd_train_adamw_multi": [_p, _i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _f, _i],
+    "mugd_train_adamw_chunks": [_p, _p, _i, _f, _f, _f, _f, _f, _i],
     "mugd_train_conv": [_p] * 13 + [_i] * 8 + [_p],
     "mugd_train_resnet_block": [_p] * 7 + [_i] * 7 + [_p],
     "mugd_train_time_embed": [_p] * 12 + [_i] * 3,
@@ -549,6 +551,15 @@ class Lib:
     def train_set_precision(self, bf16):
         """Training GEMMs on the bf16 matrix cores (fp32 accumulation; BASELINE configs[4]) instead of the fp32-input MFMA parity mode."""
         self.check(self.dll.mugd_train_set_precision(self.ctx, 1 if bf16 else 0))
+
+    def train_profile(self, enable):
+        """Event-bracket the training GEMM launches (True), or stop and return {'conv': {ms, flops, launches}, 'wgrad': {...}} (False)."""
+        if enable:
+            self.check(self.dll.mugd_train_profile(self.ctx, 1, None))
+            return None
+        out = (C.c_double * 6)()
+        self.check(self.dll.mugd_train_profile(self.ctx, 0, out))
+        return {"conv": dict(ms=out[0], flops=out[2], launches=int(out[4])), "wgrad": dict(ms=out[1], flops=out[3], launches=int(out[5]))}
 
     def train_concat(self, a, b):
         """cat([a, b], dim=1) of (B, C, T) tensors (skip / audio concatenation)."""

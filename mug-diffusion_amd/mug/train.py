@@ -88,16 +88,23 @@ class AdamW:
     single native call with prebuilt pointer arrays (configure_optimizers, diffusion.py:477-499: AdamW over the trainable tensors)."""
 
     def __init__(self, lib, params, grads, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
-        import ctypes as C
         self.lib, self.hp = lib, (float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay))
         self.keys = list(grads)
         self.tensors = [(params[k], grads[k], torch.zeros_like(params[k]), torch.zeros_like(params[k])) for k in self.keys]
         for p_, g_, _, _ in self.tensors:
             assert p_.is_contiguous() and g_.is_contiguous() and p_.dtype == torch.float32 and p_.device == lib.device and p_.shape == g_.shape
-        n = len(self.keys)
-        self.n = n
-        self.arrs = [(C.c_void_p * n)(*[t[i].data_ptr() for t in self.tensors]) for i in range(4)]
-        self.sizes = (C.c_longlong * n)(*[t[0].numel() for t in self.tensors])
+        # every tensor cut into runs of <= 4096 elements: one descriptor row {param, grad, exp_avg, exp_avg_sq address, count} per
+        # run, one workgroup per row, ONE launch per optimiser step (mugd_train_adamw_chunks)
+        import numpy as np
+        rows = []
+        for p_, g_, m_, v_ in self.tensors:
+            n = p_.numel()
+            offs = np.arange(0, n, 4096, dtype=np.int64)
+            cnt = np.minimum(4096, n - offs)
+            rows.append(np.stack([p_.data_ptr() + 4 * offs, g_.data_ptr() + 4 * offs, m_.data_ptr() + 4 * offs, v_.data_ptr() + 4 * offs, cnt], axis=1))
+        desc = np.concatenate(rows).astype(np.int64)
+        self.nchunks = int(desc.shape[0])
+        self.desc = torch.from_numpy(desc).to(lib.device)
         self.t = 0
 
     def step(self, lr=None):
@@ -105,8 +112,7 @@ class AdamW:
         lr_, b1, b2, eps, wd = self.hp
         lib = self.lib
         with lib.on_stream():
-            lib.check(lib.dll.mugd_train_adamw_multi(lib.ctx, self.n, self.arrs[0], self.arrs[1], self.arrs[2], self.arrs[3], self.sizes,
-                                                     float(lr_ if lr is None else lr), b1, b2, eps, wd, self.t))
+            lib.check(lib.dll.mugd_train_adamw_chunks(lib.ctx, self.desc.data_ptr(), self.nchunks, float(lr_ if lr is None else lr), b1, b2, eps, wd, self.t))
 
 
 # ------------------------------------------------------------------------------------------------------------------------------

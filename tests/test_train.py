@@ -323,6 +323,29 @@ def test_adamw_step_matches_torch(lib):
         close(p, pt, 2e-6, "parameters after step %d" % step)
 
 
+def test_fused_adamw_over_a_tensor_list_matches_torch(lib):
+    """mug.train.AdamW: the whole parameter list in ONE launch (mugd_train_adamw_chunks: tensors cut into runs of <= 4096 elements) against
+    torch.optim.AdamW, three steps, tensors below / at / above the run length and of odd sizes."""
+    from mug import train
+    dev = lib.device
+    shapes = [(7,), (4096,), (4097,), (3, 5000), (64, 16, 3)]
+    ps = [rnd(300 + i, *sh) for i, sh in enumerate(shapes)]
+    pts = [p.clone().requires_grad_(True) for p in ps]
+    opt_t = torch.optim.AdamW(pts, lr=2e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.02)
+    params = {"p%d" % i: p.clone().to(dev) for i, p in enumerate(ps)}
+    grads = {k: torch.zeros_like(v) for k, v in params.items()}
+    opt = train.AdamW(lib, params, grads, lr=2e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.02)
+    for step in range(3):
+        for i, pt in enumerate(pts):
+            g = rnd(400 + 10 * step + i, *shapes[i])
+            pt.grad = g.clone()
+            grads["p%d" % i].copy_(g.to(dev))
+        opt_t.step()
+        opt.step()
+        for i, pt in enumerate(pts):
+            close(params["p%d" % i], pt, 2e-6, "tensor %d after step %d" % (i, step + 1))
+
+
 def test_whole_model_training_step_vs_autograd(lib):
     """configs[4] in miniature: DDPM.p_losses (diffusion.py:356-414) on the structurally complete `tiny` model -- q_sample, prompt
     embedding, wave encoder, U-Net (ResBlocks, transformers with cross-attention, S4 layers, down / upsampling, audio and skip
