@@ -8,7 +8,7 @@
 One STEP = one batch of `--batch` charts for one synthetic 3-minute 22.05 kHz song, i.e. one full pass of
 the hot path with the PCM already resident in HBM:
     log-mel (HIP FFT + mel GEMM) -> wave encoder (once per song, shared by the seeds) -> prompt embedding
-    -> 50-step DDIM loop over the U-Net (hipGraph replay) -> VAE decode -> thresholded 4K note grid.
+    -> 50-step DDIM loop over the U-Net (one native call, eager launches) -> VAE decode -> thresholded 4K note grid.
 Every rank works on its own (song, seeds) units; there is no data-path collective (weak scaling).
 Weights are seeded synthetic values of the shipped architecture (no checkpoint exists offline), with the
 reference's zero-initialised tensors randomised so no branch is a no-op.  Arithmetic is fp32 end to end
@@ -223,13 +223,18 @@ def main():
         elapsed = float(tt.item())
     Bl = B * (a.pack_songs if a.audios_per_rank >= a.pack_songs else 1)      # charts per U-Net launch
 
-    train_info = None
+    train_info = train_info32 = None
     if not a.no_training_step and a.weights == "f32" and a.pack_songs == 1 and a.audios_per_rank == 1:
         try:                                                  # an extra: its failure must not take the headline line with it
-            train_info = training_leg(a, lib, model, dev, world, rank, grouped, sync_all)
-            note("training step done: %.1f samples/s" % train_info["value"])
+            train_info = training_leg(a, lib, model, dev, world, rank, grouped, sync_all, bf16=True)
+            note("training step (bf16 GEMMs) done: %.1f samples/s" % train_info["value"])
+            train_info32 = training_leg(a, lib, model, dev, world, rank, grouped, sync_all, bf16=False)
+            note("training step (fp32) done: %.1f samples/s" % train_info32["value"])
         except Exception as e:                                # noqa: BLE001
-            train_info = {"error": repr(e)[:400]}
+            if train_info is None:
+                train_info = {"error": repr(e)[:400]}
+            else:
+                train_info32 = {"error": repr(e)[:400]}
             note("training step failed: %r" % e)
 
     out = None
@@ -258,7 +263,7 @@ def main():
             prof = unet.native().profile()
             k = {f: prof["conv_gemm"][f] + prof["conv_gemm_gated"][f] for f in ("ms", "flops", "launches")}
             # An event pair around a launch also times the gap to the previous kernel.  Calibrate it from two live measurements
-            # of the same program: (sum of event-bracketed launch times, eager) - (time of one graph-replayed step of the timed
+            # of the same program: (sum of event-bracketed launch times, eager) - (time of one step of the timed
             # region), spread over the launches; rocprofv3's per-kernel averages (profiles/) agree with the corrected figure.
             eager_ms = sum(v["ms"] for v in prof.values())
             launches = sum(v["launches"] for v in prof.values())
@@ -338,6 +343,8 @@ def main():
             note("reduced-precision mode done: %.1f charts/s" % (len(units) / dt))
         if train_info is not None:
             out["training_step"] = train_info
+        if train_info32 is not None:
+            out["training_step_fp32"] = train_info32
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a, z, n_unet_steps)
             note("cpu baseline done")
@@ -393,14 +400,22 @@ def launcher_selftest(a, rank, world):
     dist.destroy_process_group()
 
 
-def training_leg(a, lib, model, dev, world, rank, grouped, sync_all):
-    """BASELINE configs[4] shape, fp32: one DDPM training step per rank on `--train-batch` synthetic samples (z = 512 latents,
-    32768-frame log-mel, random prompts and timesteps) = q_sample -> wave encoder -> prompt embedding -> U-Net -> smooth-L1 loss ->
-    backward through all three networks (mug/train.py: native block forward / backward entry points; blocks keep their forward intermediates) ->
-    bucketed all-reduce of the 1327 gradient tensors overlapped with the backward sweep (RCCL when N > 1) -> AdamW on every tensor.  1 warm-up + 2 timed steps,
-    barrier + synchronize on both sides, MAX over ranks.  Reported next to the headline, never as it."""
+PEAK_BF16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16), 256 CUs @ 2.4 GHz
+TRAIN_GFLOP_PER_SAMPLE = 3 * (22.37 + 50.5)      # forward + data gradients + weight gradients of the U-Net (22.37) and wave encoder (50.5), BASELINE.md section 2
+
+
+def training_leg(a, lib, model, dev, world, rank, grouped, sync_all, bf16=True):
+    """BASELINE configs[4] shape: one DDPM training step per rank on `--train-batch` synthetic samples (z = 512 latents, 32768-frame
+    log-mel, random prompts and timesteps) = q_sample -> wave encoder -> prompt embedding -> U-Net -> smooth-L1 loss -> backward
+    through all three networks (mug/train.py TrainPlan: native block forward / backward entry points, blocks keep their forward
+    intermediates, no host synchronisation inside the step) -> bucketed all-reduce of the 1327 gradient tensors overlapped with the
+    backward sweep (RCCL when N > 1) -> AdamW on every tensor (one launch).  bf16: the GEMMs on the bf16 matrix cores with fp32
+    accumulation (configs[4]'s precision; everything else fp32); else the fp32-input MFMA parity mode.  1 warm-up + 3 timed steps,
+    barrier + synchronize on both sides, MAX over ranks; then one more step with an event pair around every GEMM launch for the
+    GEMM roofline.  Reported next to the headline, never as it."""
     import torch.distributed as dist
     from mug import train
+    lib.train_set_precision(bf16)
     sd = {k: v.detach() for k, v in model.state_dict().items()}
     Bt, z = a.train_batch, SHIPPED["z_length"]
     g = torch.Generator().manual_seed(1234 + rank)
@@ -419,24 +434,43 @@ def training_leg(a, lib, model, dev, world, rank, grouped, sync_all):
         opt[0].step()
         return loss, grads
 
-    loss, grads = step(1)
-    sync_all()
-    t0 = time.perf_counter()
-    reps = 2
-    for i in range(reps):
-        loss, grads = step(2 + i)
-    sync_all()
-    dt = (time.perf_counter() - t0) / reps
-    if grouped:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    try:
+        loss, grads = step(1)
+        sync_all()
+        t0 = time.perf_counter()
+        reps = 3
+        for i in range(reps):
+            loss, grads = step(2 + i)
+        sync_all()
+        dt = (time.perf_counter() - t0) / reps
+        if grouped:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        lib.train_profile(True)                      # one more step with HIP events around every GEMM launch (library stream)
+        step(2 + reps)
+        prof = lib.train_profile(False)
+    finally:
+        lib.train_set_precision(False)
     nparam = sum(v.numel() for v in grads.values())
-    return {"what": "configs[4] shape in fp32: DDPM training step (q_sample, wave encoder, prompt embedding, U-Net, smooth-L1, backward through all "
-                    "three networks, bucketed gradient all-reduce overlapped with the backward sweep, AdamW), per-GPU batch %d, z = %d, synthetic data; "
-                    "first version, fp32, not tuned" % (Bt, z),
-            "value": Bt * world / dt, "unit": "samples/s", "ms_per_step": dt * 1e3, "global_batch": Bt * world, "dtype": "f32",
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+    gemm_ms = prof["conv"]["ms"] + prof["wgrad"]["ms"]
+    gemm_fl = prof["conv"]["flops"] + prof["wgrad"]["flops"]
+    kern = "tconv_bf16_kernel / twgrad_bf16_kernel (v_mfma_f32_32x32x16_bf16)" if bf16 else "conv_gemm_kernel / wgrad_mfma_kernel (v_mfma_f32_32x32x2_f32)"
+    return {"what": "configs[4] shape: DDPM training step (q_sample, wave encoder, prompt embedding, U-Net, smooth-L1, backward through all three "
+                    "networks, bucketed gradient all-reduce overlapped with the backward sweep, AdamW), per-GPU batch %d, z = %d, synthetic data; %s"
+                    % (Bt, z, "conv / Linear GEMMs (forward, data and weight gradients) with bf16 MFMA inputs and fp32 accumulation, fp32 master weights, "
+                              "activations, norms, softmax, S4 and reductions" if bf16 else "fp32-input MFMA everywhere (the parity mode)"),
+            "value": Bt * world / dt, "unit": "samples/s", "ms_per_step": dt * 1e3, "global_batch": Bt * world, "dtype": "bf16" if bf16 else "f32",
             "loss": float(loss), "gradient_tensors": len(grads), "trainable_parameters": int(nparam),
+            "algorithmic_tflops_whole_step": TRAIN_GFLOP_PER_SAMPLE * Bt / dt / 1e3,
+            "roofline": {"kernel": kern + ": all %d GEMM launches of one step, HIP event pair around each on the library stream (pack / split-K "
+                                         "reduce launches of a call included in its bracket)" % (prof["conv"]["launches"] + prof["wgrad"]["launches"]),
+                         "bound": "mfma", "achieved": gemm_fl / (gemm_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                         "frac": gemm_fl / (gemm_ms * 1e-3) / 1e12 / peak, "traffic": None,
+                         "gemm_ms_per_step": gemm_ms, "gemm_share_of_step": gemm_ms / (dt * 1e3),
+                         "forward_and_dgrad": {"tflops": prof["conv"]["flops"] / (prof["conv"]["ms"] * 1e-3) / 1e12, "ms": prof["conv"]["ms"], "launches": prof["conv"]["launches"]},
+                         "wgrad": {"tflops": prof["wgrad"]["flops"] / (prof["wgrad"]["ms"] * 1e-3) / 1e12, "ms": prof["wgrad"]["ms"], "launches": prof["wgrad"]["launches"]}},
             "allreduce": ("RCCL, %.0f MB of fp32 gradients per step in 64 MB buckets, asynchronous, overlapped with the backward sweep"
                           % (nparam * 4 / 1e6)) if world > 1 else "none (1 rank)"}
 

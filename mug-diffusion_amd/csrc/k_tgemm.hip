@@ -25,6 +25,7 @@
 //   one barrier per slab, next slab's loads in flight during the MFMAs.  KS > 1 writes partial tiles; wgrad_reduce sums them in
 //   fixed order (deterministic).
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -63,15 +64,18 @@ __global__ void tpack_weights_kernel(const float* src, unsigned short* dst, int 
 // ---------------------------------------------------------------------------------------
 // tconv
 // ---------------------------------------------------------------------------------------
-constexpr int TC_TN = 64;                 // output samples per workgroup
 constexpr int TC_WINMAX = 144;            // 63 * 2 + 2 * 8 + 1 = 143 window columns at most
 constexpr int TC_BUF = 16 * TC_WINMAX + 4; // dwords per LDS buffer: 16 pair-rows (3-tap, KC = 32) x 144, or 32 pair-rows (1-tap, KC = 64) x 64 -- both <= 2304 (+ a dead slot)
 
-template <int TAPS>
+// NT = 32-sample accumulator tiles per wave: 2 (128 x 64 workgroup tile) or 1 (128 x 32: twice the workgroups for the layers whose
+// 128 x 64 tile grid cannot fill the chip -- the U-Net's GEMMs at batch 32 have 2048..16384 columns)
+template <int TAPS, int NT>
 __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
+    constexpr int TC_TN = 32 * NT;
     constexpr int KSUB = TAPS == 1 ? 4 : 2;             // 16-channel blocks per stage
     constexpr int PR = KSUB * 8;                        // pair-rows per stage
-    constexpr int NIT = TAPS == 1 ? 8 : 9;              // staging passes: PR * WIN / 256 (1-tap: WIN <= 64 -> 8; 3-tap: 16 * 144 / 256 = 9)
+    constexpr int WINMAX = TAPS == 1 ? TC_TN : (TC_TN - 1) * 2 + 17;
+    constexpr int NIT = (PR * WINMAX + 255) / 256;      // staging passes: PR * WIN / 256 (NT = 2: 8 for 1x1, 9 for 3-tap layers)
     __shared__ unsigned smem[2 * TC_BUF];
 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, h = lane >> 5, n = lane & 31;
@@ -117,9 +121,11 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
     const int nkb = a.nkb;
     const unsigned short* wp = a.wpk + ((size_t)(active ? mtile : 0) * nkb * TAPS * 64 + lane) * 8;
 
-    f32x16 acc[2];
+    f32x16 acc[NT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
 
     // The packed weights hold a whole number of stages (zero blocks behind the last channel block: launch_tpack_weights), so every
     // stage runs the same straight-line code; activation channels past C are zeroed when they are parked.
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
             for (int tap = 0; tap < TAPS; ++tap) {
                 const bf16x8 af = __builtin_bit_cast(bf16x8, A[kk * TAPS + tap]);
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
+                for (int nt = 0; nt < NT; ++nt) {
                     const unsigned* r = w + (kk * 8 + 4 * h) * WIN + (nt * 32 + n) * a.stride + tap * a.dil;
                     u32x4 bv;
                     bv[0] = r[0]; bv[1] = r[WIN]; bv[2] = r[2 * WIN]; bv[3] = r[3 * WIN];
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
             float add = a.bias ? a.bias[m] : 0.f;
             if (a.rowadd) add += a.rowadd[(size_t)b * a.rowadd_stride + m];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
+            for (int nt = 0; nt < NT; ++nt) {
                 const int t = t0 + nt * 32 + n;
                 if (t < a.Tout) {
                     const size_t o = ((size_t)b * a.M + m) * a.Tout + t;
@@ -355,11 +361,13 @@ void launch_tconv_bf16(hipStream_t st, const TConvArgs& a0) {
     MUGD_CHECK(a.taps == 3 || a.stride == 1, -2, "tconv: strided 1x1 convs are not used by the model");
     MUGD_CHECK((long long)a.C * a.Tin < (1ll << 31), -2, "tconv: batch row too long for 32-bit offsets");
     a.nkb = tpack_nkb(a.C, a.taps);
-    a.gx = cdiv(a.Tout, TC_TN);
     a.gy = cdiv(a.M, 128);
+    int nt = (long long)cdiv(a.Tout, 64) * a.gy * a.B < 768 ? 1 : 2;        // too few 128 x 64 tiles for 256 CUs x 2-3 workgroups: halve them
+    if (const char* e = getenv("MUGD_TCONV_NT")) { const int v = atoi(e); if (v == 1 || v == 2) nt = v; }      // development / test knob
+    a.gx = cdiv(a.Tout, 32 * nt);
     const dim3 grid((unsigned)a.gx * a.gy * a.B);
-    if (a.taps == 1) hipLaunchKernelGGL(tconv_bf16_kernel<1>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(tconv_bf16_kernel<3>, grid, dim3(256), 0, st, a);
+    if (a.taps == 1) { if (nt == 1) hipLaunchKernelGGL((tconv_bf16_kernel<1, 1>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((tconv_bf16_kernel<1, 2>), grid, dim3(256), 0, st, a); }
+    else { if (nt == 1) hipLaunchKernelGGL((tconv_bf16_kernel<3, 1>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((tconv_bf16_kernel<3, 2>), grid, dim3(256), 0, st, a); }
 }
 
 // K-slices of a bf16 weight-gradient launch: enough workgroups to fill the chip, every slice with >= 4 slabs, partial tiles

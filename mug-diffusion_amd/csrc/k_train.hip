@@ -377,6 +377,7 @@ __global__ __launch_bounds__(256) void emb_linear_bwd_kernel(const float* e, con
         if (m >= M) return;
         for (int k = lane; k < K; k += 64) {
             float s = 0.f;
+#pragma unroll 8                                       // the loads of 8 batch rows go out together; the sum keeps its order
             for (int b = 0; b < B; ++b) { const float v = e[(size_t)b * K + k]; s += dE[(size_t)b * M + m] * (SILU ? v / (1.0f + expf(-v)) : v); }
             dWe[(size_t)m * K + k] = s;
         }
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(256) void emb_linear_bwd_kernel(const float* e, con
         {
             const int b = idx / kblocks;
             float s = 0.f;
+#pragma unroll 16                                      // 16 independent weight loads in flight per thread instead of one dependent round trip per row
             for (int m = 0; m < M; ++m) s += We[(size_t)m * K + k] * dE[(size_t)b * M + m];
             const float v = e[(size_t)b * K + k];
             const float sg = 1.0f / (1.0f + expf(-v));

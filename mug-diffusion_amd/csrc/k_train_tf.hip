@@ -127,6 +127,7 @@ __global__ void geglu_bwd_kernel(const float* u, const float* df, float* du, int
 
 // ---- attention backward, row kernel: one wave per query row.  grid (ceil(Tq / 4), heads, B), block 256.
 constexpr int ATB_TK = 1024;            // keys per row held in LDS
+constexpr int ATB_TKS = 512;            // ... in the LDS-staged forms
 __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(const AttnBwdArgs a) {
     __shared__ float qs[4][64], dos[4][64];
     __shared__ float srow[4][ATB_TK], drow[4][ATB_TK];
@@ -214,6 +215,119 @@ __global__ __launch_bounds__(256) void attn_bwd_cols_kernel(const AttnBwdArgs a)
         }
 }
 
+// ---------------------------------------------------------------------------------------
+// LDS-staged forms (round 3).  The first versions above re-read K / V (rows kernel) and q / dO (column kernel) of a head from global
+// memory for every query row / inside every key lane's loop: 4 GB of L2 reads per call at T = 256, 10-12 TFLOP/s, 25 ms of a batch-32
+// training step.  Here a workgroup stages the head's K and V (rows) or q and dO (columns) ONCE in LDS and serves 32 query rows /
+// 64 keys from it: the inner products read LDS (conflict-free: lanes walk consecutive keys of one channel row; rows padded by one float
+// for the transposed walk of the dq sum).  Same arithmetic and the same summation order per output as the first versions.
+// ---------------------------------------------------------------------------------------
+constexpr int ATB_RB = 32;               // query rows per workgroup (8 per wave)
+
+template <int KVF>                       // floats of LDS per staged operand: >= d * (Tk + 1)
+__global__ __launch_bounds__(256) void attn_bwd_rows_lds_kernel(const AttnBwdArgs a) {
+    __shared__ float ks[KVF], vs[KVF];
+    __shared__ float srow[4][ATB_TKS], drow[4][ATB_TKS];
+    __shared__ float qs[4][64], dos[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int d = a.d, Tq = a.Tq, Tk = a.Tk, KS = Tk + 1;
+    const float* q = a.q + (size_t)b * a.q_bstride + (size_t)h * d * Tq;
+    const float* k = a.k + (size_t)b * a.k_bstride + (size_t)h * d * Tk;
+    const float* v = a.v + (size_t)b * a.v_bstride + (size_t)h * d * Tk;
+    const float* dO = a.dout + (size_t)b * a.o_bstride + (size_t)h * d * Tq;
+    for (int e = threadIdx.x; e < d * Tk; e += 256) {
+        const int r = e / Tk, c = e - r * Tk;
+        ks[r * KS + c] = k[e];
+        vs[r * KS + c] = v[e];
+    }
+    __syncthreads();
+    for (int ii = wave; ii < ATB_RB; ii += 4) {
+        const int i = blockIdx.x * ATB_RB + ii;
+        if (i >= Tq) break;                                // whole wave
+        if (lane < d) { qs[wave][lane] = q[(size_t)lane * Tq + i]; dos[wave][lane] = dO[(size_t)lane * Tq + i]; }
+        wave_sync();
+        float mx = -3.0e38f;
+        for (int j = lane; j < Tk; j += 64) {
+            float dot = 0.f, da = 0.f;
+            for (int e = 0; e < d; ++e) { dot += qs[wave][e] * ks[e * KS + j]; da += dos[wave][e] * vs[e * KS + j]; }
+            int idx = j - i;
+            idx = (idx < -a.pmax ? -a.pmax : (idx > a.pmax ? a.pmax : idx)) + a.pmax;
+            const float sim = (dot + a.rel[idx * a.heads + h]) * a.scale;
+            srow[wave][j] = sim; drow[wave][j] = da;
+            mx = fmaxf(mx, sim);
+        }
+        mx = wave_max_ff(mx);
+        float sum = 0.f;
+        for (int j = lane; j < Tk; j += 64) { const float e = expf(srow[wave][j] - mx); srow[wave][j] = e; sum += e; }
+        sum = wave_sum_ff(sum);
+        const float inv = 1.0f / sum;
+        float D = 0.f;
+        for (int j = lane; j < Tk; j += 64) {
+            int idx = j - i;
+            idx = (idx < -a.pmax ? -a.pmax : (idx > a.pmax ? a.pmax : idx)) + a.pmax;
+            const float S = srow[wave][j] * inv, G = a.cemb[idx * a.heads + h];
+            srow[wave][j] = S;
+            D += drow[wave][j] * G * S;
+        }
+        D = wave_sum_ff(D);
+        const size_t mrow = (((size_t)b * a.heads + h) * Tq + i) * Tk;
+        for (int j = lane; j < Tk; j += 64) {
+            int idx = j - i;
+            idx = (idx < -a.pmax ? -a.pmax : (idx > a.pmax ? a.pmax : idx)) + a.pmax;
+            const float S = srow[wave][j], G = a.cemb[idx * a.heads + h], dA = drow[wave][j];
+            const float ds = S * (dA * G - D);
+            a.Amat[mrow + j] = S * G;
+            a.dsim[mrow + j] = ds;
+            a.dG[mrow + j] = dA * S;
+            drow[wave][j] = ds;
+        }
+        wave_sync();
+        if (lane < d) {                                     // dq_i[e] = scale sum_j dsim_j k[e][j]: lane = e, padded rows: conflict-free
+            float s = 0.f;
+            const float* kr = ks + lane * KS;
+            for (int j = 0; j < Tk; ++j) s += drow[wave][j] * kr[j];
+            a.dq[(size_t)b * a.q_bstride + ((size_t)h * d + lane) * Tq + i] = s * a.scale;
+        }
+        wave_sync();
+    }
+}
+
+// column kernel with q / dO of the head staged in LDS: one lane per key, the 4 waves split the head dimension
+template <int QF>
+__global__ __launch_bounds__(256) void attn_bwd_cols_lds_kernel(const AttnBwdArgs a) {
+    __shared__ float qsm[QF], dsm[QF];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 64 + lane, h = blockIdx.y, b = blockIdx.z;
+    const int d = a.d, Tq = a.Tq, Tk = a.Tk, dq = d >> 2, e0 = wave * dq;
+    const bool ok = j < Tk;
+    const int jc = ok ? j : Tk - 1;
+    const float* q = a.q + (size_t)b * a.q_bstride + (size_t)h * d * Tq;
+    const float* dO = a.dout + (size_t)b * a.o_bstride + (size_t)h * d * Tq;
+    for (int e = threadIdx.x; e < d * Tq; e += 256) { qsm[e] = q[e]; dsm[e] = dO[e]; }
+    __syncthreads();
+    const size_t m0 = ((size_t)b * a.heads + h) * Tq * Tk;
+    const float* qw = qsm + e0 * Tq;
+    const float* dw = dsm + e0 * Tq;
+    float dk[16], dv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dk[e] = 0.f; dv[e] = 0.f; }
+#pragma unroll 4
+    for (int i = 0; i < Tq; ++i) {
+        const float ds = a.dsim[m0 + (size_t)i * Tk + jc], aa = a.Amat[m0 + (size_t)i * Tk + jc];
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            if (e < dq) { dk[e] += ds * qw[e * Tq + i]; dv[e] += aa * dw[e * Tq + i]; }
+    }
+    if (!ok) return;
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+        if (e < dq) {
+            a.dk[(size_t)b * a.k_bstride + ((size_t)h * d + e0 + e) * Tk + j] = dk[e] * a.scale;
+            a.dv[(size_t)b * a.v_bstride + ((size_t)h * d + e0 + e) * Tk + j] = dv[e];
+        }
+}
+
 // table kernel, stage 1: part[b][r][h] = {scale sum dsim, sum dA S} over the cells of batch row b with idx == r.
 // grid (2 pmax + 1, heads, B), block 256; stage 2 sums over b in fixed order.
 __global__ __launch_bounds__(256) void attn_bwd_tables_kernel(const AttnBwdArgs a, double* part) {
@@ -277,8 +391,14 @@ void launch_geglu_bwd(hipStream_t st, const float* u, const float* df, float* du
 void launch_attention_bwd(hipStream_t st, const AttnBwdArgs& a) {
     MUGD_CHECK(a.d >= 4 && a.d <= 64 && a.d % 4 == 0 && a.Tk >= 1 && a.Tk <= ATB_TK, -2, "attention backward: head dim 4..64 (multiple of 4), at most 1024 keys");
     MUGD_CHECK(a.tab_part, -2, "attention backward: no partial buffer for the table gradients");
-    hipLaunchKernelGGL(attn_bwd_rows_kernel, dim3(cdiv(a.Tq, 4), a.heads, a.B), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(attn_bwd_cols_kernel, dim3(cdiv(a.Tk, 64), a.heads, a.B), dim3(256), 0, st, a);
+    // LDS-staged forms when the head's K / V (resp. q / dO) fit: every shape of the model at z = 512 (d * T <= 16384); else the first versions
+    const int kv = a.d * (a.Tk + 1), qf = a.d * a.Tq;
+    if (a.Tk <= ATB_TKS && kv <= 4224) hipLaunchKernelGGL(attn_bwd_rows_lds_kernel<4224>, dim3(cdiv(a.Tq, ATB_RB), a.heads, a.B), dim3(256), 0, st, a);
+    else if (a.Tk <= ATB_TKS && kv <= 16640) hipLaunchKernelGGL(attn_bwd_rows_lds_kernel<16640>, dim3(cdiv(a.Tq, ATB_RB), a.heads, a.B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(attn_bwd_rows_kernel, dim3(cdiv(a.Tq, 4), a.heads, a.B), dim3(256), 0, st, a);
+    if (qf <= 4096) hipLaunchKernelGGL(attn_bwd_cols_lds_kernel<4096>, dim3(cdiv(a.Tk, 64), a.heads, a.B), dim3(256), 0, st, a);
+    else if (qf <= 16384) hipLaunchKernelGGL(attn_bwd_cols_lds_kernel<16384>, dim3(cdiv(a.Tk, 64), a.heads, a.B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(attn_bwd_cols_kernel, dim3(cdiv(a.Tk, 64), a.heads, a.B), dim3(256), 0, st, a);
     hipLaunchKernelGGL(attn_bwd_tables_kernel, dim3(2 * a.pmax + 1, a.heads, a.B), dim3(256), 0, st, a, a.tab_part);
     const int n = (2 * a.pmax + 1) * a.heads;
     hipLaunchKernelGGL(attn_tables_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, a.tab_part, a.drel, a.dcemb, a.B, n);
