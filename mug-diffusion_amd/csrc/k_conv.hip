@@ -66,7 +66,20 @@ __device__ __forceinline__ void load_a(const WT* wp, const WT* wp2, float4 (&A)[
     }
 }
 
-template <int TAPS, bool DUAL>
+typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 cbf16x2 __attribute__((ext_vector_type(2)));
+typedef float cf32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned cu32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned conv_pack_bf16(float lo, float hi) {
+    cf32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, cbf16x2));
+}
+
+// BF16 (the reduced-precision mode: bfloat16 weight fragments): the chunk's 8 channels per lane and tap -- A[i = 2 tap + g8] = weights
+// of channels 4 h + j + 8 g8, bf[...] = the same channels of the window -- are exactly the 8 k of ONE v_mfma_f32_32x32x16_bf16 per tap
+// (A and B use the same slot -> channel map, which is all the instruction needs), instead of 8 fp32-input MFMAs: the widened weights
+// are packed back (exact: they were bf16), the activations are rounded to bf16 here (round to nearest even); fp32 accumulation.
+template <int TAPS, bool DUAL, bool BF16 = false>
 __device__ __forceinline__ void mfma_chunk(const char* smem_bytes, int rb0, int dil, const float4 (&A)[6], const float4 (&A2)[6],
                                            f32x16& acc, f32x16& acc2) {
     float bf[TAPS * 8];
@@ -77,6 +90,25 @@ __device__ __forceinline__ void mfma_chunk(const char* smem_bytes, int rb0, int 
         for (int g8 = 0; g8 < 2; ++g8)
 #pragma unroll
             for (int j = 0; j < 4; ++j) bf[(tap * 2 + g8) * 4 + j] = *reinterpret_cast<const float*>(p + (g8 * 8 + j) * RS * 4);
+    }
+    if (BF16) {
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const float4 a0 = A[2 * tap], a1 = A[2 * tap + 1];
+            cu32x4 av, bv;
+            av[0] = conv_pack_bf16(a0.x, a0.y); av[1] = conv_pack_bf16(a0.z, a0.w); av[2] = conv_pack_bf16(a1.x, a1.y); av[3] = conv_pack_bf16(a1.z, a1.w);
+            const float* b8 = bf + tap * 8;
+            bv[0] = conv_pack_bf16(b8[0], b8[1]); bv[1] = conv_pack_bf16(b8[2], b8[3]); bv[2] = conv_pack_bf16(b8[4], b8[5]); bv[3] = conv_pack_bf16(b8[6], b8[7]);
+            const cbf16x8 bfr = __builtin_bit_cast(cbf16x8, bv);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cbf16x8, av), bfr, acc, 0, 0, 0);
+            if (DUAL) {
+                const float4 g0 = A2[2 * tap], g1 = A2[2 * tap + 1];
+                cu32x4 gv;
+                gv[0] = conv_pack_bf16(g0.x, g0.y); gv[1] = conv_pack_bf16(g0.z, g0.w); gv[2] = conv_pack_bf16(g1.x, g1.y); gv[3] = conv_pack_bf16(g1.z, g1.w);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cbf16x8, gv), bfr, acc2, 0, 0, 0);
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int i = 0; i < TAPS * 2; ++i) {
@@ -277,7 +309,7 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const WT* wseg
                 const int cc = c + d;
                 if (cc < nch) {
                     const int dn = (d + 1) % D;
-                    mfma_chunk<TAPS, DUAL>(smem_bytes + (d & 1) * W1, rb0, s.dil, RA[d], RA2[d], acc, acc2);
+                    mfma_chunk<TAPS, DUAL, sizeof(WT) == 2>(smem_bytes + (d & 1) * W1, rb0, s.dil, RA[d], RA2[d], acc, acc2);
                     if (cc + 1 < nch) {
                         park_v(((d + 1) & 1) * W1, RX0[dn], RX1[dn], RXH[dn], RGB[dn], RGG[dn]);
                         if (cc + 1 + D < nch) fetch_x(cc + 1 + D, dn);
@@ -315,7 +347,7 @@ __device__ __forceinline__ void run_segment_vec(const ConvSeg& s, const WT* wseg
             ++crel;
             if (xf) gbv = load_gb(crel);
         }
-        mfma_chunk<TAPS, DUAL>(smem_bytes, rb0, s.dil, A, A2, acc, acc2);
+        mfma_chunk<TAPS, DUAL, sizeof(WT) == 2>(smem_bytes, rb0, s.dil, A, A2, acc, acc2);
         wave_sync();               // all lanes done reading the window before it is overwritten
     };
 

@@ -65,14 +65,14 @@ __global__ void tpack_weights_kernel(const float* src, unsigned short* dst, int 
 // tconv
 // ---------------------------------------------------------------------------------------
 constexpr int TC_WINMAX = 144;            // 63 * 2 + 2 * 8 + 1 = 143 window columns at most
-constexpr int TC_BUF = 16 * TC_WINMAX + 4; // dwords per LDS buffer: 16 pair-rows (3-tap, KC = 32) x 144, or 32 pair-rows (1-tap, KC = 64) x 64 -- both <= 2304 (+ a dead slot)
+constexpr int TC_BUF = 32 * 79 + 4;        // dwords per LDS buffer: the largest of {16 pair-rows x 143, 32 x 64 (NT = 2)} and {32 x 79, 64 x 32 (NT = 1)} columns, + a dead slot
 
 // NT = 32-sample accumulator tiles per wave: 2 (128 x 64 workgroup tile) or 1 (128 x 32: twice the workgroups for the layers whose
 // 128 x 64 tile grid cannot fill the chip -- the U-Net's GEMMs at batch 32 have 2048..16384 columns)
 template <int TAPS, int NT>
 __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
     constexpr int TC_TN = 32 * NT;
-    constexpr int KSUB = TAPS == 1 ? 4 : 2;             // 16-channel blocks per stage
+    constexpr int KSUB = (TAPS == 1 ? 4 : 2) * (NT == 1 ? 2 : 1);      // 16-channel blocks per stage: the narrow tile stages twice the channels (same bytes per stage, half the barriers / latency periods per FLOP)
     constexpr int PR = KSUB * 8;                        // pair-rows per stage
     constexpr int WINMAX = TAPS == 1 ? TC_TN : (TC_TN - 1) * 2 + 17;
     constexpr int NIT = (PR * WINMAX + 255) / 256;      // staging passes: PR * WIN / 256 (NT = 2: 8 for 1x1, 9 for 3-tap layers)
@@ -217,13 +217,13 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
 // ---------------------------------------------------------------------------------------
 // twgrad
 // ---------------------------------------------------------------------------------------
-constexpr int TW_KT = 32;                 // samples per slab
-constexpr int TW_YS = 33;                 // LDS row stride of the dY slab (floats, odd)
-constexpr int TW_XS = 81;                 // LDS row stride of the input window: 31 * 2 + 2 * 8 + 1 = 79 columns at most, odd stride
-constexpr int TW_BUF = 64 * TW_YS + 64 * TW_XS;     // floats per LDS buffer
+constexpr int TW_XS = 81;                 // LDS row stride of the input window (floats, odd): 63 + 2 * 8 + 1 = 80 columns (64-sample slabs, stride 1) or 31 * 2 + 17 = 79 (32-sample slabs, stride 2)
 
-template <int TAPS>
+// TW_KT = samples per slab: 64 for stride-1 layers (half the barriers / latency periods per FLOP), 32 for the stride-2 Downsample convs
+template <int TAPS, int TW_KT>
 __global__ __launch_bounds__(256) void twgrad_bf16_kernel(const TWgradArgs a) {
+    constexpr int TW_YS = TW_KT + 1;                    // LDS row stride of the dY slab (floats, odd)
+    constexpr int TW_BUF = 64 * TW_YS + 64 * TW_XS;     // floats per LDS buffer
     __shared__ float smem[2 * TW_BUF];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, h = lane >> 5, n = lane & 31;
     const int wm = wave >> 1, wc = wave & 1;
@@ -232,8 +232,8 @@ __global__ __launch_bounds__(256) void twgrad_bf16_kernel(const TWgradArgs a) {
     const int W = (TW_KT - 1) * a.stride + (TAPS - 1) * a.dil + 1;
     const int vlen = a.ups ? 2 * a.Tin : a.Tin;
     const float inv_w = 1.0f / (float)W;
-    constexpr int NY = 8;                 // 64 * 32 / 256
-    constexpr int NX = 20;                // ceil(64 * 79 / 256)
+    constexpr int NY = 64 * TW_KT / 256;
+    constexpr int NX = 20;                // ceil(64 * 80 / 256)
     float vy[NY], vx[NX];
     f32x16 acc[TAPS];
 #pragma unroll
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void twgrad_bf16_kernel(const TWgradArgs a) {
         const float* yb = a.dY + (size_t)b * a.M * a.Tout;
 #pragma unroll
         for (int i = 0; i < NY; ++i) {
-            const int e = tid + 256 * i, row = e >> 5, col = e & 31;
+            const int e = tid + 256 * i, row = e / TW_KT, col = e % TW_KT;
             const int m = m0 + row, t = t0 + col;
             vy[i] = yb[(size_t)(unsigned)((m < a.M ? m : a.M - 1) * a.Tout + (t < a.Tout ? t : a.Tout - 1))];
         }
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void twgrad_bf16_kernel(const TWgradArgs a) {
         float* sx = sy + 64 * TW_YS;
 #pragma unroll
         for (int i = 0; i < NY; ++i) {
-            const int e = tid + 256 * i, row = e >> 5, col = e & 31;
+            const int e = tid + 256 * i, row = e / TW_KT, col = e % TW_KT;
             sy[row * TW_YS + col] = (m0 + row < a.M && t0 + col < a.Tout) ? vy[i] : 0.f;
         }
         const int u0 = t0 * a.stride - a.pad;
@@ -342,8 +342,8 @@ __global__ void twgrad_reduce_kernel(const float* part, float* dW, long long n, 
 
 }  // namespace
 
-// 16-channel blocks of the packed form: a whole number of tconv stages (4 blocks per stage for 1x1 layers, 2 for 3-tap ones)
-static int tpack_nkb(int K, int taps) { const int ksub = taps == 1 ? 4 : 2; return cdiv(cdiv(K, 16), ksub) * ksub; }
+// 16-channel blocks of the packed form: a whole number of tconv stages (up to 8 blocks per stage for 1x1 layers, 4 for 3-tap ones)
+static int tpack_nkb(int K, int taps) { const int ksub = taps == 1 ? 8 : 4; return cdiv(cdiv(K, 16), ksub) * ksub; }      // the larger (NT = 1) stage; the NT = 2 stage divides it
 size_t tpack_elems(int rows, int K, int taps) { return (size_t)cdiv(rows, 32) * tpack_nkb(K, taps) * taps * 512; }
 
 void launch_tpack_weights(hipStream_t st, const float* src, unsigned short* dst, int rows, int K, int taps, long long s_row, long long s_k, int flip) {
@@ -372,8 +372,8 @@ void launch_tconv_bf16(hipStream_t st, const TConvArgs& a0) {
 
 // K-slices of a bf16 weight-gradient launch: enough workgroups to fill the chip, every slice with >= 4 slabs, partial tiles
 // (KS * M * C * taps floats written and read back) kept below half the bytes of the operands
-int twgrad_splits(int B, int M, int C, int Tout, int taps) {
-    const long long tiles = (long long)cdiv(M, 64) * cdiv(C, 64), slabs = (long long)B * cdiv(Tout, TW_KT);
+int twgrad_splits(int B, int M, int C, int Tout, int taps, int kt) {
+    const long long tiles = (long long)cdiv(M, 64) * cdiv(C, 64), slabs = (long long)B * cdiv(Tout, kt);
     long long ks = std::max<long long>(1, 768 / tiles);
     ks = std::min(ks, std::max<long long>(1, slabs / 4));
     const double operand = (double)B * Tout * ((double)M + C);
@@ -391,8 +391,13 @@ void launch_twgrad_bf16(hipStream_t st, const TWgradArgs& a0, float* partial) {
     float* final_dw = a.dW;
     if (a.KS > 1) a.dW = partial;
     const dim3 grid(cdiv(a.M, 64), cdiv(a.C, 64), a.KS);
-    if (a.taps == 1) hipLaunchKernelGGL(twgrad_bf16_kernel<1>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(twgrad_bf16_kernel<3>, grid, dim3(256), 0, st, a);
+    if (a.stride == 1) {
+        if (a.taps == 1) hipLaunchKernelGGL((twgrad_bf16_kernel<1, 64>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((twgrad_bf16_kernel<3, 64>), grid, dim3(256), 0, st, a);
+    } else {
+        MUGD_CHECK(a.taps == 3, -2, "twgrad: strided 1x1 convs are not used by the model");
+        hipLaunchKernelGGL((twgrad_bf16_kernel<3, 32>), grid, dim3(256), 0, st, a);
+    }
     if (a.KS > 1) {
         const long long nn = (long long)a.M * a.C * a.taps;
         hipLaunchKernelGGL(twgrad_reduce_kernel, dim3((unsigned)std::min<long long>((nn + 255) / 256, 4096)), dim3(256), 0, st, partial, final_dw, nn, a.KS);

@@ -159,7 +159,7 @@ void run_wgrad(Ctx& c, Scratch& sc, const float* dY, const float* A, float* dW, 
                int stride = 1, int ups = 0) {
     ProfScope prof(g_tprof, c.stream, 1, 2.0 * M * C * taps * (double)B * Tout);
     if (c.train_bf16) {
-        TWgradArgs a{dY, A, dW, B, M, C, Tout, Tin, taps, pad, dil, stride, ups, twgrad_splits(B, M, C, Tout, taps)};
+        TWgradArgs a{dY, A, dW, B, M, C, Tout, Tin, taps, pad, dil, stride, ups, twgrad_splits(B, M, C, Tout, taps, stride == 1 ? 64 : 32)};
         float* part = a.KS > 1 ? sc.get((size_t)a.KS * M * C * taps, false, c.stream) : nullptr;
         launch_twgrad_bf16(c.stream, a, part);
         return;

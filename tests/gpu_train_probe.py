@@ -40,6 +40,7 @@ def main():
     t = torch.from_numpy(rng.integers(0, 1000, B))
     ids = torch.from_numpy(rng.integers(0, sd["model.cond_stage_model.embedding.weight"].shape[0], (B, case["n_ctx_tok"])))
     mel = torch.from_numpy(np.abs(rng.standard_normal((B, case["wave"]["n_freq"], z * case["audio_ratio"]))).astype(np.float32))
+    x0, noise, t, ids, mel = (v.to(lib.device) for v in (x0, noise, t, ids, mel))        # resident inputs, like bench.py's training leg
     plan = train.TrainPlan(lib, sd, case["unet"], case["wave"])
     opt = None
     prof = None
