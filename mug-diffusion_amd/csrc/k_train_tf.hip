@@ -127,7 +127,7 @@ __global__ void geglu_bwd_kernel(const float* u, const float* df, float* du, int
 
 // ---- attention backward, row kernel: one wave per query row.  grid (ceil(Tq / 4), heads, B), block 256.
 constexpr int ATB_TK = 1024;            // keys per row held in LDS
-constexpr int ATB_TKS = 512;            // ... in the LDS-staged forms
+constexpr int ATB_TKS = 256;            // ... in the LDS-staged forms
 __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(const AttnBwdArgs a) {
     __shared__ float qs[4][64], dos[4][64];
     __shared__ float srow[4][ATB_TK], drow[4][ATB_TK];
@@ -250,6 +250,7 @@ __global__ __launch_bounds__(256) void attn_bwd_rows_lds_kernel(const AttnBwdArg
         float mx = -3.0e38f;
         for (int j = lane; j < Tk; j += 64) {
             float dot = 0.f, da = 0.f;
+#pragma unroll 8                                           // 16 LDS operands in flight per lane: the loop is LDS-latency bound at one wave per SIMD
             for (int e = 0; e < d; ++e) { dot += qs[wave][e] * ks[e * KS + j]; da += dos[wave][e] * vs[e * KS + j]; }
             int idx = j - i;
             idx = (idx < -a.pmax ? -a.pmax : (idx > a.pmax ? a.pmax : idx)) + a.pmax;
@@ -286,6 +287,7 @@ __global__ __launch_bounds__(256) void attn_bwd_rows_lds_kernel(const AttnBwdArg
         if (lane < d) {                                     // dq_i[e] = scale sum_j dsim_j k[e][j]: lane = e, padded rows: conflict-free
             float s = 0.f;
             const float* kr = ks + lane * KS;
+#pragma unroll 8
             for (int j = 0; j < Tk; ++j) s += drow[wave][j] * kr[j];
             a.dq[(size_t)b * a.q_bstride + ((size_t)h * d + lane) * Tq + i] = s * a.scale;
         }
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(256) void attn_bwd_cols_lds_kernel(const AttnBwdArg
     float dk[16], dv[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { dk[e] = 0.f; dv[e] = 0.f; }
-#pragma unroll 4
+#pragma unroll 8
     for (int i = 0; i < Tq; ++i) {
         const float ds = a.dsim[m0 + (size_t)i * Tk + jc], aa = a.Amat[m0 + (size_t)i * Tk + jc];
 #pragma unroll
@@ -394,9 +396,11 @@ void launch_attention_bwd(hipStream_t st, const AttnBwdArgs& a) {
     // LDS-staged forms when the head's K / V (resp. q / dO) fit: every shape of the model at z = 512 (d * T <= 16384); else the first versions
     const int kv = a.d * (a.Tk + 1), qf = a.d * a.Tq;
     if (a.Tk <= ATB_TKS && kv <= 4224) hipLaunchKernelGGL(attn_bwd_rows_lds_kernel<4224>, dim3(cdiv(a.Tq, ATB_RB), a.heads, a.B), dim3(256), 0, st, a);
+    else if (a.Tk <= ATB_TKS && kv <= 8448) hipLaunchKernelGGL(attn_bwd_rows_lds_kernel<8448>, dim3(cdiv(a.Tq, ATB_RB), a.heads, a.B), dim3(256), 0, st, a);
     else if (a.Tk <= ATB_TKS && kv <= 16640) hipLaunchKernelGGL(attn_bwd_rows_lds_kernel<16640>, dim3(cdiv(a.Tq, ATB_RB), a.heads, a.B), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(attn_bwd_rows_kernel, dim3(cdiv(a.Tq, 4), a.heads, a.B), dim3(256), 0, st, a);
     if (qf <= 4096) hipLaunchKernelGGL(attn_bwd_cols_lds_kernel<4096>, dim3(cdiv(a.Tk, 64), a.heads, a.B), dim3(256), 0, st, a);
+    else if (qf <= 8192) hipLaunchKernelGGL(attn_bwd_cols_lds_kernel<8192>, dim3(cdiv(a.Tk, 64), a.heads, a.B), dim3(256), 0, st, a);
     else if (qf <= 16384) hipLaunchKernelGGL(attn_bwd_cols_lds_kernel<16384>, dim3(cdiv(a.Tk, 64), a.heads, a.B), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(attn_bwd_cols_kernel, dim3(cdiv(a.Tk, 64), a.heads, a.B), dim3(256), 0, st, a);
     hipLaunchKernelGGL(attn_bwd_tables_kernel, dim3(2 * a.pmax + 1, a.heads, a.B), dim3(256), 0, st, a, a.tab_part);

@@ -5,7 +5,7 @@ import csv
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
-for pat in ("tconv_bf16_kernel<1>", "tconv_bf16_kernel<3>", "twgrad_bf16_kernel<1>", "twgrad_bf16_kernel<3>", "attn_bwd", "gn_silu_bwd"):
+for pat in ("tconv_bf16_kernel<1", "tconv_bf16_kernel<3", "twgrad_bf16_kernel<1", "twgrad_bf16_kernel<3", "attn_bwd", "gn_silu_bwd"):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in rows:
         if pat not in r["Kernel_Name"]:
