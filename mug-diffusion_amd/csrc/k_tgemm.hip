@@ -235,6 +235,11 @@ __global__ __launch_bounds__(256) void twgrad_bf16_kernel(const TWgradArgs a) {
     constexpr int NY = 64 * TW_KT / 256;
     constexpr int NX = 20;                // ceil(64 * 80 / 256)
     float vy[NY], vx[NX];
+    // bias gradient db[m] = sum_{b,t} dY[b][m][t], fused: the c-tile-0 workgroups add up the dY values they stage anyway (fp32, fixed order)
+    const bool want_db = a.db != nullptr && blockIdx.y == 0;
+    float rs[NY];
+#pragma unroll
+    for (int i = 0; i < NY; ++i) rs[i] = 0.f;
     f32x16 acc[TAPS];
 #pragma unroll
     for (int k = 0; k < TAPS; ++k)
@@ -272,7 +277,9 @@ __global__ __launch_bounds__(256) void twgrad_bf16_kernel(const TWgradArgs a) {
 #pragma unroll
         for (int i = 0; i < NY; ++i) {
             const int e = tid + 256 * i, row = e / TW_KT, col = e % TW_KT;
-            sy[row * TW_YS + col] = (m0 + row < a.M && t0 + col < a.Tout) ? vy[i] : 0.f;
+            const float yv = (m0 + row < a.M && t0 + col < a.Tout) ? vy[i] : 0.f;
+            sy[row * TW_YS + col] = yv;
+            rs[i] += yv;
         }
         const int u0 = t0 * a.stride - a.pad;
 #pragma unroll
@@ -320,6 +327,16 @@ __global__ __launch_bounds__(256) void twgrad_bf16_kernel(const TWgradArgs a) {
         }
         if (more) park(s + s_step, (it + 1) & 1);
         __syncthreads();
+    }
+    if (want_db) {           // element i of this thread sits in row (tid + 256 i) / TW_KT: one row per wave (64-sample slabs) or per half wave (32)
+#pragma unroll
+        for (int i = 0; i < NY; ++i) {
+            float v = rs[i];
+#pragma unroll
+            for (int o = 1; o < (TW_KT < 64 ? TW_KT : 64); o <<= 1) v += __shfl_xor(v, o);
+            const int row = (tid + 256 * i) / TW_KT;
+            if ((tid & (TW_KT - 1)) == 0 && m0 + row < a.M) a.db[(size_t)ks * a.M + m0 + row] = v;
+        }
     }
     // ---- store: dW (or partial slice ks) [m][c][tap]; accumulator register i of lane (h, n): row (i & 3) + 8 (i >> 2) + 4 h, column n
     float* out = a.dW + (size_t)ks * a.M * a.C * TAPS;
@@ -389,17 +406,23 @@ void launch_twgrad_bf16(hipStream_t st, const TWgradArgs& a0, float* partial) {
     MUGD_CHECK(a.dil >= 1 && a.dil <= 8 && (a.stride == 1 || a.stride == 2), -2, "twgrad: dilation 1..8, stride 1 | 2");
     MUGD_CHECK(a.KS == 1 || partial, -2, "twgrad: split-K needs a partial buffer");
     float* final_dw = a.dW;
-    if (a.KS > 1) a.dW = partial;
+    float* final_db = a.db;
+    const long long nn = (long long)a.M * a.C * a.taps;
+    if (a.KS > 1) {                      // partial buffer: KS slices of dW, then (bias gradient wanted) KS slices of db
+        a.dW = partial;
+        if (a.db) a.db = partial + (size_t)a.KS * nn;
+    }
     const dim3 grid(cdiv(a.M, 64), cdiv(a.C, 64), a.KS);
-    if (a.stride == 1) {
-        if (a.taps == 1) hipLaunchKernelGGL((twgrad_bf16_kernel<1, 64>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((twgrad_bf16_kernel<3, 64>), grid, dim3(256), 0, st, a);
+    // 64-sample slabs pay for 1x1 layers (2 MFMAs per wave and 32-sample slab are too little work per barrier); the 3-tap kernels
+    // measured faster with 32-sample slabs (474 vs 369 us on the 128 x 128 x 3 wave-encoder layers: registers / LDS per workgroup)
+    if (a.taps == 1) {
+        MUGD_CHECK(a.stride == 1, -2, "twgrad: strided 1x1 convs are not used by the model");
+        hipLaunchKernelGGL((twgrad_bf16_kernel<1, 64>), grid, dim3(256), 0, st, a);
     } else {
-        MUGD_CHECK(a.taps == 3, -2, "twgrad: strided 1x1 convs are not used by the model");
         hipLaunchKernelGGL((twgrad_bf16_kernel<3, 32>), grid, dim3(256), 0, st, a);
     }
     if (a.KS > 1) {
-        const long long nn = (long long)a.M * a.C * a.taps;
         hipLaunchKernelGGL(twgrad_reduce_kernel, dim3((unsigned)std::min<long long>((nn + 255) / 256, 4096)), dim3(256), 0, st, partial, final_dw, nn, a.KS);
+        if (final_db) hipLaunchKernelGGL(twgrad_reduce_kernel, dim3((unsigned)cdiv(a.M, 256)), dim3(256), 0, st, a.db, final_db, (long long)a.M, a.KS);
     }
 }

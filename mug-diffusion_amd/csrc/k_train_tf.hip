@@ -393,15 +393,14 @@ void launch_geglu_bwd(hipStream_t st, const float* u, const float* df, float* du
 void launch_attention_bwd(hipStream_t st, const AttnBwdArgs& a) {
     MUGD_CHECK(a.d >= 4 && a.d <= 64 && a.d % 4 == 0 && a.Tk >= 1 && a.Tk <= ATB_TK, -2, "attention backward: head dim 4..64 (multiple of 4), at most 1024 keys");
     MUGD_CHECK(a.tab_part, -2, "attention backward: no partial buffer for the table gradients");
-    // LDS-staged forms when the head's K / V (resp. q / dO) fit: every shape of the model at z = 512 (d * T <= 16384); else the first versions
+    // LDS-staged forms when the head's K / V (resp. q / dO) fit with two workgroups per CU (d * T <= 8192: all U-Net shapes at z = 512);
+    // larger heads (the wave encoder's d = 64 at T = 256: one 150 KB workgroup per CU measured SLOWER, 796 / 1131 us) keep the first versions
     const int kv = a.d * (a.Tk + 1), qf = a.d * a.Tq;
     if (a.Tk <= ATB_TKS && kv <= 4224) hipLaunchKernelGGL(attn_bwd_rows_lds_kernel<4224>, dim3(cdiv(a.Tq, ATB_RB), a.heads, a.B), dim3(256), 0, st, a);
     else if (a.Tk <= ATB_TKS && kv <= 8448) hipLaunchKernelGGL(attn_bwd_rows_lds_kernel<8448>, dim3(cdiv(a.Tq, ATB_RB), a.heads, a.B), dim3(256), 0, st, a);
-    else if (a.Tk <= ATB_TKS && kv <= 16640) hipLaunchKernelGGL(attn_bwd_rows_lds_kernel<16640>, dim3(cdiv(a.Tq, ATB_RB), a.heads, a.B), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(attn_bwd_rows_kernel, dim3(cdiv(a.Tq, 4), a.heads, a.B), dim3(256), 0, st, a);
     if (qf <= 4096) hipLaunchKernelGGL(attn_bwd_cols_lds_kernel<4096>, dim3(cdiv(a.Tk, 64), a.heads, a.B), dim3(256), 0, st, a);
     else if (qf <= 8192) hipLaunchKernelGGL(attn_bwd_cols_lds_kernel<8192>, dim3(cdiv(a.Tk, 64), a.heads, a.B), dim3(256), 0, st, a);
-    else if (qf <= 16384) hipLaunchKernelGGL(attn_bwd_cols_lds_kernel<16384>, dim3(cdiv(a.Tk, 64), a.heads, a.B), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(attn_bwd_cols_kernel, dim3(cdiv(a.Tk, 64), a.heads, a.B), dim3(256), 0, st, a);
     hipLaunchKernelGGL(attn_bwd_tables_kernel, dim3(2 * a.pmax + 1, a.heads, a.B), dim3(256), 0, st, a, a.tab_part);
     const int n = (2 * a.pmax + 1) * a.heads;

@@ -376,13 +376,14 @@ struct TConvArgs {           // y[b][m][t] = bias[m] + rowadd[b][m] + resid[b][m
 struct TWgradArgs {          // dW[m][c][tap] = sum_{b,t} dY[b][m][t] X[b][c][stride t + tap dil - pad]
     const float* dY; const float* X; float* dW;
     int B, M, C, Tout, Tin, taps, pad, dil, stride, ups, KS;
+    float* db;               // null, or [M]: the bias gradient sum_{b,t} dY[b][m][t], summed from the dY slabs the kernel stages anyway
 };
 size_t tpack_elems(int rows, int K, int taps);               // bf16 elements of the packed form
 // A[row][k][tap] = src[row * s_row + k * s_k + (flip ? taps - 1 - tap : tap)]  ->  bf16 MFMA A-fragment order (zero padded to 32 rows / 16 k)
 void launch_tpack_weights(hipStream_t st, const float* src, unsigned short* dst, int rows, int K, int taps, long long s_row, long long s_k, int flip);
 void launch_tconv_bf16(hipStream_t st, const TConvArgs& a);
-int twgrad_splits(int B, int M, int C, int Tout, int taps, int kt /* samples per slab: 64 at stride 1, 32 at stride 2 */);
-void launch_twgrad_bf16(hipStream_t st, const TWgradArgs& a, float* partial /* KS * M * C * taps floats when KS > 1 */);
+int twgrad_splits(int B, int M, int C, int Tout, int taps, int kt /* samples per slab: 64 for 1x1 layers, 32 for 3-tap ones */);
+void launch_twgrad_bf16(hipStream_t st, const TWgradArgs& a, float* partial /* KS * (M * C * taps + M) floats when KS > 1 */);
 
 void launch_adamw_chunks(hipStream_t st, const long long* desc, int nchunks, float lr, float b1, float b2, float eps, float wd, int step);
 void launch_embed_tokens(hipStream_t st, const float* table, const long long* ids, float* out, int B, int ntok, int dim);

@@ -155,24 +155,29 @@ void run_dgrad(Ctx& c, Scratch& sc, const float* dy, const float* w, float* wt, 
 }
 
 // weight gradient with split-K partials from the call's scratch
-void run_wgrad(Ctx& c, Scratch& sc, const float* dY, const float* A, float* dW, int B, int M, int C, int Tout, int Tin, int taps, int pad, int dil = 1,
-               int stride = 1, int ups = 0) {
-    ProfScope prof(g_tprof, c.stream, 1, 2.0 * M * C * taps * (double)B * Tout);
-    if (c.train_bf16) {
-        TWgradArgs a{dY, A, dW, B, M, C, Tout, Tin, taps, pad, dil, stride, ups, twgrad_splits(B, M, C, Tout, taps, stride == 1 ? 64 : 32)};
-        float* part = a.KS > 1 ? sc.get((size_t)a.KS * M * C * taps, false, c.stream) : nullptr;
-        launch_twgrad_bf16(c.stream, a, part);
-        return;
-    }
-    const int ks = wgrad_splits(B, M, C, Tout);
-    float* part = ks > 1 ? sc.get((size_t)ks * M * C * taps, false, c.stream) : nullptr;
-    launch_wgrad_ex(c.stream, dY, A, dW, B, M, C, Tout, Tin, taps, pad, dil, stride, ups, part, ks);
-}
-
 void run_bias_grad(Ctx& c, Scratch& sc, const float* x, float* out, int B, int M, int T) {
     double* part = reinterpret_cast<double*>(sc.get((size_t)B * M * 2, false, c.stream));
     launch_bias_grad(c.stream, x, out, B, M, T, 0, part);
 }
+// weight gradient (+ bias gradient when db is given) with split-K partials from the call's scratch.  bf16 mode sums the bias gradient
+// inside the weight-gradient kernel (fp32, fixed order); fp32 mode keeps the fp64 row-sum kernels
+void run_wgrad(Ctx& c, Scratch& sc, const float* dY, const float* A, float* dW, int B, int M, int C, int Tout, int Tin, int taps, int pad, int dil = 1,
+               int stride = 1, int ups = 0, float* db = nullptr) {
+    {
+        ProfScope prof(g_tprof, c.stream, 1, 2.0 * M * C * taps * (double)B * Tout);
+        if (c.train_bf16) {
+            TWgradArgs a{dY, A, dW, B, M, C, Tout, Tin, taps, pad, dil, stride, ups, twgrad_splits(B, M, C, Tout, taps, taps == 1 ? 64 : 32), db};
+            float* part = a.KS > 1 ? sc.get((size_t)a.KS * ((size_t)M * C * taps + M), false, c.stream) : nullptr;
+            launch_twgrad_bf16(c.stream, a, part);
+            return;
+        }
+        const int ks = wgrad_splits(B, M, C, Tout);
+        float* part = ks > 1 ? sc.get((size_t)ks * M * C * taps, false, c.stream) : nullptr;
+        launch_wgrad_ex(c.stream, dY, A, dW, B, M, C, Tout, Tin, taps, pad, dil, stride, ups, part, ks);
+    }
+    if (db) run_bias_grad(c, sc, dY, db, B, M, Tout);
+}
+
 void run_gn_bwd(Ctx& c, Scratch& sc, const float* x, const float* da, const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta,
                 int B, int C, int T, int groups, int silu) {
     double* part = reinterpret_cast<double*>(sc.get((size_t)B * C * 4, false, c.stream));
@@ -203,8 +208,8 @@ struct Lin {
     }
     // dx (+= if acc) = W^T dy ;  dW = dy x^T ;  db = row sums of dy
     void bwd(const float* x, const float* w, const float* dy, float* dx, bool acc, float* dW, float* db, int K, int M, float* wt) {
-        if (dW) run_wgrad(c, sc, dy, x, dW, B, M, K, T, T, 1, 0);
-        if (db) run_bias_grad(c, sc, dy, db, B, M, T);
+        if (dW) run_wgrad(c, sc, dy, x, dW, B, M, K, T, T, 1, 0, 1, 1, 0, db);
+        else if (db) run_bias_grad(c, sc, dy, db, B, M, T);
         if (dx) run_dgrad(c, sc, dy, w, wt, acc ? dx : nullptr, dx, B, M, K, T, 1, 0);
     }
 };
@@ -247,8 +252,7 @@ void resblock_impl(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x,
         float* da1 = sc.get(nin, false, st);
         float* wt = sc.get((size_t)Cout * std::max(Cin, Cout) * 3, false, st);
         // out_layers conv: dW2, db2, da2 = conv3(dy; W2 transposed + flipped)
-        run_wgrad(c, sc, dy, a2, g->conv2_w, B, Cout, Cout, T, T, 3, d2, d2);
-        run_bias_grad(c, sc, dy, g->conv2_b, B, Cout, T);
+        run_wgrad(c, sc, dy, a2, g->conv2_w, B, Cout, Cout, T, T, 3, d2, d2, 1, 0, g->conv2_b);
         run_dgrad(c, sc, dy, p->conv2_w, wt, nullptr, da2, B, Cout, Cout, T, 3, d2, d2);
         run_gn_bwd(c, sc, h, da2, p->gn2_w, p->gn2_b, dh, g->gn2_w, g->gn2_b, B, Cout, T, groups, 1);
         if (emb) {          // h = conv1 + b1 + E: time-embedding branch
@@ -256,13 +260,11 @@ void resblock_impl(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x,
             launch_time_sum(st, dh, dE, B * Cout, T);
             launch_emb_linear_bwd(st, emb, p->emb_w, dE, g->emb_w, g->emb_b, demb, B, Kemb, Cout);
         }
-        run_wgrad(c, sc, dh, a1, g->conv1_w, B, Cout, Cin, T, T, 3, d1, d1);
-        run_bias_grad(c, sc, dh, g->conv1_b, B, Cout, T);
+        run_wgrad(c, sc, dh, a1, g->conv1_w, B, Cout, Cin, T, T, 3, d1, d1, 1, 0, g->conv1_b);
         run_dgrad(c, sc, dh, p->conv1_w, wt, nullptr, da1, B, Cout, Cin, T, 3, d1, d1);
         run_gn_bwd(c, sc, x, da1, p->gn1_w, p->gn1_b, dx, g->gn1_w, g->gn1_b, B, Cin, T, groups, 1);
         if (p->skip_w) {
-            run_wgrad(c, sc, dy, x, g->skip_w, B, Cout, Cin, T, T, 1, 0);
-            run_bias_grad(c, sc, dy, g->skip_b, B, Cout, T);
+            run_wgrad(c, sc, dy, x, g->skip_w, B, Cout, Cin, T, T, 1, 0, 1, 1, 0, g->skip_b);
             run_dgrad(c, sc, dy, p->skip_w, wt, dx, dx, B, Cout, Cin, T, 1, 0);
         } else {
             launch_bias_sum(st, dx, dy, dx, (int)nin);          // dx += dy
@@ -300,8 +302,7 @@ int mugd_train_conv(mugd_ctx* ctx, const float* w, const float* bias, const floa
         if (!in.replay) run_conv(c, sc, a, w, bias, nullptr, 0, nullptr, y, B, Cin, Tin, Cout, taps, pad, dil, stride, ups, Tout);
         if (!dy) { in.keep(); return; }
         // ---- backward
-        run_wgrad(c, sc, dy, a, dw, B, Cout, Cin, Tout, Tin, taps, pad, dil, stride, ups);
-        if (db) run_bias_grad(c, sc, dy, db, B, Cout, Tout);
+        run_wgrad(c, sc, dy, a, dw, B, Cout, Cin, Tout, Tin, taps, pad, dil, stride, ups, db);
         float* da = gn_w ? sc.get(nin, false, st) : dx;
         float* wt = sc.get((size_t)Cout * Cin * 3, true, st);
         if (mode == 0) {
@@ -353,8 +354,7 @@ int mugd_train_s4layer(mugd_ctx* ctx, const float* const* P, const float* x, con
         if (!dy) { in.keep(); return; }
         // ---- backward
         float *wt = buf((size_t)2 * H * H * 3), *df = buf(n), *dv = buf(2 * n), *dg = buf(n), *dpre = buf(n), *dn = buf(n), *dk = buf((size_t)H * T);
-        run_wgrad(c, sc, dy, f, G[MUGD_S4_OUT_LAYER_W], B, H, H, T, T, 3, 1);
-        run_bias_grad(c, sc, dy, G[MUGD_S4_OUT_LAYER_B], B, H, T);
+        run_wgrad(c, sc, dy, f, G[MUGD_S4_OUT_LAYER_W], B, H, H, T, T, 3, 1, 1, 1, 0, G[MUGD_S4_OUT_LAYER_B]);
         run_dgrad(c, sc, dy, P[MUGD_S4_OUT_LAYER_W], wt, nullptr, df, B, H, H, T, 3, 1);
         launch_glu_bwd(st, v, df, dv, B, H, T);
         lt.bwd(g, P[MUGD_S4_OUT_LIN_W], dv, dg, false, G[MUGD_S4_OUT_LIN_W], G[MUGD_S4_OUT_LIN_B], H, 2 * H, wt);
