@@ -68,15 +68,21 @@ constexpr int TC_WINMAX = 144;            // 63 * 2 + 2 * 8 + 1 = 143 window col
 constexpr int TC_BUF = 32 * 79 + 4;        // dwords per LDS buffer: the largest of {16 pair-rows x 143, 32 x 64 (NT = 2)} and {32 x 79, 64 x 32 (NT = 1)} columns, + a dead slot
 
 // NT = 32-sample accumulator tiles per wave: 2 (128 x 64 workgroup tile) or 1 (128 x 32: twice the workgroups for the layers whose
-// 128 x 64 tile grid cannot fill the chip -- the U-Net's GEMMs at batch 32 have 2048..16384 columns)
-template <int TAPS, int NT>
+// 128 x 64 tile grid cannot fill the chip -- the U-Net's GEMMs at batch 32 have 2048..16384 columns).
+// FAST (stride 1, no upsample, Tin % 4 == 0 -- every layer of the model but its 6 resampling convs): the window's interior is staged
+// with 16-byte loads (a thread: 4 samples of two adjacent channels -> 4 bf16 pairs -> one ds_write_b128), the halo with scalar ones;
+// the generic form walks the window as a flat index with scalar loads.
+template <int TAPS, int NT, bool FAST>
 __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
     constexpr int TC_TN = 32 * NT;
     constexpr int KSUB = (TAPS == 1 ? 4 : 2) * (NT == 1 ? 2 : 1);      // 16-channel blocks per stage: the narrow tile stages twice the channels (same bytes per stage, half the barriers / latency periods per FLOP)
     constexpr int PR = KSUB * 8;                        // pair-rows per stage
     constexpr int WINMAX = TAPS == 1 ? TC_TN : (TC_TN - 1) * 2 + 17;
-    constexpr int NIT = (PR * WINMAX + 255) / 256;      // staging passes: PR * WIN / 256 (NT = 2: 8 for 1x1, 9 for 3-tap layers)
-    __shared__ unsigned smem[2 * TC_BUF];
+    constexpr int NIT = FAST ? 1 : (PR * WINMAX + 255) / 256;          // generic staging passes: PR * WIN / 256
+    constexpr int QPR = TC_TN / 4;                      // FAST: 4-sample granules per pair-row
+    constexpr int NQ = FAST ? PR * QPR / 256 : 1;       // FAST: interior granules per thread (1 or 2)
+    constexpr int NH = (FAST && TAPS == 3) ? (PR * 16 + 255) / 256 : 1;      // FAST: halo elements per thread (halo <= 16 samples per row)
+    __shared__ __attribute__((aligned(16))) unsigned smem[2 * TC_BUF];
 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, h = lane >> 5, n = lane & 31;
     // ---- tile decode: XCD-aware renumbering (consecutive hardware ids go round-robin to the 8 XCDs: give each XCD a contiguous range
@@ -94,26 +100,64 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
     const int u0 = t0 * a.stride - a.pad;
     const int vlen = a.ups ? 2 * a.Tin : a.Tin;
     const float inv_win = 1.0f / (float)WIN;
-    // ---- staging map: element e = tid + 256 i -> (pair-row p, window column col): channels 2p, 2p + 1 of the stage, sample u0 + col.
+    // LDS window layout: pair-row stride WS dwords, window column c at dword LOFF + c.  FAST shifts the columns so that the interior
+    // (column pad) starts on a 16-byte boundary and rounds the stride to 4 dwords
+    const int LOFF = FAST ? (4 - (a.pad & 3)) & 3 : 0;
+    const int WS = FAST ? (WIN + LOFF + 3) & ~3 : WIN;
+    // ---- generic staging map: element e = tid + 256 i -> (pair-row p, window column col): channels 2p, 2p + 1 of the stage, sample u0 + col.
     // Loads are UNCONDITIONAL from clamped (always valid) addresses and zeroed by a select afterwards: a predicated load makes the
     // compiler branch around every element (exec-mask juggling + 64-bit address math per element, no batching of the loads).
     unsigned goff[NIT];
     int loff[NIT], pch[NIT];           // pch: first channel of the element's pair inside the stage (2 p)
     bool ok[NIT];
+    if (!FAST) {
 #pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-        int e = tid + 256 * i;
-        const bool in = e < PR * WIN;
-        e = in ? e : 0;
-        const int p = (int)(((float)e + 0.5f) * inv_win);
-        const int col = e - p * WIN;
-        const int u = u0 + col;
-        ok[i] = in && u >= 0 && u < vlen;
-        int uc = u < 0 ? 0 : u;
-        uc = uc < vlen ? uc : vlen - 1;
-        goff[i] = (unsigned)(a.ups ? (uc >> 1) : uc);          // sample offset inside a channel row
-        pch[i] = 2 * p;
-        loff[i] = in ? p * WIN + col : TC_BUF - 1;             // dead elements park in the buffer's last dword (no window reaches it)
+        for (int i = 0; i < NIT; ++i) {
+            int e = tid + 256 * i;
+            const bool in = e < PR * WIN;
+            e = in ? e : 0;
+            const int p = (int)(((float)e + 0.5f) * inv_win);
+            const int col = e - p * WIN;
+            const int u = u0 + col;
+            ok[i] = in && u >= 0 && u < vlen;
+            int uc = u < 0 ? 0 : u;
+            uc = uc < vlen ? uc : vlen - 1;
+            goff[i] = (unsigned)(a.ups ? (uc >> 1) : uc);          // sample offset inside a channel row
+            pch[i] = 2 * p;
+            loff[i] = in ? p * WIN + col : TC_BUF - 1;             // dead elements park in the buffer's last dword (no window reaches it)
+        }
+    }
+    // ---- FAST staging map: interior granule g = tid + 256 i -> (pair-row g / QPR, samples t0 + 4 (g % QPR) ..+3); halo element
+    // e = tid + 256 i -> (pair-row e / hw, halo column e % hw: the first `pad` are left of the interior, the rest right of it)
+    const int hw = (TAPS - 1) * a.dil;
+    int qp[NQ], qoff[NQ], qlds[NQ]; bool qok[NQ];
+    int hp[NH], hoff[NH], hlds[NH]; bool hok[NH];
+    if (FAST) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int g = tid + 256 * i, p = g / QPR, q4 = (g - p * QPR) * 4;
+            const int t = t0 + q4;
+            qok[i] = t < a.Tin;                                    // Tin % 4 == 0: a granule is wholly inside or outside
+            qp[i] = 2 * p;
+            qoff[i] = qok[i] ? t : a.Tin - 4;
+            qlds[i] = p * WS + LOFF + a.pad + q4;
+        }
+        if (TAPS == 3) {
+            const float inv_hw = 1.0f / (float)(hw > 0 ? hw : 1);
+#pragma unroll
+            for (int i = 0; i < NH; ++i) {
+                int e = tid + 256 * i;
+                const bool in = e < PR * hw;
+                e = in ? e : 0;
+                const int p = (int)(((float)e + 0.5f) * inv_hw), hc = e - p * hw;
+                const int col = hc < a.pad ? hc : TC_TN + hc;      // window column
+                const int u = u0 + col;
+                hok[i] = in && u >= 0 && u < a.Tin;
+                hp[i] = 2 * p;
+                hoff[i] = u < 0 ? 0 : (u < a.Tin ? u : a.Tin - 1);
+                hlds[i] = in ? p * WS + LOFF + col : TC_BUF - 1;
+            }
+        }
     }
     const float* xb = a.x + (size_t)b * a.C * a.Tin;
     const int mtile = mb * 4 + wave;
@@ -127,41 +171,122 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
 
+    // ---- epilogue operands requested NOW (bias + time-embedding row per accumulator row, residual per element), from clamped
+    // addresses: their latency hides behind the whole K loop instead of sitting exposed at the end of every workgroup.
+    // FAST: the tile leaves through LDS as 16-byte row segments (lane -> (row = (lane + 64 k) / 8, 4 samples)), so the residual is
+    // requested in that shape; the generic form stores (and reads the residual) one dword per accumulator register.
+    float eadd[16];
+    float eres[FAST ? 1 : NT][FAST ? 1 : 16];
+    float4 rres[FAST ? NT : 1][FAST ? 4 : 1];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        int m = mtile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        m = m < a.M ? m : a.M - 1;
+        float add = a.bias ? a.bias[m] : 0.f;
+        if (a.rowadd) add += a.rowadd[(size_t)b * a.rowadd_stride + m];
+        eadd[i] = add;
+        if (!FAST) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                int t = t0 + nt * 32 + n;
+                t = t < a.Tout ? t : a.Tout - 1;
+                eres[nt][i] = a.resid ? a.resid[((size_t)b * a.M + m) * a.Tout + t] : 0.f;
+            }
+        }
+    }
+    if (FAST) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = lane + 64 * k;
+                int m = mtile * 32 + (idx >> 3), t = t0 + nt * 32 + (idx & 7) * 4;
+                m = m < a.M ? m : a.M - 1;
+                t = t < a.Tout ? t : a.Tout - 4;                   // Tout % 4 == 0: a granule is wholly inside or outside
+                rres[nt][k] = a.resid ? *reinterpret_cast<const float4*>(a.resid + ((size_t)b * a.M + m) * a.Tout + t) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+    }
+
     // The packed weights hold a whole number of stages (zero blocks behind the last channel block: launch_tpack_weights), so every
     // stage runs the same straight-line code; activation channels past C are zeroed when they are parked.
     const int nstage = nkb / KSUB;
-    float xlo[NIT], xhi[NIT];
-    u32x4 Aa[KSUB * TAPS], Ab[KSUB * TAPS];          // ping-pong weight fragments: no register copies in the loop
+    struct XRegs {                                   // the raw window samples of one stage, as loaded
+        float4 qlo[NQ], qhi[NQ];
+        float hlo[NH], hhi[NH];
+        float xlo[NIT], xhi[NIT];
+    };
+    XRegs Xa, Xb;                                    // ping-pong: the activation stream runs TWO stages ahead of the matrix pipe
+    u32x4 Aa[KSUB * TAPS], Ab[KSUB * TAPS];          // ping-pong weight fragments (one stage ahead: L2 hits): no register copies in the loop
 
-    // raw, unconditional loads of stage s (window samples + weight fragments); nothing here USES a loaded value, so the loads stay in
-    // flight across the MFMAs of the stage before
-    auto load_stage = [&](int s, u32x4 (&Ad)[KSUB * TAPS]) {
+    // raw, unconditional loads; nothing here USES a loaded value, so the loads stay in flight across the MFMAs of the stages in front
+    auto load_x = [&](int s, XRegs& X) {
         const int c0 = s * KSUB * 16;
         const int cmax = a.C - 2 - c0;                       // last pair of the tensor, relative to the stage (C is a multiple of 16)
+        if (FAST) {
 #pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            const int pc = pch[i] < cmax ? pch[i] : cmax;    // channels past C (the last, partial stage): clamped address, zeroed in park()
-            const float* q = xb + (size_t)(unsigned)((c0 + pc) * a.Tin) + goff[i];
-            xlo[i] = q[0];
-            xhi[i] = q[a.Tin];
+            for (int i = 0; i < NQ; ++i) {
+                const int pc = qp[i] < cmax ? qp[i] : cmax;  // channels past C (the last, partial stage): clamped address, zeroed in park()
+                const float* q = xb + (size_t)(unsigned)((c0 + pc) * a.Tin) + qoff[i];
+                X.qlo[i] = *reinterpret_cast<const float4*>(q);
+                X.qhi[i] = *reinterpret_cast<const float4*>(q + a.Tin);
+            }
+            if (TAPS == 3) {
+#pragma unroll
+                for (int i = 0; i < NH; ++i) {
+                    const int pc = hp[i] < cmax ? hp[i] : cmax;
+                    const float* q = xb + (size_t)(unsigned)((c0 + pc) * a.Tin) + hoff[i];
+                    X.hlo[i] = q[0];
+                    X.hhi[i] = q[a.Tin];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int pc = pch[i] < cmax ? pch[i] : cmax;
+                const float* q = xb + (size_t)(unsigned)((c0 + pc) * a.Tin) + goff[i];
+                X.xlo[i] = q[0];
+                X.xhi[i] = q[a.Tin];
+            }
         }
+    };
+    auto load_a = [&](int s, u32x4 (&Ad)[KSUB * TAPS]) {
 #pragma unroll
         for (int kk = 0; kk < KSUB; ++kk)
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap)
                 Ad[kk * TAPS + tap] = *reinterpret_cast<const u32x4*>(wp + ((size_t)(s * KSUB + kk) * TAPS + tap) * 512);
     };
-    auto park = [&](int s, int buf) {                        // zero padding / channel tail, round to bf16 pairs, store
+    auto park = [&](int s, int buf, const XRegs& X) {        // zero padding / channel tail, round to bf16 pairs, store
         unsigned* w = smem + buf * TC_BUF;
         const int cmax = a.C - 2 - s * KSUB * 16;
+        if (FAST) {
 #pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            const bool okc = ok[i] && pch[i] <= cmax;
-            w[loff[i]] = pack_bf16(okc ? xlo[i] : 0.f, okc ? xhi[i] : 0.f);
+            for (int i = 0; i < NQ; ++i) {
+                const bool okc = qok[i] && qp[i] <= cmax;
+                u32x4 v;
+                v[0] = pack_bf16(okc ? X.qlo[i].x : 0.f, okc ? X.qhi[i].x : 0.f);
+                v[1] = pack_bf16(okc ? X.qlo[i].y : 0.f, okc ? X.qhi[i].y : 0.f);
+                v[2] = pack_bf16(okc ? X.qlo[i].z : 0.f, okc ? X.qhi[i].z : 0.f);
+                v[3] = pack_bf16(okc ? X.qlo[i].w : 0.f, okc ? X.qhi[i].w : 0.f);
+                *reinterpret_cast<u32x4*>(w + qlds[i]) = v;
+            }
+            if (TAPS == 3) {
+#pragma unroll
+                for (int i = 0; i < NH; ++i) {
+                    const bool okc = hok[i] && hp[i] <= cmax;
+                    w[hlds[i]] = pack_bf16(okc ? X.hlo[i] : 0.f, okc ? X.hhi[i] : 0.f);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const bool okc = ok[i] && pch[i] <= cmax;
+                w[loff[i]] = pack_bf16(okc ? X.xlo[i] : 0.f, okc ? X.xhi[i] : 0.f);
+            }
         }
     };
     auto compute = [&](int buf, const u32x4 (&A)[KSUB * TAPS]) {
-        const unsigned* w = smem + buf * TC_BUF;
+        const unsigned* w = smem + buf * TC_BUF + LOFF;
 #pragma unroll
         for (int kk = 0; kk < KSUB; ++kk)
 #pragma unroll
@@ -169,46 +294,68 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
                 const bf16x8 af = __builtin_bit_cast(bf16x8, A[kk * TAPS + tap]);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const unsigned* r = w + (kk * 8 + 4 * h) * WIN + (nt * 32 + n) * a.stride + tap * a.dil;
+                    const unsigned* r = w + (kk * 8 + 4 * h) * WS + (nt * 32 + n) * (FAST ? 1 : a.stride) + tap * a.dil;
                     u32x4 bv;
-                    bv[0] = r[0]; bv[1] = r[WIN]; bv[2] = r[2 * WIN]; bv[3] = r[3 * WIN];
+                    bv[0] = r[0]; bv[1] = r[WS]; bv[2] = r[2 * WS]; bv[3] = r[3 * WS];
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bv), acc[nt], 0, 0, 0);
                 }
             }
     };
-    // one stage: next stage's loads out, this stage on the matrix pipe, then the loaded window goes to the other LDS buffer
-    auto step = [&](int s, const u32x4 (&A)[KSUB * TAPS], u32x4 (&An)[KSUB * TAPS]) {
-        const bool more = s + 1 < nstage;
-        if (more) load_stage(s + 1, An);
+    // One stage.  Program order = request order (loads complete in order): the NEXT stage's weight fragments first, then the window two
+    // stages ahead -- waiting for the fragments at the top of the next stage then leaves that window in flight; this stage on the matrix
+    // pipe; then the window of the next stage (requested a whole stage ago) goes to the other LDS buffer.
+    auto step = [&](int s, const u32x4 (&A)[KSUB * TAPS], u32x4 (&An)[KSUB * TAPS], XRegs& Xfar, const XRegs& Xnext) {
+        if (s + 1 < nstage) load_a(s + 1, An);
+        if (s + 2 < nstage) load_x(s + 2, Xfar);
         if (active) compute(s & 1, A);
-        if (more) park(s + 1, (s + 1) & 1);
+        if (s + 1 < nstage) park(s + 1, (s + 1) & 1, Xnext);
         __syncthreads();
     };
 
-    load_stage(0, Aa);
-    park(0, 0);
+    load_x(0, Xa);
+    load_a(0, Aa);
+    if (nstage > 1) load_x(1, Xb);
+    park(0, 0, Xa);
     __syncthreads();
     for (int s = 0; s < nstage; s += 2) {
-        step(s, Aa, Ab);
-        if (s + 1 < nstage) step(s + 1, Ab, Aa);
+        step(s, Aa, Ab, Xa, Xb);                     // window s + 2 -> Xa (its old content, stage s, is in LDS), park stage s + 1 from Xb
+        if (s + 1 < nstage) step(s + 1, Ab, Aa, Xb, Xa);
+    }
+    // ---- epilogue: accumulator register i of lane (h, n) is row (i & 3) + 8 (i >> 2) + 4 h, column n
+    if (FAST) {
+        // through LDS (the staging windows are free after the last barrier): each wave turns its 32 x 32 tile into 16-byte row
+        // segments -- 8 wide stores per lane and tile instead of 32 narrow ones (the store ISSUE was the tail of every workgroup)
+        constexpr int OS = 36;                                     // floats per tile row in LDS: 16-byte aligned rows, conflict-free
+        float* ob = reinterpret_cast<float*>(smem) + wave * (32 * OS);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ob[((i & 3) + 8 * (i >> 2) + 4 * h) * OS + n] = acc[nt][i] + eadd[i];
+            wave_sync();
+            if (active) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int idx = lane + 64 * k, row = idx >> 3, c4 = (idx & 7) * 4;
+                    const int m = mtile * 32 + row, t = t0 + nt * 32 + c4;
+                    float4 v = *reinterpret_cast<const float4*>(ob + row * OS + c4);
+                    const float4 r = rres[nt][k];
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                    if (m < a.M && t < a.Tout) *reinterpret_cast<float4*>(a.y + ((size_t)b * a.M + m) * a.Tout + t) = v;
+                }
+            }
+            wave_sync();
+        }
+        return;
     }
     if (!active) return;
-    // ---- epilogue: accumulator register i of lane (h, n) is row (i & 3) + 8 (i >> 2) + 4 h, column n
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int m = mtile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
         if (m < a.M) {
-            float add = a.bias ? a.bias[m] : 0.f;
-            if (a.rowadd) add += a.rowadd[(size_t)b * a.rowadd_stride + m];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int t = t0 + nt * 32 + n;
-                if (t < a.Tout) {
-                    const size_t o = ((size_t)b * a.M + m) * a.Tout + t;
-                    float v = acc[nt][i] + add;
-                    if (a.resid) v += a.resid[o];
-                    a.y[o] = v;
-                }
+                if (t < a.Tout) a.y[((size_t)b * a.M + m) * a.Tout + t] = (acc[nt][i] + eadd[i]) + eres[nt][i];
             }
         }
     }
@@ -220,7 +367,9 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
 constexpr int TW_XS = 81;                 // LDS row stride of the input window (floats, odd): 63 + 2 * 8 + 1 = 80 columns (64-sample slabs, stride 1) or 31 * 2 + 17 = 79 (32-sample slabs, stride 2)
 
 // TW_KT = samples per slab: 64 for stride-1 layers (half the barriers / latency periods per FLOP), 32 for the stride-2 Downsample convs
-template <int TAPS, int TW_KT>
+// DB: also sum the bias gradient (16 more live registers: compiled in only where they fit -- the 3-tap form; the 1x1 form with 64-sample
+// slabs would drop to one wave per SIMD, measured 1.5x slower, and leaves the bias gradient to the row-sum kernels)
+template <int TAPS, int TW_KT, bool DB>
 __global__ __launch_bounds__(256) void twgrad_bf16_kernel(const TWgradArgs a) {
     constexpr int TW_YS = TW_KT + 1;                    // LDS row stride of the dY slab (floats, odd)
     constexpr int TW_BUF = 64 * TW_YS + 64 * TW_XS;     // floats per LDS buffer
@@ -236,10 +385,10 @@ __global__ __launch_bounds__(256) void twgrad_bf16_kernel(const TWgradArgs a) {
     constexpr int NX = 20;                // ceil(64 * 80 / 256)
     float vy[NY], vx[NX];
     // bias gradient db[m] = sum_{b,t} dY[b][m][t], fused: the c-tile-0 workgroups add up the dY values they stage anyway (fp32, fixed order)
-    const bool want_db = a.db != nullptr && blockIdx.y == 0;
-    float rs[NY];
+    const bool want_db = DB && a.db != nullptr && blockIdx.y == 0;
+    float rs[DB ? NY : 1];
 #pragma unroll
-    for (int i = 0; i < NY; ++i) rs[i] = 0.f;
+    for (int i = 0; i < (DB ? NY : 1); ++i) rs[i] = 0.f;
     f32x16 acc[TAPS];
 #pragma unroll
     for (int k = 0; k < TAPS; ++k)
@@ -279,7 +428,7 @@ __global__ __launch_bounds__(256) void twgrad_bf16_kernel(const TWgradArgs a) {
             const int e = tid + 256 * i, row = e / TW_KT, col = e % TW_KT;
             const float yv = (m0 + row < a.M && t0 + col < a.Tout) ? vy[i] : 0.f;
             sy[row * TW_YS + col] = yv;
-            rs[i] += yv;
+            if (DB) rs[i] += yv;
         }
         const int u0 = t0 * a.stride - a.pad;
 #pragma unroll
@@ -328,9 +477,9 @@ __global__ __launch_bounds__(256) void twgrad_bf16_kernel(const TWgradArgs a) {
         if (more) park(s + s_step, (it + 1) & 1);
         __syncthreads();
     }
-    if (want_db) {           // element i of this thread sits in row (tid + 256 i) / TW_KT: one row per wave (64-sample slabs) or per half wave (32)
+    if (DB && want_db) {     // element i of this thread sits in row (tid + 256 i) / TW_KT: one row per wave (64-sample slabs) or per half wave (32)
 #pragma unroll
-        for (int i = 0; i < NY; ++i) {
+        for (int i = 0; i < (DB ? NY : 1); ++i) {
             float v = rs[i];
 #pragma unroll
             for (int o = 1; o < (TW_KT < 64 ? TW_KT : 64); o <<= 1) v += __shfl_xor(v, o);
@@ -349,11 +498,18 @@ __global__ __launch_bounds__(256) void twgrad_bf16_kernel(const TWgradArgs a) {
         }
 }
 
-__global__ void twgrad_reduce_kernel(const float* part, float* dW, long long n, int KS) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+// dW[i] = sum_k part[k][i] (fixed order); the same launch sums the bias-gradient slices (partb: KS x nb) when there are any
+__global__ void twgrad_reduce_kernel(const float* part, float* dW, long long n, int KS, const float* partb, float* db, int nb) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n + nb; i += (long long)gridDim.x * blockDim.x) {
         float v = 0.f;
-        for (int k = 0; k < KS; ++k) v += part[(size_t)k * n + i];
-        dW[i] = v;
+        if (i < n) {
+            for (int k = 0; k < KS; ++k) v += part[(size_t)k * n + i];
+            dW[i] = v;
+        } else {
+            const long long j = i - n;
+            for (int k = 0; k < KS; ++k) v += partb[(size_t)k * nb + j];
+            db[j] = v;
+        }
     }
 }
 
@@ -383,8 +539,16 @@ void launch_tconv_bf16(hipStream_t st, const TConvArgs& a0) {
     if (const char* e = getenv("MUGD_TCONV_NT")) { const int v = atoi(e); if (v == 1 || v == 2) nt = v; }      // development / test knob
     a.gx = cdiv(a.Tout, 32 * nt);
     const dim3 grid((unsigned)a.gx * a.gy * a.B);
-    if (a.taps == 1) { if (nt == 1) hipLaunchKernelGGL((tconv_bf16_kernel<1, 1>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((tconv_bf16_kernel<1, 2>), grid, dim3(256), 0, st, a); }
-    else { if (nt == 1) hipLaunchKernelGGL((tconv_bf16_kernel<3, 1>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((tconv_bf16_kernel<3, 2>), grid, dim3(256), 0, st, a); }
+    bool fast = a.stride == 1 && !a.ups && (a.Tin & 3) == 0 && a.pad <= (a.taps - 1) * a.dil;
+    if (const char* e = getenv("MUGD_TCONV_GENERIC")) { if (e[0] == '1') fast = false; }                  // development / test knob: the generic staging
+#define MUGD_TC(T, N)                                                                                     \
+    do {                                                                                                  \
+        if (fast) hipLaunchKernelGGL((tconv_bf16_kernel<T, N, true>), grid, dim3(256), 0, st, a);         \
+        else hipLaunchKernelGGL((tconv_bf16_kernel<T, N, false>), grid, dim3(256), 0, st, a);             \
+    } while (0)
+    if (a.taps == 1) { if (nt == 1) MUGD_TC(1, 1); else MUGD_TC(1, 2); }
+    else { if (nt == 1) MUGD_TC(3, 1); else MUGD_TC(3, 2); }
+#undef MUGD_TC
 }
 
 // K-slices of a bf16 weight-gradient launch: enough workgroups to fill the chip, every slice with >= 4 slabs, partial tiles
@@ -399,6 +563,8 @@ int twgrad_splits(int B, int M, int C, int Tout, int taps, int kt) {
     ks = std::min(ks, std::max<long long>(cap, 1));
     return (int)std::min<long long>(ks, 512);
 }
+
+bool twgrad_fuses_bias(int taps) { return taps == 3; }
 
 void launch_twgrad_bf16(hipStream_t st, const TWgradArgs& a0, float* partial) {
     TWgradArgs a = a0;
@@ -417,12 +583,16 @@ void launch_twgrad_bf16(hipStream_t st, const TWgradArgs& a0, float* partial) {
     // measured faster with 32-sample slabs (474 vs 369 us on the 128 x 128 x 3 wave-encoder layers: registers / LDS per workgroup)
     if (a.taps == 1) {
         MUGD_CHECK(a.stride == 1, -2, "twgrad: strided 1x1 convs are not used by the model");
-        hipLaunchKernelGGL((twgrad_bf16_kernel<1, 64>), grid, dim3(256), 0, st, a);
+        MUGD_CHECK(!a.db, -2, "twgrad: the 1x1 form does not produce the bias gradient (twgrad_fuses_bias)");
+        hipLaunchKernelGGL((twgrad_bf16_kernel<1, 64, false>), grid, dim3(256), 0, st, a);
+    } else if (a.db) {
+        hipLaunchKernelGGL((twgrad_bf16_kernel<3, 32, true>), grid, dim3(256), 0, st, a);
     } else {
-        hipLaunchKernelGGL((twgrad_bf16_kernel<3, 32>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((twgrad_bf16_kernel<3, 32, false>), grid, dim3(256), 0, st, a);
     }
     if (a.KS > 1) {
-        hipLaunchKernelGGL(twgrad_reduce_kernel, dim3((unsigned)std::min<long long>((nn + 255) / 256, 4096)), dim3(256), 0, st, partial, final_dw, nn, a.KS);
-        if (final_db) hipLaunchKernelGGL(twgrad_reduce_kernel, dim3((unsigned)cdiv(a.M, 256)), dim3(256), 0, st, a.db, final_db, (long long)a.M, a.KS);
+        const int nb = final_db ? a.M : 0;
+        hipLaunchKernelGGL(twgrad_reduce_kernel, dim3((unsigned)std::min<long long>((nn + nb + 255) / 256, 4096)), dim3(256), 0, st, partial, final_dw, nn, a.KS,
+                           a.db, final_db, nb);
     }
 }

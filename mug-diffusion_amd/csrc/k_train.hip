@@ -288,72 +288,128 @@ __device__ __forceinline__ double wg_sum(double v, double* red) {        // 256-
 }
 
 // Backward of a = silu(GroupNorm(x; gamma, beta)):  given da, returns dx (+= if accumulate) and dgamma / dbeta.
-// One workgroup per (group, batch row): pass 1 statistics of x, pass 2 the two group means of the normalised-gradient terms,
-// pass 3 dx.  The row's dgamma / dbeta contributions go to part (B, C, 2) in fp64; batch_reduce_kernel sums them over the batch
-// in fixed order: deterministic.
-template <bool SILU>
+// One workgroup per (group, batch row); the 4 waves take the group's channels round-robin, a wave's lanes walk one channel row
+// (16-byte loads when T % 4 == 0).  Pass A: statistics of x (one workgroup reduction); pass B: per channel du = da silu'(u), the
+// channel's dgamma / dbeta contributions (a wave-level fp64 sum each, written by lane 0 -- no workgroup barrier inside the channel
+// loop; the first version reduced every channel over the whole workgroup, 4 barriers per channel and up to 48 channels per group)
+// and the two group sums of the normalised-gradient terms (one workgroup reduction at the end); pass C: dx.
+// The row's dgamma / dbeta contributions go to part (B, C, 2) in fp64; gn_param_reduce_kernel sums them over the batch in fixed
+// order: deterministic.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __hiloint2double(__shfl_xor(__double2hiint(v), o), __shfl_xor(__double2loint(v), o));
+    return v;
+}
+
+template <bool SILU, bool VEC4>
 __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float* x, const float* da, const float* gamma, const float* beta, float eps,
                                                           float* dx, double* part, int B, int C, int T, int groups, int accumulate) {
-    __shared__ double red[4];
-    __shared__ double cg_g[64], cg_b[64];          // per channel of the group (cg <= 64)
-    const int g = blockIdx.x, cg = C / groups, tid = threadIdx.x;
-    const long long n = (long long)cg * T;
-    if (tid < cg) { cg_g[tid] = 0.0; cg_b[tid] = 0.0; }
-    const int b = blockIdx.y;
-    {
-        const float* xg = x + ((size_t)b * C + (size_t)g * cg) * T;
-        const float* ag = da + ((size_t)b * C + (size_t)g * cg) * T;
-        float* dg = dx + ((size_t)b * C + (size_t)g * cg) * T;
-        double s1 = 0.0, s2 = 0.0;
-        for (long long i = tid; i < n; i += 256) { const double v = xg[i]; s1 += v; s2 += v * v; }
-        s1 = wg_sum(s1, red);
-        s2 = wg_sum(s2, red);
-        const double mean = s1 / (double)n;
-        double var = s2 / (double)n - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float mu = (float)mean;
-        // pass 2: du = da silu'(u); sums of dxhat = du gamma and dxhat xhat over the group; per-channel dgamma / dbeta
-        double m1 = 0.0, m2 = 0.0;
-        for (int c = 0; c < cg; ++c) {
-            const float gm = gamma[g * cg + c], bt = beta[g * cg + c];
-            double dgm = 0.0, dbt = 0.0;
-            for (int t = tid; t < T; t += 256) {
-                const float xh = (xg[(size_t)c * T + t] - mu) * rstd;
-                const float u = xh * gm + bt;
-                const float sg = 1.0f / (1.0f + expf(-u));
-                const float du = ag[(size_t)c * T + t] * (SILU ? sg * (1.0f + u * (1.0f - sg)) : 1.0f);
-                dgm += (double)du * (double)xh;
-                dbt += (double)du;
-                const float dxh = du * gm;
-                m1 += (double)dxh;
-                m2 += (double)dxh * (double)xh;
+    __shared__ double red[4][4];
+    const int g = blockIdx.x, b = blockIdx.y, cg = C / groups, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const double n = (double)cg * (double)T;
+    const float* xg = x + ((size_t)b * C + (size_t)g * cg) * T;
+    const float* ag = da + ((size_t)b * C + (size_t)g * cg) * T;
+    float* dg = dx + ((size_t)b * C + (size_t)g * cg) * T;
+    const int T4 = T >> 2;
+    // ---- pass A: group statistics
+    double s1 = 0.0, s2 = 0.0;
+    for (int c = wave; c < cg; c += 4) {
+        const float* p = xg + (size_t)c * T;
+        if (VEC4) {
+            const float4* p4 = reinterpret_cast<const float4*>(p);
+            for (int t = lane; t < T4; t += 64) {
+                const float4 v = p4[t];
+                s1 += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+                s2 += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
             }
-            dgm = wg_sum(dgm, red);
-            dbt = wg_sum(dbt, red);
-            if (tid == 0) { cg_g[c] += dgm; cg_b[c] += dbt; }
-        }
-        m1 = wg_sum(m1, red) / (double)n;
-        m2 = wg_sum(m2, red) / (double)n;
-        const float fm1 = (float)m1, fm2 = (float)m2;
-        // pass 3: dx = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat))
-        for (int c = 0; c < cg; ++c) {
-            const float gm = gamma[g * cg + c], bt = beta[g * cg + c];
-            for (int t = tid; t < T; t += 256) {
-                const size_t o = (size_t)c * T + t;
-                const float xh = (xg[o] - mu) * rstd;
-                const float u = xh * gm + bt;
-                const float sg = 1.0f / (1.0f + expf(-u));
-                const float dxh = ag[o] * (SILU ? sg * (1.0f + u * (1.0f - sg)) : 1.0f) * gm;
-                const float v = rstd * (dxh - fm1 - xh * fm2);
-                dg[o] = accumulate ? dg[o] + v : v;
-            }
+        } else {
+            for (int t = lane; t < T; t += 64) { const double v = p[t]; s1 += v; s2 += v * v; }
         }
     }
+    s1 = wave_sum_f64(s1);
+    s2 = wave_sum_f64(s2);
+    if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
     __syncthreads();
-    if (tid < cg) {
-        part[2 * ((size_t)b * C + g * cg + tid)] = cg_g[tid];
-        part[2 * ((size_t)b * C + g * cg + tid) + 1] = cg_b[tid];
+    const double mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / n;
+    double var = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / n - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float mu = (float)mean;
+    // the normalised gradient of one element: dxh = da silu'(u) gamma, with xh and u recomputed
+    auto elem = [&](float xv, float av, float gm, float bt, float& xh, float& du) {
+        xh = (xv - mu) * rstd;
+        const float u = xh * gm + bt;
+        const float sg = 1.0f / (1.0f + expf(-u));
+        du = av * (SILU ? sg * (1.0f + u * (1.0f - sg)) : 1.0f);
+    };
+    // ---- pass B: per-channel dgamma / dbeta (wave sums) and the two group sums
+    double m1 = 0.0, m2 = 0.0;
+    for (int c = wave; c < cg; c += 4) {
+        const float gm = gamma[g * cg + c], bt = beta[g * cg + c];
+        const float* p = xg + (size_t)c * T;
+        const float* q = ag + (size_t)c * T;
+        double dgm = 0.0, dbt = 0.0;
+        if (VEC4) {
+            const float4* p4 = reinterpret_cast<const float4*>(p);
+            const float4* q4 = reinterpret_cast<const float4*>(q);
+            for (int t = lane; t < T4; t += 64) {
+                const float4 xv = p4[t], av = q4[t];
+                float xh, du;
+                elem(xv.x, av.x, gm, bt, xh, du); dgm += (double)du * xh; dbt += du;
+                elem(xv.y, av.y, gm, bt, xh, du); dgm += (double)du * xh; dbt += du;
+                elem(xv.z, av.z, gm, bt, xh, du); dgm += (double)du * xh; dbt += du;
+                elem(xv.w, av.w, gm, bt, xh, du); dgm += (double)du * xh; dbt += du;
+            }
+        } else {
+            for (int t = lane; t < T; t += 64) {
+                float xh, du;
+                elem(p[t], q[t], gm, bt, xh, du); dgm += (double)du * xh; dbt += du;
+            }
+        }
+        dgm = wave_sum_f64(dgm);
+        dbt = wave_sum_f64(dbt);
+        // sum_t dxh = gamma dbeta_c, sum_t dxh xh = gamma dgamma_c: the group sums follow from the channel sums
+        m1 += (double)gm * dbt;
+        m2 += (double)gm * dgm;
+        if (lane == 0) {
+            part[2 * ((size_t)b * C + g * cg + c)] = dgm;
+            part[2 * ((size_t)b * C + g * cg + c) + 1] = dbt;
+        }
+    }
+    if (lane == 0) { red[2][wave] = m1; red[3][wave] = m2; }      // identical in every lane of the wave
+    __syncthreads();
+    const float fm1 = (float)(((red[2][0] + red[2][1]) + (red[2][2] + red[2][3])) / n);
+    const float fm2 = (float)(((red[3][0] + red[3][1]) + (red[3][2] + red[3][3])) / n);
+    // ---- pass C: dx = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat))
+    for (int c = wave; c < cg; c += 4) {
+        const float gm = gamma[g * cg + c], bt = beta[g * cg + c];
+        const float* p = xg + (size_t)c * T;
+        const float* q = ag + (size_t)c * T;
+        float* o = dg + (size_t)c * T;
+        if (VEC4) {
+            const float4* p4 = reinterpret_cast<const float4*>(p);
+            const float4* q4 = reinterpret_cast<const float4*>(q);
+            float4* o4 = reinterpret_cast<float4*>(o);
+            for (int t = lane; t < T4; t += 64) {
+                const float4 xv = p4[t], av = q4[t];
+                float4 r;
+                float xh, du;
+                elem(xv.x, av.x, gm, bt, xh, du); r.x = rstd * (du * gm - fm1 - xh * fm2);
+                elem(xv.y, av.y, gm, bt, xh, du); r.y = rstd * (du * gm - fm1 - xh * fm2);
+                elem(xv.z, av.z, gm, bt, xh, du); r.z = rstd * (du * gm - fm1 - xh * fm2);
+                elem(xv.w, av.w, gm, bt, xh, du); r.w = rstd * (du * gm - fm1 - xh * fm2);
+                if (accumulate) { const float4 old = o4[t]; r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w; }
+                o4[t] = r;
+            }
+        } else {
+            for (int t = lane; t < T; t += 64) {
+                float xh, du;
+                elem(p[t], q[t], gm, bt, xh, du);
+                const float v = rstd * (du * gm - fm1 - xh * fm2);
+                o[t] = accumulate ? o[t] + v : v;
+            }
+        }
     }
 }
 // dgamma[c] = sum_b part[b][c][0] ; dbeta[c] = sum_b part[b][c][1]
@@ -516,9 +572,11 @@ void launch_pair_sum(hipStream_t st, const float* src, float* dst, long long n) 
 }
 void launch_gn_bwd(hipStream_t st, const float* x, const float* da, const float* gamma, const float* beta, float eps, float* dx,
                    float* dgamma, float* dbeta, int B, int C, int T, int groups, int accumulate, int silu, double* partial) {
-    MUGD_CHECK(C % groups == 0 && C / groups <= 64, -2, "gn_bwd: at most 64 channels per group");
-    if (silu) hipLaunchKernelGGL(gn_silu_bwd_kernel<true>, dim3(groups, B), dim3(256), 0, st, x, da, gamma, beta, eps, dx, partial, B, C, T, groups, accumulate);
-    else hipLaunchKernelGGL(gn_silu_bwd_kernel<false>, dim3(groups, B), dim3(256), 0, st, x, da, gamma, beta, eps, dx, partial, B, C, T, groups, accumulate);
+    MUGD_CHECK(C % groups == 0, -2, "gn_bwd: channels not divisible by groups");
+#define MUGD_GNB(S, V) hipLaunchKernelGGL((gn_silu_bwd_kernel<S, V>), dim3(groups, B), dim3(256), 0, st, x, da, gamma, beta, eps, dx, partial, B, C, T, groups, accumulate)
+    if (T % 4 == 0) { if (silu) MUGD_GNB(true, true); else MUGD_GNB(false, true); }
+    else { if (silu) MUGD_GNB(true, false); else MUGD_GNB(false, false); }
+#undef MUGD_GNB
     hipLaunchKernelGGL(gn_param_reduce_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, partial, dgamma, dbeta, B, C);
 }
 void launch_emb_linear_bwd(hipStream_t st, const float* e, const float* We, const float* dE, float* dWe, float* dbe, float* de, int B, int K, int M) {

@@ -382,6 +382,7 @@ size_t tpack_elems(int rows, int K, int taps);               // bf16 elements of
 // A[row][k][tap] = src[row * s_row + k * s_k + (flip ? taps - 1 - tap : tap)]  ->  bf16 MFMA A-fragment order (zero padded to 32 rows / 16 k)
 void launch_tpack_weights(hipStream_t st, const float* src, unsigned short* dst, int rows, int K, int taps, long long s_row, long long s_k, int flip);
 void launch_tconv_bf16(hipStream_t st, const TConvArgs& a);
+bool twgrad_fuses_bias(int taps);            // whether launch_twgrad_bf16 can also produce TWgradArgs::db for this tap count
 int twgrad_splits(int B, int M, int C, int Tout, int taps, int kt /* samples per slab: 64 for 1x1 layers, 32 for 3-tap ones */);
 void launch_twgrad_bf16(hipStream_t st, const TWgradArgs& a, float* partial /* KS * (M * C * taps + M) floats when KS > 1 */);
 

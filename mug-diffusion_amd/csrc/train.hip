@@ -163,17 +163,22 @@ void run_bias_grad(Ctx& c, Scratch& sc, const float* x, float* out, int B, int M
 // inside the weight-gradient kernel (fp32, fixed order); fp32 mode keeps the fp64 row-sum kernels
 void run_wgrad(Ctx& c, Scratch& sc, const float* dY, const float* A, float* dW, int B, int M, int C, int Tout, int Tin, int taps, int pad, int dil = 1,
                int stride = 1, int ups = 0, float* db = nullptr) {
+    bool fused_done = false;
     {
         ProfScope prof(g_tprof, c.stream, 1, 2.0 * M * C * taps * (double)B * Tout);
         if (c.train_bf16) {
-            TWgradArgs a{dY, A, dW, B, M, C, Tout, Tin, taps, pad, dil, stride, ups, twgrad_splits(B, M, C, Tout, taps, taps == 1 ? 64 : 32), db};
+            const bool fuse = db && twgrad_fuses_bias(taps);
+            TWgradArgs a{dY, A, dW, B, M, C, Tout, Tin, taps, pad, dil, stride, ups, twgrad_splits(B, M, C, Tout, taps, taps == 1 ? 64 : 32), fuse ? db : nullptr};
             float* part = a.KS > 1 ? sc.get((size_t)a.KS * ((size_t)M * C * taps + M), false, c.stream) : nullptr;
             launch_twgrad_bf16(c.stream, a, part);
-            return;
+            if (fuse) return;
+            fused_done = true;
         }
-        const int ks = wgrad_splits(B, M, C, Tout);
-        float* part = ks > 1 ? sc.get((size_t)ks * M * C * taps, false, c.stream) : nullptr;
-        launch_wgrad_ex(c.stream, dY, A, dW, B, M, C, Tout, Tin, taps, pad, dil, stride, ups, part, ks);
+        if (!fused_done) {
+            const int ks = wgrad_splits(B, M, C, Tout);
+            float* part = ks > 1 ? sc.get((size_t)ks * M * C * taps, false, c.stream) : nullptr;
+            launch_wgrad_ex(c.stream, dY, A, dW, B, M, C, Tout, Tin, taps, pad, dil, stride, ups, part, ks);
+        }
     }
     if (db) run_bias_grad(c, sc, dY, db, B, M, Tout);
 }
