@@ -45,9 +45,11 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {          // 
 // weights -> bf16 A fragments.  dst[(((mt * nkb + kb) * taps + tap) * 64 + lane) * 8 + j] = A[32 mt + (lane & 31)][16 kb + 8 (lane >> 5) + j][tap]
 // with A[row][k][tap] = src[row * s_row + k * s_k + (flip ? taps - 1 - tap : tap)]; rows >= rows_valid and k >= K are zero.
 // ---------------------------------------------------------------------------------------
-__global__ void tpack_weights_kernel(const float* src, unsigned short* dst, int rows_valid, int K, int taps, long long s_row, long long s_k, int flip,
-                                     int MT, int nkb) {
+__global__ void tpack_weights_kernel(const float* src0, unsigned short* dst0, int rows_valid, int K, int taps, long long s_row, long long s_k, int flip,
+                                     int MT, int nkb, long long src_bstride, float scale) {
     const long long total = (long long)MT * nkb * taps * 512;
+    const float* src = src0 + (size_t)blockIdx.y * src_bstride;           // blockIdx.y: weight set of a batched pack
+    unsigned short* dst = dst0 + (size_t)blockIdx.y * total;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
         long long q = i >> 9;
@@ -56,7 +58,7 @@ __global__ void tpack_weights_kernel(const float* src, unsigned short* dst, int 
         const int mt = (int)(q / nkb);
         const int row = mt * 32 + (lane & 31), k = kb * 16 + 8 * (lane >> 5) + j;
         float v = 0.f;
-        if (row < rows_valid && k < K) v = src[(long long)row * s_row + (long long)k * s_k + (flip ? taps - 1 - tap : tap)];
+        if (row < rows_valid && k < K) v = scale * src[(long long)row * s_row + (long long)k * s_k + (flip ? taps - 1 - tap : tap)];
         dst[i] = (unsigned short)(pack_bf16(v, 0.f) & 0xffffu);
     }
 }
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
     const int mtile = mb * 4 + wave;
     const bool active = mtile * 32 < a.M;
     const int nkb = a.nkb;
-    const unsigned short* wp = a.wpk + ((size_t)(active ? mtile : 0) * nkb * TAPS * 64 + lane) * 8;
+    const unsigned short* wp = a.wpk + (size_t)b * a.w_bstride + ((size_t)(active ? mtile : 0) * nkb * TAPS * 64 + lane) * 8;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -523,7 +525,15 @@ void launch_tpack_weights(hipStream_t st, const float* src, unsigned short* dst,
     const int MT = cdiv(rows, 32), nkb = tpack_nkb(K, taps);
     const long long total = (long long)MT * nkb * taps * 512;
     hipLaunchKernelGGL(tpack_weights_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 8192)), dim3(256), 0, st, src, dst, rows, K, taps, s_row, s_k,
-                       flip, MT, nkb);
+                       flip, MT, nkb, 0ll, 1.0f);
+}
+
+void launch_tpack_weights_batched(hipStream_t st, const float* src, unsigned short* dst, int batch, long long src_bstride, int rows, int K, int taps,
+                                  long long s_row, long long s_k, int flip, float scale) {
+    const int MT = cdiv(rows, 32), nkb = tpack_nkb(K, taps);
+    const long long total = (long long)MT * nkb * taps * 512;
+    hipLaunchKernelGGL(tpack_weights_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 64), (unsigned)batch), dim3(256), 0, st, src, dst, rows, K, taps,
+                       s_row, s_k, flip, MT, nkb, src_bstride, scale);
 }
 
 void launch_tconv_bf16(hipStream_t st, const TConvArgs& a0) {

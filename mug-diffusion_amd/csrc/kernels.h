@@ -338,6 +338,7 @@ struct AttnBwdArgs {         // layouts as AttnArgs; dout = gradient of the atte
     float* dq; float* dk; float* dv;          // same strides as q / k / v
     float* drel; float* dcemb;                // (2 pmax + 1, heads)
     double* tab_part;                         // scratch, (B, 2 pmax + 1, heads, 2)
+    int skip_cols;                            // 1: dk / dv are produced by the caller (bf16 mode: two batched tconv GEMMs over dsim / Amat)
 };
 void launch_attention_bwd(hipStream_t st, const AttnBwdArgs& a);
 // k_train_s4.hip: S4 layer backward pieces
@@ -366,6 +367,8 @@ void launch_adamw(hipStream_t st, float* p, const float* g, float* m, float* v, 
 struct TConvArgs {           // y[b][m][t] = bias[m] + rowadd[b][m] + resid[b][m][t] + sum_{c,tap} W[m][c][tap] x[b][c][stride t + tap dil - pad]
     const float* x;                  // (B, C, Tin)
     const unsigned short* wpk;       // bf16 A fragments from launch_tpack_weights (rows = M, K = C)
+    long long w_bstride;             // bf16 elements between the weight sets of consecutive batch rows (0: one set for all -- every conv / Linear;
+                                     // > 0: a batched matmul, e.g. the attention backward's dK = dS^T Q per (batch row, head))
     const float* bias;               // [M] or null
     const float* rowadd; int rowadd_stride;      // [B][rowadd_stride] or null
     const float* resid;              // (B, M, Tout) or null (may alias y)
@@ -381,6 +384,9 @@ struct TWgradArgs {          // dW[m][c][tap] = sum_{b,t} dY[b][m][t] X[b][c][st
 size_t tpack_elems(int rows, int K, int taps);               // bf16 elements of the packed form
 // A[row][k][tap] = src[row * s_row + k * s_k + (flip ? taps - 1 - tap : tap)]  ->  bf16 MFMA A-fragment order (zero padded to 32 rows / 16 k)
 void launch_tpack_weights(hipStream_t st, const float* src, unsigned short* dst, int rows, int K, int taps, long long s_row, long long s_k, int flip);
+// `batch` weight sets at once: set i reads src + i * src_bstride and writes dst + i * tpack_elems(rows, K, taps); values multiplied by `scale`
+void launch_tpack_weights_batched(hipStream_t st, const float* src, unsigned short* dst, int batch, long long src_bstride, int rows, int K, int taps,
+                                  long long s_row, long long s_k, int flip, float scale);
 void launch_tconv_bf16(hipStream_t st, const TConvArgs& a);
 bool twgrad_fuses_bias(int taps);            // whether launch_twgrad_bf16 can also produce TWgradArgs::db for this tap count
 int twgrad_splits(int B, int M, int C, int Tout, int taps, int kt /* samples per slab: 64 for 1x1 layers, 32 for 3-tap ones */);

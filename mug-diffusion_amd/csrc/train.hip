@@ -438,7 +438,26 @@ int mugd_train_transformer(mugd_ctx* ctx, const float* const* P, const float* x,
             a.q = q; a.q_bstride = C * T; a.k = k; a.k_bstride = C * tk; a.v = v; a.v_bstride = C * tk; a.dout = dO; a.o_bstride = C * T;
             a.rel = P[rel_i]; a.cemb = P[cemb_i]; a.B = B; a.heads = heads; a.d = d; a.Tq = T; a.Tk = tk; a.pmax = pmax; a.scale = scale;
             a.Amat = Am; a.dsim = dsm; a.dG = dGm; a.dq = dq; a.dk = dk; a.dv = dv; a.drel = G[rel_i]; a.dcemb = G[cemb_i]; a.tab_part = tabp;
+            // bf16 mode: the key-side gradients are two batched GEMMs over the matrices the row kernel materialises anyway,
+            //   dk[(b,h)][e][j] = scale sum_i q[e][i] dsim[i][j],   dv[(b,h)][e][j] = sum_i dO[e][i] A[i][j]
+            // -- per (batch row, head) a (d x Tq) "weight" (q resp. dO, packed per head) applied to a (Tq x tk) input: tconv with per-batch weights
+            const bool gemm_cols = c.train_bf16 && T % 16 == 0;
+            a.skip_cols = gemm_cols ? 1 : 0;
             launch_attention_bwd(st, a);
+            if (gemm_cols) {
+                const int BH = B * heads;
+                const size_t pe = tpack_elems(d, T, 1);
+                unsigned short* wq = reinterpret_cast<unsigned short*>(sc.get((pe * BH + 1) / 2, false, st));
+                unsigned short* wo = reinterpret_cast<unsigned short*>(sc.get((pe * BH + 1) / 2, false, st));
+                launch_tpack_weights_batched(st, q, wq, BH, (long long)d * T, d, T, 1, T, 1, 0, scale);
+                launch_tpack_weights_batched(st, dO, wo, BH, (long long)d * T, d, T, 1, T, 1, 0, 1.0f);
+                TConvArgs g{};
+                g.B = BH; g.C = T; g.Tin = tk; g.M = d; g.Tout = tk; g.taps = 1; g.dil = 1; g.stride = 1; g.pad = 0; g.ups = 0; g.w_bstride = (long long)pe;
+                g.x = dsm; g.wpk = wq; g.y = dk;
+                launch_tconv_bf16(st, g);
+                g.x = Am; g.wpk = wo; g.y = dv;
+                launch_tconv_bf16(st, g);
+            }
         };
         // proj_out: y = Wout h3 + b + x
         lt.bwd(h3, P[MUGD_TF_PROJ_OUT_W], dy, dh, false, G[MUGD_TF_PROJ_OUT_W], G[MUGD_TF_PROJ_OUT_B], C, C, wt);       // dh = d h3

@@ -155,6 +155,30 @@ def test_transformer_forward_backward_vs_autograd(lib, B, C, T, Cc, Tk, heads, g
         close(grads[k], pt["m." + k].grad, 3e-4, "grad of " + k)
 
 
+@pytest.mark.parametrize("B,C,T,Cc,Tk,heads,groups,pmax", [(2, 64, 96, 32, 21, 4, 16, 64), (1, 64, 48, 0, 0, 4, 32, 8)])
+def test_transformer_bf16_mode_vs_fp32_mode(lib, B, C, T, Cc, Tk, heads, groups, pmax):
+    """The transformer block with its GEMMs on the bf16 matrix cores -- the Linears AND the key-side attention gradients (two batched
+    matmuls with per-(batch row, head) operands: dk = dsim^T q, dv = A^T dO) -- against the fp32 mode (which equals autograd, above):
+    every output within bf16 rounding of the operands (relative L2 error <= 2 %)."""
+    p = transformer_params(C, Cc if Cc else C, heads, pmax)
+    x, dy = rnd(40, B, C, T), rnd(41, B, C, T)
+    ctx = rnd(42, B, Cc, Tk) if Cc else None
+    y32, dx32, dc32, g32 = lib.train_transformer(p, x, ctx, dy, heads, groups=groups)
+    lib.train_set_precision(True)
+    try:
+        y16, dx16, dc16, g16 = lib.train_transformer(p, x, ctx, dy, heads, groups=groups)
+    finally:
+        lib.train_set_precision(False)
+
+    def rel(a, b):
+        a, b = a.detach().cpu().double(), b.detach().cpu().double()
+        return float((a - b).norm() / b.norm())
+    worst = max([("forward", rel(y16, y32)), ("dx", rel(dx16, dx32))] + ([("dcontext", rel(dc16, dc32))] if ctx is not None else [])
+                + [(k, rel(g16[k], g32[k])) for k in p], key=lambda kv: kv[1])
+    print("bf16 transformer block vs fp32: worst relative L2 error %.2e (%s)" % (worst[1], worst[0]))
+    assert worst[1] <= 2e-2, worst
+
+
 def s4layer_params(H, N, L, seed=200):
     """An S4Layer's tensors with the reference's shapes (state-dict names relative to the layer) in a trained-checkpoint-like
     state: stored kernel length L, poles spread along the imaginary axis, dt in [1e-3, 1e-1]."""
