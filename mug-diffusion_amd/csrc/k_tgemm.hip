@@ -369,33 +369,41 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
 constexpr int TW_XS = 81;                 // LDS row stride of the input window (floats, odd): 63 + 2 * 8 + 1 = 80 columns (64-sample slabs, stride 1) or 31 * 2 + 17 = 79 (32-sample slabs, stride 2)
 
 // TW_KT = samples per slab: 64 for stride-1 layers (half the barriers / latency periods per FLOP), 32 for the stride-2 Downsample convs
-// DB: also sum the bias gradient (16 more live registers: compiled in only where they fit -- the 3-tap form; the 1x1 form with 64-sample
-// slabs would drop to one wave per SIMD, measured 1.5x slower, and leaves the bias gradient to the row-sum kernels)
-template <int TAPS, int TW_KT, bool DB>
-__global__ __launch_bounds__(256) void twgrad_bf16_kernel(const TWgradArgs a) {
+// DB: also sum the bias gradient (more live registers: compiled in only where they fit -- the 3-tap form; the 1x1 form with 64-sample
+// slabs would drop to one wave per SIMD, measured 1.5x slower, and leaves the bias gradient to the row-sum kernels).
+// BIG: a 128 (m) x 128 (c) tile on 8 waves (4 x 2, a wave: 32 rows x 64 columns = two accumulators per tap) instead of 64 x 64 on 4
+// (2 x 2): each operand slab is staged once per 128 rows / columns -- the 64 x 64 form reads every dY slab once per c tile and every
+// input slab once per m tile, which made the 128-channel wave-encoder layers (2 x 2 tiles) stream their 0.5 GB operands twice.
+template <int TAPS, int TW_KT, bool DB, bool BIG>
+__global__ __launch_bounds__(BIG ? 512 : 256) void twgrad_bf16_kernel(const TWgradArgs a) {
+    constexpr int NTHR = BIG ? 512 : 256;
+    constexpr int TM = BIG ? 128 : 64;                  // tile rows (m) = tile columns (c)
+    constexpr int NC = BIG ? 2 : 1;                     // 32-column accumulator tiles per wave
     constexpr int TW_YS = TW_KT + 1;                    // LDS row stride of the dY slab (floats, odd)
-    constexpr int TW_BUF = 64 * TW_YS + 64 * TW_XS;     // floats per LDS buffer
+    constexpr int TW_BUF = TM * TW_YS + TM * TW_XS;     // floats per LDS buffer
     __shared__ float smem[2 * TW_BUF];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, h = lane >> 5, n = lane & 31;
     const int wm = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64, ks = blockIdx.z;
+    const int m0 = blockIdx.x * TM, c0 = blockIdx.y * TM, ks = blockIdx.z;
     const int nslab = (a.Tout + TW_KT - 1) / TW_KT, total = a.B * nslab;
     const int W = (TW_KT - 1) * a.stride + (TAPS - 1) * a.dil + 1;
     const int vlen = a.ups ? 2 * a.Tin : a.Tin;
     const float inv_w = 1.0f / (float)W;
-    constexpr int NY = 64 * TW_KT / 256;
-    constexpr int NX = 20;                // ceil(64 * 80 / 256)
+    constexpr int NY = TM * TW_KT / NTHR;
+    constexpr int NX = (TM * 80 + NTHR - 1) / NTHR;     // = 20
     float vy[NY], vx[NX];
     // bias gradient db[m] = sum_{b,t} dY[b][m][t], fused: the c-tile-0 workgroups add up the dY values they stage anyway (fp32, fixed order)
     const bool want_db = DB && a.db != nullptr && blockIdx.y == 0;
     float rs[DB ? NY : 1];
 #pragma unroll
     for (int i = 0; i < (DB ? NY : 1); ++i) rs[i] = 0.f;
-    f32x16 acc[TAPS];
+    f32x16 acc[TAPS][NC];
 #pragma unroll
     for (int k = 0; k < TAPS; ++k)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
+        for (int q = 0; q < NC; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[k][q][i] = 0.f;
 
     // raw, unconditional loads of slab s from clamped addresses; the zero padding is applied when the slab is parked (a select right
     // behind a load would make the wave wait for it before the MFMAs of the slab in front)
@@ -404,7 +412,7 @@ __global__ __launch_bounds__(256) void twgrad_bf16_kernel(const TWgradArgs a) {
         const float* yb = a.dY + (size_t)b * a.M * a.Tout;
 #pragma unroll
         for (int i = 0; i < NY; ++i) {
-            const int e = tid + 256 * i, row = e / TW_KT, col = e % TW_KT;
+            const int e = tid + NTHR * i, row = e / TW_KT, col = e % TW_KT;
             const int m = m0 + row, t = t0 + col;
             vy[i] = yb[(size_t)(unsigned)((m < a.M ? m : a.M - 1) * a.Tout + (t < a.Tout ? t : a.Tout - 1))];
         }
@@ -412,8 +420,8 @@ __global__ __launch_bounds__(256) void twgrad_bf16_kernel(const TWgradArgs a) {
         const float* xbp = a.X + (size_t)b * a.C * a.Tin;
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            int e = tid + 256 * i;
-            e = e < 64 * W ? e : 0;
+            int e = tid + NTHR * i;
+            e = e < TM * W ? e : 0;
             const int row = (int)(((float)e + 0.5f) * inv_w), col = e - row * W;
             const int c = c0 + row, u = u0 + col;
             int uc = u < 0 ? 0 : u;
@@ -424,10 +432,10 @@ __global__ __launch_bounds__(256) void twgrad_bf16_kernel(const TWgradArgs a) {
     auto park = [&](int s, int buf) {
         const int b = s / nslab, t0 = (s - b * nslab) * TW_KT;
         float* sy = smem + buf * TW_BUF;
-        float* sx = sy + 64 * TW_YS;
+        float* sx = sy + TM * TW_YS;
 #pragma unroll
         for (int i = 0; i < NY; ++i) {
-            const int e = tid + 256 * i, row = e / TW_KT, col = e % TW_KT;
+            const int e = tid + NTHR * i, row = e / TW_KT, col = e % TW_KT;
             const float yv = (m0 + row < a.M && t0 + col < a.Tout) ? vy[i] : 0.f;
             sy[row * TW_YS + col] = yv;
             if (DB) rs[i] += yv;
@@ -435,8 +443,8 @@ __global__ __launch_bounds__(256) void twgrad_bf16_kernel(const TWgradArgs a) {
         const int u0 = t0 * a.stride - a.pad;
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const int e = tid + 256 * i;
-            if (e < 64 * W) {
+            const int e = tid + NTHR * i;
+            if (e < TM * W) {
                 const int row = (int)(((float)e + 0.5f) * inv_w), col = e - row * W;
                 const int u = u0 + col;
                 sx[row * TW_XS + col] = (c0 + row < a.C && u >= 0 && u < vlen) ? vx[i] : 0.f;
@@ -453,7 +461,7 @@ __global__ __launch_bounds__(256) void twgrad_bf16_kernel(const TWgradArgs a) {
         const bool more = s + s_step < total;
         if (more) load_slab(s + s_step);
         const float* sy = smem + (it & 1) * TW_BUF;
-        const float* sx = sy + 64 * TW_YS;
+        const float* sx = sy + TM * TW_YS;
 #pragma unroll
         for (int kk = 0; kk < TW_KT / 16; ++kk) {
             const float* ar = sy + (wm * 32 + n) * TW_YS + kk * 16 + 8 * h;
@@ -462,30 +470,32 @@ __global__ __launch_bounds__(256) void twgrad_bf16_kernel(const TWgradArgs a) {
             for (int j = 0; j < 4; ++j) av[j] = pack_bf16(ar[2 * j], ar[2 * j + 1]);
             const bf16x8 af = __builtin_bit_cast(bf16x8, av);
 #pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
-                // sample t of the slab pairs with window column t * stride + tap * dil; a lane's 8 k are 8 consecutive t
-                const float* br = sx + (wc * 32 + n) * TW_XS + (kk * 16 + 8 * h) * a.stride + tap * a.dil;
-                u32x4 bv;
-                if (a.stride == 1) {
+            for (int tap = 0; tap < TAPS; ++tap)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) bv[j] = pack_bf16(br[2 * j], br[2 * j + 1]);
-                } else {
+                for (int q = 0; q < NC; ++q) {
+                    // sample t of the slab pairs with window column t * stride + tap * dil; a lane's 8 k are 8 consecutive t
+                    const float* br = sx + ((wc * NC + q) * 32 + n) * TW_XS + (kk * 16 + 8 * h) * a.stride + tap * a.dil;
+                    u32x4 bv;
+                    if (a.stride == 1) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) bv[j] = pack_bf16(br[4 * j], br[4 * j + 2]);
+                        for (int j = 0; j < 4; ++j) bv[j] = pack_bf16(br[2 * j], br[2 * j + 1]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) bv[j] = pack_bf16(br[4 * j], br[4 * j + 2]);
+                    }
+                    acc[tap][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bv), acc[tap][q], 0, 0, 0);
                 }
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bv), acc[tap], 0, 0, 0);
-            }
         }
         if (more) park(s + s_step, (it + 1) & 1);
         __syncthreads();
     }
-    if (DB && want_db) {     // element i of this thread sits in row (tid + 256 i) / TW_KT: one row per wave (64-sample slabs) or per half wave (32)
+    if (DB && want_db) {     // element i of this thread sits in row (tid + NTHR i) / TW_KT: one row per wave (64-sample slabs) or per half wave (32)
 #pragma unroll
         for (int i = 0; i < (DB ? NY : 1); ++i) {
             float v = rs[i];
 #pragma unroll
             for (int o = 1; o < (TW_KT < 64 ? TW_KT : 64); o <<= 1) v += __shfl_xor(v, o);
-            const int row = (tid + 256 * i) / TW_KT;
+            const int row = (tid + NTHR * i) / TW_KT;
             if ((tid & (TW_KT - 1)) == 0 && m0 + row < a.M) a.db[(size_t)ks * a.M + m0 + row] = v;
         }
     }
@@ -494,10 +504,12 @@ __global__ __launch_bounds__(256) void twgrad_bf16_kernel(const TWgradArgs a) {
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int m = m0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, c = c0 + wc * 32 + n;
-            if (m < a.M && c < a.C) out[((size_t)m * a.C + c) * TAPS + tap] = acc[tap][i];
-        }
+        for (int q = 0; q < NC; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = m0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, c = c0 + (wc * NC + q) * 32 + n;
+                if (m < a.M && c < a.C) out[((size_t)m * a.C + c) * TAPS + tap] = acc[tap][q][i];
+            }
 }
 
 // dW[i] = sum_k part[k][i] (fixed order); the same launch sums the bias-gradient slices (partb: KS x nb) when there are any
@@ -563,13 +575,19 @@ void launch_tconv_bf16(hipStream_t st, const TConvArgs& a0) {
 
 // K-slices of a bf16 weight-gradient launch: enough workgroups to fill the chip, every slice with >= 4 slabs, partial tiles
 // (KS * M * C * taps floats written and read back) kept below half the bytes of the operands
+// 128 x 128 tiles when both dimensions have them and the contraction is long enough to give every K-slice work
+bool twgrad_big_tile(int B, int M, int C, int Tout) {
+    if (const char* e = getenv("MUGD_TWGRAD_BIG")) return e[0] == '1';                  // development / test knob
+    return M >= 128 && C >= 128 && (long long)B * Tout >= 8192;
+}
 int twgrad_splits(int B, int M, int C, int Tout, int taps, int kt) {
-    const long long tiles = (long long)cdiv(M, 64) * cdiv(C, 64), slabs = (long long)B * cdiv(Tout, kt);
-    long long ks = std::max<long long>(1, 768 / tiles);
+    const int tm = twgrad_big_tile(B, M, C, Tout) ? 128 : 64;
+    const long long tiles = (long long)cdiv(M, tm) * cdiv(C, tm), slabs = (long long)B * cdiv(Tout, kt);
+    long long ks = std::max<long long>(1, (tm == 128 ? 512 : 768) / tiles);
     ks = std::min(ks, std::max<long long>(1, slabs / 4));
     const double operand = (double)B * Tout * ((double)M + C);
     long long cap = (long long)std::max(1.0, 0.5 * operand / ((double)M * C * taps));
-    cap = std::max(cap, std::min<long long>(cdiv(512, (int)tiles), slabs / 8));      // ... but never fewer than ~512 workgroups of >= 8 slabs
+    cap = std::max(cap, std::min<long long>(cdiv(tm == 128 ? 256 : 512, (int)tiles), slabs / 8));      // ... but never fewer than ~256-512 workgroups of >= 8 slabs
     ks = std::min(ks, std::max<long long>(cap, 1));
     return (int)std::min<long long>(ks, 512);
 }
@@ -588,18 +606,26 @@ void launch_twgrad_bf16(hipStream_t st, const TWgradArgs& a0, float* partial) {
         a.dW = partial;
         if (a.db) a.db = partial + (size_t)a.KS * nn;
     }
-    const dim3 grid(cdiv(a.M, 64), cdiv(a.C, 64), a.KS);
     // 64-sample slabs pay for 1x1 layers (2 MFMAs per wave and 32-sample slab are too little work per barrier); the 3-tap kernels
     // measured faster with 32-sample slabs (474 vs 369 us on the 128 x 128 x 3 wave-encoder layers: registers / LDS per workgroup)
+    const bool big = a.big != 0;
+    const dim3 grid(cdiv(a.M, big ? 128 : 64), cdiv(a.C, big ? 128 : 64), a.KS);
+    const dim3 blk(big ? 512 : 256);
+#define MUGD_TW(T, K, D)                                                                                   \
+    do {                                                                                                   \
+        if (big) hipLaunchKernelGGL((twgrad_bf16_kernel<T, K, D, true>), grid, blk, 0, st, a);             \
+        else hipLaunchKernelGGL((twgrad_bf16_kernel<T, K, D, false>), grid, blk, 0, st, a);                \
+    } while (0)
     if (a.taps == 1) {
         MUGD_CHECK(a.stride == 1, -2, "twgrad: strided 1x1 convs are not used by the model");
         MUGD_CHECK(!a.db, -2, "twgrad: the 1x1 form does not produce the bias gradient (twgrad_fuses_bias)");
-        hipLaunchKernelGGL((twgrad_bf16_kernel<1, 64, false>), grid, dim3(256), 0, st, a);
+        MUGD_TW(1, 64, false);
     } else if (a.db) {
-        hipLaunchKernelGGL((twgrad_bf16_kernel<3, 32, true>), grid, dim3(256), 0, st, a);
+        MUGD_TW(3, 32, true);
     } else {
-        hipLaunchKernelGGL((twgrad_bf16_kernel<3, 32, false>), grid, dim3(256), 0, st, a);
+        MUGD_TW(3, 32, false);
     }
+#undef MUGD_TW
     if (a.KS > 1) {
         const int nb = final_db ? a.M : 0;
         hipLaunchKernelGGL(twgrad_reduce_kernel, dim3((unsigned)std::min<long long>((nn + nb + 255) / 256, 4096)), dim3(256), 0, st, partial, final_dw, nn, a.KS,

@@ -236,11 +236,11 @@ __global__ __launch_bounds__(256) void attn_bwd_rows_lds_kernel(const AttnBwdArg
     const float* k = a.k + (size_t)b * a.k_bstride + (size_t)h * d * Tk;
     const float* v = a.v + (size_t)b * a.v_bstride + (size_t)h * d * Tk;
     const float* dO = a.dout + (size_t)b * a.o_bstride + (size_t)h * d * Tq;
-    for (int e = threadIdx.x; e < d * Tk; e += 256) {
-        const int r = e / Tk, c = e - r * Tk;
-        ks[r * KS + c] = k[e];
-        vs[r * KS + c] = v[e];
-    }
+    for (int r = wave; r < d; r += 4)
+        for (int c = lane; c < Tk; c += 64) {
+            ks[r * KS + c] = k[(size_t)r * Tk + c];
+            vs[r * KS + c] = v[(size_t)r * Tk + c];
+        }
     __syncthreads();
     for (int ii = wave; ii < ATB_RB; ii += 4) {
         const int i = blockIdx.x * ATB_RB + ii;
@@ -248,15 +248,42 @@ __global__ __launch_bounds__(256) void attn_bwd_rows_lds_kernel(const AttnBwdArg
         if (lane < d) { qs[wave][lane] = q[(size_t)lane * Tq + i]; dos[wave][lane] = dO[(size_t)lane * Tq + i]; }
         wave_sync();
         float mx = -3.0e38f;
-        for (int j = lane; j < Tk; j += 64) {
-            float dot = 0.f, da = 0.f;
-#pragma unroll 8                                           // 16 LDS operands in flight per lane: the loop is LDS-latency bound at one wave per SIMD
-            for (int e = 0; e < d; ++e) { dot += qs[wave][e] * ks[e * KS + j]; da += dos[wave][e] * vs[e * KS + j]; }
-            int idx = j - i;
-            idx = (idx < -a.pmax ? -a.pmax : (idx > a.pmax ? a.pmax : idx)) + a.pmax;
-            const float sim = (dot + a.rel[idx * a.heads + h]) * a.scale;
-            srow[wave][j] = sim; drow[wave][j] = da;
-            mx = fmaxf(mx, sim);
+        {   // the four 64-key groups of the row side by side: 8 independent LDS operands per channel step (the loop is LDS-latency
+            // bound at one or two waves per SIMD; one group at a time left the LDS pipe idle 7/8 of the time)
+            float dot[4] = {0.f, 0.f, 0.f, 0.f}, da[4] = {0.f, 0.f, 0.f, 0.f};
+            int jj[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { const int j = lane + 64 * g; jj[g] = j < Tk ? j : Tk - 1; }
+            if (Tk > 128) {
+#pragma unroll 2
+                for (int e = 0; e < d; ++e) {
+                    const float qe = qs[wave][e], de = dos[wave][e];
+                    const float* kr = ks + e * KS;
+                    const float* vr = vs + e * KS;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) { dot[g] += qe * kr[jj[g]]; da[g] += de * vr[jj[g]]; }
+                }
+            } else {                                       // <= 128 keys (the deep levels, the 21 prompt tokens): two groups, four channels in flight
+#pragma unroll 4
+                for (int e = 0; e < d; ++e) {
+                    const float qe = qs[wave][e], de = dos[wave][e];
+                    const float* kr = ks + e * KS;
+                    const float* vr = vs + e * KS;
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) { dot[g] += qe * kr[jj[g]]; da[g] += de * vr[jj[g]]; }
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int j = lane + 64 * g;
+                if (j < Tk) {
+                    int idx = j - i;
+                    idx = (idx < -a.pmax ? -a.pmax : (idx > a.pmax ? a.pmax : idx)) + a.pmax;
+                    const float sim = (dot[g] + a.rel[idx * a.heads + h]) * a.scale;
+                    srow[wave][j] = sim; drow[wave][j] = da[g];
+                    mx = fmaxf(mx, sim);
+                }
+            }
         }
         mx = wave_max_ff(mx);
         float sum = 0.f;
@@ -393,11 +420,13 @@ void launch_geglu_bwd(hipStream_t st, const float* u, const float* df, float* du
 void launch_attention_bwd(hipStream_t st, const AttnBwdArgs& a) {
     MUGD_CHECK(a.d >= 4 && a.d <= 64 && a.d % 4 == 0 && a.Tk >= 1 && a.Tk <= ATB_TK, -2, "attention backward: head dim 4..64 (multiple of 4), at most 1024 keys");
     MUGD_CHECK(a.tab_part, -2, "attention backward: no partial buffer for the table gradients");
-    // LDS-staged forms when the head's K / V (resp. q / dO) fit with two workgroups per CU (d * T <= 8192: all U-Net shapes at z = 512);
-    // larger heads (the wave encoder's d = 64 at T = 256: one 150 KB workgroup per CU measured SLOWER, 796 / 1131 us) keep the first versions
+    // LDS-staged forms when the head's K / V (resp. q / dO) fit (rows: up to d * T = 16384, one 150 KB workgroup per CU at that size -- worth it
+    // only since the row loop runs its four key groups side by side; columns: up to 8192, larger heads keep the first version or, in bf16
+    // mode, leave the key-side gradients to the caller's batched GEMMs)
     const int kv = a.d * (a.Tk + 1), qf = a.d * a.Tq;
     if (a.Tk <= ATB_TKS && kv <= 4224) hipLaunchKernelGGL(attn_bwd_rows_lds_kernel<4224>, dim3(cdiv(a.Tq, ATB_RB), a.heads, a.B), dim3(256), 0, st, a);
     else if (a.Tk <= ATB_TKS && kv <= 8448) hipLaunchKernelGGL(attn_bwd_rows_lds_kernel<8448>, dim3(cdiv(a.Tq, ATB_RB), a.heads, a.B), dim3(256), 0, st, a);
+    else if (a.Tk <= ATB_TKS && kv <= 16640) hipLaunchKernelGGL(attn_bwd_rows_lds_kernel<16640>, dim3(cdiv(a.Tq, ATB_RB), a.heads, a.B), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(attn_bwd_rows_kernel, dim3(cdiv(a.Tq, 4), a.heads, a.B), dim3(256), 0, st, a);
     if (a.skip_cols) { /* dk / dv come from the caller's batched GEMMs */ }
     else if (qf <= 4096) hipLaunchKernelGGL(attn_bwd_cols_lds_kernel<4096>, dim3(cdiv(a.Tk, 64), a.heads, a.B), dim3(256), 0, st, a);

@@ -380,6 +380,7 @@ struct TWgradArgs {          // dW[m][c][tap] = sum_{b,t} dY[b][m][t] X[b][c][st
     const float* dY; const float* X; float* dW;
     int B, M, C, Tout, Tin, taps, pad, dil, stride, ups, KS;
     float* db;               // null, or [M]: the bias gradient sum_{b,t} dY[b][m][t], summed from the dY slabs the kernel stages anyway
+    int big;                 // 1: 128 x 128 tiles on 8 waves (twgrad_big_tile), 0: 64 x 64 on 4
 };
 size_t tpack_elems(int rows, int K, int taps);               // bf16 elements of the packed form
 // A[row][k][tap] = src[row * s_row + k * s_k + (flip ? taps - 1 - tap : tap)]  ->  bf16 MFMA A-fragment order (zero padded to 32 rows / 16 k)
@@ -388,6 +389,7 @@ void launch_tpack_weights(hipStream_t st, const float* src, unsigned short* dst,
 void launch_tpack_weights_batched(hipStream_t st, const float* src, unsigned short* dst, int batch, long long src_bstride, int rows, int K, int taps,
                                   long long s_row, long long s_k, int flip, float scale);
 void launch_tconv_bf16(hipStream_t st, const TConvArgs& a);
+bool twgrad_big_tile(int B, int M, int C, int Tout);
 bool twgrad_fuses_bias(int taps);            // whether launch_twgrad_bf16 can also produce TWgradArgs::db for this tap count
 int twgrad_splits(int B, int M, int C, int Tout, int taps, int kt /* samples per slab: 64 for 1x1 layers, 32 for 3-tap ones */);
 void launch_twgrad_bf16(hipStream_t st, const TWgradArgs& a, float* partial /* KS * (M * C * taps + M) floats when KS > 1 */);
