@@ -390,7 +390,8 @@ __global__ __launch_bounds__(BIG ? 512 : 256) void twgrad_bf16_kernel(const TWgr
     const int vlen = a.ups ? 2 * a.Tin : a.Tin;
     const float inv_w = 1.0f / (float)W;
     constexpr int NY = TM * TW_KT / NTHR;
-    constexpr int NX = (TM * 80 + NTHR - 1) / NTHR;     // = 20
+    constexpr int WMAX = BIG ? TW_KT + 16 : 80;         // window columns: the big tile is only launched at stride 1 (slab + 2 * 8 halo); else 31 * 2 + 17 | 63 + 17
+    constexpr int NX = (TM * WMAX + NTHR - 1) / NTHR;   // 12 (big, 32-sample slabs) | 20
     float vy[NY], vx[NX];
     // bias gradient db[m] = sum_{b,t} dY[b][m][t], fused: the c-tile-0 workgroups add up the dY values they stage anyway (fp32, fixed order)
     const bool want_db = DB && a.db != nullptr && blockIdx.y == 0;
@@ -580,10 +581,11 @@ bool twgrad_big_tile(int B, int M, int C, int Tout) {
     if (const char* e = getenv("MUGD_TWGRAD_BIG")) return e[0] == '1';                  // development / test knob
     return M >= 128 && C >= 128 && (long long)B * Tout >= 8192;
 }
+static bool twgrad_big_ok(const TWgradArgs& a) { return a.stride == 1; }      // the big tile's staging registers are sized for stride-1 windows
 int twgrad_splits(int B, int M, int C, int Tout, int taps, int kt) {
     const int tm = twgrad_big_tile(B, M, C, Tout) ? 128 : 64;
     const long long tiles = (long long)cdiv(M, tm) * cdiv(C, tm), slabs = (long long)B * cdiv(Tout, kt);
-    long long ks = std::max<long long>(1, (tm == 128 ? 512 : 768) / tiles);
+    long long ks = std::max<long long>(1, (tm == 128 ? 256 : 768) / tiles);      // one 8-wave workgroup per CU is all the big tile can hold (LDS)
     ks = std::min(ks, std::max<long long>(1, slabs / 4));
     const double operand = (double)B * Tout * ((double)M + C);
     long long cap = (long long)std::max(1.0, 0.5 * operand / ((double)M * C * taps));
@@ -609,6 +611,7 @@ void launch_twgrad_bf16(hipStream_t st, const TWgradArgs& a0, float* partial) {
     // 64-sample slabs pay for 1x1 layers (2 MFMAs per wave and 32-sample slab are too little work per barrier); the 3-tap kernels
     // measured faster with 32-sample slabs (474 vs 369 us on the 128 x 128 x 3 wave-encoder layers: registers / LDS per workgroup)
     const bool big = a.big != 0;
+    MUGD_CHECK(!big || twgrad_big_ok(a), -2, "twgrad: 128 x 128 tiles are built for stride-1 windows");
     const dim3 grid(cdiv(a.M, big ? 128 : 64), cdiv(a.C, big ? 128 : 64), a.KS);
     const dim3 blk(big ? 512 : 256);
 #define MUGD_TW(T, K, D)                                                                                   \

@@ -168,7 +168,7 @@ void run_wgrad(Ctx& c, Scratch& sc, const float* dY, const float* A, float* dW, 
         ProfScope prof(g_tprof, c.stream, 1, 2.0 * M * C * taps * (double)B * Tout);
         if (c.train_bf16) {
             const bool fuse = db && twgrad_fuses_bias(taps);
-            TWgradArgs a{dY, A, dW, B, M, C, Tout, Tin, taps, pad, dil, stride, ups, twgrad_splits(B, M, C, Tout, taps, taps == 1 ? 64 : 32), fuse ? db : nullptr, twgrad_big_tile(B, M, C, Tout) ? 1 : 0};
+            TWgradArgs a{dY, A, dW, B, M, C, Tout, Tin, taps, pad, dil, stride, ups, twgrad_splits(B, M, C, Tout, taps, taps == 1 ? 64 : 32), fuse ? db : nullptr, (stride == 1 && twgrad_big_tile(B, M, C, Tout)) ? 1 : 0};
             float* part = a.KS > 1 ? sc.get((size_t)a.KS * ((size_t)M * C * taps + M), false, c.stream) : nullptr;
             launch_twgrad_bf16(c.stream, a, part);
             if (fuse) return;
