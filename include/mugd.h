@@ -230,6 +230,16 @@ int mugd_op_timestep_embedding(mugd_ctx* ctx, const int64_t* t, float* out, int 
  * reference would get from Lightning's `precision: bf16`, main.py / configs/mug/mug_diffusion.yaml:151): operands are rounded to
  * bfloat16 on their way into the matrix cores; master weights, activations in memory, norms, softmax, S4 and reductions stay fp32. */
 int mugd_train_set_precision(mugd_ctx* ctx, int bf16);
+/* The step bracket of the bf16 training path.  Between _begin and _end the caller promises that NO weight tensor changes.  Inside it
+ *   - the bf16 MFMA operand form of every conv / Linear weight is read from a cache that _begin refreshes with ONE launch for all tensors
+ *     seen in the previous step (a tensor seen for the first time is packed on the spot), instead of two small launches per GEMM;
+ *   - split-K slices of the weight gradients and the per-batch-row bias sums are summed (same fixed order) by ONE launch per _flush / _end
+ *     instead of one per GEMM: weight and bias gradients written by the block calls are complete only after _flush or _end.
+ * A weight tensor used inside a bracket must stay allocated until the _begin after the next one (or mugd_destroy).  Outside a bracket
+ * every block call packs and reduces on its own.  None of the three synchronises the host. */
+int mugd_train_step_begin(mugd_ctx* ctx);
+int mugd_train_step_flush(mugd_ctx* ctx);
+int mugd_train_step_end(mugd_ctx* ctx);
 /* Measurement hook of the training GEMMs.  enable != 0: from now on every conv / Linear forward + data-gradient GEMM (class 0) and every
  * weight-gradient GEMM (class 1) launch is bracketed by a HIP event pair on the context's stream.  enable == 0: stop, synchronise, and
  * (out != NULL) report out[0..1] = elapsed milliseconds, out[2..3] = algorithmic FLOPs (2 M K N), out[4..5] = launches per class. */

@@ -107,6 +107,8 @@ void mugd_destroy(mugd_ctx* ctx) {
     hipStreamSynchronize(ctx->c.stream);
     if (ctx->c.order_event) hipEventDestroy(ctx->c.order_event);
     if (ctx->c.scratch) hipFree(ctx->c.scratch);
+    ctx->step.ring.release();
+    for (auto& e : ctx->step.packs) hipFree(e.dst);
     ctx->pool.release();
     for (auto& kv : ctx->c.resample_taps) hipFree(kv.second);
     if (ctx->c.own_stream) hipStreamDestroy(ctx->c.stream);

@@ -2,6 +2,10 @@
 #pragma once
 #include "net.h"
 
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <tuple>
 #include <vector>
 
 // Scratch blocks of the training entry points, kept across calls (a training step makes several hundred block calls of a few
@@ -46,10 +50,66 @@ struct TrainProfile {
     }
 };
 
+// ---- the step bracket of the bf16 training path (mugd_train_step_begin / _flush / _end) --------------------------------------
+// Inside the bracket the caller promises that no weight tensor changes.  That buys two things:
+//  * packed weights: the bf16 A-fragment form of every conv / Linear weight (both orientations: forward and data gradient) lives in a
+//    cache keyed by (tensor, geometry); step_begin refreshes ALL of it with ONE table-driven launch instead of ~930 small ones;
+//  * deferred reductions: split-K partial tiles of the weight gradients and the per-batch-row bias sums stay in their pool blocks
+//    until flush / step_end sums all of them with ONE table-driven launch (same fixed summation order: deterministic).
+// Outside the bracket every call packs and reduces on its own, as before.
+struct PackEntry {
+    const float* src; unsigned short* dst; int rows, K, taps, flip; long long s_row, s_k, total; int MT, nkb; long long packed_epoch, used_epoch;
+};
+// a table handed to a kernel: pinned host staging + device copy, a ring of slots so that the host can be several launches ahead
+struct UploadRing {
+    static constexpr int SLOTS = 4;
+    struct Slot { void* host = nullptr; void* dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
+    Slot slots[SLOTS];
+    int next = 0;
+    // copies `bytes` from src to a device table ordered on st; call mark(st) after the consuming launch
+    void* upload(const void* src, size_t bytes, hipStream_t st) {
+        Slot& s = slots[next];
+        if (s.busy) { HIP_CHECK(hipEventSynchronize(s.done)); s.busy = false; }      // only when the device is SLOTS tables behind
+        if (s.cap < bytes) {
+            if (s.host) { HIP_CHECK(hipHostFree(s.host)); HIP_CHECK(hipFree(s.dev)); }
+            s.cap = std::max<size_t>(2 * bytes, 1 << 16);
+            HIP_CHECK(hipHostMalloc(&s.host, s.cap, 0));
+            HIP_CHECK(hipMalloc(&s.dev, s.cap));
+        }
+        if (!s.done) HIP_CHECK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        memcpy(s.host, src, bytes);
+        HIP_CHECK(hipMemcpyAsync(s.dev, s.host, bytes, hipMemcpyHostToDevice, st));
+        return s.dev;
+    }
+    void mark(hipStream_t st) {
+        Slot& s = slots[next];
+        HIP_CHECK(hipEventRecord(s.done, st));
+        s.busy = true;
+        next = (next + 1) % SLOTS;
+    }
+    void release() {
+        for (Slot& s : slots) {
+            if (s.host) { hipHostFree(s.host); hipFree(s.dev); }
+            if (s.done) hipEventDestroy(s.done);
+            s = Slot{};
+        }
+    }
+};
+struct TrainStep {
+    bool on = false;
+    long long epoch = 0;
+    std::map<std::tuple<const float*, int, int, int, int>, int> index;      // (tensor, flip, rows, K, taps) -> packs[]
+    std::vector<PackEntry> packs;
+    std::vector<TReduceDesc> jobs;
+    std::vector<void*> held;               // pool blocks of the queued partial sums
+    UploadRing ring;
+};
+
 struct mugd_ctx {
     Ctx c;
     TrainProfile tprof;
     TrainPool pool;
+    TrainStep step;
     // forward intermediates a training block kept for its backward call (mugd_train_*'s `state` argument): pool blocks in the
     // block's allocation order
     std::unordered_map<long long, std::vector<void*>> saved;

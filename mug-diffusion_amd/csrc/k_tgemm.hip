@@ -63,6 +63,33 @@ __global__ void tpack_weights_kernel(const float* src0, unsigned short* dst0, in
     }
 }
 
+// the same for a table of weight tensors: workgroup b packs elements [TPACK_CHUNK (b - chunk0), ...) of the entry whose chunk range holds b
+__global__ __launch_bounds__(256) void tpack_table_kernel(const TPackDesc* __restrict__ tab, int n) {
+    int lo = 0, hi = n - 1;
+    const long long b = blockIdx.x;
+    while (lo < hi) {                                   // last entry with chunk0 <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].chunk0 <= b) lo = mid; else hi = mid - 1;
+    }
+    const TPackDesc d = tab[lo];
+    const long long i0 = (b - d.chunk0) * TPACK_CHUNK, i1 = i0 + TPACK_CHUNK < d.total ? i0 + TPACK_CHUNK : d.total;
+    // a thread: the 8 consecutive k of one (tile, block, tap, lane) fragment -> one 16-byte store
+    for (long long f = (i0 >> 3) + threadIdx.x; f < (i1 >> 3); f += 256) {
+        const int lane = (int)(f & 63);
+        long long q = f >> 6;
+        const int tap = (int)(q % d.taps); q /= d.taps;
+        const int kb = (int)(q % d.nkb);
+        const int mt = (int)(q / d.nkb);
+        const int row = mt * 32 + (lane & 31), k0 = kb * 16 + 8 * (lane >> 5);
+        const float* s = d.src + (long long)row * d.s_row + (d.flip ? d.taps - 1 - tap : tap);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (row < d.rows_valid && k0 + j < d.K) ? s[(long long)(k0 + j) * d.s_k] : 0.f;
+        u32x4 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+        *reinterpret_cast<u32x4*>(d.dst + (f << 3)) = o;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // tconv
 // ---------------------------------------------------------------------------------------
@@ -528,10 +555,45 @@ __global__ void twgrad_reduce_kernel(const float* part, float* dW, long long n, 
     }
 }
 
+// the same for a table of reductions: workgroup b sums outputs [TREDUCE_CHUNK (b - chunk0), ...) of its entry, k ascending
+__global__ __launch_bounds__(256) void treduce_table_kernel(const TReduceDesc* __restrict__ tab, int n) {
+    int lo = 0, hi = n - 1;
+    const long long b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].chunk0 <= b) lo = mid; else hi = mid - 1;
+    }
+    const TReduceDesc d = tab[lo];
+    const long long i0 = (b - d.chunk0) * TREDUCE_CHUNK;
+#pragma unroll
+    for (int r = 0; r < TREDUCE_CHUNK / 256; ++r) {
+        const long long i = i0 + r * 256 + threadIdx.x;
+        if (i >= d.n) break;
+        if (d.is_double) {
+            const double* p = static_cast<const double*>(d.part) + i;
+            double v = 0.0;
+            for (int k = 0; k < d.KS; ++k) v += p[(size_t)k * d.n];
+            d.out[i] = (float)v;
+        } else {
+            const float* p = static_cast<const float*>(d.part) + i;
+            float v = 0.f;
+            for (int k = 0; k < d.KS; ++k) v += p[(size_t)k * d.n];
+            d.out[i] = v;
+        }
+    }
+}
+
 }  // namespace
 
 // 16-channel blocks of the packed form: a whole number of tconv stages (up to 8 blocks per stage for 1x1 layers, 4 for 3-tap ones)
 static int tpack_nkb(int K, int taps) { const int ksub = taps == 1 ? 8 : 4; return cdiv(cdiv(K, 16), ksub) * ksub; }      // the larger (NT = 1) stage; the NT = 2 stage divides it
+int tpack_blocks(int K, int taps) { return tpack_nkb(K, taps); }
+void launch_tpack_table(hipStream_t st, const TPackDesc* dev_table, int n, long long chunks) {
+    if (n > 0 && chunks > 0) hipLaunchKernelGGL(tpack_table_kernel, dim3((unsigned)chunks), dim3(256), 0, st, dev_table, n);
+}
+void launch_treduce_table(hipStream_t st, const TReduceDesc* dev_table, int n, long long chunks) {
+    if (n > 0 && chunks > 0) hipLaunchKernelGGL(treduce_table_kernel, dim3((unsigned)chunks), dim3(256), 0, st, dev_table, n);
+}
 size_t tpack_elems(int rows, int K, int taps) { return (size_t)cdiv(rows, 32) * tpack_nkb(K, taps) * taps * 512; }
 
 void launch_tpack_weights(hipStream_t st, const float* src, unsigned short* dst, int rows, int K, int taps, long long s_row, long long s_k, int flip) {
@@ -596,7 +658,7 @@ int twgrad_splits(int B, int M, int C, int Tout, int taps, int kt) {
 
 bool twgrad_fuses_bias(int taps) { return taps == 3; }
 
-void launch_twgrad_bf16(hipStream_t st, const TWgradArgs& a0, float* partial) {
+void launch_twgrad_bf16(hipStream_t st, const TWgradArgs& a0, float* partial, bool reduce) {
     TWgradArgs a = a0;
     MUGD_CHECK(a.taps == 1 || a.taps == 3, -2, "twgrad: taps must be 1 or 3");
     MUGD_CHECK(a.dil >= 1 && a.dil <= 8 && (a.stride == 1 || a.stride == 2), -2, "twgrad: dilation 1..8, stride 1 | 2");
@@ -629,7 +691,7 @@ void launch_twgrad_bf16(hipStream_t st, const TWgradArgs& a0, float* partial) {
         MUGD_TW(3, 32, false);
     }
 #undef MUGD_TW
-    if (a.KS > 1) {
+    if (a.KS > 1 && reduce) {
         const int nb = final_db ? a.M : 0;
         hipLaunchKernelGGL(twgrad_reduce_kernel, dim3((unsigned)std::min<long long>((nn + nb + 255) / 256, 4096)), dim3(256), 0, st, partial, final_dw, nn, a.KS,
                            a.db, final_db, nb);

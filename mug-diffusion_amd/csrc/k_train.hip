@@ -533,6 +533,9 @@ void launch_transpose_flip(hipStream_t st, const float* src, float* dst, int M, 
     const long long total = (long long)M * C * taps;
     hipLaunchKernelGGL(transpose_flip_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, st, src, dst, M, C, taps);
 }
+void launch_bias_grad_rows(hipStream_t st, const float* x, double* partial, int B, int M, int T) {
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(cdiv(M, 4), B), dim3(256), 0, st, x, partial, B, M, T);
+}
 void launch_bias_grad(hipStream_t st, const float* x, float* out, int B, int M, int T, int accumulate, double* partial) {
     hipLaunchKernelGGL(bias_grad_kernel, dim3(cdiv(M, 4), B), dim3(256), 0, st, x, partial, B, M, T);
     hipLaunchKernelGGL(batch_reduce_kernel, dim3(cdiv(M, 256)), dim3(256), 0, st, partial, out, B, M, accumulate);

@@ -313,6 +313,7 @@ void launch_transpose_flip(hipStream_t st, const float* src, float* dst, int M, 
 void launch_concat2(hipStream_t st, const float* a, const float* b, float* out, int B, int Ca, int Cb, int T);            // out = cat([a, b], dim = 1)
 void launch_split2(hipStream_t st, const float* src, float* a, float* b, int B, int Ca, int Cb, int T, int acc_a, int acc_b);   // a (+)= src[:, :Ca]; b (+)= src[:, Ca:]
 void launch_bias_grad(hipStream_t st, const float* x, float* out, int B, int M, int T, int accumulate, double* partial /* B * M */);
+void launch_bias_grad_rows(hipStream_t st, const float* x, double* partial /* [B][M] row sums */, int B, int M, int T);      // stage 1 only
 void launch_time_sum(hipStream_t st, const float* x, float* rows, int BM, int T);
 // conv weight gradient; KS = wgrad_splits(...) K-slices need a partial buffer of KS * M * C * taps floats (KS == 1: none)
 int wgrad_splits(int B, int M, int C, int Tout);
@@ -392,7 +393,17 @@ void launch_tconv_bf16(hipStream_t st, const TConvArgs& a);
 bool twgrad_big_tile(int B, int M, int C, int Tout);
 bool twgrad_fuses_bias(int taps);            // whether launch_twgrad_bf16 can also produce TWgradArgs::db for this tap count
 int twgrad_splits(int B, int M, int C, int Tout, int taps, int kt /* samples per slab: 64 for 1x1 layers, 32 for 3-tap ones */);
-void launch_twgrad_bf16(hipStream_t st, const TWgradArgs& a, float* partial /* KS * (M * C * taps + M) floats when KS > 1 */);
+// reduce = false (KS > 1): the partial slices stay unreduced (train.hip queues them for launch_treduce_table)
+void launch_twgrad_bf16(hipStream_t st, const TWgradArgs& a, float* partial /* KS * (M * C * taps + M) floats when KS > 1 */, bool reduce = true);
+
+// table-driven forms (the step bracket of train.hip): ONE launch for a whole list of weight packs / partial-sum reductions.  chunk0 = the
+// entry's first workgroup (prefix sums of cdiv(total, TPACK_CHUNK) / cdiv(n, TREDUCE_CHUNK)); a workgroup finds its entry by bisection
+struct TPackDesc { const float* src; unsigned short* dst; long long s_row, s_k, total, chunk0; int rows_valid, K, taps, flip, MT, nkb; };
+struct TReduceDesc { const void* part; float* out; long long n, chunk0; int KS, is_double; };      // out[i] = sum_{k < KS} part[k * n + i], k ascending
+constexpr int TPACK_CHUNK = 8192, TREDUCE_CHUNK = 1024;
+int tpack_blocks(int K, int taps);                           // 16-channel blocks of the packed form (padded to whole tconv stages)
+void launch_tpack_table(hipStream_t st, const TPackDesc* dev_table, int n, long long chunks);
+void launch_treduce_table(hipStream_t st, const TReduceDesc* dev_table, int n, long long chunks);
 
 void launch_adamw_chunks(hipStream_t st, const long long* desc, int nchunks, float lr, float b1, float b2, float eps, float wd, int step);
 void launch_embed_tokens(hipStream_t st, const float* table, const long long* ids, float* out, int B, int ntok, int dim);

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <exception>
 #include <vector>
 
@@ -33,10 +34,12 @@ int guarded(mugd_ctx* ctx, F&& f) {
 // may still be queued: the pool only serves this context, whose work is all on ONE stream, so the next user of a block is
 // ordered behind them
 struct Scratch {
+    mugd_ctx* ctx;
     TrainPool& pool;
     hipStream_t stream;
     std::vector<void*> bufs;
-    explicit Scratch(mugd_ctx* ctx) : pool(ctx->pool), stream(ctx->c.stream) {}
+    bool temp_weights = false;         // set around convs whose "weights" are call-scoped temporaries: never through the pack cache
+    explicit Scratch(mugd_ctx* ctx_) : ctx(ctx_), pool(ctx_->pool), stream(ctx_->c.stream) {}
     float* get(size_t nfloats, bool zero, hipStream_t st) {
         float* p = (float*)pool.take(nfloats * sizeof(float) + 8192);
         if (zero) HIP_CHECK(hipMemsetAsync(p, 0, nfloats * sizeof(float) + 8192, st));
@@ -106,6 +109,91 @@ struct ProfScope {
 };
 TrainProfile* g_tprof = nullptr;       // the active context's profile (one training context per process: set by mugd_train_profile)
 
+// ---- the step bracket (ctx.h: TrainStep) ---------------------------------------------------------------------------------------
+// bf16 A fragments of the (M, C, taps) weight tensor `w` (transposed: w is (C, M, taps), used flipped -- the data-gradient form).  Inside
+// the bracket they come from the cache (packed here only the first time a tensor is seen in a step); outside, from call scratch.
+const unsigned short* packed_weights(Scratch& sc, hipStream_t st, const float* w, int M, int C, int taps, bool transposed) {
+    // plain: A[m][ci][tap] = w[m][ci][tap];  transposed: A[m][ci][tap] = w[ci][m][taps - 1 - tap]
+    const long long s_row = transposed ? taps : (long long)C * taps, s_k = transposed ? (long long)M * taps : taps;
+    TrainStep& ts = sc.ctx->step;
+    if (!ts.on || sc.temp_weights) {
+        unsigned short* wpk = reinterpret_cast<unsigned short*>(sc.get((tpack_elems(M, C, taps) + 1) / 2, false, st));
+        launch_tpack_weights(st, w, wpk, M, C, taps, s_row, s_k, transposed ? 1 : 0);
+        return wpk;
+    }
+    const auto key = std::make_tuple(w, transposed ? 1 : 0, M, C, taps);
+    auto it = ts.index.find(key);
+    if (it == ts.index.end()) {
+        PackEntry e{};
+        e.src = w; e.rows = M; e.K = C; e.taps = taps; e.flip = transposed ? 1 : 0; e.s_row = s_row; e.s_k = s_k;
+        e.MT = cdiv(M, 32); e.nkb = tpack_blocks(C, taps); e.total = (long long)tpack_elems(M, C, taps);
+        HIP_CHECK(hipMalloc(&e.dst, (size_t)e.total * 2 + 8192));          // lives as long as the tensor keeps being used (step_begin drops it otherwise)
+        e.packed_epoch = -1;
+        ts.packs.push_back(e);
+        it = ts.index.emplace(key, (int)ts.packs.size() - 1).first;
+    }
+    PackEntry& e = ts.packs[it->second];
+    if (e.packed_epoch != ts.epoch) {                 // first sight of this tensor: from the next step on step_begin's table launch covers it
+        launch_tpack_weights(st, w, e.dst, M, C, taps, s_row, s_k, e.flip);
+        e.packed_epoch = ts.epoch;
+    }
+    e.used_epoch = ts.epoch;
+    return e.dst;
+}
+// queue out[i] = sum_{k < KS} part[k * n + i] for the bracket's table launch; `block` (the pool block holding part) stays taken until then
+void queue_reduce(mugd_ctx* ctx, void* block, const void* part, float* out, long long n, int KS, int is_double) {
+    TrainStep& ts = ctx->step;
+    if (block) ts.held.push_back(block);
+    ts.jobs.push_back(TReduceDesc{part, out, n, 0, KS, is_double});
+}
+void step_flush(mugd_ctx* ctx) {
+    TrainStep& ts = ctx->step;
+    hipStream_t st = ctx->c.stream;
+    if (!ts.jobs.empty()) {
+        long long chunks = 0;
+        for (auto& j : ts.jobs) { j.chunk0 = chunks; chunks += cdiv(j.n, (long long)TREDUCE_CHUNK); }
+        const void* tab = ts.ring.upload(ts.jobs.data(), ts.jobs.size() * sizeof(TReduceDesc), st);
+        launch_treduce_table(st, static_cast<const TReduceDesc*>(tab), (int)ts.jobs.size(), chunks);
+        ts.ring.mark(st);
+        ts.jobs.clear();
+    }
+    for (void* p : ts.held) ctx->pool.give(p);        // stream-ordered reuse: the next user of a block queues behind the reduction
+    ts.held.clear();
+}
+void step_begin(mugd_ctx* ctx) {
+    TrainStep& ts = ctx->step;
+    hipStream_t st = ctx->c.stream;
+    step_flush(ctx);                                  // an abandoned step's leftovers
+    ++ts.epoch;
+    ts.on = true;
+    if (const char* e = getenv("MUGD_NO_STEP_BRACKET")) { if (e[0] == '1') { ts.on = false; return; } }      // development / test knob: every call on its own
+    // tensors the previous step did not touch are gone from the model (or were never part of it): drop them
+    std::vector<PackEntry> keep;
+    for (auto& e : ts.packs) {
+        if (e.used_epoch >= ts.epoch - 1) keep.push_back(e); else hipFree(e.dst);
+    }
+    ts.packs.swap(keep);
+    ts.index.clear();
+    std::vector<TPackDesc> tab(ts.packs.size());
+    long long chunks = 0;
+    for (size_t i = 0; i < ts.packs.size(); ++i) {
+        PackEntry& e = ts.packs[i];
+        ts.index.emplace(std::make_tuple(e.src, e.flip, e.rows, e.K, e.taps), (int)i);
+        tab[i] = TPackDesc{e.src, e.dst, e.s_row, e.s_k, e.total, chunks, e.rows, e.K, e.taps, e.flip, e.MT, e.nkb};
+        chunks += cdiv(e.total, (long long)TPACK_CHUNK);
+        e.packed_epoch = ts.epoch;
+    }
+    if (!tab.empty()) {
+        const void* dev = ts.ring.upload(tab.data(), tab.size() * sizeof(TPackDesc), st);
+        launch_tpack_table(st, static_cast<const TPackDesc*>(dev), (int)tab.size(), chunks);
+        ts.ring.mark(st);
+    }
+}
+void step_end(mugd_ctx* ctx) {
+    step_flush(ctx);
+    ctx->step.on = false;
+}
+
 // y = conv1d(x; w) (+ bias) (+ rowadd[b][m]) (+ resid): w is a plain (M, C, taps) tensor, packed here.
 // wt_src (optional, with `transposed`): the conv runs on the transposed, tap-flipped form of the (C_of_x = rows of w, M = ..., taps)
 // tensor `w` -- the data gradient of a conv: x is the upstream gradient (B, Mw, T), the result has Cw channels.  fp32 mode packs from a
@@ -116,10 +204,7 @@ void run_conv_ex(Ctx& c, Scratch& sc, const float* x, const float* w, bool trans
     hipStream_t st = c.stream;
     ProfScope prof(g_tprof, st, 0, 2.0 * M * C * taps * (double)B * (Tout > 0 ? Tout : T));
     if (c.train_bf16) {
-        unsigned short* wpk = reinterpret_cast<unsigned short*>(sc.get((tpack_elems(M, C, taps) + 1) / 2, false, st));
-        // plain: A[m][ci][tap] = w[m][ci][tap];  transposed: w is (C, M, taps) and A[m][ci][tap] = w[ci][m][taps - 1 - tap]
-        if (transposed) launch_tpack_weights(st, w, wpk, M, C, taps, taps, (long long)M * taps, 1);
-        else launch_tpack_weights(st, w, wpk, M, C, taps, (long long)C * taps, taps, 0);
+        const unsigned short* wpk = packed_weights(sc, st, w, M, C, taps, transposed);
         TConvArgs a{};
         a.x = x; a.wpk = wpk; a.bias = bias; a.rowadd = rowadd; a.rowadd_stride = rowadd_stride; a.resid = resid; a.y = y;
         a.B = B; a.C = C; a.Tin = T; a.M = M; a.Tout = Tout > 0 ? Tout : T; a.taps = taps; a.dil = dil; a.stride = stride; a.pad = pad; a.ups = ups;
@@ -156,6 +241,12 @@ void run_dgrad(Ctx& c, Scratch& sc, const float* dy, const float* w, float* wt, 
 
 // weight gradient with split-K partials from the call's scratch
 void run_bias_grad(Ctx& c, Scratch& sc, const float* x, float* out, int B, int M, int T) {
+    if (sc.ctx->step.on) {                 // inside the step bracket: the sum over batch rows joins the step's table of reductions
+        double* part = static_cast<double*>(sc.pool.take((size_t)B * M * 8 + 8192));
+        launch_bias_grad_rows(c.stream, x, part, B, M, T);
+        queue_reduce(sc.ctx, part, part, out, M, B, 1);
+        return;
+    }
     double* part = reinterpret_cast<double*>(sc.get((size_t)B * M * 2, false, c.stream));
     launch_bias_grad(c.stream, x, out, B, M, T, 0, part);
 }
@@ -169,8 +260,16 @@ void run_wgrad(Ctx& c, Scratch& sc, const float* dY, const float* A, float* dW, 
         if (c.train_bf16) {
             const bool fuse = db && twgrad_fuses_bias(taps);
             TWgradArgs a{dY, A, dW, B, M, C, Tout, Tin, taps, pad, dil, stride, ups, twgrad_splits(B, M, C, Tout, taps, taps == 1 ? 64 : 32), fuse ? db : nullptr, (stride == 1 && twgrad_big_tile(B, M, C, Tout)) ? 1 : 0};
-            float* part = a.KS > 1 ? sc.get((size_t)a.KS * ((size_t)M * C * taps + M), false, c.stream) : nullptr;
-            launch_twgrad_bf16(c.stream, a, part);
+            const size_t nn = (size_t)M * C * taps;
+            if (a.KS > 1 && sc.ctx->step.on) {           // split-K slices stay in their pool block until the step's table of reductions runs
+                float* part = static_cast<float*>(sc.pool.take((size_t)a.KS * (nn + M) * 4 + 8192));
+                launch_twgrad_bf16(c.stream, a, part, false);
+                queue_reduce(sc.ctx, part, part, dW, (long long)nn, a.KS, 0);
+                if (fuse) queue_reduce(sc.ctx, nullptr, part + (size_t)a.KS * nn, db, M, a.KS, 0);
+            } else {
+                float* part = a.KS > 1 ? sc.get((size_t)a.KS * (nn + M), false, c.stream) : nullptr;
+                launch_twgrad_bf16(c.stream, a, part);
+            }
             if (fuse) return;
             fused_done = true;
         }
@@ -318,8 +417,10 @@ int mugd_train_conv(mugd_ctx* ctx, const float* w, const float* bias, const floa
             float* ev = sc.get((size_t)B * Cin * Tout, false, st);
             float* od = sc.get((size_t)B * Cin * Tout, false, st);
             launch_down_dgrad_weights(st, w, wt, wo, Cout, Cin);
+            sc.temp_weights = true;                   // wt / wo are this call's scratch
             run_conv(c, sc, dy, wt, nullptr, nullptr, 0, nullptr, ev, B, Cout, Tout, Cin, 3, 1);
             run_conv(c, sc, dy, wo, nullptr, nullptr, 0, nullptr, od, B, Cout, Tout, Cin, 1, 0);
+            sc.temp_weights = false;
             launch_interleave_parity(st, ev, da, (long long)B * Cin, Tout, 0);
             launch_interleave_parity(st, od, da, (long long)B * Cin, Tout, 1);
         } else {
@@ -550,6 +651,18 @@ int mugd_train_set_precision(mugd_ctx* ctx, int bf16) {
     if (!ctx) return MUGD_ERR_INVALID;
     ctx->c.train_bf16 = bf16 != 0;
     return MUGD_OK;
+}
+
+// The step bracket (ctx.h: TrainStep).  Between _begin and _end the caller must not change any weight tensor; weight / bias gradients of
+// the bf16 GEMMs are complete only after _flush or _end (ONE reduction launch for everything queued so far).
+int mugd_train_step_begin(mugd_ctx* ctx) {
+    return guarded(ctx, [&] { step_begin(ctx); });
+}
+int mugd_train_step_flush(mugd_ctx* ctx) {
+    return guarded(ctx, [&] { step_flush(ctx); });
+}
+int mugd_train_step_end(mugd_ctx* ctx) {
+    return guarded(ctx, [&] { step_end(ctx); });
 }
 
 // enable != 0: start (and clear) the GEMM profile; enable == 0 with out != NULL: stop, wait for the stream and report

@@ -88,6 +88,9 @@ _SIGS = {
     "mugd_train_release_states": [_p],
     "mugd_train_set_precision": [_p, _i],
     "mugd_train_profile": [_p, _i, C.POINTER(C.c_double)],
+    "mugd_train_step_begin": [_p],
+    "mugd_train_step_flush": [_p],
+    "mugd_train_step_end": [_p],
     "mugd_train_concat": [_p, _p, _p, _p, _i, _i, _i, _i],
     "mugd_train_split": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i],
     "mugd_train_add": [_p, _p, _p, _p, C.c_int64],
@@ -551,6 +554,17 @@ class Lib:
     def train_set_precision(self, bf16):
         """Training GEMMs on the bf16 matrix cores (fp32 accumulation; BASELINE configs[4]) instead of the fp32-input MFMA parity mode."""
         self.check(self.dll.mugd_train_set_precision(self.ctx, 1 if bf16 else 0))
+
+    def train_step_begin(self):
+        """Open the step bracket (include/mugd.h): weights must not change until train_step_end; packed bf16 weights come from a cache
+        refreshed here by one launch, weight / bias gradients are complete after train_step_flush / train_step_end."""
+        self.check(self.dll.mugd_train_step_begin(self.ctx))
+
+    def train_step_flush(self):
+        self.check(self.dll.mugd_train_step_flush(self.ctx))
+
+    def train_step_end(self):
+        self.check(self.dll.mugd_train_step_end(self.ctx))
 
     def train_profile(self, enable):
         """Event-bracket the training GEMM launches (True), or stop and return {'conv': {ms, flops, launches}, 'wgrad': {...}} (False)."""

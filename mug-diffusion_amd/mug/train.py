@@ -205,6 +205,7 @@ class BucketedAllReduce:
         self.open, self.open_bytes, self.inflight = [], 0, []
         self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.n_buckets = 0
+        self.before_launch = None            # TrainPlan.step: the library's queued gradient reductions run before a bucket is read
 
     def push(self, t):
         if not self.on:
@@ -217,6 +218,8 @@ class BucketedAllReduce:
     def _launch(self):
         if not self.open:
             return
+        if self.before_launch is not None:
+            self.before_launch()
         dev = self.open[0].device
         backend_dev = dev if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
         flat = torch.cat([t.reshape(-1).to(backend_dev) for t in self.open])
@@ -473,6 +476,11 @@ class TrainPlan:
         self.arena = FlatGrads(n_train, self.lib.device)
         self.packs = {}
         self.first = True
+        # the library's step bracket keys its packed-weight cache on tensor addresses: only when every parameter already lives on the
+        # library's device as contiguous fp32 (no per-call staging copies whose addresses could be recycled inside a step)
+        dev = torch.device(self.lib.device)
+        self.bracket = all(v.device.type == dev.type and v.dtype == torch.float32 and v.is_contiguous()
+                           for k, v in sd.items() if torch.is_tensor(v) and v.is_floating_point() and k.startswith("model.") and not k.startswith("model.first_stage_model."))
 
     def step(self, x0, noise, t, ids, mel, beta=0.02, add=0.01, reducer=None):
         lib = self.lib
@@ -482,10 +490,20 @@ class TrainPlan:
                 self.arena.buf.zero_()                # packs hold views of the arena: clear it, keep the layout
             self.first = False
             lib.grad_arena = self.arena
+            # the step bracket: no parameter changes until step_end, so packed weights come from the library's cache (one refresh launch
+            # here) and the split-K / bias-row reductions of the weight gradients run as one launch per flush
+            if self.bracket:
+                lib.train_step_begin()
+                if reducer is not None:
+                    reducer.before_launch = lib.train_step_flush
             try:
                 return _training_step(lib, self.sd, self.unet_cfg, self.wave_cfg, x0, noise, t, ids, mel, beta, add, reducer, self.recompute,
                                       _Grads(reducer), self.packs)
             finally:
+                if self.bracket:
+                    lib.train_step_end()
+                if reducer is not None:
+                    reducer.before_launch = None
                 lib.grad_arena = None
 
 

@@ -68,6 +68,8 @@ hipError_t hipDeviceGetAttribute(int*, hipDeviceAttribute_t, int);
 hipError_t hipMalloc(void**, size_t);
 template <class T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
 hipError_t hipFree(void*);
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+static inline hipError_t hipHostFree(void* p) { return hipFree(p); }
 hipError_t hipMemcpy(void*, const void*, size_t, hipMemcpyKind);
 hipError_t hipMemcpyAsync(void*, const void*, size_t, hipMemcpyKind, hipStream_t);
 hipError_t hipMemset(void*, int, size_t);

@@ -347,6 +347,43 @@ def test_adamw_step_matches_torch(lib):
         close(p, pt, 2e-6, "parameters after step %d" % step)
 
 
+def test_step_bracket_changes_nothing_over_two_steps(lib, monkeypatch):
+    """TrainPlan.step inside the library's step bracket (packed bf16 weights from the cache -- refreshed by ONE table launch from the
+    second step on -- and all split-K / bias-row reductions as ONE table launch) against the same two steps with every call packing
+    and reducing on its own (MUGD_NO_STEP_BRACKET=1): loss and every gradient bit-identical, with an AdamW update between the steps so
+    that the second step's cache refresh has new values to pick up."""
+    from oracle import cases
+    from mug import train
+    case, z, B = cases.TINY, 32, 2
+    g, sd0, seed, batch = _load_train_fixture(case, z, B)
+    t, noise = torch.from_numpy(g["t"]), torch.from_numpy(g["noise"])
+    dev = lib.device
+
+    def two_steps(no_bracket):
+        monkeypatch.setenv("MUGD_NO_STEP_BRACKET", "1" if no_bracket else "0")
+        sd = {k: (v.clone().to(dev) if torch.is_tensor(v) else v) for k, v in sd0.items()}
+        x0 = train.encode_x0(lib, sd, case["vae"], batch["note"])
+        plan = train.TrainPlan(lib, sd, case["unet"], case["wave"])
+        assert plan.bracket
+        ids, mel = batch["feature"].long().to(dev), batch["audio"].to(dev)
+        loss1, grads = plan.step(x0, noise.to(dev), t.to(dev), ids, mel)
+        opt = train.AdamW(lib, sd, grads, lr=1e-3)
+        opt.step()
+        loss2, grads = plan.step(x0, noise.to(dev), t.to(dev), ids, mel)
+        return float(loss1), float(loss2), {k: v.clone().cpu() for k, v in grads.items()}
+
+    lib.train_set_precision(True)
+    try:
+        a1, a2, ga = two_steps(False)
+        b1, b2, gb = two_steps(True)
+    finally:
+        lib.train_set_precision(False)
+    assert a1 == b1 and a2 == b2 and a1 != a2, (a1, b1, a2, b2)
+    assert set(ga) == set(gb)
+    bad = [k for k in ga if not torch.equal(ga[k], gb[k])]
+    assert not bad, bad[:5]
+
+
 def test_fused_adamw_over_a_tensor_list_matches_torch(lib):
     """mug.train.AdamW: the whole parameter list in ONE launch (mugd_train_adamw_chunks: tensors cut into runs of <= 4096 elements) against
     torch.optim.AdamW, three steps, tensors below / at / above the run length and of odd sizes."""
