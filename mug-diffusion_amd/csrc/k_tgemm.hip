@@ -569,7 +569,13 @@ __global__ __launch_bounds__(256) void treduce_table_kernel(const TReduceDesc* _
     for (int r = 0; r < TREDUCE_CHUNK / 256; ++r) {
         const long long i = i0 + r * 256 + threadIdx.x;
         if (i >= d.n) break;
-        if (d.is_double) {
+        if (d.kind == 2) {
+            const double* p = static_cast<const double*>(d.part) + 2 * i;
+            double v = 0.0, w = 0.0;
+            for (int k = 0; k < d.KS; ++k) { v += p[(size_t)k * d.n * 2]; w += p[(size_t)k * d.n * 2 + 1]; }
+            d.out[i] = (float)v;
+            d.out2[i] = (float)w;
+        } else if (d.kind == 1) {
             const double* p = static_cast<const double*>(d.part) + i;
             double v = 0.0;
             for (int k = 0; k < d.KS; ++k) v += p[(size_t)k * d.n];

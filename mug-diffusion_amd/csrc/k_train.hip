@@ -304,13 +304,14 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 
 template <bool SILU, bool VEC4>
 __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float* x, const float* da, const float* gamma, const float* beta, float eps,
-                                                          float* dx, double* part, int B, int C, int T, int groups, int accumulate) {
+                                                          float* dx, double* part, int B, int C, int T, int groups, const float* resid) {
     __shared__ double red[4][4];
     const int g = blockIdx.x, b = blockIdx.y, cg = C / groups, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const double n = (double)cg * (double)T;
     const float* xg = x + ((size_t)b * C + (size_t)g * cg) * T;
     const float* ag = da + ((size_t)b * C + (size_t)g * cg) * T;
     float* dg = dx + ((size_t)b * C + (size_t)g * cg) * T;
+    const float* rg = resid ? resid + ((size_t)b * C + (size_t)g * cg) * T : nullptr;      // added to dx (may be dx itself: read before the write)
     const int T4 = T >> 2;
     // ---- pass A: group statistics
     double s1 = 0.0, s2 = 0.0;
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float* x, const 
                 elem(xv.y, av.y, gm, bt, xh, du); r.y = rstd * (du * gm - fm1 - xh * fm2);
                 elem(xv.z, av.z, gm, bt, xh, du); r.z = rstd * (du * gm - fm1 - xh * fm2);
                 elem(xv.w, av.w, gm, bt, xh, du); r.w = rstd * (du * gm - fm1 - xh * fm2);
-                if (accumulate) { const float4 old = o4[t]; r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w; }
+                if (rg) { const float4 old = reinterpret_cast<const float4*>(rg + (size_t)c * T)[t]; r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w; }
                 o4[t] = r;
             }
         } else {
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float* x, const 
                 float xh, du;
                 elem(p[t], q[t], gm, bt, xh, du);
                 const float v = rstd * (du * gm - fm1 - xh * fm2);
-                o[t] = accumulate ? o[t] + v : v;
+                o[t] = rg ? rg[(size_t)c * T + t] + v : v;
             }
         }
     }
@@ -574,13 +575,16 @@ void launch_pair_sum(hipStream_t st, const float* src, float* dst, long long n) 
     hipLaunchKernelGGL(pair_sum_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 8192)), dim3(256), 0, st, src, dst, n);
 }
 void launch_gn_bwd(hipStream_t st, const float* x, const float* da, const float* gamma, const float* beta, float eps, float* dx,
-                   float* dgamma, float* dbeta, int B, int C, int T, int groups, int accumulate, int silu, double* partial) {
+                   float* dgamma, float* dbeta, int B, int C, int T, int groups, const float* resid, int silu, double* partial, bool reduce_params) {
     MUGD_CHECK(C % groups == 0, -2, "gn_bwd: channels not divisible by groups");
-#define MUGD_GNB(S, V) hipLaunchKernelGGL((gn_silu_bwd_kernel<S, V>), dim3(groups, B), dim3(256), 0, st, x, da, gamma, beta, eps, dx, partial, B, C, T, groups, accumulate)
+#define MUGD_GNB(S, V) hipLaunchKernelGGL((gn_silu_bwd_kernel<S, V>), dim3(groups, B), dim3(256), 0, st, x, da, gamma, beta, eps, dx, partial, B, C, T, groups, resid)
     if (T % 4 == 0) { if (silu) MUGD_GNB(true, true); else MUGD_GNB(false, true); }
     else { if (silu) MUGD_GNB(true, false); else MUGD_GNB(false, false); }
 #undef MUGD_GNB
-    hipLaunchKernelGGL(gn_param_reduce_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, partial, dgamma, dbeta, B, C);
+    if (reduce_params) hipLaunchKernelGGL(gn_param_reduce_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, partial, dgamma, dbeta, B, C);
+}
+void launch_pair_reduce(hipStream_t st, const double* part, float* out0, float* out1, int KS, int n) {
+    hipLaunchKernelGGL(gn_param_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, part, out0, out1, KS, n);
 }
 void launch_emb_linear_bwd(hipStream_t st, const float* e, const float* We, const float* dE, float* dWe, float* dbe, float* de, int B, int K, int M) {
     const int rb = cdiv(M, 4);

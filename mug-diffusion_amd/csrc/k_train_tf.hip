@@ -81,6 +81,84 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* x, const float
     }
 }
 
+// The same with the column's channels held in registers (C <= 16 NCH): x, dy and gamma are read ONCE (all loads of a thread in flight
+// together; the three-pass form above re-reads x three times and dy twice behind two workgroup reductions), and the parameter gradients
+// come out of the same registers: per workgroup the 16-column sums of dy xhat / dy (a DPP row sum: tid = 16 prt + col puts a channel's
+// 16 columns in one 16-lane row) go to part[workgroup][c][2] in fp64; gn_param_reduce / the step's reduction table sums them over the
+// workgroups in fixed order.  dx is bit-identical to the three-pass form (same fp64 sums in the same order).
+__device__ __forceinline__ float row16_sum(float v) {          // sum over the 16 lanes of a DPP row, in every lane of the row
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));      // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_reg_kernel(const float* x, const float* dy, const float* gamma, float eps, float* dx, double* part,
+                                                         int B, int C, int T, int accumulate) {
+    __shared__ double red[2][LNB_PARTS][LNB_COLS + 1];
+    const int col = threadIdx.x % LNB_COLS, prt = threadIdx.x / LNB_COLS;
+    const int t = blockIdx.x * LNB_COLS + col, b = blockIdx.y;
+    const bool ok = t < T;
+    const int tc = ok ? t : T - 1;
+    const float* xb = x + (size_t)b * C * T + tc;
+    const float* db = dy + (size_t)b * C * T + tc;
+    float xv[NCH], dv[NCH], gm[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {                  // unconditional clamped loads, masked below
+        const int c = prt + LNB_PARTS * i, cc = c < C ? c : C - 1;
+        xv[i] = xb[(size_t)cc * T]; dv[i] = db[(size_t)cc * T]; gm[i] = gamma[cc];
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+        if (prt + LNB_PARTS * i >= C) { xv[i] = 0.f; dv[i] = 0.f; gm[i] = 0.f; }
+    auto colsum = [&](double v, int which) {
+        red[which][prt][col] = v;
+        __syncthreads();
+        double s = 0.0;
+#pragma unroll
+        for (int p = 0; p < LNB_PARTS; ++p) s += red[which][p][col];
+        return s;
+    };
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) { const double v = xv[i]; s1 += v; s2 += v * v; }
+    s1 = colsum(s1, 0);
+    s2 = colsum(s2, 1);
+    __syncthreads();
+    const double mean = s1 / (double)C;
+    double var = s2 / (double)C - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps)), mu = (float)mean;
+    double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        xv[i] = (xv[i] - mu) * rstd;                 // xhat from here on
+        const float gd = gm[i] * dv[i];
+        a1 += (double)gd; a2 += (double)gd * (double)xv[i];
+    }
+    a1 = colsum(a1, 0);
+    a2 = colsum(a2, 1);
+    const float m1 = (float)(a1 / (double)C), m2 = (float)(a2 / (double)C);
+    float* ob = dx + (size_t)b * C * T + tc;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = prt + LNB_PARTS * i;
+        if (ok && c < C) {
+            const float v = rstd * (gm[i] * dv[i] - m1 - xv[i] * m2);
+            ob[(size_t)c * T] = accumulate ? ob[(size_t)c * T] + v : v;
+        }
+    }
+    double* pw = part + 2 * ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * C);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = prt + LNB_PARTS * i;
+        const float d = ok ? dv[i] : 0.f;            // columns past T contribute nothing
+        const float pg = row16_sum(d * xv[i]), pb = row16_sum(d);
+        if (col == 0 && c < C) { pw[2 * c] = (double)pg; pw[2 * c + 1] = (double)pb; }
+    }
+}
+
 // dgamma[c] = sum_{b,t} dy xhat ; dbeta[c] = sum_{b,t} dy.  One wave per channel, fp64.
 __global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* x, const float* dy, const float* stat, float* dgamma, float* dbeta,
                                                             int B, int C, int T) {
@@ -404,10 +482,27 @@ __global__ void attn_tables_reduce_kernel(const double* part, float* drel, float
 
 }  // namespace
 
-void launch_ln_bwd(hipStream_t st, const float* x, const float* dy, const float* gamma, float eps, float* dx, float* stat, float* dgamma,
-                   float* dbeta, int B, int C, int T, int accumulate) {
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(T, LNB_COLS), B), dim3(256), 0, st, x, dy, gamma, eps, dx, stat, B, C, T, accumulate);
+size_t ln_bwd_scratch_bytes(int B, int C, int T) {
+    return std::max((size_t)B * T * 2 * sizeof(float), (size_t)B * cdiv(T, LNB_COLS) * C * 2 * sizeof(double));
+}
+int launch_ln_bwd(hipStream_t st, const float* x, const float* dy, const float* gamma, float eps, float* dx, void* scratch, float* dgamma,
+                  float* dbeta, int B, int C, int T, int accumulate, bool reduce_params) {
+    const dim3 grid(cdiv(T, LNB_COLS), B);
+    if (C <= 16 * 32) {                    // channels through registers, parameter gradients from the same pass
+        double* part = static_cast<double*>(scratch);
+        if (C <= 128) hipLaunchKernelGGL(ln_bwd_reg_kernel<8>, grid, dim3(256), 0, st, x, dy, gamma, eps, dx, part, B, C, T, accumulate);
+        else if (C <= 256) hipLaunchKernelGGL(ln_bwd_reg_kernel<16>, grid, dim3(256), 0, st, x, dy, gamma, eps, dx, part, B, C, T, accumulate);
+        else if (C <= 384) hipLaunchKernelGGL(ln_bwd_reg_kernel<24>, grid, dim3(256), 0, st, x, dy, gamma, eps, dx, part, B, C, T, accumulate);
+        else hipLaunchKernelGGL(ln_bwd_reg_kernel<32>, grid, dim3(256), 0, st, x, dy, gamma, eps, dx, part, B, C, T, accumulate);
+        const int nwg = (int)(grid.x * grid.y);
+        if (!reduce_params) return nwg;
+        launch_pair_reduce(st, part, dgamma, dbeta, nwg, C);
+        return 0;
+    }
+    float* stat = static_cast<float*>(scratch);
+    hipLaunchKernelGGL(ln_bwd_kernel, grid, dim3(256), 0, st, x, dy, gamma, eps, dx, stat, B, C, T, accumulate);
     hipLaunchKernelGGL(ln_param_grad_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, x, dy, stat, dgamma, dbeta, B, C, T);
+    return 0;
 }
 void launch_geglu_fwd(hipStream_t st, const float* u, float* f, int B, int Ch, int T) {
     const long long n = (long long)B * Ch * T;

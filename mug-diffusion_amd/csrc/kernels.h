@@ -322,12 +322,20 @@ void launch_wgrad_ex(hipStream_t st, const float* dY, const float* A, float* dW,
 void launch_down_dgrad_weights(hipStream_t st, const float* w, float* ev, float* od, int M, int C);
 void launch_interleave_parity(hipStream_t st, const float* src, float* dst, long long rows, int T, int par);
 void launch_pair_sum(hipStream_t st, const float* src, float* dst, long long n);
-// GroupNorm backward with (silu = 1) or without (0) the SiLU that follows it
+// GroupNorm backward with (silu = 1) or without (0) the SiLU that follows it; resid (nullable, may be dx): added to dx (an identity skip's
+// gradient, or accumulation).  reduce_params = false: dgamma / dbeta stay as the per-batch-row fp64 pairs in `partial` ([b][c][2]) for a
+// later reduction (TReduceDesc kind 2)
 void launch_gn_bwd(hipStream_t st, const float* x, const float* da, const float* gamma, const float* beta, float eps, float* dx,
-                   float* dgamma, float* dbeta, int B, int C, int T, int groups, int accumulate, int silu, double* partial /* B * C * 2 */);
+                   float* dgamma, float* dbeta, int B, int C, int T, int groups, const float* resid, int silu, double* partial /* B * C * 2 */,
+                   bool reduce_params = true);
 // k_train_tf.hip: LayerNorm over channels (stat: (B, T, 2) scratch), GEGLU, relative-position attention
-void launch_ln_bwd(hipStream_t st, const float* x, const float* dy, const float* gamma, float eps, float* dx, float* stat, float* dgamma,
-                   float* dbeta, int B, int C, int T, int accumulate);
+// scratch: ln_bwd_scratch_bytes().  reduce_params = false: when the return value KS is > 0, dgamma / dbeta are left as KS fp64 pair rows
+// in scratch ([k][c][2]; TReduceDesc kind 2 / launch_pair_reduce), 0: they are final
+size_t ln_bwd_scratch_bytes(int B, int C, int T);
+int launch_ln_bwd(hipStream_t st, const float* x, const float* dy, const float* gamma, float eps, float* dx, void* scratch, float* dgamma,
+                  float* dbeta, int B, int C, int T, int accumulate, bool reduce_params = true);
+// out0[i] = sum_k part[2 (k n + i)], out1[i] = sum_k part[2 (k n + i) + 1], k ascending (fp64 pair rows: GroupNorm / LayerNorm parameter gradients)
+void launch_pair_reduce(hipStream_t st, const double* part, float* out0, float* out1, int KS, int n);
 void launch_geglu_fwd(hipStream_t st, const float* u, float* f, int B, int Ch, int T);
 void launch_geglu_bwd(hipStream_t st, const float* u, const float* df, float* du, int B, int Ch, int T);
 struct AttnBwdArgs {         // layouts as AttnArgs; dout = gradient of the attention output
@@ -399,7 +407,9 @@ void launch_twgrad_bf16(hipStream_t st, const TWgradArgs& a, float* partial /* K
 // table-driven forms (the step bracket of train.hip): ONE launch for a whole list of weight packs / partial-sum reductions.  chunk0 = the
 // entry's first workgroup (prefix sums of cdiv(total, TPACK_CHUNK) / cdiv(n, TREDUCE_CHUNK)); a workgroup finds its entry by bisection
 struct TPackDesc { const float* src; unsigned short* dst; long long s_row, s_k, total, chunk0; int rows_valid, K, taps, flip, MT, nkb; };
-struct TReduceDesc { const void* part; float* out; long long n, chunk0; int KS, is_double; };      // out[i] = sum_{k < KS} part[k * n + i], k ascending
+// kind 0: float partials, out[i] = sum_{k < KS} part[k * n + i] (k ascending);  1: the same over fp64 partials;
+// 2: fp64 pairs, out[i] = sum_k part[2 (k * n + i)], out2[i] = sum_k part[2 (k * n + i) + 1]   (GroupNorm's dgamma / dbeta rows)
+struct TReduceDesc { const void* part; float* out; float* out2; long long n, chunk0; int KS, kind; };
 constexpr int TPACK_CHUNK = 8192, TREDUCE_CHUNK = 1024;
 int tpack_blocks(int K, int taps);                           // 16-channel blocks of the packed form (padded to whole tconv stages)
 void launch_tpack_table(hipStream_t st, const TPackDesc* dev_table, int n, long long chunks);

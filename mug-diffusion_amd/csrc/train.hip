@@ -141,10 +141,10 @@ const unsigned short* packed_weights(Scratch& sc, hipStream_t st, const float* w
     return e.dst;
 }
 // queue out[i] = sum_{k < KS} part[k * n + i] for the bracket's table launch; `block` (the pool block holding part) stays taken until then
-void queue_reduce(mugd_ctx* ctx, void* block, const void* part, float* out, long long n, int KS, int is_double) {
+void queue_reduce(mugd_ctx* ctx, void* block, const void* part, float* out, long long n, int KS, int kind, float* out2 = nullptr) {
     TrainStep& ts = ctx->step;
     if (block) ts.held.push_back(block);
-    ts.jobs.push_back(TReduceDesc{part, out, n, 0, KS, is_double});
+    ts.jobs.push_back(TReduceDesc{part, out, out2, n, 0, KS, kind});
 }
 void step_flush(mugd_ctx* ctx) {
     TrainStep& ts = ctx->step;
@@ -283,9 +283,15 @@ void run_wgrad(Ctx& c, Scratch& sc, const float* dY, const float* A, float* dW, 
 }
 
 void run_gn_bwd(Ctx& c, Scratch& sc, const float* x, const float* da, const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta,
-                int B, int C, int T, int groups, int silu) {
+                int B, int C, int T, int groups, int silu, const float* resid = nullptr) {
+    if (sc.ctx->step.on) {                 // the sum over batch rows of the dgamma / dbeta pairs joins the step's table of reductions
+        double* part = static_cast<double*>(sc.pool.take((size_t)B * C * 16 + 8192));
+        launch_gn_bwd(c.stream, x, da, gamma, beta, 1e-6f, dx, dgamma, dbeta, B, C, T, groups, resid, silu, part, false);
+        queue_reduce(sc.ctx, part, part, dgamma, C, B, 2, dbeta);
+        return;
+    }
     double* part = reinterpret_cast<double*>(sc.get((size_t)B * C * 4, false, c.stream));
-    launch_gn_bwd(c.stream, x, da, gamma, beta, 1e-6f, dx, dgamma, dbeta, B, C, T, groups, 0, silu, part);
+    launch_gn_bwd(c.stream, x, da, gamma, beta, 1e-6f, dx, dgamma, dbeta, B, C, T, groups, resid, silu, part);
 }
 
 void run_group_norm_silu(Ctx& c, const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T, int groups) {
@@ -366,12 +372,10 @@ void resblock_impl(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x,
         }
         run_wgrad(c, sc, dh, a1, g->conv1_w, B, Cout, Cin, T, T, 3, d1, d1, 1, 0, g->conv1_b);
         run_dgrad(c, sc, dh, p->conv1_w, wt, nullptr, da1, B, Cout, Cin, T, 3, d1, d1);
-        run_gn_bwd(c, sc, x, da1, p->gn1_w, p->gn1_b, dx, g->gn1_w, g->gn1_b, B, Cin, T, groups, 1);
+        run_gn_bwd(c, sc, x, da1, p->gn1_w, p->gn1_b, dx, g->gn1_w, g->gn1_b, B, Cin, T, groups, 1, p->skip_w ? nullptr : dy);      // identity skip: dx += dy
         if (p->skip_w) {
             run_wgrad(c, sc, dy, x, g->skip_w, B, Cout, Cin, T, T, 1, 0, 1, 1, 0, g->skip_b);
             run_dgrad(c, sc, dy, p->skip_w, wt, dx, dx, B, Cout, Cin, T, 1, 0);
-        } else {
-            launch_bias_sum(st, dx, dy, dx, (int)nin);          // dx += dy
         }
     }
 }
@@ -469,8 +473,7 @@ int mugd_train_s4layer(mugd_ctx* ctx, const float* const* P, const float* x, con
         S4GenBwdArgs gb{P[MUGD_S4_K_C], P[MUGD_S4_K_B], P[MUGD_S4_K_P], P[MUGD_S4_K_INV_W_REAL], P[MUGD_S4_K_W_IMAG], P[MUGD_S4_K_LOG_DT], H, N, Lint, T, dk,
                         G[MUGD_S4_K_C], G[MUGD_S4_K_B], G[MUGD_S4_K_P], G[MUGD_S4_K_INV_W_REAL], G[MUGD_S4_K_W_IMAG], G[MUGD_S4_K_LOG_DT], c.s4_symmetric ? 1 : 0};
         launch_s4_kernel_gen_bwd(st, gb);
-        run_gn_bwd(c, sc, x, dn, P[MUGD_S4_NORM_W], P[MUGD_S4_NORM_B], dx, G[MUGD_S4_NORM_W], G[MUGD_S4_NORM_B], B, H, T, groups, 0);
-        launch_bias_sum(st, dx, dy, dx, (int)n);          // + the identity skip
+        run_gn_bwd(c, sc, x, dn, P[MUGD_S4_NORM_W], P[MUGD_S4_NORM_B], dx, G[MUGD_S4_NORM_W], G[MUGD_S4_NORM_B], B, H, T, groups, 0, dy);      // + the identity skip
     });
 }
 
@@ -528,7 +531,18 @@ int mugd_train_transformer(mugd_ctx* ctx, const float* const* P, const float* x,
         // ---- backward
         const size_t wmax = (size_t)2 * Ch * C;
         float* wt = buf(wmax);
-        float* stat = buf((size_t)B * T * 2);
+        // LayerNorm backward: inside the step bracket the per-workgroup parameter-gradient rows wait for the step's reduction table
+        auto ln_bwd = [&](const float* xin, const float* dyin, const float* gamma, float* dxo, float* dgam, float* dbet) {
+            const size_t bytes = ln_bwd_scratch_bytes(B, C, T);
+            if (ctx->step.on) {
+                void* blk = ctx->pool.take(bytes + 8192);
+                const int ks = launch_ln_bwd(st, xin, dyin, gamma, 1e-5f, dxo, blk, dgam, dbet, B, C, T, 1, false);
+                if (ks > 0) queue_reduce(ctx, blk, blk, dgam, C, ks, 2, dbet);
+                else ctx->step.held.push_back(blk);
+            } else {
+                launch_ln_bwd(st, xin, dyin, gamma, 1e-5f, dxo, buf((bytes + 3) / 4), dgam, dbet, B, C, T, 1);
+            }
+        };
         float *dh = buf(n), *da = buf(n), *dq = buf(n), *dk = buf(std::max(n, nk)), *dv = buf(std::max(n, nk)), *dl = buf(n);      // dk / dv serve both attentions
         float *df = buf((size_t)B * Ch * T), *du = buf(2 * (size_t)B * Ch * T);
         const size_t nm = (size_t)B * heads * T * std::max(T, Tk);
@@ -566,7 +580,7 @@ int mugd_train_transformer(mugd_ctx* ctx, const float* const* P, const float* x,
         lt.bwd(f, P[MUGD_TF_FF2_W], dh, df, false, G[MUGD_TF_FF2_W], G[MUGD_TF_FF2_B], Ch, C, wt);
         launch_geglu_bwd(st, u, df, du, B, Ch, T);
         lt.bwd(l3, P[MUGD_TF_FF0_W], du, dl, false, G[MUGD_TF_FF0_W], G[MUGD_TF_FF0_B], C, 2 * Ch, wt);
-        launch_ln_bwd(st, h2, dl, P[MUGD_TF_LN3_W], 1e-5f, dh, stat, G[MUGD_TF_LN3_W], G[MUGD_TF_LN3_B], B, C, T, 1);      // dh = d h2
+        ln_bwd(h2, dl, P[MUGD_TF_LN3_W], dh, G[MUGD_TF_LN3_W], G[MUGD_TF_LN3_B]);      // dh = d h2
         // attn2: h2 = Wo2 o2 + bo2 + h1
         lt.bwd(o2, P[MUGD_TF_A2_OUT_W], dh, da, false, G[MUGD_TF_A2_OUT_W], G[MUGD_TF_A2_OUT_B], C, C, wt);
         attn_bwd(q2, k2, v2, da, Tk, MUGD_TF_A2_REL, MUGD_TF_A2_CEMB);
@@ -578,18 +592,17 @@ int mugd_train_transformer(mugd_ctx* ctx, const float* const* P, const float* x,
             lt.bwd(l2, P[MUGD_TF_A2_K], dk, dl, true, G[MUGD_TF_A2_K], nullptr, C, C, wt);
             lt.bwd(l2, P[MUGD_TF_A2_V], dv, dl, true, G[MUGD_TF_A2_V], nullptr, C, C, wt);
         }
-        launch_ln_bwd(st, h1, dl, P[MUGD_TF_LN2_W], 1e-5f, dh, stat, G[MUGD_TF_LN2_W], G[MUGD_TF_LN2_B], B, C, T, 1);      // dh = d h1
+        ln_bwd(h1, dl, P[MUGD_TF_LN2_W], dh, G[MUGD_TF_LN2_W], G[MUGD_TF_LN2_B]);      // dh = d h1
         // attn1: h1 = Wo o1 + bo + h0
         lt.bwd(o1, P[MUGD_TF_A1_OUT_W], dh, da, false, G[MUGD_TF_A1_OUT_W], G[MUGD_TF_A1_OUT_B], C, C, wt);
         attn_bwd(q1, k1, v1, da, T, MUGD_TF_A1_REL, MUGD_TF_A1_CEMB);
         lt.bwd(l1, P[MUGD_TF_A1_Q], dq, dl, false, G[MUGD_TF_A1_Q], nullptr, C, C, wt);
         lt.bwd(l1, P[MUGD_TF_A1_K], dk, dl, true, G[MUGD_TF_A1_K], nullptr, C, C, wt);
         lt.bwd(l1, P[MUGD_TF_A1_V], dv, dl, true, G[MUGD_TF_A1_V], nullptr, C, C, wt);
-        launch_ln_bwd(st, h0, dl, P[MUGD_TF_LN1_W], 1e-5f, dh, stat, G[MUGD_TF_LN1_W], G[MUGD_TF_LN1_B], B, C, T, 1);      // dh = d h0
+        ln_bwd(h0, dl, P[MUGD_TF_LN1_W], dh, G[MUGD_TF_LN1_W], G[MUGD_TF_LN1_B]);      // dh = d h0
         // proj_in and the GroupNorm in front of it
         lt.bwd(n0, P[MUGD_TF_PROJ_IN_W], dh, da, false, G[MUGD_TF_PROJ_IN_W], G[MUGD_TF_PROJ_IN_B], C, C, wt);
-        run_gn_bwd(c, sc, x, da, P[MUGD_TF_NORM_W], P[MUGD_TF_NORM_B], dx, G[MUGD_TF_NORM_W], G[MUGD_TF_NORM_B], B, C, T, groups, 0);
-        launch_bias_sum(st, dx, dy, dx, (int)n);          // + the identity skip
+        run_gn_bwd(c, sc, x, da, P[MUGD_TF_NORM_W], P[MUGD_TF_NORM_B], dx, G[MUGD_TF_NORM_W], G[MUGD_TF_NORM_B], B, C, T, groups, 0, dy);      // + the identity skip
     });
 }
 

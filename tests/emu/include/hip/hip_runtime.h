@@ -122,6 +122,14 @@ static inline void __builtin_amdgcn_wave_barrier_emu() { emu::wave_barrier(); }
 #define __builtin_amdgcn_sched_group_barrier(m, n, id) ((void)0)
 #define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_amdgcn_readfirstlane(x) (x)
+// DPP row rotate (ctrl 0x121..0x12f = row_ror:1..15): lane i of a 16-lane row reads lane (i - n) mod 16 of the same row
+static inline int emu_update_dpp(int src, int ctrl) {
+    const int lane = emu::lane_id(), n = ctrl - 0x120;
+    float f; std::memcpy(&f, &src, 4);
+    f = emu::wave_xchg(f, (lane & ~15) | ((lane - n) & 15));
+    int r; std::memcpy(&r, &f, 4); return r;
+}
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu_update_dpp((src), (ctrl))
 
 static inline float __shfl_xor(float v, int mask, int width = 64) { (void)width; return emu::wave_xchg(v, emu::lane_id() ^ mask); }
 static inline float __shfl_down(float v, unsigned d, int width = 64) {
