@@ -572,6 +572,7 @@ __global__ __launch_bounds__(256) void treduce_table_kernel(const TReduceDesc* _
         if (d.kind == 2) {
             const double* p = static_cast<const double*>(d.part) + 2 * i;
             double v = 0.0, w = 0.0;
+#pragma unroll 8
             for (int k = 0; k < d.KS; ++k) { v += p[(size_t)k * d.n * 2]; w += p[(size_t)k * d.n * 2 + 1]; }
             d.out[i] = (float)v;
             d.out2[i] = (float)w;
@@ -583,6 +584,7 @@ __global__ __launch_bounds__(256) void treduce_table_kernel(const TReduceDesc* _
         } else {
             const float* p = static_cast<const float*>(d.part) + i;
             float v = 0.f;
+#pragma unroll 16                                      // 16 slices' loads in flight per thread; the sum keeps its order
             for (int k = 0; k < d.KS; ++k) v += p[(size_t)k * d.n];
             d.out[i] = v;
         }
@@ -650,14 +652,18 @@ bool twgrad_big_tile(int B, int M, int C, int Tout) {
     return M >= 128 && C >= 128 && (long long)B * Tout >= 8192;
 }
 static bool twgrad_big_ok(const TWgradArgs& a) { return a.stride == 1; }      // the big tile's staging registers are sized for stride-1 windows
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e && *e ? atoi(e) : dflt; }
 int twgrad_splits(int B, int M, int C, int Tout, int taps, int kt) {
+    // development knobs: workgroups aimed at (small tile), fewest slabs a slice may have, MB of partial tiles below which the operand-ratio cap is waived
+    static const int wgs = env_int("MUGD_TWGRAD_WGS", 768), minslabs = env_int("MUGD_TWGRAD_MINSLABS", 8), freemb = env_int("MUGD_TWGRAD_FREE_MB", 0);
     const int tm = twgrad_big_tile(B, M, C, Tout) ? 128 : 64;
     const long long tiles = (long long)cdiv(M, tm) * cdiv(C, tm), slabs = (long long)B * cdiv(Tout, kt);
-    long long ks = std::max<long long>(1, (tm == 128 ? 256 : 768) / tiles);      // one 8-wave workgroup per CU is all the big tile can hold (LDS)
-    ks = std::min(ks, std::max<long long>(1, slabs / 4));
+    long long ks = std::max<long long>(1, (tm == 128 ? 256 : wgs) / tiles);      // one 8-wave workgroup per CU is all the big tile can hold (LDS)
+    ks = std::min(ks, std::max<long long>(1, slabs / std::min(4, minslabs)));
     const double operand = (double)B * Tout * ((double)M + C);
     long long cap = (long long)std::max(1.0, 0.5 * operand / ((double)M * C * taps));
-    cap = std::max(cap, std::min<long long>(cdiv(tm == 128 ? 256 : 512, (int)tiles), slabs / 8));      // ... but never fewer than ~256-512 workgroups of >= 8 slabs
+    cap = std::max(cap, std::min<long long>(cdiv(tm == 128 ? 256 : 512, (int)tiles), slabs / minslabs));      // ... but never fewer than ~256-512 workgroups of >= 8 slabs
+    if ((double)ks * M * C * taps * 4.0 <= freemb * 1048576.0) cap = ks;       // small enough to stay in L2 / MALL: only the workgroup count matters
     ks = std::min(ks, std::max<long long>(cap, 1));
     return (int)std::min<long long>(ks, 512);
 }

@@ -428,30 +428,39 @@ __global__ void gn_param_reduce_kernel(const double* part, float* dgamma, float*
 template <bool SILU>
 __global__ __launch_bounds__(256) void emb_linear_bwd_kernel(const float* e, const float* We, const float* dE, float* dWe, float* dbe, float* de,
                                                              int B, int K, int M, int row_blocks) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if ((int)blockIdx.x < row_blocks) {
-        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        const int m = blockIdx.x * 4 + wave;
+        // dWe / dbe: one wave per (row m, 64 columns of k).  Every load of the wave's batch loop is independent (one round trip for up
+        // to 32 rows); the first version walked all of K and B per wave -- 8 x 32 dependent-latency steps for a 16 MFLOP problem
+        const int kchunks = (K + 63) / 64;
+        const int unit = blockIdx.x * 4 + wave, m = unit / kchunks, k = (unit % kchunks) * 64 + lane;
         if (m >= M) return;
-        for (int k = lane; k < K; k += 64) {
+        if (k < K) {
             float s = 0.f;
-#pragma unroll 8                                       // the loads of 8 batch rows go out together; the sum keeps its order
+#pragma unroll 32
             for (int b = 0; b < B; ++b) { const float v = e[(size_t)b * K + k]; s += dE[(size_t)b * M + m] * (SILU ? v / (1.0f + expf(-v)) : v); }
             dWe[(size_t)m * K + k] = s;
         }
-        if (lane == 0) {
+        if (unit % kchunks == 0 && lane == 0) {
             float s = 0.f;
+#pragma unroll 32
             for (int b = 0; b < B; ++b) s += dE[(size_t)b * M + m];
             dbe[m] = s;
         }
     } else if (de) {
-        const int kblocks = (K + 255) / 256, idx = (int)blockIdx.x - row_blocks;
-        const int k = (idx % kblocks) * 256 + threadIdx.x;
-        if (k >= K) return;
-        {
-            const int b = idx / kblocks;
-            float s = 0.f;
-#pragma unroll 16                                      // 16 independent weight loads in flight per thread instead of one dependent round trip per row
-            for (int m = 0; m < M; ++m) s += We[(size_t)m * K + k] * dE[(size_t)b * M + m];
+        // de[b][k]: one workgroup per (batch row, 64 columns); the 4 waves split the rows of We, partial sums meet in LDS (fixed order)
+        __shared__ float red[4][64];
+        const int kblocks = (K + 63) / 64, idx = (int)blockIdx.x - row_blocks;
+        const int b = idx / kblocks, k = (idx % kblocks) * 64 + lane, kc = k < K ? k : K - 1;
+        const int mq = (M + 3) / 4, m0 = wave * mq, m1 = m0 + mq < M ? m0 + mq : M;
+        const float* dr = dE + (size_t)b * M;
+        float s = 0.f;
+#pragma unroll 16
+        for (int m = m0; m < m1; ++m) s += We[(size_t)m * K + kc] * dr[m];
+        red[wave][lane] = s;
+        __syncthreads();
+        if (wave == 0 && k < K) {
+            s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
             const float v = e[(size_t)b * K + k];
             const float sg = 1.0f / (1.0f + expf(-v));
             de[(size_t)b * K + k] = SILU ? s * (sg * (1.0f + v * (1.0f - sg))) : s;
@@ -587,13 +596,13 @@ void launch_pair_reduce(hipStream_t st, const double* part, float* out0, float* 
     hipLaunchKernelGGL(gn_param_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, part, out0, out1, KS, n);
 }
 void launch_emb_linear_bwd(hipStream_t st, const float* e, const float* We, const float* dE, float* dWe, float* dbe, float* de, int B, int K, int M) {
-    const int rb = cdiv(M, 4);
-    hipLaunchKernelGGL(emb_linear_bwd_kernel<true>, dim3(rb + cdiv(K, 256) * B), dim3(256), 0, st, e, We, dE, dWe, dbe, de, B, K, M, rb);
+    const int rb = cdiv(M * cdiv(K, 64), 4);
+    hipLaunchKernelGGL(emb_linear_bwd_kernel<true>, dim3(rb + (de ? cdiv(K, 64) * B : 0)), dim3(256), 0, st, e, We, dE, dWe, dbe, de, B, K, M, rb);
 }
 // the same for a plain Linear (no activation in front): dWe = dE^T e, dbe, de (nullable) = dE We
 void launch_emb_linear_bwd_plain(hipStream_t st, const float* e, const float* We, const float* dE, float* dWe, float* dbe, float* de, int B, int K, int M) {
-    const int rb = cdiv(M, 4);
-    hipLaunchKernelGGL(emb_linear_bwd_kernel<false>, dim3(rb + cdiv(K, 256) * B), dim3(256), 0, st, e, We, dE, dWe, dbe, de, B, K, M, rb);
+    const int rb = cdiv(M * cdiv(K, 64), 4);
+    hipLaunchKernelGGL(emb_linear_bwd_kernel<false>, dim3(rb + (de ? cdiv(K, 64) * B : 0)), dim3(256), 0, st, e, We, dE, dWe, dbe, de, B, K, M, rb);
 }
 void launch_embedding_bwd(hipStream_t st, const long long* ids, const float* dctx, float* dtable, int B, int ntok, int dim, int rows) {
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3(rows), dim3(128), 0, st, ids, dctx, dtable, B, ntok, dim);

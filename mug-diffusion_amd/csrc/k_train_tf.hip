@@ -437,6 +437,49 @@ __global__ __launch_bounds__(256) void attn_bwd_cols_lds_kernel(const AttnBwdArg
 
 // table kernel, stage 1: part[b][r][h] = {scale sum dsim, sum dA S} over the cells of batch row b with idx == r.
 // grid (2 pmax + 1, heads, B), block 256; stage 2 sums over b in fixed order.
+// Row-major form of the same sums (pmax <= ATB_PMAX): one workgroup per (head, batch row) walks both matrices ONCE with coalesced row
+// reads -- rows round-robin over the 4 waves, lanes over keys -- instead of 2 pmax + 1 workgroups each walking a diagonal (4-byte reads
+// one row pitch apart).  An interior element goes to the wave's LDS bin of its offset j - i (the 64 lanes of a row chunk hit 64 distinct
+// bins: plain read-add-write, rows in program order); the two clamped regions accumulate per lane and meet in one wave sum at the end.
+// fp64 throughout, fixed order: deterministic.
+constexpr int ATB_PMAX = 128;
+__global__ __launch_bounds__(256) void attn_bwd_tables_rows_kernel(const AttnBwdArgs a, double* part) {
+    __shared__ double bins[4][2][2 * ATB_PMAX + 1];
+    __shared__ double edge[4][4];
+    const int h = blockIdx.x, b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int Tq = a.Tq, Tk = a.Tk, pmax = a.pmax, nb = 2 * pmax + 1;
+    for (int r = lane; r < nb; r += 64) { bins[wave][0][r] = 0.0; bins[wave][1][r] = 0.0; }
+    __builtin_amdgcn_wave_barrier();
+    double lo1 = 0.0, lo2 = 0.0, hi1 = 0.0, hi2 = 0.0;
+    const size_t base = ((size_t)b * a.heads + h) * Tq * Tk;
+    for (int i = wave; i < Tq; i += 4) {
+        const float* r1 = a.dsim + base + (size_t)i * Tk;
+        const float* r2 = a.dG + base + (size_t)i * Tk;
+        for (int j0 = 0; j0 < Tk; j0 += 64) {
+            const int j = j0 + lane;
+            if (j < Tk) {
+                const double v1 = (double)r1[j], v2 = (double)r2[j];
+                const int off = j - i;
+                if (off <= -pmax) { lo1 += v1; lo2 += v2; }
+                else if (off >= pmax) { hi1 += v1; hi2 += v2; }
+                else { bins[wave][0][off + pmax] += v1; bins[wave][1][off + pmax] += v2; }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    lo1 = wave_sum_dd(lo1); lo2 = wave_sum_dd(lo2); hi1 = wave_sum_dd(hi1); hi2 = wave_sum_dd(hi2);
+    if (lane == 0) { edge[wave][0] = lo1; edge[wave][1] = lo2; edge[wave][2] = hi1; edge[wave][3] = hi2; }
+    __syncthreads();
+    for (int r = threadIdx.x; r < nb; r += 256) {
+        double s1 = (bins[0][0][r] + bins[1][0][r]) + (bins[2][0][r] + bins[3][0][r]);
+        double s2 = (bins[0][1][r] + bins[1][1][r]) + (bins[2][1][r] + bins[3][1][r]);
+        if (r == 0) { s1 += (edge[0][0] + edge[1][0]) + (edge[2][0] + edge[3][0]); s2 += (edge[0][1] + edge[1][1]) + (edge[2][1] + edge[3][1]); }
+        if (r == nb - 1) { s1 += (edge[0][2] + edge[1][2]) + (edge[2][2] + edge[3][2]); s2 += (edge[0][3] + edge[1][3]) + (edge[2][3] + edge[3][3]); }
+        const size_t o = 2 * (((size_t)b * nb + r) * a.heads + h);
+        part[o] = s1 * (double)a.scale;
+        part[o + 1] = s2;
+    }
+}
 __global__ __launch_bounds__(256) void attn_bwd_tables_kernel(const AttnBwdArgs a, double* part) {
     __shared__ double red[2][4];
     const int r = blockIdx.x, h = blockIdx.y, b = blockIdx.z, off = r - a.pmax;
@@ -527,7 +570,8 @@ void launch_attention_bwd(hipStream_t st, const AttnBwdArgs& a) {
     else if (qf <= 4096) hipLaunchKernelGGL(attn_bwd_cols_lds_kernel<4096>, dim3(cdiv(a.Tk, 64), a.heads, a.B), dim3(256), 0, st, a);
     else if (qf <= 8192) hipLaunchKernelGGL(attn_bwd_cols_lds_kernel<8192>, dim3(cdiv(a.Tk, 64), a.heads, a.B), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(attn_bwd_cols_kernel, dim3(cdiv(a.Tk, 64), a.heads, a.B), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(attn_bwd_tables_kernel, dim3(2 * a.pmax + 1, a.heads, a.B), dim3(256), 0, st, a, a.tab_part);
+    if (a.pmax <= ATB_PMAX) hipLaunchKernelGGL(attn_bwd_tables_rows_kernel, dim3(a.heads, a.B), dim3(256), 0, st, a, a.tab_part);
+    else hipLaunchKernelGGL(attn_bwd_tables_kernel, dim3(2 * a.pmax + 1, a.heads, a.B), dim3(256), 0, st, a, a.tab_part);
     const int n = (2 * a.pmax + 1) * a.heads;
-    hipLaunchKernelGGL(attn_tables_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, a.tab_part, a.drel, a.dcemb, a.B, n);
+    if (!a.defer_tables) hipLaunchKernelGGL(attn_tables_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, a.tab_part, a.drel, a.dcemb, a.B, n);
 }

@@ -348,6 +348,7 @@ struct AttnBwdArgs {         // layouts as AttnArgs; dout = gradient of the atte
     float* drel; float* dcemb;                // (2 pmax + 1, heads)
     double* tab_part;                         // scratch, (B, 2 pmax + 1, heads, 2)
     int skip_cols;                            // 1: dk / dv are produced by the caller (bf16 mode: two batched tconv GEMMs over dsim / Amat)
+    int defer_tables;                         // 1: drel / dcemb stay as the B fp64 pair rows of tab_part (TReduceDesc kind 2, n = (2 pmax + 1) heads)
 };
 void launch_attention_bwd(hipStream_t st, const AttnBwdArgs& a);
 // k_train_s4.hip: S4 layer backward pieces
