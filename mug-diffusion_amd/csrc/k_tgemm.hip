@@ -401,7 +401,11 @@ constexpr int TW_XS = 81;                 // LDS row stride of the input window 
 // BIG: a 128 (m) x 128 (c) tile on 8 waves (4 x 2, a wave: 32 rows x 64 columns = two accumulators per tap) instead of 64 x 64 on 4
 // (2 x 2): each operand slab is staged once per 128 rows / columns -- the 64 x 64 form reads every dY slab once per c tile and every
 // input slab once per m tile, which made the 128-channel wave-encoder layers (2 x 2 tiles) stream their 0.5 GB operands twice.
-template <int TAPS, int TW_KT, bool DB, bool BIG>
+// FAST (stride 1, no upsample, Tout % 4 == 0 and Tin % 4 == 0 -- every layer of the model but its 6 resampling convs): a slab is staged
+// with 16-byte loads (dY and the window's interior: 4 samples per load; the <= 16 halo columns of a 3-tap window with scalar ones), and the
+// operand stream runs TWO slabs ahead of the matrix pipe in ping-pong registers -- the generic form requests one slab ahead with a 4-byte
+// load (and an index division) per element, which left a whole memory round trip exposed per slab on the short 1x1 layers.
+template <int TAPS, int TW_KT, bool DB, bool BIG, bool FAST>
 __global__ __launch_bounds__(BIG ? 512 : 256) void twgrad_bf16_kernel(const TWgradArgs a) {
     constexpr int NTHR = BIG ? 512 : 256;
     constexpr int TM = BIG ? 128 : 64;                  // tile rows (m) = tile columns (c)
@@ -419,12 +423,20 @@ __global__ __launch_bounds__(BIG ? 512 : 256) void twgrad_bf16_kernel(const TWgr
     constexpr int NY = TM * TW_KT / NTHR;
     constexpr int WMAX = BIG ? TW_KT + 16 : 80;         // window columns: the big tile is only launched at stride 1 (slab + 2 * 8 halo); else 31 * 2 + 17 | 63 + 17
     constexpr int NX = (TM * WMAX + NTHR - 1) / NTHR;   // 12 (big, 32-sample slabs) | 20
-    float vy[NY], vx[NX];
+    constexpr int QPR = TW_KT / 4;                      // FAST: 4-sample granules per row
+    constexpr int NQ = TM * QPR / NTHR;                 // FAST: granules per thread of dY, and of the window's interior (4 | 2)
+    constexpr int NH = TAPS == 3 ? (TM * 16 + NTHR - 1) / NTHR : 1;      // FAST: halo elements per thread (<= 16 halo columns per row)
+    struct Slab {                                       // the raw samples of one slab, as loaded
+        float4 qy[FAST ? NQ : 1], qx[FAST ? NQ : 1];
+        float hx[FAST ? NH : 1];
+        float vy[FAST ? 1 : NY], vx[FAST ? 1 : NX];
+    };
     // bias gradient db[m] = sum_{b,t} dY[b][m][t], fused: the c-tile-0 workgroups add up the dY values they stage anyway (fp32, fixed order)
     const bool want_db = DB && a.db != nullptr && blockIdx.y == 0;
-    float rs[DB ? NY : 1];
+    constexpr int NRS = DB ? (FAST ? NQ : NY) : 1;
+    float rs[NRS];
 #pragma unroll
-    for (int i = 0; i < (DB ? NY : 1); ++i) rs[i] = 0.f;
+    for (int i = 0; i < NRS; ++i) rs[i] = 0.f;
     f32x16 acc[TAPS][NC];
 #pragma unroll
     for (int k = 0; k < TAPS; ++k)
@@ -433,19 +445,65 @@ __global__ __launch_bounds__(BIG ? 512 : 256) void twgrad_bf16_kernel(const TWgr
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[k][q][i] = 0.f;
 
+    // ---- FAST maps (slab independent): granule g = tid + NTHR i -> (row g / QPR, samples 4 (g % QPR) ..+3) of the dY tile and of the
+    // window interior; halo element e = tid + NTHR i -> (row e / hw, halo column e % hw: the first `pad` left of the interior, the rest right)
+    const int hw = (TAPS - 1) * a.dil;
+    int qrow[FAST ? NQ : 1], qcol[FAST ? NQ : 1], hrow[FAST ? NH : 1], hcol[FAST ? NH : 1];
+    unsigned qyo[FAST ? NQ : 1], qxo[FAST ? NQ : 1], hxo[FAST ? NH : 1];      // row offsets into a batch row of dY / X (rows clamped)
+    if (FAST) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int g = tid + NTHR * i;
+            qrow[i] = g / QPR; qcol[i] = (g % QPR) * 4;
+            const int m = m0 + qrow[i], c = c0 + qrow[i];
+            qyo[i] = (unsigned)((m < a.M ? m : a.M - 1) * a.Tout);
+            qxo[i] = (unsigned)((c < a.C ? c : a.C - 1) * a.Tin);
+        }
+        if (TAPS == 3) {
+            const float inv_hw = 1.0f / (float)(hw > 0 ? hw : 1);
+#pragma unroll
+            for (int i = 0; i < NH; ++i) {
+                int e = tid + NTHR * i;
+                const bool in = e < TM * hw;
+                e = in ? e : 0;
+                const int row = (int)(((float)e + 0.5f) * inv_hw), hc = e - row * hw;
+                hrow[i] = in ? row : -1;
+                hcol[i] = hc < a.pad ? hc : TW_KT + hc;                       // window column
+                const int c = c0 + row;
+                hxo[i] = (unsigned)((c < a.C ? c : a.C - 1) * a.Tin);
+            }
+        }
+    }
+
     // raw, unconditional loads of slab s from clamped addresses; the zero padding is applied when the slab is parked (a select right
     // behind a load would make the wave wait for it before the MFMAs of the slab in front)
-    auto load_slab = [&](int s) {
+    auto load_slab = [&](int s, Slab& R) {
         const int b = s / nslab, t0 = (s - b * nslab) * TW_KT;
         const float* yb = a.dY + (size_t)b * a.M * a.Tout;
+        const float* xbp = a.X + (size_t)b * a.C * a.Tin;
+        if (FAST) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int t = t0 + qcol[i];                                     // Tout = Tin (stride 1, taps 1 | 3 with "same" padding or not: X sample of column pad + q is t0 + q)
+                R.qy[i] = *reinterpret_cast<const float4*>(yb + qyo[i] + (t < a.Tout ? t : a.Tout - 4));
+                R.qx[i] = *reinterpret_cast<const float4*>(xbp + qxo[i] + (t < a.Tin ? t : a.Tin - 4));
+            }
+            if (TAPS == 3) {
+#pragma unroll
+                for (int i = 0; i < NH; ++i) {
+                    const int u = t0 - a.pad + hcol[i];
+                    R.hx[i] = xbp[hxo[i] + (u < 0 ? 0 : (u < a.Tin ? u : a.Tin - 1))];
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NY; ++i) {
             const int e = tid + NTHR * i, row = e / TW_KT, col = e % TW_KT;
             const int m = m0 + row, t = t0 + col;
-            vy[i] = yb[(size_t)(unsigned)((m < a.M ? m : a.M - 1) * a.Tout + (t < a.Tout ? t : a.Tout - 1))];
+            R.vy[i] = yb[(size_t)(unsigned)((m < a.M ? m : a.M - 1) * a.Tout + (t < a.Tout ? t : a.Tout - 1))];
         }
         const int u0 = t0 * a.stride - a.pad;
-        const float* xbp = a.X + (size_t)b * a.C * a.Tin;
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             int e = tid + NTHR * i;
@@ -454,17 +512,38 @@ __global__ __launch_bounds__(BIG ? 512 : 256) void twgrad_bf16_kernel(const TWgr
             const int c = c0 + row, u = u0 + col;
             int uc = u < 0 ? 0 : u;
             uc = uc < vlen ? uc : vlen - 1;
-            vx[i] = xbp[(size_t)(unsigned)((c < a.C ? c : a.C - 1) * a.Tin + (a.ups ? (uc >> 1) : uc))];
+            R.vx[i] = xbp[(size_t)(unsigned)((c < a.C ? c : a.C - 1) * a.Tin + (a.ups ? (uc >> 1) : uc))];
         }
     };
-    auto park = [&](int s, int buf) {
+    auto park = [&](int s, int buf, const Slab& R) {
         const int b = s / nslab, t0 = (s - b * nslab) * TW_KT;
         float* sy = smem + buf * TW_BUF;
         float* sx = sy + TM * TW_YS;
+        if (FAST) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int t = t0 + qcol[i];
+                const bool oky = m0 + qrow[i] < a.M && t < a.Tout, okx = c0 + qrow[i] < a.C && t < a.Tin;
+                float* py = sy + qrow[i] * TW_YS + qcol[i];
+                const float y0 = oky ? R.qy[i].x : 0.f, y1 = oky ? R.qy[i].y : 0.f, y2 = oky ? R.qy[i].z : 0.f, y3 = oky ? R.qy[i].w : 0.f;
+                py[0] = y0; py[1] = y1; py[2] = y2; py[3] = y3;
+                if (DB) rs[i] += (y0 + y1) + (y2 + y3);
+                float* px = sx + qrow[i] * TW_XS + a.pad + qcol[i];
+                px[0] = okx ? R.qx[i].x : 0.f; px[1] = okx ? R.qx[i].y : 0.f; px[2] = okx ? R.qx[i].z : 0.f; px[3] = okx ? R.qx[i].w : 0.f;
+            }
+            if (TAPS == 3) {
+#pragma unroll
+                for (int i = 0; i < NH; ++i) {
+                    const int u = t0 - a.pad + hcol[i];
+                    if (hrow[i] >= 0) sx[hrow[i] * TW_XS + hcol[i]] = (c0 + hrow[i] < a.C && u >= 0 && u < a.Tin) ? R.hx[i] : 0.f;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NY; ++i) {
             const int e = tid + NTHR * i, row = e / TW_KT, col = e % TW_KT;
-            const float yv = (m0 + row < a.M && t0 + col < a.Tout) ? vy[i] : 0.f;
+            const float yv = (m0 + row < a.M && t0 + col < a.Tout) ? R.vy[i] : 0.f;
             sy[row * TW_YS + col] = yv;
             if (DB) rs[i] += yv;
         }
@@ -475,20 +554,12 @@ __global__ __launch_bounds__(BIG ? 512 : 256) void twgrad_bf16_kernel(const TWgr
             if (e < TM * W) {
                 const int row = (int)(((float)e + 0.5f) * inv_w), col = e - row * W;
                 const int u = u0 + col;
-                sx[row * TW_XS + col] = (c0 + row < a.C && u >= 0 && u < vlen) ? vx[i] : 0.f;
+                sx[row * TW_XS + col] = (c0 + row < a.C && u >= 0 && u < vlen) ? R.vx[i] : 0.f;
             }
         }
     };
-
-    const int s_step = a.KS;
-    int s = ks;
-    if (s < total) { load_slab(s); park(s, 0); }
-    __syncthreads();
-    int it = 0;
-    for (; s < total; s += s_step, ++it) {
-        const bool more = s + s_step < total;
-        if (more) load_slab(s + s_step);
-        const float* sy = smem + (it & 1) * TW_BUF;
+    auto compute = [&](int buf) {
+        const float* sy = smem + buf * TW_BUF;
         const float* sx = sy + TM * TW_YS;
 #pragma unroll
         for (int kk = 0; kk < TW_KT / 16; ++kk) {
@@ -502,9 +573,9 @@ __global__ __launch_bounds__(BIG ? 512 : 256) void twgrad_bf16_kernel(const TWgr
 #pragma unroll
                 for (int q = 0; q < NC; ++q) {
                     // sample t of the slab pairs with window column t * stride + tap * dil; a lane's 8 k are 8 consecutive t
-                    const float* br = sx + ((wc * NC + q) * 32 + n) * TW_XS + (kk * 16 + 8 * h) * a.stride + tap * a.dil;
+                    const float* br = sx + ((wc * NC + q) * 32 + n) * TW_XS + (kk * 16 + 8 * h) * (FAST ? 1 : a.stride) + tap * a.dil;
                     u32x4 bv;
-                    if (a.stride == 1) {
+                    if (FAST || a.stride == 1) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) bv[j] = pack_bf16(br[2 * j], br[2 * j + 1]);
                     } else {
@@ -514,17 +585,50 @@ __global__ __launch_bounds__(BIG ? 512 : 256) void twgrad_bf16_kernel(const TWgr
                     acc[tap][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bv), acc[tap][q], 0, 0, 0);
                 }
         }
-        if (more) park(s + s_step, (it + 1) & 1);
+    };
+
+    const int s_step = a.KS;
+    const int nit = ks < total ? (total - ks + s_step - 1) / s_step : 0;      // slabs of this slice: ks, ks + KS, ...
+    if (FAST) {
+        // LDS buffer (it & 1) holds slab `it`; the registers hold slab it + 1; slab it + 2 is requested before the MFMAs of slab it
+        Slab Ra, Rb;
+        auto step = [&](int it, Slab& Rfar, const Slab& Rnext) {
+            if (it + 2 < nit) load_slab(ks + (it + 2) * s_step, Rfar);
+            compute(it & 1);
+            if (it + 1 < nit) park(ks + (it + 1) * s_step, (it + 1) & 1, Rnext);
+            __syncthreads();
+        };
+        if (nit > 0) load_slab(ks, Ra);
+        if (nit > 1) load_slab(ks + s_step, Rb);
+        if (nit > 0) park(ks, 0, Ra);
         __syncthreads();
+        for (int it = 0; it < nit; it += 2) {
+            step(it, Ra, Rb);                         // slab it + 2 -> Ra (slab it is in LDS), park slab it + 1 from Rb
+            if (it + 1 < nit) step(it + 1, Rb, Ra);
+        }
+    } else {
+        Slab R;
+        if (nit > 0) { load_slab(ks, R); park(ks, 0, R); }
+        __syncthreads();
+        for (int it = 0; it < nit; ++it) {
+            const bool more = it + 1 < nit;
+            if (more) load_slab(ks + (it + 1) * s_step, R);
+            compute(it & 1);
+            if (more) park(ks + (it + 1) * s_step, (it + 1) & 1, R);
+            __syncthreads();
+        }
     }
-    if (DB && want_db) {     // element i of this thread sits in row (tid + NTHR i) / TW_KT: one row per wave (64-sample slabs) or per half wave (32)
+    if (DB && want_db) {
+        // FAST: granule i of this thread sits in row (tid + NTHR i) / QPR -- QPR consecutive lanes share a row; generic: element i in row
+        // (tid + NTHR i) / TW_KT -- one row per wave (64-sample slabs) or per half wave (32)
+        constexpr int RL = FAST ? QPR : (TW_KT < 64 ? TW_KT : 64);
 #pragma unroll
-        for (int i = 0; i < (DB ? NY : 1); ++i) {
+        for (int i = 0; i < NRS; ++i) {
             float v = rs[i];
 #pragma unroll
-            for (int o = 1; o < (TW_KT < 64 ? TW_KT : 64); o <<= 1) v += __shfl_xor(v, o);
-            const int row = (tid + NTHR * i) / TW_KT;
-            if ((tid & (TW_KT - 1)) == 0 && m0 + row < a.M) a.db[(size_t)ks * a.M + m0 + row] = v;
+            for (int o = 1; o < RL; o <<= 1) v += __shfl_xor(v, o);
+            const int row = (tid + NTHR * i) / (FAST ? QPR : TW_KT);
+            if ((tid & (RL - 1)) == 0 && m0 + row < a.M) a.db[(size_t)ks * a.M + m0 + row] = v;
         }
     }
     // ---- store: dW (or partial slice ks) [m][c][tap]; accumulator register i of lane (h, n): row (i & 3) + 8 (i >> 2) + 4 h, column n
@@ -688,10 +792,15 @@ void launch_twgrad_bf16(hipStream_t st, const TWgradArgs& a0, float* partial, bo
     MUGD_CHECK(!big || twgrad_big_ok(a), -2, "twgrad: 128 x 128 tiles are built for stride-1 windows");
     const dim3 grid(cdiv(a.M, big ? 128 : 64), cdiv(a.C, big ? 128 : 64), a.KS);
     const dim3 blk(big ? 512 : 256);
+    // 16-byte staging + two slabs in flight (FAST) where rows are 16-byte aligned and windows are plain shifted slabs
+    bool fast = a.stride == 1 && !a.ups && (a.Tout & 3) == 0 && (a.Tin & 3) == 0 && a.Tin == a.Tout && a.pad >= 0 && a.pad <= (a.taps - 1) * a.dil;
+    if (const char* e = getenv("MUGD_TWGRAD_GENERIC")) { if (e[0] == '1') fast = false; }                  // development / test knob: the generic staging
 #define MUGD_TW(T, K, D)                                                                                   \
     do {                                                                                                   \
-        if (big) hipLaunchKernelGGL((twgrad_bf16_kernel<T, K, D, true>), grid, blk, 0, st, a);             \
-        else hipLaunchKernelGGL((twgrad_bf16_kernel<T, K, D, false>), grid, blk, 0, st, a);                \
+        if (big && fast) hipLaunchKernelGGL((twgrad_bf16_kernel<T, K, D, true, true>), grid, blk, 0, st, a);       \
+        else if (big) hipLaunchKernelGGL((twgrad_bf16_kernel<T, K, D, true, false>), grid, blk, 0, st, a);         \
+        else if (fast) hipLaunchKernelGGL((twgrad_bf16_kernel<T, K, D, false, true>), grid, blk, 0, st, a);        \
+        else hipLaunchKernelGGL((twgrad_bf16_kernel<T, K, D, false, false>), grid, blk, 0, st, a);                 \
     } while (0)
     if (a.taps == 1) {
         MUGD_CHECK(a.stride == 1, -2, "twgrad: strided 1x1 convs are not used by the model");

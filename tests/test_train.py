@@ -744,7 +744,7 @@ class _ConvBF16(torch.autograd.Function):
 @pytest.mark.parametrize("B,Cin,Cout,T,taps,dil,mode,gn", [(2, 32, 48, 40, 3, 1, 0, False), (2, 32, 32, 64, 3, 4, 0, False), (1, 48, 32, 50, 3, 8, 0, False),
                                                            (2, 32, 64, 36, 1, 1, 0, False), (2, 32, 48, 40, 3, 1, 1, False), (2, 48, 32, 26, 3, 1, 2, False),
                                                            (2, 64, 16, 40, 3, 1, 0, True), (2, 32, 160, 200, 3, 2, 0, False), (1, 144, 32, 132, 1, 1, 0, False),
-                                                           (2, 32, 32, 130, 3, 1, 1, False)])
+                                                           (2, 32, 32, 130, 3, 1, 1, False), (3, 64, 128, 512, 1, 1, 0, False), (2, 128, 128, 256, 3, 2, 0, False)])
 def test_conv_layer_bf16_gemms_vs_rounded_operand_reference(lib, B, Cin, Cout, T, taps, dil, mode, gn):
     """The bf16 training GEMMs (tconv forward / data gradient, twgrad) on every conv geometry of the model -- plain, dilated, Downsample,
     Upsample, 1x1, the GroupNorm + SiLU head; row counts off the 128-row block, channel counts off the 64-channel stage, lengths off the
