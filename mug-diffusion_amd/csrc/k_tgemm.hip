@@ -111,19 +111,26 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
     constexpr int QPR = TC_TN / 4;                      // FAST: 4-sample granules per pair-row
     constexpr int NQ = FAST ? PR * QPR / 256 : 1;       // FAST: interior granules per thread (1 or 2)
     constexpr int NH = (FAST && TAPS == 3) ? (PR * 16 + 255) / 256 : 1;      // FAST: halo elements per thread (halo <= 16 samples per row)
-    __shared__ __attribute__((aligned(16))) unsigned smem[2 * TC_BUF];
+    constexpr int OS = 36;                              // FAST epilogue: floats per tile row in LDS (16-byte aligned rows, conflict-free)
+    __shared__ __attribute__((aligned(16))) unsigned smem[2 * TC_BUF + (FAST ? 4 * 32 * OS : 0)];
 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, h = lane >> 5, n = lane & 31;
     // ---- tile decode: XCD-aware renumbering (consecutive hardware ids go round-robin to the 8 XCDs: give each XCD a contiguous range
     // of the (row block major) tile order, so a weight block lives in ONE private L2)
-    const int gx = a.gx, gy = a.gy, gz = a.B;
+    // FAST: a workgroup walks `tpw` consecutive time tiles of its (row block, batch row) as ONE flattened stage sequence -- the window
+    // stream keeps running two stages ahead across the tile boundary, so a layer with few K stages per tile (128 channels: 2..4) does not
+    // pay a cold pipeline start and an exposed epilogue per 64 columns
+    const int tpw = FAST ? a.tpw : 1;
+    const int gx = (a.gx + tpw - 1) / tpw, gy = a.gy, gz = a.B;
     const int nblk = gx * gy * gz;
     int lid = blockIdx.x;
     if ((nblk & 7) == 0) lid = (lid & 7) * (nblk >> 3) + (lid >> 3);
     const int mb = lid / (gx * gz);
     const int rem = lid - mb * (gx * gz);
     const int b = rem / gx;
-    const int t0 = (rem - b * gx) * TC_TN;
+    const int tile0 = (rem - b * gx) * tpw;
+    const int ntile = a.gx - tile0 < tpw ? a.gx - tile0 : tpw;
+    const int t0 = tile0 * TC_TN;                       // first tile; tile j starts at t0 + j * TC_TN
 
     const int WIN = (TC_TN - 1) * a.stride + (TAPS - 1) * a.dil + 1;
     const int u0 = t0 * a.stride - a.pad;
@@ -159,16 +166,14 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
     // ---- FAST staging map: interior granule g = tid + 256 i -> (pair-row g / QPR, samples t0 + 4 (g % QPR) ..+3); halo element
     // e = tid + 256 i -> (pair-row e / hw, halo column e % hw: the first `pad` are left of the interior, the rest right of it)
     const int hw = (TAPS - 1) * a.dil;
-    int qp[NQ], qoff[NQ], qlds[NQ]; bool qok[NQ];
-    int hp[NH], hoff[NH], hlds[NH]; bool hok[NH];
+    int qp[NQ], qt[NQ], qlds[NQ];                                 // qt: the granule's first sample in tile 0 (tile j: + j * TC_TN)
+    int hp[NH], hu[NH], hlds[NH]; bool hin[NH];                    // hu: the halo element's sample in tile 0
     if (FAST) {
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int g = tid + 256 * i, p = g / QPR, q4 = (g - p * QPR) * 4;
-            const int t = t0 + q4;
-            qok[i] = t < a.Tin;                                    // Tin % 4 == 0: a granule is wholly inside or outside
             qp[i] = 2 * p;
-            qoff[i] = qok[i] ? t : a.Tin - 4;
+            qt[i] = t0 + q4;
             qlds[i] = p * WS + LOFF + a.pad + q4;
         }
         if (TAPS == 3) {
@@ -180,10 +185,9 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
                 e = in ? e : 0;
                 const int p = (int)(((float)e + 0.5f) * inv_hw), hc = e - p * hw;
                 const int col = hc < a.pad ? hc : TC_TN + hc;      // window column
-                const int u = u0 + col;
-                hok[i] = in && u >= 0 && u < a.Tin;
+                hin[i] = in;
                 hp[i] = 2 * p;
-                hoff[i] = u < 0 ? 0 : (u < a.Tin ? u : a.Tin - 1);
+                hu[i] = u0 + col;
                 hlds[i] = in ? p * WS + LOFF + col : TC_BUF - 1;
             }
         }
@@ -223,18 +227,19 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
             }
         }
     }
-    if (FAST) {
+    auto load_resid = [&](int j) {                        // FAST: the residual granules of tile j
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int idx = lane + 64 * k;
-                int m = mtile * 32 + (idx >> 3), t = t0 + nt * 32 + (idx & 7) * 4;
+                int m = mtile * 32 + (idx >> 3), t = t0 + j * TC_TN + nt * 32 + (idx & 7) * 4;
                 m = m < a.M ? m : a.M - 1;
                 t = t < a.Tout ? t : a.Tout - 4;                   // Tout % 4 == 0: a granule is wholly inside or outside
                 rres[nt][k] = a.resid ? *reinterpret_cast<const float4*>(a.resid + ((size_t)b * a.M + m) * a.Tout + t) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-    }
+    };
+    if (FAST) load_resid(0);
 
     // The packed weights hold a whole number of stages (zero blocks behind the last channel block: launch_tpack_weights), so every
     // stage runs the same straight-line code; activation channels past C are zeroed when they are parked.
@@ -248,14 +253,16 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
     u32x4 Aa[KSUB * TAPS], Ab[KSUB * TAPS];          // ping-pong weight fragments (one stage ahead: L2 hits): no register copies in the loop
 
     // raw, unconditional loads; nothing here USES a loaded value, so the loads stay in flight across the MFMAs of the stages in front
-    auto load_x = [&](int s, XRegs& X) {
+    auto load_x = [&](int j, int s, XRegs& X) {             // tile j of the workgroup (FAST; 0 otherwise), stage s
         const int c0 = s * KSUB * 16;
         const int cmax = a.C - 2 - c0;                       // last pair of the tensor, relative to the stage (C is a multiple of 16)
+        const int tj = j * TC_TN;
         if (FAST) {
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
                 const int pc = qp[i] < cmax ? qp[i] : cmax;  // channels past C (the last, partial stage): clamped address, zeroed in park()
-                const float* q = xb + (size_t)(unsigned)((c0 + pc) * a.Tin) + qoff[i];
+                const int t = qt[i] + tj;                    // Tin % 4 == 0: a granule is wholly inside or outside
+                const float* q = xb + (size_t)(unsigned)((c0 + pc) * a.Tin) + (t < a.Tin ? t : a.Tin - 4);
                 X.qlo[i] = *reinterpret_cast<const float4*>(q);
                 X.qhi[i] = *reinterpret_cast<const float4*>(q + a.Tin);
             }
@@ -263,7 +270,8 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
 #pragma unroll
                 for (int i = 0; i < NH; ++i) {
                     const int pc = hp[i] < cmax ? hp[i] : cmax;
-                    const float* q = xb + (size_t)(unsigned)((c0 + pc) * a.Tin) + hoff[i];
+                    const int u = hu[i] + tj;
+                    const float* q = xb + (size_t)(unsigned)((c0 + pc) * a.Tin) + (u < 0 ? 0 : (u < a.Tin ? u : a.Tin - 1));
                     X.hlo[i] = q[0];
                     X.hhi[i] = q[a.Tin];
                 }
@@ -285,13 +293,14 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
             for (int tap = 0; tap < TAPS; ++tap)
                 Ad[kk * TAPS + tap] = *reinterpret_cast<const u32x4*>(wp + ((size_t)(s * KSUB + kk) * TAPS + tap) * 512);
     };
-    auto park = [&](int s, int buf, const XRegs& X) {        // zero padding / channel tail, round to bf16 pairs, store
+    auto park = [&](int j, int s, int buf, const XRegs& X) {        // zero padding / channel tail, round to bf16 pairs, store
         unsigned* w = smem + buf * TC_BUF;
         const int cmax = a.C - 2 - s * KSUB * 16;
+        const int tj = j * TC_TN;
         if (FAST) {
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
-                const bool okc = qok[i] && qp[i] <= cmax;
+                const bool okc = qt[i] + tj < a.Tin && qp[i] <= cmax;
                 u32x4 v;
                 v[0] = pack_bf16(okc ? X.qlo[i].x : 0.f, okc ? X.qhi[i].x : 0.f);
                 v[1] = pack_bf16(okc ? X.qlo[i].y : 0.f, okc ? X.qhi[i].y : 0.f);
@@ -302,7 +311,8 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
             if (TAPS == 3) {
 #pragma unroll
                 for (int i = 0; i < NH; ++i) {
-                    const bool okc = hok[i] && hp[i] <= cmax;
+                    const int u = hu[i] + tj;
+                    const bool okc = hin[i] && u >= 0 && u < a.Tin && hp[i] <= cmax;
                     w[hlds[i]] = pack_bf16(okc ? X.hlo[i] : 0.f, okc ? X.hhi[i] : 0.f);
                 }
             }
@@ -330,52 +340,62 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
                 }
             }
     };
-    // One stage.  Program order = request order (loads complete in order): the NEXT stage's weight fragments first, then the window two
-    // stages ahead -- waiting for the fragments at the top of the next stage then leaves that window in flight; this stage on the matrix
-    // pipe; then the window of the next stage (requested a whole stage ago) goes to the other LDS buffer.
-    auto step = [&](int s, const u32x4 (&A)[KSUB * TAPS], u32x4 (&An)[KSUB * TAPS], XRegs& Xfar, const XRegs& Xnext) {
-        if (s + 1 < nstage) load_a(s + 1, An);
-        if (s + 2 < nstage) load_x(s + 2, Xfar);
-        if (active) compute(s & 1, A);
-        if (s + 1 < nstage) park(s + 1, (s + 1) & 1, Xnext);
-        __syncthreads();
-    };
-
-    load_x(0, Xa);
-    load_a(0, Aa);
-    if (nstage > 1) load_x(1, Xb);
-    park(0, 0, Xa);
-    __syncthreads();
-    for (int s = 0; s < nstage; s += 2) {
-        step(s, Aa, Ab, Xa, Xb);                     // window s + 2 -> Xa (its old content, stage s, is in LDS), park stage s + 1 from Xb
-        if (s + 1 < nstage) step(s + 1, Ab, Aa, Xb, Xa);
-    }
-    // ---- epilogue: accumulator register i of lane (h, n) is row (i & 3) + 8 (i >> 2) + 4 h, column n
-    if (FAST) {
-        // through LDS (the staging windows are free after the last barrier): each wave turns its 32 x 32 tile into 16-byte row
-        // segments -- 8 wide stores per lane and tile instead of 32 narrow ones (the store ISSUE was the tail of every workgroup)
-        constexpr int OS = 36;                                     // floats per tile row in LDS: 16-byte aligned rows, conflict-free
-        float* ob = reinterpret_cast<float*>(smem) + wave * (32 * OS);
+    // FAST epilogue of tile j: accumulator register i of lane (h, n) is row (i & 3) + 8 (i >> 2) + 4 h, column n.  Through the wave's own
+    // LDS region: each wave turns its 32 x 32 tile into 16-byte row segments -- 8 wide stores per lane and tile instead of 32 narrow
+    // ones (the store ISSUE was the tail of every workgroup); then the accumulators restart and the next tile's residual is requested
+    auto epilogue = [&](int j, bool more) {
+        float* ob = reinterpret_cast<float*>(smem + 2 * TC_BUF) + wave * (32 * OS);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) ob[((i & 3) + 8 * (i >> 2) + 4 * h) * OS + n] = acc[nt][i] + eadd[i];
+            for (int i = 0; i < 16; ++i) { ob[((i & 3) + 8 * (i >> 2) + 4 * h) * OS + n] = acc[nt][i] + eadd[i]; acc[nt][i] = 0.f; }
             wave_sync();
             if (active) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int idx = lane + 64 * k, row = idx >> 3, c4 = (idx & 7) * 4;
-                    const int m = mtile * 32 + row, t = t0 + nt * 32 + c4;
+                    const int m = mtile * 32 + row, t = t0 + j * TC_TN + nt * 32 + c4;
                     float4 v = *reinterpret_cast<const float4*>(ob + row * OS + c4);
-                    const float4 r = rres[nt][k];
+                    const float4 r = rres[FAST ? nt : 0][FAST ? k : 0];
                     v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                     if (m < a.M && t < a.Tout) *reinterpret_cast<float4*>(a.y + ((size_t)b * a.M + m) * a.Tout + t) = v;
                 }
             }
             wave_sync();
         }
-        return;
+        if (more) load_resid(j + 1);
+    };
+    // One stage of the flattened (tile, stage) sequence g = j * nstage + s.  Program order = request order (loads complete in order): the
+    // NEXT stage's weight fragments first, then the window two stages ahead -- waiting for the fragments at the top of the next stage then
+    // leaves that window in flight; this stage on the matrix pipe; then the window of the next stage (requested a whole stage ago) goes
+    // to the other LDS buffer; behind a tile's last stage, its epilogue (the next tile's first windows are parked / in flight by then).
+    const int G = ntile * nstage;
+    int j0 = 0, s0 = 0;                                  // (tile, stage) of g; g + 1 and g + 2 follow by carry
+    auto step = [&](int g, const u32x4 (&A)[KSUB * TAPS], u32x4 (&An)[KSUB * TAPS], XRegs& Xfar, const XRegs& Xnext) {
+        int s1 = s0 + 1, j1 = j0;
+        if (s1 == nstage) { s1 = 0; ++j1; }
+        int s2 = s1 + 1, j2 = j1;
+        if (s2 == nstage) { s2 = 0; ++j2; }
+        if (g + 1 < G) load_a(s1, An);
+        if (g + 2 < G) load_x(j2, s2, Xfar);
+        if (active) compute(g & 1, A);
+        if (g + 1 < G) park(j1, s1, (g + 1) & 1, Xnext);
+        if (FAST && s0 == nstage - 1) epilogue(j0, j0 + 1 < ntile);
+        __syncthreads();
+        s0 = s1; j0 = j1;
+    };
+
+    load_x(0, 0, Xa);
+    load_a(0, Aa);
+    if (G > 1) load_x(nstage > 1 ? 0 : 1, nstage > 1 ? 1 : 0, Xb);
+    park(0, 0, 0, Xa);
+    __syncthreads();
+    for (int g = 0; g < G; g += 2) {
+        step(g, Aa, Ab, Xa, Xb);                     // window g + 2 -> Xa (its old content, stage g, is in LDS), park stage g + 1 from Xb
+        if (g + 1 < G) step(g + 1, Ab, Aa, Xb, Xa);
     }
+    if (FAST) return;
+    // ---- generic epilogue: accumulator register i of lane (h, n) is row (i & 3) + 8 (i >> 2) + 4 h, column n
     if (!active) return;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -735,9 +755,16 @@ void launch_tconv_bf16(hipStream_t st, const TConvArgs& a0) {
     int nt = (long long)cdiv(a.Tout, 64) * a.gy * a.B < 768 ? 1 : 2;        // too few 128 x 64 tiles for 256 CUs x 2-3 workgroups: halve them
     if (const char* e = getenv("MUGD_TCONV_NT")) { const int v = atoi(e); if (v == 1 || v == 2) nt = v; }      // development / test knob
     a.gx = cdiv(a.Tout, 32 * nt);
-    const dim3 grid((unsigned)a.gx * a.gy * a.B);
     bool fast = a.stride == 1 && !a.ups && (a.Tin & 3) == 0 && a.pad <= (a.taps - 1) * a.dil;
     if (const char* e = getenv("MUGD_TCONV_GENERIC")) { if (e[0] == '1') fast = false; }                  // development / test knob: the generic staging
+    // consecutive time tiles per workgroup (FAST): as many as leave >= 1024 workgroups (4 per CU), at most 8
+    a.tpw = 1;
+    if (fast) {
+        const long long tiles = (long long)a.gx * a.gy * a.B;
+        while (a.tpw < 8 && tiles / (2 * a.tpw) >= 1024 && a.gx >= 2 * a.tpw) a.tpw *= 2;
+        if (const char* e = getenv("MUGD_TCONV_TPW")) { const int v = atoi(e); if (v >= 1 && v <= 64) a.tpw = v; }      // development / test knob
+    }
+    const dim3 grid((unsigned)cdiv(a.gx, a.tpw) * a.gy * a.B);
 #define MUGD_TC(T, N)                                                                                     \
     do {                                                                                                  \
         if (fast) hipLaunchKernelGGL((tconv_bf16_kernel<T, N, true>), grid, dim3(256), 0, st, a);         \

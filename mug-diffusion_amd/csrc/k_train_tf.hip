@@ -443,27 +443,36 @@ __global__ __launch_bounds__(256) void attn_bwd_cols_lds_kernel(const AttnBwdArg
 // bins: plain read-add-write, rows in program order); the two clamped regions accumulate per lane and meet in one wave sum at the end.
 // fp64 throughout, fixed order: deterministic.
 constexpr int ATB_PMAX = 128;
+constexpr int ATB_TROWS = 64;             // query rows per workgroup (16 per wave)
 __global__ __launch_bounds__(256) void attn_bwd_tables_rows_kernel(const AttnBwdArgs a, double* part) {
     __shared__ double bins[4][2][2 * ATB_PMAX + 1];
     __shared__ double edge[4][4];
-    const int h = blockIdx.x, b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int h = blockIdx.x, b = blockIdx.y, rc = blockIdx.z, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int Tq = a.Tq, Tk = a.Tk, pmax = a.pmax, nb = 2 * pmax + 1;
     for (int r = lane; r < nb; r += 64) { bins[wave][0][r] = 0.0; bins[wave][1][r] = 0.0; }
     __builtin_amdgcn_wave_barrier();
     double lo1 = 0.0, lo2 = 0.0, hi1 = 0.0, hi2 = 0.0;
     const size_t base = ((size_t)b * a.heads + h) * Tq * Tk;
-    for (int i = wave; i < Tq; i += 4) {
-        const float* r1 = a.dsim + base + (size_t)i * Tk;
-        const float* r2 = a.dG + base + (size_t)i * Tk;
+    const int iend = (rc + 1) * ATB_TROWS < Tq ? (rc + 1) * ATB_TROWS : Tq;
+    for (int i0 = rc * ATB_TROWS + wave; i0 < iend; i0 += 8) {             // two rows of the wave per trip: their loads go out together
+        const int i1 = i0 + 4;
+        const bool two = i1 < iend;
         for (int j0 = 0; j0 < Tk; j0 += 64) {
             const int j = j0 + lane;
-            if (j < Tk) {
-                const double v1 = (double)r1[j], v2 = (double)r2[j];
+            const bool in = j < Tk;
+            const int jc = in ? j : Tk - 1;
+            const size_t o0 = base + (size_t)i0 * Tk + jc, o1 = base + (size_t)(two ? i1 : i0) * Tk + jc;
+            const float f01 = a.dsim[o0], f02 = a.dG[o0], f11 = a.dsim[o1], f12 = a.dG[o1];
+            auto put = [&](int i, float f1, float f2) {
+                const double v1 = (double)f1, v2 = (double)f2;
                 const int off = j - i;
                 if (off <= -pmax) { lo1 += v1; lo2 += v2; }
                 else if (off >= pmax) { hi1 += v1; hi2 += v2; }
                 else { bins[wave][0][off + pmax] += v1; bins[wave][1][off + pmax] += v2; }
-            }
+            };
+            if (in) put(i0, f01, f02);
+            __builtin_amdgcn_wave_barrier();
+            if (in && two) put(i1, f11, f12);
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -475,7 +484,7 @@ __global__ __launch_bounds__(256) void attn_bwd_tables_rows_kernel(const AttnBwd
         double s2 = (bins[0][1][r] + bins[1][1][r]) + (bins[2][1][r] + bins[3][1][r]);
         if (r == 0) { s1 += (edge[0][0] + edge[1][0]) + (edge[2][0] + edge[3][0]); s2 += (edge[0][1] + edge[1][1]) + (edge[2][1] + edge[3][1]); }
         if (r == nb - 1) { s1 += (edge[0][2] + edge[1][2]) + (edge[2][2] + edge[3][2]); s2 += (edge[0][3] + edge[1][3]) + (edge[2][3] + edge[3][3]); }
-        const size_t o = 2 * (((size_t)b * nb + r) * a.heads + h);
+        const size_t o = 2 * ((((size_t)b * gridDim.z + rc) * nb + r) * a.heads + h);      // part rows: (batch row, row chunk)
         part[o] = s1 * (double)a.scale;
         part[o + 1] = s2;
     }
@@ -555,6 +564,8 @@ void launch_geglu_bwd(hipStream_t st, const float* u, const float* df, float* du
     const long long n = (long long)B * Ch * T;
     hipLaunchKernelGGL(geglu_bwd_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 8192)), dim3(256), 0, st, u, df, du, B, Ch, T);
 }
+// fp64 pair rows of tab_part: one per (batch row, chunk of ATB_TROWS query rows) in the row-major table kernel, one per batch row otherwise
+int attn_bwd_table_rows(int B, int Tq, int pmax) { return pmax <= ATB_PMAX ? B * cdiv(Tq, ATB_TROWS) : B; }
 void launch_attention_bwd(hipStream_t st, const AttnBwdArgs& a) {
     MUGD_CHECK(a.d >= 4 && a.d <= 64 && a.d % 4 == 0 && a.Tk >= 1 && a.Tk <= ATB_TK, -2, "attention backward: head dim 4..64 (multiple of 4), at most 1024 keys");
     MUGD_CHECK(a.tab_part, -2, "attention backward: no partial buffer for the table gradients");
@@ -570,8 +581,9 @@ void launch_attention_bwd(hipStream_t st, const AttnBwdArgs& a) {
     else if (qf <= 4096) hipLaunchKernelGGL(attn_bwd_cols_lds_kernel<4096>, dim3(cdiv(a.Tk, 64), a.heads, a.B), dim3(256), 0, st, a);
     else if (qf <= 8192) hipLaunchKernelGGL(attn_bwd_cols_lds_kernel<8192>, dim3(cdiv(a.Tk, 64), a.heads, a.B), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(attn_bwd_cols_kernel, dim3(cdiv(a.Tk, 64), a.heads, a.B), dim3(256), 0, st, a);
-    if (a.pmax <= ATB_PMAX) hipLaunchKernelGGL(attn_bwd_tables_rows_kernel, dim3(a.heads, a.B), dim3(256), 0, st, a, a.tab_part);
+    const int rows = attn_bwd_table_rows(a.B, a.Tq, a.pmax);
+    if (a.pmax <= ATB_PMAX) hipLaunchKernelGGL(attn_bwd_tables_rows_kernel, dim3(a.heads, a.B, rows / a.B), dim3(256), 0, st, a, a.tab_part);
     else hipLaunchKernelGGL(attn_bwd_tables_kernel, dim3(2 * a.pmax + 1, a.heads, a.B), dim3(256), 0, st, a, a.tab_part);
     const int n = (2 * a.pmax + 1) * a.heads;
-    if (!a.defer_tables) hipLaunchKernelGGL(attn_tables_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, a.tab_part, a.drel, a.dcemb, a.B, n);
+    if (!a.defer_tables) hipLaunchKernelGGL(attn_tables_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, a.tab_part, a.drel, a.dcemb, rows, n);
 }

@@ -346,10 +346,11 @@ struct AttnBwdArgs {         // layouts as AttnArgs; dout = gradient of the atte
     float* Amat; float* dsim; float* dG;      // scratch, (B, heads, Tq, Tk) each
     float* dq; float* dk; float* dv;          // same strides as q / k / v
     float* drel; float* dcemb;                // (2 pmax + 1, heads)
-    double* tab_part;                         // scratch, (B, 2 pmax + 1, heads, 2)
+    double* tab_part;                         // scratch, (attn_bwd_table_rows(), 2 pmax + 1, heads, 2)
     int skip_cols;                            // 1: dk / dv are produced by the caller (bf16 mode: two batched tconv GEMMs over dsim / Amat)
-    int defer_tables;                         // 1: drel / dcemb stay as the B fp64 pair rows of tab_part (TReduceDesc kind 2, n = (2 pmax + 1) heads)
+    int defer_tables;                         // 1: drel / dcemb stay as the fp64 pair rows of tab_part (TReduceDesc kind 2, n = (2 pmax + 1) heads, KS = attn_bwd_table_rows())
 };
+int attn_bwd_table_rows(int B, int Tq, int pmax);
 void launch_attention_bwd(hipStream_t st, const AttnBwdArgs& a);
 // k_train_s4.hip: S4 layer backward pieces
 struct S4GenBwdArgs {        // gradient of launch_s4_kernel_gen's output k (H, L) w.r.t. its parameters (either Cauchy form)
@@ -384,7 +385,7 @@ struct TConvArgs {           // y[b][m][t] = bias[m] + rowadd[b][m] + resid[b][m
     const float* resid;              // (B, M, Tout) or null (may alias y)
     float* y;                        // (B, M, Tout)
     int B, C, Tin, M, Tout, taps, dil, stride, pad, ups;
-    int nkb, gx, gy;                 // set by the launcher
+    int nkb, gx, gy, tpw;            // set by the launcher (tpw: consecutive time tiles per workgroup)
 };
 struct TWgradArgs {          // dW[m][c][tap] = sum_{b,t} dY[b][m][t] X[b][c][stride t + tap dil - pad]
     const float* dY; const float* X; float* dW;

@@ -547,7 +547,8 @@ int mugd_train_transformer(mugd_ctx* ctx, const float* const* P, const float* x,
         float *df = buf((size_t)B * Ch * T), *du = buf(2 * (size_t)B * Ch * T);
         const size_t nm = (size_t)B * heads * T * std::max(T, Tk);
         float *Am = buf(nm), *dsm = buf(nm), *dGm = buf(nm);
-        double* tabp = reinterpret_cast<double*>(buf((size_t)B * (2 * pmax + 1) * heads * 4));
+        const int trows = attn_bwd_table_rows(B, T, pmax);
+        double* tabp = reinterpret_cast<double*>(buf((size_t)trows * (2 * pmax + 1) * heads * 4));
         auto attn_bwd = [&](const float* q, const float* k, const float* v, const float* dO, int tk, int rel_i, int cemb_i) {
             AttnBwdArgs a{};
             a.q = q; a.q_bstride = C * T; a.k = k; a.k_bstride = C * tk; a.v = v; a.v_bstride = C * tk; a.dout = dO; a.o_bstride = C * T;
@@ -559,10 +560,10 @@ int mugd_train_transformer(mugd_ctx* ctx, const float* const* P, const float* x,
             const bool gemm_cols = c.train_bf16 && T % 16 == 0;
             a.skip_cols = gemm_cols ? 1 : 0;
             if (ctx->step.on) {                     // the table gradients' sum over batch rows joins the step's reduction table
-                const size_t tb = (size_t)B * (2 * pmax + 1) * heads * 16;
+                const size_t tb = (size_t)trows * (2 * pmax + 1) * heads * 16;
                 a.tab_part = static_cast<double*>(ctx->pool.take(tb + 8192));
                 a.defer_tables = 1;
-                queue_reduce(ctx, a.tab_part, a.tab_part, a.drel, (long long)(2 * pmax + 1) * heads, B, 2, a.dcemb);
+                queue_reduce(ctx, a.tab_part, a.tab_part, a.drel, (long long)(2 * pmax + 1) * heads, trows, 2, a.dcemb);
             }
             launch_attention_bwd(st, a);
             if (gemm_cols) {
