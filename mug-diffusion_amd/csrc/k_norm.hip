@@ -40,11 +40,17 @@ __global__ __launch_bounds__(256) void group_norm_kernel(const GnArgs a) {
         const float* p = gn_chan_ptr(a, b, c_lo + c);
         if (VEC4) {
             const float4* p4 = reinterpret_cast<const float4*>(p);
-            for (int t = lane; t < (T >> 2); t += 64) {
-                const float4 v = p4[t];
+            auto add = [&](const float4 v) {
                 s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
                 q += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+            };
+            const int T4 = T >> 2;
+            int t = lane;
+            for (; t + 192 < T4; t += 256) {       // four loads in flight per lane: long rows stream from HBM and bytes in flight set the rate (same order of sums)
+                const float4 v0 = p4[t], v1 = p4[t + 64], v2 = p4[t + 128], v3 = p4[t + 192];
+                add(v0); add(v1); add(v2); add(v3);
             }
+            for (; t < T4; t += 64) add(p4[t]);
         } else {
             for (int t = lane; t < T; t += 64) { const double v = p[t]; s += v; q += v * v; }
         }
@@ -67,13 +73,19 @@ __global__ __launch_bounds__(256) void group_norm_kernel(const GnArgs a) {
         if (VEC4) {
             const float4* p4 = reinterpret_cast<const float4*>(p);
             float4* o4 = reinterpret_cast<float4*>(o);
-            for (int t = lane; t < (T >> 2); t += 64) {
-                float4 v = p4[t];
+            auto out = [&](int t, float4 v) {
                 v.x = (v.x - mean) * ga + be; v.y = (v.y - mean) * ga + be;
                 v.z = (v.z - mean) * ga + be; v.w = (v.w - mean) * ga + be;
                 if (a.silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
                 o4[t] = v;
+            };
+            const int T4 = T >> 2;
+            int t = lane;
+            for (; t + 192 < T4; t += 256) {
+                const float4 v0 = p4[t], v1 = p4[t + 64], v2 = p4[t + 128], v3 = p4[t + 192];
+                out(t, v0); out(t + 64, v1); out(t + 128, v2); out(t + 192, v3);
             }
+            for (; t < T4; t += 64) out(t, p4[t]);
         } else {
             for (int t = lane; t < T; t += 64) {
                 float v = (p[t] - mean) * ga + be;

@@ -249,8 +249,12 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
         float hlo[NH], hhi[NH];
         float xlo[NIT], xhi[NIT];
     };
-    XRegs Xa, Xb;                                    // ping-pong: the activation stream runs TWO stages ahead of the matrix pipe
-    u32x4 Aa[KSUB * TAPS], Ab[KSUB * TAPS];          // ping-pong weight fragments (one stage ahead: L2 hits): no register copies in the loop
+    // The activation stream runs D stages ahead of the matrix pipe in a ring of register sets.  FAST: D = 4 -- a stage is 8.5 KB per
+    // workgroup, two workgroups per CU: 4 stages keep ~68 KB per CU in flight, what 8 TB/s x ~2 us of memory latency needs (with 2 the
+    // big wave-encoder layers sat at 3 TB/s); a FAST stage is only 10..20 registers.  The generic form (18+ registers per stage) keeps D = 2.
+    constexpr int D = FAST ? 4 : 2;
+    XRegs X[D];
+    u32x4 A[2][KSUB * TAPS];                          // ping-pong weight fragments (one stage ahead: L2 hits): no register copies in the loop
 
     // raw, unconditional loads; nothing here USES a loaded value, so the loads stay in flight across the MFMAs of the stages in front
     auto load_x = [&](int j, int s, XRegs& X) {             // tile j of the workgroup (FAST; 0 otherwise), stage s
@@ -366,33 +370,35 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
         if (more) load_resid(j + 1);
     };
     // One stage of the flattened (tile, stage) sequence g = j * nstage + s.  Program order = request order (loads complete in order): the
-    // NEXT stage's weight fragments first, then the window two stages ahead -- waiting for the fragments at the top of the next stage then
-    // leaves that window in flight; this stage on the matrix pipe; then the window of the next stage (requested a whole stage ago) goes
+    // NEXT stage's weight fragments first, then the window D stages ahead -- waiting for the fragments at the top of the next stage then
+    // leaves the windows behind them in flight; this stage on the matrix pipe; then the window of the next stage (requested a whole stage ago) goes
     // to the other LDS buffer; behind a tile's last stage, its epilogue (the next tile's first windows are parked / in flight by then).
     const int G = ntile * nstage;
-    int j0 = 0, s0 = 0;                                  // (tile, stage) of g; g + 1 and g + 2 follow by carry
-    auto step = [&](int g, const u32x4 (&A)[KSUB * TAPS], u32x4 (&An)[KSUB * TAPS], XRegs& Xfar, const XRegs& Xnext) {
-        int s1 = s0 + 1, j1 = j0;
-        if (s1 == nstage) { s1 = 0; ++j1; }
-        int s2 = s1 + 1, j2 = j1;
-        if (s2 == nstage) { s2 = 0; ++j2; }
-        if (g + 1 < G) load_a(s1, An);
-        if (g + 2 < G) load_x(j2, s2, Xfar);
-        if (active) compute(g & 1, A);
-        if (g + 1 < G) park(j1, s1, (g + 1) & 1, Xnext);
-        if (FAST && s0 == nstage - 1) epilogue(j0, j0 + 1 < ntile);
-        __syncthreads();
-        s0 = s1; j0 = j1;
-    };
-
-    load_x(0, 0, Xa);
-    load_a(0, Aa);
-    if (G > 1) load_x(nstage > 1 ? 0 : 1, nstage > 1 ? 1 : 0, Xb);
-    park(0, 0, 0, Xa);
+    auto adv = [&](int& j, int& st) { if (++st == nstage) { st = 0; ++j; } };
+    int jf = 0, sf = 0;                                  // (tile, stage) of the next window to request
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+        if (u < G) load_x(jf, sf, X[u]);
+        adv(jf, sf);
+    }
+    load_a(0, A[0]);
+    park(0, 0, 0, X[0]);
     __syncthreads();
-    for (int g = 0; g < G; g += 2) {
-        step(g, Aa, Ab, Xa, Xb);                     // window g + 2 -> Xa (its old content, stage g, is in LDS), park stage g + 1 from Xb
-        if (g + 1 < G) step(g + 1, Ab, Aa, Xb, Xa);
+    int jc = 0, sc = 0, jn = 0, sn = 0;                  // (tile, stage) of g and of g + 1
+    adv(jn, sn);
+    for (int g = 0; g < G; g += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {                    // g + u: LDS buffer u & 1, fragments A[u & 1]; ring slot u is free (stage g + u is in LDS)
+            if (g + u < G) {
+                if (g + u + 1 < G) load_a(sn, A[(u + 1) & 1]);
+                if (g + u + D < G) load_x(jf, sf, X[u]);
+                if (active) compute(u & 1, A[u & 1]);
+                if (g + u + 1 < G) park(jn, sn, (u + 1) & 1, X[(u + 1) % D]);
+                if (FAST && sc == nstage - 1) epilogue(jc, jc + 1 < ntile);
+                __syncthreads();
+                adv(jc, sc); adv(jn, sn); adv(jf, sf);
+            }
+        }
     }
     if (FAST) return;
     // ---- generic epilogue: accumulator register i of lane (h, n) is row (i & 3) + 8 (i >> 2) + 4 h, column n

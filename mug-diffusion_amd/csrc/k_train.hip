@@ -319,11 +319,16 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float* x, const 
         const float* p = xg + (size_t)c * T;
         if (VEC4) {
             const float4* p4 = reinterpret_cast<const float4*>(p);
-            for (int t = lane; t < T4; t += 64) {
-                const float4 v = p4[t];
+            auto add = [&](const float4 v) {
                 s1 += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
                 s2 += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+            };
+            int t = lane;
+            for (; t + 192 < T4; t += 256) {       // four loads in flight per lane (long rows stream from HBM: bytes in flight set the rate); same order of sums
+                const float4 v0 = p4[t], v1 = p4[t + 64], v2 = p4[t + 128], v3 = p4[t + 192];
+                add(v0); add(v1); add(v2); add(v3);
             }
+            for (; t < T4; t += 64) add(p4[t]);
         } else {
             for (int t = lane; t < T; t += 64) { const double v = p[t]; s1 += v; s2 += v * v; }
         }
@@ -354,14 +359,20 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float* x, const 
         if (VEC4) {
             const float4* p4 = reinterpret_cast<const float4*>(p);
             const float4* q4 = reinterpret_cast<const float4*>(q);
-            for (int t = lane; t < T4; t += 64) {
-                const float4 xv = p4[t], av = q4[t];
+            auto add = [&](const float4 xv, const float4 av) {
                 float xh, du;
                 elem(xv.x, av.x, gm, bt, xh, du); dgm += (double)du * xh; dbt += du;
                 elem(xv.y, av.y, gm, bt, xh, du); dgm += (double)du * xh; dbt += du;
                 elem(xv.z, av.z, gm, bt, xh, du); dgm += (double)du * xh; dbt += du;
                 elem(xv.w, av.w, gm, bt, xh, du); dgm += (double)du * xh; dbt += du;
+            };
+            int t = lane;
+            for (; t + 192 < T4; t += 256) {
+                const float4 x0 = p4[t], x1 = p4[t + 64], x2 = p4[t + 128], x3 = p4[t + 192];
+                const float4 a0 = q4[t], a1 = q4[t + 64], a2 = q4[t + 128], a3 = q4[t + 192];
+                add(x0, a0); add(x1, a1); add(x2, a2); add(x3, a3);
             }
+            for (; t < T4; t += 64) add(p4[t], q4[t]);
         } else {
             for (int t = lane; t < T; t += 64) {
                 float xh, du;
@@ -392,17 +403,26 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float* x, const 
             const float4* p4 = reinterpret_cast<const float4*>(p);
             const float4* q4 = reinterpret_cast<const float4*>(q);
             float4* o4 = reinterpret_cast<float4*>(o);
-            for (int t = lane; t < T4; t += 64) {
-                const float4 xv = p4[t], av = q4[t];
+            const float4* r4 = rg ? reinterpret_cast<const float4*>(rg + (size_t)c * T) : nullptr;
+            const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            auto out = [&](int t, const float4 xv, const float4 av, const float4 old) {
                 float4 r;
                 float xh, du;
                 elem(xv.x, av.x, gm, bt, xh, du); r.x = rstd * (du * gm - fm1 - xh * fm2);
                 elem(xv.y, av.y, gm, bt, xh, du); r.y = rstd * (du * gm - fm1 - xh * fm2);
                 elem(xv.z, av.z, gm, bt, xh, du); r.z = rstd * (du * gm - fm1 - xh * fm2);
                 elem(xv.w, av.w, gm, bt, xh, du); r.w = rstd * (du * gm - fm1 - xh * fm2);
-                if (rg) { const float4 old = reinterpret_cast<const float4*>(rg + (size_t)c * T)[t]; r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w; }
+                if (rg) { r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w; }
                 o4[t] = r;
+            };
+            int t = lane;
+            for (; t + 192 < T4; t += 256) {       // all loads of the four granules before the first store (resid may be dx itself: read first)
+                const float4 x0 = p4[t], x1 = p4[t + 64], x2 = p4[t + 128], x3 = p4[t + 192];
+                const float4 a0 = q4[t], a1 = q4[t + 64], a2 = q4[t + 128], a3 = q4[t + 192];
+                const float4 r0 = rg ? r4[t] : zero4, r1 = rg ? r4[t + 64] : zero4, r2 = rg ? r4[t + 128] : zero4, r3 = rg ? r4[t + 192] : zero4;
+                out(t, x0, a0, r0); out(t + 64, x1, a1, r1); out(t + 128, x2, a2, r2); out(t + 192, x3, a3, r3);
             }
+            for (; t < T4; t += 64) out(t, p4[t], q4[t], rg ? r4[t] : zero4);
         } else {
             for (int t = lane; t < T; t += 64) {
                 float xh, du;

@@ -66,7 +66,8 @@ def test_resblock_forward_backward_vs_autograd(lib, B, Cin, Cout, T, Kemb, group
 
 @pytest.mark.parametrize("B,Cin,Cout,T,taps,dil,mode,gn", [(2, 32, 48, 40, 3, 1, 0, False), (2, 32, 32, 64, 3, 4, 0, False), (1, 48, 32, 50, 3, 8, 0, False),
                                                            (2, 32, 64, 36, 1, 1, 0, False), (2, 32, 48, 40, 3, 1, 1, False), (2, 48, 32, 26, 3, 1, 2, False),
-                                                           (2, 64, 16, 40, 3, 1, 0, True), (2, 32, 32, 1024, 3, 2, 0, False), (2, 32, 32, 1024, 3, 1, 1, False)])
+                                                           (2, 64, 16, 40, 3, 1, 0, True), (2, 32, 32, 1024, 3, 2, 0, False), (2, 32, 32, 1024, 3, 1, 1, False),
+                                                           (1, 32, 16, 2200, 3, 1, 0, True)])      # the last: GroupNorm rows long enough for the 4-granule batches
 def test_conv_layer_forward_backward_vs_autograd(lib, B, Cin, Cout, T, taps, dil, mode, gn):
     """Plain / dilated conv (ResnetBlock, models.py:106-122), Downsample (pad right + stride 2, models.py:84-88), Upsample (nearest x2 +
     conv, models.py:66-70) and the GroupNorm + SiLU + conv head (unet.py:489-493): forward, dx, dw, db vs torch autograd."""
