@@ -101,7 +101,9 @@ constexpr int TC_BUF = 32 * 79 + 4;        // dwords per LDS buffer: the largest
 // FAST (stride 1, no upsample, Tin % 4 == 0 -- every layer of the model but its 6 resampling convs): the window's interior is staged
 // with 16-byte loads (a thread: 4 samples of two adjacent channels -> 4 bf16 pairs -> one ds_write_b128), the halo with scalar ones;
 // the generic form walks the window as a flat index with scalar loads.
-template <int TAPS, int NT, bool FAST>
+// RESID (FAST only): the launch has a residual operand; its prefetch registers (32 for NT = 2) are what decides between a window ring of
+// 4 stages (without) and of 2 (with) inside the 256 registers two waves per SIMD allow.
+template <int TAPS, int NT, bool FAST, bool RESID>
 __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
     constexpr int TC_TN = 32 * NT;
     constexpr int KSUB = (TAPS == 1 ? 4 : 2) * (NT == 1 ? 2 : 1);      // 16-channel blocks per stage: the narrow tile stages twice the channels (same bytes per stage, half the barriers / latency periods per FLOP)
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
     // requested in that shape; the generic form stores (and reads the residual) one dword per accumulator register.
     float eadd[16];
     float eres[FAST ? 1 : NT][FAST ? 1 : 16];
-    float4 rres[FAST ? NT : 1][FAST ? 4 : 1];
+    float4 rres[FAST && RESID ? NT : 1][FAST && RESID ? 4 : 1];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         int m = mtile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
         }
     }
     auto load_resid = [&](int j) {                        // FAST: the residual granules of tile j
+        if (!RESID) return;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
                 int m = mtile * 32 + (idx >> 3), t = t0 + j * TC_TN + nt * 32 + (idx & 7) * 4;
                 m = m < a.M ? m : a.M - 1;
                 t = t < a.Tout ? t : a.Tout - 4;                   // Tout % 4 == 0: a granule is wholly inside or outside
-                rres[nt][k] = a.resid ? *reinterpret_cast<const float4*>(a.resid + ((size_t)b * a.M + m) * a.Tout + t) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rres[RESID ? nt : 0][RESID ? k : 0] = *reinterpret_cast<const float4*>(a.resid + ((size_t)b * a.M + m) * a.Tout + t);
             }
     };
     if (FAST) load_resid(0);
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
     // The activation stream runs D stages ahead of the matrix pipe in a ring of register sets.  FAST: D = 4 -- a stage is 8.5 KB per
     // workgroup, two workgroups per CU: 4 stages keep ~68 KB per CU in flight, what 8 TB/s x ~2 us of memory latency needs (with 2 the
     // big wave-encoder layers sat at 3 TB/s); a FAST stage is only 10..20 registers.  The generic form (18+ registers per stage) keeps D = 2.
-    constexpr int D = FAST ? 4 : 2;
+    constexpr int D = FAST && !RESID ? 4 : 2;
     XRegs X[D];
     u32x4 A[2][KSUB * TAPS];                          // ping-pong weight fragments (one stage ahead: L2 hits): no register copies in the loop
 
@@ -360,8 +363,10 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
                     const int idx = lane + 64 * k, row = idx >> 3, c4 = (idx & 7) * 4;
                     const int m = mtile * 32 + row, t = t0 + j * TC_TN + nt * 32 + c4;
                     float4 v = *reinterpret_cast<const float4*>(ob + row * OS + c4);
-                    const float4 r = rres[FAST ? nt : 0][FAST ? k : 0];
-                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                    if (RESID) {
+                        const float4 r = rres[FAST && RESID ? nt : 0][FAST && RESID ? k : 0];
+                        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                    }
                     if (m < a.M && t < a.Tout) *reinterpret_cast<float4*>(a.y + ((size_t)b * a.M + m) * a.Tout + t) = v;
                 }
             }
@@ -771,10 +776,11 @@ void launch_tconv_bf16(hipStream_t st, const TConvArgs& a0) {
         if (const char* e = getenv("MUGD_TCONV_TPW")) { const int v = atoi(e); if (v >= 1 && v <= 64) a.tpw = v; }      // development / test knob
     }
     const dim3 grid((unsigned)cdiv(a.gx, a.tpw) * a.gy * a.B);
-#define MUGD_TC(T, N)                                                                                     \
-    do {                                                                                                  \
-        if (fast) hipLaunchKernelGGL((tconv_bf16_kernel<T, N, true>), grid, dim3(256), 0, st, a);         \
-        else hipLaunchKernelGGL((tconv_bf16_kernel<T, N, false>), grid, dim3(256), 0, st, a);             \
+#define MUGD_TC(T, N)                                                                                                     \
+    do {                                                                                                                  \
+        if (fast && a.resid) hipLaunchKernelGGL((tconv_bf16_kernel<T, N, true, true>), grid, dim3(256), 0, st, a);         \
+        else if (fast) hipLaunchKernelGGL((tconv_bf16_kernel<T, N, true, false>), grid, dim3(256), 0, st, a);              \
+        else hipLaunchKernelGGL((tconv_bf16_kernel<T, N, false, true>), grid, dim3(256), 0, st, a);                        \
     } while (0)
     if (a.taps == 1) { if (nt == 1) MUGD_TC(1, 1); else MUGD_TC(1, 2); }
     else { if (nt == 1) MUGD_TC(3, 1); else MUGD_TC(3, 2); }
