@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256) void group_norm_kernel(const GnArgs a) {
     var_d = var_d > 0.0 ? var_d : 0.0;
     const float mean = (float)mean_d;
     const float rstd = (float)(1.0 / sqrt(var_d + (double)a.eps));
+    if (a.stats && threadIdx.x == 0) { a.stats[2 * ((size_t)b * a.groups + g)] = mean; a.stats[2 * ((size_t)b * a.groups + g) + 1] = rstd; }
 
     for (int c = wave; c < cg; c += 4) {
         const float* p = gn_chan_ptr(a, b, c_lo + c);

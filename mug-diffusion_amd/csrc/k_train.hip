@@ -304,7 +304,8 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 
 template <bool SILU, bool VEC4>
 __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float* x, const float* da, const float* gamma, const float* beta, float eps,
-                                                          float* dx, double* part, int B, int C, int T, int groups, const float* resid) {
+                                                          float* dx, double* part, int B, int C, int T, int groups, const float* resid,
+                                                          const float* stats) {
     __shared__ double red[4][4];
     const int g = blockIdx.x, b = blockIdx.y, cg = C / groups, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const double n = (double)cg * (double)T;
@@ -313,7 +314,12 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float* x, const 
     float* dg = dx + ((size_t)b * C + (size_t)g * cg) * T;
     const float* rg = resid ? resid + ((size_t)b * C + (size_t)g * cg) * T : nullptr;      // added to dx (may be dx itself: read before the write)
     const int T4 = T >> 2;
-    // ---- pass A: group statistics
+    // ---- pass A: group statistics (skipped when the forward pass kept them)
+    float rstd, mu;
+    if (stats) {
+        mu = stats[2 * ((size_t)b * groups + g)];
+        rstd = stats[2 * ((size_t)b * groups + g) + 1];
+    } else {
     double s1 = 0.0, s2 = 0.0;
     for (int c = wave; c < cg; c += 4) {
         const float* p = xg + (size_t)c * T;
@@ -340,8 +346,9 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const float* x, const 
     const double mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / n;
     double var = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / n - mean * mean;
     var = var > 0.0 ? var : 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float mu = (float)mean;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+    mu = (float)mean;
+    }
     // the normalised gradient of one element: dxh = da silu'(u) gamma, with xh and u recomputed
     auto elem = [&](float xv, float av, float gm, float bt, float& xh, float& du) {
         xh = (xv - mu) * rstd;
@@ -604,9 +611,10 @@ void launch_pair_sum(hipStream_t st, const float* src, float* dst, long long n) 
     hipLaunchKernelGGL(pair_sum_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 8192)), dim3(256), 0, st, src, dst, n);
 }
 void launch_gn_bwd(hipStream_t st, const float* x, const float* da, const float* gamma, const float* beta, float eps, float* dx,
-                   float* dgamma, float* dbeta, int B, int C, int T, int groups, const float* resid, int silu, double* partial, bool reduce_params) {
+                   float* dgamma, float* dbeta, int B, int C, int T, int groups, const float* resid, int silu, double* partial, bool reduce_params,
+                   const float* stats) {
     MUGD_CHECK(C % groups == 0, -2, "gn_bwd: channels not divisible by groups");
-#define MUGD_GNB(S, V) hipLaunchKernelGGL((gn_silu_bwd_kernel<S, V>), dim3(groups, B), dim3(256), 0, st, x, da, gamma, beta, eps, dx, partial, B, C, T, groups, resid)
+#define MUGD_GNB(S, V) hipLaunchKernelGGL((gn_silu_bwd_kernel<S, V>), dim3(groups, B), dim3(256), 0, st, x, da, gamma, beta, eps, dx, partial, B, C, T, groups, resid, stats)
     if (T % 4 == 0) { if (silu) MUGD_GNB(true, true); else MUGD_GNB(false, true); }
     else { if (silu) MUGD_GNB(true, false); else MUGD_GNB(false, false); }
 #undef MUGD_GNB

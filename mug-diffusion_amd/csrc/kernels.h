@@ -169,6 +169,7 @@ struct GnArgs {
     const float* gamma; const float* beta;
     float eps;
     float* y;                // (B, Ctot, T) contiguous
+    float* stats;            // null, or (B, groups, 2): the group's {mean, rstd} as applied, kept for the backward pass (training)
 };
 void launch_group_norm(hipStream_t st, const GnArgs& a);
 
@@ -325,9 +326,10 @@ void launch_pair_sum(hipStream_t st, const float* src, float* dst, long long n);
 // GroupNorm backward with (silu = 1) or without (0) the SiLU that follows it; resid (nullable, may be dx): added to dx (an identity skip's
 // gradient, or accumulation).  reduce_params = false: dgamma / dbeta stay as the per-batch-row fp64 pairs in `partial` ([b][c][2]) for a
 // later reduction (TReduceDesc kind 2)
+// stats (nullable): the forward pass's (B, groups, 2) {mean, rstd} (GnArgs::stats) -- saves the backward kernel its statistics pass over x
 void launch_gn_bwd(hipStream_t st, const float* x, const float* da, const float* gamma, const float* beta, float eps, float* dx,
                    float* dgamma, float* dbeta, int B, int C, int T, int groups, const float* resid, int silu, double* partial /* B * C * 2 */,
-                   bool reduce_params = true);
+                   bool reduce_params = true, const float* stats = nullptr);
 // k_train_tf.hip: LayerNorm over channels (stat: (B, T, 2) scratch), GEGLU, relative-position attention
 // scratch: ln_bwd_scratch_bytes().  reduce_params = false: when the return value KS is > 0, dgamma / dbeta are left as KS fp64 pair rows
 // in scratch ([k][c][2]; TReduceDesc kind 2 / launch_pair_reduce), 0: they are final

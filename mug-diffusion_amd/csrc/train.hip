@@ -283,27 +283,30 @@ void run_wgrad(Ctx& c, Scratch& sc, const float* dY, const float* A, float* dW, 
 }
 
 void run_gn_bwd(Ctx& c, Scratch& sc, const float* x, const float* da, const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta,
-                int B, int C, int T, int groups, int silu, const float* resid = nullptr) {
+                int B, int C, int T, int groups, int silu, const float* resid = nullptr, const float* stats = nullptr) {
     if (sc.ctx->step.on) {                 // the sum over batch rows of the dgamma / dbeta pairs joins the step's table of reductions
         double* part = static_cast<double*>(sc.pool.take((size_t)B * C * 16 + 8192));
-        launch_gn_bwd(c.stream, x, da, gamma, beta, 1e-6f, dx, dgamma, dbeta, B, C, T, groups, resid, silu, part, false);
+        launch_gn_bwd(c.stream, x, da, gamma, beta, 1e-6f, dx, dgamma, dbeta, B, C, T, groups, resid, silu, part, false, stats);
         queue_reduce(sc.ctx, part, part, dgamma, C, B, 2, dbeta);
         return;
     }
     double* part = reinterpret_cast<double*>(sc.get((size_t)B * C * 4, false, c.stream));
-    launch_gn_bwd(c.stream, x, da, gamma, beta, 1e-6f, dx, dgamma, dbeta, B, C, T, groups, resid, silu, part);
+    launch_gn_bwd(c.stream, x, da, gamma, beta, 1e-6f, dx, dgamma, dbeta, B, C, T, groups, resid, silu, part, true, stats);
 }
 
-void run_group_norm_silu(Ctx& c, const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T, int groups) {
+// stats (nullable): (B, groups, 2) {mean, rstd} kept with the block's intermediates; the backward kernel then skips its statistics pass
+void run_group_norm_silu(Ctx& c, const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T, int groups, float* stats = nullptr) {
     GnArgs a{};
+    a.stats = stats;
     a.seg[0] = NormSeg{x, C, 0};
     a.nseg = 1; a.Ctot = C; a.T = T; a.groups = groups; a.B = B; a.silu = 1;
     a.gamma = gamma; a.beta = beta; a.eps = 1e-6f; a.y = y;
     launch_group_norm(c.stream, a);
 }
 
-void run_group_norm_plain(Ctx& c, const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T, int groups) {
+void run_group_norm_plain(Ctx& c, const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T, int groups, float* stats = nullptr) {
     GnArgs a{};
+    a.stats = stats;
     a.seg[0] = NormSeg{x, C, 0};
     a.nseg = 1; a.Ctot = C; a.T = T; a.groups = groups; a.B = B; a.silu = 0;
     a.gamma = gamma; a.beta = beta; a.eps = 1e-6f; a.y = y;
@@ -343,11 +346,13 @@ void resblock_impl(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x,
     float* E = emb ? in.get((size_t)B * Cout) : nullptr;
     float* h = in.get(nout);
     float* a2 = in.get(nout);
+    float* st1 = in.get((size_t)B * groups * 2);
+    float* st2 = in.get((size_t)B * groups * 2);
     if (!in.replay) {
-        run_group_norm_silu(c, x, p->gn1_w, p->gn1_b, a1, B, Cin, T, groups);
+        run_group_norm_silu(c, x, p->gn1_w, p->gn1_b, a1, B, Cin, T, groups, st1);
         if (emb) launch_linear_small(st, LinSmallArgs{emb, p->emb_w, p->emb_b, E, B, Kemb, Cout, 1, 0, Kemb, Cout});
         run_conv(c, sc, a1, p->conv1_w, p->conv1_b, E, Cout, nullptr, h, B, Cin, T, Cout, 3, d1, d1);
-        run_group_norm_silu(c, h, p->gn2_w, p->gn2_b, a2, B, Cout, T, groups);
+        run_group_norm_silu(c, h, p->gn2_w, p->gn2_b, a2, B, Cout, T, groups, st2);
         if (p->skip_w) {
             run_conv(c, sc, x, p->skip_w, p->skip_b, nullptr, 0, nullptr, y, B, Cin, T, Cout, 1, 0);
             run_conv(c, sc, a2, p->conv2_w, p->conv2_b, nullptr, 0, y, y, B, Cout, T, Cout, 3, d2, d2);
@@ -364,7 +369,7 @@ void resblock_impl(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x,
         // out_layers conv: dW2, db2, da2 = conv3(dy; W2 transposed + flipped)
         run_wgrad(c, sc, dy, a2, g->conv2_w, B, Cout, Cout, T, T, 3, d2, d2, 1, 0, g->conv2_b);
         run_dgrad(c, sc, dy, p->conv2_w, wt, nullptr, da2, B, Cout, Cout, T, 3, d2, d2);
-        run_gn_bwd(c, sc, h, da2, p->gn2_w, p->gn2_b, dh, g->gn2_w, g->gn2_b, B, Cout, T, groups, 1);
+        run_gn_bwd(c, sc, h, da2, p->gn2_w, p->gn2_b, dh, g->gn2_w, g->gn2_b, B, Cout, T, groups, 1, nullptr, st2);
         if (emb) {          // h = conv1 + b1 + E: time-embedding branch
             float* dE = sc.get((size_t)B * Cout, false, st);
             launch_time_sum(st, dh, dE, B * Cout, T);
@@ -372,7 +377,7 @@ void resblock_impl(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x,
         }
         run_wgrad(c, sc, dh, a1, g->conv1_w, B, Cout, Cin, T, T, 3, d1, d1, 1, 0, g->conv1_b);
         run_dgrad(c, sc, dh, p->conv1_w, wt, nullptr, da1, B, Cout, Cin, T, 3, d1, d1);
-        run_gn_bwd(c, sc, x, da1, p->gn1_w, p->gn1_b, dx, g->gn1_w, g->gn1_b, B, Cin, T, groups, 1, p->skip_w ? nullptr : dy);      // identity skip: dx += dy
+        run_gn_bwd(c, sc, x, da1, p->gn1_w, p->gn1_b, dx, g->gn1_w, g->gn1_b, B, Cin, T, groups, 1, p->skip_w ? nullptr : dy, st1);      // identity skip: dx += dy
         if (p->skip_w) {
             run_wgrad(c, sc, dy, x, g->skip_w, B, Cout, Cin, T, T, 1, 0, 1, 1, 0, g->skip_b);
             run_dgrad(c, sc, dy, p->skip_w, wt, dx, dx, B, Cout, Cin, T, 1, 0);
@@ -402,9 +407,11 @@ int mugd_train_conv(mugd_ctx* ctx, const float* w, const float* bias, const floa
         const size_t nin = (size_t)B * Cin * Tin;
         Inter in(ctx, dy, state);
         const float* a = x;
+        float* gst = nullptr;
         if (gn_w) {
             float* an = in.get(nin);
-            if (!in.replay) run_group_norm_silu(c, x, gn_w, gn_b, an, B, Cin, Tin, groups);
+            gst = in.get((size_t)B * groups * 2);
+            if (!in.replay) run_group_norm_silu(c, x, gn_w, gn_b, an, B, Cin, Tin, groups, gst);
             a = an;
         }
         if (!in.replay) run_conv(c, sc, a, w, bias, nullptr, 0, nullptr, y, B, Cin, Tin, Cout, taps, pad, dil, stride, ups, Tout);
@@ -432,7 +439,7 @@ int mugd_train_conv(mugd_ctx* ctx, const float* w, const float* bias, const floa
             run_dgrad(c, sc, dy, w, wt, nullptr, dxu, B, Cout, Cin, Tout, 3, 1);
             launch_pair_sum(st, dxu, da, (long long)nin);
         }
-        if (gn_w) run_gn_bwd(c, sc, x, da, gn_w, gn_b, dx, dgn_w, dgn_b, B, Cin, Tin, groups, 1);
+        if (gn_w) run_gn_bwd(c, sc, x, da, gn_w, gn_b, dx, dgn_w, dgn_b, B, Cin, Tin, groups, 1, nullptr, gst);
     });
 }
 
@@ -452,10 +459,11 @@ int mugd_train_s4layer(mugd_ctx* ctx, const float* const* P, const float* x, con
         Inter in(ctx, dy, state);
         float *k = in.get((size_t)H * T), *kf = in.get((size_t)H * (Lint / 2 + 1) * 2);
         float *nrm = in.get(n), *pre = in.get(n), *g = in.get(n), *v = in.get(2 * n), *f = in.get(n);
+        float* gst = in.get((size_t)B * groups * 2);
         if (!in.replay) {
             S4GenArgs ga{P[MUGD_S4_K_C], P[MUGD_S4_K_B], P[MUGD_S4_K_P], P[MUGD_S4_K_INV_W_REAL], P[MUGD_S4_K_W_IMAG], P[MUGD_S4_K_LOG_DT], H, N, Lint, T, kf, k, c.s4_symmetric ? 1 : 0};
             launch_s4_kernel_gen(st, ga);
-            run_group_norm_plain(c, x, P[MUGD_S4_NORM_W], P[MUGD_S4_NORM_B], nrm, B, H, T, groups);
+            run_group_norm_plain(c, x, P[MUGD_S4_NORM_W], P[MUGD_S4_NORM_B], nrm, B, H, T, groups, gst);
             launch_s4_conv_train_fwd(st, nrm, k, P[MUGD_S4_D], pre, g, B, H, T);
             lt.fwd(g, P[MUGD_S4_OUT_LIN_W], P[MUGD_S4_OUT_LIN_B], nullptr, v, H, 2 * H);
             launch_glu_fwd(st, v, f, B, H, T);
@@ -473,7 +481,7 @@ int mugd_train_s4layer(mugd_ctx* ctx, const float* const* P, const float* x, con
         S4GenBwdArgs gb{P[MUGD_S4_K_C], P[MUGD_S4_K_B], P[MUGD_S4_K_P], P[MUGD_S4_K_INV_W_REAL], P[MUGD_S4_K_W_IMAG], P[MUGD_S4_K_LOG_DT], H, N, Lint, T, dk,
                         G[MUGD_S4_K_C], G[MUGD_S4_K_B], G[MUGD_S4_K_P], G[MUGD_S4_K_INV_W_REAL], G[MUGD_S4_K_W_IMAG], G[MUGD_S4_K_LOG_DT], c.s4_symmetric ? 1 : 0};
         launch_s4_kernel_gen_bwd(st, gb);
-        run_gn_bwd(c, sc, x, dn, P[MUGD_S4_NORM_W], P[MUGD_S4_NORM_B], dx, G[MUGD_S4_NORM_W], G[MUGD_S4_NORM_B], B, H, T, groups, 0, dy);      // + the identity skip
+        run_gn_bwd(c, sc, x, dn, P[MUGD_S4_NORM_W], P[MUGD_S4_NORM_B], dx, G[MUGD_S4_NORM_W], G[MUGD_S4_NORM_B], B, H, T, groups, 0, dy, gst);      // + the identity skip
     });
 }
 
@@ -498,6 +506,7 @@ int mugd_train_transformer(mugd_ctx* ctx, const float* const* P, const float* x,
         float *n0 = in.get(n), *h0 = in.get(n), *l1 = in.get(n), *q1 = in.get(n), *k1 = in.get(n), *v1 = in.get(n), *o1 = in.get(n), *h1 = in.get(n);
         float *l2 = in.get(n), *q2 = in.get(n), *k2 = in.get(nk), *v2 = in.get(nk), *o2 = in.get(n), *h2 = in.get(n);
         float *l3 = in.get(n), *u = in.get(2 * (size_t)B * Ch * T), *f = in.get((size_t)B * Ch * T), *h3 = in.get(n);
+        float* gst = in.get((size_t)B * groups * 2);
         auto attn = [&](const float* q, const float* k, const float* v, float* o, int tk, const float* rel, const float* cemb) {
             AttnArgs a{};
             a.q = q; a.q_bstride = C * T; a.k = k; a.k_bstride = C * tk; a.v = v; a.v_bstride = C * tk; a.out = o; a.o_bstride = C * T;
@@ -506,7 +515,7 @@ int mugd_train_transformer(mugd_ctx* ctx, const float* const* P, const float* x,
         };
         const float* ctxp = context ? context : l2;
         if (!in.replay) {
-            run_group_norm_plain(c, x, P[MUGD_TF_NORM_W], P[MUGD_TF_NORM_B], n0, B, C, T, groups);
+            run_group_norm_plain(c, x, P[MUGD_TF_NORM_W], P[MUGD_TF_NORM_B], n0, B, C, T, groups, gst);
             lt.fwd(n0, P[MUGD_TF_PROJ_IN_W], P[MUGD_TF_PROJ_IN_B], nullptr, h0, C, C);
             launch_layer_norm(st, LnArgs{h0, l1, P[MUGD_TF_LN1_W], P[MUGD_TF_LN1_B], B, C, T, 1e-5f});
             lt.fwd(l1, P[MUGD_TF_A1_Q], nullptr, nullptr, q1, C, C);
@@ -609,7 +618,7 @@ int mugd_train_transformer(mugd_ctx* ctx, const float* const* P, const float* x,
         ln_bwd(h0, dl, P[MUGD_TF_LN1_W], dh, G[MUGD_TF_LN1_W], G[MUGD_TF_LN1_B]);      // dh = d h0
         // proj_in and the GroupNorm in front of it
         lt.bwd(n0, P[MUGD_TF_PROJ_IN_W], dh, da, false, G[MUGD_TF_PROJ_IN_W], G[MUGD_TF_PROJ_IN_B], C, C, wt);
-        run_gn_bwd(c, sc, x, da, P[MUGD_TF_NORM_W], P[MUGD_TF_NORM_B], dx, G[MUGD_TF_NORM_W], G[MUGD_TF_NORM_B], B, C, T, groups, 0, dy);      // + the identity skip
+        run_gn_bwd(c, sc, x, da, P[MUGD_TF_NORM_W], P[MUGD_TF_NORM_B], dx, G[MUGD_TF_NORM_W], G[MUGD_TF_NORM_B], B, C, T, groups, 0, dy, gst);      // + the identity skip
     });
 }
 
