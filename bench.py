@@ -410,7 +410,7 @@ def training_leg(a, lib, model, dev, world, rank, grouped, sync_all, bf16=True):
     through all three networks (mug/train.py TrainPlan: native block forward / backward entry points, blocks keep their forward
     intermediates, no host synchronisation inside the step) -> bucketed all-reduce of the 1327 gradient tensors overlapped with the
     backward sweep (RCCL when N > 1) -> AdamW on every tensor (one launch).  bf16: the GEMMs on the bf16 matrix cores with fp32
-    accumulation (configs[4]'s precision; everything else fp32); else the fp32-input MFMA parity mode.  1 warm-up + 3 timed steps,
+    accumulation (configs[4]'s precision; everything else fp32); else the fp32-input MFMA parity mode.  2 warm-up + 3 timed steps,
     barrier + synchronize on both sides, MAX over ranks; then one more step with an event pair around every GEMM launch for the
     GEMM roofline.  Reported next to the headline, never as it."""
     import torch.distributed as dist
@@ -435,7 +435,8 @@ def training_leg(a, lib, model, dev, world, rank, grouped, sync_all, bf16=True):
         return loss, grads
 
     try:
-        loss, grads = step(1)
+        loss, grads = step(0)                        # first sight: weights packed one by one, scratch pool filled
+        loss, grads = step(1)                        # steady state from here: one pack-table launch, one reduction-table launch per step
         sync_all()
         t0 = time.perf_counter()
         reps = 3
@@ -464,8 +465,11 @@ def training_leg(a, lib, model, dev, world, rank, grouped, sync_all, bf16=True):
             "value": Bt * world / dt, "unit": "samples/s", "ms_per_step": dt * 1e3, "global_batch": Bt * world, "dtype": "bf16" if bf16 else "f32",
             "loss": float(loss), "gradient_tensors": len(grads), "trainable_parameters": int(nparam),
             "algorithmic_tflops_whole_step": TRAIN_GFLOP_PER_SAMPLE * Bt / dt / 1e3,
-            "roofline": {"kernel": kern + ": all %d GEMM launches of one step, HIP event pair around each on the library stream (pack / split-K "
-                                         "reduce launches of a call included in its bracket)" % (prof["conv"]["launches"] + prof["wgrad"]["launches"]),
+            "roofline": {"kernel": kern + ": all %d GEMM launches of one step, HIP event pair around each on the library stream (bf16 mode: packed "
+                                         "weights come from the step bracket's cache and the split-K slices are summed by the step's one reduction "
+                                         "launch -- both outside the brackets; the wave encoder's 128-channel layers at 16k-32k frames are HBM-bound "
+                                         "on their fp32 activations, the U-Net's are launch-latency-bound: DESIGN.md 8c)"
+                                         % (prof["conv"]["launches"] + prof["wgrad"]["launches"]),
                          "bound": "mfma", "achieved": gemm_fl / (gemm_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
                          "frac": gemm_fl / (gemm_ms * 1e-3) / 1e12 / peak, "traffic": None,
                          "gemm_ms_per_step": gemm_ms, "gemm_share_of_step": gemm_ms / (dt * 1e3),

@@ -108,6 +108,7 @@ void mugd_destroy(mugd_ctx* ctx) {
     if (ctx->c.order_event) hipEventDestroy(ctx->c.order_event);
     if (ctx->c.scratch) hipFree(ctx->c.scratch);
     ctx->step.ring.release();
+    ctx->step.side.release();
     for (auto& e : ctx->step.packs) hipFree(e.dst);
     ctx->pool.release();
     for (auto& kv : ctx->c.resample_taps) hipFree(kv.second);

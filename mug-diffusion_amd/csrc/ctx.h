@@ -95,8 +95,41 @@ struct UploadRing {
         }
     }
 };
+// A second stream for the weight-gradient GEMM of a Linear / conv while its data-gradient GEMM runs on the context's stream (both read
+// the same upstream gradient and write disjoint outputs; the small layers' launches fill a fraction of the chip each): fork = the side
+// stream waits for the main one, join = the main stream waits for the side one.  Events are reused round-robin (a wait captures the
+// record that precedes it).
+struct SideStream {
+    static constexpr int NEV = 16;
+    hipStream_t st = nullptr;
+    hipEvent_t ev[NEV] = {};
+    int next = 0;
+    hipEvent_t event() {
+        hipEvent_t& e = ev[next];
+        next = (next + 1) % NEV;
+        if (!e) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        return e;
+    }
+    void fork(hipStream_t main_st) {
+        if (!st) HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        hipEvent_t e = event();
+        HIP_CHECK(hipEventRecord(e, main_st));
+        HIP_CHECK(hipStreamWaitEvent(st, e, 0));
+    }
+    void join(hipStream_t main_st) {
+        hipEvent_t e = event();
+        HIP_CHECK(hipEventRecord(e, st));
+        HIP_CHECK(hipStreamWaitEvent(main_st, e, 0));
+    }
+    void release() {
+        for (auto& e : ev) if (e) { hipEventDestroy(e); e = nullptr; }
+        if (st) { hipStreamDestroy(st); st = nullptr; }
+    }
+};
 struct TrainStep {
     bool on = false;
+    int side_mode = 0;                     // 1: weight-gradient GEMMs on the side stream next to their data-gradient GEMM
+    SideStream side;
     long long epoch = 0;
     std::map<std::tuple<const float*, int, int, int, int>, int> index;      // (tensor, flip, rows, K, taps) -> packs[]
     std::vector<PackEntry> packs;

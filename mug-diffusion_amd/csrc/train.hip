@@ -167,6 +167,7 @@ void step_begin(mugd_ctx* ctx) {
     ++ts.epoch;
     ts.on = true;
     if (const char* e = getenv("MUGD_NO_STEP_BRACKET")) { if (e[0] == '1') { ts.on = false; return; } }      // development / test knob: every call on its own
+    if (const char* e = getenv("MUGD_TRAIN_SIDE")) ts.side_mode = atoi(e);                                   // development knob
     // tensors the previous step did not touch are gone from the model (or were never part of it): drop them
     std::vector<PackEntry> keep;
     for (auto& e : ts.packs) {
@@ -321,6 +322,18 @@ struct Lin {
     }
     // dx (+= if acc) = W^T dy ;  dW = dy x^T ;  db = row sums of dy
     void bwd(const float* x, const float* w, const float* dy, float* dx, bool acc, float* dW, float* db, int K, int M, float* wt) {
+        TrainStep& ts = sc.ctx->step;
+        const bool side = ts.on && ts.side_mode && c.train_bf16 && dW && dx;      // inside the bracket the weight-gradient call needs no call scratch
+        if (side) {
+            hipStream_t main_st = c.stream;
+            ts.side.fork(main_st);
+            c.stream = ts.side.st;
+            run_wgrad(c, sc, dy, x, dW, B, M, K, T, T, 1, 0, 1, 1, 0, db);
+            c.stream = main_st;
+            run_dgrad(c, sc, dy, w, wt, acc ? dx : nullptr, dx, B, M, K, T, 1, 0);
+            ts.side.join(main_st);
+            return;
+        }
         if (dW) run_wgrad(c, sc, dy, x, dW, B, M, K, T, T, 1, 0, 1, 1, 0, db);
         else if (db) run_bias_grad(c, sc, dy, db, B, M, T);
         if (dx) run_dgrad(c, sc, dy, w, wt, acc ? dx : nullptr, dx, B, M, K, T, 1, 0);

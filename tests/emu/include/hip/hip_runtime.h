@@ -76,6 +76,8 @@ hipError_t hipMemset(void*, int, size_t);
 hipError_t hipMemsetAsync(void*, int, size_t, hipStream_t);
 hipError_t hipDeviceSynchronize();
 hipError_t hipStreamCreate(hipStream_t*);
+#define hipStreamNonBlocking 1
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
 hipError_t hipStreamDestroy(hipStream_t);
 hipError_t hipStreamSynchronize(hipStream_t);
 hipError_t hipEventCreate(hipEvent_t*);
