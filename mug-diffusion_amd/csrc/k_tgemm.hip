@@ -437,7 +437,7 @@ constexpr int TW_XS = 81;                 // LDS row stride of the input window 
 // operand stream runs TWO slabs ahead of the matrix pipe in ping-pong registers -- the generic form requests one slab ahead with a 4-byte
 // load (and an index division) per element, which left a whole memory round trip exposed per slab on the short 1x1 layers.
 template <int TAPS, int TW_KT, bool DB, bool BIG, bool FAST>
-__global__ __launch_bounds__(BIG ? 512 : 256) void twgrad_bf16_kernel(const TWgradArgs a) {
+__global__ __launch_bounds__(BIG ? 512 : 256) MUGD_WAVES_PER_EU(2) void twgrad_bf16_kernel(const TWgradArgs a) {
     constexpr int NTHR = BIG ? 512 : 256;
     constexpr int TM = BIG ? 128 : 64;                  // tile rows (m) = tile columns (c)
     constexpr int NC = BIG ? 2 : 1;                     // 32-column accumulator tiles per wave
@@ -811,7 +811,12 @@ int twgrad_splits(int B, int M, int C, int Tout, int taps, int kt) {
     return (int)std::min<long long>(ks, 512);
 }
 
-bool twgrad_fuses_bias(int taps) { return taps == 3; }
+static bool twgrad_fast(const TWgradArgs& a) {
+    if (const char* e = getenv("MUGD_TWGRAD_GENERIC")) { if (e[0] == '1') return false; }                  // development / test knob: the generic staging
+    return a.stride == 1 && !a.ups && (a.Tout & 3) == 0 && (a.Tin & 3) == 0 && a.Tin == a.Tout && a.pad >= 0 && a.pad <= (a.taps - 1) * a.dil;
+}
+// 3-tap layers always; 1x1 layers in the FAST form (the generic 1x1 form with the bias sums would drop to one wave per SIMD)
+bool twgrad_fuses_bias(const TWgradArgs& a) { return a.taps == 3 || twgrad_fast(a); }
 
 void launch_twgrad_bf16(hipStream_t st, const TWgradArgs& a0, float* partial, bool reduce) {
     TWgradArgs a = a0;
@@ -832,8 +837,7 @@ void launch_twgrad_bf16(hipStream_t st, const TWgradArgs& a0, float* partial, bo
     const dim3 grid(cdiv(a.M, big ? 128 : 64), cdiv(a.C, big ? 128 : 64), a.KS);
     const dim3 blk(big ? 512 : 256);
     // 16-byte staging + two slabs in flight (FAST) where rows are 16-byte aligned and windows are plain shifted slabs
-    bool fast = a.stride == 1 && !a.ups && (a.Tout & 3) == 0 && (a.Tin & 3) == 0 && a.Tin == a.Tout && a.pad >= 0 && a.pad <= (a.taps - 1) * a.dil;
-    if (const char* e = getenv("MUGD_TWGRAD_GENERIC")) { if (e[0] == '1') fast = false; }                  // development / test knob: the generic staging
+    const bool fast = twgrad_fast(a);
 #define MUGD_TW(T, K, D)                                                                                   \
     do {                                                                                                   \
         if (big && fast) hipLaunchKernelGGL((twgrad_bf16_kernel<T, K, D, true, true>), grid, blk, 0, st, a);       \
@@ -843,8 +847,10 @@ void launch_twgrad_bf16(hipStream_t st, const TWgradArgs& a0, float* partial, bo
     } while (0)
     if (a.taps == 1) {
         MUGD_CHECK(a.stride == 1, -2, "twgrad: strided 1x1 convs are not used by the model");
-        MUGD_CHECK(!a.db, -2, "twgrad: the 1x1 form does not produce the bias gradient (twgrad_fuses_bias)");
-        MUGD_TW(1, 64, false);
+        MUGD_CHECK(!a.db || fast, -2, "twgrad: the generic 1x1 form does not produce the bias gradient (twgrad_fuses_bias)");
+        if (a.db && big) hipLaunchKernelGGL((twgrad_bf16_kernel<1, 64, true, true, true>), grid, blk, 0, st, a);
+        else if (a.db) hipLaunchKernelGGL((twgrad_bf16_kernel<1, 64, true, false, true>), grid, blk, 0, st, a);
+        else MUGD_TW(1, 64, false);
     } else if (a.db) {
         MUGD_TW(3, 32, true);
     } else {

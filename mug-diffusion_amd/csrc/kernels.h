@@ -403,7 +403,7 @@ void launch_tpack_weights_batched(hipStream_t st, const float* src, unsigned sho
                                   long long s_row, long long s_k, int flip, float scale);
 void launch_tconv_bf16(hipStream_t st, const TConvArgs& a);
 bool twgrad_big_tile(int B, int M, int C, int Tout);
-bool twgrad_fuses_bias(int taps);            // whether launch_twgrad_bf16 can also produce TWgradArgs::db for this tap count
+bool twgrad_fuses_bias(const TWgradArgs& a);   // whether launch_twgrad_bf16 can also produce TWgradArgs::db for this geometry
 int twgrad_splits(int B, int M, int C, int Tout, int taps, int kt /* samples per slab: 64 for 1x1 layers, 32 for 3-tap ones */);
 // reduce = false (KS > 1): the partial slices stay unreduced (train.hip queues them for launch_treduce_table)
 void launch_twgrad_bf16(hipStream_t st, const TWgradArgs& a, float* partial /* KS * (M * C * taps + M) floats when KS > 1 */, bool reduce = true);

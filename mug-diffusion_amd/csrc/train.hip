@@ -259,8 +259,9 @@ void run_wgrad(Ctx& c, Scratch& sc, const float* dY, const float* A, float* dW, 
     {
         ProfScope prof(g_tprof, c.stream, 1, 2.0 * M * C * taps * (double)B * Tout);
         if (c.train_bf16) {
-            const bool fuse = db && twgrad_fuses_bias(taps);
-            TWgradArgs a{dY, A, dW, B, M, C, Tout, Tin, taps, pad, dil, stride, ups, twgrad_splits(B, M, C, Tout, taps, taps == 1 ? 64 : 32), fuse ? db : nullptr, (stride == 1 && twgrad_big_tile(B, M, C, Tout)) ? 1 : 0};
+            TWgradArgs a{dY, A, dW, B, M, C, Tout, Tin, taps, pad, dil, stride, ups, twgrad_splits(B, M, C, Tout, taps, taps == 1 ? 64 : 32), nullptr, (stride == 1 && twgrad_big_tile(B, M, C, Tout)) ? 1 : 0};
+            const bool fuse = db && twgrad_fuses_bias(a);
+            if (fuse) a.db = db;
             const size_t nn = (size_t)M * C * taps;
             if (a.KS > 1 && sc.ctx->step.on) {           // split-K slices stay in their pool block until the step's table of reductions runs
                 float* part = static_cast<float*>(sc.pool.take((size_t)a.KS * (nn + M) * 4 + 8192));
