@@ -16,6 +16,8 @@
 // Everything fp32 with fp64 accumulation where sums are long (statistics, bias / gamma / beta gradients).
 #include <algorithm>
 
+#include <cstdint>
+
 #include "kernels.h"
 
 namespace {
@@ -250,6 +252,16 @@ __global__ void interleave_parity_kernel(const float* src, float* dst, long long
         const long long rr = i / T; const int u = (int)(i - rr * T);
         dst[rr * 2 * T + 2 * u + par] = src[i];
     }
+}
+// both parities at once: dst[2 i] = ev[i], dst[2 i + 1] = od[i] (flat: row r, sample u -> r 2T + 2u = 2 (r T + u)): full-width coalesced
+// stores instead of two stride-2 passes
+__global__ void interleave2_kernel(const float* ev, const float* od, float* dst, long long n) {
+    const long long n2 = n >> 1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
+        const float2 e = reinterpret_cast<const float2*>(ev)[i], o = reinterpret_cast<const float2*>(od)[i];
+        reinterpret_cast<float4*>(dst)[i] = make_float4(e.x, o.x, e.y, o.y);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) { dst[2 * (n - 1)] = ev[n - 1]; dst[2 * (n - 1) + 1] = od[n - 1]; }
 }
 // dst[b][c][u] = src[b][c][2u] + src[b][c][2u + 1]: data gradient of the nearest x2 upsample
 __global__ void pair_sum_kernel(const float* src, float* dst, long long n) {
@@ -606,6 +618,14 @@ void launch_down_dgrad_weights(hipStream_t st, const float* w, float* ev, float*
 void launch_interleave_parity(hipStream_t st, const float* src, float* dst, long long rows, int T, int par) {
     const long long n = rows * T;
     hipLaunchKernelGGL(interleave_parity_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 8192)), dim3(256), 0, st, src, dst, rows, T, par);
+}
+void launch_interleave2(hipStream_t st, const float* ev, const float* od, float* dst, long long n) {
+    if ((reinterpret_cast<uintptr_t>(dst) & 15) || (reinterpret_cast<uintptr_t>(ev) & 7) || (reinterpret_cast<uintptr_t>(od) & 7)) {      // unaligned views: one parity at a time
+        launch_interleave_parity(st, ev, dst, 1, (int)n, 0);
+        launch_interleave_parity(st, od, dst, 1, (int)n, 1);
+        return;
+    }
+    hipLaunchKernelGGL(interleave2_kernel, dim3((unsigned)std::min<long long>((n / 2 + 255) / 256 + 1, 8192)), dim3(256), 0, st, ev, od, dst, n);
 }
 void launch_pair_sum(hipStream_t st, const float* src, float* dst, long long n) {
     hipLaunchKernelGGL(pair_sum_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 8192)), dim3(256), 0, st, src, dst, n);

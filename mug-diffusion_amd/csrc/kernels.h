@@ -322,6 +322,7 @@ void launch_wgrad_ex(hipStream_t st, const float* dY, const float* A, float* dW,
                      int stride, int ups, float* partial, int KS);
 void launch_down_dgrad_weights(hipStream_t st, const float* w, float* ev, float* od, int M, int C);
 void launch_interleave_parity(hipStream_t st, const float* src, float* dst, long long rows, int T, int par);
+void launch_interleave2(hipStream_t st, const float* ev, const float* od, float* dst /* 2 n */, long long n);      // dst[2 i] = ev[i], dst[2 i + 1] = od[i]
 void launch_pair_sum(hipStream_t st, const float* src, float* dst, long long n);
 // GroupNorm backward with (silu = 1) or without (0) the SiLU that follows it; resid (nullable, may be dx): added to dx (an identity skip's
 // gradient, or accumulation).  reduce_params = false: dgamma / dbeta stay as the per-batch-row fp64 pairs in `partial` ([b][c][2]) for a

@@ -446,8 +446,7 @@ int mugd_train_conv(mugd_ctx* ctx, const float* w, const float* bias, const floa
             run_conv(c, sc, dy, wt, nullptr, nullptr, 0, nullptr, ev, B, Cout, Tout, Cin, 3, 1);
             run_conv(c, sc, dy, wo, nullptr, nullptr, 0, nullptr, od, B, Cout, Tout, Cin, 1, 0);
             sc.temp_weights = false;
-            launch_interleave_parity(st, ev, da, (long long)B * Cin, Tout, 0);
-            launch_interleave_parity(st, od, da, (long long)B * Cin, Tout, 1);
+            launch_interleave2(st, ev, od, da, (long long)B * Cin * Tout);
         } else {
             float* dxu = sc.get((size_t)B * Cin * Tout, false, st);
             run_dgrad(c, sc, dy, w, wt, nullptr, dxu, B, Cout, Cin, Tout, 3, 1);
