@@ -10,6 +10,7 @@
 //   First version: A, dsim and dA*S are MATERIALISED per (batch row, head) ((Tq, Tk) each; T <= 256 in the U-Net), row kernel ->
 //   column kernel -> table kernel, VALU arithmetic, fixed summation orders (deterministic).  Not tuned.
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -437,12 +438,227 @@ __global__ __launch_bounds__(256) void attn_bwd_cols_lds_kernel(const AttnBwdArg
 
 // table kernel, stage 1: part[b][r][h] = {scale sum dsim, sum dA S} over the cells of batch row b with idx == r.
 // grid (2 pmax + 1, heads, B), block 256; stage 2 sums over b in fixed order.
+// ---- attention backward rows on the bf16 matrix cores (bf16 training mode; Tq, Tk multiples of 32, Tk <= 256, d a multiple of 16 <= 64).
+// One workgroup = 4 waves = 32 query rows of one (batch row, head).  K and V of the head and the 32 columns of q and dO are staged ONCE in
+// LDS as bf16 channel PAIRS (dword = {x[2p][t], x[2p+1][t]}: the layout tconv uses -- a lane's MFMA fragment, 8 consecutive channels of
+// one sample, is 4 ds_read_b32).  Wave w owns the 32-key column tiles w, w + 4:
+//   S tile = q^T k, dA tile = dO^T v                      (2 x d / 16 MFMAs per tile, m = query, n = key, k = channel)
+//   softmax / Cemb / dsim arithmetic on the accumulators   (C layout: register r of lane (h, n) = row (r & 3) + 8 (r >> 2) + 4 h, column n;
+//                                                           row reductions = a 16-lane DPP row op + one xor-16 shuffle + 4 waves through LDS)
+//   A, dsim, dA S tiles -> global (the key-side GEMMs and the table kernel read them), dsim also -> LDS as bf16 rows
+//   dq^T block = dsim k^T                                  (m = query, n = channel, k = key: every fourth 16-key step per wave; partial
+//                                                           32 x d blocks summed over the waves through LDS, fixed order)
+// The VALU form above spends its time in d x Tk LDS-operand multiply-adds per row and a serial Tk loop on d lanes for dq.
+typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 abf16x2 __attribute__((ext_vector_type(2)));
+typedef float af32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned au32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned apack_bf16(float lo, float hi) {
+    af32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, abf16x2));
+}
+__device__ __forceinline__ float row16_rot(float v, int which) {      // lane i of a 16-lane row reads lane (i - n) of the row; n = 8, 4, 2, 1
+    switch (which) {
+        case 0: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+        case 1: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+        case 2: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+        default: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    }
+}
+__device__ __forceinline__ float half_sum(float v) {                  // over the 32 lanes of a wave half, result in every lane of the half
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v += row16_rot(v, k);
+    return v + __shfl_xor(v, 16);
+}
+__device__ __forceinline__ float half_max(float v) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v = fmaxf(v, row16_rot(v, k));
+    return fmaxf(v, __shfl_xor(v, 16));
+}
+constexpr int ATB_PMAX = 128;              // relative-position clamp at most (LDS tables / bins)
+constexpr int ATM_TK = 256;                // keys at most
+constexpr int ATM_KS = ATM_TK + 8;         // dwords per pair-row of K / V (the two wave halves read rows 4 apart: 4 KS = 32 mod 64 banks)
+template <int DH>                          // head dim (16 | 32 | 48 | 64)
+__global__ __launch_bounds__(256) MUGD_WAVES_PER_EU(2) void attn_bwd_rows_mfma_kernel(const AttnBwdArgs a) {
+    constexpr int NP = DH / 2;                                         // pair-rows
+    constexpr int DSS = ATM_TK + 8;                                    // ushorts per row of the bf16 dsim block
+    constexpr int VREG = NP * ATM_KS + 2 * NP * 32;                    // dwords: V pairs, then the q and dO column blocks
+    constexpr int PART = 4 * 32 * DH;                                  // floats: the waves' partial dq blocks (aliases V / q / dO)
+    __shared__ __attribute__((aligned(16))) unsigned kp[NP * ATM_KS];
+    __shared__ __attribute__((aligned(16))) unsigned vq[VREG > PART ? VREG : PART];
+    __shared__ __attribute__((aligned(16))) unsigned short dsb[32 * DSS];
+    __shared__ float rels[2 * ATB_PMAX + 1], cembs[2 * ATB_PMAX + 1];
+    __shared__ float red[4][32];
+    unsigned* vp = vq;
+    unsigned* qp = vq + NP * ATM_KS;
+    unsigned* dop = qp + NP * 32;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, hh = lane >> 5, n = lane & 31;
+    const int i0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+    const int Tq = a.Tq, Tk = a.Tk, pmax = a.pmax;
+    const float* q = a.q + (size_t)b * a.q_bstride + (size_t)h * DH * Tq;
+    const float* k = a.k + (size_t)b * a.k_bstride + (size_t)h * DH * Tk;
+    const float* v = a.v + (size_t)b * a.v_bstride + (size_t)h * DH * Tk;
+    const float* dO = a.dout + (size_t)b * a.o_bstride + (size_t)h * DH * Tq;
+    // ---- stage K, V (NP pair-rows x Tk / 4 granules) and the q / dO blocks (NP x 8 granules): 4 samples of two adjacent channels ->
+    // 4 bf16 pairs -> one 16-byte LDS store
+    const int gk = Tk >> 2;
+    for (int g = tid; g < NP * gk; g += 256) {
+        const int p = g / gk, c4 = (g - p * gk) * 4;
+        const float4 k0 = *reinterpret_cast<const float4*>(k + (size_t)(2 * p) * Tk + c4), k1 = *reinterpret_cast<const float4*>(k + (size_t)(2 * p + 1) * Tk + c4);
+        const float4 v0 = *reinterpret_cast<const float4*>(v + (size_t)(2 * p) * Tk + c4), v1 = *reinterpret_cast<const float4*>(v + (size_t)(2 * p + 1) * Tk + c4);
+        au32x4 kk = {apack_bf16(k0.x, k1.x), apack_bf16(k0.y, k1.y), apack_bf16(k0.z, k1.z), apack_bf16(k0.w, k1.w)};
+        au32x4 vv = {apack_bf16(v0.x, v1.x), apack_bf16(v0.y, v1.y), apack_bf16(v0.z, v1.z), apack_bf16(v0.w, v1.w)};
+        *reinterpret_cast<au32x4*>(kp + p * ATM_KS + c4) = kk;
+        *reinterpret_cast<au32x4*>(vp + p * ATM_KS + c4) = vv;
+    }
+    for (int g = tid; g < NP * 8; g += 256) {
+        const int p = g >> 3, c4 = (g & 7) * 4;
+        const float4 q0 = *reinterpret_cast<const float4*>(q + (size_t)(2 * p) * Tq + i0 + c4), q1 = *reinterpret_cast<const float4*>(q + (size_t)(2 * p + 1) * Tq + i0 + c4);
+        const float4 d0 = *reinterpret_cast<const float4*>(dO + (size_t)(2 * p) * Tq + i0 + c4), d1 = *reinterpret_cast<const float4*>(dO + (size_t)(2 * p + 1) * Tq + i0 + c4);
+        au32x4 qq = {apack_bf16(q0.x, q1.x), apack_bf16(q0.y, q1.y), apack_bf16(q0.z, q1.z), apack_bf16(q0.w, q1.w)};
+        au32x4 dd = {apack_bf16(d0.x, d1.x), apack_bf16(d0.y, d1.y), apack_bf16(d0.z, d1.z), apack_bf16(d0.w, d1.w)};
+        *reinterpret_cast<au32x4*>(qp + p * 32 + c4) = qq;
+        *reinterpret_cast<au32x4*>(dop + p * 32 + c4) = dd;
+    }
+    for (int r = tid; r < 2 * pmax + 1; r += 256) { rels[r] = a.rel[r * a.heads + h]; cembs[r] = a.cemb[r * a.heads + h]; }
+    __syncthreads();
+    // ---- S and dA tiles of this wave (column tiles wave, wave + 4).  A tile past the last one is computed on tile 0's operands and
+    // masked out of the reductions and stores: no control flow around the accumulator vectors
+    const int ntile = Tk >> 5;
+    const bool tv0 = wave < ntile, tv1 = wave + 4 < ntile;
+    const int jt0 = tv0 ? wave : 0, jt1 = tv1 ? wave + 4 : 0;
+    f32x16 s0, s1, d0, d1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; d0[r] = 0.f; d1[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < DH / 16; ++ks) {
+        const int pr = ks * 8 + 4 * hh;                                  // the lane's 4 pair-rows of this 16-channel step
+        au32x4 aq, ad, bk0, bv0, bk1, bv1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            aq[j] = qp[(pr + j) * 32 + n]; ad[j] = dop[(pr + j) * 32 + n];
+            bk0[j] = kp[(pr + j) * ATM_KS + jt0 * 32 + n]; bv0[j] = vp[(pr + j) * ATM_KS + jt0 * 32 + n];
+            bk1[j] = kp[(pr + j) * ATM_KS + jt1 * 32 + n]; bv1[j] = vp[(pr + j) * ATM_KS + jt1 * 32 + n];
+        }
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(abf16x8, aq), __builtin_bit_cast(abf16x8, bk0), s0, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(abf16x8, ad), __builtin_bit_cast(abf16x8, bv0), d0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(abf16x8, aq), __builtin_bit_cast(abf16x8, bk1), s1, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(abf16x8, ad), __builtin_bit_cast(abf16x8, bv1), d1, 0, 0, 0);
+    }
+    // ---- row arithmetic.  Row of register r: (r & 3) + 8 (r >> 2) + 4 hh; a row's 32 columns of a tile live in one wave half.
+    // A per-lane row value is combined over the half (DPP row op + one shuffle), then over the 4 waves through LDS.
+    float rowv[16];
+    const int c0 = jt0 * 32 + n - i0, c1 = jt1 * 32 + n - i0;            // column - first row of the block
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        int x0 = c0 - row, x1 = c1 - row;
+        x0 = (x0 < -pmax ? -pmax : (x0 > pmax ? pmax : x0)) + pmax;
+        x1 = (x1 < -pmax ? -pmax : (x1 > pmax ? pmax : x1)) + pmax;
+        s0[r] = (s0[r] + rels[x0]) * a.scale;
+        s1[r] = (s1[r] + rels[x1]) * a.scale;
+        rowv[r] = half_max(fmaxf(tv0 ? s0[r] : -3.0e38f, tv1 ? s1[r] : -3.0e38f));
+    }
+#define MUGD_ACROSS_WAVES(IS_MAX)                                                                                      \
+    do {                                                                                                               \
+        __syncthreads();                                                                                               \
+        if (n == 0) {                                                                                                  \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * hh] = rowv[r];       \
+        }                                                                                                              \
+        __syncthreads();                                                                                               \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                               \
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;                                                           \
+            const float y0 = red[0][row], y1 = red[1][row], y2 = red[2][row], y3 = red[3][row];                        \
+            rowv[r] = (IS_MAX) ? fmaxf(fmaxf(y0, y1), fmaxf(y2, y3)) : (y0 + y1) + (y2 + y3);                          \
+        }                                                                                                              \
+    } while (0)
+    MUGD_ACROSS_WAVES(true);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        s0[r] = tv0 ? expf(s0[r] - rowv[r]) : 0.f;
+        s1[r] = tv1 ? expf(s1[r] - rowv[r]) : 0.f;
+        rowv[r] = half_sum(s0[r] + s1[r]);
+    }
+    MUGD_ACROSS_WAVES(false);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        int x0 = c0 - row, x1 = c1 - row;
+        x0 = (x0 < -pmax ? -pmax : (x0 > pmax ? pmax : x0)) + pmax;
+        x1 = (x1 < -pmax ? -pmax : (x1 > pmax ? pmax : x1)) + pmax;
+        const float inv = 1.0f / rowv[r];
+        s0[r] *= inv; s1[r] *= inv;
+        rowv[r] = half_sum(d0[r] * cembs[x0] * s0[r] + d1[r] * cembs[x1] * s1[r]);      // a masked tile's S is 0
+    }
+    MUGD_ACROSS_WAVES(false);
+#undef MUGD_ACROSS_WAVES
+    // ---- outputs: A = S G, dsim = S (dA G - D), dG = dA S -> global; dsim -> LDS as bf16 rows
+    const size_t mbase = (((size_t)b * a.heads + h) * Tq + i0) * Tk;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        int x0 = c0 - row, x1 = c1 - row;
+        x0 = (x0 < -pmax ? -pmax : (x0 > pmax ? pmax : x0)) + pmax;
+        x1 = (x1 < -pmax ? -pmax : (x1 > pmax ? pmax : x1)) + pmax;
+        if (tv0) {
+            const float S = s0[r], G = cembs[x0], dA = d0[r], ds = S * (dA * G - rowv[r]);
+            const size_t o = mbase + (size_t)row * Tk + jt0 * 32 + n;
+            a.Amat[o] = S * G; a.dsim[o] = ds; a.dG[o] = dA * S;
+            dsb[row * DSS + jt0 * 32 + n] = (unsigned short)(apack_bf16(ds, 0.f) & 0xffffu);
+        }
+        if (tv1) {
+            const float S = s1[r], G = cembs[x1], dA = d1[r], ds = S * (dA * G - rowv[r]);
+            const size_t o = mbase + (size_t)row * Tk + jt1 * 32 + n;
+            a.Amat[o] = S * G; a.dsim[o] = ds; a.dG[o] = dA * S;
+            dsb[row * DSS + jt1 * 32 + n] = (unsigned short)(apack_bf16(ds, 0.f) & 0xffffu);
+        }
+    }
+    __syncthreads();                             // dsim block complete; V / q / dO no longer read: their LDS becomes the partial dq blocks
+    // ---- dq^T partial of this wave: every fourth 16-key step, channels in 32-wide tiles
+    constexpr int NE = (DH + 31) / 32;
+    f32x16 dacc[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dacc[e][r] = 0.f;
+    for (int j0 = wave * 16; j0 < Tk; j0 += 64) {                        // the 16-key steps round-robin over the waves
+        const int jl = j0 + 8 * hh;                                      // the lane's 8 keys of this step
+        const au32x4 af = *reinterpret_cast<const au32x4*>(dsb + n * DSS + jl);       // row n, keys jl .. jl + 7
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int ch = e * 32 + n;                                   // the lane's channel (B column)
+            const int chc = ch < DH ? ch : DH - 1;
+            const unsigned* kr = kp + (chc >> 1) * ATM_KS + jl;
+            const unsigned sh = (chc & 1) * 16;
+            unsigned w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = (kr[j] >> sh) & 0xffffu;
+            au32x4 bf = {w[0] | (w[1] << 16), w[2] | (w[3] << 16), w[4] | (w[5] << 16), w[6] | (w[7] << 16)};
+            if (ch >= DH) bf = au32x4{0u, 0u, 0u, 0u};
+            dacc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(abf16x8, af), __builtin_bit_cast(abf16x8, bf), dacc[e], 0, 0, 0);
+        }
+    }
+    float* part = reinterpret_cast<float*>(vq);                          // [wave][row][DH]
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = e * 32 + n;
+            if (ch < DH) part[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * DH + ch] = dacc[e][r];
+        }
+    __syncthreads();
+    for (int o = tid; o < 32 * DH; o += 256) {                           // o -> (channel, query) with the query fastest: 128-byte stores
+        const int ch = o >> 5, row = o & 31;
+        const float s4 = (part[(0 * 32 + row) * DH + ch] + part[(1 * 32 + row) * DH + ch]) + (part[(2 * 32 + row) * DH + ch] + part[(3 * 32 + row) * DH + ch]);
+        a.dq[(size_t)b * a.q_bstride + ((size_t)h * DH + ch) * Tq + i0 + row] = s4 * a.scale;
+    }
+}
+
 // Row-major form of the same sums (pmax <= ATB_PMAX): one workgroup per (head, batch row) walks both matrices ONCE with coalesced row
 // reads -- rows round-robin over the 4 waves, lanes over keys -- instead of 2 pmax + 1 workgroups each walking a diagonal (4-byte reads
 // one row pitch apart).  An interior element goes to the wave's LDS bin of its offset j - i (the 64 lanes of a row chunk hit 64 distinct
 // bins: plain read-add-write, rows in program order); the two clamped regions accumulate per lane and meet in one wave sum at the end.
 // fp64 throughout, fixed order: deterministic.
-constexpr int ATB_PMAX = 128;
 constexpr int ATB_TROWS = 64;             // query rows per workgroup (16 per wave)
 __global__ __launch_bounds__(256) void attn_bwd_tables_rows_kernel(const AttnBwdArgs a, double* part) {
     __shared__ double bins[4][2][2 * ATB_PMAX + 1];
@@ -564,6 +780,11 @@ void launch_geglu_bwd(hipStream_t st, const float* u, const float* df, float* du
     const long long n = (long long)B * Ch * T;
     hipLaunchKernelGGL(geglu_bwd_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 8192)), dim3(256), 0, st, u, df, du, B, Ch, T);
 }
+// the bf16 matrix-core row kernel: requested by the caller (bf16 training mode) and the shape fits
+static bool attn_bwd_mfma_ok(const AttnBwdArgs& a) {
+    if (const char* e = getenv("MUGD_ATTN_BWD_VALU")) { if (e[0] == '1') return false; }      // development / test knob
+    return a.mfma && (a.d == 16 || a.d == 32 || a.d == 48 || a.d == 64) && a.Tq % 32 == 0 && a.Tk % 32 == 0 && a.Tk <= ATM_TK && a.pmax <= ATB_PMAX;
+}
 // fp64 pair rows of tab_part: one per (batch row, chunk of ATB_TROWS query rows) in the row-major table kernel, one per batch row otherwise
 int attn_bwd_table_rows(int B, int Tq, int pmax) { return pmax <= ATB_PMAX ? B * cdiv(Tq, ATB_TROWS) : B; }
 void launch_attention_bwd(hipStream_t st, const AttnBwdArgs& a) {
@@ -573,7 +794,13 @@ void launch_attention_bwd(hipStream_t st, const AttnBwdArgs& a) {
     // only since the row loop runs its four key groups side by side; columns: up to 8192, larger heads keep the first version or, in bf16
     // mode, leave the key-side gradients to the caller's batched GEMMs)
     const int kv = a.d * (a.Tk + 1), qf = a.d * a.Tq;
-    if (a.Tk <= ATB_TKS && kv <= 4224) hipLaunchKernelGGL(attn_bwd_rows_lds_kernel<4224>, dim3(cdiv(a.Tq, ATB_RB), a.heads, a.B), dim3(256), 0, st, a);
+    if (attn_bwd_mfma_ok(a)) {
+        const dim3 grid(a.Tq / 32, a.heads, a.B);
+        if (a.d == 16) hipLaunchKernelGGL(attn_bwd_rows_mfma_kernel<16>, grid, dim3(256), 0, st, a);
+        else if (a.d == 32) hipLaunchKernelGGL(attn_bwd_rows_mfma_kernel<32>, grid, dim3(256), 0, st, a);
+        else if (a.d == 48) hipLaunchKernelGGL(attn_bwd_rows_mfma_kernel<48>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(attn_bwd_rows_mfma_kernel<64>, grid, dim3(256), 0, st, a);
+    } else if (a.Tk <= ATB_TKS && kv <= 4224) hipLaunchKernelGGL(attn_bwd_rows_lds_kernel<4224>, dim3(cdiv(a.Tq, ATB_RB), a.heads, a.B), dim3(256), 0, st, a);
     else if (a.Tk <= ATB_TKS && kv <= 8448) hipLaunchKernelGGL(attn_bwd_rows_lds_kernel<8448>, dim3(cdiv(a.Tq, ATB_RB), a.heads, a.B), dim3(256), 0, st, a);
     else if (a.Tk <= ATB_TKS && kv <= 16640) hipLaunchKernelGGL(attn_bwd_rows_lds_kernel<16640>, dim3(cdiv(a.Tq, ATB_RB), a.heads, a.B), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(attn_bwd_rows_kernel, dim3(cdiv(a.Tq, 4), a.heads, a.B), dim3(256), 0, st, a);

@@ -351,6 +351,7 @@ struct AttnBwdArgs {         // layouts as AttnArgs; dout = gradient of the atte
     float* drel; float* dcemb;                // (2 pmax + 1, heads)
     double* tab_part;                         // scratch, (attn_bwd_table_rows(), 2 pmax + 1, heads, 2)
     int skip_cols;                            // 1: dk / dv are produced by the caller (bf16 mode: two batched tconv GEMMs over dsim / Amat)
+    int mfma;                                 // 1: bf16 training mode -- the row kernel may run on the bf16 matrix cores (q, k, v, dO and dsim rounded to bf16 on their way in)
     int defer_tables;                         // 1: drel / dcemb stay as the fp64 pair rows of tab_part (TReduceDesc kind 2, n = (2 pmax + 1) heads, KS = attn_bwd_table_rows())
 };
 int attn_bwd_table_rows(int B, int Tq, int pmax);

@@ -581,6 +581,7 @@ int mugd_train_transformer(mugd_ctx* ctx, const float* const* P, const float* x,
             // -- per (batch row, head) a (d x Tq) "weight" (q resp. dO, packed per head) applied to a (Tq x tk) input: tconv with per-batch weights
             const bool gemm_cols = c.train_bf16 && T % 16 == 0;
             a.skip_cols = gemm_cols ? 1 : 0;
+            a.mfma = c.train_bf16 ? 1 : 0;
             if (ctx->step.on) {                     // the table gradients' sum over batch rows joins the step's reduction table
                 const size_t tb = (size_t)trows * (2 * pmax + 1) * heads * 16;
                 a.tab_part = static_cast<double*>(ctx->pool.take(tb + 8192));

@@ -156,10 +156,14 @@ def test_transformer_forward_backward_vs_autograd(lib, B, C, T, Cc, Tk, heads, g
         close(grads[k], pt["m." + k].grad, 3e-4, "grad of " + k)
 
 
-@pytest.mark.parametrize("B,C,T,Cc,Tk,heads,groups,pmax", [(2, 64, 96, 32, 21, 4, 16, 64), (1, 64, 48, 0, 0, 4, 32, 8)])
+@pytest.mark.parametrize("B,C,T,Cc,Tk,heads,groups,pmax", [(2, 64, 96, 32, 21, 4, 16, 64), (1, 64, 48, 0, 0, 4, 32, 8),
+                                                           # the matrix-core attention backward at every head dim it is built for (32 / 48 / 64), one and
+                                                           # two column tiles per wave (T = 64 ... 256), relative offsets beyond the clamp
+                                                           (1, 128, 256, 0, 0, 4, 32, 64), (1, 192, 128, 32, 21, 4, 32, 16), (2, 128, 64, 0, 0, 2, 32, 64)])
 def test_transformer_bf16_mode_vs_fp32_mode(lib, B, C, T, Cc, Tk, heads, groups, pmax):
     """The transformer block with its GEMMs on the bf16 matrix cores -- the Linears AND the key-side attention gradients (two batched
-    matmuls with per-(batch row, head) operands: dk = dsim^T q, dv = A^T dO) -- against the fp32 mode (which equals autograd, above):
+    matmuls with per-(batch row, head) operands: dk = dsim^T q, dv = A^T dO) and, where T is a multiple of 32, the attention backward's
+    row kernel (S = q^T k, dA = dO^T v, dq = dsim k^T as MFMA tiles) -- against the fp32 mode (which equals autograd, above):
     every output within bf16 rounding of the operands (relative L2 error <= 2 %)."""
     p = transformer_params(C, Cc if Cc else C, heads, pmax)
     x, dy = rnd(40, B, C, T), rnd(41, B, C, T)
