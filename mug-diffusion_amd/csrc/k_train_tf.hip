@@ -438,7 +438,8 @@ __global__ __launch_bounds__(256) void attn_bwd_cols_lds_kernel(const AttnBwdArg
 
 // table kernel, stage 1: part[b][r][h] = {scale sum dsim, sum dA S} over the cells of batch row b with idx == r.
 // grid (2 pmax + 1, heads, B), block 256; stage 2 sums over b in fixed order.
-// ---- attention backward rows on the bf16 matrix cores (bf16 training mode; Tq, Tk multiples of 32, Tk <= 256, d a multiple of 16 <= 64).
+// ---- attention backward rows on the bf16 matrix cores (bf16 training mode; Tq a multiple of 32, Tk <= 256 -- ragged key counts are
+// padded to 32 with masked columns -- d a multiple of 16 <= 64).
 // One workgroup = 4 waves = 32 query rows of one (batch row, head).  K and V of the head and the 32 columns of q and dO are staged ONCE in
 // LDS as bf16 channel PAIRS (dword = {x[2p][t], x[2p+1][t]}: the layout tconv uses -- a lane's MFMA fragment, 8 consecutive channels of
 // one sample, is 4 ds_read_b32).  Wave w owns the 32-key column tiles w, w + 4:
@@ -501,15 +502,28 @@ __global__ __launch_bounds__(256) MUGD_WAVES_PER_EU(2) void attn_bwd_rows_mfma_k
     const float* dO = a.dout + (size_t)b * a.o_bstride + (size_t)h * DH * Tq;
     // ---- stage K, V (NP pair-rows x Tk / 4 granules) and the q / dO blocks (NP x 8 granules): 4 samples of two adjacent channels ->
     // 4 bf16 pairs -> one 16-byte LDS store
-    const int gk = Tk >> 2;
-    for (int g = tid; g < NP * gk; g += 256) {
-        const int p = g / gk, c4 = (g - p * gk) * 4;
-        const float4 k0 = *reinterpret_cast<const float4*>(k + (size_t)(2 * p) * Tk + c4), k1 = *reinterpret_cast<const float4*>(k + (size_t)(2 * p + 1) * Tk + c4);
-        const float4 v0 = *reinterpret_cast<const float4*>(v + (size_t)(2 * p) * Tk + c4), v1 = *reinterpret_cast<const float4*>(v + (size_t)(2 * p + 1) * Tk + c4);
-        au32x4 kk = {apack_bf16(k0.x, k1.x), apack_bf16(k0.y, k1.y), apack_bf16(k0.z, k1.z), apack_bf16(k0.w, k1.w)};
-        au32x4 vv = {apack_bf16(v0.x, v1.x), apack_bf16(v0.y, v1.y), apack_bf16(v0.z, v1.z), apack_bf16(v0.w, v1.w)};
-        *reinterpret_cast<au32x4*>(kp + p * ATM_KS + c4) = kk;
-        *reinterpret_cast<au32x4*>(vp + p * ATM_KS + c4) = vv;
+    const int ntile = (Tk + 31) >> 5, Tkp = ntile * 32;                // keys padded to whole column tiles: zero K / V, masked in the row arithmetic
+    if ((Tk & 3) == 0) {
+        const int gk = Tkp >> 2;
+        for (int g = tid; g < NP * gk; g += 256) {
+            const int p = g / gk, c4 = (g - p * gk) * 4;
+            au32x4 kk = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+            if (c4 < Tk) {
+                const float4 k0 = *reinterpret_cast<const float4*>(k + (size_t)(2 * p) * Tk + c4), k1 = *reinterpret_cast<const float4*>(k + (size_t)(2 * p + 1) * Tk + c4);
+                const float4 v0 = *reinterpret_cast<const float4*>(v + (size_t)(2 * p) * Tk + c4), v1 = *reinterpret_cast<const float4*>(v + (size_t)(2 * p + 1) * Tk + c4);
+                kk = au32x4{apack_bf16(k0.x, k1.x), apack_bf16(k0.y, k1.y), apack_bf16(k0.z, k1.z), apack_bf16(k0.w, k1.w)};
+                vv = au32x4{apack_bf16(v0.x, v1.x), apack_bf16(v0.y, v1.y), apack_bf16(v0.z, v1.z), apack_bf16(v0.w, v1.w)};
+            }
+            *reinterpret_cast<au32x4*>(kp + p * ATM_KS + c4) = kk;
+            *reinterpret_cast<au32x4*>(vp + p * ATM_KS + c4) = vv;
+        }
+    } else {                                                           // ragged key count (the 21 prompt tokens): element by element
+        for (int g = tid; g < NP * Tkp; g += 256) {
+            const int p = g / Tkp, j = g - p * Tkp;
+            const bool in = j < Tk;
+            kp[p * ATM_KS + j] = in ? apack_bf16(k[(size_t)(2 * p) * Tk + j], k[(size_t)(2 * p + 1) * Tk + j]) : 0u;
+            vp[p * ATM_KS + j] = in ? apack_bf16(v[(size_t)(2 * p) * Tk + j], v[(size_t)(2 * p + 1) * Tk + j]) : 0u;
+        }
     }
     for (int g = tid; g < NP * 8; g += 256) {
         const int p = g >> 3, c4 = (g & 7) * 4;
@@ -524,9 +538,8 @@ __global__ __launch_bounds__(256) MUGD_WAVES_PER_EU(2) void attn_bwd_rows_mfma_k
     __syncthreads();
     // ---- S and dA tiles of this wave (column tiles wave, wave + 4).  A tile past the last one is computed on tile 0's operands and
     // masked out of the reductions and stores: no control flow around the accumulator vectors
-    const int ntile = Tk >> 5;
-    const bool tv0 = wave < ntile, tv1 = wave + 4 < ntile;
-    const int jt0 = tv0 ? wave : 0, jt1 = tv1 ? wave + 4 : 0;
+    const int jt0 = wave < ntile ? wave : 0, jt1 = wave + 4 < ntile ? wave + 4 : 0;
+    const bool tv0 = wave < ntile && jt0 * 32 + n < Tk, tv1 = wave + 4 < ntile && jt1 * 32 + n < Tk;      // this lane's column exists
     f32x16 s0, s1, d0, d1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; d0[r] = 0.f; d1[r] = 0.f; }
@@ -600,17 +613,17 @@ __global__ __launch_bounds__(256) MUGD_WAVES_PER_EU(2) void attn_bwd_rows_mfma_k
         int x0 = c0 - row, x1 = c1 - row;
         x0 = (x0 < -pmax ? -pmax : (x0 > pmax ? pmax : x0)) + pmax;
         x1 = (x1 < -pmax ? -pmax : (x1 > pmax ? pmax : x1)) + pmax;
-        if (tv0) {
-            const float S = s0[r], G = cembs[x0], dA = d0[r], ds = S * (dA * G - rowv[r]);
+        {
+            const float S = s0[r], G = cembs[x0], dA = d0[r], ds = S * (dA * G - rowv[r]);      // a masked column's S is 0: ds = 0
             const size_t o = mbase + (size_t)row * Tk + jt0 * 32 + n;
-            a.Amat[o] = S * G; a.dsim[o] = ds; a.dG[o] = dA * S;
-            dsb[row * DSS + jt0 * 32 + n] = (unsigned short)(apack_bf16(ds, 0.f) & 0xffffu);
+            if (tv0) { a.Amat[o] = S * G; a.dsim[o] = ds; a.dG[o] = dA * S; }
+            if (wave < ntile) dsb[row * DSS + jt0 * 32 + n] = (unsigned short)(apack_bf16(ds, 0.f) & 0xffffu);
         }
-        if (tv1) {
+        {
             const float S = s1[r], G = cembs[x1], dA = d1[r], ds = S * (dA * G - rowv[r]);
             const size_t o = mbase + (size_t)row * Tk + jt1 * 32 + n;
-            a.Amat[o] = S * G; a.dsim[o] = ds; a.dG[o] = dA * S;
-            dsb[row * DSS + jt1 * 32 + n] = (unsigned short)(apack_bf16(ds, 0.f) & 0xffffu);
+            if (tv1) { a.Amat[o] = S * G; a.dsim[o] = ds; a.dG[o] = dA * S; }
+            if (wave + 4 < ntile) dsb[row * DSS + jt1 * 32 + n] = (unsigned short)(apack_bf16(ds, 0.f) & 0xffffu);
         }
     }
     __syncthreads();                             // dsim block complete; V / q / dO no longer read: their LDS becomes the partial dq blocks
@@ -621,7 +634,7 @@ __global__ __launch_bounds__(256) MUGD_WAVES_PER_EU(2) void attn_bwd_rows_mfma_k
     for (int e = 0; e < NE; ++e)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dacc[e][r] = 0.f;
-    for (int j0 = wave * 16; j0 < Tk; j0 += 64) {                        // the 16-key steps round-robin over the waves
+    for (int j0 = wave * 16; j0 < Tkp; j0 += 64) {                       // the 16-key steps round-robin over the waves
         const int jl = j0 + 8 * hh;                                      // the lane's 8 keys of this step
         const au32x4 af = *reinterpret_cast<const au32x4*>(dsb + n * DSS + jl);       // row n, keys jl .. jl + 7
 #pragma unroll
@@ -783,7 +796,7 @@ void launch_geglu_bwd(hipStream_t st, const float* u, const float* df, float* du
 // the bf16 matrix-core row kernel: requested by the caller (bf16 training mode) and the shape fits
 static bool attn_bwd_mfma_ok(const AttnBwdArgs& a) {
     if (const char* e = getenv("MUGD_ATTN_BWD_VALU")) { if (e[0] == '1') return false; }      // development / test knob
-    return a.mfma && (a.d == 16 || a.d == 32 || a.d == 48 || a.d == 64) && a.Tq % 32 == 0 && a.Tk % 32 == 0 && a.Tk <= ATM_TK && a.pmax <= ATB_PMAX;
+    return a.mfma && (a.d == 16 || a.d == 32 || a.d == 48 || a.d == 64) && a.Tq % 32 == 0 && a.Tk >= 1 && a.Tk <= ATM_TK && a.pmax <= ATB_PMAX;
 }
 // fp64 pair rows of tab_part: one per (batch row, chunk of ATB_TROWS query rows) in the row-major table kernel, one per batch row otherwise
 int attn_bwd_table_rows(int B, int Tq, int pmax) { return pmax <= ATB_PMAX ? B * cdiv(Tq, ATB_TROWS) : B; }
