@@ -27,6 +27,8 @@
 // and the explicit-dt term keeps its form with the full s_ab.
 #include <algorithm>
 
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace {
@@ -216,6 +218,131 @@ __global__ __launch_bounds__(256) void s4_conv_train_bwd_kernel(const float* n, 
     __syncthreads();
     if (tid == 0) pD[(size_t)b * H + h] = (float)((red[0] + red[1]) + (red[2] + red[3]));
 }
+// ---- the same two kernels as Toeplitz GEMMs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: fp32 products and sums -- S4 stays fp32
+// in either training mode), L a multiple of 32, <= 512.  The direct forms above spend one LDS operand pair per multiply-add (58 / 159 us
+// per layer at L = 512: LDS-throughput bound); here a 32 x 32 x 32 block costs 16 MFMAs and 2 LDS reads per lane and MFMA.
+//   forward:   pre[b][t]  = sum_s n[b][s] K[s][t],  K[s][t] = k[t - s] (0 for s > t)        m = batch row, n = t, k = s <= t
+//   backward:  dn[b][t']  = sum_t dpre[b][t] K'[t][t'],  K'[t][t'] = k[t - t'] (0 for t < t') m = batch row, n = t', k = t >= t'
+//              DK[t][u]   = sum_b dpre[b][t] n[b][u]  ->  dk[s] = sum_{t - u = s} DK[t][u]    m = t, n = u <= t, k = batch row; the tiles of one
+//                           block diagonal (t / 32 - u / 32 = D) accumulate into ONE accumulator, whose own diagonals are the lags 32 D + e
+//              dD = dk[0] before the D n term is separated (the lag-0 correlation IS sum dpre n)
+// kz[i] = k[i - L] for i >= L, 0 below: k[t - s] = kz[L + t - s] without a branch.  Batch rows in LDS at stride LS = 2 (mod 64) floats: the
+// two k-halves of a fragment read hit disjoint banks.
+constexpr int S4M_LMAX = 512;
+template <int LM>                          // L <= LM (128 | 256 | 512: sizes the LDS)
+__global__ __launch_bounds__(256) void s4_conv_train_fwd_mfma_kernel(const float* n, const float* k, const float* D, float* pre, float* g, int B, int H, int L) {
+    constexpr int LS = LM + 2;
+    __shared__ float kz[2 * LM], us[32 * LS];
+    const int h = blockIdx.x, b0 = blockIdx.y * 32, tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, hh = lane >> 5, nn = lane & 31;
+    for (int i = tid; i < 2 * L; i += 256) kz[i] = i >= L ? k[(size_t)h * L + i - L] : 0.f;
+    for (int i = tid; i < 32 * L; i += 256) {
+        const int r = i / L, t = i - r * L;
+        us[r * LS + t] = b0 + r < B ? n[((size_t)(b0 + r) * H + h) * L + t] : 0.f;
+    }
+    __syncthreads();
+    const float Dh = D[h];
+    const int nt = L >> 5;
+    for (int ti = wave; ti < nt; ti += 4) {                                // column tile of t; its k tiles are si <= ti
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* bp = kz + L + ti * 32 + nn - hh;                      // B[s][t] = kz[L + t - s], s = s0 + hh
+        const float* ap = us + nn * LS + hh;                               // A[b][s]
+        for (int s0 = 0; s0 < (ti + 1) * 32; s0 += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[s0], bp[-s0], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int br = (r & 3) + 8 * (r >> 2) + 4 * hh, t = ti * 32 + nn;
+            if (b0 + br < B) {
+                const float v = acc[r] + Dh * us[br * LS + t];
+                const size_t o = ((size_t)(b0 + br) * H + h) * L + t;
+                pre[o] = v;
+                g[o] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+            }
+        }
+    }
+}
+template <int LM>
+__global__ __launch_bounds__(256) void s4_conv_train_bwd_mfma_kernel(const float* n, const float* k, const float* D, const float* dpre, float* dn, float* dk,
+                                                                     float* dD, int B, int H, int L) {
+    constexpr int LS = LM + 2;
+    __shared__ float kz[2 * LM];
+    __shared__ float lag[2 * LM];          // 2 x L: a lag's sums from the e >= 0 and the e < 0 halves of two accumulators
+    __shared__ float us[32 * LS], ds[32 * LS];
+    __shared__ float tb[4 * 32 * 33];      // per wave: an accumulator as a tile
+    const int h = blockIdx.x, tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, hh = lane >> 5, nn = lane & 31;
+    for (int i = tid; i < 2 * L; i += 256) { kz[i] = i >= L ? k[(size_t)h * L + i - L] : 0.f; lag[i] = 0.f; }
+    const float Dh = D[h];
+    const int nt = L >> 5;
+    f32x16 dacc[4];                                                        // block diagonals wave, wave + 4, wave + 8, wave + 12
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dacc[q][r] = 0.f;
+    for (int b0 = 0; b0 < B; b0 += 32) {
+        __syncthreads();                                                   // previous batch tile consumed
+        for (int i = tid; i < 32 * L; i += 256) {
+            const int r = i / L, t = i - r * L;
+            const bool in = b0 + r < B;
+            const size_t o = ((size_t)(b0 + r) * H + h) * L + t;
+            us[r * LS + t] = in ? n[o] : 0.f;
+            ds[r * LS + t] = in ? dpre[o] : 0.f;
+        }
+        __syncthreads();
+        // dn tiles of this wave: column tile ti (t'), k tiles >= ti
+        for (int ti = wave; ti < nt; ti += 4) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* ap = ds + nn * LS + hh;                           // A[b][t]
+            const float* bp = kz + L - (ti * 32 + nn) + hh;                // B[t][t'] = kz[L + t - t'], t = t0 + hh
+            for (int t0 = ti * 32; t0 < L; t0 += 2)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[t0], bp[t0], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int br = (r & 3) + 8 * (r >> 2) + 4 * hh, t = ti * 32 + nn;
+                if (b0 + br < B) dn[((size_t)(b0 + br) * H + h) * L + t] = acc[r] + Dh * ds[br * LS + t];
+            }
+        }
+        // DK block diagonals of this wave: tiles (ti, ti - dlt), k = the 32 batch rows of the tile
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int dlt = wave + 4 * q;
+            for (int ti = dlt; ti < nt; ++ti) {
+                const float* ap = ds + hh * LS + ti * 32 + nn;             // A[t][b] = dpre[b][t], b = bb + hh
+                const float* bp = us + hh * LS + (ti - dlt) * 32 + nn;     // B[b][u] = n[b][u]
+#pragma unroll 8
+                for (int bb = 0; bb < 32; bb += 2)
+                    dacc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[bb * LS], bp[bb * LS], dacc[q], 0, 0, 0);
+            }
+        }
+    }
+    // ---- lags: accumulator of block diagonal dlt, element (r, c) -> lag 32 dlt + r - c (r - c = e in [-31, 31]; dlt = 0 keeps e >= 0)
+    float* tw = tb + wave * (32 * 33);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int dlt = wave + 4 * q;
+        if (dlt < nt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tw[((r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + nn] = dacc[q][r];
+            wave_sync();
+            if (lane < 63) {
+                const int e = lane - 31;                                   // r - c
+                float sm = 0.f;
+                for (int c = (e < 0 ? -e : 0); c < 32 && c + e < 32; ++c) sm += tw[(c + e) * 33 + c];
+                const int sl = 32 * dlt + e;
+                if (sl >= 0 && sl < L) lag[(e < 0 ? L : 0) + sl] = sm;     // each (half, lag) slot has exactly one writer
+            }
+            wave_sync();
+        }
+    }
+    __syncthreads();
+    for (int sidx = tid; sidx < L; sidx += 256) dk[(size_t)h * L + sidx] = lag[sidx] + lag[L + sidx];
+    if (tid == 0) dD[h] = lag[0] + lag[L];
+}
+
 // dk[h][s] = sum_b pk[b][h][s] ; dD[h] = sum_b pD[b][h]
 __global__ void s4_conv_bwd_reduce_kernel(const float* pk, const float* pD, float* dk, float* dD, int B, int H, int L) {
     const long long n = (long long)H * L;
@@ -267,13 +394,30 @@ void launch_s4_kernel_gen_bwd(hipStream_t st, const S4GenBwdArgs& a) {
     MUGD_CHECK(a.N <= 64 && a.Lint % 2 == 0 && a.Lint > 0 && a.Lint <= S4T_LMAX && a.L <= a.Lint, -2, "s4 kernel gradient: internal length <= 1024, <= 64 poles");
     hipLaunchKernelGGL(s4_kernel_gen_bwd_kernel, dim3(a.H), dim3(256), 0, st, a);
 }
+static bool s4_mfma_ok(int L) {
+    if (const char* e = getenv("MUGD_S4_TRAIN_DIRECT")) { if (e[0] == '1') return false; }      // development / test knob: the direct (VALU) forms
+    return L % 32 == 0 && L <= S4M_LMAX;
+}
 void launch_s4_conv_train_fwd(hipStream_t st, const float* n, const float* k, const float* D, float* pre, float* g, int B, int H, int L) {
     MUGD_CHECK(L <= 4096, -2, "s4: sequence longer than 4096");
+    if (s4_mfma_ok(L)) {
+        const dim3 grid(H, cdiv(B, 32));
+        if (L <= 128) hipLaunchKernelGGL(s4_conv_train_fwd_mfma_kernel<128>, grid, dim3(256), 0, st, n, k, D, pre, g, B, H, L);
+        else if (L <= 256) hipLaunchKernelGGL(s4_conv_train_fwd_mfma_kernel<256>, grid, dim3(256), 0, st, n, k, D, pre, g, B, H, L);
+        else hipLaunchKernelGGL(s4_conv_train_fwd_mfma_kernel<512>, grid, dim3(256), 0, st, n, k, D, pre, g, B, H, L);
+        return;
+    }
     hipLaunchKernelGGL(s4_conv_train_fwd_kernel, dim3(H, B), dim3(256), 0, st, n, k, D, pre, g, B, H, L);
 }
 void launch_s4_conv_train_bwd(hipStream_t st, const float* n, const float* k, const float* D, const float* dpre, float* dn, float* dk, float* dD,
                               int B, int H, int L, float* partial) {
     MUGD_CHECK(L <= 4096, -2, "s4: sequence longer than 4096");
+    if (s4_mfma_ok(L)) {
+        if (L <= 128) hipLaunchKernelGGL(s4_conv_train_bwd_mfma_kernel<128>, dim3(H), dim3(256), 0, st, n, k, D, dpre, dn, dk, dD, B, H, L);
+        else if (L <= 256) hipLaunchKernelGGL(s4_conv_train_bwd_mfma_kernel<256>, dim3(H), dim3(256), 0, st, n, k, D, dpre, dn, dk, dD, B, H, L);
+        else hipLaunchKernelGGL(s4_conv_train_bwd_mfma_kernel<512>, dim3(H), dim3(256), 0, st, n, k, D, dpre, dn, dk, dD, B, H, L);
+        return;
+    }
     float* pk = partial;
     float* pD = partial + (size_t)B * H * L;
     hipLaunchKernelGGL(s4_conv_train_bwd_kernel, dim3(H, B), dim3(256), 0, st, n, k, D, dpre, dn, pk, pD, B, H, L);

@@ -202,7 +202,10 @@ def s4layer_params(H, N, L, seed=200):
 
 
 @pytest.mark.parametrize("symmetric", [False, True])
-@pytest.mark.parametrize("B,H,T,N,Lint,groups", [(2, 32, 32, 8, 32, 8), (2, 32, 48, 32, 64, 16), (1, 64, 128, 32, 128, 32)])
+@pytest.mark.parametrize("B,H,T,N,Lint,groups", [(2, 32, 32, 8, 32, 8), (2, 32, 48, 32, 64, 16), (1, 64, 128, 32, 128, 32),
+                                                 # the Toeplitz-GEMM long convolution at its largest length (16 block diagonals) and over two
+                                                 # batch tiles with a ragged second one
+                                                 (3, 16, 512, 8, 512, 8), (34, 16, 64, 8, 64, 8)])
 def test_s4layer_forward_backward_vs_autograd(lib, B, H, T, N, Lint, groups, symmetric):
     """S4Layer (unet.py:76-91): GroupNorm -> NPLR kernel (s4.py:706-832) -> causal long conv + D u -> GELU -> Conv1d(H->2H) + GLU ->
     conv3 -> + x.  Native forward + backward, INCLUDING the kernel generator's parameter gradients (C, B, P, inv_w_real, w_imag,
