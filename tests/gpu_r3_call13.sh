@@ -6,7 +6,7 @@ python mug-diffusion_amd/build.py > gpurun_out/r3_build.log 2>&1
 timeout 900 python -m pytest tests/test_train.py -x -q -m gpu -p no:cacheprovider > gpurun_out/r3_train_tests_gpu_g.log 2>&1
 tail -2 gpurun_out/r3_train_tests_gpu_g.log
 for v in 1 0; do
-  MUGD_ATTN_BWD_VALU=$v timeout 300 python tests/gpu_train_probe.py --B 32 --reps 6 --bf16 --adamw 2>&1 | grep "step 5" | sed "s/^/valu=$v /"
+  MUGD_S4_TRAIN_DIRECT=$v timeout 300 python tests/gpu_train_probe.py --B 32 --reps 6 --bf16 --adamw 2>&1 | grep "step 5" | sed "s/^/s4direct=$v /"
 done
 rm -rf /tmp/trp
 (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/trp -- python $GRAFT_REPO_ROOT/tests/gpu_train_probe.py --B 32 --reps 4 --bf16 --adamw) > gpurun_out/r3_train_probe_bf16_prof.log 2>&1
