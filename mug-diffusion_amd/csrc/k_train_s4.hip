@@ -243,22 +243,46 @@ __global__ __launch_bounds__(256) void s4_conv_train_fwd_mfma_kernel(const float
     __syncthreads();
     const float Dh = D[h];
     const int nt = L >> 5;
-    for (int ti = wave; ti < nt; ti += 4) {                                // column tile of t; its k tiles are si <= ti
-        f32x16 acc;
+    // the wave's column tiles ta = wave + 8 j and tb = ta + 4 side by side: two independent accumulator chains share the A operand
+    // (a dependent MFMA chain on one accumulator leaves the matrix pipe idle between issues); an absent tb is computed on ta's operands and
+    // dropped (no control flow around the accumulators)
+    for (int ta = wave; ta < nt; ta += 8) {
+        const int tb = ta + 4;
+        const bool two = tb < nt;
+        f32x16 acc0, acc1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* bp = kz + L + ti * 32 + nn - hh;                      // B[s][t] = kz[L + t - s], s = s0 + hh
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
         const float* ap = us + nn * LS + hh;                               // A[b][s]
-        for (int s0 = 0; s0 < (ti + 1) * 32; s0 += 2)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[s0], bp[-s0], acc, 0, 0, 0);
+        const float* bp0 = kz + L + ta * 32 + nn - hh;                     // B[s][t] = kz[L + t - s], s = s0 + hh
+        const float* bp1 = kz + L + (two ? tb : ta) * 32 + nn - hh;
+        const int e0 = (ta + 1) * 32, e1 = two ? (tb + 1) * 32 : 0;
+        int s0 = 0;
+#pragma unroll 4
+        for (; s0 < e0; s0 += 2) {
+            const float av = ap[s0];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp0[-s0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp1[-s0], acc1, 0, 0, 0);
+        }
+#pragma unroll 4
+        for (; s0 < e1; s0 += 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[s0], bp1[-s0], acc1, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int br = (r & 3) + 8 * (r >> 2) + 4 * hh, t = ti * 32 + nn;
+            const int br = (r & 3) + 8 * (r >> 2) + 4 * hh;
             if (b0 + br < B) {
-                const float v = acc[r] + Dh * us[br * LS + t];
-                const size_t o = ((size_t)(b0 + br) * H + h) * L + t;
-                pre[o] = v;
-                g[o] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                {
+                    const int t = ta * 32 + nn;
+                    const float v = acc0[r] + Dh * us[br * LS + t];
+                    const size_t o = ((size_t)(b0 + br) * H + h) * L + t;
+                    pre[o] = v;
+                    g[o] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                }
+                if (two) {
+                    const int t = tb * 32 + nn;
+                    const float v = acc1[r] + Dh * us[br * LS + t];
+                    const size_t o = ((size_t)(b0 + br) * H + h) * L + t;
+                    pre[o] = v;
+                    g[o] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                }
             }
         }
     }
@@ -291,31 +315,53 @@ __global__ __launch_bounds__(256) void s4_conv_train_bwd_mfma_kernel(const float
             ds[r * LS + t] = in ? dpre[o] : 0.f;
         }
         __syncthreads();
-        // dn tiles of this wave: column tile ti (t'), k tiles >= ti
-        for (int ti = wave; ti < nt; ti += 4) {
-            f32x16 acc;
+        // dn tiles of this wave, two side by side (ta = wave + 8 j, tb = ta + 4): column tile t', k tiles >= the column tile
+        for (int ta = wave; ta < nt; ta += 8) {
+            const int tb = ta + 4;
+            const bool two = tb < nt;
+            f32x16 acc0, acc1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
             const float* ap = ds + nn * LS + hh;                           // A[b][t]
-            const float* bp = kz + L - (ti * 32 + nn) + hh;                // B[t][t'] = kz[L + t - t'], t = t0 + hh
-            for (int t0 = ti * 32; t0 < L; t0 += 2)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[t0], bp[t0], acc, 0, 0, 0);
+            const float* bp0 = kz + L - (ta * 32 + nn) + hh;               // B[t][t'] = kz[L + t - t'], t = t0 + hh
+            const float* bp1 = kz + L - ((two ? tb : ta) * 32 + nn) + hh;
+            const int m = two ? tb * 32 : L;                               // from here on both tiles have terms
+            int t0 = ta * 32;
+#pragma unroll 4
+            for (; t0 < m; t0 += 2) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[t0], bp0[t0], acc0, 0, 0, 0);
+#pragma unroll 4
+            for (; t0 < L; t0 += 2) {
+                const float av = ap[t0];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp0[t0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp1[t0], acc1, 0, 0, 0);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int br = (r & 3) + 8 * (r >> 2) + 4 * hh, t = ti * 32 + nn;
-                if (b0 + br < B) dn[((size_t)(b0 + br) * H + h) * L + t] = acc[r] + Dh * ds[br * LS + t];
+                const int br = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (b0 + br < B) {
+                    dn[((size_t)(b0 + br) * H + h) * L + ta * 32 + nn] = acc0[r] + Dh * ds[br * LS + ta * 32 + nn];
+                    if (two) dn[((size_t)(b0 + br) * H + h) * L + tb * 32 + nn] = acc1[r] + Dh * ds[br * LS + tb * 32 + nn];
+                }
             }
         }
-        // DK block diagonals of this wave: tiles (ti, ti - dlt), k = the 32 batch rows of the tile
+        // DK block diagonals of this wave (dlt = wave + 4 q): tiles (ti, ti - dlt), k = the 32 batch rows.  The four accumulators advance
+        // together per row tile ti and share its A operand; a diagonal that has no tile at this ti multiplies by the zero half of kz
+        for (int ti = wave; ti < nt; ++ti) {
+            const float* ap = ds + hh * LS + ti * 32 + nn;                 // A[t][b] = dpre[b][t], b = bb + hh
+            const float* bq[4];
+            int sq[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int dlt = wave + 4 * q;
-            for (int ti = dlt; ti < nt; ++ti) {
-                const float* ap = ds + hh * LS + ti * 32 + nn;             // A[t][b] = dpre[b][t], b = bb + hh
-                const float* bp = us + hh * LS + (ti - dlt) * 32 + nn;     // B[b][u] = n[b][u]
-#pragma unroll 8
-                for (int bb = 0; bb < 32; bb += 2)
-                    dacc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[bb * LS], bp[bb * LS], dacc[q], 0, 0, 0);
+            for (int q = 0; q < 4; ++q) {
+                const int dlt = wave + 4 * q;
+                const bool on = dlt <= ti;
+                bq[q] = on ? us + hh * LS + (ti - dlt) * 32 + nn : kz;     // B[b][u] = n[b][u]; kz[0] = 0
+                sq[q] = on ? LS : 0;
+            }
+#pragma unroll 4
+            for (int bb = 0; bb < 32; bb += 2) {
+                const float av = ap[bb * LS];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dacc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[q][bb * sq[q]], dacc[q], 0, 0, 0);
             }
         }
     }
