@@ -315,53 +315,31 @@ __global__ __launch_bounds__(256) void s4_conv_train_bwd_mfma_kernel(const float
             ds[r * LS + t] = in ? dpre[o] : 0.f;
         }
         __syncthreads();
-        // dn tiles of this wave, two side by side (ta = wave + 8 j, tb = ta + 4): column tile t', k tiles >= the column tile
-        for (int ta = wave; ta < nt; ta += 8) {
-            const int tb = ta + 4;
-            const bool two = tb < nt;
-            f32x16 acc0, acc1;
+        // dn tiles of this wave: column tile ti (t'), k tiles >= ti
+        for (int ti = wave; ti < nt; ti += 4) {
+            f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             const float* ap = ds + nn * LS + hh;                           // A[b][t]
-            const float* bp0 = kz + L - (ta * 32 + nn) + hh;               // B[t][t'] = kz[L + t - t'], t = t0 + hh
-            const float* bp1 = kz + L - ((two ? tb : ta) * 32 + nn) + hh;
-            const int m = two ? tb * 32 : L;                               // from here on both tiles have terms
-            int t0 = ta * 32;
-#pragma unroll 4
-            for (; t0 < m; t0 += 2) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[t0], bp0[t0], acc0, 0, 0, 0);
-#pragma unroll 4
-            for (; t0 < L; t0 += 2) {
-                const float av = ap[t0];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp0[t0], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp1[t0], acc1, 0, 0, 0);
-            }
+            const float* bp = kz + L - (ti * 32 + nn) + hh;                // B[t][t'] = kz[L + t - t'], t = t0 + hh
+            for (int t0 = ti * 32; t0 < L; t0 += 2)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[t0], bp[t0], acc, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int br = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (b0 + br < B) {
-                    dn[((size_t)(b0 + br) * H + h) * L + ta * 32 + nn] = acc0[r] + Dh * ds[br * LS + ta * 32 + nn];
-                    if (two) dn[((size_t)(b0 + br) * H + h) * L + tb * 32 + nn] = acc1[r] + Dh * ds[br * LS + tb * 32 + nn];
-                }
+                const int br = (r & 3) + 8 * (r >> 2) + 4 * hh, t = ti * 32 + nn;
+                if (b0 + br < B) dn[((size_t)(b0 + br) * H + h) * L + t] = acc[r] + Dh * ds[br * LS + t];
             }
         }
-        // DK block diagonals of this wave (dlt = wave + 4 q): tiles (ti, ti - dlt), k = the 32 batch rows.  The four accumulators advance
-        // together per row tile ti and share its A operand; a diagonal that has no tile at this ti multiplies by the zero half of kz
-        for (int ti = wave; ti < nt; ++ti) {
-            const float* ap = ds + hh * LS + ti * 32 + nn;                 // A[t][b] = dpre[b][t], b = bb + hh
-            const float* bq[4];
-            int sq[4];
+        // DK block diagonals of this wave: tiles (ti, ti - dlt), k = the 32 batch rows of the tile
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int dlt = wave + 4 * q;
-                const bool on = dlt <= ti;
-                bq[q] = on ? us + hh * LS + (ti - dlt) * 32 + nn : kz;     // B[b][u] = n[b][u]; kz[0] = 0
-                sq[q] = on ? LS : 0;
-            }
-#pragma unroll 4
-            for (int bb = 0; bb < 32; bb += 2) {
-                const float av = ap[bb * LS];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) dacc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[q][bb * sq[q]], dacc[q], 0, 0, 0);
+        for (int q = 0; q < 4; ++q) {
+            const int dlt = wave + 4 * q;
+            for (int ti = dlt; ti < nt; ++ti) {
+                const float* ap = ds + hh * LS + ti * 32 + nn;             // A[t][b] = dpre[b][t], b = bb + hh
+                const float* bp = us + hh * LS + (ti - dlt) * 32 + nn;     // B[b][u] = n[b][u]
+#pragma unroll 8
+                for (int bb = 0; bb < 32; bb += 2)
+                    dacc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[bb * LS], bp[bb * LS], dacc[q], 0, 0, 0);
             }
         }
     }
