@@ -26,6 +26,12 @@ __device__ __forceinline__ const float* gn_chan_ptr(const GnArgs& a, int b, int 
     return a.seg[s].x + ((size_t)bb * a.seg[s].C + c) * a.T;
 }
 
+__device__ __forceinline__ unsigned gn_pack_bf16(float lo, float hi) {        // {bf16(lo), bf16(hi)}, round to nearest even
+    typedef __bf16 gbf16x2 __attribute__((ext_vector_type(2)));
+    typedef float gf32x2 __attribute__((ext_vector_type(2)));
+    gf32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, gbf16x2));
+}
 // grid (groups, B), block 256.  mug/model/models.py:10-13 (eps 1e-6, biased variance).
 template <bool VEC4>
 __global__ __launch_bounds__(256) void group_norm_kernel(const GnArgs a) {
@@ -74,11 +80,13 @@ __global__ __launch_bounds__(256) void group_norm_kernel(const GnArgs a) {
         if (VEC4) {
             const float4* p4 = reinterpret_cast<const float4*>(p);
             float4* o4 = reinterpret_cast<float4*>(o);
+            uint2* o16 = a.y16 ? reinterpret_cast<uint2*>(a.y16 + ((size_t)b * a.Ctot + c_lo + c) * T) : nullptr;
             auto out = [&](int t, float4 v) {
                 v.x = (v.x - mean) * ga + be; v.y = (v.y - mean) * ga + be;
                 v.z = (v.z - mean) * ga + be; v.w = (v.w - mean) * ga + be;
                 if (a.silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
-                o4[t] = v;
+                if (o16) o16[t] = make_uint2(gn_pack_bf16(v.x, v.y), gn_pack_bf16(v.z, v.w));      // round to nearest even, like the GEMMs' staging
+                else o4[t] = v;
             };
             const int T4 = T >> 2;
             int t = lane;
@@ -91,7 +99,7 @@ __global__ __launch_bounds__(256) void group_norm_kernel(const GnArgs a) {
             for (int t = lane; t < T; t += 64) {
                 float v = (p[t] - mean) * ga + be;
                 if (a.silu) v = silu_f(v);
-                o[t] = v;
+                o[t] = v;                                   // (y16 needs T % 4 == 0: launch_group_norm checks)
             }
         }
     }
@@ -285,6 +293,7 @@ void launch_group_norm(hipStream_t st, const GnArgs& a) {
     int ct = 0;
     for (int i = 0; i < a.nseg; ++i) ct += a.seg[i].C;
     MUGD_CHECK(ct == a.Ctot, -2, "group_norm: segment channels do not add up");
+    MUGD_CHECK(!a.y16 || a.T % 4 == 0, -2, "group_norm: bf16 output needs T % 4 == 0");
     if (a.T % 4 == 0) hipLaunchKernelGGL((group_norm_kernel<true>), dim3(a.groups, a.B), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((group_norm_kernel<false>), dim3(a.groups, a.B), dim3(256), 0, st, a);
 }

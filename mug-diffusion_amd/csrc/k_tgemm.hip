@@ -103,7 +103,9 @@ constexpr int TC_BUF = 32 * 79 + 4;        // dwords per LDS buffer: the largest
 // the generic form walks the window as a flat index with scalar loads.
 // RESID (FAST only): the launch has a residual operand; its prefetch registers (32 for NT = 2) are what decides between a window ring of
 // 4 stages (without) and of 2 (with) inside the 256 registers two waves per SIMD allow.
-template <int TAPS, int NT, bool FAST, bool RESID>
+// XB (FAST, 3-tap): the activation tensor is stored as bfloat16 (GnArgs::y16) -- the same values the fp32 form rounds at staging, half
+// the bytes: 8-byte granule loads, pairs assembled with bit operations.
+template <int TAPS, int NT, bool FAST, bool RESID, bool XB = false>
 __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
     constexpr int TC_TN = 32 * NT;
     constexpr int KSUB = (TAPS == 1 ? 4 : 2) * (NT == 1 ? 2 : 1);      // 16-channel blocks per stage: the narrow tile stages twice the channels (same bytes per stage, half the barriers / latency periods per FLOP)
@@ -195,6 +197,7 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
         }
     }
     const float* xb = a.x + (size_t)b * a.C * a.Tin;
+    const unsigned short* xb16 = reinterpret_cast<const unsigned short*>(a.x) + (size_t)b * a.C * a.Tin;      // XB
     const int mtile = mb * 4 + wave;
     const bool active = mtile * 32 < a.M;
     const int nkb = a.nkb;
@@ -248,8 +251,9 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
     // stage runs the same straight-line code; activation channels past C are zeroed when they are parked.
     const int nstage = nkb / KSUB;
     struct XRegs {                                   // the raw window samples of one stage, as loaded
-        float4 qlo[NQ], qhi[NQ];
-        float hlo[NH], hhi[NH];
+        float4 qlo[XB ? 1 : NQ], qhi[XB ? 1 : NQ];
+        uint2 blo[XB ? NQ : 1], bhi[XB ? NQ : 1];      // XB: 4 bf16 samples per granule and channel
+        float hlo[NH], hhi[NH];                         // XB: the halo sample's bits << 16 (= its fp32 value)
         float xlo[NIT], xhi[NIT];
     };
     // The activation stream runs D stages ahead of the matrix pipe in a ring of register sets.  FAST: D = 4 -- a stage is 8.5 KB per
@@ -269,18 +273,30 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
             for (int i = 0; i < NQ; ++i) {
                 const int pc = qp[i] < cmax ? qp[i] : cmax;  // channels past C (the last, partial stage): clamped address, zeroed in park()
                 const int t = qt[i] + tj;                    // Tin % 4 == 0: a granule is wholly inside or outside
-                const float* q = xb + (size_t)(unsigned)((c0 + pc) * a.Tin) + (t < a.Tin ? t : a.Tin - 4);
-                X.qlo[i] = *reinterpret_cast<const float4*>(q);
-                X.qhi[i] = *reinterpret_cast<const float4*>(q + a.Tin);
+                const size_t eo = (size_t)(unsigned)((c0 + pc) * a.Tin) + (t < a.Tin ? t : a.Tin - 4);
+                if (XB) {
+                    const unsigned short* q = xb16 + eo;
+                    X.blo[i] = *reinterpret_cast<const uint2*>(q);
+                    X.bhi[i] = *reinterpret_cast<const uint2*>(q + a.Tin);
+                } else {
+                    const float* q = xb + eo;
+                    X.qlo[XB ? 0 : i] = *reinterpret_cast<const float4*>(q);
+                    X.qhi[XB ? 0 : i] = *reinterpret_cast<const float4*>(q + a.Tin);
+                }
             }
             if (TAPS == 3) {
 #pragma unroll
                 for (int i = 0; i < NH; ++i) {
                     const int pc = hp[i] < cmax ? hp[i] : cmax;
                     const int u = hu[i] + tj;
-                    const float* q = xb + (size_t)(unsigned)((c0 + pc) * a.Tin) + (u < 0 ? 0 : (u < a.Tin ? u : a.Tin - 1));
-                    X.hlo[i] = q[0];
-                    X.hhi[i] = q[a.Tin];
+                    const size_t eo = (size_t)(unsigned)((c0 + pc) * a.Tin) + (u < 0 ? 0 : (u < a.Tin ? u : a.Tin - 1));
+                    if (XB) {
+                        X.hlo[i] = __builtin_bit_cast(float, (unsigned)xb16[eo] << 16);
+                        X.hhi[i] = __builtin_bit_cast(float, (unsigned)xb16[eo + a.Tin] << 16);
+                    } else {
+                        X.hlo[i] = xb[eo];
+                        X.hhi[i] = xb[eo + a.Tin];
+                    }
                 }
             }
         } else {
@@ -309,10 +325,19 @@ __global__ __launch_bounds__(256) void tconv_bf16_kernel(const TConvArgs a) {
             for (int i = 0; i < NQ; ++i) {
                 const bool okc = qt[i] + tj < a.Tin && qp[i] <= cmax;
                 u32x4 v;
-                v[0] = pack_bf16(okc ? X.qlo[i].x : 0.f, okc ? X.qhi[i].x : 0.f);
-                v[1] = pack_bf16(okc ? X.qlo[i].y : 0.f, okc ? X.qhi[i].y : 0.f);
-                v[2] = pack_bf16(okc ? X.qlo[i].z : 0.f, okc ? X.qhi[i].z : 0.f);
-                v[3] = pack_bf16(okc ? X.qlo[i].w : 0.f, okc ? X.qhi[i].w : 0.f);
+                if (XB) {                                    // {lo sample, hi sample} per column from two rows of 4 bf16
+                    const uint2 lo = X.blo[XB ? i : 0], hi = X.bhi[XB ? i : 0];
+                    v[0] = okc ? (lo.x & 0xffffu) | (hi.x << 16) : 0u;
+                    v[1] = okc ? (lo.x >> 16) | (hi.x & 0xffff0000u) : 0u;
+                    v[2] = okc ? (lo.y & 0xffffu) | (hi.y << 16) : 0u;
+                    v[3] = okc ? (lo.y >> 16) | (hi.y & 0xffff0000u) : 0u;
+                } else {
+                    const float4 lo = X.qlo[XB ? 0 : i], hi = X.qhi[XB ? 0 : i];
+                    v[0] = pack_bf16(okc ? lo.x : 0.f, okc ? hi.x : 0.f);
+                    v[1] = pack_bf16(okc ? lo.y : 0.f, okc ? hi.y : 0.f);
+                    v[2] = pack_bf16(okc ? lo.z : 0.f, okc ? hi.z : 0.f);
+                    v[3] = pack_bf16(okc ? lo.w : 0.f, okc ? hi.w : 0.f);
+                }
                 *reinterpret_cast<u32x4*>(w + qlds[i]) = v;
             }
             if (TAPS == 3) {
@@ -436,7 +461,8 @@ constexpr int TW_XS = 81;                 // LDS row stride of the input window 
 // with 16-byte loads (dY and the window's interior: 4 samples per load; the <= 16 halo columns of a 3-tap window with scalar ones), and the
 // operand stream runs TWO slabs ahead of the matrix pipe in ping-pong registers -- the generic form requests one slab ahead with a 4-byte
 // load (and an index division) per element, which left a whole memory round trip exposed per slab on the short 1x1 layers.
-template <int TAPS, int TW_KT, bool DB, bool BIG, bool FAST>
+// XB (FAST, 3-tap): the input tensor X is stored as bfloat16 (GnArgs::y16): 8-byte granule loads, widened to fp32 (exactly) when parked.
+template <int TAPS, int TW_KT, bool DB, bool BIG, bool FAST, bool XB = false>
 __global__ __launch_bounds__(BIG ? 512 : 256) MUGD_WAVES_PER_EU(2) void twgrad_bf16_kernel(const TWgradArgs a) {
     constexpr int NTHR = BIG ? 512 : 256;
     constexpr int TM = BIG ? 128 : 64;                  // tile rows (m) = tile columns (c)
@@ -458,8 +484,9 @@ __global__ __launch_bounds__(BIG ? 512 : 256) MUGD_WAVES_PER_EU(2) void twgrad_b
     constexpr int NQ = TM * QPR / NTHR;                 // FAST: granules per thread of dY, and of the window's interior (4 | 2)
     constexpr int NH = TAPS == 3 ? (TM * 16 + NTHR - 1) / NTHR : 1;      // FAST: halo elements per thread (<= 16 halo columns per row)
     struct Slab {                                       // the raw samples of one slab, as loaded
-        float4 qy[FAST ? NQ : 1], qx[FAST ? NQ : 1];
-        float hx[FAST ? NH : 1];
+        float4 qy[FAST ? NQ : 1], qx[FAST && !XB ? NQ : 1];
+        uint2 bx[XB ? NQ : 1];                          // XB: 4 bf16 samples of the window interior
+        float hx[FAST ? NH : 1];                        // XB: the halo sample widened to fp32
         float vy[FAST ? 1 : NY], vx[FAST ? 1 : NX];
     };
     // bias gradient db[m] = sum_{b,t} dY[b][m][t], fused: the c-tile-0 workgroups add up the dY values they stage anyway (fp32, fixed order)
@@ -512,18 +539,21 @@ __global__ __launch_bounds__(BIG ? 512 : 256) MUGD_WAVES_PER_EU(2) void twgrad_b
         const int b = s / nslab, t0 = (s - b * nslab) * TW_KT;
         const float* yb = a.dY + (size_t)b * a.M * a.Tout;
         const float* xbp = a.X + (size_t)b * a.C * a.Tin;
+        const unsigned short* xbp16 = reinterpret_cast<const unsigned short*>(a.X) + (size_t)b * a.C * a.Tin;      // XB
         if (FAST) {
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
                 const int t = t0 + qcol[i];                                     // Tout = Tin (stride 1, taps 1 | 3 with "same" padding or not: X sample of column pad + q is t0 + q)
                 R.qy[i] = *reinterpret_cast<const float4*>(yb + qyo[i] + (t < a.Tout ? t : a.Tout - 4));
-                R.qx[i] = *reinterpret_cast<const float4*>(xbp + qxo[i] + (t < a.Tin ? t : a.Tin - 4));
+                if (XB) R.bx[XB ? i : 0] = *reinterpret_cast<const uint2*>(xbp16 + qxo[i] + (t < a.Tin ? t : a.Tin - 4));
+                else R.qx[XB ? 0 : i] = *reinterpret_cast<const float4*>(xbp + qxo[i] + (t < a.Tin ? t : a.Tin - 4));
             }
             if (TAPS == 3) {
 #pragma unroll
                 for (int i = 0; i < NH; ++i) {
                     const int u = t0 - a.pad + hcol[i];
-                    R.hx[i] = xbp[hxo[i] + (u < 0 ? 0 : (u < a.Tin ? u : a.Tin - 1))];
+                    const unsigned eo = hxo[i] + (u < 0 ? 0 : (u < a.Tin ? u : a.Tin - 1));
+                    R.hx[i] = XB ? __builtin_bit_cast(float, (unsigned)xbp16[eo] << 16) : xbp[eo];
                 }
             }
             return;
@@ -560,7 +590,14 @@ __global__ __launch_bounds__(BIG ? 512 : 256) MUGD_WAVES_PER_EU(2) void twgrad_b
                 py[0] = y0; py[1] = y1; py[2] = y2; py[3] = y3;
                 if (DB) rs[i] += (y0 + y1) + (y2 + y3);
                 float* px = sx + qrow[i] * TW_XS + a.pad + qcol[i];
-                px[0] = okx ? R.qx[i].x : 0.f; px[1] = okx ? R.qx[i].y : 0.f; px[2] = okx ? R.qx[i].z : 0.f; px[3] = okx ? R.qx[i].w : 0.f;
+                if (XB) {
+                    const uint2 w = R.bx[XB ? i : 0];
+                    px[0] = okx ? __builtin_bit_cast(float, w.x << 16) : 0.f; px[1] = okx ? __builtin_bit_cast(float, w.x & 0xffff0000u) : 0.f;
+                    px[2] = okx ? __builtin_bit_cast(float, w.y << 16) : 0.f; px[3] = okx ? __builtin_bit_cast(float, w.y & 0xffff0000u) : 0.f;
+                } else {
+                    const float4 w = R.qx[XB ? 0 : i];
+                    px[0] = okx ? w.x : 0.f; px[1] = okx ? w.y : 0.f; px[2] = okx ? w.z : 0.f; px[3] = okx ? w.w : 0.f;
+                }
             }
             if (TAPS == 3) {
 #pragma unroll
@@ -776,6 +813,14 @@ void launch_tconv_bf16(hipStream_t st, const TConvArgs& a0) {
         if (const char* e = getenv("MUGD_TCONV_TPW")) { const int v = atoi(e); if (v >= 1 && v <= 64) a.tpw = v; }      // development / test knob
     }
     const dim3 grid((unsigned)cdiv(a.gx, a.tpw) * a.gy * a.B);
+    MUGD_CHECK(!a.x_bf16 || (fast && a.taps == 3), -2, "tconv: bfloat16 activations only in the 3-tap FAST form");
+    if (a.x_bf16) {
+        if (nt == 1 && a.resid) hipLaunchKernelGGL((tconv_bf16_kernel<3, 1, true, true, true>), grid, dim3(256), 0, st, a);
+        else if (nt == 1) hipLaunchKernelGGL((tconv_bf16_kernel<3, 1, true, false, true>), grid, dim3(256), 0, st, a);
+        else if (a.resid) hipLaunchKernelGGL((tconv_bf16_kernel<3, 2, true, true, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((tconv_bf16_kernel<3, 2, true, false, true>), grid, dim3(256), 0, st, a);
+        return;
+    }
 #define MUGD_TC(T, N)                                                                                                     \
     do {                                                                                                                  \
         if (fast && a.resid) hipLaunchKernelGGL((tconv_bf16_kernel<T, N, true, true>), grid, dim3(256), 0, st, a);         \
@@ -845,12 +890,19 @@ void launch_twgrad_bf16(hipStream_t st, const TWgradArgs& a0, float* partial, bo
         else if (fast) hipLaunchKernelGGL((twgrad_bf16_kernel<T, K, D, false, true>), grid, blk, 0, st, a);        \
         else hipLaunchKernelGGL((twgrad_bf16_kernel<T, K, D, false, false>), grid, blk, 0, st, a);                 \
     } while (0)
+    MUGD_CHECK(!a.x_bf16 || a.taps == 3, -2, "twgrad: bfloat16 activations only for 3-tap layers");
     if (a.taps == 1) {
         MUGD_CHECK(a.stride == 1, -2, "twgrad: strided 1x1 convs are not used by the model");
         MUGD_CHECK(!a.db || fast, -2, "twgrad: the generic 1x1 form does not produce the bias gradient (twgrad_fuses_bias)");
         if (a.db && big) hipLaunchKernelGGL((twgrad_bf16_kernel<1, 64, true, true, true>), grid, blk, 0, st, a);
         else if (a.db) hipLaunchKernelGGL((twgrad_bf16_kernel<1, 64, true, false, true>), grid, blk, 0, st, a);
         else MUGD_TW(1, 64, false);
+    } else if (a.x_bf16) {
+        MUGD_CHECK(fast, -2, "twgrad: bfloat16 activations only in the FAST form");
+        if (a.db && big) hipLaunchKernelGGL((twgrad_bf16_kernel<3, 32, true, true, true, true>), grid, blk, 0, st, a);
+        else if (a.db) hipLaunchKernelGGL((twgrad_bf16_kernel<3, 32, true, false, true, true>), grid, blk, 0, st, a);
+        else if (big) hipLaunchKernelGGL((twgrad_bf16_kernel<3, 32, false, true, true, true>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((twgrad_bf16_kernel<3, 32, false, false, true, true>), grid, blk, 0, st, a);
     } else if (a.db) {
         MUGD_TW(3, 32, true);
     } else {

@@ -170,6 +170,8 @@ struct GnArgs {
     float eps;
     float* y;                // (B, Ctot, T) contiguous
     float* stats;            // null, or (B, groups, 2): the group's {mean, rstd} as applied, kept for the backward pass (training)
+    unsigned short* y16;     // null, or the output as bfloat16 (B, Ctot, T) INSTEAD of y (T % 4 == 0): the bf16 training GEMMs round their
+                             // activation operand to bf16 anyway -- same values, half the bytes written here and read by both consumers
 };
 void launch_group_norm(hipStream_t st, const GnArgs& a);
 
@@ -389,6 +391,7 @@ struct TConvArgs {           // y[b][m][t] = bias[m] + rowadd[b][m] + resid[b][m
     const float* resid;              // (B, M, Tout) or null (may alias y)
     float* y;                        // (B, M, Tout)
     int B, C, Tin, M, Tout, taps, dil, stride, pad, ups;
+    int x_bf16;                      // 1: x points at bfloat16 (B, C, Tin) (GnArgs::y16); 3-tap FAST launches only
     int nkb, gx, gy, tpw;            // set by the launcher (tpw: consecutive time tiles per workgroup)
 };
 struct TWgradArgs {          // dW[m][c][tap] = sum_{b,t} dY[b][m][t] X[b][c][stride t + tap dil - pad]
@@ -396,6 +399,7 @@ struct TWgradArgs {          // dW[m][c][tap] = sum_{b,t} dY[b][m][t] X[b][c][st
     int B, M, C, Tout, Tin, taps, pad, dil, stride, ups, KS;
     float* db;               // null, or [M]: the bias gradient sum_{b,t} dY[b][m][t], summed from the dY slabs the kernel stages anyway
     int big;                 // 1: 128 x 128 tiles on 8 waves (twgrad_big_tile), 0: 64 x 64 on 4
+    int x_bf16;              // 1: X points at bfloat16 (B, C, Tin); 3-tap FAST launches only
 };
 size_t tpack_elems(int rows, int K, int taps);               // bf16 elements of the packed form
 // A[row][k][tap] = src[row * s_row + k * s_k + (flip ? taps - 1 - tap : tap)]  ->  bf16 MFMA A-fragment order (zero padded to 32 rows / 16 k)

@@ -39,6 +39,7 @@ struct Scratch {
     hipStream_t stream;
     std::vector<void*> bufs;
     bool temp_weights = false;         // set around convs whose "weights" are call-scoped temporaries: never through the pack cache
+    bool x_bf16 = false;               // set around a conv / weight-gradient call whose activation operand is stored as bfloat16 (GnArgs::y16)
     explicit Scratch(mugd_ctx* ctx_) : ctx(ctx_), pool(ctx_->pool), stream(ctx_->c.stream) {}
     float* get(size_t nfloats, bool zero, hipStream_t st) {
         float* p = (float*)pool.take(nfloats * sizeof(float) + 8192);
@@ -108,6 +109,12 @@ struct ProfScope {
     }
 };
 TrainProfile* g_tprof = nullptr;       // the active context's profile (one training context per process: set by mugd_train_profile)
+
+// development / test knob: MUGD_TRAIN_ACT_FP32=1 keeps the resblocks' normalised activations in fp32 (the A/B arm of their bf16 storage)
+bool train_act_bf16() {
+    if (const char* e = getenv("MUGD_TRAIN_ACT_FP32")) return e[0] != '1';
+    return true;
+}
 
 // ---- the step bracket (ctx.h: TrainStep) ---------------------------------------------------------------------------------------
 // bf16 A fragments of the (M, C, taps) weight tensor `w` (transposed: w is (C, M, taps), used flipped -- the data-gradient form).  Inside
@@ -209,6 +216,7 @@ void run_conv_ex(Ctx& c, Scratch& sc, const float* x, const float* w, bool trans
         TConvArgs a{};
         a.x = x; a.wpk = wpk; a.bias = bias; a.rowadd = rowadd; a.rowadd_stride = rowadd_stride; a.resid = resid; a.y = y;
         a.B = B; a.C = C; a.Tin = T; a.M = M; a.Tout = Tout > 0 ? Tout : T; a.taps = taps; a.dil = dil; a.stride = stride; a.pad = pad; a.ups = ups;
+        a.x_bf16 = sc.x_bf16 ? 1 : 0;
         launch_tconv_bf16(st, a);
         return;
     }
@@ -260,6 +268,7 @@ void run_wgrad(Ctx& c, Scratch& sc, const float* dY, const float* A, float* dW, 
         ProfScope prof(g_tprof, c.stream, 1, 2.0 * M * C * taps * (double)B * Tout);
         if (c.train_bf16) {
             TWgradArgs a{dY, A, dW, B, M, C, Tout, Tin, taps, pad, dil, stride, ups, twgrad_splits(B, M, C, Tout, taps, taps == 1 ? 64 : 32), nullptr, (stride == 1 && twgrad_big_tile(B, M, C, Tout)) ? 1 : 0};
+            a.x_bf16 = sc.x_bf16 ? 1 : 0;
             const bool fuse = db && twgrad_fuses_bias(a);
             if (fuse) a.db = db;
             const size_t nn = (size_t)M * C * taps;
@@ -297,9 +306,11 @@ void run_gn_bwd(Ctx& c, Scratch& sc, const float* x, const float* da, const floa
 }
 
 // stats (nullable): (B, groups, 2) {mean, rstd} kept with the block's intermediates; the backward kernel then skips its statistics pass
-void run_group_norm_silu(Ctx& c, const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T, int groups, float* stats = nullptr) {
+void run_group_norm_silu(Ctx& c, const float* x, const float* gamma, const float* beta, float* y, int B, int C, int T, int groups, float* stats = nullptr,
+                         bool as_bf16 = false) {
     GnArgs a{};
     a.stats = stats;
+    if (as_bf16) { a.y16 = reinterpret_cast<unsigned short*>(y); y = nullptr; }
     a.seg[0] = NormSeg{x, C, 0};
     a.nseg = 1; a.Ctot = C; a.T = T; a.groups = groups; a.B = B; a.silu = 1;
     a.gamma = gamma; a.beta = beta; a.eps = 1e-6f; a.y = y;
@@ -362,17 +373,25 @@ void resblock_impl(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x,
     float* a2 = in.get(nout);
     float* st1 = in.get((size_t)B * groups * 2);
     float* st2 = in.get((size_t)B * groups * 2);
+    // bf16 mode: the two normalised activations are only ever read by bf16 GEMMs (conv forward, weight gradient) that round them to
+    // bfloat16 at staging -- store them rounded: bit-identical results, half the bytes written once and read twice
+    const bool a16 = c.train_bf16 && (T & 3) == 0 && train_act_bf16();
     if (!in.replay) {
-        run_group_norm_silu(c, x, p->gn1_w, p->gn1_b, a1, B, Cin, T, groups, st1);
+        run_group_norm_silu(c, x, p->gn1_w, p->gn1_b, a1, B, Cin, T, groups, st1, a16);
         if (emb) launch_linear_small(st, LinSmallArgs{emb, p->emb_w, p->emb_b, E, B, Kemb, Cout, 1, 0, Kemb, Cout});
+        sc.x_bf16 = a16;
         run_conv(c, sc, a1, p->conv1_w, p->conv1_b, E, Cout, nullptr, h, B, Cin, T, Cout, 3, d1, d1);
-        run_group_norm_silu(c, h, p->gn2_w, p->gn2_b, a2, B, Cout, T, groups, st2);
+        sc.x_bf16 = false;
+        run_group_norm_silu(c, h, p->gn2_w, p->gn2_b, a2, B, Cout, T, groups, st2, a16);
         if (p->skip_w) {
             run_conv(c, sc, x, p->skip_w, p->skip_b, nullptr, 0, nullptr, y, B, Cin, T, Cout, 1, 0);
+            sc.x_bf16 = a16;
             run_conv(c, sc, a2, p->conv2_w, p->conv2_b, nullptr, 0, y, y, B, Cout, T, Cout, 3, d2, d2);
         } else {
+            sc.x_bf16 = a16;
             run_conv(c, sc, a2, p->conv2_w, p->conv2_b, nullptr, 0, x, y, B, Cout, T, Cout, 3, d2, d2);
         }
+        sc.x_bf16 = false;
     }
     if (!dy) { in.keep(); return; }
     if (dy) {
@@ -381,7 +400,9 @@ void resblock_impl(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x,
         float* da1 = sc.get(nin, false, st);
         float* wt = sc.get((size_t)Cout * std::max(Cin, Cout) * 3, false, st);
         // out_layers conv: dW2, db2, da2 = conv3(dy; W2 transposed + flipped)
+        sc.x_bf16 = a16;
         run_wgrad(c, sc, dy, a2, g->conv2_w, B, Cout, Cout, T, T, 3, d2, d2, 1, 0, g->conv2_b);
+        sc.x_bf16 = false;
         run_dgrad(c, sc, dy, p->conv2_w, wt, nullptr, da2, B, Cout, Cout, T, 3, d2, d2);
         run_gn_bwd(c, sc, h, da2, p->gn2_w, p->gn2_b, dh, g->gn2_w, g->gn2_b, B, Cout, T, groups, 1, nullptr, st2);
         if (emb) {          // h = conv1 + b1 + E: time-embedding branch
@@ -389,7 +410,9 @@ void resblock_impl(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x,
             launch_time_sum(st, dh, dE, B * Cout, T);
             launch_emb_linear_bwd(st, emb, p->emb_w, dE, g->emb_w, g->emb_b, demb, B, Kemb, Cout);
         }
+        sc.x_bf16 = a16;
         run_wgrad(c, sc, dh, a1, g->conv1_w, B, Cout, Cin, T, T, 3, d1, d1, 1, 0, g->conv1_b);
+        sc.x_bf16 = false;
         run_dgrad(c, sc, dh, p->conv1_w, wt, nullptr, da1, B, Cout, Cin, T, 3, d1, d1);
         run_gn_bwd(c, sc, x, da1, p->gn1_w, p->gn1_b, dx, g->gn1_w, g->gn1_b, B, Cin, T, groups, 1, p->skip_w ? nullptr : dy, st1);      // identity skip: dx += dy
         if (p->skip_w) {

@@ -45,6 +45,7 @@ struct uint2 { unsigned x, y; };
 struct int2 { int x, y; };
 struct int4 { int x, y, z, w; };
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline double2 make_double2(double x, double y) { return double2{x, y}; }
 

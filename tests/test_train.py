@@ -201,6 +201,36 @@ def s4layer_params(H, N, L, seed=200):
     return p
 
 
+@pytest.mark.parametrize("B,Cin,Cout,T,Kemb,groups", [(2, 32, 32, 40, 48, 8), (3, 32, 64, 64, 64, 16), (2, 128, 128, 96, 512, 32), (1, 64, 32, 132, 32, 32)])
+def test_resblock_bf16_activation_storage_changes_nothing(lib, monkeypatch, B, Cin, Cout, T, Kemb, groups):
+    """bf16 mode stores a ResBlock's two normalised activations (the conv / weight-gradient operands) as bfloat16 -- the GEMMs round them at
+    staging anyway: forward, input / embedding gradients and every parameter gradient are BIT-IDENTICAL to the fp32-stored arm
+    (MUGD_TRAIN_ACT_FP32=1), with and without the time embedding, with the block's intermediates kept between the two calls or not."""
+    p = resblock_params(Cin, Cout, Kemb)
+    x, emb, dy = rnd(20, B, Cin, T), rnd(21, B, Kemb), rnd(22, B, Cout, T)
+
+    def run(fp32_store, keep):
+        monkeypatch.setenv("MUGD_TRAIN_ACT_FP32", "1" if fp32_store else "0")
+        if keep:
+            from mug._native import TrainState
+            st = TrainState()
+            y = lib.train_resblock(p, x, emb, None, groups=groups, state=st)[0]
+            _, dx, demb, g = lib.train_resblock(p, x, emb, dy, groups=groups, state=st)
+        else:
+            y, dx, demb, g = lib.train_resblock(p, x, emb, dy, groups=groups)
+        return [y, dx, demb] + [g[k] for k in sorted(g)]
+
+    lib.train_set_precision(True)
+    try:
+        for keep in (False, True):
+            a, b = run(False, keep), run(True, keep)
+            for i, (u, v) in enumerate(zip(a, b)):
+                assert torch.equal(u.cpu(), v.cpu()), (keep, i, float((u.cpu() - v.cpu()).abs().max()))
+    finally:
+        lib.train_set_precision(False)
+
+
+
 @pytest.mark.parametrize("symmetric", [False, True])
 @pytest.mark.parametrize("B,H,T,N,Lint,groups", [(2, 32, 32, 8, 32, 8), (2, 32, 48, 32, 64, 16), (1, 64, 128, 32, 128, 32),
                                                  # the Toeplitz-GEMM long convolution at its largest length (16 block diagonals) and over two
