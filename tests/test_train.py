@@ -519,6 +519,17 @@ def _step_worker(rank, world, port, q):
         loss2, grads2 = train.training_step(lib, sd, case["unet"], case["wave"], x0[sl], noise[sl], t[sl], ids[sl], mel[sl])
         train.allreduce_gradients(grads2, average=True)
         assert set(grads) == set(grads2) and all(torch.equal(grads[k], grads2[k]) for k in grads), "bucketed / overlapped reduction differs"
+        # the same in bf16 mode: weight-gradient split-K slices are still queued in the library's reduction table when a bucket fills --
+        # the reducer flushes the table before it reads the bucket's tensors
+        lib.train_set_precision(True)
+        try:
+            red16 = train.BucketedAllReduce(bucket_bytes=64 << 10)
+            _, g16 = train.training_step(lib, sd, case["unet"], case["wave"], x0[sl], noise[sl], t[sl], ids[sl], mel[sl], reducer=red16)
+            _, g16b = train.training_step(lib, sd, case["unet"], case["wave"], x0[sl], noise[sl], t[sl], ids[sl], mel[sl])
+            train.allreduce_gradients(g16b, average=True)
+            assert red16.n_buckets > 3 and all(torch.equal(g16[k], g16b[k]) for k in g16), "bf16 mode: bucketed / overlapped reduction differs"
+        finally:
+            lib.train_set_precision(False)
         q.put((rank, float(loss), {k: v.cpu().numpy() for k, v in grads.items()}))
     finally:
         dist.destroy_process_group()
