@@ -35,6 +35,7 @@ __device__ __forceinline__ cf cdivc(cf a, cf b) {
 // grid (H), block 256
 __global__ __launch_bounds__(256) void s4_kernel_gen_kernel(const S4GenArgs a) {
     __shared__ float kfr[S4_LMAX / 2 + 1], kfi[S4_LMAX / 2 + 1];
+    __shared__ float twc[S4_LMAX], tws[S4_LMAX];
     __shared__ cf pw[64], pv00[64], pv01[64], pv10[64], pv11[64];
     const int h = blockIdx.x, N = a.N, L = a.Lint, Lf = L / 2 + 1;
     const float dt = expf(a.log_dt[h]);
@@ -82,16 +83,19 @@ __global__ __launch_bounds__(256) void s4_kernel_gen_kernel(const S4GenArgs a) {
         kfr[l] = 2.0f * kf.x;
         kfi[l] = 2.0f * kf.y;
     }
+    // twiddles by phase index: the values the loop below used to compute per (l, t) -- sincospif(2 ph / L) with ph = l t mod L -- once per
+    // phase (L of them instead of L^2 / 2 per channel: the kernel was 50 us of sincos per layer and training step)
+    for (int ph = threadIdx.x; ph < L; ph += 256) sincospif(2.0f * (float)ph / (float)L, &tws[ph], &twc[ph]);
     __syncthreads();
     // irfft(n = L): k[t] = (1/L) (Re kf[0] + (-1)^t Re kf[L/2] + 2 sum_{l=1}^{L/2-1} Re(kf[l] e^{+2 pi i l t / L}))
     for (int t = threadIdx.x; t < a.L; t += 256) {
         float acc = kfr[0] + ((t & 1) ? -kfr[L / 2] : kfr[L / 2]);
         float s2 = 0.f;
+        int ph = t;                                     // l t mod L for l = 1, advanced by t per step (t < L)
         for (int l = 1; l < L / 2; ++l) {
-            const int ph = (int)(((long long)l * t) % L);
-            float sn, cs;
-            sincospif(2.0f * (float)ph / (float)L, &sn, &cs);
-            s2 += kfr[l] * cs - kfi[l] * sn;
+            s2 += kfr[l] * twc[ph] - kfi[l] * tws[ph];
+            ph += t;
+            ph = ph >= L ? ph - L : ph;
         }
         a.k[(size_t)h * a.L + t] = (acc + 2.0f * s2) / (float)L;
     }

@@ -77,9 +77,12 @@ __global__ __launch_bounds__(256) void s4_kernel_gen_bwd_kernel(const S4GenBwdAr
     double gdt = 0.0;                                 // explicit-dt term: sum Re(g_s conj(s)) / dt
     for (int l = tid; l < Lf; l += 256) {
         cd gk{0.0, 0.0};
+        int ph = 0;                                   // l t mod Lint, advanced by l per step (l < Lint): no 64-bit modulo per term
         for (int t = 0; t < L; ++t) {
-            const cd e = tw[(int)(((long long)l * t) % Lint)];
+            const cd e = tw[ph];
             gk.x += (double)dk[t] * e.x; gk.y += (double)dk[t] * e.y;
+            ph += l;
+            ph = ph >= Lint ? ph - Lint : ph;
         }
         const bool edge = (l == 0) || (2 * l == Lint);
         gk = cscale(gk, (edge ? 1.0 : 2.0) / (double)Lint);
