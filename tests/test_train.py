@@ -422,6 +422,29 @@ def test_step_bracket_changes_nothing_over_two_steps(lib, monkeypatch):
     assert not bad, bad[:5]
 
 
+def test_step_bracket_entry_points_tolerate_any_call_order(lib):
+    """mugd_train_step_begin / _flush / _end in odd orders (end or flush without begin, begin twice, an empty bracket) succeed and leave the
+    block entry points working -- a conv layer's results inside a bracket opened twice equal the unbracketed ones, and a bracket that is
+    never closed is closed by the next begin (its queued reductions run then)."""
+    lib.train_step_end()
+    lib.train_step_flush()
+    lib.train_step_begin()
+    lib.train_step_begin()
+    lib.train_step_end()
+    w, b, x, dy = rnd(1, 48, 32, 3, scale=0.1), rnd(2, 48), rnd(3, 2, 32, 40), rnd(4, 2, 48, 40)
+    lib.train_set_precision(True)
+    try:
+        want = lib.train_conv(w, b, x, dy)
+        lib.train_step_begin()
+        got = lib.train_conv(w, b, x, dy)                 # weight / bias gradients are only queued here ...
+        lib.train_step_begin()                           # ... and reduced by the next begin (an abandoned step's leftovers)
+        lib.train_step_end()
+        for u, v in zip(want[:4], got[:4]):
+            assert torch.equal(u.cpu(), v.cpu())
+    finally:
+        lib.train_set_precision(False)
+
+
 def test_fused_adamw_over_a_tensor_list_matches_torch(lib):
     """mug.train.AdamW: the whole parameter list in ONE launch (mugd_train_adamw_chunks: tensors cut into runs of <= 4096 elements) against
     torch.optim.AdamW, three steps, tensors below / at / above the run length and of odd sizes."""
