@@ -431,7 +431,8 @@ def test_step_bracket_entry_points_tolerate_any_call_order(lib):
     lib.train_step_begin()
     lib.train_step_begin()
     lib.train_step_end()
-    w, b, x, dy = rnd(1, 48, 32, 3, scale=0.1), rnd(2, 48), rnd(3, 2, 32, 40), rnd(4, 2, 48, 40)
+    # resident tensors: a weight used inside a bracket must outlive it (include/mugd.h) -- no per-call staging copies
+    w, b, x, dy = (v.to(lib.device) for v in (rnd(1, 48, 32, 3, scale=0.1), rnd(2, 48), rnd(3, 2, 32, 40), rnd(4, 2, 48, 40)))
     lib.train_set_precision(True)
     try:
         want = lib.train_conv(w, b, x, dy)
