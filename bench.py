@@ -34,6 +34,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+PEAK_HBM_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E, 8 TB/s nominal (~6.3 TB/s achievable on a streaming kernel)
 UNET_GFLOP_PER_SAMPLE_STEP = 22.37     # BASELINE.md section 2 (z = 512)
 
 SHIPPED = dict(          # configs/mug/mug_diffusion.yaml of the reference (shapes only)
@@ -427,11 +428,11 @@ def training_leg(a, lib, model, dev, world, rank, grouped, sync_all, bf16=True):
     plan, opt = train.TrainPlan(lib, sd, SHIPPED["unet"], SHIPPED["wave"]), [None]
 
     def step(i):
-        red = train.BucketedAllReduce(bucket_bytes=64 << 20) if grouped else None          # 64 MB buckets, reduced while the backward sweep runs
+        red = train.BucketedAllReduce(bucket_bytes=64 << 20, even_single=True) if grouped else None          # 64 MB buckets, reduced while the backward sweep runs
         loss, grads = plan.step(x0, noise, t, ids, mel, reducer=red)
         if opt[0] is None:
             opt[0] = train.AdamW(lib, {k: sd[k] for k in grads}, grads, lr=1e-6)           # the model's own tensors: updated in place
-        opt[0].step()
+        opt[0].step(grads=grads)
         return loss, grads
 
     try:
@@ -458,6 +459,30 @@ def training_leg(a, lib, model, dev, world, rank, grouped, sync_all, bf16=True):
     gemm_ms = prof["conv"]["ms"] + prof["wgrad"]["ms"]
     gemm_fl = prof["conv"]["flops"] + prof["wgrad"]["flops"]
     kern = "tconv_bf16_kernel / twgrad_bf16_kernel (v_mfma_f32_32x32x16_bf16)" if bf16 else "conv_gemm_kernel / wgrad_mfma_kernel (v_mfma_f32_32x32x2_f32)"
+    gemm = {"kernel": kern + ": all %d GEMM launches of one step, HIP event pair around each on the library stream (bf16 mode: packed weights "
+                             "come from the step bracket's cache and the split-K slices are summed by the step's one reduction launch -- both "
+                             "outside the brackets)" % (prof["conv"]["launches"] + prof["wgrad"]["launches"]),
+            "bound": "mfma", "achieved": gemm_fl / (gemm_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+            "frac": gemm_fl / (gemm_ms * 1e-3) / 1e12 / peak,
+            "gemm_ms_per_step": gemm_ms, "gemm_share_of_step": gemm_ms / (dt * 1e3),
+            "forward_and_dgrad": {"tflops": prof["conv"]["flops"] / (prof["conv"]["ms"] * 1e-3) / 1e12, "ms": prof["conv"]["ms"], "launches": prof["conv"]["launches"]},
+            "wgrad": {"tflops": prof["wgrad"]["flops"] / (prof["wgrad"]["ms"] * 1e-3) / 1e12, "ms": prof["wgrad"]["ms"], "launches": prof["wgrad"]["launches"]}}
+    # What bounds the step is the memory system, not the matrix pipe: fp32 activations / gradients of 0.5 GB per tensor at the
+    # wave encoder's first level stream through every pass.  `traffic` is NOT measured by this process: counter bytes per step from
+    # profiles/train_traffic.json (separate rocprofv3 --pmc passes), scaled by the batch; `achieved` = those bytes over this run's step time.
+    roof = dict(gemm, bound="mfma (no counter file: GEMM-only figure)", traffic=None)
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "train_traffic.json")) as f:
+            tr = json.load(f)
+        if bf16 and tr.get("mode") == "bf16":
+            per_step = (tr["fetch_gb_x2"] + tr["write_gb"]) * 1e9 * Bt / tr["batch"]
+            roof = {"kernel": "the whole step's launch list (tconv / twgrad / GroupNorm forward + backward are 85 % of its bytes)",
+                    "bound": "hbm", "achieved": per_step / dt / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": per_step / dt / 1e9 / PEAK_HBM_GBS,
+                    "traffic": per_step, "traffic_source": "profiles/train_traffic.json: %s" % tr["source"],
+                    "traffic_range_gb": [(tr["fetch_gb_raw"] + tr["write_gb"]) * Bt / tr["batch"], (tr["fetch_gb_x2"] + tr["write_gb"]) * Bt / tr["batch"]],
+                    "gemm_mfma": gemm}
+    except (OSError, ValueError, KeyError):
+        pass
     return {"what": "configs[4] shape: DDPM training step (q_sample, wave encoder, prompt embedding, U-Net, smooth-L1, backward through all three "
                     "networks, bucketed gradient all-reduce overlapped with the backward sweep, AdamW), per-GPU batch %d, z = %d, synthetic data; %s"
                     % (Bt, z, "conv / Linear GEMMs (forward, data and weight gradients) with bf16 MFMA inputs and fp32 accumulation, fp32 master weights, "
@@ -465,16 +490,7 @@ def training_leg(a, lib, model, dev, world, rank, grouped, sync_all, bf16=True):
             "value": Bt * world / dt, "unit": "samples/s", "ms_per_step": dt * 1e3, "global_batch": Bt * world, "dtype": "bf16" if bf16 else "f32",
             "loss": float(loss), "gradient_tensors": len(grads), "trainable_parameters": int(nparam),
             "algorithmic_tflops_whole_step": TRAIN_GFLOP_PER_SAMPLE * Bt / dt / 1e3,
-            "roofline": {"kernel": kern + ": all %d GEMM launches of one step, HIP event pair around each on the library stream (bf16 mode: packed "
-                                         "weights come from the step bracket's cache and the split-K slices are summed by the step's one reduction "
-                                         "launch -- both outside the brackets; the wave encoder's 128-channel layers at 16k-32k frames are HBM-bound "
-                                         "on their fp32 activations, the U-Net's are launch-latency-bound: DESIGN.md 8c)"
-                                         % (prof["conv"]["launches"] + prof["wgrad"]["launches"]),
-                         "bound": "mfma", "achieved": gemm_fl / (gemm_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
-                         "frac": gemm_fl / (gemm_ms * 1e-3) / 1e12 / peak, "traffic": None,
-                         "gemm_ms_per_step": gemm_ms, "gemm_share_of_step": gemm_ms / (dt * 1e3),
-                         "forward_and_dgrad": {"tflops": prof["conv"]["flops"] / (prof["conv"]["ms"] * 1e-3) / 1e12, "ms": prof["conv"]["ms"], "launches": prof["conv"]["launches"]},
-                         "wgrad": {"tflops": prof["wgrad"]["flops"] / (prof["wgrad"]["ms"] * 1e-3) / 1e12, "ms": prof["wgrad"]["ms"], "launches": prof["wgrad"]["launches"]}},
+            "roofline": roof,
             "allreduce": ("RCCL, %.0f MB of fp32 gradients per step in 64 MB buckets, asynchronous, overlapped with the backward sweep"
                           % (nparam * 4 / 1e6)) if world > 1 else "none (1 rank)"}
 

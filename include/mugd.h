@@ -235,11 +235,17 @@ int mugd_train_set_precision(mugd_ctx* ctx, int bf16);
  *     seen in the previous step (a tensor seen for the first time is packed on the spot), instead of two small launches per GEMM;
  *   - split-K slices of the weight gradients and the per-batch-row bias sums are summed (same fixed order) by ONE launch per _flush / _end
  *     instead of one per GEMM: weight and bias gradients written by the block calls are complete only after _flush or _end.
- * A weight tensor used inside a bracket must stay allocated until the _begin after the next one (or mugd_destroy).  Outside a bracket
- * every block call packs and reduces on its own.  None of the three synchronises the host. */
+ * The cache is keyed by tensor ADDRESS and _begin re-reads every tensor the previous step used: a weight tensor used inside a bracket
+ * must stay allocated until the _begin after the next one, mugd_train_step_reset or mugd_destroy -- a caller that frees, replaces or
+ * moves parameters (another model, model.to(), an allocator cache flush) calls mugd_train_step_reset FIRST (the Python binding does:
+ * mug/train.py TrainPlan.invalidate, and it keeps the bracket's tensors referenced until then).  In fp32 mode nothing is cached or re-read.
+ * Outside a bracket every block call packs and reduces on its own.  _begin / _flush / _end do not synchronise the host. */
 int mugd_train_step_begin(mugd_ctx* ctx);
 int mugd_train_step_flush(mugd_ctx* ctx);
 int mugd_train_step_end(mugd_ctx* ctx);
+/* Runs the queued reductions, closes an open bracket and DROPS the packed-weight cache (no source pointer is kept).  Synchronises the
+ * device (the cache blocks are freed). */
+int mugd_train_step_reset(mugd_ctx* ctx);
 /* Measurement hook of the training GEMMs.  enable != 0: from now on every conv / Linear forward + data-gradient GEMM (class 0) and every
  * weight-gradient GEMM (class 1) launch is bracketed by a HIP event pair on the context's stream.  enable == 0: stop, synchronise, and
  * (out != NULL) report out[0..1] = elapsed milliseconds, out[2..3] = algorithmic FLOPs (2 M K N), out[4..5] = launches per class. */
@@ -287,14 +293,14 @@ int mugd_train_embedding_bwd(mugd_ctx* ctx, const int64_t* ids, const float* dco
  * mode 0: stride 1, padding dil (taps - 1) / 2 (torch padding=dilation for the dilated ResnetBlock convs, models.py:106-122);
  * mode 1: Downsample (models.py:84-88: pad right by one zero, k = 3, stride 2; Tin even, Tout = Tin / 2);
  * mode 2: Upsample (models.py:66-70: nearest x2, then k = 3 pad 1; Tout = 2 Tin).
- * w (Cout, Cin, taps), bias nullable; x / dx (B, Cin, Tin); y / dy (B, Cout, Tout); dw like w; db nullable.  Synchronises. */
+ * w (Cout, Cin, taps), bias nullable; x / dx (B, Cin, Tin); y / dy (B, Cout, Tout); dw like w; db nullable. */
 int mugd_train_conv(mugd_ctx* ctx, const float* w, const float* bias, const float* gn_w, const float* gn_b, const float* x, const float* dy, float* y,
                     float* dx, float* dw, float* db, float* dgn_w, float* dgn_b, int B, int Cin, int Cout, int Tin, int taps, int dil, int mode, int groups,
                     int64_t* state);
 /* mug/model/attention.py:154-199 ContextualTransformer (depth 1) forward and backward.  params / grads: MUGD_TF_NPARAMS pointers in the
  * order of the enum below, every tensor in the module's own layout (Linear weights (out, in), proj_in / proj_out (C, C, 1), the two
  * attention tables (2 pmax + 1, heads)).  x, dy, y, dx: (B, C, T).  context (B, Cc, Tk) channel-major, or NULL: attn2 is then a second
- * self-attention (wave encoder) and dcontext is ignored.  dcontext (nullable): (B, Cc, Tk).  Synchronises. */
+ * self-attention (wave encoder) and dcontext is ignored.  dcontext (nullable): (B, Cc, Tk). */
 enum {
     MUGD_TF_NORM_W, MUGD_TF_NORM_B, MUGD_TF_PROJ_IN_W, MUGD_TF_PROJ_IN_B,
     MUGD_TF_LN1_W, MUGD_TF_LN1_B, MUGD_TF_A1_Q, MUGD_TF_A1_K, MUGD_TF_A1_V, MUGD_TF_A1_OUT_W, MUGD_TF_A1_OUT_B, MUGD_TF_A1_REL, MUGD_TF_A1_CEMB,
@@ -307,7 +313,7 @@ int mugd_train_transformer(mugd_ctx* ctx, const float* const* params, const floa
 /* mug/diffusion/unet.py:76-91 S4Layer (GroupNorm -> S4 (s4.py:1471-1541: NPLR kernel, causal long conv + D u, GELU, Conv1d(H -> 2H) + GLU)
  * -> conv3 -> + x) forward and backward, INCLUDING the gradients of the kernel generator's parameters (C, B, P as (H, N, 2) real views,
  * inv_w_real / w_imag (H, N), log_dt (H)).  Lint = the stored kernel.L buffer (>= T; C is the stored, already length-adapted tensor).
- * params / grads: MUGD_S4_NPARAMS pointers in the order of the enum.  cauchy_naive kernel form only.  x, dy, y, dx: (B, H, T).  Synchronises. */
+ * params / grads: MUGD_S4_NPARAMS pointers in the order of the enum.  Either Cauchy form (mugd_set_s4_symmetric).  x, dy, y, dx: (B, H, T). */
 enum {
     MUGD_S4_NORM_W, MUGD_S4_NORM_B, MUGD_S4_K_C, MUGD_S4_K_B, MUGD_S4_K_P, MUGD_S4_K_INV_W_REAL, MUGD_S4_K_W_IMAG, MUGD_S4_K_LOG_DT, MUGD_S4_D,
     MUGD_S4_OUT_LIN_W, MUGD_S4_OUT_LIN_B, MUGD_S4_OUT_LAYER_W, MUGD_S4_OUT_LAYER_B, MUGD_S4_NPARAMS

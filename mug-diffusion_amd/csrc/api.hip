@@ -72,12 +72,10 @@ int mugd_create(int device, void* stream, mugd_ctx** out) {
             HIP_CHECK(hipStreamCreate(&ctx->c.stream));
             ctx->c.own_stream = true;
         }
-        const char* g = getenv("MUGD_NO_GRAPH");
         // eager launches by default: measured 5 % faster than hipGraph replay on this program (profiles/r3_graph_vs_eager.txt);
-        // MUGD_GRAPH=1 | 2 selects the per-step / whole-loop graph (MUGD_NO_GRAPH is kept for old scripts: it is the default now)
+        // MUGD_GRAPH=1 | 2 selects the per-step / whole-loop graph
         const char* gm = getenv("MUGD_GRAPH");
         ctx->c.use_graph = (gm && (gm[0] == '1' || gm[0] == '2')) ? gm[0] - '0' : 0;
-        (void)g;
         const char* u = getenv("MUGD_UNFUSED_NORM");
         ctx->c.fuse_norm = !(u && u[0] == '1');
         const char* ns = getenv("MUGD_NO_STATS_FUSION");

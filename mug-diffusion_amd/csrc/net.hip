@@ -1113,7 +1113,7 @@ void UNet::sample(float* x, const float* c, const float* uc, int n_tok, const fl
     const bool wn = noise != nullptr, wp = pred_x0 != nullptr, wf = first != nullptr;
     launch_ddim_step(st, step_args(cfg_on, scale, wn, wp, wf, nstate, S, 0));      // x_T -> U-Net input, embedding rows of step 0
     if (ctx->use_graph) {
-        const int per_graph = ctx->use_graph == 2 ? S : 1;        // steps captured into one graph
+        const int per_graph = ctx->use_graph == 2 ? std::max(S, 1) : 1;        // steps captured into one graph
         if (graph && (graph_steps != per_graph || graph_cfg != cfg_on || graph_noise != wn || graph_pred != wp || graph_first != wf || graph_scale != scale)) {
             HIP_CHECK(hipStreamSynchronize(st));
             hipGraphExecDestroy(graph);

@@ -175,10 +175,11 @@ void step_begin(mugd_ctx* ctx) {
     ts.on = true;
     if (const char* e = getenv("MUGD_NO_STEP_BRACKET")) { if (e[0] == '1') { ts.on = false; return; } }      // development / test knob: every call on its own
     if (const char* e = getenv("MUGD_TRAIN_SIDE")) ts.side_mode = atoi(e);                                   // development knob
-    // tensors the previous step did not touch are gone from the model (or were never part of it): drop them
+    // tensors the previous step did not touch are gone from the model (or were never part of it): drop them.  fp32 mode never reads
+    // a pack: nothing is kept and NO source pointer is re-read (a cache left by a bf16 step may point at tensors freed since)
     std::vector<PackEntry> keep;
     for (auto& e : ts.packs) {
-        if (e.used_epoch >= ts.epoch - 1) keep.push_back(e); else hipFree(e.dst);
+        if (ctx->c.train_bf16 && e.used_epoch >= ts.epoch - 1) keep.push_back(e); else hipFree(e.dst);
     }
     ts.packs.swap(keep);
     ts.index.clear();
@@ -200,6 +201,15 @@ void step_begin(mugd_ctx* ctx) {
 void step_end(mugd_ctx* ctx) {
     step_flush(ctx);
     ctx->step.on = false;
+}
+// forget every cached pack: after this no pointer into the caller's weight tensors is held (mugd.h: mugd_train_step_reset)
+void step_reset(mugd_ctx* ctx) {
+    step_end(ctx);
+    TrainStep& ts = ctx->step;
+    HIP_CHECK(hipStreamSynchronize(ctx->c.stream));      // kernels of the last step may still read the packs
+    for (auto& e : ts.packs) hipFree(e.dst);
+    ts.packs.clear();
+    ts.index.clear();
 }
 
 // y = conv1d(x; w) (+ bias) (+ rowadd[b][m]) (+ resid): w is a plain (M, C, taps) tensor, packed here.
@@ -337,13 +347,20 @@ struct Lin {
         TrainStep& ts = sc.ctx->step;
         const bool side = ts.on && ts.side_mode && c.train_bf16 && dW && dx;      // inside the bracket the weight-gradient call needs no call scratch
         if (side) {
+            // the context's stream is swapped for the weight-gradient call: restored and the side stream joined on EVERY way out
+            // (a throwing launch must not leave the context on the side stream)
+            struct Guard {
+                Ctx& c; SideStream& s; hipStream_t main_st; bool swapped = true;
+                void restore() { if (swapped) { c.stream = main_st; swapped = false; } }
+                ~Guard() { restore(); hipEvent_t e = s.event(); if (hipEventRecord(e, s.st) == hipSuccess) hipStreamWaitEvent(main_st, e, 0); }
+            };
             hipStream_t main_st = c.stream;
             ts.side.fork(main_st);
+            Guard guard{c, ts.side, main_st};
             c.stream = ts.side.st;
             run_wgrad(c, sc, dy, x, dW, B, M, K, T, T, 1, 0, 1, 1, 0, db);
-            c.stream = main_st;
+            guard.restore();
             run_dgrad(c, sc, dy, w, wt, acc ? dx : nullptr, dx, B, M, K, T, 1, 0);
-            ts.side.join(main_st);
             return;
         }
         if (dW) run_wgrad(c, sc, dy, x, dW, B, M, K, T, T, 1, 0, 1, 1, 0, db);
@@ -729,6 +746,9 @@ int mugd_train_step_flush(mugd_ctx* ctx) {
 }
 int mugd_train_step_end(mugd_ctx* ctx) {
     return guarded(ctx, [&] { step_end(ctx); });
+}
+int mugd_train_step_reset(mugd_ctx* ctx) {
+    return guarded(ctx, [&] { step_reset(ctx); });
 }
 
 // enable != 0: start (and clear) the GEMM profile; enable == 0 with out != NULL: stop, wait for the stream and report

@@ -91,6 +91,7 @@ _SIGS = {
     "mugd_train_step_begin": [_p],
     "mugd_train_step_flush": [_p],
     "mugd_train_step_end": [_p],
+    "mugd_train_step_reset": [_p],
     "mugd_train_concat": [_p, _p, _p, _p, _i, _i, _i, _i],
     "mugd_train_split": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i],
     "mugd_train_add": [_p, _p, _p, _p, C.c_int64],
@@ -235,9 +236,11 @@ class Lib:
                 yield
                 return
             ext.wait_stream(prev)
-            with torch.cuda.stream(ext):
-                yield
-            prev.wait_stream(ext)
+            try:
+                with torch.cuda.stream(ext):
+                    yield
+            finally:                       # also when the body raises: the caller's stream stays ordered behind what the library queued
+                prev.wait_stream(ext)
         return cm()
 
     # ------------------------------------------------------------------ plumbing
@@ -566,6 +569,15 @@ class Lib:
     def train_step_end(self):
         self.check(self.dll.mugd_train_step_end(self.ctx))
 
+    # The bracket's packed-weight cache is keyed by tensor address and re-read by the next train_step_begin (include/mugd.h): the binding
+    # keeps whatever owns those tensors (a mug.train.TrainPlan: its state dict and argument packs) referenced until the cache is dropped.
+    _bracket_owner = None
+
+    def train_step_reset(self, owner=None):
+        """Drop the library's packed-weight cache (no pointer into parameter tensors survives) and hand the bracket to `owner`."""
+        self.check(self.dll.mugd_train_step_reset(self.ctx))
+        self._bracket_owner = owner
+
     def train_profile(self, enable):
         """Event-bracket the training GEMM launches (True), or stop and return {'conv': {ms, flops, launches}, 'wgrad': {...}} (False)."""
         if enable:
@@ -628,25 +640,39 @@ class Lib:
                                                     int(dilations[0]), int(dilations[1]), _sref(state)))
         return y, dx, grads
 
-    def train_time_embed(self, params, temb, demb):
-        """time_embed (unet.py:334-339): params '0.weight', '0.bias', '2.weight', '2.bias'; temb (B, K).  Returns emb, grads."""
+    def train_time_embed(self, params, temb, demb, pack=None):
+        """time_embed (unet.py:334-339): params '0.weight', '0.bias', '2.weight', '2.bias'; temb (B, K).  Returns emb, grads.
+        pack (a dict kept by the caller across steps): the four gradient tensors are taken ONCE and reused, like every block's."""
         temb = self.f32(temb)
         demb = None if demb is None else self.f32(demb)
         w1, b1, w2, b2 = (self.f32(params[k]) for k in ("0.weight", "0.bias", "2.weight", "2.bias"))
         B, K = temb.shape
         M = w1.shape[0]
         emb = self.empty(B, M)
-        g = [self.zgrad(t) for t in (w1, b1, w2, b2)] if demb is not None else [None] * 4
+        if demb is None:
+            g = [None] * 4
+        elif pack is not None and "g" in pack:
+            g = pack["g"]
+        else:
+            g = [self.zgrad(t) for t in (w1, b1, w2, b2)]
+            if pack is not None:
+                pack["g"] = g
         self.check(self.dll.mugd_train_time_embed(self.ctx, _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(temb), _ptr(demb), _ptr(emb),
                                                   _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), B, K, M))
         return emb, ({} if demb is None else {"0.weight": g[0], "0.bias": g[1], "2.weight": g[2], "2.bias": g[3]})
 
-    def train_embedding_bwd(self, ids, dcontext, rows):
-        """BeatmapFeatureEmbedder backward: gradient of the (rows, dim) table from dcontext (B, dim, ntok)."""
+    def train_embedding_bwd(self, ids, dcontext, rows, pack=None):
+        """BeatmapFeatureEmbedder backward: gradient of the (rows, dim) table from dcontext (B, dim, ntok).
+        pack (a dict kept by the caller across steps): the gradient tensor is allocated ONCE and rewritten every step."""
         ids = ids.to(device=self.device, dtype=torch.int64).contiguous()
         dc = self.f32(dcontext)
         B, dim, ntok = dc.shape
-        dt = self.empty(rows, dim)          # every row is written by the kernel
+        if pack is not None and "dt" in pack:
+            dt = pack["dt"]
+        else:
+            dt = self.empty(rows, dim)      # every row is written by the kernel
+            if pack is not None:
+                pack["dt"] = dt
         self.check(self.dll.mugd_train_embedding_bwd(self.ctx, _ptr(ids), _ptr(dc), _ptr(dt), B, ntok, dim, rows))
         return dt
 

@@ -105,9 +105,31 @@ class AdamW:
         desc = np.concatenate(rows).astype(np.int64)
         self.nchunks = int(desc.shape[0])
         self.desc = torch.from_numpy(desc).to(lib.device)
+        self.gptrs = [g_.data_ptr() for _, g_, _, _ in self.tensors]
         self.t = 0
 
-    def step(self, lr=None):
+    def _rebind(self, grads):
+        """Point the descriptor table at `grads` (same keys / shapes) -- keeps the moment tensors and the step count."""
+        import numpy as np
+        self.tensors = [(p_, grads[k], m_, v_) for k, (p_, _, m_, v_) in zip(self.keys, self.tensors)]
+        rows = []
+        for p_, g_, m_, v_ in self.tensors:
+            assert g_.is_contiguous() and g_.dtype == torch.float32 and g_.device == p_.device and g_.shape == p_.shape
+            n = p_.numel()
+            offs = np.arange(0, n, 4096, dtype=np.int64)
+            cnt = np.minimum(4096, n - offs)
+            rows.append(np.stack([p_.data_ptr() + 4 * offs, g_.data_ptr() + 4 * offs, m_.data_ptr() + 4 * offs, v_.data_ptr() + 4 * offs, cnt], axis=1))
+        self.desc = torch.from_numpy(np.concatenate(rows).astype(np.int64)).to(self.lib.device)
+        self.gptrs = [g_.data_ptr() for _, g_, _, _ in self.tensors]
+
+    def step(self, lr=None, grads=None):
+        """One optimiser step.  grads (optional): this step's gradient dict -- the table was built from the tensors given to the constructor;
+        when a tensor of `grads` lives elsewhere (a step that handed out fresh gradient tensors) the table is rebuilt instead of silently
+        applying stale or cleared memory."""
+        if grads is not None:
+            assert set(grads) == set(self.keys), "AdamW: the gradient set changed"
+            if any(grads[k].data_ptr() != q for k, q in zip(self.keys, self.gptrs)):
+                self._rebind(grads)
         self.t += 1
         lr_, b1, b2, eps, wd = self.hp
         lib = self.lib
@@ -200,10 +222,11 @@ class BucketedAllReduce:
     bucket, waits for all of them and writes the averaged values back into the gradient tensors.  Ranks produce gradients in the
     same order (same model, same sweep), so bucket boundaries agree without negotiation."""
 
-    def __init__(self, bucket_bytes=64 << 20, average=True, group=None):
+    def __init__(self, bucket_bytes=64 << 20, average=True, group=None, even_single=False):
+        """even_single: run the collectives in a one-rank group too (a dry run of the RCCL path on a single GPU; a no-op otherwise)."""
         self.bucket_bytes, self.average, self.group = bucket_bytes, average, group
         self.open, self.open_bytes, self.inflight = [], 0, []
-        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.on = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or even_single)
         self.n_buckets = 0
         self.before_launch = None            # TrainPlan.step: the library's queued gradient reductions run before a bucket is read
 
@@ -309,7 +332,7 @@ class UNetStep:
         lib, sd, cfg, p = self.lib, self.sd, self.cfg, self.p
         nl = len(cfg["channel_mult"])
         self.temb = lib.op_timestep_embedding(t, cfg["model_channels"])
-        self.emb, _ = lib.train_time_embed(_sub(sd, p + ".time_embed"), self.temb, None)
+        self.emb, _ = lib.train_time_embed(_sub(sd, p + ".time_embed"), self.temb, None, pack=self._pk(p + ".time_embed"))
         self.context, self.audios = context, [a.to(lib.device) for a in audios]
         inp, out = unet_plan(cfg)
         tape, hs, h, ai = [], [], lib.f32(x), -nl
@@ -385,7 +408,7 @@ class UNetStep:
                 dh, daud[rec[2]] = lib.train_split(dh, rec[1], acc_b=daud.get(rec[2]))
             elif kind == "push":                          # the tensor went to the next block AND onto the skip stack
                 dh = lib.train_add(dh, skips.pop(rec[1]), out=dh)
-        _, g = lib.train_time_embed(_sub(sd, self.p + ".time_embed"), self.temb, demb)
+        _, g = lib.train_time_embed(_sub(sd, self.p + ".time_embed"), self.temb, demb, pack=self._pk(self.p + ".time_embed"))
         grads.add(self.p + ".time_embed", g)
         return dh, dctx, daud
 
@@ -470,8 +493,12 @@ class TrainPlan:
         self.invalidate()
 
     def invalidate(self):
+        """Forget everything derived from the tensors of `sd` (call after replacing / moving parameters).  Also drops the library's
+        packed-weight cache, which is keyed by tensor address and re-read by the next bracketed step (include/mugd.h), and makes this
+        plan the owner the binding keeps alive while that cache may point into its tensors."""
         sd = self.sd
         invalidate_param_cache(sd)
+        self.lib.train_step_reset(owner=self)
         n_train = sum(v.numel() + 64 for k, v in sd.items() if v.dtype == torch.float32 and k.startswith("model.") and not k.startswith("model.first_stage_model."))
         self.arena = FlatGrads(n_train, self.lib.device)
         self.packs = {}
@@ -484,6 +511,8 @@ class TrainPlan:
 
     def step(self, x0, noise, t, ids, mel, beta=0.02, add=0.01, reducer=None):
         lib = self.lib
+        if lib._bracket_owner is not self:            # another plan (another model's tensors) used the bracket since: its cache entries go first
+            lib.train_step_reset(owner=self)
         with lib.on_stream():                         # torch's fills / allocations and the library's kernels on ONE stream: no event per call
             lib.train_release_states()                # intermediates of a sweep that was abandoned half-way
             if not self.first:
@@ -529,7 +558,8 @@ def _training_step(lib, sd, unet_cfg, wave_cfg, x0, noise, t, ids, mel, beta, ad
     pred = unet.forward(xt, t, context, audios)
     loss, dpred = lib.train_smooth_l1(pred, noise, beta=beta, add=add)
     _, dctx, daud = unet.backward(dpred, grads)
-    grads.add("", {"model.cond_stage_model.embedding.weight": lib.train_embedding_bwd(ids, dctx, table.shape[0])})
+    grads.add("", {"model.cond_stage_model.embedding.weight": lib.train_embedding_bwd(ids, dctx, table.shape[0],
+                                                                                     pack=None if packs is None else packs.setdefault("#embedding", {}))})
     wave.backward(daud, grads)
     if reducer is not None:
         reducer.finish()
@@ -609,9 +639,9 @@ def fit(lib, sd, unet_cfg, wave_cfg, steps, batch, z, lr=1e-4, weight_decay=0.01
         noise = torch.randn(batch, unet_cfg["in_channels"], z, generator=g).to(dev)
         red = BucketedAllReduce() if world > 1 else None
         loss, grads = plan.step(x0, noise, t, ids, mel, reducer=red)
-        if opt is None:                                   # the plan's gradient tensors are the same views every step
+        if opt is None:                                   # the plan's gradient tensors are the same views every step (AdamW.step checks)
             opt = AdamW(lib, {k: sd[k] for k in grads}, grads, lr=lr, weight_decay=weight_decay)
-        opt.step()
+        opt.step(grads=grads)
         losses.append(float(loss))
         if log is not None and rank == 0:
             log(i, losses[-1])

@@ -315,3 +315,127 @@ def test_audio_ingest_resamples_on_the_device_when_only_soundfile_is_present(as_
     diff = np.abs(got.astype(np.float32) - want.astype(np.float32))
     ulp = np.spacing(np.abs(want).astype(np.float16)).astype(np.float32)
     assert (diff <= ulp).all() and (diff > 0).mean() < 0.02, (diff.max(), (diff > 0).mean())
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the reference's own headless caller, unchanged, on the drop-in
+# ------------------------------------------------------------------------------------------------------------------------------
+_MAPPING = "/root/reference/scripts/mapping.py"
+
+
+def _sections(path):
+    """[TimingPoints] and [HitObjects] of a written chart (the metadata lines carry names the two callers choose differently)."""
+    out, cur = {}, None
+    for line in open(path, encoding="utf8").read().splitlines():
+        if line.startswith("["):
+            cur = line.strip()
+            out[cur] = []
+        elif cur and line.strip():
+            out[cur].append(line)
+    return out["[TimingPoints]"], out["[HitObjects]"]
+
+
+@pytest.mark.skipif(not os.path.exists(_MAPPING), reason="needs the reference checkout (authoring container only)")
+def test_reference_cli_runs_unchanged_on_the_drop_in(tmp_path, monkeypatch):
+    """`python scripts/mapping.py ...` of the REFERENCE (scripts/mapping.py:308-522, run through runpy as __main__, not a line
+    changed) with the drop-in `mug` package ahead of it on sys.path: OmegaConf.load(models/ckpt/model.yaml) ->
+    instantiate_from_config -> load_state_dict(strict=False) -> model.cuda() -> load_audio_without_cache -> wave_model ->
+    DDIMSampler.sample -> decode -> parse_osu_file / save_osu_file(gridify=mini-jack pass + gridify).  Stubs: eyed3 and omegaconf
+    only (tests/refcaller_stubs; neither is installed).  Test-side adaptations, all outside the caller: the emulated library is
+    the process default, nn.Module.cuda is the identity (no GPU in this container), and DDIMSampler.sample is wrapped to seed the
+    global RNG the caller draws x_T from (mapping.py has no seed argument).  The charts it writes must equal, in their
+    [TimingPoints] and [HitObjects], the ones mug.job produces for the same seed (one sample) and the ones a direct use of the
+    drop-in API produces for the same x_T (two samples)."""
+    import runpy
+    import sys
+    import wave as wavmod
+    import yaml
+    from conftest import emu_lib, PKG
+    import mug._native as N
+    from mug import job
+    from mug.diffusion.ddim import DDIMSampler
+    case, z, S, seed = cases.TINY, 32, 4, 4321
+    lib = emu_lib()
+    monkeypatch.setattr(N, "_default", lib)
+    monkeypatch.setattr(torch.nn.Module, "cuda", lambda self, device=None: self)
+    # ---- the working directory the caller expects: models/ckpt/model.{yaml,ckpt}, a WAV, a template, the feature YAML
+    n_fft, sr, ratio = 512, 22050, case["audio_ratio"]
+    frames = z * ratio
+    cfg = dict(version="test", model=model_config(case),
+               data=dict(params=dict(common_params=dict(n_fft=n_fft, sr=sr, n_mels=case["wave"]["n_freq"], max_audio_frame=frames,
+                                                         audio_note_window_ratio=max(1, ratio // 2 ** (len(case["vae"]["channel_mult"]) - 1))))))
+    cfg["model"]["params"]["z_length"] = z
+    (tmp_path / "models" / "ckpt").mkdir(parents=True)
+    (tmp_path / "models" / "ckpt" / "model.yaml").write_text(yaml.safe_dump(cfg))
+    man = weights.load_manifest(os.path.join(G, case["manifest"]))
+    sd = weights.set_s4_lengths(weights.make_state_dict(man, seed=0), case["unet"], z)
+    torch.save({"state_dict": sd}, tmp_path / "models" / "ckpt" / "model.ckpt")
+    pcm = (0.4 * np.sin(2 * np.pi * 440 * np.arange(sr) / sr) + 0.2 * np.random.default_rng(3).standard_normal(sr)).clip(-1, 1)
+    with wavmod.open(str(tmp_path / "song.wav"), "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(sr)
+        f.writeframes((pcm * 32767).astype("<i2").tobytes())
+    from test_osu_io import TEMPLATE
+    (tmp_path / "template.osu").write_text(TEMPLATE, encoding="utf-8")
+    fy_path = os.path.join(G, "mania_beatmap_features.yaml")
+    (tmp_path / "prompts").mkdir()
+    for i in (1, 2):                                   # --prompt_dir has a default the caller always reads (mapping.py:422-425)
+        (tmp_path / "prompts" / ("feature_%d.yaml" % i)).write_text("{}\n")
+
+    orig_sample = DDIMSampler.sample
+
+    def seeded(self, *a, **k):
+        torch.manual_seed(seed)
+        return orig_sample(self, *a, **k)
+    monkeypatch.setattr(DDIMSampler, "sample", seeded)
+    monkeypatch.chdir(tmp_path)
+    stubs = os.path.join(os.path.dirname(os.path.abspath(__file__)), "refcaller_stubs")
+    monkeypatch.setattr(sys, "path", [PKG, stubs] + [p for p in sys.path if "refstubs" not in p])
+    for m in ("omegaconf", "eyed3"):
+        monkeypatch.delitem(sys.modules, m, raising=False)
+
+    def run_cli(n_samples, outdir):
+        monkeypatch.setattr(sys, "argv", ["mapping.py", "--audio", "song.wav", "--feature_yaml", fy_path, "--template_beatmap", "template.osu",
+                                          "--prompt_dir", "prompts", "--outdir", outdir, "--ddim_steps", str(S), "--n_samples", str(n_samples)])
+        ns = runpy.run_path(_MAPPING, run_name="__main__")
+        assert "mug-diffusion_amd" in sys.modules["mug.diffusion.ddim"].__file__ and ns["DDIMSampler"] is DDIMSampler
+        d = os.path.join(outdir, "Test Artist - Test Song")
+        return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(".osu"))
+
+    one = run_cli(1, "out1")
+    two = run_cli(2, "out2")
+    assert len(one) == 1 and len(two) == 2 and os.path.exists(os.path.join("out1", "Test Artist - Test Song", "audio.mp3"))
+    monkeypatch.setattr(DDIMSampler, "sample", orig_sample)
+
+    # ---- (a) mug.job for the same seed: one unit whose x_T comes from a CPU generator seeded like the caller's global RNG
+    from mug.util import instantiate_from_config, load_audio_without_cache
+    model = instantiate_from_config(cfg["model"]).eval()
+    model.load_state_dict(sd, strict=False)
+    hop = n_fft // 4
+    mel = torch.from_numpy(load_audio_without_cache("song.wav", case["wave"]["n_freq"], hop, n_fft, sr, hop / sr * frames).astype(np.float32))
+    cp = cfg["data"]["params"]["common_params"]
+    frame_ms = hop / sr * cp["audio_note_window_ratio"] * 1000
+    on_chart, written = job.chart_writer("job_out", "template.osu", frame_ms, frames // cp["audio_note_window_ratio"], lib=lib)
+    with open(fy_path) as f:
+        fy = yaml.safe_load(f)
+    # the caller pads / truncates to max_audio_frame and samples at model.z_length; run_job's length rule gives the same z when the
+    # mel is exactly max_audio_frame - 1 frames long or shorter by less than one latent block: hand it the padded mel and pin z
+    sampler = DDIMSampler(model)
+    units = [job.Unit(audio=0, seed=seed, prompt={})]
+    monkeypatch.setattr(job, "z_length_for", lambda *a, **k: z)
+    job.run_job(model, sampler, units, lambda a: mel[:, :frames], fy, steps=S, batch=1, max_audio_frame=frames, z_length_cfg=z, on_chart=on_chart)
+    assert _sections(written[0]) == _sections(one[0])
+    assert len(_sections(one[0])[1]) > 10
+
+    # ---- (b) two samples: the same x_T through the drop-in API directly
+    from mug.util import feature_dict_to_embedding_ids
+    x_T = torch.randn((2, 16, z), generator=torch.Generator().manual_seed(seed))
+    ids = torch.tensor([feature_dict_to_embedding_ids({}, fy)] * 2, dtype=torch.float32)
+    m2 = job.fit_mel(mel, z, ratio)
+    w = model.model.wave_model(torch.stack([m2, m2]))
+    model.z_length = z
+    lat, _ = sampler.sample(S=S, c=model.model.cond_stage_model(ids), w=w, batch_size=2, shape=None, verbose=False, x_T=x_T, eta=0.0)
+    logits = model.model.decode(lat)
+    on2, written2 = job.chart_writer("api_out", "template.osu", frame_ms, frames // cp["audio_note_window_ratio"], lib=lib)
+    for i in range(2):
+        on2(i, job.Unit(audio=0, seed=seed + i, prompt={}), logits[i])
+    assert [_sections(p) for p in written2] == [_sections(p) for p in two]

@@ -614,6 +614,102 @@ def test_fit_reduces_the_loss_on_a_fixed_batch(lib):
     assert all(torch.isfinite(v).all() for v in sd.values() if v.dtype == torch.float32)
 
 
+def test_fit_three_steps_match_autograd_plus_torch_adamw(lib):
+    """mug.train.fit against the same optimisation done by torch: three AdamW steps on one fixed batch of the tiny model, gradients
+    from autograd through the oracle's restatement, torch.optim.AdamW with the same hyper-parameters -- EVERY trainable tensor after
+    step 3.  A gradient tensor that moves between steps while the optimiser's table still points at step 1's (the round-3 bug: the four
+    time_embed tensors and the prompt-embedding table) shows up here as a tensor that only saw weight decay."""
+    from oracle import nets
+    from mug import train
+    case, sd, *_ = _tiny_training_inputs(2, 32)
+    B, z, steps, lr, seed = 2, 32, 3, 1e-3, 1
+    sd_fit = {k: v.clone() for k, v in sd.items()}
+    train.fit(lib, sd_fit, case["unet"], case["wave"], steps=steps, batch=B, z=z, lr=lr, seed=seed, fixed_batch=True,
+              audio_ratio=case["audio_ratio"], ntok=case["n_ctx_tok"])
+    # ---- the same three steps with torch (fit's batch and (t, noise) draws, reproduced)
+    n_ids = sd["model.cond_stage_model.embedding.weight"].shape[0]
+    x0, mel, ids = train.synthetic_batch(B, z, case["unet"], case["wave"], n_ids, case["n_ctx_tok"], case["audio_ratio"], seed * 7919, "cpu")
+    g = torch.Generator().manual_seed(seed * 1000)
+    t = torch.randint(0, sd["sqrt_alphas_cumprod"].shape[0], (B,), generator=g)
+    noise = torch.randn(B, case["unet"]["in_channels"], z, generator=g)
+    trainable = [k for k, v in sd.items() if v.dtype == torch.float32 and k.startswith("model.") and not k.startswith("model.first_stage_model")]
+    st = {k: (v.clone().requires_grad_(True) if k in trainable else v) for k, v in sd.items()}
+    opt, gmin = None, {}
+    for _ in range(steps):
+        xt = st["sqrt_alphas_cumprod"][t][:, None, None] * x0 + st["sqrt_one_minus_alphas_cumprod"][t][:, None, None] * noise
+        pred = nets.unet_forward(st, case["unet"], xt, t, nets.cond_embed(st, ids), nets.wave_encode(st, case["wave"], mel))
+        loss = (F.smooth_l1_loss(noise, pred, beta=0.02, reduction="none") + 0.01).mean(dim=[1, 2]).mean()
+        for k in trainable:
+            st[k].grad = None
+        loss.backward()
+        if opt is None:                   # fit optimises exactly the tensors the step produced a gradient for
+            reached = [k for k in trainable if st[k].grad is not None]
+            opt = torch.optim.AdamW([st[k] for k in reached], lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+        for k in reached:
+            gmin[k] = st[k].grad.abs() if k not in gmin else torch.minimum(gmin[k], st[k].grad.abs())
+        opt.step()
+    moved = 0
+    for k in reached:
+        a, b, o = sd_fit[k].detach().cpu(), st[k].detach(), sd[k]
+        # Adam divides by sqrt(v) + 1e-8: where the gradient is rounding noise (a conv bias in front of a GroupNorm is analytically
+        # gradient-free) the update's sign is arbitrary on both sides -- compare the elements with a real gradient in all three steps
+        alive = gmin[k] > 1e-5
+        if not alive.any():
+            continue
+        # Adam's first steps move every element by ~lr whatever the gradient's size: compare the UPDATE, not the value
+        du, dr = (a - o), (b - o)
+        tol = 0.05 * steps * lr + 8 * 1.2e-7 * o.abs()          # + a few ulps of the parameter itself (S4's w_imag is O(100))
+        assert bool(((du - dr).abs() <= tol)[alive].all()), "%s: update differs from torch's by %.3e (lr %.0e)" % (k, (du - dr).abs().max().item(), lr)
+        moved += int(dr.abs().max().item() > 0.5 * lr)
+    for k in ("model.unet_model.time_embed.0.weight", "model.unet_model.time_embed.2.bias", "model.cond_stage_model.embedding.weight"):
+        du, dr = (sd_fit[k].cpu() - sd[k]), (st[k].detach() - sd[k])
+        live = dr.abs() > 0.5 * lr                      # elements the gradient reaches (embedding rows of ids that occur)
+        assert live.any() and (du[live] - dr[live]).abs().max().item() <= 0.05 * steps * lr, k
+    assert moved > 0.9 * len(reached)
+
+
+def test_replacing_a_parameter_between_bracketed_steps(lib):
+    """The step bracket's cache is keyed by tensor address (include/mugd.h): after a parameter is REPLACED (not updated in place) and the
+    plan invalidated, the next bracketed step must use the new tensor -- and nothing may read the old one, which is freed here.  Same
+    for a second plan on another state dict after the first plan is gone."""
+    import gc
+    from mug import train
+    case, sd0, x0, noise, t, ids, mel = _tiny_training_inputs(2, 32)
+    dev = lib.device
+    lib.train_set_precision(True)
+    try:
+        sd = {k: v.clone().to(dev) for k, v in sd0.items()}
+        plan = train.TrainPlan(lib, sd, case["unet"], case["wave"])
+        assert plan.bracket and lib._bracket_owner is plan
+        args = [v.to(dev) for v in (x0, noise, t, ids, mel)]
+        loss_a, _ = plan.step(*args)
+        k = "model.unet_model.input_blocks.2.0.in_layers.2.weight"
+        sd[k] = (sd[k] * 1.5).contiguous()               # a new tensor; the old one is dropped
+        plan.invalidate()
+        gc.collect()
+        loss_b, grads_b = plan.step(*args)
+        grads_b = {q: v.clone() for q, v in grads_b.items()}
+        loss_b2, _ = plan.step(*args)                     # the cached packs of the NEW tensor
+        assert float(loss_b) == float(loss_b2) and float(loss_b) != float(loss_a)
+        # reference: a fresh plan over an equal state dict
+        sd_ref = {q: v.clone() for q, v in sd.items()}
+        del plan
+        gc.collect()
+        plan2 = train.TrainPlan(lib, sd_ref, case["unet"], case["wave"])
+        assert lib._bracket_owner is plan2
+        loss_c, grads_c = plan2.step(*args)
+        assert float(loss_c) == float(loss_b)
+        assert all(torch.equal(grads_b[q].cpu(), grads_c[q].cpu()) for q in grads_c)
+        # fp32 mode after a bf16 step: the bracket re-reads nothing (the bf16 cache is dropped, not refreshed)
+        lib.train_set_precision(False)
+        del sd, sd_ref
+        loss_d, _ = plan2.step(*args)
+        assert np.isfinite(float(loss_d))
+    finally:
+        lib.train_set_precision(False)
+        lib.train_step_reset()
+
+
 # ------------------------------------------------------------------ data parallel: gradient all-reduce over 2 gloo ranks
 def _worker(rank, world, port, q):
     import torch.distributed as dist
