@@ -62,6 +62,17 @@ int mugd_order_before(mugd_ctx* ctx, void* other_stream);
  * 1: replay each DDIM step from a captured hipGraph;
  * 2: capture the whole S-step loop into ONE graph (one hipGraphLaunch per sampling call; re-captured when S changes). */
 int mugd_set_graph_mode(mugd_ctx* ctx, int enabled);
+/* How a U-Net program (mugd_unet_forward / mugd_ddim_sample) is put on the GPU, for programs COMPILED after the call (a new batch /
+ * length, or mugd_net_invalidate):
+ *   0: one kernel launch per op (229 dependent launches per evaluation of the shipped model);
+ *   1: the XCD-RESIDENT EXECUTOR -- when the network batch is a multiple of 8, the whole per-step op chain (every conv / Linear GEMM, the
+ *      self-attention tiles, the S4 convolutions) runs inside ONE persistent kernel: batch row b is computed by the 32 CUs of XCD b % 8,
+ *      its activations never leave that XCD's L2, and ops are separated by XCD-local barriers (~1 us) instead of kernel boundaries.
+ *      Same device code per tile as mode 0, same results up to the summation order of the GroupNorm row sums.  Other batch sizes and
+ *      devices without 8 x 32 CUs fall back to mode 0.  In this mode mugd_ddim_sample / mugd_unet_forward synchronise the host at the end
+ *      of the call (they verify that no persistent launch gave up waiting for its peers).  Graph modes are ignored (launches are eager).
+ * The default is read from MUGD_XEXEC at mugd_create. */
+int mugd_set_exec_mode(mugd_ctx* ctx, int mode);
 /* Tuning / test knob: force the conv_gemm decomposition for networks COMPILED and operators run after the call
  * (wk: waves splitting K per workgroup, 1|2|4|8; tn: output tile width 16|32; 0 = pick per layer).  Call
  * mugd_net_invalidate on existing networks to recompile them. */

@@ -76,6 +76,7 @@ int mugd_create(int device, void* stream, mugd_ctx** out) {
         // MUGD_GRAPH=1 | 2 selects the per-step / whole-loop graph
         const char* gm = getenv("MUGD_GRAPH");
         ctx->c.use_graph = (gm && (gm[0] == '1' || gm[0] == '2')) ? gm[0] - '0' : 0;
+        if (const char* xe = getenv("MUGD_XEXEC")) ctx->c.xexec = xe[0] == '1' ? 1 : 0;      // the XCD-resident executor (mugd_set_exec_mode)
         const char* u = getenv("MUGD_UNFUSED_NORM");
         ctx->c.fuse_norm = !(u && u[0] == '1');
         const char* ns = getenv("MUGD_NO_STATS_FUSION");
@@ -138,6 +139,12 @@ int mugd_order_before(mugd_ctx* ctx, void* other) { return ctx ? order_streams(c
 int mugd_set_graph_mode(mugd_ctx* ctx, int enabled) {
     if (!ctx) return MUGD_ERR_INVALID;
     ctx->c.use_graph = enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled);
+    return MUGD_OK;
+}
+
+int mugd_set_exec_mode(mugd_ctx* ctx, int mode) {
+    if (!ctx) return MUGD_ERR_INVALID;
+    ctx->c.xexec = mode != 0 ? 1 : 0;
     return MUGD_OK;
 }
 

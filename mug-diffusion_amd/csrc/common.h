@@ -85,6 +85,20 @@ __device__ __forceinline__ int fastdiv(int n, unsigned m, int d) {
 #define KARG_PIN4(a, b, c, d) asm volatile("" ::"s"(a), "s"(b), "s"(c), "s"(d))
 #endif
 
+// Argument blocks that live in device memory instead of the kernarg segment (the executor's op table, xexec.hip) are read through the
+// CONSTANT address space: uniform loads from it are scalar (s_load into SGPRs), which is exactly what by-value kernel arguments compile
+// to -- the tile bodies keep their register budget whichever way their arguments arrive.  The table is written by the host before the
+// launch and never modified while a kernel reads it.
+#ifdef MUGD_EMULATED
+#define MUGD_CONST_AS
+#else
+#define MUGD_CONST_AS __attribute__((address_space(4)))
+#endif
+template <class T>
+__device__ __forceinline__ const MUGD_CONST_AS T* to_const_as(const T* p) {
+    return (const MUGD_CONST_AS T*)p;
+}
+
 // ---------------------------------------------------------------------------------------
 // Phase timeline (development build only: `python build.py --tl` compiles the same sources with -DMUGD_TL into
 // tests/tl/libmugd_tl.so; the product library carries none of this).  Every wave of an instrumented kernel stamps

@@ -44,12 +44,13 @@ struct WgStats {
     // fp64 {sum, sum of squares} of channel c of the normalised concat (segments 0 .. gn_nseg-1), batch row b; zero if !ok.
     // One predicated load per segment with COMPILE-TIME segment indices: a per-lane segment index would turn the kernarg
     // accesses into vector loads of the argument block -- a second dependent round trip in front of the sums themselves.
-    static __device__ __forceinline__ double2 row_load(const ConvArgs& a, int b, int c, bool ok) {
+    template <class A>
+    static __device__ __forceinline__ double2 row_load(const A& a, int b, int c, bool ok) {
         double2 v = make_double2(0.0, 0.0);
 #pragma unroll
         for (int si = 0; si < CONV_MAXSEG; ++si) {
             if (si < a.gn_nseg) {
-                const ConvSeg& s = a.seg[si];
+                const auto& s = a.seg[si];
                 if (ok && c >= 0 && c < s.C) {
                     const int bb = s.bmod > 0 ? b % s.bmod : b;
                     v = *reinterpret_cast<const double2*>(reinterpret_cast<const double*>(s.xf_a) + (size_t)bb * s.xf_stride + 2 * (size_t)c);
@@ -60,7 +61,8 @@ struct WgStats {
         return v;
     }
 
-    __device__ __forceinline__ void issue(const ConvArgs& a, int b, int t0, int tid) {
+    template <class A>
+    __device__ __forceinline__ void issue(const A& a, int b, int t0, int tid) {
         ln = a.seg[0].xf == 3;
         pending = ln || a.gn_groups != 0;
         if (a.gn_groups) {
@@ -72,7 +74,7 @@ struct WgStats {
             }
         }
         if (ln) {
-            const ConvSeg& s = a.seg[0];
+            const auto& s = a.seg[0];
             const int col = tid % TN, part = tid / TN;
             int t = t0 + col;
             t = t < s.Tin ? t : s.Tin - 1;
@@ -85,7 +87,8 @@ struct WgStats {
         }
     }
 
-    __device__ __forceinline__ void finish(const ConvArgs& a, int b, int t0, int tid, Lds& l) {
+    template <class A>
+    __device__ __forceinline__ void finish(const A& a, int b, int t0, int tid, Lds& l) {
         if (!pending) return;
         pending = false;
         if (a.gn_groups) {
@@ -111,7 +114,7 @@ struct WgStats {
             }
         }
         if (ln) {
-            const ConvSeg& s = a.seg[0];
+            const auto& s = a.seg[0];
             const int col = tid % TN, part = tid / TN;
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -128,7 +131,7 @@ struct WgStats {
         }
         __syncthreads();
         if (ln) {
-            const ConvSeg& s = a.seg[0];
+            const auto& s = a.seg[0];
             if (tid < TN) {
                 float s1 = 0.f, s2 = 0.f;
                 const int np = s.xf_np < NPART ? s.xf_np : NPART;
@@ -148,8 +151,8 @@ struct WgStats {
 // EPI_XSOFTMAX epilogue (kernels.h): `xs` holds the tile's raw scores [32 key rows][TN query columns] (row stride TN + 1).
 // The NTHR / TN lanes of a column sit in one wave: they split the key rows, reduce max / sum with xor shuffles and write
 // softmax(..) * Cemb for the real keys and zeros for the padding rows (the consumer's K axis is all 32 rows of every head).
-template <int WK, int TN>
-__device__ __forceinline__ void xsoftmax_epilogue(const ConvArgs& a, const float* xs, int head, int b, int t0, int tid) {
+template <int WK, int TN, class A>
+__device__ __forceinline__ void xsoftmax_epilogue(const A& a, const float* xs, int head, int b, int t0, int tid, bool live = true) {
     constexpr int NTHR = WK * 64;
     constexpr int LPC = NTHR / TN >= 32 ? 32 : NTHR / TN;          // lanes per column (power of two, <= 32 <= wave)
     constexpr int NR = 32 / LPC;                                   // key rows per lane
@@ -179,7 +182,7 @@ __device__ __forceinline__ void xsoftmax_epilogue(const ConvArgs& a, const float
 #pragma unroll
         for (int o = 1; o < LPC; o <<= 1) l += __shfl_xor(l, o);
         const float inv = 1.0f / l;
-        if (i < a.Tout) {
+        if (live && i < a.Tout) {
 #pragma unroll
             for (int u = 0; u < NR; ++u) {
                 const int j = jj + u * LPC;

@@ -16,7 +16,7 @@
 // s4_conv: y = gelu( sum_{s<=t} k[s] u[t-s] + D u[t] )  (S4.forward, s4.py:1503-1531; the
 // reference's zero-padded FFT product is this causal convolution).  k and u of one (b,h) row
 // live in LDS; lanes own consecutive outputs so u reads are conflict-free and k reads broadcast.
-#include "kernels.h"
+#include "s4_body.h"
 
 namespace {
 
@@ -129,137 +129,10 @@ __global__ __launch_bounds__(256) void s4_conv_kernel(const S4ConvArgs a) {
 }
 
 
-// Fast path for any L <= 2048: one workgroup per (batch, feature) row, padded to LP = 64 R samples (R = 1..32, the smallest
-// that covers L).  The 4 waves split the TAP range (wave w takes taps [w LP/4, (w+1) LP/4) of every output); inside a
-// wave, lane l owns the R consecutive outputs t = l R .. l R + R-1 and keeps the R inputs u[t - s] it needs in a register
-// window that slides by one sample per tap (one LDS read per tap per lane, k[s] read as broadcast vectors): R FMAs per
-// ~1.25 LDS reads.  Causality is a zero-filled prefix of the LDS copy of u (branch-free), k and u are zero beyond L; one
-// pad word per 32 samples (index i lives at i + i/32) makes the stride-R window reads conflict-free.  The 4 partial sums
-// per output are combined through LDS in fixed order.  With a.gn_gamma the workgroup also computes the GroupNorm
-// statistics of its (batch row, group) itself (cg rows of L samples, L2-resident) instead of a separate statistics launch.
 template <int R>
 __global__ __launch_bounds__(256) void s4_conv_fast_kernel(const S4ConvArgs a) {
-    constexpr int LP = 64 * R;
-    constexpr int LPP = 2 * LP + (2 * LP) / 32;
-    constexpr int SEG = LP / 4;                      // taps per wave
-    __shared__ __attribute__((aligned(16))) float ks[LP];
-    __shared__ float uw[LPP];
-    __shared__ float part[4][LP];
-    __shared__ double red[2][4];
-    const int L = a.L;
-    const int h = blockIdx.x, b = blockIdx.y;
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const float* u = a.u + ((size_t)b * a.H + h) * L;
-
-    // k and u rows requested before the statistics: their round trip overlaps the GroupNorm reduction
-    constexpr int NE = (LP + 255) / 256;
-    float kreg[NE], ureg[NE];
-#pragma unroll
-    for (int e = 0; e < NE; ++e) {
-        const int i = tid + e * 256;
-        const int ic = i < L ? i : L - 1;
-        kreg[e] = a.k[(size_t)h * L + ic];
-        ureg[e] = u[ic];
-    }
-
-    float ag = 1.f, ab = 0.f;
-    if (a.aff) {
-        ag = a.aff[2 * ((size_t)b * a.H + h)]; ab = a.aff[2 * ((size_t)b * a.H + h) + 1];
-    } else if (a.gn_gamma && a.rowstat) {
-        // GroupNorm statistics from the producer's fp64 row sums: every wave reduces the group's cg rows itself (no barrier)
-        const int cg = a.H / a.gn_groups, c0 = (h / cg) * cg;
-        double s1 = 0.0, s2 = 0.0;
-        for (int c = lane; c < cg; c += 64) {
-            const double* p = a.rowstat + 2 * ((size_t)b * a.H + c0 + c);
-            s1 += p[0]; s2 += p[1];
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            s1 += __hiloint2double(__shfl_xor(__double2hiint(s1), o), __shfl_xor(__double2loint(s1), o));
-            s2 += __hiloint2double(__shfl_xor(__double2hiint(s2), o), __shfl_xor(__double2loint(s2), o));
-        }
-        const double inv = 1.0 / ((double)cg * (double)L);
-        const double mean_d = s1 * inv;
-        double var_d = s2 * inv - mean_d * mean_d;
-        var_d = var_d > 0.0 ? var_d : 0.0;
-        const float rstd = 1.0f / sqrtf((float)var_d + a.gn_eps);
-        ag = a.gn_gamma[h] * rstd;
-        ab = a.gn_beta[h] - (float)mean_d * ag;
-    } else if (a.gn_gamma) {
-        const int cg = a.H / a.gn_groups, c0 = (h / cg) * cg;
-        const float* ug = a.u + ((size_t)b * a.H + c0) * L;
-        const int n = cg * L;
-        double s1 = 0.0, s2 = 0.0;
-        for (int base = tid; base < n; base += 256 * 8) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const int i = base + j * 256; v[j] = ug[i < n ? i : n - 1]; }
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (base + j * 256 < n) { s1 += (double)v[j]; s2 += (double)v[j] * (double)v[j]; }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            s1 += __hiloint2double(__shfl_xor(__double2hiint(s1), o), __shfl_xor(__double2loint(s1), o));
-            s2 += __hiloint2double(__shfl_xor(__double2hiint(s2), o), __shfl_xor(__double2loint(s2), o));
-        }
-        if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
-        __syncthreads();
-        const double nn = (double)n;
-        const double mean_d = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / nn;
-        double var_d = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / nn - mean_d * mean_d;
-        var_d = var_d > 0.0 ? var_d : 0.0;
-        const float rstd = (float)(1.0 / sqrt(var_d + (double)a.gn_eps));
-        ag = a.gn_gamma[h] * rstd;
-        ab = a.gn_beta[h] - (float)mean_d * ag;
-    }
-#pragma unroll
-    for (int e = 0; e < NE; ++e) {
-        const int i = tid + e * 256;
-        if (i < LP) {
-            const bool in = i < L;
-            ks[i] = in ? kreg[e] : 0.f;
-            const int i1 = LP + i;
-            uw[i1 + (i1 >> 5)] = in ? ureg[e] * ag + ab : 0.f;
-            uw[i + (i >> 5)] = 0.f;                  // causal padding: u[t] = 0 for t < 0
-        }
-    }
-    __syncthreads();
-
-    const int t0 = lane * R, s0 = wave * SEG;
-    float w[R], acc[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int i = LP + t0 + r - s0;
-        w[r] = uw[i + (i >> 5)];
-        acc[r] = 0.f;
-    }
-    const int base = LP + t0 - 1 - s0;               // sample index of u[t0 - s0 - 1]
-    constexpr int STEP = R < SEG ? R : SEG;          // R = 1: SEG = 16 taps, one per iteration
-    const int s_end = (L - s0 < SEG) ? (L - s0) : SEG;     // taps >= L are zero: skip whole blocks of them
-    for (int s = 0; s < s_end; s += STEP) {
-        float kv[R];
-#pragma unroll
-        for (int j = 0; j < STEP; ++j) kv[j] = ks[s0 + s + j];
-#pragma unroll
-        for (int j = 0; j < STEP; ++j) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] += kv[j] * w[(r - j + R) % R];      // w[(r-j) mod R] holds u[t0 + r - (s0+s+j)]
-            const int i = base - (s + j);
-            w[(2 * R - 1 - j) % R] = uw[i + (i >> 5)];                               // u[t0 - (s0+s+j) - 1] for the next tap
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) part[wave][t0 + r] = acc[r];
-    __syncthreads();
-    const float Dh = a.D[h];
-    float* y = a.y + ((size_t)b * a.H + h) * L;
-    for (int i = tid; i < L; i += 256) {
-        const int i1 = LP + i;
-        const float conv = ((part[0][i] + part[1][i]) + part[2][i]) + part[3][i];
-        y[i] = gelu_erf_f(conv + Dh * uw[i1 + (i1 >> 5)]);
-    }
+    __shared__ __attribute__((aligned(16))) char lds[S4Lds<R>::BYTES];
+    s4_conv_fast_row<R>(a, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, lds, true);
 }
 
 }  // namespace

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "xexec.h"
 
 struct Tensor {
     float* p = nullptr;
@@ -49,6 +50,8 @@ struct Ctx {
     bool fold_xattn = true;     // false (MUGD_NO_XATTN_FOLD=1): cross-attention as to_q -> attention kernel -> to_out instead of the folded two-GEMM form
     bool train_bf16 = false;    // mugd_train_set_precision: the training GEMMs (conv / Linear forward, data and weight gradients) on the bf16 matrix cores
     bool fuse_norm = true;      // false (MUGD_UNFUSED_NORM=1): materialise GroupNorm / LayerNorm outputs with the stand-alone kernels (A/B + debugging)
+    int xexec = 0;              // mugd_set_exec_mode / MUGD_XEXEC: 1 = U-Net programs whose batch is a multiple of 8 run their per-step op chain inside the
+                                // XCD-resident persistent executor (xexec.h) instead of one launch per op; 0 = one launch per op
 };
 
 class Arena {
@@ -56,7 +59,10 @@ public:
     void begin(bool dry) { dry_ = dry; top_ = 0; if (dry) peak_ = 0; }
     float* alloc(size_t nfloats);
     size_t mark() const { return top_; }
-    void release(size_t m) { top_ = m; }
+    void release(size_t m) { if (!monotonic) top_ = m; }
+    // true: release() keeps the block -- every buffer of a program gets an address of its own (single assignment inside one pass over
+    // the program: what lets the executor's consumers use plain loads, xexec.h)
+    bool monotonic = false;
     size_t peak() const { return peak_; }
     void reserve(size_t bytes);
     void free_all();
@@ -108,6 +114,7 @@ struct Op {
     int kind;
     double flops;     // algorithmic 2*MAC count of the contractions (0 for bandwidth-class ops)
     std::string label;
+    int xi = -1;      // index into Net::xops when the op can run inside the XCD-resident executor
 };
 
 struct ProfileRow { double ms = 0, flops = 0; long long launches = 0; };
@@ -150,7 +157,23 @@ protected:
     void emit(std::function<void(hipStream_t)> f, int kind = OP_SMALL, double flops = 0, const std::string& label = "") {
         if (!dry) (to_pre ? pre_ops : to_emb ? emb_ops : ops).push_back(Op{std::move(f), kind, flops, label});
     }
-    void run_ops(hipStream_t st) { for (auto& o : ops) o.fn(st); }
+    void run_ops(hipStream_t st);
+    // ---- XCD-resident executor (xexec.h): ops that can run inside it carry an entry of `xops`; runs of consecutive such ops become ONE launch
+    bool xmode = false;                           // the program being built / held is laid out for the executor (monotonic arena, 32-wide tiles)
+    std::vector<XOp> xops;
+    XOp* xops_dev = nullptr;
+    XSync* xsync = nullptr;
+    unsigned xbarriers = 0;                       // XCD barriers executed so far on xsync
+    struct XRun { int op_lo, op_hi; int x_lo, x_hi; };     // ops [op_lo, op_hi): x_lo < x_hi -> executor launch over xops [x_lo, x_hi), else plain launches
+    std::vector<XRun> xruns;
+    void emit_x(std::function<void(hipStream_t)> f, int kind, double flops, const std::string& label, const XOp& x) {
+        if (dry) return;
+        if (to_pre || to_emb || !xmode) { emit(std::move(f), kind, flops, label); return; }
+        ops.push_back(Op{std::move(f), kind, flops, label, (int)xops.size()});
+        xops.push_back(x);
+    }
+    void finish_xprogram();                       // after build(false): upload the table, cut the program into runs
+    void check_xexec();                           // throws if an executor launch gave up (synchronises)
     void run_pre_ops(hipStream_t st) { for (auto& o : pre_ops) o.fn(st); }
 
     // layer emitters

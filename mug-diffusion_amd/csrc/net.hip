@@ -166,6 +166,60 @@ void Net::invalidate() {
     ops.clear();
     pre_ops.clear();
     emb_ops.clear();
+    xops.clear(); xruns.clear();
+    xops_dev = nullptr; xsync = nullptr; xbarriers = 0;       // freed with `owned`
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The program as launches: one per op, or -- executor mode -- one persistent launch per run of consecutive executor-capable ops
+// ---------------------------------------------------------------------------------------------------------------------------
+void Net::run_ops(hipStream_t st) {
+    if (!xmode || xruns.empty()) {
+        for (auto& o : ops) o.fn(st);
+        return;
+    }
+    for (const XRun& r : xruns) {
+        if (r.x_hi > r.x_lo) {
+            launch_xexec(st, xops_dev, r.x_lo, r.x_hi, xsync, xbarriers, Bn);
+            xbarriers += (unsigned)(r.x_hi - r.x_lo - 1);
+        } else {
+            for (int i = r.op_lo; i < r.op_hi; ++i) ops[i].fn(st);
+        }
+    }
+}
+
+void Net::finish_xprogram() {
+    xruns.clear();
+    if (!xmode || xops.empty()) return;
+    if (!xsync) xsync = reinterpret_cast<XSync*>(dev_alloc(sizeof(XSync) / 4 + 64, true));
+    xops_dev = reinterpret_cast<XOp*>(dev_alloc(xops.size() * sizeof(XOp) / 4 + 64));
+    HIP_CHECK(hipMemcpyAsync(xops_dev, xops.data(), xops.size() * sizeof(XOp), hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));                  // `xops` may be rebuilt before the copy would otherwise have run
+    size_t i = 0;
+    while (i < ops.size()) {
+        size_t j = i;
+        if (ops[i].xi >= 0) {
+            while (j + 1 < ops.size() && ops[j + 1].xi == ops[j].xi + 1) ++j;
+            xruns.push_back(XRun{(int)i, (int)j + 1, ops[i].xi, ops[j].xi + 1});
+        } else {
+            while (j + 1 < ops.size() && ops[j + 1].xi < 0) ++j;
+            xruns.push_back(XRun{(int)i, (int)j + 1, 0, 0});
+        }
+        i = j + 1;
+    }
+}
+
+void Net::check_xexec() {
+    if (!xmode || !xsync) return;
+    unsigned err = 0;
+    HIP_CHECK(hipMemcpyAsync(&err, &xsync->err[0], sizeof(err), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (err) {
+        HIP_CHECK(hipMemsetAsync(xsync, 0, sizeof(XSync), ctx->stream));
+        xbarriers = 0;
+        MUGD_CHECK(false, -7, "XCD-resident executor: a workgroup gave up at a phase barrier (workgroups not placed 32 per XCD, or the device is shared); "
+                              "results of this call are invalid -- run with mugd_set_exec_mode(ctx, 0)");
+    }
 }
 
 const Param& Net::P(const std::string& n) const {
@@ -476,7 +530,7 @@ Tensor Net::conv(const ConvSpec& s) {
     a.gn_nseg = s.gn.nseg; a.gn_groups = s.gn.groups; a.gn_cg = s.gn.cg; a.gn_count = s.gn.count; a.gn_eps = s.gn.eps;
     a.B = Bn; a.Mrows = s.Mrows; a.Mout = s.Mout; a.Tout = s.Tout; a.epi = s.epi;
     a.wk = ctx->force_wk;
-    a.tn = ctx->force_tn == 16 ? (conv16_supported(a) ? 16 : 32) : ctx->force_tn == 32 ? 32 : conv_pick_tn(a);
+    a.tn = (xmode && !to_pre) ? 32 : ctx->force_tn == 16 ? (conv16_supported(a) ? 16 : 32) : ctx->force_tn == 32 ? 32 : conv_pick_tn(a);      // the executor's tiles are 32 wide
     a.xs_rel = s.xs_rel; a.xs_cemb = s.xs_cemb; a.xs_heads = s.xs_heads; a.xs_pmax = s.xs_pmax; a.xs_ntok = s.xs_ntok; a.xs_scale = s.xs_scale;
     a.w16 = (ctx->weights_bf16 && !s.ext_plain && conv_w16_supported(a)) ? 1 : 0;
     const PackedW& pw = s.ext_plain ? get_packed_ext(s, a.tn) : get_packed(s, a.tn, a.w16 != 0);       // the tile width decides the weight fragment order
@@ -509,9 +563,14 @@ Tensor Net::conv(const ConvSpec& s) {
     }
     double kdim = 0;
     for (auto& in : s.in) kdim += (double)in.x.C * in.taps;
-    emit([a](hipStream_t st) { launch_conv(st, a); }, (s.epi == EPI_GLU || s.epi == EPI_GEGLU) ? OP_CONV_GATED : OP_CONV, 2.0 * s.Mrows * kdim * s.Tout * Bn,
-         s.key + " M=" + std::to_string(s.Mrows) + " K=" + std::to_string((long long)kdim) + " T=" + std::to_string(s.Tout) +
-             " nseg=" + std::to_string(a.nseg) + " tn=" + std::to_string(a.tn));
+    const std::string label = s.key + " M=" + std::to_string(s.Mrows) + " K=" + std::to_string((long long)kdim) + " T=" + std::to_string(s.Tout) +
+                              " nseg=" + std::to_string(a.nseg) + " tn=" + std::to_string(a.tn);
+    const int okind = (s.epi == EPI_GLU || s.epi == EPI_GEGLU) ? OP_CONV_GATED : OP_CONV;
+    const double oflops = 2.0 * s.Mrows * kdim * s.Tout * Bn;
+    if (xmode && !dry && !to_pre && !to_emb && !rowstat_pass && xexec_conv_supported(a))
+        emit_x([a](hipStream_t st) { launch_conv(st, a); }, okind, oflops, label, xexec_make_conv(a, Bn));
+    else
+        emit([a](hipStream_t st) { launch_conv(st, a); }, okind, oflops, label);
     if (rowstat_pass) {
         const float* yp = y.p; double* rp = y.rowstat; const int rows = Bn * s.Mout, T = s.Tout;
         emit([=](hipStream_t st) { launch_row_sums_add(st, yp, rp, rows, T); }, OP_SMALL, 0, s.key + " row sums");
@@ -548,8 +607,11 @@ Tensor Net::attention(const std::string& prefix, const Tensor& q, const Tensor& 
     MUGD_CHECK((int)rel.shape[1] == heads, -2, "attention: head count mismatch at " + prefix);
     a.B = Bn; a.heads = heads; a.d = C / heads; a.Tq = q.T; a.Tk = k.T;
     a.scale = 1.0f / sqrtf((float)a.d);
-    emit([a](hipStream_t st) { launch_attention(st, a); }, OP_ATTENTION, 4.0 * Bn * C * (double)q.T * k.T,
-         prefix + " d=" + std::to_string(a.d) + " Tq=" + std::to_string(q.T) + " Tk=" + std::to_string(k.T));
+    const std::string label = prefix + " d=" + std::to_string(a.d) + " Tq=" + std::to_string(q.T) + " Tk=" + std::to_string(k.T);
+    if (xmode && !dry && xexec_attn_supported(a))
+        emit_x([a](hipStream_t st) { launch_attention(st, a); }, OP_ATTENTION, 4.0 * Bn * C * (double)q.T * k.T, label, xexec_make_attn(a));
+    else
+        emit([a](hipStream_t st) { launch_attention(st, a); }, OP_ATTENTION, 4.0 * Bn * C * (double)q.T * k.T, label);
     return o;
 }
 
@@ -761,7 +823,10 @@ Tensor Net::s4_layer(const std::string& prefix, const Tensor& x) {
     S4ConvArgs ca{u.p, k, PF(prefix + ".s4_model.D"), y.p, Bn, H, L, aff,
                   in_kernel_gn ? PF(prefix + ".norm.weight") : nullptr, in_kernel_gn ? PF(prefix + ".norm.bias") : nullptr, 32, 1e-6f,
                   (in_kernel_gn && ctx->fuse_stats && x.bmod == 0) ? x.rowstat : nullptr};
-    emit([ca](hipStream_t st) { launch_s4_conv(st, ca); }, OP_S4_CONV, 0, prefix + " H=" + std::to_string(H) + " L=" + std::to_string(L));
+    if (xmode && !dry && in_kernel_gn && ca.rowstat && xexec_s4_supported(ca))
+        emit_x([ca](hipStream_t st) { launch_s4_conv(st, ca); }, OP_S4_CONV, 0, prefix + " H=" + std::to_string(H) + " L=" + std::to_string(L), xexec_make_s4(ca));
+    else
+        emit([ca](hipStream_t st) { launch_s4_conv(st, ca); }, OP_S4_CONV, 0, prefix + " H=" + std::to_string(H) + " L=" + std::to_string(L));
     ConvSpec gl;
     gl.key = prefix + ".s4_model.output_linear.0";
     gl.in.push_back(ConvIn{y});
@@ -856,10 +921,14 @@ Tensor UNet::resblock(const std::string& prefix, const std::vector<Tensor>& segs
 
 void UNet::build(bool dry_run) {
     dry = dry_run;
+    // executor mode: batch rows map to XCDs (b % 8), so the batch must fill them; the workspace becomes single-assignment (xexec.h)
+    xmode = ctx->xexec != 0 && key.B % 8 == 0 && xexec_device_ok(ctx->device);
+    arena.monotonic = xmode;
     arena.begin(dry_run);
     ops.clear();
     pre_ops.clear();
     emb_ops.clear();
+    xops.clear();
     begin_rowstat();
     Bn = key.B;
     const int mc = cfg.model_channels, nl = (int)cfg.channel_mult.size(), z = key.z;
@@ -995,6 +1064,8 @@ void UNet::drop_programs() {
     ops.clear();
     pre_ops.clear();
     emb_ops.clear();
+    xops.clear();
+    xruns.clear();
 }
 
 void UNet::ensure(int B, int z, int ntok, int bmod) {
@@ -1007,6 +1078,7 @@ void UNet::ensure(int B, int z, int ntok, int bmod) {
     build(true);
     arena.reserve(arena.peak());
     build(false);
+    finish_xprogram();
     built = true;
 }
 
@@ -1029,6 +1101,7 @@ void UNet::forward(const float* x, const long long* t, const float* context, int
     for (auto& o : emb_ops) o.fn(st);
     run_ops(st);
     HIP_CHECK(hipMemcpyAsync(eps, out_eps.p, (size_t)B * out_eps.C * z * sizeof(float), hipMemcpyDeviceToDevice, st));
+    check_xexec();
 }
 
 DdimStepArgs UNet::step_args(bool cfg_on, float scale, bool with_noise, bool with_pred, bool with_first, int nstate, int S, int mode) const {
@@ -1112,7 +1185,7 @@ void UNet::sample(float* x, const float* c, const float* uc, int n_tok, const fl
     }
     const bool wn = noise != nullptr, wp = pred_x0 != nullptr, wf = first != nullptr;
     launch_ddim_step(st, step_args(cfg_on, scale, wn, wp, wf, nstate, S, 0));      // x_T -> U-Net input, embedding rows of step 0
-    if (ctx->use_graph) {
+    if (ctx->use_graph && !xmode) {             // executor launches carry a per-launch barrier base: not replayable
         const int per_graph = ctx->use_graph == 2 ? std::max(S, 1) : 1;        // steps captured into one graph
         if (graph && (graph_steps != per_graph || graph_cfg != cfg_on || graph_noise != wn || graph_pred != wp || graph_first != wf || graph_scale != scale)) {
             HIP_CHECK(hipStreamSynchronize(st));
@@ -1135,6 +1208,7 @@ void UNet::sample(float* x, const float* c, const float* uc, int n_tok, const fl
     HIP_CHECK(hipMemcpyAsync(x, x_state, (size_t)nstate * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (wp) HIP_CHECK(hipMemcpyAsync(pred_x0, pred_dev, (size_t)nstate * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (wf) HIP_CHECK(hipMemcpyAsync(first, first_dev, 2 * (size_t)nstate * sizeof(float), hipMemcpyDeviceToDevice, st));
+    check_xexec();                 // executor mode only: synchronises and fails loudly if a persistent launch bailed out
 }
 
 // =======================================================================================

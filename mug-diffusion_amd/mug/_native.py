@@ -52,6 +52,7 @@ _SIGS = {
     "mugd_order_after": [_p, _p],
     "mugd_order_before": [_p, _p],
     "mugd_set_graph_mode": [_p, _i],
+    "mugd_set_exec_mode": [_p, _i],
     "mugd_set_conv_tiling": [_p, _i, _i],
     "mugd_set_s4_symmetric": [_p, _i],
     "mugd_set_weight_precision": [_p, _i],
@@ -144,7 +145,7 @@ class MugdError(RuntimeError):
 
 
 _UNORDERED = {"mugd_get_stream", "mugd_create", "mugd_destroy", "mugd_net_destroy", "mugd_last_error", "mugd_version", "mugd_profile_kind_name",
-              "mugd_order_after", "mugd_order_before", "mugd_set_graph_mode", "mugd_set_conv_tiling", "mugd_set_s4_symmetric", "mugd_set_weight_precision", "mugd_remove_mini_jacks",
+              "mugd_order_after", "mugd_order_before", "mugd_set_graph_mode", "mugd_set_exec_mode", "mugd_set_conv_tiling", "mugd_set_s4_symmetric", "mugd_set_weight_precision", "mugd_remove_mini_jacks",
               "mugd_train_set_precision"}
 
 
@@ -258,6 +259,11 @@ class Lib:
     def set_graph_mode(self, on):
         """True / 1: one hipGraph per DDIM step, replayed S times; False / 0: eager launches; 2: the whole loop as one graph."""
         self.check(self.dll.mugd_set_graph_mode(self.ctx, int(on)))
+
+    def set_exec_mode(self, xexec):
+        """True / 1: U-Net programs compiled afterwards with a batch that is a multiple of 8 run their per-step op chain inside the
+        XCD-resident persistent executor (include/mugd.h: mugd_set_exec_mode); False / 0: one launch per op."""
+        self.check(self.dll.mugd_set_exec_mode(self.ctx, 1 if xexec else 0))
 
     def set_weight_precision(self, bf16):
         """Reduced-precision mode: networks compiled afterwards keep their packed conv / linear weights in bfloat16
