@@ -78,6 +78,47 @@ void Net::profile_program(ProfileRow* rows) {
         }
     }
     for (auto& e : ev) hipEventDestroy(e);
+    // executor mode: the same program once more as persistent launches, with the per-phase clock stamps of every XCD (xexec.h)
+    if (xmode && !xruns.empty()) {
+        const char* path = getenv("MUGD_XEXEC_CSV");
+        for (const XRun& r : xruns) {
+            if (r.x_hi <= r.x_lo) { for (int i = r.op_lo; i < r.op_hi; ++i) ops[i].fn(st); continue; }
+            const int n = r.x_hi - r.x_lo;
+            const bool twice = getenv("MUGD_XEXEC_TWICE") != nullptr;       // development experiment, see xexec.hip (results invalid)
+            unsigned long long* tl = nullptr;
+            HIP_CHECK(hipMalloc((void**)&tl, (size_t)(2 * n + 1) * 8 * sizeof(unsigned long long)));
+            HIP_CHECK(hipMemsetAsync(tl, 0, (size_t)(2 * n + 1) * 8 * sizeof(unsigned long long), st));
+            launch_xexec(st, xops_dev, r.x_lo, r.x_hi, xsync, xbarriers, Bn | (twice ? 0x10000 : 0), tl);
+            xbarriers += (unsigned)(n - 1) + (twice ? (unsigned)n : 0u);
+            std::vector<unsigned long long> h((size_t)(2 * n + 1) * 8);
+            HIP_CHECK(hipStreamSynchronize(st));
+            HIP_CHECK(hipMemcpy(h.data(), tl, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            hipFree(tl);
+            if (FILE* f = path ? fopen(path, "a") : nullptr) {
+                fprintf(f, "idx,kind,wk,variant,items,us_max_xcd,us_min_xcd,%slabel\n", twice ? "us_first_pass,us_second_pass_hot," : "");
+                for (int k = 0; k < n; ++k) {
+                    double mx = 0, mn = 1e30, p1 = 0, p2 = 0;
+                    for (int x = 0; x < 8; ++x) {
+                        const double us = (double)(h[(size_t)(k + 1) * 8 + x] - h[(size_t)k * 8 + x]) * 0.01;
+                        mx = std::max(mx, us); mn = std::min(mn, us);
+                        if (twice) {
+                            p1 = std::max(p1, (double)(h[(size_t)(n + 1 + k) * 8 + x] - h[(size_t)k * 8 + x]) * 0.01);
+                            p2 = std::max(p2, (double)(h[(size_t)(k + 1) * 8 + x] - h[(size_t)(n + 1 + k) * 8 + x]) * 0.01);
+                        }
+                    }
+                    const XOp& o = xops[r.x_lo + k];
+                    fprintf(f, "%d,%s,%d,%d,%d,%.2f,%.2f,", r.op_lo + k, op_kind_name(ops[r.op_lo + k].kind), o.wk, o.variant, o.items, mx, mn);
+                    if (twice) fprintf(f, "%.2f,%.2f,", p1, p2);
+                    fprintf(f, "%s\n", ops[r.op_lo + k].label.c_str());
+                }
+                double tot = 0;
+                for (int x = 0; x < 8; ++x) tot = std::max(tot, (double)(h[(size_t)n * 8 + x] - h[x]) * 0.01);
+                fprintf(f, "-1,total,0,0,0,%.2f,0,executor launch over %d ops\n", tot, n);
+                fclose(f);
+            }
+        }
+        check_xexec();
+    }
 }
 
 TlSink g_tl;

@@ -51,5 +51,7 @@ XOp xexec_make_attn(const AttnArgs& a);
 XOp xexec_make_s4(const S4ConvArgs& a);
 // ops[lo, hi) of a device-resident table as one persistent launch.  `barriers_done`: XCD barriers executed by earlier launches on
 // this XSync block (the caller adds hi - lo - 1 after the call).
-void launch_xexec(hipStream_t st, const XOp* dev_ops, int lo, int hi, XSync* sync, unsigned barriers_done, int B);
+// tl (development aid, nullable): (hi - lo + 1) x 8 words -- rank 0 of XCD x writes the 100 MHz s_memrealtime at the start of phase k to tl[8 k + x]
+// (the last row: the end of the launch); the last phase's end is NOT behind a barrier (it is that XCD's rank 0 finishing its own share).
+void launch_xexec(hipStream_t st, const XOp* dev_ops, int lo, int hi, XSync* sync, unsigned barriers_done, int B, unsigned long long* tl = nullptr);
 bool xexec_device_ok(int device);      // 256 CUs in 8 XCDs

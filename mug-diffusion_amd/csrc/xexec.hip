@@ -157,7 +157,9 @@ __device__ X_NOINLINE void x_s4(const SA* ap, const int H, const int xcd, const 
     }
 }
 
-__global__ __launch_bounds__(XW * 64) MUGD_WAVES_PER_EU(2) void xexec_kernel(const XOp* ops_g, int lo, int hi, XSync* sync, unsigned barriers_done, int B) {
+__global__ __launch_bounds__(XW * 64) MUGD_WAVES_PER_EU(2) void xexec_kernel(const XOp* ops_g, int lo, int hi, XSync* sync, unsigned barriers_done, int B,
+                                                                             unsigned long long* tl) {
+    (void)0;
     __shared__ unsigned s_xcd, s_rank;
 #ifdef MUGD_EMULATED
     const unsigned xcd = blockIdx.x & 7, rank = blockIdx.x >> 3;
@@ -172,7 +174,25 @@ __global__ __launch_bounds__(XW * 64) MUGD_WAVES_PER_EU(2) void xexec_kernel(con
     const unsigned xcd = __builtin_amdgcn_readfirstlane(s_xcd), rank = __builtin_amdgcn_readfirstlane(s_rank);
 #endif
     XOpC* ops = to_const_as(ops_g);
+#ifndef MUGD_EMULATED
+    // development aid (launch_xexec's `tl`): rank 0 of every XCD stamps the 100 MHz clock at the start of each phase and at the end
+    if (tl && rank == 0 && threadIdx.x == 0) tl[xcd] = __builtin_amdgcn_s_memrealtime();
+#endif
+    // development experiment (tl set and bit 16 of B): every phase runs TWICE back to back (the second pass finds its weights, activations and
+    // code hot in the XCD's L2) with a barrier and a clock stamp in between -- an upper bound on what a perfect prefetch of phase p + 1's
+    // operands during phase p could buy.  Results of such a launch are NOT valid (row sums are added twice).
+    const bool twice = tl != nullptr && (B & 0x10000) != 0;
+    B &= 0xffff;
+    unsigned extra = 0;                     // barriers this launch executed beyond one per phase boundary
     for (int i = lo; i < hi; ++i) {
+      for (int rep = 0; rep < (twice ? 2 : 1); ++rep) {
+        if (rep == 1) {
+            if (!xcd_barrier(sync, xcd, (barriers_done + (unsigned)(i - lo) + extra + 1u) * XCD_WGS)) return;
+            ++extra;
+#ifndef MUGD_EMULATED
+            if (rank == 0 && threadIdx.x == 0) tl[(size_t)(hi - lo + 1 + (i - lo)) * NXCD + xcd] = __builtin_amdgcn_s_memrealtime();
+#endif
+        }
         XOpC& op = ops[i];
         const int items = op.items, gx = op.gx;
         if (op.type == XOP_CONV) {
@@ -209,9 +229,13 @@ __global__ __launch_bounds__(XW * 64) MUGD_WAVES_PER_EU(2) void xexec_kernel(con
                 default: break;
             }
         }
+      }
         if (i + 1 < hi) {
-            if (!xcd_barrier(sync, xcd, (barriers_done + (unsigned)(i - lo) + 1u) * XCD_WGS)) return;
+            if (!xcd_barrier(sync, xcd, (barriers_done + (unsigned)(i - lo) + extra + 1u) * XCD_WGS)) return;
         }
+#ifndef MUGD_EMULATED
+        if (tl && rank == 0 && threadIdx.x == 0) tl[(size_t)(i - lo + 1) * NXCD + xcd] = __builtin_amdgcn_s_memrealtime();
+#endif
     }
 }
 
@@ -298,13 +322,13 @@ XOp xexec_make_s4(const S4ConvArgs& a) {
     return op;
 }
 
-void launch_xexec(hipStream_t st, const XOp* dev_ops, int lo, int hi, XSync* sync, unsigned barriers_done, int B) {
+void launch_xexec(hipStream_t st, const XOp* dev_ops, int lo, int hi, XSync* sync, unsigned barriers_done, int B, unsigned long long* tl) {
     if (hi <= lo) return;
 #ifdef MUGD_EMULATED
     // the emulation runs workgroups one after another: a barrier BETWEEN workgroups cannot be waited for -- one launch per phase
-    for (int i = lo; i < hi; ++i) hipLaunchKernelGGL(xexec_kernel, dim3(NXCD * XCD_WGS), dim3(XW * 64), 0, st, dev_ops, i, i + 1, sync, barriers_done, B);
+    for (int i = lo; i < hi; ++i) hipLaunchKernelGGL(xexec_kernel, dim3(NXCD * XCD_WGS), dim3(XW * 64), 0, st, dev_ops, i, i + 1, sync, barriers_done, B, tl);
 #else
-    hipLaunchKernelGGL(xexec_kernel, dim3(NXCD * XCD_WGS), dim3(XW * 64), 0, st, dev_ops, lo, hi, sync, barriers_done, B);
+    hipLaunchKernelGGL(xexec_kernel, dim3(NXCD * XCD_WGS), dim3(XW * 64), 0, st, dev_ops, lo, hi, sync, barriers_done, B, tl);
 #endif
 }
 

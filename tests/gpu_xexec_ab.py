@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--S", type=int, default=50)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--rounds", type=int, default=2, help="A/B alternations per batch size")
+    ap.add_argument("--profile", default=None, help="path prefix: dump per-op event timings and the executor's per-phase timeline for the first batch size")
     a = ap.parse_args()
     case, z, S = cases.FULL, a.z, a.S
     lib = get_lib()
@@ -61,6 +62,21 @@ def main():
             print("RESULT B=%d z=%d S=%d %s: %.2f ms per loop, %.3f ms/step, %.0f sample-steps/s" % (
                 B, z, S, "executor  " if mode else "per-op    ", best[mode] * 1e3, best[mode] * 1e3 / S, B * S / best[mode]), flush=True)
         print("RESULT B=%d latent max|executor - per-op| = %.3e (range %.1f); speed-up %.3fx" % (B, d, lat[0].abs().max().item(), best[0] / best[1]), flush=True)
+    if a.profile:
+        # per-op event profile (mode 0 program and the executor-mode program run op by op) + the executor's per-phase clock stamps
+        B = a.B[0]
+        x = cases.x_T(1, B, z).to(dev)
+        t = torch.full((B,), 501, dtype=torch.long, device=dev)
+        c = cases.context(case, 1, B).to(dev)
+        w = [m.to(dev) for m in cases.audio_maps(case, 1, max(1, B // 4), z)]
+        for mode in (0, 1):
+            lib.set_exec_mode(mode)
+            os.environ["MUGD_PROFILE_CSV"] = a.profile + ".mode%d_per_op.csv" % mode
+            os.environ["MUGD_XEXEC_CSV"] = a.profile + ".executor_phases.csv"
+            nets[mode].forward(x, t, c, w)
+            prof = nets[mode].profile()
+            tot = sum(v["ms"] for v in prof.values())
+            print("PROFILE mode %d program, op by op (event-bracketed): %.3f ms over %d launches" % (mode, tot, sum(v["launches"] for v in prof.values())), flush=True)
     lib.set_exec_mode(0)
 
 
