@@ -43,6 +43,28 @@ def _run(cmd):
     return r.stdout
 
 
+def build_variant(name, defines, verbose=True):
+    """DEVELOPMENT A/B builds: the same sources with extra -D flags into tests/var/<name>/libmugd.so (git-ignored; loaded through
+    MUGD_LIB_PATH by the GPU probes, never by the product)."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    outdir = os.path.join(ROOT, "tests", "var", name)
+    objdir = os.path.join(outdir, "build")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"] + ["-D" + d for d in defines]
+
+    def cc(src):
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        _run([hipcc] + flags + ["-c", src, "-o", obj])
+        return obj
+    with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(cc, _sources()))
+    lib = os.path.join(outdir, "libmugd.so")
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib])
+    if verbose:
+        print("built", lib)
+    return lib
+
+
 def build(force=False, verbose=True, timeline=False):
     """hipcc --offload-arch=gfx950 for every csrc/*.hip, linked into libmugd.so next to this file.
 
@@ -101,7 +123,10 @@ def build_emulated(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    if "--emu" in sys.argv:
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        build_variant(sys.argv[i + 1], sys.argv[i + 2:])
+    elif "--emu" in sys.argv:
         build_emulated(force="--force" in sys.argv)
     elif "--tl" in sys.argv:
         build(force="--force" in sys.argv, timeline=True)

@@ -51,13 +51,43 @@ __device__ __forceinline__ unsigned conv_pack_bf16(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, cbf16x2));
 }
 
+// ---------------------------------------------------------------------------------------
+// H3 (the default arithmetic of conv_gemm since round 4; -DMUGD_CONV_H3=0 restores v_mfma_f32_32x32x2_f32): fp32-EQUIVALENT products on
+// the f16 matrix cores.  Every operand x is carried as two halves  hi = rn_f16(x),  lo = rn_f16((x - hi) 2^11)  (x = hi + lo / 2^11 to
+// 2^-23 relative: f16 has 11 significant bits; the 2^11 keeps the residual out of the f16 subnormal range) and a product block
+// (32 x 32 x 16: one tap of a 16-channel chunk) is three v_mfma_f32_32x32x16_f16:
+//     acc  += a_hi b_hi              accL += a_hi b_lo + a_lo b_hi              result = acc + accL / 2^11        (a_lo b_lo: 2^-22, dropped)
+// with fp32 accumulation (Ootomo & Yokota 2022, "Recovering single precision accuracy from Tensor Cores").  Measured on MI355X
+// (tests/gpu_h3_probe.hip, profiles/r4_h3_probe.txt): error against float64 2.7e-7 relative at K = 1024 -- BELOW the fp32 MFMA chain's
+// 7.7e-7 (fewer, wider-k accumulation steps), also with operands in the f16 subnormal range; 96 cycles per block and wave instead of 512.
+// Why it matters: v_mfma_f32_32x32x2_f32 runs on the SIMD's fp32 FMA lanes (its peak IS the vector peak: SQ_VALU_MFMA_COEXEC_CYCLES = 0
+// over a whole launch, profiles/r4_pmc_conv_stalls.txt), so the operand transform's VALU work and the matrix work of BOTH waves of a SIMD
+// serialise; the f16 matrix pipe is a separate unit.
+//   weights : packed per (tap, lane) as two 16-byte planes -- 8 hi halves, 8 lo halves of the lane's 8 channels (same bytes as fp32,
+//             split once at pack time: pack_weights_kernel);
+//   windows : every staged sample is stored in LDS as the dword {hi | lo << 16} (split once per sample when the window is parked); a
+//             fragment is 8 such dwords de-interleaved into the hi and lo vectors with 8 v_perm_b32.
+// ---------------------------------------------------------------------------------------
+#ifndef MUGD_CONV_H3
+#define MUGD_CONV_H3 1
+#endif
+typedef _Float16 ch16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float h3_split(float v) {          // {hi | lo << 16} as a dword carried in a float
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)((v - (float)hi) * 2048.0f);
+    const unsigned u = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+    return __uint_as_float(u);
+}
+template <class WT>
+constexpr bool conv_h3() { return MUGD_CONV_H3 != 0 && sizeof(WT) == 4; }
+
 // BF16 (the reduced-precision mode: bfloat16 weight fragments): the chunk's 8 channels per lane and tap -- A[i = 2 tap + g8] = weights
 // of channels 4 h + j + 8 g8, bf[...] = the same channels of the window -- are exactly the 8 k of ONE v_mfma_f32_32x32x16_bf16 per tap
 // (A and B use the same slot -> channel map, which is all the instruction needs), instead of 8 fp32-input MFMAs: the widened weights
 // are packed back (exact: they were bf16), the activations are rounded to bf16 here (round to nearest even); fp32 accumulation.
 template <int TAPS, bool DUAL, bool BF16 = false>
 __device__ __forceinline__ void mfma_chunk(const char* smem_bytes, int rb0, int dil, const float4 (&A)[6], const float4 (&A2)[6],
-                                           f32x16& acc, f32x16& acc2) {
+                                           f32x16& acc, f32x16& acc2, f32x16& accL, f32x16& acc2L) {
     float bf[TAPS * 8];
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
@@ -86,6 +116,30 @@ __device__ __forceinline__ void mfma_chunk(const char* smem_bytes, int rb0, int 
         }
         return;
     }
+#if MUGD_CONV_H3
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+        // the window holds {hi | lo << 16} per sample: de-interleave the lane's 8 channels into the two operand vectors
+        cu32x4 hv, lv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned d0 = __float_as_uint(bf[tap * 8 + 2 * e]), d1 = __float_as_uint(bf[tap * 8 + 2 * e + 1]);
+            hv[e] = __builtin_amdgcn_perm(d1, d0, 0x05040100u);
+            lv[e] = __builtin_amdgcn_perm(d1, d0, 0x07060302u);
+        }
+        const ch16x8 bh = __builtin_bit_cast(ch16x8, hv), bl = __builtin_bit_cast(ch16x8, lv);
+        const ch16x8 ah = __builtin_bit_cast(ch16x8, A[2 * tap]), al = __builtin_bit_cast(ch16x8, A[2 * tap + 1]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+        accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accL, 0, 0, 0);
+        accL = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accL, 0, 0, 0);
+        if (DUAL) {
+            const ch16x8 gh = __builtin_bit_cast(ch16x8, A2[2 * tap]), gl = __builtin_bit_cast(ch16x8, A2[2 * tap + 1]);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, bh, acc2, 0, 0, 0);
+            acc2L = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, bl, acc2L, 0, 0, 0);
+            acc2L = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, bh, acc2L, 0, 0, 0);
+        }
+    }
+#else
 #pragma unroll
     for (int i = 0; i < TAPS * 2; ++i) {
         const float4 av = A[i];
@@ -101,6 +155,7 @@ __device__ __forceinline__ void mfma_chunk(const char* smem_bytes, int rb0, int 
             acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(gv.w, bf[i * 4 + 3], acc2, 0, 0, 0);
         }
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -113,7 +168,7 @@ __device__ __forceinline__ void mfma_chunk(const char* smem_bytes, int rb0, int 
 template <int TAPS, bool DUAL, int NH, int XFK = -1, int ACT = -1, bool PIPE = false, class WT = float, class SEG = ConvSeg>
 __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, const WT* wseg2, int lo, int hi,
                                                 int b, int t0, int lane, int h, int n, char* smem_bytes, int wave_base,
-                                                f32x16& acc, f32x16& acc2, const float2* gst, const float2* lnst, float inv_cg, int rot_seed) {
+                                                f32x16& acc, f32x16& acc2, f32x16& accL, f32x16& acc2L, const float2* gst, const float2* lnst, float inv_cg, int rot_seed) {
     const int r = lane >> 2, q = lane & 3;
     const int Tin = s.Tin;
     const int hw = (TAPS - 1) * s.dil;                     // halo samples per row (left pad + right rest)
@@ -223,6 +278,12 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
                 for (int j = 0; j < NH; ++j) vh[j] = silu_fast(vh[j]);
             }
         }
+        if (conv_h3<WT>()) {                            // H3: the window holds the {hi | lo} f16 halves of every sample (0.f is {0 | 0})
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = h3_split(v[i]);
+#pragma unroll
+            for (int j = 0; j < NH; ++j) vh[j] = h3_split(vh[j]);
+        }
         float4 w0, w1;                                  // zero padding AFTER the transform (component selects: no scratch)
         w0.x = ok0 ? v[0] : 0.f; w0.y = ok0 ? v[1] : 0.f; w0.z = ok0 ? v[2] : 0.f; w0.w = ok0 ? v[3] : 0.f;
         w1.x = ok1 ? v[4] : 0.f; w1.y = ok1 ? v[5] : 0.f; w1.z = ok1 ? v[6] : 0.f; w1.w = ok1 ? v[7] : 0.f;
@@ -285,7 +346,7 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
                 const int cc = c + d;
                 if (cc < nch) {
                     const int dn = (d + 1) % D;
-                    mfma_chunk<TAPS, DUAL, sizeof(WT) == 2>(smem_bytes + (d & 1) * W1, rb0, s.dil, RA[d], RA2[d], acc, acc2);
+                    mfma_chunk<TAPS, DUAL, sizeof(WT) == 2>(smem_bytes + (d & 1) * W1, rb0, s.dil, RA[d], RA2[d], acc, acc2, accL, acc2L);
                     if (cc + 1 < nch) {
                         park_v(((d + 1) & 1) * W1, RX0[dn], RX1[dn], RXH[dn], RGB[dn], RGG[dn]);
                         if (cc + 1 + D < nch) fetch_x(cc + 1 + D, dn);
@@ -323,7 +384,7 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
             ++crel;
             if (xf) gbv = load_gb(crel);
         }
-        mfma_chunk<TAPS, DUAL, sizeof(WT) == 2>(smem_bytes, rb0, s.dil, A, A2, acc, acc2);
+        mfma_chunk<TAPS, DUAL, sizeof(WT) == 2>(smem_bytes, rb0, s.dil, A, A2, acc, acc2, accL, acc2L);
         wave_sync();               // all lanes done reading the window before it is overwritten
     };
 
@@ -343,7 +404,7 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
 template <int TAPS, bool DUAL, int NIT, bool XF, class SEG = ConvSeg>
 __device__ __forceinline__ void run_segment_gen(const SEG& s, const float* wseg, const float* wseg2, int lo, int hi,
                                                 int b, int t0, int lane, int h, int n, char* smem_bytes, int wave_base,
-                                                f32x16& acc, f32x16& acc2) {
+                                                f32x16& acc, f32x16& acc2, f32x16& accL, f32x16& acc2L) {
     const int RW = 31 * s.stride + (TAPS - 1) * s.dil + 1;
     const float inv = 1.0f / (float)RW;
     const int last = CONV_CK * RW - 1;
@@ -406,6 +467,10 @@ __device__ __forceinline__ void run_segment_gen(const SEG& s, const float* wseg,
                 for (int k = 0; k < NIT; ++k) v[k] = silu_f(v[k]);
             }
         }
+        if (conv_h3<float>()) {
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) v[k] = h3_split(v[k]);
+        }
 #pragma unroll
         for (int k = 0; k < NIT; ++k) *reinterpret_cast<float*>(smem_bytes + loff[k]) = ok[k] ? v[k] : 0.f;
         wave_sync();
@@ -422,7 +487,7 @@ __device__ __forceinline__ void run_segment_gen(const SEG& s, const float* wseg,
                 for (int k = 0; k < NIT; ++k) gbr[k] = *reinterpret_cast<const float2*>(gb + 2 * rowk[k]);
             }
         }
-        mfma_chunk<TAPS, DUAL>(smem_bytes, rb0, s.dil, A, A2, acc, acc2);
+        mfma_chunk<TAPS, DUAL>(smem_bytes, rb0, s.dil, A, A2, acc, acc2, accL, acc2L);
         wave_sync();
     };
 
@@ -459,9 +524,15 @@ constexpr int conv_lds_bytes() { return ConvLds<WK, DUAL>::BYTES; }
 // KIND 1: fast window path, any dilation (wave encoder / VAE ResnetBlocks).
 // KIND 2: every segment through the generic window walk (stride 2, nearest-x2 upsample, T % 4 != 0); NITG = its
 //         staging passes.  Separate kernels keep each instantiation's register budget to what it needs.
-template <int WK, bool DUAL, int KIND, int NITG, class WT, class A>
+// TALL: the (virtual) workgroup owns TWO row tiles, mt and mt + 1 (64 x 32 outputs): the second accumulator of the gated kernels holds the
+//       second row tile instead of the gate rows, so every staged window element and every B fragment read from LDS feeds two MFMAs
+//       (weights: each wave streams both row tiles' fragments).  For launches with enough tiles to fill the chip at half the count
+//       (launch_conv_gemm); mt must be even, a missing last row tile (odd tile count) is computed on clamped weights and not stored.
+template <int WK, bool DUAL, int KIND, int NITG, class WT, bool TALL = false, class A = ConvArgs>
 __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b, const int t0, const int rot, const int tid, char* lds, const bool live) {
-    typedef ConvLds<WK, DUAL> L;
+    static_assert(!(DUAL && TALL), "gated layers already share their windows between two row sets");
+    constexpr bool A2 = DUAL || TALL;               // two weight streams / two accumulators per wave
+    typedef ConvLds<WK, A2> L;
     constexpr int RED = L::RED;
     constexpr int WIN = L::WIN;
     // staging windows, then the partial-tile exchange in a region of its own: a wave that has finished its K-slice parks its
@@ -470,7 +541,7 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
     typedef WgStats<WK, CONV_TN> Stats;
     typename Stats::Lds& stl = *reinterpret_cast<typename Stats::Lds*>(lds + L::STAT_OFF);
 
-    const int gy = a.gy;
+    const int gy = (a.Mout + 31) >> 5;             // 32-row tiles of the output (the launch grid counts PAIRS of them under TALL)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, h = lane >> 5, n = lane & 31;
 
@@ -486,12 +557,13 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
     for (int w = 1; w < WK; ++w)
         if (wave == w) { g0 = a.kb[w]; g1 = a.kb[w + 1]; }
 
-    f32x16 acc, acc2;
+    f32x16 acc, acc2, accL, acc2L;               // accL / acc2L: the 2^11-scaled cross terms of the H3 arithmetic (unused otherwise)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; }
+    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; accL[i] = 0.f; acc2L[i] = 0.f; }
 
     const WT* wtile = reinterpret_cast<const WT*>(a.wpk) + (size_t)b * a.w_b_stride + (size_t)mt * a.w_mt_stride + lane * 4;
-    const WT* wtile2 = DUAL ? wtile + (size_t)(a.Mout >> 5) * a.w_mt_stride : wtile;
+    const bool has2 = !TALL || mt + 1 < gy;        // TALL: the second row tile exists
+    const WT* wtile2 = DUAL ? wtile + (size_t)(a.Mout >> 5) * a.w_mt_stride : (TALL && has2) ? wtile + a.w_mt_stride : wtile;
     char* smem_bytes = lds;
     const int wave_base = wave * WAVE_LDS * 4;
 
@@ -504,6 +576,12 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
     size_t oo[EPT];
     int mm[EPT];
     bool valid[EPT];
+    // TALL: the same for the rows of the second row tile (m + 32)
+    constexpr int EPT2 = TALL ? EPT : 1;
+    float ra2[EPT2], rsv2[EPT2];
+    size_t oo2[EPT2];
+    int mm2[EPT2];
+    bool valid2[EPT2];
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
         const int r = wave * EPT + q;
@@ -513,20 +591,27 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
         mm[q] = m < a.Mout ? m : a.Mout - 1;
         oo[q] = ((size_t)b * a.Mout + mm[q]) * a.Tout + (t < a.Tout ? t : a.Tout - 1);
         bv[q] = 0.f; bg[q] = 0.f; ra[q] = 0.f; rsv[q] = 0.f;
+        if (TALL) {
+            const int m2 = m + 32;
+            valid2[q] = live && has2 && (m2 < a.Mout) && (t < a.Tout);
+            mm2[q] = m2 < a.Mout ? m2 : a.Mout - 1;
+            oo2[q] = ((size_t)b * a.Mout + mm2[q]) * a.Tout + (t < a.Tout ? t : a.Tout - 1);
+            ra2[q] = 0.f; rsv2[q] = 0.f;
+        }
     }
-    constexpr bool PRELOAD = EPT <= 4;   // wide per-wave epilogues (WK 1, 2) load late instead: registers
+    constexpr bool PRELOAD = TALL ? EPT <= 2 : EPT <= 4;   // wide per-wave epilogues (WK 1, 2; TALL: WK 4 too) load late instead: registers
     auto load_side = [&]() {
         if (a.bias) {
     #pragma unroll
-            for (int q = 0; q < EPT; ++q) { bv[q] = a.bias[mm[q]]; if (DUAL) bg[q] = a.bias[mm[q] + a.Mout]; }
+            for (int q = 0; q < EPT; ++q) { bv[q] = a.bias[mm[q]]; if (DUAL) bg[q] = a.bias[mm[q] + a.Mout]; if (TALL) bg[q] = a.bias[mm2[q]]; }
         }
         if (a.rowadd) {
     #pragma unroll
-            for (int q = 0; q < EPT; ++q) ra[q] = a.rowadd[(size_t)b * a.rowadd_stride + mm[q]];
+            for (int q = 0; q < EPT; ++q) { ra[q] = a.rowadd[(size_t)b * a.rowadd_stride + mm[q]]; if (TALL) ra2[q] = a.rowadd[(size_t)b * a.rowadd_stride + mm2[q]]; }
         }
         if (a.resid) {
     #pragma unroll
-            for (int q = 0; q < EPT; ++q) rsv[q] = a.resid[oo[q]];
+            for (int q = 0; q < EPT; ++q) { rsv[q] = a.resid[oo[q]]; if (TALL) rsv2[q] = a.resid[oo2[q]]; }
         }
     };
     if (PRELOAD) load_side();
@@ -535,6 +620,10 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
     TL_STAMP(1);
     TL_SET(10, g1 - g0);
 
+#ifdef MUGD_CONV_SKEW
+    // development variant: the two waves that share a SIMD (w and w + 4 of an 8-wave workgroup) enter the K loop half an iteration apart
+    if (WK == 8 && wave >= 4) __builtin_amdgcn_s_sleep(MUGD_CONV_SKEW);
+#endif
 #pragma unroll
     for (int si = 0; si < CONV_MAXSEG; ++si) {
         if (si < a.nseg) {
@@ -545,33 +634,33 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
             if (lo < hi) {
                 const WT* w1 = wtile + s.woff;
                 const WT* w2 = wtile2 + s.woff;
-#define MUGD_SEG_ARGS s, w1, w2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, acc, acc2
+#define MUGD_SEG_ARGS s, w1, w2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, acc, acc2, accL, acc2L
 #define MUGD_SEG_VARGS MUGD_SEG_ARGS, stl.gnst, stl.lnst, gn_inv_cg, rot
                 if (KIND == 0) {
                     // specialise on (transform, activation): branch-free chunk loops
 #define MUGD_SEG_XF(T, NHALO)                                                                     \
     switch (s.xf * 4 + s.act) {                                                                   \
-        case 0: run_segment_vec<T, DUAL, NHALO, 0, 0, MUGD_PIPE>(MUGD_SEG_VARGS); break;                      \
-        case 4: case 16: run_segment_vec<T, DUAL, NHALO, 1, 0, MUGD_PIPE>(MUGD_SEG_VARGS); break;            \
-        case 5: case 17: run_segment_vec<T, DUAL, NHALO, 1, 1, MUGD_PIPE>(MUGD_SEG_VARGS); break;            \
-        case 6: case 18: run_segment_vec<T, DUAL, NHALO, 1, 2, MUGD_PIPE>(MUGD_SEG_VARGS); break;            \
-        case 8: case 12: run_segment_vec<T, DUAL, NHALO, 2, 0, MUGD_PIPE>(MUGD_SEG_VARGS); break;            \
-        default: run_segment_vec<T, DUAL, NHALO>(MUGD_SEG_VARGS);                                  \
+        case 0: run_segment_vec<T, A2, NHALO, 0, 0, MUGD_PIPE>(MUGD_SEG_VARGS); break;                      \
+        case 4: case 16: run_segment_vec<T, A2, NHALO, 1, 0, MUGD_PIPE>(MUGD_SEG_VARGS); break;            \
+        case 5: case 17: run_segment_vec<T, A2, NHALO, 1, 1, MUGD_PIPE>(MUGD_SEG_VARGS); break;            \
+        case 6: case 18: run_segment_vec<T, A2, NHALO, 1, 2, MUGD_PIPE>(MUGD_SEG_VARGS); break;            \
+        case 8: case 12: run_segment_vec<T, A2, NHALO, 2, 0, MUGD_PIPE>(MUGD_SEG_VARGS); break;            \
+        default: run_segment_vec<T, A2, NHALO>(MUGD_SEG_VARGS);                                  \
     }
                     if (DUAL || s.taps == 1) { MUGD_SEG_XF(1, 0) }
                     else { MUGD_SEG_XF(3, 1) }
 #undef MUGD_SEG_XF
                 } else if (KIND == 1) {
-                    if (s.taps == 1) run_segment_vec<1, DUAL, 0>(MUGD_SEG_VARGS);
-                    else if (s.dil <= 2) run_segment_vec<3, DUAL, 1>(MUGD_SEG_VARGS);
-                    else if (s.dil == 4) run_segment_vec<3, DUAL, 2>(MUGD_SEG_VARGS);
-                    else run_segment_vec<3, DUAL, 4>(MUGD_SEG_VARGS);
+                    if (s.taps == 1) run_segment_vec<1, A2, 0>(MUGD_SEG_VARGS);
+                    else if (s.dil <= 2) run_segment_vec<3, A2, 1>(MUGD_SEG_VARGS);
+                    else if (s.dil == 4) run_segment_vec<3, A2, 2>(MUGD_SEG_VARGS);
+                    else run_segment_vec<3, A2, 4>(MUGD_SEG_VARGS);
                 } else {
                     if (sizeof(WT) == 4) {          // the generic windows exist with fp32 weights only
                         const float* f1 = reinterpret_cast<const float*>(w1);
                         const float* f2 = reinterpret_cast<const float*>(w2);
-                        if (s.taps == 3) run_segment_gen<3, DUAL, NITG, (NITG <= 9)>(s, f1, f2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, acc, acc2);
-                        else run_segment_gen<1, DUAL, NITG, (NITG <= 9)>(s, f1, f2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, acc, acc2);
+                        if (s.taps == 3) run_segment_gen<3, A2, NITG, (NITG <= 9)>(s, f1, f2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, acc, acc2, accL, acc2L);
+                        else run_segment_gen<1, A2, NITG, (NITG <= 9)>(s, f1, f2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, acc, acc2, accL, acc2L);
                     }
                 }
 #undef MUGD_SEG_VARGS
@@ -580,6 +669,10 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
         }
     }
 
+    if (conv_h3<WT>()) {                            // H3: fold the scaled cross terms in
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[r] += accL[r] * (1.0f / 2048.0f); if (A2) acc2[r] += acc2L[r] * (1.0f / 2048.0f); }
+    }
     // ---- combine the WK K-slices through LDS (exchange region behind the staging windows)
     TL_STAMP(3);
     float acc_v[EPT], acc_g[EPT];
@@ -588,7 +681,7 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             ex[(wave * 16 + r) * 64 + lane] = acc[r];
-            if (DUAL) ex[RED + (wave * 16 + r) * 64 + lane] = acc2[r];
+            if (A2) ex[RED + (wave * 16 + r) * 64 + lane] = acc2[r];
         }
         __syncthreads();
 #pragma unroll
@@ -599,7 +692,7 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
 #pragma unroll
             for (int w = 0; w < WK; ++w) {
                 acc_v[q] += ex[(w * 16 + r) * 64 + lane];
-                if (DUAL) acc_g[q] += ex[RED + (w * 16 + r) * 64 + lane];
+                if (A2) acc_g[q] += ex[RED + (w * 16 + r) * 64 + lane];
             }
         }
     } else {
@@ -607,7 +700,7 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
         for (int q = 0; q < EPT; ++q) { acc_v[q] = acc[q]; acc_g[q] = acc2[q]; }
     }
     TL_STAMP(4);
-    if (!DUAL && a.epi == EPI_XSOFTMAX) {          // folded cross-attention: the tile is one head's key scores (conv_stats.h)
+    if (!A2 && a.epi == EPI_XSOFTMAX) {          // folded cross-attention: the tile is one head's key scores (conv_stats.h)
         float* xs = reinterpret_cast<float*>(lds + L::EPI_OFF);      // [32][CONV_TN + 1]
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
@@ -631,6 +724,11 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
         v = (v + ra[q]) + rsv[q];
         if (valid[q]) a.y[oo[q]] = v;
         acc_v[q] = v;
+        if (TALL) {
+            float v2 = ((acc_g[q] + bg[q]) + ra2[q]) + rsv2[q];
+            if (valid2[q]) a.y[oo2[q]] = v2;
+            acc_g[q] = v2;
+        }
     }
     TL_STAMP(5);
     // ---- optional: add this tile's {sum, sum of squares} per row to the fp64 row accumulators (GroupNorm of the consumers)
@@ -647,6 +745,17 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
                 double* o = a.rowstat + 2 * ((size_t)b * a.Mout + m);
                 atomicAdd(o, (double)s1);
                 atomicAdd(o + 1, (double)s2);
+            }
+            if (TALL) {
+                float u1 = valid2[q] ? acc_g[q] : 0.f;
+                float u2 = u1 * u1;
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) { u1 += __shfl_xor(u1, o); u2 += __shfl_xor(u2, o); }
+                if (live && has2 && n == 0 && m + 32 < a.Mout) {
+                    double* o = a.rowstat + 2 * ((size_t)b * a.Mout + m + 32);
+                    atomicAdd(o, (double)u1);
+                    atomicAdd(o + 1, (double)u2);
+                }
             }
         }
     }
@@ -671,6 +780,28 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
             for (int w = 0; w < WK; ++w) { t1 += cst[0][w][tid]; t2 += cst[1][w][tid]; }
             float* o = a.colstat + 2 * (((size_t)b * gy + mt) * a.Tout + t0 + tid);
             o[0] = t1; o[1] = t2;
+        }
+        if (TALL) {                                      // the second row tile's column sums, through the same scratch
+            __syncthreads();
+            float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) {
+                const int r = wave * EPT + q;
+                const int m = mt * 32 + 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v = m < a.Mout ? acc_g[q] : 0.f;
+                u1 += v; u2 += v * v;
+            }
+            u1 += __shfl_xor(u1, 32);
+            u2 += __shfl_xor(u2, 32);
+            if (h == 0) { cst[0][wave][n] = u1; cst[1][wave][n] = u2; }
+            __syncthreads();
+            if (live && has2 && tid < 32 && t0 + tid < a.Tout) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WK; ++w) { t1 += cst[0][w][tid]; t2 += cst[1][w][tid]; }
+                float* o = a.colstat + 2 * (((size_t)b * gy + mt + 1) * a.Tout + t0 + tid);
+                o[0] = t1; o[1] = t2;
+            }
         }
     }
     TL_STAMP(6);

@@ -38,9 +38,9 @@
 namespace {
 
 // One workgroup = one tile: decodes blockIdx into (row tile, batch row, column tile) and runs the shared tile body (conv_body.h).
-template <int WK, bool DUAL, int KIND, int NITG, class WT = float>
+template <int WK, bool DUAL, int KIND, int NITG, class WT = float, bool TALL = false>
 __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel(const ConvArgs a) {
-    __shared__ __attribute__((aligned(16))) char lds[conv_lds_bytes<WK, DUAL>()];
+    __shared__ __attribute__((aligned(16))) char lds[conv_lds_bytes<WK, DUAL || TALL>()];
     TL_BEGIN();
 
     // ---- kernel arguments of the prologue in one batch (common.h: KARG_PIN)
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
     else { mt = fastdiv(lid, a.mgxz, gx * gz); rem = lid - mt * (gx * gz); }
     const int b = fastdiv(rem, a.mgx, gx);
     const int t0 = (rem - b * gx) * CONV_TN;
-    conv_tile<WK, DUAL, KIND, NITG, WT>(a, mt, b, t0, rem, (int)threadIdx.x, lds, true);
+    conv_tile<WK, DUAL, KIND, NITG, WT, TALL>(a, TALL ? 2 * mt : mt, b, t0, rem, (int)threadIdx.x, lds, true);      // TALL: the grid's row axis counts PAIRS of row tiles
     TL_END(a.tl, WK);
 }
 
@@ -86,6 +86,15 @@ __global__ void pack_weights_kernel(const PackArgs p) {
         if (p.w16) {
             const unsigned u = __float_as_uint(wv);
             reinterpret_cast<unsigned short*>(p.dst)[d] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);      // round to nearest even
+        } else if (MUGD_CONV_H3) {
+            // H3 (conv_body.h): per (tap, lane) two 16-byte planes -- the hi halves, then the lo halves of the lane's 8 channels
+            // (slot e = 4 g8 + j <-> channel 4 hh + j + 8 g8, the order the window fragments are read in)
+            const long long blk = (long long)mt * p.w_mt_stride + p.seg_woff + (long long)chunk * (p.taps * 512) + (tap * 2) * 256 + lane * 4;
+            const _Float16 hi = (_Float16)wv;
+            const _Float16 lo = (_Float16)((wv - (float)hi) * 2048.0f);
+            _Float16* h = reinterpret_cast<_Float16*>(p.dst);
+            h[2 * blk + (g8 * 4 + j)] = hi;
+            h[2 * (blk + 256) + (g8 * 4 + j)] = lo;
         } else {
             p.dst[d] = wv;
         }
@@ -93,11 +102,16 @@ __global__ void pack_weights_kernel(const PackArgs p) {
 }
 
 template <int WK, bool DUAL>
-void launch_wk(hipStream_t st, const ConvArgs& a0, dim3 grid, int gx, int gy, int gz, int kind, int nitg) {
+void launch_wk(hipStream_t st, const ConvArgs& a0, dim3 grid, int gx, int gy, int gz, int kind, int nitg, bool tall) {
     ConvArgs a = a0;
     conv_split_k(a, WK);
     conv_set_grid(a, gx, gy, gz);
     a.tl = tl_claim((int)grid.x, WK, 32);
+    if (tall) {                               // 64 x 32 tiles (conv_body.h: TALL): plain epilogue, fast windows (KIND 0 / 1), fp32 weights
+        if (kind == 0) hipLaunchKernelGGL((conv_gemm_kernel<WK, false, 0, 1, float, true>), grid, dim3(WK * 64), 0, st, a);
+        else hipLaunchKernelGGL((conv_gemm_kernel<WK, false, 1, 1, float, true>), grid, dim3(WK * 64), 0, st, a);
+        return;
+    }
 #define MUGD_CONV_LAUNCH(K, N) hipLaunchKernelGGL((conv_gemm_kernel<WK, DUAL, K, N>), grid, dim3(WK * 64), 0, st, a)
     if (a.w16) {
         MUGD_CHECK(kind == 0, -2, "conv_gemm: bfloat16 weights exist for the plain fast-window kernels only");
@@ -122,15 +136,15 @@ bool conv_w16_supported(const ConvArgs& a) {
     return true;
 }
 
-int conv_pick_wk(const ConvArgs& a) {
+static int conv_pick_wk_tiles(long long tiles, int nchunk) {
     // ~2 waves on each of the 1024 SIMDs, every wave with at least 2 chunks of work where K allows
-    const long long tiles = (long long)cdiv(a.Tout, CONV_TN) * cdiv(a.Mout, 32) * a.B;
     int wk = 8;
     while (wk > 1 && tiles * wk > 2048) wk >>= 1;
-    while (wk > 1 && a.nchunk < wk) wk >>= 1;
-    if (wk < 2 && tiles < 2048) wk = a.nchunk >= 4 ? 2 : 1;
+    while (wk > 1 && nchunk < wk) wk >>= 1;
+    if (wk < 2 && tiles < 2048) wk = nchunk >= 4 ? 2 : 1;
     return wk;
 }
+int conv_pick_wk(const ConvArgs& a) { return conv_pick_wk_tiles((long long)cdiv(a.Tout, CONV_TN) * cdiv(a.Mout, 32) * a.B, a.nchunk); }
 
 void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
     MUGD_CHECK(a.nseg >= 1 && a.nseg <= CONV_MAXSEG, -2, "conv_gemm: bad segment count");
@@ -178,17 +192,25 @@ void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
         for (int i = 0; i < a.nseg; ++i) MUGD_CHECK(a.seg[i].taps == 1, -2, "conv_gemm: gated epilogue is implemented for 1x1 convs");
     }
     else MUGD_CHECK(a.Mrows == a.Mout, -2, "conv_gemm: Mrows != Mout");
-    const int gx = cdiv(a.Tout, CONV_TN), gy = cdiv(a.Mout, 32), gz = a.B;
+    int gx = cdiv(a.Tout, CONV_TN), gy = cdiv(a.Mout, 32), gz = a.B;
+    // 64 x 32 tiles when half the tile count still fills the chip (2 workgroups of <= 4 waves, or one of 8, per CU): every staged window
+    // element then feeds two row tiles.  MUGD_CONV_TALL=0 | 1 forces it off / on wherever it is implemented (A/B, tests)
+    bool tall = !dual && a.epi == EPI_NONE && kind != 2 && !a.w16 && gy >= 2 && (long long)gx * ((gy + 1) / 2) * gz >= 256;
+    if (const char* e = getenv("MUGD_CONV_TALL")) {
+        if (e[0] == '0') tall = false;
+        else if (e[0] == '1') tall = !dual && a.epi == EPI_NONE && kind != 2 && !a.w16 && gy >= 2;
+    }
+    if (tall) gy = (gy + 1) / 2;
     const dim3 grid((unsigned)gx * gy * gz);
-    int wk = a.wk > 0 ? a.wk : conv_pick_wk(a);
+    int wk = a.wk > 0 ? a.wk : conv_pick_wk_tiles((long long)gx * gy * gz, a.nchunk);
     if (const char* e = getenv("MUGD_CONV_WK")) {            // development / test knob: force the K-split
         const int v = atoi(e);
         if (v == 1 || v == 2 || v == 4 || v == 8) wk = v;
     }
 #define MUGD_WK(W)                                                             \
     case W:                                                                    \
-        if (dual) launch_wk<W, true>(st, a, grid, gx, gy, gz, kind, nitg);     \
-        else launch_wk<W, false>(st, a, grid, gx, gy, gz, kind, nitg);         \
+        if (dual) launch_wk<W, true>(st, a, grid, gx, gy, gz, kind, nitg, false);     \
+        else launch_wk<W, false>(st, a, grid, gx, gy, gz, kind, nitg, tall);         \
         break;
     switch (wk) {
         MUGD_WK(1) MUGD_WK(2) MUGD_WK(4) MUGD_WK(8)

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmugd.so")
+LIB_PATH = os.environ.get("MUGD_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "libmugd.so")      # MUGD_LIB_PATH: development A/B builds (build.py --variant)
 
 F32, I64 = 0, 1
 _p = C.c_void_p

@@ -175,6 +175,24 @@ static inline emu_f32x16 emu_mfma32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x16 
     return d;
 }
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu_mfma32_bf16((a), (b), (c))
+typedef _Float16 emu_f16x8 __attribute__((ext_vector_type(8)));
+static inline emu_f32x16 emu_mfma32_f16(emu_f16x8 a, emu_f16x8 b, emu_f32x16 c) {      // v_mfma_f32_32x32x16_f16: same operand layout as the bf16 form
+    float af[8], bf[8], ci[16], di[16];
+    for (int i = 0; i < 8; ++i) { af[i] = (float)a[i]; bf[i] = (float)b[i]; }
+    for (int i = 0; i < 16; ++i) ci[i] = c[i];
+    emu::mfma_32x32x16_bf16(af, bf, ci, di);
+    emu_f32x16 d;
+    for (int i = 0; i < 16; ++i) d[i] = di[i];
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu_mfma32_f16((a), (b), (c))
+// v_perm_b32: result byte i = byte sel[i] of the 8-byte value {s0 : s1} (bytes 0-3 = s1, 4-7 = s0); selectors >= 8 are not used here
+static inline unsigned __builtin_amdgcn_perm(unsigned s0, unsigned s1, unsigned sel) {
+    const unsigned long long v = ((unsigned long long)s0 << 32) | s1;
+    unsigned r = 0;
+    for (int i = 0; i < 4; ++i) r |= (unsigned)((v >> (8 * ((sel >> (8 * i)) & 7))) & 0xff) << (8 * i);
+    return r;
+}
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma32((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu_mfma16((a), (b), (c))
 

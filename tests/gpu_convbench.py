@@ -68,15 +68,18 @@ def main():
     ap.add_argument("--shape", type=int, default=0)
     ap.add_argument("--tn", type=int, default=0)
     ap.add_argument("--wk", type=int, default=0)
+    ap.add_argument("--hot", action="store_true", help="--pmc: one weight copy (L2-resident) instead of a fresh copy per launch")
+    ap.add_argument("--B", type=int, default=0, help="--pmc: override the batch")
     a = ap.parse_args()
     lib = get_lib()
     if a.sweep:
         return sweep(lib)
     if a.pmc:
         name, B, C, T, M, taps, norm, gated = SHAPES[a.shape]
-        copies = max(1, int(300e6 / (M * C * taps * 4)))
+        B = a.B or B
+        copies = 1 if a.hot else max(1, int(300e6 / (M * C * taps * 4)))
         us = lib.dev_bench_conv(B, C, T, M, taps, norm, bool(gated), wk=a.wk, tn=a.tn, copies=copies, iters=20)
-        print("%s tn=%d wk=%d cold: %.2f us" % (name, a.tn, a.wk, us))
+        print("%s B=%d tn=%d wk=%d %s: %.2f us" % (name, B, a.tn, a.wk, "hot" if a.hot else "cold", us))
         return
     print("%-16s %8s | %s" % ("shape", "GFLOP", "us per launch (TF/s): hot tn32 | hot tn16 | cold tn32 wk8/wk4 | cold tn16 wk8/wk4 | cold no-norm auto"))
     for name, B, C, T, M, taps, norm, gated in SHAPES:
