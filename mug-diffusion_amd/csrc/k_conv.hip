@@ -193,13 +193,11 @@ void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
     }
     else MUGD_CHECK(a.Mrows == a.Mout, -2, "conv_gemm: Mrows != Mout");
     int gx = cdiv(a.Tout, CONV_TN), gy = cdiv(a.Mout, 32), gz = a.B;
-    // 64 x 32 tiles when half the tile count still fills the chip (2 workgroups of <= 4 waves, or one of 8, per CU): every staged window
-    // element then feeds two row tiles.  MUGD_CONV_TALL=0 | 1 forces it off / on wherever it is implemented (A/B, tests)
-    bool tall = !dual && a.epi == EPI_NONE && kind != 2 && !a.w16 && gy >= 2 && (long long)gx * ((gy + 1) / 2) * gz >= 256;
-    if (const char* e = getenv("MUGD_CONV_TALL")) {
-        if (e[0] == '0') tall = false;
-        else if (e[0] == '1') tall = !dual && a.epi == EPI_NONE && kind != 2 && !a.w16 && gy >= 2;
-    }
+    // 64 x 32 tiles (conv_body.h: TALL): opt-in only (MUGD_CONV_TALL=1, wherever the form exists).  Measured slower than 32 x 32 tiles at every
+    // batch size under both arithmetics (profiles/r4_tall_ab.txt: the second accumulator pair and weight stream push the kernel to 256 VGPRs
+    // + scratch; with the H3 arithmetic batch 16 runs 4.87 ms / step without it and 5.46 with it)
+    bool tall = false;
+    if (const char* e = getenv("MUGD_CONV_TALL")) tall = e[0] == '1' && !dual && a.epi == EPI_NONE && kind != 2 && !a.w16 && gy >= 2;
     if (tall) gy = (gy + 1) / 2;
     const dim3 grid((unsigned)gx * gy * gz);
     int wk = a.wk > 0 ? a.wk : conv_pick_wk_tiles((long long)gx * gy * gz, a.nchunk);

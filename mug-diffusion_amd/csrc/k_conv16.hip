@@ -27,6 +27,21 @@ constexpr int WIN_LDS = CONV_CK * RS;           // floats per window
 constexpr int WAVE_LDS = 2 * WIN_LDS;           // two windows per wave (software-pipelined loops, see k_conv.hip)
 constexpr int HL = 8;                           // window column of sample t0
 
+// The H3 arithmetic of conv_body.h (fp32-equivalent products on the f16 matrix cores: operands split into f16 hi + 2^11-scaled lo halves)
+// on 16 x 16 tiles: v_mfma_f32_16x16x16f16, lane (kq, r) supplies the 4 k-slots <-> channels 4 s + kq -- the map the fp32 kernel uses.
+#ifndef MUGD_CONV_H3
+#define MUGD_CONV_H3 1
+#endif
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float h3_split16(float v) {          // {hi | lo << 16}
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)((v - (float)hi) * 2048.0f);
+    return __uint_as_float((unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16));
+}
+template <class WT>
+constexpr bool conv16_h3() { return MUGD_CONV_H3 != 0 && sizeof(WT) == 4; }
+
 __device__ __forceinline__ float4 widen16_bf16x4(const uint2 r) {       // see k_conv.hip
     return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
 }
@@ -48,7 +63,8 @@ __device__ __forceinline__ void load_a16(const WT* wp, const WT* wp2, float4 (&A
 template <int TAPS, bool DUAL, int XFK = -1, int ACT = -1, bool PIPE = false, class WT = float>       // XFK / ACT / PIPE: see k_conv.hip
 __device__ __forceinline__ void run_segment16(const ConvSeg& s, const WT* wseg, const WT* wseg2, int lo, int hi,
                                               int b, int t0, int lane, char* smem_bytes, int wave_base,
-                                              f32x4 (&acc)[2], f32x4 (&accg)[2], const float2* gst, const float2* lnst, float inv_cg, int rot_seed) {
+                                              f32x4 (&acc)[2], f32x4 (&accg)[2], f32x4 (&accL)[2], f32x4 (&accgL)[2], const float2* gst, const float2* lnst,
+                                              float inv_cg, int rot_seed) {
     constexpr int NH = TAPS == 3 ? 1 : 0;                  // dilation 1: 2 halo samples per row, one load for lanes q < 2
     const int r = lane >> 2, q = lane & 3;
     const int l15 = lane & 15, kq = lane >> 4;
@@ -143,6 +159,11 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const WT* wseg, 
                 vh = silu_fast(vh);
             }
         }
+        if (conv16_h3<WT>()) {                          // H3: the window holds {hi | lo} f16 halves
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = h3_split16(v[i]);
+            vh = h3_split16(vh);
+        }
         float4 w0;
         w0.x = ok0 ? v[0] : 0.f; w0.y = ok0 ? v[1] : 0.f; w0.z = ok0 ? v[2] : 0.f; w0.w = ok0 ? v[3] : 0.f;
         *reinterpret_cast<float4*>(smem_bytes + wofs + l0) = w0;
@@ -156,6 +177,37 @@ __device__ __forceinline__ void run_segment16(const ConvSeg& s, const WT* wseg, 
 #pragma unroll
             for (int kg = 0; kg < 4; ++kg)
                 bf[tap * 4 + kg] = *reinterpret_cast<const float*>(smem_bytes + wofs + rb0 + (4 * kg * RS + tap) * 4);
+        if (conv16_h3<WT>()) {
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const unsigned d0 = __float_as_uint(bf[tap * 4 + 0]), d1 = __float_as_uint(bf[tap * 4 + 1]);
+                const unsigned d2 = __float_as_uint(bf[tap * 4 + 2]), d3 = __float_as_uint(bf[tap * 4 + 3]);
+                u32x2_16 hv, lv;
+                hv[0] = __builtin_amdgcn_perm(d1, d0, 0x05040100u); hv[1] = __builtin_amdgcn_perm(d3, d2, 0x05040100u);
+                lv[0] = __builtin_amdgcn_perm(d1, d0, 0x07060302u); lv[1] = __builtin_amdgcn_perm(d3, d2, 0x07060302u);
+                const h16x4 bh = __builtin_bit_cast(h16x4, hv), bl = __builtin_bit_cast(h16x4, lv);
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const float4 av = A[tap * 2 + half];
+                    u32x2_16 ahv, alv;
+                    ahv[0] = __float_as_uint(av.x); ahv[1] = __float_as_uint(av.y); alv[0] = __float_as_uint(av.z); alv[1] = __float_as_uint(av.w);
+                    const h16x4 ah = __builtin_bit_cast(h16x4, ahv), al = __builtin_bit_cast(h16x4, alv);
+                    acc[half] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, acc[half], 0, 0, 0);
+                    accL[half] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, accL[half], 0, 0, 0);
+                    accL[half] = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh, accL[half], 0, 0, 0);
+                    if (DUAL) {
+                        const float4 gv = A2[tap * 2 + half];
+                        u32x2_16 ghv, glv;
+                        ghv[0] = __float_as_uint(gv.x); ghv[1] = __float_as_uint(gv.y); glv[0] = __float_as_uint(gv.z); glv[1] = __float_as_uint(gv.w);
+                        const h16x4 gh = __builtin_bit_cast(h16x4, ghv), gl = __builtin_bit_cast(h16x4, glv);
+                        accg[half] = __builtin_amdgcn_mfma_f32_16x16x16f16(gh, bh, accg[half], 0, 0, 0);
+                        accgL[half] = __builtin_amdgcn_mfma_f32_16x16x16f16(gh, bl, accgL[half], 0, 0, 0);
+                        accgL[half] = __builtin_amdgcn_mfma_f32_16x16x16f16(gl, bh, accgL[half], 0, 0, 0);
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const float4 a0 = A[tap * 2], a1 = A[tap * 2 + 1];
@@ -314,9 +366,9 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
     for (int w = 1; w < WK; ++w)
         if (wave == w) { g0 = a.kb[w]; g1 = a.kb[w + 1]; }
 
-    f32x4 acc[2], accg[2];
+    f32x4 acc[2], accg[2], accL[2], accgL[2];      // accL / accgL: the scaled cross terms of the H3 arithmetic
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; accg[0][i] = 0.f; accg[1][i] = 0.f; }
+    for (int i = 0; i < 4; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; accg[0][i] = 0.f; accg[1][i] = 0.f; accL[0][i] = 0.f; accL[1][i] = 0.f; accgL[0][i] = 0.f; accgL[1][i] = 0.f; }
 
     const WT* wtile = reinterpret_cast<const WT*>(a.wpk) + (size_t)b * a.w_b_stride + (size_t)mt * a.w_mt_stride + lane * 4;
     const WT* wtile2 = DUAL ? wtile + (size_t)(a.Mout >> 5) * a.w_mt_stride : wtile;
@@ -368,7 +420,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
             if (lo < hi) {
                 const WT* w1 = wtile + s.woff;
                 const WT* w2 = wtile2 + s.woff;
-#define MUGD_SEG16_ARGS s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, acc, accg, stl.gnst, stl.lnst, gn_inv_cg, rem
+#define MUGD_SEG16_ARGS s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, acc, accg, accL, accgL, stl.gnst, stl.lnst, gn_inv_cg, rem
 #define MUGD_SEG16_XF(T)                                                                  \
     switch (s.xf * 4 + s.act) {                                                           \
         case 0: run_segment16<T, DUAL, 0, 0, true>(MUGD_SEG16_ARGS); break;                     \
@@ -386,6 +438,13 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm16_kern
         }
     }
 
+    if (conv16_h3<WT>()) {                          // H3: fold the scaled cross terms in
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[0][i] += accL[0][i] * (1.0f / 2048.0f); acc[1][i] += accL[1][i] * (1.0f / 2048.0f);
+            if (DUAL) { accg[0][i] += accgL[0][i] * (1.0f / 2048.0f); accg[1][i] += accgL[1][i] * (1.0f / 2048.0f); }
+        }
+    }
     TL_STAMP(3);
     float acc_v[EPT], acc_g[EPT];
     if (WK > 1) {
@@ -498,6 +557,14 @@ __global__ void pack_weights16_kernel(const PackArgs p) {
         if (p.w16) {
             const unsigned u = __float_as_uint(wv);
             reinterpret_cast<unsigned short*>(p.dst)[d] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);      // round to nearest even
+        } else if (MUGD_CONV_H3) {
+            // H3: the lane's 16 bytes of a (tap, row half) = 4 hi halves (slots kg = 0..3), then 4 scaled lo halves
+            const long long blk = (long long)mt * p.w_mt_stride + p.seg_woff + (long long)chunk * (p.taps * 512) + (tap * 2 + half) * 256 + lane * 4;
+            const _Float16 hi = (_Float16)wv;
+            const _Float16 lo = (_Float16)((wv - (float)hi) * 2048.0f);
+            _Float16* h = reinterpret_cast<_Float16*>(p.dst);
+            h[2 * blk + kg] = hi;
+            h[2 * blk + 4 + kg] = lo;
         } else {
             p.dst[d] = wv;
         }

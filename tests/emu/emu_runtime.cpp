@@ -228,6 +228,23 @@ void mfma_16x16x4(float a, float b, const float* c, float* d) {
     wave_barrier();
 }
 
+// v_mfma_f32_16x16x16f16: lane l holds 4 consecutive k (k = 4 (l >> 4) + e) of A row i = l & 15 and of B column j = l & 15; D map as the
+// 16x16x4 f32 form (lane l: column l & 15, rows 4 (l >> 4) + r)
+void mfma_16x16x16(const float* a4, const float* b4, const float* c, float* d) {
+    WaveScratch& w = waves[cur->lin >> 6];
+    const int l = cur->lin & 63;
+    for (int e = 0; e < 4; ++e) { w.a8[l][e] = a4[e]; w.b8[l][e] = b4[e]; }
+    wave_barrier();
+    const int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int row = (l >> 4) * 4 + r;
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) acc = fmaf(w.a8[row + 16 * (k >> 2)][k & 3], w.b8[col + 16 * (k >> 2)][k & 3], acc);
+        d[r] = acc;
+    }
+    wave_barrier();
+}
+
 // v_mfma_f32_32x32x16_bf16: lane l holds 8 consecutive k of A row i = l & 31 and of B column j = l & 31, k = 8 (l >> 5) + e;
 // D map as the f32 form.  The hardware's internal summation order is not specified: fp32 accumulation, k ascending here.
 void mfma_32x32x16_bf16(const float* a8, const float* b8, const float* c, float* d) {

@@ -105,6 +105,7 @@ float wave_xchg(float v, int src_lane);
 void mfma_32x32x2(float a, float b, const float* c, float* d);
 void mfma_16x16x4(float a, float b, const float* c, float* d);
 void mfma_32x32x16_bf16(const float* a8, const float* b8, const float* c, float* d);
+void mfma_16x16x16(const float* a4, const float* b4, const float* c, float* d);
 int lane_id();
 }  // namespace emu
 
@@ -186,6 +187,16 @@ static inline emu_f32x16 emu_mfma32_f16(emu_f16x8 a, emu_f16x8 b, emu_f32x16 c) 
     return d;
 }
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu_mfma32_f16((a), (b), (c))
+typedef _Float16 emu_f16x4 __attribute__((ext_vector_type(4)));
+static inline emu_f32x4 emu_mfma16_f16(emu_f16x4 a, emu_f16x4 b, emu_f32x4 c) {      // v_mfma_f32_16x16x16f16: lane (kq, r | n) supplies k = 4 kq + j
+    float af[4], bf[4], ci[4], di[4];
+    for (int i = 0; i < 4; ++i) { af[i] = (float)a[i]; bf[i] = (float)b[i]; ci[i] = c[i]; }
+    emu::mfma_16x16x16(af, bf, ci, di);
+    emu_f32x4 d;
+    for (int i = 0; i < 4; ++i) d[i] = di[i];
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, x, y, z) emu_mfma16_f16((a), (b), (c))
 // v_perm_b32: result byte i = byte sel[i] of the 8-byte value {s0 : s1} (bytes 0-3 = s1, 4-7 = s0); selectors >= 8 are not used here
 static inline unsigned __builtin_amdgcn_perm(unsigned s0, unsigned s1, unsigned sel) {
     const unsigned long long v = ((unsigned long long)s0 << 32) | s1;
