@@ -34,6 +34,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+PEAK_F16_MFMA_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense f16 / bf16 MFMA (v_mfma_f32_32x32x16_f16)
+# conv_gemm since round 4: every fp32-equivalent product block is THREE f16 MFMAs on split operands (csrc/conv_body.h: H3), so the matrix
+# pipe's ceiling for ALGORITHMIC (2 M K N) flops is a third of the dense f16 peak
+PEAK_H3_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0
 PEAK_HBM_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E, 8 TB/s nominal (~6.3 TB/s achievable on a streaming kernel)
 UNET_GFLOP_PER_SAMPLE_STEP = 22.37     # BASELINE.md section 2 (z = 512)
 
@@ -145,6 +149,7 @@ def main():
     import yaml
 
     lib = get_lib()
+    h3 = "f16x3" in lib.version()            # the library's conv arithmetic (csrc/conv_body.h: MUGD_CONV_H3)
     if a.weights == "bf16":
         lib.set_weight_precision(True)
     note("library loaded")
@@ -246,7 +251,12 @@ def main():
             "metric": "charts_per_sec (3-min audio, %d DDIM steps, batch %d)" % (S, B),
             "value": charts / elapsed, "unit": "charts/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if a.weights == "f32" else "bf16 weights, f32 activations / MFMA inputs after widening / accumulation (reduced-precision mode)",
+            "dtype": ("f32" if a.weights == "f32" else "bf16 weights, f32 activations / MFMA inputs after widening / accumulation (reduced-precision mode)"),
+            "dtype_detail": ("fp32 tensors, fp32 accumulation; conv / linear products on the f16 matrix cores with BOTH operands split into f16 hi + 2^11-scaled lo "
+                             "halves (3 MFMAs per block): fp32-equivalent -- measured error vs float64 2.7e-7 relative at K = 1024 against 7.7e-7 for the "
+                             "fp32-input MFMA chain (profiles/r4_h3_probe.txt); every parity test runs at the fp32 tolerances" if h3 else
+                             "fp32 tensors, fp32-input MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulation") if a.weights == "f32" else None,
+            "library": lib.version(),
             "data": "synthetic",
             "config": {"workload": "configs[1]: %.0f s synthetic %.2f kHz audio -> %s z=%d, %d DDIM steps, batch %d, cfg_scale %g, "
                                    "mel + wave-encode (once per song, shared by the seeds) + DDIM + VAE decode + note grid"
@@ -283,11 +293,16 @@ def main():
                 traffic = tj.get("hbm_bytes_per_launch")
                 traffic_source = "profiles/conv_traffic.json (%s): separate rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled " \
                                  "per MI355X_MICROARCH.md; not measured by this run" % tj.get("round", "round 1 tree")
-            out["roofline"] = {"kernel": "conv_gemm_kernel / conv_gemm16_kernel (fp32-MFMA implicit-GEMM conv1d / linear, 32x32 and 32x16 tiles; "
+            peak = PEAK_H3_TFLOPS if h3 else PEAK_FP32_MFMA_TFLOPS
+            out["roofline"] = {"kernel": "conv_gemm_kernel / conv_gemm16_kernel (implicit-GEMM conv1d / linear, 32x32 and 32x16 tiles, %s; "
                                          "all %d launches of one U-Net evaluation, HIP events around every launch on the library stream, "
-                                         "minus the calibrated inter-launch gap)" % k["launches"],
-                               "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
+                                         "minus the calibrated inter-launch gap)" % ("f16x3-split MFMA" if h3 else "fp32-input MFMA", k["launches"]),
+                               "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                               "peak_detail": ("algorithmic 2MKN flops against the dense f16 MFMA peak / 3 (three MFMAs per fp32-equivalent product block); "
+                                               "these launches are small dependent GEMMs bound by their per-tile latency chain and the VALU work of the operand "
+                                               "transform / split, not by the matrix pipe (DESIGN.md 4)") if h3 else "fp32-input MFMA peak = vector fp32 peak",
+                               "frac": achieved / peak, "frac_of_fp32_input_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
+                               "traffic": traffic, "traffic_source": traffic_source,
                                "launches_per_unet_eval": k["launches"], "avg_launch_us": conv_ms * 1e3 / max(k["launches"], 1),
                                "avg_launch_us_event_bracketed": k["ms"] * 1e3 / max(k["launches"], 1),
                                "event_gap_us_per_launch": gap_ms * 1e3,

@@ -54,7 +54,13 @@ struct Scratch {
 
 extern "C" {
 
-const char* mugd_version(void) { return "mugd 0.1 (gfx950, fp32 MFMA)"; }
+// conv_gemm's arithmetic is a build-time choice (conv_body.h: MUGD_CONV_H3): the version string names it so that measurements can label themselves
+#ifndef MUGD_CONV_H3
+#define MUGD_CONV_H3 1
+#endif
+const char* mugd_version(void) {
+    return MUGD_CONV_H3 ? "mugd 0.2 (gfx950, conv=f16x3-split MFMA, fp32-equivalent)" : "mugd 0.2 (gfx950, conv=fp32 MFMA)";
+}
 
 int mugd_create(int device, void* stream, mugd_ctx** out) {
     if (!out) return MUGD_ERR_INVALID;
