@@ -257,6 +257,7 @@ def main():
                              "fp32-input MFMA chain (profiles/r4_h3_probe.txt); every parity test runs at the fp32 tolerances" if h3 else
                              "fp32 tensors, fp32-input MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulation") if a.weights == "f32" else None,
             "library": lib.version(),
+            "shader_clock_mhz_under_matrix_load": lib.dev_clock_probe(),      # boxes of the pool differ by up to 25 % in what they sustain
             "data": "synthetic",
             "config": {"workload": "configs[1]: %.0f s synthetic %.2f kHz audio -> %s z=%d, %d DDIM steps, batch %d, cfg_scale %g, "
                                    "mel + wave-encode (once per song, shared by the seeds) + DDIM + VAE decode + note grid"

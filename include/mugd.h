@@ -220,6 +220,9 @@ int mugd_op_norm_conv1d(mugd_ctx* ctx, const float* x, const float* gamma, const
                         float* y, int B, int C, int T, int M, int taps, int dil, int pad, int norm, int groups, int silu, int wk);
 /* Development micro-benchmark of one conv_gemm launch shape with `copies` weight sets cycled (cold weights, like a layer
  * inside the U-Net step); mean microseconds per launch. */
+/* Development probe: the shader clock (MHz) the device sustains while every SIMD issues matrix instructions back to back (~0.3 ms);
+ * measurements quote it because boxes of one pool differ by up to 25 %.  Synchronises. */
+int mugd_dev_clock_probe(mugd_ctx* ctx, float* mhz_out);
 int mugd_dev_bench_conv(mugd_ctx* ctx, int B, int C, int T, int M, int taps, int norm, int gated, int wk, int tn, int copies,
                         int iters, float* us_out);
 int mugd_op_attention(mugd_ctx* ctx, const float* q, const float* k, const float* v, const float* rel, const float* cemb,

@@ -50,6 +50,31 @@ struct Scratch {
     ~Scratch() { for (void* p : bufs) hipFree(p); }
 };
 
+// ---- development probe: the shader clock this device sustains under matrix load (boxes of a pool differ: a measurement should say which it ran on)
+__global__ __launch_bounds__(256) void clock_probe_kernel(int iters, float* sink, long long* clk) {
+    f32x16 acc;
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const float a = (float)threadIdx.x * 1e-3f, b = 1.0f;
+#ifdef MUGD_EMULATED
+    const long long c0 = 0, w0 = 0;
+#else
+    const long long c0 = clock64(), w0 = wall_clock64();
+#endif
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+#ifdef MUGD_EMULATED
+    const long long c1 = 2400, w1 = 100;
+#else
+    const long long c1 = clock64(), w1 = wall_clock64();
+#endif
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += acc[i];
+    if (s == 12345.678f) sink[0] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = c1 - c0; clk[1] = w1 - w0; }
+}
+
 }  // namespace
 
 extern "C" {
@@ -503,6 +528,28 @@ int mugd_dev_bench_conv(mugd_ctx* ctx, int B, int C, int T, int M, int taps, int
         hipEventDestroy(e0);
         hipEventDestroy(e1);
         *us_out = ms * 1e3f / iters;
+    });
+}
+
+int mugd_dev_clock_probe(mugd_ctx* ctx, float* mhz_out) {
+    return guarded(ctx, [&] {
+        MUGD_CHECK(mhz_out != nullptr, MUGD_ERR_INVALID, "null argument");
+        hipStream_t st = ctx->c.stream;
+        Scratch sc;
+        long long* clk = reinterpret_cast<long long*>(sc.get(8, true, st));
+        float* sink = sc.get(4, false, st);
+#ifdef MUGD_EMULATED
+        const int blocks = 1, iters = 1;
+#else
+        const int blocks = 1024, iters = 600;              // ~0.3 ms of back-to-back MFMAs on every SIMD
+#endif
+        hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, st, iters, sink, clk);
+        long long h[2] = {0, 0};
+        HIP_CHECK(hipMemcpyAsync(h, clk, sizeof(h), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        int wall_khz = 100000;                              // wall_clock64: 100 MHz on this part
+        hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, ctx->c.device);
+        *mhz_out = h[1] > 0 ? (float)((double)h[0] / (double)h[1] * (double)wall_khz / 1e3) : 0.f;
     });
 }
 

@@ -78,6 +78,7 @@ _SIGS = {
     "mugd_op_conv1d": [_p, _p, _p, _p, _p, _p] + [_i] * 11,
     "mugd_op_norm_conv1d": [_p, _p, _p, _p, _p, _p, _p] + [_i] * 11,
     "mugd_dev_bench_conv": [_p] + [_i] * 11 + [C.POINTER(_f)],
+    "mugd_dev_clock_probe": [_p, C.POINTER(_f)],
     "mugd_op_attention": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i],
     "mugd_op_s4_kernel": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i],
     "mugd_op_s4_conv": [_p, _p, _p, _p, _p, _i, _i, _i],
@@ -449,6 +450,12 @@ class Lib:
         us = _f()
         self.check(self.dll.mugd_dev_bench_conv(self.ctx, B, Cc, T, M, taps, norm, int(gated), wk, tn, copies, iters, C.byref(us)))
         return us.value
+
+    def dev_clock_probe(self):
+        """Shader clock (MHz) sustained under matrix load: which class of box a measurement ran on."""
+        mhz = _f()
+        self.check(self.dll.mugd_dev_clock_probe(self.ctx, C.byref(mhz)))
+        return mhz.value
 
     def op_attention(self, q, k, v, rel, cemb, heads):
         q, k, v, rel, cemb = map(self.f32, (q, k, v, rel, cemb))

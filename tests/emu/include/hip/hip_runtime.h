@@ -58,7 +58,7 @@ typedef struct EmuGraph* hipGraph_t;
 typedef struct EmuGraph* hipGraphExec_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum hipStreamCaptureMode { hipStreamCaptureModeGlobal, hipStreamCaptureModeThreadLocal, hipStreamCaptureModeRelaxed };
-enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 16 };
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 16, hipDeviceAttributeWallClockRate = 17 };
 
 const char* hipGetErrorString(hipError_t);
 hipError_t hipGetLastError();
