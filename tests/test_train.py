@@ -884,6 +884,65 @@ def test_shipped_training_step_vs_reference_golden_and_autograd(gpu_lib):
         print("   %-26s %.2e   %s" % (bt, rel, n))
 
 
+@pytest.mark.gpu
+def test_shipped_training_step_at_the_timed_geometry_vs_autograd(gpu_lib):
+    """The geometry bench.py times -- shipped model, z = 512, 32768-frame mel -- at batch 4 (the batch-32 step is the same launch list
+    with 8x the rows per launch): loss and the gradient of ALL 1327 trainable tensors against autograd through the oracle's restatement
+    (identical to the reference on the z = 96 fixture).  Covers what the z = 96 tests cannot: the multi-tile walks of the long layers
+    (T = 32768 ... 512), S4 at L = 512, 2048-column GEMMs, the 0.5 GB-tensor layers of the wave encoder.  fp32 mode at the fp32
+    tolerances of the z = 96 test; then the bf16 step against the fp32 step at the stated bf16 tolerance."""
+    from oracle import cases, nets, weights
+    from mug import train
+    case, z, B = cases.FULL, 512, 4
+    man = weights.load_manifest(os.path.join(cases.GOLDEN, case["manifest"]))
+    sd = weights.set_s4_lengths(weights.make_state_dict(man, 7), case["unet"], z)
+    n_ids = sd["model.cond_stage_model.embedding.weight"].shape[0]
+    x0, noise = rnd(170, B, 16, z), rnd(171, B, 16, z)
+    t = torch.tensor([17, 803, 402, 999])
+    ids = torch.from_numpy(np.random.default_rng(5).integers(0, n_ids, (B, case["n_ctx_tok"])))
+    mel = cases.mel_input(case, 172, B, z * case["audio_ratio"])
+    trainable = [k for k, v in sd.items() if v.dtype == torch.float32 and k.startswith("model.") and not k.startswith("model.first_stage_model")]
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(32, threads))
+    try:
+        st = {k: (v.clone().requires_grad_(True) if k in trainable else v) for k, v in sd.items()}
+        xt = st["sqrt_alphas_cumprod"][t][:, None, None] * x0 + st["sqrt_one_minus_alphas_cumprod"][t][:, None, None] * noise
+        pred = nets.unet_forward(st, case["unet"], xt, t, nets.cond_embed(st, ids), nets.wave_encode(st, case["wave"], mel))
+        lt = (F.smooth_l1_loss(noise, pred, beta=0.02, reduction="none") + 0.01).mean(dim=[1, 2]).mean()
+        lt.backward()
+    finally:
+        torch.set_num_threads(threads)
+    dev = gpu_lib.device
+    sdd = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sd.items()}
+    args = [v.to(dev) for v in (x0, noise, t, ids, mel)]
+    loss, grads = train.training_step(gpu_lib, sdd, case["unet"], case["wave"], *args)
+    assert abs(float(loss) - float(lt)) <= 1e-5 * max(1.0, abs(float(lt))), (float(loss), float(lt))
+    gmax = max(float(st[k].grad.abs().max()) for k in trainable if st[k].grad is not None)
+    worst, n_cmp = {}, 0
+    for k in trainable:
+        if st[k].grad is None:
+            continue
+        a, b = grads[k].detach().cpu().reshape(st[k].shape), st[k].grad
+        d, sc = (a - b).abs().max().item(), b.abs().max().item()
+        if sc < 1e-6 * gmax:
+            continue                                     # analytically vanishing gradients (a conv bias in front of a GroupNorm): noise on both sides
+        n_cmp += 1
+        bt = block_type(k)
+        worst[bt] = max(worst.get(bt, (0.0, "")), (d / sc, k))
+        assert d <= 3e-4 * sc, "gradient of %s: max|diff| %.3e (autograd max %.3e)" % (k, d, sc)
+    assert n_cmp > 1200
+    print("z = 512, B = 4: worst element error / max|autograd| per block type over %d tensors:" % n_cmp)
+    for bt, (rel, n) in sorted(worst.items()):
+        print("   %-26s %.2e   %s" % (bt, rel, n))
+    g32 = {k: v.detach().clone() for k, v in grads.items()}
+    gpu_lib.train_set_precision(True)
+    try:
+        loss16, g16 = train.training_step(gpu_lib, sdd, case["unet"], case["wave"], *args)
+    finally:
+        gpu_lib.train_set_precision(False)
+    _report_bf16(float(loss16), float(loss), g16, g32)
+
+
 # ------------------------------------------------------------------------------------------------------------------------------
 # bf16 training GEMMs (k_tgemm.hip; mugd_train_set_precision(1)): BASELINE configs[4]'s precision
 # ------------------------------------------------------------------------------------------------------------------------------
