@@ -5,10 +5,9 @@
 // log1p and fp16 rounding -- and librosa's PRECISION path: the window product and the FFT run in float64 (numpy's rfft of a
 // float64 frame), the spectrum is cast to complex64, and the power is |X|^2 formed in float32 as abs(X)**2.
 //
-//   stft_power : one workgroup = 32 consecutive frames; each frame is a radix-2 DIT FFT in LDS
-//                (n_fft/2 butterflies per stage across the 256 threads, twiddles from an LDS
-//                table); |X|^2 is transposed through an LDS tile so the (bin, frame) output is
-//                written 32 frames (128 B) at a time.
+//   stft_power : one workgroup = 32 consecutive frames as 16 pairs, one complex radix-2 DIT FFT in LDS per PAIR and wave
+//                (two real frames per transform; below); |X|^2 is transposed through an LDS tile so the (bin, frame)
+//                output is written 32 frames (128 B) at a time.
 //   mel matmul : the (n_mels x bins) filterbank is a 1x1 conv_gemm over the power "channels".
 //   log1p+fp16 : elementwise.
 #include <cmath>
@@ -24,53 +23,81 @@ namespace {
 constexpr int FB = 32;          // frames per workgroup
 constexpr int NFFT_MAX = 1024;
 
+// One workgroup = 32 consecutive frames = 16 frame PAIRS, four per wave.  A pair (fa, fb) is ONE complex FFT of z = w xa + i w xb
+// (both real): X_a[k] = (Z[k] + conj Z[N - k]) / 2, X_b[k] = (Z[k] - conj Z[N - k]) / 2i -- half the transforms of a frame-by-frame pass.
+// Each wave owns a complex float64 buffer in LDS and runs its radix-2 DIT stages with wave-local synchronisation only (64 lanes x
+// four butterflies per stage at N = 512, operands of all four in registers before the first store): the four pairs of a workgroup --
+// eight with the two workgroups a CU holds -- are in flight concurrently instead of one frame per CU behind eleven workgroup barriers.
+// Window and twiddles come from one LDS table (cospi / sinpi of 2 i / N, i < N / 2; the Hann window is 0.5 -+ 0.5 cos: the same float64
+// values the per-sample sincospi of the first version produced).  float64 throughout, as librosa's stft; the complex64 cast and the
+// float32 |X|^2 follow it.
+template <int NMAX>
 __global__ __launch_bounds__(256) void stft_power_kernel(const float* pcm, long long n, int n_fft, int log2n, int hop,
                                                          int frames, int kpad, float* P) {
-    __shared__ double re[NFFT_MAX], im[NFFT_MAX];
-    __shared__ double twc[NFFT_MAX / 2], tws[NFFT_MAX / 2];
-    __shared__ float tile[(NFFT_MAX / 2 + 1) * (FB + 1)];
+    __shared__ double2 zb[4][NMAX];                        // per wave: the pair's complex buffer
+    __shared__ double2 tw[NMAX / 2];                       // {cos, -sin}(2 pi i / N)
+    __shared__ float tile[(NMAX / 2 + 1) * (FB + 1)];
     const int tid = threadIdx.x, half = n_fft >> 1, nb = half + 1;
+    const int wave = tid >> 6, lane = tid & 63;
     for (int i = tid; i < half; i += 256) {
-        double s, c;
-        sincospi(2.0 * (double)i / (double)n_fft, &s, &c);
-        twc[i] = c;
-        tws[i] = -s;                       // e^{-2 pi i k / N}
+        double sn, cs;
+        sincospi(2.0 * (double)i / (double)n_fft, &sn, &cs);
+        tw[i] = make_double2(cs, -sn);                     // e^{-2 pi i k / N}
     }
+    __syncthreads();
     const int f0 = blockIdx.x * FB;
-    for (int ff = 0; ff < FB; ++ff) {
-        const int f = f0 + ff;
-        __syncthreads();
-        // windowed, zero-padded (centred) frame, stored bit-reversed
-        for (int i = tid; i < n_fft; i += 256) {
-            const long long src = (long long)f * hop + i - half;
-            double v = 0.0;
-            if (f < frames && src >= 0 && src < n) {
-                double sw, cw;
-                sincospi(2.0 * (double)i / (double)n_fft, &sw, &cw);
-                v = (double)pcm[src] * (0.5 - 0.5 * cw);      // periodic Hann in float64 (scipy get_window) x float32 sample
-            }
-            unsigned r = __builtin_bitreverse32((unsigned)i) >> (32 - log2n);
-            re[r] = v;
-            im[r] = 0.0;
+    double2* z = zb[wave];
+    for (int pp = 0; pp < FB / 8; ++pp) {
+        const int ff = 2 * (wave + 4 * pp);                // this wave's pair: tile columns ff, ff + 1
+        const int fa = f0 + ff, fb = fa + 1;
+        // windowed, zero-padded (centred) frames, stored bit-reversed: re <- frame a, im <- frame b
+        for (int i = lane; i < n_fft; i += 64) {
+            const double c = i < half ? tw[i].x : -tw[i - half].x;
+            const double w = 0.5 - 0.5 * c;                // periodic Hann in float64 (scipy get_window) x float32 sample
+            const long long sa = (long long)fa * hop + i - half, sb = sa + hop;
+            double va = 0.0, vb = 0.0;
+            if (fa < frames && sa >= 0 && sa < n) va = (double)pcm[sa] * w;
+            if (fb < frames && sb >= 0 && sb < n) vb = (double)pcm[sb] * w;
+            const unsigned r = __builtin_bitreverse32((unsigned)i) >> (32 - log2n);
+            z[r] = make_double2(va, vb);
         }
-        __syncthreads();
+        wave_sync();
         for (int s = 1; s <= log2n; ++s) {
-            const int m = 1 << s, mh = m >> 1, tstep = n_fft >> s;
-            for (int j = tid; j < half; j += 256) {
-                const int grp = j / mh, pos = j - grp * mh;
-                const int i0 = grp * m + pos, i1 = i0 + mh;
-                const double wr = twc[pos * tstep], wi = tws[pos * tstep];
-                const double xr = re[i1] * wr - im[i1] * wi, xi = re[i1] * wi + im[i1] * wr;
-                const double ur = re[i0], ui = im[i0];
-                re[i0] = ur + xr; im[i0] = ui + xi;
-                re[i1] = ur - xr; im[i1] = ui - xi;
+            const int mh = 1 << (s - 1), tstep = n_fft >> s;
+            for (int j0 = 0; j0 < half; j0 += 256) {
+                double2 u[4], x[4], w[4];
+                int i0[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int j = j0 + lane + 64 * q;
+                    j = j < half ? j : half - 1;           // N < 512: the surplus slots repeat the last butterfly's loads and store nothing
+                    const int pos = j & (mh - 1);
+                    i0[q] = ((j >> (s - 1)) << s) + pos;
+                    u[q] = z[i0[q]];
+                    x[q] = z[i0[q] + mh];
+                    w[q] = tw[pos * tstep];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (j0 + lane + 64 * q < half) {
+                        const double xr = x[q].x * w[q].x - x[q].y * w[q].y, xi = x[q].x * w[q].y + x[q].y * w[q].x;
+                        z[i0[q]] = make_double2(u[q].x + xr, u[q].y + xi);
+                        z[i0[q] + mh] = make_double2(u[q].x - xr, u[q].y - xi);
+                    }
+                }
             }
-            __syncthreads();
+            wave_sync();
         }
-        for (int k = tid; k < nb; k += 256) {          // complex64 cast, then numpy's abs(complex64) ** 2.0 in float32
-            const float a = hypotf((float)re[k], (float)im[k]);
-            tile[k * (FB + 1) + ff] = a * a;
+        // untangle the two spectra; complex64 cast, then numpy's abs(complex64) ** 2.0 in float32
+        for (int k = lane; k < nb; k += 64) {
+            const double2 a = z[k], c = z[(n_fft - k) & (n_fft - 1)];
+            const float ar = (float)(0.5 * (a.x + c.x)), ai = (float)(0.5 * (a.y - c.y));
+            const float br = (float)(0.5 * (a.y + c.y)), bi = (float)(0.5 * (c.x - a.x));
+            const float ha = hypotf(ar, ai), hb = hypotf(br, bi);
+            tile[k * (FB + 1) + ff] = ha * ha;
+            tile[k * (FB + 1) + ff + 1] = hb * hb;
         }
+        wave_sync();                                       // the buffer is free for the next pair
     }
     __syncthreads();
     for (int i = tid; i < kpad * FB; i += 256) {
@@ -171,7 +198,8 @@ void log_mel(Ctx* ctx, const float* pcm, long long n, int sr, int n_fft, int hop
     }
     float* P = ctx->scratch;
     float* M = P + (((size_t)kpad * frames + 63) / 64) * 64;
-    hipLaunchKernelGGL(stft_power_kernel, dim3(cdiv(frames, FB)), dim3(256), 0, st, pcm, n, n_fft, log2n, hop, frames, kpad, P);
+    if (n_fft <= 512) hipLaunchKernelGGL(stft_power_kernel<512>, dim3(cdiv(frames, FB)), dim3(256), 0, st, pcm, n, n_fft, log2n, hop, frames, kpad, P);
+    else hipLaunchKernelGGL(stft_power_kernel<NFFT_MAX>, dim3(cdiv(frames, FB)), dim3(256), 0, st, pcm, n, n_fft, log2n, hop, frames, kpad, P);
     ConvArgs a{};
     a.nseg = 1;
     a.seg[0] = ConvSeg{P, kpad, frames, 1, 1, 1, 0, 0, 0, 0, 0};

@@ -293,3 +293,18 @@ def test_log_mel(lib, seconds):
     ulp = torch.maximum(ref.abs(), torch.tensor(2.0 ** -14)) * 2.0 ** -10
     assert (err <= ulp * 1.01).all(), float((err / ulp).max())
     assert (err > 0).float().mean().item() < 0.02
+
+
+@pytest.mark.parametrize("n_fft,hop,n_mels", [(64, 16, 16), (256, 64, 64), (1024, 256, 128)])
+def test_log_mel_other_transform_sizes(lib, n_fft, hop, n_mels):
+    """The paired-frame FFT at the other power-of-two sizes the entry point accepts (N < 512: a lane's butterfly slots are
+    partly empty; N = 1024: two slot groups per stage and the wide instantiation); an odd frame count leaves the last pair half empty."""
+    from oracle import host
+    y = host.synth_audio(0.21, seed=5)[:4 * hop * 9]          # 37 frames
+    ref = torch.from_numpy(host.log_mel(y, n_fft=n_fft, hop=hop, n_mels=n_mels).astype(np.float32))
+    got = lib.log_mel(torch.from_numpy(y), n_fft=n_fft, hop=hop, n_mels=n_mels).cpu()
+    assert got.shape == ref.shape == (n_mels, 1 + len(y) // hop)
+    err = (got - ref).abs()
+    ulp = torch.maximum(ref.abs(), torch.tensor(2.0 ** -14)) * 2.0 ** -10
+    assert (err <= ulp * 1.01).all(), float((err / ulp).max())
+    assert (err > 0).float().mean().item() < 0.02
