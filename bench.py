@@ -295,7 +295,7 @@ def main():
                 traffic_source = "profiles/conv_traffic.json (%s): separate rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled " \
                                  "per MI355X_MICROARCH.md; not measured by this run" % tj.get("round", "round 1 tree")
             peak = PEAK_H3_TFLOPS if h3 else PEAK_FP32_MFMA_TFLOPS
-            out["roofline"] = {"kernel": "conv_gemm_kernel / conv_gemm16_kernel (implicit-GEMM conv1d / linear, 32x32 and 32x16 tiles, %s; "
+            out["roofline"] = {"kernel": "conv_gemm_kernel<..., TN = 32 | 16> (implicit-GEMM conv1d / linear, 32x32 and 32x16 tiles of one template, %s; "
                                          "all %d launches of one U-Net evaluation, HIP events around every launch on the library stream, "
                                          "minus the calibrated inter-launch gap)" % ("f16x3-split MFMA" if h3 else "fp32-input MFMA", k["launches"]),
                                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",

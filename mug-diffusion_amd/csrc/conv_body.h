@@ -18,10 +18,69 @@
 
 namespace {
 
-constexpr int RS = CONV_RS;
+constexpr int RS = CONV_RS;                     // LDS row stride (floats) of the 32-wide tiles' windows
 constexpr int WIN_LDS = CONV_CK * RS;           // floats per window
 constexpr int WAVE_LDS = 2 * WIN_LDS;           // two windows per wave: the pipelined loops park chunk c+1 while chunk c is on the matrix pipe
 constexpr int HL = 8;                           // fast path: window column of sample t0 (left halo lives in [HL-pad, HL))
+
+// ---------------------------------------------------------------------------------------
+// Tile geometry.  TN = 32: one 32 x 32 accumulator per wave (v_mfma 32x32: lane (h, n) = column n, rows (r & 3) + 8 (r >> 2) + 4 h of
+// register r).  TN = 16: 32 x 16 output tiles for the layers whose 32-wide tiling gives fewer workgroups than the chip has CUs (the
+// U-Net's deep levels at batch 4: 128 / 192 tiles; a workgroup lives on one CU, so half the chip would idle whatever the K-split) --
+// two 16 x 16 accumulators per wave (rows 0..15, 16..31) that share every B fragment (v_mfma 16x16: lane (kq, l15) = column l15, rows
+// 4 kq + i of register i), twice the weight traffic per flop out of L2.  Only the fast window path with dilation 1 exists at TN = 16
+// (conv16_supported, k_conv.hip).  Everything else of the tile body -- statistics, K-split, ring, epilogues -- is the same code.
+// ---------------------------------------------------------------------------------------
+template <int TN>
+struct ConvGeo {
+    static_assert(TN == 32 || TN == 16, "tile widths: 32 | 16");
+    static constexpr int RS = TN == 32 ? CONV_RS : 48;                 // LDS row stride (floats); 48 mod 32 = 16: conflict-free 16-lane x 4-row reads
+    static constexpr int WIN_LDS = CONV_CK * RS;
+    static constexpr int WAVE_LDS = 2 * WIN_LDS;
+    static constexpr int NREG = TN == 32 ? 16 : 8;                     // accumulator registers (tile rows) per lane
+    __device__ static __forceinline__ int col(int lane) { return TN == 32 ? (lane & 31) : (lane & 15); }
+    __device__ static __forceinline__ int row(int r, int lane) {       // tile row of accumulator register r
+        return TN == 32 ? (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) : 16 * (r >> 2) + 4 * (lane >> 4) + (r & 3);
+    }
+    __device__ static __forceinline__ int frag_row0(int lane) { return TN == 32 ? 4 * (lane >> 5) : (lane >> 4); }      // first window row of the lane's B fragment
+};
+
+// the accumulators of one wave: values, second row set (gate rows | TALL's second row tile), and the 2^11-scaled cross terms of H3
+template <int TN>
+struct ConvAcc;
+template <>
+struct ConvAcc<32> {
+    f32x16 a, a2, l, l2;
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { a[i] = 0.f; a2[i] = 0.f; l[i] = 0.f; l2[i] = 0.f; }
+    }
+    __device__ __forceinline__ void fold_cross(bool two) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { a[r] += l[r] * (1.0f / 2048.0f); if (two) a2[r] += l2[r] * (1.0f / 2048.0f); }
+    }
+    __device__ __forceinline__ float get(int r) const { return a[r]; }
+    __device__ __forceinline__ float get2(int r) const { return a2[r]; }
+};
+template <>
+struct ConvAcc<16> {
+    f32x4 a[2], a2[2], l[2], l2[2];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[0][i] = 0.f; a[1][i] = 0.f; a2[0][i] = 0.f; a2[1][i] = 0.f; l[0][i] = 0.f; l[1][i] = 0.f; l2[0][i] = 0.f; l2[1][i] = 0.f;
+        }
+    }
+    __device__ __forceinline__ void fold_cross(bool two) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[0][i] += l[0][i] * (1.0f / 2048.0f); a[1][i] += l[1][i] * (1.0f / 2048.0f);
+            if (two) { a2[0][i] += l2[0][i] * (1.0f / 2048.0f); a2[1][i] += l2[1][i] * (1.0f / 2048.0f); }
+        }
+    }
+    __device__ __forceinline__ float get(int r) const { return a[r >> 2][r & 3]; }
+    __device__ __forceinline__ float get2(int r) const { return a2[r >> 2][r & 3]; }
+};
 
 // bfloat16 weight fragments (ConvArgs::w16): 8 bytes per lane instead of 16, widened to fp32 with two shifts / masks per pair
 __device__ __forceinline__ float4 widen_bf16x4(const uint2 r) {
@@ -158,6 +217,79 @@ __device__ __forceinline__ void mfma_chunk(const char* smem_bytes, int rb0, int 
 #endif
 }
 
+// The same on 32 x 16 tiles.  Weights are packed per (tap, row half) as [lane = kq * 16 + r][kg] = W[16 half + r][4 kg + kq]: one
+// 16-byte load per lane feeds the 4 channel groups kg of one (tap, half); under H3 those 16 bytes are 4 hi halves (slots kg), then 4
+// scaled lo halves, and a product block is three v_mfma_f32_16x16x16f16 per row half (lane (kq, r) supplies the 4 k-slots <-> channels
+// 4 kg + kq).  B fragment: window row 4 kg + kq, column l15 + tap.  Without H3 (and with bfloat16 weights): v_mfma_f32_16x16x4_f32.
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned cu32x2 __attribute__((ext_vector_type(2)));
+template <int TAPS, bool DUAL, class WT>
+__device__ __forceinline__ void mfma_chunk16(const char* smem_bytes, int rb0, int dil, const float4 (&A)[6], const float4 (&A2)[6], ConvAcc<16>& ac) {
+    constexpr int RSV = ConvGeo<16>::RS;
+    float bf[TAPS * 4];
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) bf[tap * 4 + kg] = *reinterpret_cast<const float*>(smem_bytes + rb0 + (4 * kg * RSV + tap * dil) * 4);
+    if (conv_h3<WT>()) {
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const unsigned d0 = __float_as_uint(bf[tap * 4 + 0]), d1 = __float_as_uint(bf[tap * 4 + 1]);
+            const unsigned d2 = __float_as_uint(bf[tap * 4 + 2]), d3 = __float_as_uint(bf[tap * 4 + 3]);
+            cu32x2 hv, lv;
+            hv[0] = __builtin_amdgcn_perm(d1, d0, 0x05040100u); hv[1] = __builtin_amdgcn_perm(d3, d2, 0x05040100u);
+            lv[0] = __builtin_amdgcn_perm(d1, d0, 0x07060302u); lv[1] = __builtin_amdgcn_perm(d3, d2, 0x07060302u);
+            const h16x4 bh = __builtin_bit_cast(h16x4, hv), bl = __builtin_bit_cast(h16x4, lv);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const float4 av = A[tap * 2 + half];
+                cu32x2 ahv, alv;
+                ahv[0] = __float_as_uint(av.x); ahv[1] = __float_as_uint(av.y); alv[0] = __float_as_uint(av.z); alv[1] = __float_as_uint(av.w);
+                const h16x4 ah = __builtin_bit_cast(h16x4, ahv), al = __builtin_bit_cast(h16x4, alv);
+                ac.a[half] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, ac.a[half], 0, 0, 0);
+                ac.l[half] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, ac.l[half], 0, 0, 0);
+                ac.l[half] = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh, ac.l[half], 0, 0, 0);
+                if (DUAL) {
+                    const float4 gv = A2[tap * 2 + half];
+                    cu32x2 ghv, glv;
+                    ghv[0] = __float_as_uint(gv.x); ghv[1] = __float_as_uint(gv.y); glv[0] = __float_as_uint(gv.z); glv[1] = __float_as_uint(gv.w);
+                    const h16x4 gh = __builtin_bit_cast(h16x4, ghv), gl = __builtin_bit_cast(h16x4, glv);
+                    ac.a2[half] = __builtin_amdgcn_mfma_f32_16x16x16f16(gh, bh, ac.a2[half], 0, 0, 0);
+                    ac.l2[half] = __builtin_amdgcn_mfma_f32_16x16x16f16(gh, bl, ac.l2[half], 0, 0, 0);
+                    ac.l2[half] = __builtin_amdgcn_mfma_f32_16x16x16f16(gl, bh, ac.l2[half], 0, 0, 0);
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {          // the two row halves alternate: independent accumulation chains back to back
+        const float a0[4] = {A[tap * 2].x, A[tap * 2].y, A[tap * 2].z, A[tap * 2].w};
+        const float a1[4] = {A[tap * 2 + 1].x, A[tap * 2 + 1].y, A[tap * 2 + 1].z, A[tap * 2 + 1].w};
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            ac.a[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[kg], bf[tap * 4 + kg], ac.a[0], 0, 0, 0);
+            ac.a[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kg], bf[tap * 4 + kg], ac.a[1], 0, 0, 0);
+        }
+        if (DUAL) {
+            const float g0[4] = {A2[tap * 2].x, A2[tap * 2].y, A2[tap * 2].z, A2[tap * 2].w};
+            const float g1[4] = {A2[tap * 2 + 1].x, A2[tap * 2 + 1].y, A2[tap * 2 + 1].z, A2[tap * 2 + 1].w};
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                ac.a2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(g0[kg], bf[tap * 4 + kg], ac.a2[0], 0, 0, 0);
+                ac.a2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(g1[kg], bf[tap * 4 + kg], ac.a2[1], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// one chunk's products at either tile width
+template <int TN, int TAPS, bool DUAL, class WT>
+__device__ __forceinline__ void conv_mfma(const char* smem_bytes, int rb0, int dil, const float4 (&A)[6], const float4 (&A2)[6], ConvAcc<TN>& ac) {
+    if constexpr (TN == 32) mfma_chunk<TAPS, DUAL, sizeof(WT) == 2>(smem_bytes, rb0, dil, A, A2, ac.a, ac.a2, ac.l, ac.l2);
+    else mfma_chunk16<TAPS, DUAL, WT>(smem_bytes, rb0, dil, A, A2, ac);
+}
+
 // ---------------------------------------------------------------------------------------
 // Fast path: stride 1, no upsample, Tin % 4 == 0 (rows are 16-byte aligned).  NH = halo loads per lane.
 // ---------------------------------------------------------------------------------------
@@ -165,43 +297,53 @@ __device__ __forceinline__ void mfma_chunk(const char* smem_bytes, int rb0, int 
 // is the VALU budget of the kernel -- with the exact-division SiLU it issued as many VALU cycles as the MFMAs take
 // (rocprofv3 PMC: SQ_ACTIVE_INST_VALU ~ SQ_VALU_MFMA_BUSY_CYCLES) -- so the hot instantiations carry no branches
 // and the minimal arithmetic: GroupNorm is one fma per sample, SiLU is v_exp_f32 + v_rcp_f32.
-template <int TAPS, bool DUAL, int NH, int XFK = -1, int ACT = -1, bool PIPE = false, class WT = float, class SEG = ConvSeg>
+template <int TN, int TAPS, bool DUAL, int NH, int XFK = -1, int ACT = -1, bool PIPE = false, class WT = float, class SEG = ConvSeg>
 __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, const WT* wseg2, int lo, int hi,
-                                                int b, int t0, int lane, int h, int n, char* smem_bytes, int wave_base,
-                                                f32x16& acc, f32x16& acc2, f32x16& accL, f32x16& acc2L, const float2* gst, const float2* lnst, float inv_cg, int rot_seed) {
+                                                int b, int t0, int lane, char* smem_bytes, int wave_base,
+                                                ConvAcc<TN>& ac, const float2* gst, const float2* lnst, float inv_cg, int rot_seed) {
+    typedef ConvGeo<TN> G;
+    constexpr int RSV = G::RS;
+    constexpr int XV = TN / 16;                            // aligned float4 per lane and chunk (lane (row = lane / 4, q = lane % 4))
+    constexpr int SPL = 4 * XV;                            // interior samples per lane
+    constexpr int NHA = NH > 0 ? NH : 1;
     const int r = lane >> 2, q = lane & 3;
     const int Tin = s.Tin;
     const int hw = (TAPS - 1) * s.dil;                     // halo samples per row (left pad + right rest)
-    // ---- interior: samples t0 + 8q + {0..3}, {4..7}
-    const int ti0 = t0 + 8 * q, ti1 = ti0 + 4;
-    const bool ok0 = ti0 < Tin, ok1 = ti1 < Tin;           // Tin % 4 == 0: a float4 is wholly inside or outside
-    const unsigned g0 = (unsigned)(r * Tin + (ok0 ? ti0 : Tin - 4)) * 4u;
-    const unsigned g1 = (unsigned)(r * Tin + (ok1 ? ti1 : Tin - 4)) * 4u;
-    const int l0 = wave_base + (r * RS + HL + 8 * q) * 4;
-    // ---- halo: element e = q + 4j of this row: e < pad -> sample t0 - pad + e, else sample t0 + 32 + (e - pad)
-    unsigned gh[NH > 0 ? NH : 1];
-    int lh[NH > 0 ? NH : 1];
-    bool okh[NH > 0 ? NH : 1];
+    // ---- interior: samples t0 + SPL q + {0..3} (, {4..7})
+    const int ti0 = t0 + SPL * q;
+    bool okv[XV];                                          // Tin % 4 == 0: a float4 is wholly inside or outside
+    unsigned gv[XV];
+#pragma unroll
+    for (int x = 0; x < XV; ++x) {
+        const int ti = ti0 + 4 * x;
+        okv[x] = ti < Tin;
+        gv[x] = (unsigned)(r * Tin + (okv[x] ? ti : Tin - 4)) * 4u;
+    }
+    const int l0 = wave_base + (r * RSV + HL + SPL * q) * 4;
+    // ---- halo: element e = q + 4j of this row: e < pad -> sample t0 - pad + e, else sample t0 + TN + (e - pad)
+    unsigned gh[NHA];
+    int lh[NHA];
+    bool okh[NHA];
 #pragma unroll
     for (int j = 0; j < NH; ++j) {
         const int e = q + 4 * j;
-        const int col = e < s.pad ? e - s.pad : 32 + (e - s.pad);      // relative to t0
+        const int col = e < s.pad ? e - s.pad : TN + (e - s.pad);      // relative to t0
         const int t = t0 + col;
         okh[j] = (e < hw) && (t >= 0) && (t < Tin);
         int tc = t < 0 ? 0 : t;
         tc = tc < Tin ? tc : Tin - 1;
         gh[j] = (unsigned)(r * Tin + tc) * 4u;
-        lh[j] = wave_base + (r * RS + (e < hw ? HL + col : 60 + q)) * 4;      // dead lanes park in columns no tap reads
+        lh[j] = wave_base + (r * RSV + (e < hw ? HL + col : RSV - 8 + q)) * 4;      // dead lanes park in columns no tap reads
     }
     // ---- operand transform constants
     const int xf = XFK >= 0 ? XFK : (s.xf == 3 ? 2 : s.xf == 4 ? 1 : s.xf), act = ACT >= 0 ? ACT : s.act;
     const bool gn4 = s.xf == 4;                              // GroupNorm {g, b} from the wave's group table instead of a stats kernel's array
-    float mu[8], rs8[8];
-    float muh[NH > 0 ? NH : 1], rsh[NH > 0 ? NH : 1];
+    float mu[SPL], rsd[SPL];
+    float muh[NHA], rsh[NHA];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { mu[i] = 0.f; rs8[i] = 1.f; }
+    for (int i = 0; i < SPL; ++i) { mu[i] = 0.f; rsd[i] = 1.f; }
 #pragma unroll
-    for (int j = 0; j < NH; ++j) { muh[j] = 0.f; rsh[j] = 1.f; }
+    for (int j = 0; j < NHA; ++j) { muh[j] = 0.f; rsh[j] = 1.f; }
     const float* gb = nullptr;                            // per-channel {g, b} stream, advanced by 32 floats per chunk
     if (xf == 1) {
         if (!gn4) gb = s.xf_a + (size_t)b * s.xf_stride + 2 * ((size_t)lo * CONV_CK + r);
@@ -212,10 +354,10 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
         } else {
             const float* cs = s.xf_a + (size_t)b * s.xf_stride;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < SPL; ++i) {
                 int t = ti0 + i;
                 t = t < Tin ? t : Tin - 1;
-                mu[i] = cs[2 * t]; rs8[i] = cs[2 * t + 1];
+                mu[i] = cs[2 * t]; rsd[i] = cs[2 * t + 1];
             }
 #pragma unroll
             for (int j = 0; j < NH; ++j) { muh[j] = cs[gh[j] / 4u % (unsigned)Tin * 2]; rsh[j] = cs[gh[j] / 4u % (unsigned)Tin * 2 + 1]; }
@@ -226,7 +368,7 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
     auto finish_ln = [&]() {
         if (s.xf != 3) return;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const float2 st = lnst[8 * q + i]; mu[i] = st.x; rs8[i] = st.y; }
+        for (int i = 0; i < SPL; ++i) { const float2 st = lnst[SPL * q + i]; mu[i] = st.x; rsd[i] = st.y; }
     };
 
     const int bb = s.bmod > 0 ? b % s.bmod : b;
@@ -234,11 +376,11 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
     const size_t xstep = (size_t)CONV_CK * Tin * 4;
     const WT* wp = wseg + (size_t)lo * (TAPS * 512);
     const WT* wp2 = wseg2 + (size_t)lo * (TAPS * 512);
-    const int rb0 = wave_base + (4 * h * RS + HL - s.pad + n) * 4;      // this lane's B-fragment read base (bytes)
+    const int rb0 = wave_base + (G::frag_row0(lane) * RSV + HL - s.pad + G::col(lane)) * 4;      // this lane's B-fragment read base (bytes)
 
     float4 Aa[6], Aa2[6], Ab[6], Ab2[6];       // ping-pong weight fragments: no register copies in the loop
-    float4 x0, x1;
-    float xh[NH > 0 ? NH : 1];
+    float4 xv[XV];
+    float xh[NHA];
     float2 gbv = make_float2(1.f, 0.f);
 
     int gbg = 0;                                    // gn4: GroupNorm group of the channel gbv belongs to
@@ -251,48 +393,49 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
         return *reinterpret_cast<const float2*>(gb + (size_t)cr * (2 * CONV_CK));
     };
     auto load_gb = [&](int cr) -> float2 { return load_gb2(cr, gbg); };
-    auto finish_stats = [&]() {};           // the workgroup's statistics tables were completed before the K loop (conv_stats.h)
     // transform the staged samples and park them in window `wofs` (byte offset 0 | WIN_LDS*4)
-    auto park_v = [&](int wofs, const float4& xa, const float4& xb4, const float (&xhh)[NH > 0 ? NH : 1], const float2 gbq, const int ggq) {
-        float v[8];
-        float vh[NH > 0 ? NH : 1];
-        v[0] = xa.x; v[1] = xa.y; v[2] = xa.z; v[3] = xa.w; v[4] = xb4.x; v[5] = xb4.y; v[6] = xb4.z; v[7] = xb4.w;
+    auto park_v = [&](int wofs, const float4 (&xq)[XV], const float (&xhh)[NHA], const float2 gbq, const int ggq) {
+        float v[SPL];
+        float vh[NHA];
+#pragma unroll
+        for (int x = 0; x < XV; ++x) { v[4 * x] = xq[x].x; v[4 * x + 1] = xq[x].y; v[4 * x + 2] = xq[x].z; v[4 * x + 3] = xq[x].w; }
 #pragma unroll
         for (int j = 0; j < NH; ++j) vh[j] = xhh[j];
         if (xf) {
             float g = gbq.x, bt = gbq.y;
             if (gn4) { const float2 st = gst[ggq]; g = gbq.x * st.y; bt = gbq.y - st.x * g; }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = (xf == 1) ? v[i] * g + bt : (v[i] - mu[i]) * rs8[i] * g + bt;
+            for (int i = 0; i < SPL; ++i) v[i] = (xf == 1) ? v[i] * g + bt : (v[i] - mu[i]) * rsd[i] * g + bt;
 #pragma unroll
             for (int j = 0; j < NH; ++j) vh[j] = (xf == 1) ? vh[j] * g + bt : (vh[j] - muh[j]) * rsh[j] * g + bt;
             if (act == 1) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = silu_f(v[i]);
+                for (int i = 0; i < SPL; ++i) v[i] = silu_f(v[i]);
 #pragma unroll
                 for (int j = 0; j < NH; ++j) vh[j] = silu_f(vh[j]);
             } else if (act == 2) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = silu_fast(v[i]);
+                for (int i = 0; i < SPL; ++i) v[i] = silu_fast(v[i]);
 #pragma unroll
                 for (int j = 0; j < NH; ++j) vh[j] = silu_fast(vh[j]);
             }
         }
         if (conv_h3<WT>()) {                            // H3: the window holds the {hi | lo} f16 halves of every sample (0.f is {0 | 0})
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = h3_split(v[i]);
+            for (int i = 0; i < SPL; ++i) v[i] = h3_split(v[i]);
 #pragma unroll
             for (int j = 0; j < NH; ++j) vh[j] = h3_split(vh[j]);
         }
-        float4 w0, w1;                                  // zero padding AFTER the transform (component selects: no scratch)
-        w0.x = ok0 ? v[0] : 0.f; w0.y = ok0 ? v[1] : 0.f; w0.z = ok0 ? v[2] : 0.f; w0.w = ok0 ? v[3] : 0.f;
-        w1.x = ok1 ? v[4] : 0.f; w1.y = ok1 ? v[5] : 0.f; w1.z = ok1 ? v[6] : 0.f; w1.w = ok1 ? v[7] : 0.f;
-        *reinterpret_cast<float4*>(smem_bytes + wofs + l0) = w0;
-        *reinterpret_cast<float4*>(smem_bytes + wofs + l0 + 16) = w1;
+#pragma unroll
+        for (int x = 0; x < XV; ++x) {                  // zero padding AFTER the transform (component selects: no scratch)
+            float4 w;
+            w.x = okv[x] ? v[4 * x] : 0.f; w.y = okv[x] ? v[4 * x + 1] : 0.f; w.z = okv[x] ? v[4 * x + 2] : 0.f; w.w = okv[x] ? v[4 * x + 3] : 0.f;
+            *reinterpret_cast<float4*>(smem_bytes + wofs + l0 + 16 * x) = w;
+        }
 #pragma unroll
         for (int j = 0; j < NH; ++j) *reinterpret_cast<float*>(smem_bytes + wofs + lh[j]) = okh[j] ? vh[j] : 0.f;
     };
-    auto park = [&](int wofs) { park_v(wofs, x0, x1, xh, gbv, gbg); };
+    auto park = [&](int wofs) { park_v(wofs, xv, xh, gbv, gbg); };
 
     if (PIPE) {
         // ---- software-pipelined loop over a register RING of D chunks.  Chunk k's weights and raw window live in ring stage
@@ -305,12 +448,16 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
         constexpr int D = (TAPS == 1 && !DUAL) ? 4 : 2;
         const int nch = hi - lo;
         float4 RA[D][6], RA2[D][6];
-        float4 RX0[D], RX1[D];
-        float RXH[D][NH > 0 ? NH : 1];
+        float4 RX[D][XV];
+        float RXH[D][NHA];
         float2 RGB[D];
         int RGG[D];
 #pragma unroll
-        for (int d = 0; d < D; ++d) { RGB[d] = make_float2(1.f, 0.f); RGG[d] = 0; }
+        for (int d = 0; d < D; ++d) {
+            RGB[d] = make_float2(1.f, 0.f); RGG[d] = 0;
+#pragma unroll
+            for (int j = 0; j < NHA; ++j) RXH[d][j] = 0.f;
+        }
         // Workgroups that share a weight row tile (the column tiles of one XCD slab) walk a LONG K-slice from different starting
         // chunks, wrapping around: a weight line is then first touched by one workgroup and found in L2 by the others later,
         // instead of 16 requests piling up on one pending miss (tests/gpu_l2bw.hip: 22-28 -> 33-34 B/clk/CU on a cold K = 4608
@@ -320,8 +467,8 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
             int cr = cr0 + rot;
             cr = cr >= nch ? cr - nch : cr;
             const char* xq = xb + (size_t)cr * xstep;
-            RX0[d] = *reinterpret_cast<const float4*>(xq + g0);
-            RX1[d] = *reinterpret_cast<const float4*>(xq + g1);
+#pragma unroll
+            for (int x = 0; x < XV; ++x) RX[d][x] = *reinterpret_cast<const float4*>(xq + gv[x]);
 #pragma unroll
             for (int j = 0; j < NH; ++j) RXH[d][j] = *reinterpret_cast<const float*>(xq + gh[j]);
             if (xf) RGB[d] = load_gb2(cr, RGG[d]);
@@ -331,12 +478,12 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
             cr = cr >= nch ? cr - nch : cr;
             load_a<TAPS, DUAL>(wp + (size_t)cr * (TAPS * 512), wp2 + (size_t)cr * (TAPS * 512), RA[d], RA2[d]);
         };
-        constexpr int W1 = WIN_LDS * 4;
+        constexpr int W1 = G::WIN_LDS * 4;
 #pragma unroll
         for (int d = 0; d < D; ++d)                     // requested chunk by chunk (window first): the memory system serves a cold
             if (d < nch) { fetch_x(d, d); fetch_a(d, d); }      // burst roughly in order, so chunk 0 is complete after 1/D of it
         finish_ln();
-        park_v(0, RX0[0], RX1[0], RXH[0], RGB[0], RGG[0]);
+        park_v(0, RX[0], RXH[0], RGB[0], RGG[0]);
         if (D < nch) fetch_x(D, 0);
         wave_sync();
         TL_STAMP_ONCE(2);
@@ -346,9 +493,9 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
                 const int cc = c + d;
                 if (cc < nch) {
                     const int dn = (d + 1) % D;
-                    mfma_chunk<TAPS, DUAL, sizeof(WT) == 2>(smem_bytes + (d & 1) * W1, rb0, s.dil, RA[d], RA2[d], acc, acc2, accL, acc2L);
+                    conv_mfma<TN, TAPS, DUAL, WT>(smem_bytes + (d & 1) * W1, rb0, s.dil, RA[d], RA2[d], ac);
                     if (cc + 1 < nch) {
-                        park_v(((d + 1) & 1) * W1, RX0[dn], RX1[dn], RXH[dn], RGB[dn], RGG[dn]);
+                        park_v(((d + 1) & 1) * W1, RX[dn], RXH[dn], RGB[dn], RGG[dn]);
                         if (cc + 1 + D < nch) fetch_x(cc + 1 + D, dn);
                     }
                     if (cc + D < nch) fetch_a(cc + D, d);
@@ -359,14 +506,15 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
         return;
     }
 
-    x0 = *reinterpret_cast<const float4*>(xb + g0);
-    x1 = *reinterpret_cast<const float4*>(xb + g1);
+#pragma unroll
+    for (int x = 0; x < XV; ++x) xv[x] = *reinterpret_cast<const float4*>(xb + gv[x]);
+#pragma unroll
+    for (int j = 0; j < NHA; ++j) xh[j] = 0.f;
 #pragma unroll
     for (int j = 0; j < NH; ++j) xh[j] = *reinterpret_cast<const float*>(xb + gh[j]);
     load_a<TAPS, DUAL>(wp, wp2, Aa, Aa2);
     int crel = 0;
     if (xf) gbv = load_gb(0);
-    finish_stats();
     finish_ln();
 
     auto step = [&](const float4 (&A)[6], const float4 (&A2)[6], float4 (&An)[6], float4 (&An2)[6], bool more) {
@@ -377,14 +525,14 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
             wp2 += TAPS * 512;
             xb += xstep;
             load_a<TAPS, DUAL>(wp, wp2, An, An2);
-            x0 = *reinterpret_cast<const float4*>(xb + g0);
-            x1 = *reinterpret_cast<const float4*>(xb + g1);
+#pragma unroll
+            for (int x = 0; x < XV; ++x) xv[x] = *reinterpret_cast<const float4*>(xb + gv[x]);
 #pragma unroll
             for (int j = 0; j < NH; ++j) xh[j] = *reinterpret_cast<const float*>(xb + gh[j]);
             ++crel;
             if (xf) gbv = load_gb(crel);
         }
-        mfma_chunk<TAPS, DUAL, sizeof(WT) == 2>(smem_bytes, rb0, s.dil, A, A2, acc, acc2, accL, acc2L);
+        conv_mfma<TN, TAPS, DUAL, WT>(smem_bytes, rb0, s.dil, A, A2, ac);
         wave_sync();               // all lanes done reading the window before it is overwritten
     };
 
@@ -504,20 +652,20 @@ __device__ __forceinline__ void run_segment_gen(const SEG& s, const float* wseg,
 // ---------------------------------------------------------------------------------------
 // LDS block of one (virtual) workgroup: [staging windows: WK waves x 2][K-split exchange (x 2 gated)][pad][statistics tables][epilogue scratch]
 // ---------------------------------------------------------------------------------------
-template <int WK, bool DUAL>
+template <int WK, bool DUAL, int TN = CONV_TN>
 struct ConvLds {
-    static constexpr int RED = WK > 1 ? WK * 16 * 64 : 0;                  // floats for one partial-tile exchange
-    static constexpr int WIN = WK * WAVE_LDS;
+    static constexpr int RED = WK > 1 ? WK * ConvGeo<TN>::NREG * 64 : 0;   // floats for one partial-tile exchange
+    static constexpr int WIN = WK * ConvGeo<TN>::WAVE_LDS;
     static constexpr int EX_OFF = WIN * 4;                                  // byte offsets
     static constexpr int STAT_OFF = EX_OFF + ((DUAL ? 2 * RED : RED) + 4) * 4;
-    static constexpr int STAT_BYTES = (int)sizeof(typename WgStats<WK, CONV_TN>::Lds);
+    static constexpr int STAT_BYTES = (int)sizeof(typename WgStats<WK, TN>::Lds);
     static constexpr int EPI_OFF = STAT_OFF + STAT_BYTES;
-    static constexpr int EPI_BYTES = 32 * (CONV_TN + 1) * 4;               // xs[32][TN + 1] of EPI_XSOFTMAX; cst[2][WK][32] fits inside
+    static constexpr int EPI_BYTES = 32 * (TN + 1) * 4;                    // xs[32][TN + 1] of EPI_XSOFTMAX; cst[2][WK][TN] fits inside
     static constexpr int BYTES = (EPI_OFF + EPI_BYTES + 15) / 16 * 16;
-    static_assert(2 * WK * 32 * 4 <= EPI_BYTES, "column-sum scratch must fit the epilogue block");
+    static_assert(2 * WK * TN * 4 <= EPI_BYTES, "column-sum scratch must fit the epilogue block");
 };
-template <int WK, bool DUAL>
-constexpr int conv_lds_bytes() { return ConvLds<WK, DUAL>::BYTES; }
+template <int WK, bool DUAL, int TN = CONV_TN>
+constexpr int conv_lds_bytes() { return ConvLds<WK, DUAL, TN>::BYTES; }
 
 // KIND 0: every segment takes the fast window path with dilation 1 (the whole U-Net except its 6 resampling convs):
 //         chunk loops specialised on the operand transform and software-pipelined.
@@ -528,22 +676,27 @@ constexpr int conv_lds_bytes() { return ConvLds<WK, DUAL>::BYTES; }
 //       second row tile instead of the gate rows, so every staged window element and every B fragment read from LDS feeds two MFMAs
 //       (weights: each wave streams both row tiles' fragments).  For launches with enough tiles to fill the chip at half the count
 //       (launch_conv_gemm); mt must be even, a missing last row tile (odd tile count) is computed on clamped weights and not stored.
-template <int WK, bool DUAL, int KIND, int NITG, class WT, bool TALL = false, class A = ConvArgs>
+// TN: 32 | 16 output samples per tile (ConvGeo); the 16-wide tiles exist for KIND 0 without TALL.
+template <int WK, bool DUAL, int KIND, int NITG, class WT, bool TALL = false, class A = ConvArgs, int TN = CONV_TN>
 __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b, const int t0, const int rot, const int tid, char* lds, const bool live) {
     static_assert(!(DUAL && TALL), "gated layers already share their windows between two row sets");
+    static_assert(TN == 32 || (KIND == 0 && !TALL), "16-wide tiles: plain fast-window kernels only");
     constexpr bool A2 = DUAL || TALL;               // two weight streams / two accumulators per wave
-    typedef ConvLds<WK, A2> L;
+    typedef ConvGeo<TN> G;
+    typedef ConvLds<WK, A2, TN> L;
     constexpr int RED = L::RED;
     constexpr int WIN = L::WIN;
+    constexpr int NREG = G::NREG;
     // staging windows, then the partial-tile exchange in a region of its own: a wave that has finished its K-slice parks its
     // accumulators without waiting for the slower waves to leave their windows (ONE barrier per combine instead of two)
     float* smem = reinterpret_cast<float*>(lds);
-    typedef WgStats<WK, CONV_TN> Stats;
+    typedef WgStats<WK, TN> Stats;
     typename Stats::Lds& stl = *reinterpret_cast<typename Stats::Lds*>(lds + L::STAT_OFF);
 
     const int gy = (a.Mout + 31) >> 5;             // 32-row tiles of the output (the launch grid counts PAIRS of them under TALL)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63, h = lane >> 5, n = lane & 31;
+    const int lane = tid & 63, h = lane >> 5, n = lane & 31;      // (h, n): the 32-wide fragment coordinates (generic windows)
+    const int cl = G::col(lane);                                  // this lane's tile column
 
     // ---- GroupNorm / LayerNorm statistics of the normalised inputs: partial sums requested NOW, reduced once per workgroup
     // after the first chunk's loads are out (conv_stats.h)
@@ -557,21 +710,20 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
     for (int w = 1; w < WK; ++w)
         if (wave == w) { g0 = a.kb[w]; g1 = a.kb[w + 1]; }
 
-    f32x16 acc, acc2, accL, acc2L;               // accL / acc2L: the 2^11-scaled cross terms of the H3 arithmetic (unused otherwise)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; accL[i] = 0.f; acc2L[i] = 0.f; }
+    ConvAcc<TN> ac;                              // values, second row set, and the 2^11-scaled cross terms of the H3 arithmetic
+    ac.zero();
 
     const WT* wtile = reinterpret_cast<const WT*>(a.wpk) + (size_t)b * a.w_b_stride + (size_t)mt * a.w_mt_stride + lane * 4;
     const bool has2 = !TALL || mt + 1 < gy;        // TALL: the second row tile exists
     const WT* wtile2 = DUAL ? wtile + (size_t)(a.Mout >> 5) * a.w_mt_stride : (TALL && has2) ? wtile + a.w_mt_stride : wtile;
     char* smem_bytes = lds;
-    const int wave_base = wave * WAVE_LDS * 4;
+    const int wave_base = wave * G::WAVE_LDS * 4;
 
     const float gn_inv_cg = a.gn_groups ? 1.0f / (float)a.gn_cg : 0.f;
 
     // ---- epilogue operands: the side loads (bias / row term / residual) are issued HERE, before the K loop, from
     // clamped addresses under wave-uniform conditions, so their latency is off the kernel's critical path.
-    constexpr int EPT = 16 / WK;         // tile rows (accumulator registers) finished by each wave
+    constexpr int EPT = NREG / WK;       // tile rows (accumulator registers) finished by each wave
     float bv[EPT], bg[EPT], ra[EPT], rsv[EPT];
     size_t oo[EPT];
     int mm[EPT];
@@ -585,8 +737,8 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
         const int r = wave * EPT + q;
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int m = mt * 32 + row, t = t0 + n;
+        const int row = G::row(r, lane);
+        const int m = mt * 32 + row, t = t0 + cl;
         valid[q] = live && (m < a.Mout) && (t < a.Tout);
         mm[q] = m < a.Mout ? m : a.Mout - 1;
         oo[q] = ((size_t)b * a.Mout + mm[q]) * a.Tout + (t < a.Tout ? t : a.Tout - 1);
@@ -634,54 +786,49 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
             if (lo < hi) {
                 const WT* w1 = wtile + s.woff;
                 const WT* w2 = wtile2 + s.woff;
-#define MUGD_SEG_ARGS s, w1, w2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, acc, acc2, accL, acc2L
-#define MUGD_SEG_VARGS MUGD_SEG_ARGS, stl.gnst, stl.lnst, gn_inv_cg, rot
-                if (KIND == 0) {
+#define MUGD_SEG_VARGS s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, ac, stl.gnst, stl.lnst, gn_inv_cg, rot
+                if constexpr (KIND == 0) {
                     // specialise on (transform, activation): branch-free chunk loops
 #define MUGD_SEG_XF(T, NHALO)                                                                     \
     switch (s.xf * 4 + s.act) {                                                                   \
-        case 0: run_segment_vec<T, A2, NHALO, 0, 0, MUGD_PIPE>(MUGD_SEG_VARGS); break;                      \
-        case 4: case 16: run_segment_vec<T, A2, NHALO, 1, 0, MUGD_PIPE>(MUGD_SEG_VARGS); break;            \
-        case 5: case 17: run_segment_vec<T, A2, NHALO, 1, 1, MUGD_PIPE>(MUGD_SEG_VARGS); break;            \
-        case 6: case 18: run_segment_vec<T, A2, NHALO, 1, 2, MUGD_PIPE>(MUGD_SEG_VARGS); break;            \
-        case 8: case 12: run_segment_vec<T, A2, NHALO, 2, 0, MUGD_PIPE>(MUGD_SEG_VARGS); break;            \
-        default: run_segment_vec<T, A2, NHALO>(MUGD_SEG_VARGS);                                  \
+        case 0: run_segment_vec<TN, T, A2, NHALO, 0, 0, MUGD_PIPE>(MUGD_SEG_VARGS); break;                      \
+        case 4: case 16: run_segment_vec<TN, T, A2, NHALO, 1, 0, MUGD_PIPE>(MUGD_SEG_VARGS); break;            \
+        case 5: case 17: run_segment_vec<TN, T, A2, NHALO, 1, 1, MUGD_PIPE>(MUGD_SEG_VARGS); break;            \
+        case 6: case 18: run_segment_vec<TN, T, A2, NHALO, 1, 2, MUGD_PIPE>(MUGD_SEG_VARGS); break;            \
+        case 8: case 12: run_segment_vec<TN, T, A2, NHALO, 2, 0, MUGD_PIPE>(MUGD_SEG_VARGS); break;            \
+        default: run_segment_vec<TN, T, A2, NHALO>(MUGD_SEG_VARGS);                                  \
     }
                     if (DUAL || s.taps == 1) { MUGD_SEG_XF(1, 0) }
                     else { MUGD_SEG_XF(3, 1) }
 #undef MUGD_SEG_XF
-                } else if (KIND == 1) {
-                    if (s.taps == 1) run_segment_vec<1, A2, 0>(MUGD_SEG_VARGS);
-                    else if (s.dil <= 2) run_segment_vec<3, A2, 1>(MUGD_SEG_VARGS);
-                    else if (s.dil == 4) run_segment_vec<3, A2, 2>(MUGD_SEG_VARGS);
-                    else run_segment_vec<3, A2, 4>(MUGD_SEG_VARGS);
+                } else if constexpr (KIND == 1) {
+                    if (s.taps == 1) run_segment_vec<TN, 1, A2, 0>(MUGD_SEG_VARGS);
+                    else if (s.dil <= 2) run_segment_vec<TN, 3, A2, 1>(MUGD_SEG_VARGS);
+                    else if (s.dil == 4) run_segment_vec<TN, 3, A2, 2>(MUGD_SEG_VARGS);
+                    else run_segment_vec<TN, 3, A2, 4>(MUGD_SEG_VARGS);
                 } else {
-                    if (sizeof(WT) == 4) {          // the generic windows exist with fp32 weights only
+                    if constexpr (sizeof(WT) == 4 && TN == 32) {          // the generic windows exist with fp32 weights and 32-wide tiles only
                         const float* f1 = reinterpret_cast<const float*>(w1);
                         const float* f2 = reinterpret_cast<const float*>(w2);
-                        if (s.taps == 3) run_segment_gen<3, A2, NITG, (NITG <= 9)>(s, f1, f2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, acc, acc2, accL, acc2L);
-                        else run_segment_gen<1, A2, NITG, (NITG <= 9)>(s, f1, f2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, acc, acc2, accL, acc2L);
+                        if (s.taps == 3) run_segment_gen<3, A2, NITG, (NITG <= 9)>(s, f1, f2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, ac.a, ac.a2, ac.l, ac.l2);
+                        else run_segment_gen<1, A2, NITG, (NITG <= 9)>(s, f1, f2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, ac.a, ac.a2, ac.l, ac.l2);
                     }
                 }
 #undef MUGD_SEG_VARGS
-#undef MUGD_SEG_ARGS
             }
         }
     }
 
-    if (conv_h3<WT>()) {                            // H3: fold the scaled cross terms in
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[r] += accL[r] * (1.0f / 2048.0f); if (A2) acc2[r] += acc2L[r] * (1.0f / 2048.0f); }
-    }
+    if (conv_h3<WT>()) ac.fold_cross(A2);           // H3: fold the scaled cross terms in
     // ---- combine the WK K-slices through LDS (exchange region behind the staging windows)
     TL_STAMP(3);
     float acc_v[EPT], acc_g[EPT];
     if (WK > 1) {
         float* ex = smem + WIN;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            ex[(wave * 16 + r) * 64 + lane] = acc[r];
-            if (A2) ex[RED + (wave * 16 + r) * 64 + lane] = acc2[r];
+        for (int r = 0; r < NREG; ++r) {
+            ex[(wave * NREG + r) * 64 + lane] = ac.get(r);
+            if (A2) ex[RED + (wave * NREG + r) * 64 + lane] = ac.get2(r);
         }
         __syncthreads();
 #pragma unroll
@@ -691,24 +838,24 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
             acc_g[q] = 0.f;
 #pragma unroll
             for (int w = 0; w < WK; ++w) {
-                acc_v[q] += ex[(w * 16 + r) * 64 + lane];
-                if (A2) acc_g[q] += ex[RED + (w * 16 + r) * 64 + lane];
+                acc_v[q] += ex[(w * NREG + r) * 64 + lane];
+                if (A2) acc_g[q] += ex[RED + (w * NREG + r) * 64 + lane];
             }
         }
     } else {
 #pragma unroll
-        for (int q = 0; q < EPT; ++q) { acc_v[q] = acc[q]; acc_g[q] = acc2[q]; }
+        for (int q = 0; q < EPT; ++q) { acc_v[q] = ac.get(q); acc_g[q] = ac.get2(q); }
     }
     TL_STAMP(4);
     if (!A2 && a.epi == EPI_XSOFTMAX) {          // folded cross-attention: the tile is one head's key scores (conv_stats.h)
-        float* xs = reinterpret_cast<float*>(lds + L::EPI_OFF);      // [32][CONV_TN + 1]
+        float* xs = reinterpret_cast<float*>(lds + L::EPI_OFF);      // [32][TN + 1]
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
             const int r = wave * EPT + q;
-            xs[((r & 3) + 8 * (r >> 2) + 4 * h) * (CONV_TN + 1) + n] = acc_v[q];
+            xs[G::row(r, lane) * (TN + 1) + cl] = acc_v[q];
         }
         __syncthreads();
-        xsoftmax_epilogue<WK, CONV_TN>(a, xs, mt, b, t0, tid, live);
+        xsoftmax_epilogue<WK, TN>(a, xs, mt, b, t0, tid, live);
         TL_STAMP(5);
         TL_STAMP(6);
         return;
@@ -738,10 +885,10 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
             float s1 = valid[q] ? acc_v[q] : 0.f;
             float s2 = s1 * s1;
 #pragma unroll
-            for (int o = 1; o < 32; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+            for (int o = 1; o < TN; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
             const int r = wave * EPT + q;
-            const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (live && n == 0 && m < a.Mout) {
+            const int m = mt * 32 + G::row(r, lane);
+            if (live && cl == 0 && m < a.Mout) {
                 double* o = a.rowstat + 2 * ((size_t)b * a.Mout + m);
                 atomicAdd(o, (double)s1);
                 atomicAdd(o + 1, (double)s2);
@@ -751,7 +898,7 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
                 float u2 = u1 * u1;
 #pragma unroll
                 for (int o = 1; o < 32; o <<= 1) { u1 += __shfl_xor(u1, o); u2 += __shfl_xor(u2, o); }
-                if (live && has2 && n == 0 && m + 32 < a.Mout) {
+                if (live && has2 && cl == 0 && m + 32 < a.Mout) {
                     double* o = a.rowstat + 2 * ((size_t)b * a.Mout + m + 32);
                     atomicAdd(o, (double)u1);
                     atomicAdd(o + 1, (double)u2);
@@ -761,20 +908,20 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
     }
     // ---- optional: {sum, sum of squares} of this tile's final values per column, for the LayerNorm of the consumer
     if (!DUAL && a.colstat) {
-        float (*cst)[WK][32] = reinterpret_cast<float (*)[WK][32]>(lds + L::EPI_OFF);      // [2][WK][32]
+        float (*cst)[WK][TN] = reinterpret_cast<float (*)[WK][TN]>(lds + L::EPI_OFF);      // [2][WK][TN]
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
             const int r = wave * EPT + q;
-            const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int m = mt * 32 + G::row(r, lane);
             const float v = m < a.Mout ? acc_v[q] : 0.f;
             s1 += v; s2 += v * v;
         }
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
-        if (h == 0) { cst[0][wave][n] = s1; cst[1][wave][n] = s2; }
+#pragma unroll
+        for (int o = TN; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }      // the lanes that hold the same column
+        if (lane < TN) { cst[0][wave][cl] = s1; cst[1][wave][cl] = s2; }
         __syncthreads();
-        if (live && tid < 32 && t0 + tid < a.Tout) {
+        if (live && tid < TN && t0 + tid < a.Tout) {
             float t1 = 0.f, t2 = 0.f;
 #pragma unroll
             for (int w = 0; w < WK; ++w) { t1 += cst[0][w][tid]; t2 += cst[1][w][tid]; }
@@ -787,15 +934,15 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
 #pragma unroll
             for (int q = 0; q < EPT; ++q) {
                 const int r = wave * EPT + q;
-                const int m = mt * 32 + 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int m = mt * 32 + 32 + G::row(r, lane);
                 const float v = m < a.Mout ? acc_g[q] : 0.f;
                 u1 += v; u2 += v * v;
             }
             u1 += __shfl_xor(u1, 32);
             u2 += __shfl_xor(u2, 32);
-            if (h == 0) { cst[0][wave][n] = u1; cst[1][wave][n] = u2; }
+            if (lane < TN) { cst[0][wave][cl] = u1; cst[1][wave][cl] = u2; }
             __syncthreads();
-            if (live && has2 && tid < 32 && t0 + tid < a.Tout) {
+            if (live && has2 && tid < TN && t0 + tid < a.Tout) {
                 float t1 = 0.f, t2 = 0.f;
 #pragma unroll
                 for (int w = 0; w < WK; ++w) { t1 += cst[0][w][tid]; t2 += cst[1][w][tid]; }

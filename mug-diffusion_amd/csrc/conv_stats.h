@@ -1,4 +1,4 @@
-// GroupNorm / LayerNorm statistics inside a conv_gemm workgroup (ConvSeg::xf == 4 / 3), shared by k_conv.hip and k_conv16.hip.
+// GroupNorm / LayerNorm statistics inside a conv_gemm workgroup (ConvSeg::xf == 4 / 3), for either tile width (TN = 32 | 16).
 //
 // The producers of a normalised tensor left partial sums behind (fp64 {sum, sum of squares} per row: ConvArgs::rowstat;
 // fp32 {sum, sum of squares} per 32-row tile and column: ConvArgs::colstat).  The consuming workgroup turns them into

@@ -30,6 +30,9 @@
 //
 // Workgroups are renumbered so that each XCD (private L2) owns a contiguous range of row tiles,
 // i.e. of the weight stream.
+//
+// The same kernel template exists with 32 x 16 tiles (TN = 16: conv_body.h, ConvGeo) for the layers whose 32-wide tiling
+// leaves CUs without a workgroup; conv_pick_tn() below decides per launch, the weights are packed per tile width.
 #include <algorithm>
 #include <cstdlib>
 
@@ -38,9 +41,10 @@
 namespace {
 
 // One workgroup = one tile: decodes blockIdx into (row tile, batch row, column tile) and runs the shared tile body (conv_body.h).
-template <int WK, bool DUAL, int KIND, int NITG, class WT = float, bool TALL = false>
+// TN = 16: the 32 x 16 tiles of conv_body.h (ConvGeo) -- the same body, half the columns per workgroup.
+template <int WK, bool DUAL, int KIND, int NITG, class WT = float, bool TALL = false, int TN = CONV_TN>
 __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel(const ConvArgs a) {
-    __shared__ __attribute__((aligned(16))) char lds[conv_lds_bytes<WK, DUAL || TALL>()];
+    __shared__ __attribute__((aligned(16))) char lds[conv_lds_bytes<WK, DUAL || TALL, TN>()];
     TL_BEGIN();
 
     // ---- kernel arguments of the prologue in one batch (common.h: KARG_PIN)
@@ -63,8 +67,8 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
     if (a.xcd_cols) { rem = fastdiv(lid, a.mgy, gy); mt = lid - rem * gy; }       // row tile fastest: an XCD's slab is a range of column tiles
     else { mt = fastdiv(lid, a.mgxz, gx * gz); rem = lid - mt * (gx * gz); }
     const int b = fastdiv(rem, a.mgx, gx);
-    const int t0 = (rem - b * gx) * CONV_TN;
-    conv_tile<WK, DUAL, KIND, NITG, WT, TALL>(a, TALL ? 2 * mt : mt, b, t0, rem, (int)threadIdx.x, lds, true);      // TALL: the grid's row axis counts PAIRS of row tiles
+    const int t0 = (rem - b * gx) * TN;
+    conv_tile<WK, DUAL, KIND, NITG, WT, TALL, ConvArgs, TN>(a, TALL ? 2 * mt : mt, b, t0, rem, (int)threadIdx.x, lds, true);      // TALL: the grid's row axis counts PAIRS of row tiles
     TL_END(a.tl, WK);
 }
 
@@ -121,6 +125,52 @@ void launch_wk(hipStream_t st, const ConvArgs& a0, dim3 grid, int gx, int gy, in
     else if (nitg <= 9) MUGD_CONV_LAUNCH(2, 9);
     else MUGD_CONV_LAUNCH(2, 17);
 #undef MUGD_CONV_LAUNCH
+}
+
+// The 16-wide tiles' fragment order (conv_body.h: mfma_chunk16): per (tap, row half) [lane = kq * 16 + r][kg] = W[16 half + r][4 kg + kq].
+__global__ void pack_weights16_kernel(const PackArgs p) {
+    const long long total = (long long)p.rows * p.C * p.taps;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % p.taps);
+        const long long q = i / p.taps;
+        const int ci = (int)(q % p.C);
+        const int ms = (int)(q / p.C);
+        const int m = ms + p.row_off;
+        const int mt = m >> 5, half = (m >> 4) & 1, r = m & 15;
+        const int chunk = ci >> 4, within = ci & 15;
+        const int kg = within >> 2, kq = within & 3;
+        const int lane = kq * 16 + r;
+        const long long d = (long long)mt * p.w_mt_stride + p.seg_woff + (long long)chunk * (p.taps * 512) +
+                            (tap * 2 + half) * 256 + lane * 4 + kg;
+        const float wv = p.src[(long long)ms * p.src_ld + (long long)(p.src_ci_off + ci) * p.taps + tap];
+        if (p.w16) {
+            const unsigned u = __float_as_uint(wv);
+            reinterpret_cast<unsigned short*>(p.dst)[d] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);      // round to nearest even
+        } else if (MUGD_CONV_H3) {
+            // H3: the lane's 16 bytes of a (tap, row half) = 4 hi halves (slots kg = 0..3), then 4 scaled lo halves
+            const long long blk = (long long)mt * p.w_mt_stride + p.seg_woff + (long long)chunk * (p.taps * 512) + (tap * 2 + half) * 256 + lane * 4;
+            const _Float16 hi = (_Float16)wv;
+            const _Float16 lo = (_Float16)((wv - (float)hi) * 2048.0f);
+            _Float16* h = reinterpret_cast<_Float16*>(p.dst);
+            h[2 * blk + kg] = hi;
+            h[2 * blk + 4 + kg] = lo;
+        } else {
+            p.dst[d] = wv;
+        }
+    }
+}
+
+template <int WK>
+void launch16_wk(hipStream_t st, const ConvArgs& a0, dim3 grid, int gx, int gy, int gz, bool dual) {
+    ConvArgs a = a0;
+    conv_split_k(a, WK);
+    conv_set_grid(a, gx, gy, gz);
+    a.tl = tl_claim((int)grid.x, WK, 16);
+    if (a.w16) {
+        if (dual) hipLaunchKernelGGL((conv_gemm_kernel<WK, true, 0, 1, unsigned short, false, 16>), grid, dim3(WK * 64), 0, st, a);
+        else hipLaunchKernelGGL((conv_gemm_kernel<WK, false, 0, 1, unsigned short, false, 16>), grid, dim3(WK * 64), 0, st, a);
+    } else if (dual) hipLaunchKernelGGL((conv_gemm_kernel<WK, true, 0, 1, float, false, 16>), grid, dim3(WK * 64), 0, st, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<WK, false, 0, 1, float, false, 16>), grid, dim3(WK * 64), 0, st, a);
 }
 
 }  // namespace
@@ -223,4 +273,86 @@ void launch_pack_weights(hipStream_t st, const PackArgs& a) {
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, st, a);
+}
+
+// ---------------------------------------------------------------------------------------
+// 32 x 16 tiles: when they are used, their launch and weight-pack entry points
+// ---------------------------------------------------------------------------------------
+bool conv16_supported(const ConvArgs& a) {
+    for (int i = 0; i < a.nseg; ++i) {
+        const ConvSeg& s = a.seg[i];
+        if (s.stride != 1 || s.ups || (s.Tin & 3) || !(s.taps == 1 || (s.taps == 3 && s.dil == 1)) || s.pad > s.taps - 1) return false;
+        if (a.epi != EPI_NONE && s.taps != 1) return false;
+    }
+    return true;
+}
+
+// 16-wide tiles when the 32-wide tiling cannot give every CU a workgroup (MUGD_CONV_TN=16|32 forces it)
+int conv_pick_tn(const ConvArgs& a) {
+    static const int forced = [] { const char* e = getenv("MUGD_CONV_TN"); return e ? atoi(e) : 0; }();
+    if (!conv16_supported(a)) return 32;
+    if (forced == 16 || forced == 32) return forced;
+    const long long tiles32 = (long long)cdiv(a.Tout, 32) * cdiv(a.Mout, 32) * a.B;
+    return tiles32 * 2 <= 256 ? 16 : 32;       // 129..255 tiles: 16-wide tiles would need a second, half-empty round of workgroups
+}
+
+// Which operand should be the one every XCD re-reads?  With row-tile-major order the weights are fetched once and the
+// activations by up to 8 private L2s; with row-tile-fastest order it is the other way round.  Bytes moved into L2s:
+//   row major: W max(1, 8 / row_tiles) + X min(8, row_tiles)      col major: W min(8, col_tiles) + X max(1, 8 / col_tiles)
+// (MUGD_XCD_ORDER=row|col forces one; grids that are not a multiple of 8 are not renumbered at all.)
+int conv_pick_order(const ConvArgs& a) {
+    static const int forced = [] { const char* e = getenv("MUGD_XCD_ORDER"); return !e ? -1 : (e[0] == 'c' ? 1 : (e[0] == 'r' ? 0 : -1)); }();
+    if (forced >= 0) return forced;
+    const double row_tiles = cdiv(a.Mout, 32), col_tiles = (double)cdiv(a.Tout, a.tn == 16 ? 16 : 32) * a.B;
+    double W = 0, X = 0;
+    for (int i = 0; i < a.nseg; ++i) {
+        const ConvSeg& s = a.seg[i];
+        W += (double)a.Mrows * s.C * s.taps;
+        X += (double)s.C * s.Tin * (s.bmod > 0 ? std::min(s.bmod, a.B) : a.B);
+    }
+    const double row_major = W * std::max(1.0, 8.0 / row_tiles) + X * std::min(8.0, row_tiles);
+    const double col_major = W * std::min(8.0, col_tiles) + X * std::max(1.0, 8.0 / col_tiles);
+    return col_major < row_major ? 1 : 0;
+}
+
+void launch_conv_gemm16(hipStream_t st, const ConvArgs& a) {
+    MUGD_CHECK(a.nseg >= 1 && a.nseg <= CONV_MAXSEG, -2, "conv_gemm (16-wide): bad segment count");
+    MUGD_CHECK(conv16_supported(a), -2, "conv_gemm (16-wide): unsupported segment geometry");
+    for (int i = 0; i < a.nseg; ++i) {
+        const ConvSeg& s = a.seg[i];
+        MUGD_CHECK(s.C % CONV_CK == 0, -2, "conv_gemm (16-wide): channels must be a multiple of 16");
+        MUGD_CHECK((long long)CONV_CK * s.Tin * 4 < (1ll << 31), -2, "conv_gemm (16-wide): sequence too long for 32-bit window offsets");
+        MUGD_CHECK(s.xf >= 0 && s.xf <= 4 && (s.xf == 0 || s.xf_a) && (s.xf < 2 || s.xf_b), -2, "conv_gemm (16-wide): bad operand transform");
+        MUGD_CHECK(s.xf != 4 || (i < a.gn_nseg && a.gn_groups > 0 && a.gn_groups <= 32 && a.gn_cg > 0), -2, "conv_gemm (16-wide): bad GroupNorm domain");
+        MUGD_CHECK(s.xf != 3 || (s.taps == 1 && s.xf_np > 0), -2, "conv_gemm (16-wide): LayerNorm from producer sums needs a 1x1 segment");
+    }
+    const bool dual = a.epi == EPI_GLU || a.epi == EPI_GEGLU;
+    if (a.epi == EPI_XSOFTMAX)
+        MUGD_CHECK(a.xs_rel && a.xs_cemb && a.xs_heads > 0 && a.Mout == 32 * a.xs_heads && a.xs_ntok >= 1 && a.xs_ntok <= 32 && !a.rowstat && !a.colstat &&
+                       a.nseg == 1 && a.seg[0].taps == 1, -2, "conv_gemm: bad cross-attention score epilogue");
+    MUGD_CHECK((!a.colstat && !a.rowstat) || !dual, -2, "conv_gemm (16-wide): row / column sums are not produced by gated epilogues");
+    if (dual) MUGD_CHECK(a.Mout % 32 == 0 && a.Mrows == 2 * a.Mout, -2, "conv_gemm (16-wide): gated epilogue needs Mout % 32 == 0");
+    else MUGD_CHECK(a.Mrows == a.Mout, -2, "conv_gemm (16-wide): Mrows != Mout");
+    const int gx = cdiv(a.Tout, 16), gy = cdiv(a.Mout, 32), gz = a.B;
+    const dim3 grid((unsigned)gx * gy * gz);
+    int wk = a.wk > 0 ? a.wk : conv_pick_wk_tiles((long long)gx * gy * gz, a.nchunk);
+    if (const char* e = getenv("MUGD_CONV_WK")) {
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4 || v == 8) wk = v;
+    }
+    switch (wk) {
+        case 1: launch16_wk<1>(st, a, grid, gx, gy, gz, dual); break;
+        case 2: launch16_wk<2>(st, a, grid, gx, gy, gz, dual); break;
+        case 4: launch16_wk<4>(st, a, grid, gx, gy, gz, dual); break;
+        case 8: launch16_wk<8>(st, a, grid, gx, gy, gz, dual); break;
+        default: MUGD_CHECK(false, -2, "conv_gemm (16-wide): K-split must be 1, 2, 4 or 8");
+    }
+}
+
+void launch_pack_weights16(hipStream_t st, const PackArgs& a) {
+    const long long total = (long long)a.rows * a.C * a.taps;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(pack_weights16_kernel, dim3(blocks), dim3(256), 0, st, a);
 }

@@ -79,7 +79,7 @@ struct ConvArgs {
     int gn_nseg, gn_groups, gn_cg;
     float gn_count, gn_eps;  // elements per group (cg * T), eps
     int wk;                  // K-split (waves per workgroup): 1|2|4|8, 0 = pick from the shape
-    int tn;                  // output tile width: 32 (k_conv.hip) | 16 (k_conv16.hip); decides the weight packing
+    int tn;                  // output tile width: 32 | 16 (conv_body.h: ConvGeo; one kernel template, k_conv.hip); decides the weight packing
     int xcd_cols;            // workgroup order inside an XCD's slab: 0 = row tile major (a weight tile lives in one L2, every XCD reads
                              // the activations), 1 = row tile fastest (a column tile lives in one L2, every XCD reads the weights);
                              // set per launch by conv_pick_order() to whichever moves fewer bytes
@@ -134,7 +134,7 @@ inline void conv_set_grid(ConvArgs& a, int gx, int gy, int gz) {
 }
 void launch_conv_gemm(hipStream_t st, const ConvArgs& a);        // 32 x 32 tiles
 int conv_pick_wk(const ConvArgs& a);
-void launch_conv_gemm16(hipStream_t st, const ConvArgs& a);      // 32 x 16 tiles
+void launch_conv_gemm16(hipStream_t st, const ConvArgs& a);      // 32 x 16 tiles (the same kernel template with TN = 16)
 bool conv16_supported(const ConvArgs& a);
 bool conv_w16_supported(const ConvArgs& a);                      // bf16 weight variant exists for this launch shape (needs tn)
 int conv_pick_tn(const ConvArgs& a);                             // needs seg[], nseg, epi, B, Mout, Tout

@@ -1,7 +1,7 @@
 """Development tool (run through gpurun): per-launch PHASE TIMELINE of the conv_gemm kernels inside one U-Net evaluation.
 
 Loads tests/tl/libmugd_tl.so -- the product sources compiled with -DMUGD_TL (`python mug-diffusion_amd/build.py --tl`),
-in which every wave of conv_gemm / conv_gemm16 stamps s_memtime at: kernel entry, side operands requested, first chunk
+in which every wave of conv_gemm (either tile width) stamps s_memtime at: kernel entry, side operands requested, first chunk
 parked, K loop done, K-split combine done, output stored, statistics done (csrc/common.h).  Writes one CSV row per launch
 (median / max cycles of every phase over the launch's waves, span and start skew from the device-global 100 MHz counter)
 and a short text summary.
