@@ -85,6 +85,30 @@ __device__ __forceinline__ int fastdiv(int n, unsigned m, int d) {
 #define KARG_PIN4(a, b, c, d) asm volatile("" ::"s"(a), "s"(b), "s"(c), "s"(d))
 #endif
 
+// KARG_WARM: the first instructions of a kernel touch EVERY 64-byte line of its kernel-argument block -- ten for ConvArgs -- with
+// back-to-back scalar loads and wait once.  Each CU's scalar cache starts a launch without them, the compiler places the argument
+// loads lazily along the control flow (a load, a wait, a branch; the next load behind it), and a first touch of a line is a trip to
+// L2 / HBM: up to ten of those in series along the conv_gemm prologue.  After the touch they are scalar-cache hits.
+#ifdef MUGD_EMULATED
+#define KARG_WARM(bytes) do {} while (0)
+#else
+// (one asm block: left to itself the compiler interleaves such loads with its own and waits four times)
+#define KARG_WARM(bytes)                                                                                                        \
+    do {                                                                                                                        \
+        static_assert((bytes) <= 640, "KARG_WARM touches ten 64-byte lines");                                                   \
+        const auto kw_p_ = __builtin_amdgcn_kernarg_segment_ptr();                           \
+        unsigned kw0_, kw1_, kw2_, kw3_, kw4_, kw5_, kw6_, kw7_, kw8_, kw9_;                                                    \
+        asm volatile("s_load_dword %0, %10, 0x0\n\ts_load_dword %1, %10, 0x40\n\ts_load_dword %2, %10, 0x80\n\t"              \
+                     "s_load_dword %3, %10, 0xc0\n\ts_load_dword %4, %10, 0x100\n\ts_load_dword %5, %10, 0x140\n\t"            \
+                     "s_load_dword %6, %10, 0x180\n\ts_load_dword %7, %10, 0x1c0\n\ts_load_dword %8, %10, 0x200\n\t"           \
+                     "s_load_dword %9, %10, 0x240\n\ts_waitcnt lgkmcnt(0)"                                                      \
+                     : "=&s"(kw0_), "=&s"(kw1_), "=&s"(kw2_), "=&s"(kw3_), "=&s"(kw4_), "=&s"(kw5_), "=&s"(kw6_), "=&s"(kw7_),  \
+                       "=&s"(kw8_), "=&s"(kw9_)                                                                                 \
+                     : "s"(kw_p_)                                                                                               \
+                     : "memory");                                                                                               \
+    } while (0)
+#endif
+
 // Argument blocks that live in device memory instead of the kernarg segment (the executor's op table, xexec.hip) are read through the
 // CONSTANT address space: uniform loads from it are scalar (s_load into SGPRs), which is exactly what by-value kernel arguments compile
 // to -- the tile bodies keep their register budget whichever way their arguments arrive.  The table is written by the host before the
@@ -105,7 +129,7 @@ __device__ __forceinline__ const MUGD_CONST_AS T* to_const_as(const T* p) {
 // s_memtime (shader cycles) at fixed points into an LDS record and dumps it at kernel end; tests/gpu_timeline.py
 // reduces the records to a per-launch phase table (profiles/).
 // ---------------------------------------------------------------------------------------
-constexpr int TL_WORDS = 16;        // per wave: [0..6] s_memtime stamps, [7] s_memrealtime at entry, [8] at exit, [9] HW_ID | XCC_ID << 32, [10] chunks, [11..13] prologue detail: statistics requested / epilogue operands requested / statistics sums arrived
+constexpr int TL_WORDS = 16;        // per wave: [0..6] s_memtime stamps, [7] s_memrealtime at entry, [8] at exit, [9] HW_ID | XCC_ID << 32, [10] chunks, [11..13] prologue detail: statistics requested / epilogue operands requested / statistics sums arrived, [14] ring's first loads issued, [15] chunk 0's window arrived
 #if defined(MUGD_TL) && !defined(MUGD_EMULATED)
 #define TL_DECL __shared__ unsigned long long tl_lds[8][TL_WORDS];
 #define TL_BEGIN()                                                                                          \

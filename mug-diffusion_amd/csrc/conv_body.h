@@ -482,6 +482,11 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
 #pragma unroll
         for (int d = 0; d < D; ++d)                     // requested chunk by chunk (window first): the memory system serves a cold
             if (d < nch) { fetch_x(d, d); fetch_a(d, d); }      // burst roughly in order, so chunk 0 is complete after 1/D of it
+        TL_STAMP_ONCE(14);                                   // timeline build: the ring's first loads are issued
+#if defined(MUGD_TL) && !defined(MUGD_EMULATED)
+        asm volatile("" :: "v"(RX[0][0].x));                // ... and chunk 0's window has arrived
+        TL_STAMP_ONCE(15);
+#endif
         finish_ln();
         park_v(0, RX[0], RXH[0], RGB[0], RGG[0]);
         if (D < nch) fetch_x(D, 0);

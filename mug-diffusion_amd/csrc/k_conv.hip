@@ -38,6 +38,10 @@
 
 #include "conv_body.h"
 
+#ifndef MUGD_KARG_WARM
+#define MUGD_KARG_WARM 1
+#endif
+
 namespace {
 
 // One workgroup = one tile: decodes blockIdx into (row tile, batch row, column tile) and runs the shared tile body (conv_body.h).
@@ -46,6 +50,9 @@ template <int WK, bool DUAL, int KIND, int NITG, class WT = float, bool TALL = f
 __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel(const ConvArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[conv_lds_bytes<WK, DUAL || TALL, TN>()];
     TL_BEGIN();
+#if MUGD_KARG_WARM
+    KARG_WARM(sizeof(ConvArgs));
+#endif
 
     // ---- kernel arguments of the prologue in one batch (common.h: KARG_PIN)
     const int gx = a.gx, gy = a.gy, gz = a.gz;

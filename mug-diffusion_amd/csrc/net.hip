@@ -151,7 +151,7 @@ void Net::timeline_program(const char* path, const char* raw_path, int raw_op) {
     FILE* fr = raw_path ? fopen(raw_path, "a") : nullptr;
     const char* raw_label = getenv("MUGD_TL_RAW_LABEL");          // raw per-wave records of the launches whose label contains this
     fprintf(f, "op,kind,gflop,tn,wk,blocks,waves,span_ns,start_skew_ns,first_end_ns,mhz,chunks_med,"
-               "su_issue,su_side,su_wait,su_reduce,setup_med,setup_max,first_med,first_max,loop_med,loop_max,cyc_per_chunk,combine_med,combine_max,store_med,store_max,tail_med,tail_max,total_med,total_max,label\n");
+               "su_issue,su_side,su_wait,su_reduce,setup_med,setup_max,first_med,first_max,loop_med,loop_max,cyc_per_chunk,combine_med,combine_max,store_med,store_max,tail_med,tail_max,total_med,total_max,f_issue,f_arrive,f_park,label\n");
     auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
     auto mx = [](const std::vector<double>& v) { double m = 0; for (double x : v) m = std::max(m, x); return m; };
     for (size_t i = 0; i < ops.size(); ++i) {
@@ -159,7 +159,7 @@ void Net::timeline_program(const char* path, const char* raw_path, int raw_op) {
             const TlLaunch& L = g_tl.launches[li];
             const size_t nw = (size_t)L.nblk * L.nwaves;
             unsigned long long r0 = ~0ull, r1 = 0, r0max = 0, r1min = ~0ull;
-            std::vector<double> ph[7], chunks, mhz, su[4];
+            std::vector<double> ph[7], chunks, mhz, su[4], fd[3];
             for (size_t w = 0; w < nw; ++w) {
                 const unsigned long long* r = &h[L.off + w * TL_WORDS];
                 if (r[0] == 0) continue;
@@ -175,6 +175,9 @@ void Net::timeline_program(const char* path, const char* raw_path, int raw_op) {
                     su[0].push_back((double)(r[11] - r[0])); su[1].push_back((double)(r[12] - r[11]));
                     su[2].push_back((double)(t13 - r[12])); su[3].push_back((double)(r[1] - t13));
                 }
+                if (r[14] && r[15] && r[2]) {      // "first chunk parked" in detail: ring issued / chunk 0's window arrived / transformed + parked
+                    fd[0].push_back((double)(r[14] - r[1])); fd[1].push_back((double)(r[15] - r[14])); fd[2].push_back((double)(r[2] - r[15]));
+                }
                 if (r[8] > r[7]) mhz.push_back((double)(r[6] - r[0]) / ((double)(r[8] - r[7]) * 10.0) * 1e3);
                 if (fr && ((int)i == raw_op || raw_op == -1 || (raw_label && ops[i].label.find(raw_label) != std::string::npos)))
                     fprintf(fr, "%zu,%zu,%zu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu\n", i, w / L.nwaves, w % L.nwaves,
@@ -188,7 +191,7 @@ void Net::timeline_program(const char* path, const char* raw_path, int raw_op) {
                 fprintf(f, ",%.0f,%.0f", med(ph[k]), mx(ph[k]));
                 if (k == 2) fprintf(f, ",%.0f", cm > 0 ? lm / cm : 0.0);
             }
-            fprintf(f, ",%.0f,%.0f,%s\n", med(ph[6]), mx(ph[6]), ops[i].label.c_str());
+            fprintf(f, ",%.0f,%.0f,%.0f,%.0f,%.0f,%s\n", med(ph[6]), mx(ph[6]), med(fd[0]), med(fd[1]), med(fd[2]), ops[i].label.c_str());
         }
     }
     fclose(f);

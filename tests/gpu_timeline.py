@@ -44,6 +44,9 @@ def summarise(path, out):
         print("  %-66s %8.1f us  %5.1f%%" % (name, tot[k] / mhz, 100 * tot[k] / tot["total_med"]), file=out)
     print("  %-66s %8.1f us" % ("median wave total", tot["total_med"] / mhz), file=out)
     print("  %-66s %8.1f us" % ("slowest wave total", tot["total_max"] / mhz), file=out)
+    if "f_issue" in rows[0]:
+        fi, fa, fp = (sum(f(r, k) for r in rows) / mhz for k in ("f_issue", "f_arrive", "f_park"))
+        print("  'first chunk parked' in detail: ring's first loads issued %.1f us, chunk 0's window arrived %.1f us, transformed + parked %.1f us" % (fi, fa, fp), file=out)
     skew = sum(f(r, "start_skew_ns") for r in rows)
     print("sum of start skews (last wave's entry - first wave's entry): %.1f us" % (skew / 1e3), file=out)
     # MFMA-ideal loop time: cycles per chunk if the SIMD's matrix pipe were the only limit
@@ -53,7 +56,7 @@ def summarise(path, out):
             r["op"], r["tn"], r["wk"], r["blocks"], f(r, "span_ns") / 1e3, f(r, "setup_med") / mhz,
             f(r, "su_issue") / mhz, f(r, "su_side") / mhz, f(r, "su_wait") / mhz, f(r, "su_reduce") / mhz, f(r, "first_med") / mhz,
             f(r, "loop_med") / mhz, f(r, "combine_med") / mhz, f(r, "store_med") / mhz, f(r, "tail_med") / mhz,
-            f(r, "cyc_per_chunk"), r["label"]), file=out)
+            f(r, "cyc_per_chunk"), ("[first: issue %.2f arrive %.2f park %.2f] " % (f(r, "f_issue") / mhz, f(r, "f_arrive") / mhz, f(r, "f_park") / mhz) if "f_issue" in r else "") + r["label"]), file=out)
 
 
 def main():
