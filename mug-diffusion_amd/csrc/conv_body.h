@@ -777,10 +777,6 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
     TL_STAMP(1);
     TL_SET(10, g1 - g0);
 
-#ifdef MUGD_CONV_SKEW
-    // development variant: the two waves that share a SIMD (w and w + 4 of an 8-wave workgroup) enter the K loop half an iteration apart
-    if (WK == 8 && wave >= 4) __builtin_amdgcn_s_sleep(MUGD_CONV_SKEW);
-#endif
 #pragma unroll
     for (int si = 0; si < CONV_MAXSEG; ++si) {
         if (si < a.nseg) {
