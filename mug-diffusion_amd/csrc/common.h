@@ -95,7 +95,7 @@ __device__ __forceinline__ int fastdiv(int n, unsigned m, int d) {
 // (one asm block: left to itself the compiler interleaves such loads with its own and waits four times)
 #define KARG_WARM(bytes)                                                                                                        \
     do {                                                                                                                        \
-        static_assert((bytes) <= 640, "KARG_WARM touches ten 64-byte lines");                                                   \
+        static_assert((bytes) > 576 && (bytes) <= 640, "KARG_WARM touches exactly ten 64-byte lines: the block must end in the tenth");                                                   \
         const auto kw_p_ = __builtin_amdgcn_kernarg_segment_ptr();                           \
         unsigned kw0_, kw1_, kw2_, kw3_, kw4_, kw5_, kw6_, kw7_, kw8_, kw9_;                                                    \
         asm volatile("s_load_dword %0, %10, 0x0\n\ts_load_dword %1, %10, 0x40\n\ts_load_dword %2, %10, 0x80\n\t"              \
