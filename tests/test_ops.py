@@ -110,7 +110,7 @@ def test_norm_conv1d_fused(lib, B, C, T, M, taps, dil, norm, groups, silu, wk):
 @pytest.mark.parametrize("tn", [16, 32])
 @pytest.mark.parametrize("B,C,T,M,taps,dil,norm,groups,silu,wk", [c for c in NORM_CONV_CASES if c[2] % 4 == 0 and c[5] == 1])
 def test_norm_conv1d_tile_widths(lib, tn, B, C, T, M, taps, dil, norm, groups, silu, wk):
-    """Both tile shapes (32x32 on v_mfma_f32_32x32x2_f32, 32x16 on v_mfma_f32_16x16x4_f32) give the same conv."""
+    """Both tile widths of the conv_gemm template (32 x 32 and 32 x 16 tiles: csrc/conv_body.h, ConvGeo) give the same conv."""
     lib.set_conv_tiling(0, tn)
     try:
         test_norm_conv1d_fused(lib, B, C, T, M, taps, dil, norm, groups, silu, wk)
