@@ -9,6 +9,8 @@
 //   lds    the (virtual) workgroup's LDS block, conv_lds_bytes<WK, DUAL>() bytes
 //   live   false: an idle slot of the executor's last round -- runs the same barriers, stores nothing
 #pragma once
+#include <type_traits>
+
 #include "conv_stats.h"
 #include "kernels.h"
 
@@ -297,10 +299,14 @@ __device__ __forceinline__ void conv_mfma(const char* smem_bytes, int rb0, int d
 // is the VALU budget of the kernel -- with the exact-division SiLU it issued as many VALU cycles as the MFMAs take
 // (rocprofv3 PMC: SQ_ACTIVE_INST_VALU ~ SQ_VALU_MFMA_BUSY_CYCLES) -- so the hot instantiations carry no branches
 // and the minimal arithmetic: GroupNorm is one fma per sample, SiLU is v_exp_f32 + v_rcp_f32.
-template <int TN, int TAPS, bool DUAL, int NH, int XFK = -1, int ACT = -1, bool PIPE = false, class WT = float, class SEG = ConvSeg>
+// COOP > 0 (conv_tile's M-split form): the COOP waves of the workgroup own different ROW tiles and share every staged window -- wave w
+// transforms and parks the chunks k = w, w + COOP, ... (with exactly the per-wave staging code below) into slot w of a double-buffered set
+// of COOP shared windows, every wave consumes all COOP chunks of a phase with its own weight fragments, one workgroup barrier per phase:
+// the operand transform / split / park work per MFMA drops by COOP.  wave_base must be 0; coop_wave = the wave's index.
+template <int TN, int TAPS, bool DUAL, int NH, int XFK = -1, int ACT = -1, bool PIPE = false, class WT = float, class SEG = ConvSeg, int COOP = 0>
 __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, const WT* wseg2, int lo, int hi,
                                                 int b, int t0, int lane, char* smem_bytes, int wave_base,
-                                                ConvAcc<TN>& ac, const float2* gst, const float2* lnst, float inv_cg, int rot_seed) {
+                                                ConvAcc<TN>& ac, const float2* gst, const float2* lnst, float inv_cg, int rot_seed, int coop_wave = 0) {
     typedef ConvGeo<TN> G;
     constexpr int RSV = G::RS;
     constexpr int XV = TN / 16;                            // aligned float4 per lane and chunk (lane (row = lane / 4, q = lane % 4))
@@ -436,6 +442,57 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
         for (int j = 0; j < NH; ++j) *reinterpret_cast<float*>(smem_bytes + wofs + lh[j]) = okh[j] ? vh[j] : 0.f;
     };
     auto park = [&](int wofs) { park_v(wofs, xv, xh, gbv, gbg); };
+
+    if constexpr (COOP > 0) {
+        static_assert(COOP % 2 == 0, "the weight-fragment ring alternates with the chunk parity");
+        constexpr int W1 = G::WIN_LDS * 4;                 // bytes per window; slot (w, buf) = (buf COOP + w) W1
+        const int nch = hi - lo;
+        float4 RA[2][6], RA2[2][6];
+        float4 RX[XV];
+        float RXH[NHA];
+        float2 RGB = make_float2(1.f, 0.f);
+        int RGG = 0;
+#pragma unroll
+        for (int j = 0; j < NHA; ++j) RXH[j] = 0.f;
+        auto fetch_x = [&](int k) {
+            const char* xq = xb + (size_t)k * xstep;
+#pragma unroll
+            for (int x = 0; x < XV; ++x) RX[x] = *reinterpret_cast<const float4*>(xq + gv[x]);
+#pragma unroll
+            for (int j = 0; j < NH; ++j) RXH[j] = *reinterpret_cast<const float*>(xq + gh[j]);
+            if (xf) RGB = load_gb2(k, RGG);
+        };
+        auto fetch_a = [&](int k, int d) { load_a<TAPS, DUAL>(wp + (size_t)k * (TAPS * 512), wp2 + (size_t)k * (TAPS * 512), RA[d], RA2[d]); };
+        if (coop_wave < nch) fetch_x(coop_wave);
+        fetch_a(0, 0);
+        if (1 < nch) fetch_a(1, 1);
+        finish_ln();
+        if (coop_wave < nch) {
+            park_v(coop_wave * W1, RX, RXH, RGB, RGG);
+            if (coop_wave + COOP < nch) fetch_x(coop_wave + COOP);
+        }
+        __syncthreads();
+        TL_STAMP_ONCE(2);
+        const int nph = (nch + COOP - 1) / COOP;
+        for (int ph = 0; ph < nph; ++ph) {
+            const int buf = ph & 1;
+            const int kn = (ph + 1) * COOP + coop_wave;        // this wave's chunk of the next phase
+#pragma unroll
+            for (int j = 0; j < COOP; ++j) {
+                const int k = ph * COOP + j;
+                if (k < nch) {
+                    conv_mfma<TN, TAPS, DUAL, WT>(smem_bytes + (buf * COOP + j) * W1, rb0, s.dil, RA[j & 1], RA2[j & 1], ac);
+                    if (k + 2 < nch) fetch_a(k + 2, j & 1);
+                }
+                if (j == 0 && kn < nch) {                   // under the first chunk's MFMAs: the next phase's window, into the other buffer
+                    park_v(((buf ^ 1) * COOP + coop_wave) * W1, RX, RXH, RGB, RGG);
+                    if (kn + COOP < nch) fetch_x(kn + COOP);
+                }
+            }
+            __syncthreads();                                // next phase's windows complete; this phase's windows free
+        }
+        return;
+    }
 
     if (PIPE) {
         // ---- software-pipelined loop over a register RING of D chunks.  Chunk k's weights and raw window live in ring stage
@@ -682,10 +739,15 @@ constexpr int conv_lds_bytes() { return ConvLds<WK, DUAL, TN>::BYTES; }
 //       (weights: each wave streams both row tiles' fragments).  For launches with enough tiles to fill the chip at half the count
 //       (launch_conv_gemm); mt must be even, a missing last row tile (odd tile count) is computed on clamped weights and not stored.
 // TN: 32 | 16 output samples per tile (ConvGeo); the 16-wide tiles exist for KIND 0 without TALL.
-template <int WK, bool DUAL, int KIND, int NITG, class WT, bool TALL = false, class A = ConvArgs, int TN = CONV_TN>
+// MS ("M-split", launch_conv_gemm: wide): the WK waves own WK consecutive ROW tiles mt .. mt + WK - 1 of the same 32 columns instead of WK
+//       slices of K: every wave walks the whole K axis with its own weight stream, the windows are staged once per workgroup
+//       (run_segment_vec<COOP>), there is no K-split combine and every wave finishes its whole 32 x 32 tile itself.  For launches with enough
+//       column tiles to fill the chip that way (large batch); KIND 0, 32-wide tiles.
+template <int WK, bool DUAL, int KIND, int NITG, class WT, bool TALL = false, class A = ConvArgs, int TN = CONV_TN, bool MS = false>
 __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b, const int t0, const int rot, const int tid, char* lds, const bool live) {
     static_assert(!(DUAL && TALL), "gated layers already share their windows between two row sets");
     static_assert(TN == 32 || (KIND == 0 && !TALL), "16-wide tiles: plain fast-window kernels only");
+    static_assert(!MS || (KIND == 0 && TN == 32 && !TALL && WK >= 2), "M-split: plain fast-window kernels, 32-wide tiles");
     constexpr bool A2 = DUAL || TALL;               // two weight streams / two accumulators per wave
     typedef ConvGeo<TN> G;
     typedef ConvLds<WK, A2, TN> L;
@@ -709,26 +771,30 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
     stats.issue(a, b, t0, tid);
     TL_STAMP(11);
 
-    // K-slice of this wave: chunk boundaries balanced by cost on the host (a 3-tap chunk is ~2x a 1x1 chunk)
+    // K-slice of this wave: chunk boundaries balanced by cost on the host (a 3-tap chunk is ~2x a 1x1 chunk); M-split: all of K
     int g0 = a.kb[0], g1 = a.kb[1];          // constant kernarg offsets + selects: no dependent scalar load
+    if (!MS) {
 #pragma unroll
-    for (int w = 1; w < WK; ++w)
-        if (wave == w) { g0 = a.kb[w]; g1 = a.kb[w + 1]; }
+        for (int w = 1; w < WK; ++w)
+            if (wave == w) { g0 = a.kb[w]; g1 = a.kb[w + 1]; }
+    }
+    const int mtw = MS ? mt + wave : mt;           // this wave's row tile
+    const int mtc = (MS && mtw >= gy) ? gy - 1 : mtw;      // M-split, ragged last group: a wave without a row tile computes on clamped weights, stores nothing
 
     ConvAcc<TN> ac;                              // values, second row set, and the 2^11-scaled cross terms of the H3 arithmetic
     ac.zero();
 
-    const WT* wtile = reinterpret_cast<const WT*>(a.wpk) + (size_t)b * a.w_b_stride + (size_t)mt * a.w_mt_stride + lane * 4;
+    const WT* wtile = reinterpret_cast<const WT*>(a.wpk) + (size_t)b * a.w_b_stride + (size_t)mtc * a.w_mt_stride + lane * 4;
     const bool has2 = !TALL || mt + 1 < gy;        // TALL: the second row tile exists
     const WT* wtile2 = DUAL ? wtile + (size_t)(a.Mout >> 5) * a.w_mt_stride : (TALL && has2) ? wtile + a.w_mt_stride : wtile;
     char* smem_bytes = lds;
-    const int wave_base = wave * G::WAVE_LDS * 4;
+    const int wave_base = MS ? 0 : wave * G::WAVE_LDS * 4;
 
     const float gn_inv_cg = a.gn_groups ? 1.0f / (float)a.gn_cg : 0.f;
 
     // ---- epilogue operands: the side loads (bias / row term / residual) are issued HERE, before the K loop, from
     // clamped addresses under wave-uniform conditions, so their latency is off the kernel's critical path.
-    constexpr int EPT = NREG / WK;       // tile rows (accumulator registers) finished by each wave
+    constexpr int EPT = MS ? NREG : NREG / WK;       // tile rows (accumulator registers) finished by each wave
     float bv[EPT], bg[EPT], ra[EPT], rsv[EPT];
     size_t oo[EPT];
     int mm[EPT];
@@ -741,9 +807,9 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
     bool valid2[EPT2];
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
-        const int r = wave * EPT + q;
+        const int r = MS ? q : wave * EPT + q;
         const int row = G::row(r, lane);
-        const int m = mt * 32 + row, t = t0 + cl;
+        const int m = mtw * 32 + row, t = t0 + cl;
         valid[q] = live && (m < a.Mout) && (t < a.Tout);
         mm[q] = m < a.Mout ? m : a.Mout - 1;
         oo[q] = ((size_t)b * a.Mout + mm[q]) * a.Tout + (t < a.Tout ? t : a.Tout - 1);
@@ -787,17 +853,18 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
             if (lo < hi) {
                 const WT* w1 = wtile + s.woff;
                 const WT* w2 = wtile2 + s.woff;
-#define MUGD_SEG_VARGS s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, ac, stl.gnst, stl.lnst, gn_inv_cg, rot
+#define MUGD_SEG_VARGS s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, ac, stl.gnst, stl.lnst, gn_inv_cg, rot, wave
+#define MUGD_COOP , WT, typename std::remove_cv<typename std::remove_reference<decltype(s)>::type>::type, (MS ? WK : 0)
                 if constexpr (KIND == 0) {
                     // specialise on (transform, activation): branch-free chunk loops
 #define MUGD_SEG_XF(T, NHALO)                                                                     \
     switch (s.xf * 4 + s.act) {                                                                   \
-        case 0: run_segment_vec<TN, T, A2, NHALO, 0, 0, MUGD_PIPE>(MUGD_SEG_VARGS); break;                      \
-        case 4: case 16: run_segment_vec<TN, T, A2, NHALO, 1, 0, MUGD_PIPE>(MUGD_SEG_VARGS); break;            \
-        case 5: case 17: run_segment_vec<TN, T, A2, NHALO, 1, 1, MUGD_PIPE>(MUGD_SEG_VARGS); break;            \
-        case 6: case 18: run_segment_vec<TN, T, A2, NHALO, 1, 2, MUGD_PIPE>(MUGD_SEG_VARGS); break;            \
-        case 8: case 12: run_segment_vec<TN, T, A2, NHALO, 2, 0, MUGD_PIPE>(MUGD_SEG_VARGS); break;            \
-        default: run_segment_vec<TN, T, A2, NHALO>(MUGD_SEG_VARGS);                                  \
+        case 0: run_segment_vec<TN, T, A2, NHALO, 0, 0, MUGD_PIPE MUGD_COOP>(MUGD_SEG_VARGS); break;                      \
+        case 4: case 16: run_segment_vec<TN, T, A2, NHALO, 1, 0, MUGD_PIPE MUGD_COOP>(MUGD_SEG_VARGS); break;            \
+        case 5: case 17: run_segment_vec<TN, T, A2, NHALO, 1, 1, MUGD_PIPE MUGD_COOP>(MUGD_SEG_VARGS); break;            \
+        case 6: case 18: run_segment_vec<TN, T, A2, NHALO, 1, 2, MUGD_PIPE MUGD_COOP>(MUGD_SEG_VARGS); break;            \
+        case 8: case 12: run_segment_vec<TN, T, A2, NHALO, 2, 0, MUGD_PIPE MUGD_COOP>(MUGD_SEG_VARGS); break;            \
+        default: run_segment_vec<TN, T, A2, NHALO, -1, -1, false MUGD_COOP>(MUGD_SEG_VARGS);                                  \
     }
                     if (DUAL || s.taps == 1) { MUGD_SEG_XF(1, 0) }
                     else { MUGD_SEG_XF(3, 1) }
@@ -816,6 +883,7 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
                     }
                 }
 #undef MUGD_SEG_VARGS
+#undef MUGD_COOP
             }
         }
     }
@@ -824,7 +892,7 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
     // ---- combine the WK K-slices through LDS (exchange region behind the staging windows)
     TL_STAMP(3);
     float acc_v[EPT], acc_g[EPT];
-    if (WK > 1) {
+    if (WK > 1 && !MS) {
         float* ex = smem + WIN;
 #pragma unroll
         for (int r = 0; r < NREG; ++r) {
@@ -848,7 +916,7 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
         for (int q = 0; q < EPT; ++q) { acc_v[q] = ac.get(q); acc_g[q] = ac.get2(q); }
     }
     TL_STAMP(4);
-    if (!A2 && a.epi == EPI_XSOFTMAX) {          // folded cross-attention: the tile is one head's key scores (conv_stats.h)
+    if (!A2 && !MS && a.epi == EPI_XSOFTMAX) {          // folded cross-attention: the tile is one head's key scores (conv_stats.h)
         float* xs = reinterpret_cast<float*>(lds + L::EPI_OFF);      // [32][TN + 1]
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
@@ -887,8 +955,8 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
             float s2 = s1 * s1;
 #pragma unroll
             for (int o = 1; o < TN; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-            const int r = wave * EPT + q;
-            const int m = mt * 32 + G::row(r, lane);
+            const int r = MS ? q : wave * EPT + q;
+            const int m = mtw * 32 + G::row(r, lane);
             if (live && cl == 0 && m < a.Mout) {
                 double* o = a.rowstat + 2 * ((size_t)b * a.Mout + m);
                 atomicAdd(o, (double)s1);
@@ -913,13 +981,21 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
-            const int r = wave * EPT + q;
-            const int m = mt * 32 + G::row(r, lane);
+            const int r = MS ? q : wave * EPT + q;
+            const int m = mtw * 32 + G::row(r, lane);
             const float v = m < a.Mout ? acc_v[q] : 0.f;
             s1 += v; s2 += v * v;
         }
 #pragma unroll
         for (int o = TN; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }      // the lanes that hold the same column
+        if (MS) {                                        // the wave holds its row tile's complete column sums
+            if (live && mtw < gy && lane < TN && t0 + cl < a.Tout) {
+                float* o = a.colstat + 2 * (((size_t)b * gy + mtw) * a.Tout + t0 + cl);
+                o[0] = s1; o[1] = s2;
+            }
+            TL_STAMP(6);
+            return;
+        }
         if (lane < TN) { cst[0][wave][cl] = s1; cst[1][wave][cl] = s2; }
         __syncthreads();
         if (live && tid < TN && t0 + tid < a.Tout) {

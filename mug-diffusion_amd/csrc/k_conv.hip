@@ -46,7 +46,8 @@ namespace {
 
 // One workgroup = one tile: decodes blockIdx into (row tile, batch row, column tile) and runs the shared tile body (conv_body.h).
 // TN = 16: the 32 x 16 tiles of conv_body.h (ConvGeo) -- the same body, half the columns per workgroup.
-template <int WK, bool DUAL, int KIND, int NITG, class WT = float, bool TALL = false, int TN = CONV_TN>
+// MS: the M-split ("wide") form -- the grid's row axis counts GROUPS of WK row tiles (conv_body.h).
+template <int WK, bool DUAL, int KIND, int NITG, class WT = float, bool TALL = false, int TN = CONV_TN, bool MS = false>
 __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel(const ConvArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[conv_lds_bytes<WK, DUAL || TALL, TN>()];
     TL_BEGIN();
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
     else { mt = fastdiv(lid, a.mgxz, gx * gz); rem = lid - mt * (gx * gz); }
     const int b = fastdiv(rem, a.mgx, gx);
     const int t0 = (rem - b * gx) * TN;
-    conv_tile<WK, DUAL, KIND, NITG, WT, TALL, ConvArgs, TN>(a, TALL ? 2 * mt : mt, b, t0, rem, (int)threadIdx.x, lds, true);      // TALL: the grid's row axis counts PAIRS of row tiles
+    conv_tile<WK, DUAL, KIND, NITG, WT, TALL, ConvArgs, TN, MS>(a, TALL ? 2 * mt : MS ? WK * mt : mt, b, t0, rem, (int)threadIdx.x, lds, true);      // TALL / MS: the grid's row axis counts PAIRS / GROUPS of row tiles
     TL_END(a.tl, WK);
 }
 
@@ -110,6 +111,18 @@ __global__ void pack_weights_kernel(const PackArgs p) {
             p.dst[d] = wv;
         }
     }
+}
+
+// M-split form: NW row tiles per workgroup, no K-split (conv_body.h: MS)
+template <int NW, bool DUAL>
+void launch_wide(hipStream_t st, const ConvArgs& a0, int gx, int gy, int gz) {
+    ConvArgs a = a0;
+    conv_split_k(a, 1);
+    const int gyg = cdiv(gy, NW);
+    conv_set_grid(a, gx, gyg, gz);
+    const dim3 grid((unsigned)gx * gyg * gz);
+    a.tl = tl_claim((int)grid.x, NW, 32);
+    hipLaunchKernelGGL((conv_gemm_kernel<NW, DUAL, 0, 1, float, false, 32, true>), grid, dim3(NW * 64), 0, st, a);
 }
 
 template <int WK, bool DUAL>
@@ -256,6 +269,16 @@ void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
     bool tall = false;
     if (const char* e = getenv("MUGD_CONV_TALL")) tall = e[0] == '1' && !dual && a.epi == EPI_NONE && kind != 2 && !a.w16 && gy >= 2;
     if (tall) gy = (gy + 1) / 2;
+    // M-split ("wide") form: MUGD_CONV_WIDE=1 wherever it exists (plain fast windows, fp32 weights, >= 2 row tiles, not the score epilogue)
+    if (const char* e = getenv("MUGD_CONV_WIDE")) {
+        if (e[0] == '1' && !tall && kind == 0 && !a.w16 && a.epi != EPI_XSOFTMAX && gy >= 2) {
+            const int nw = gy >= 8 ? 8 : gy >= 4 ? 4 : 2;
+#define MUGD_WIDE(N) case N: if (dual) launch_wide<N, true>(st, a, gx, gy, gz); else launch_wide<N, false>(st, a, gx, gy, gz); break;
+            switch (nw) { MUGD_WIDE(2) MUGD_WIDE(4) MUGD_WIDE(8) }
+#undef MUGD_WIDE
+            return;
+        }
+    }
     const dim3 grid((unsigned)gx * gy * gz);
     int wk = a.wk > 0 ? a.wk : conv_pick_wk_tiles((long long)gx * gy * gz, a.nchunk);
     if (const char* e = getenv("MUGD_CONV_WK")) {            // development / test knob: force the K-split

@@ -160,6 +160,43 @@ def test_conv1d_tall_tiles(lib, monkeypatch, B, C, T, M, taps, dil):
             test_norm_conv1d_fused(lib, B, C, T, M, 1, 1, 2, 0, 0, 0)
 
 
+WIDE_CASES = [
+    # B, C, T, M, taps: the M-split ("wide") form of conv_gemm (conv_body.h: MS) -- 2 / 4 / 8 row tiles per workgroup, ragged last row group,
+    # M off the 32-row grid, ragged last column tile, K not a multiple of the group (partial last phase), K shorter than one phase
+    (2, 64, 64, 64, 3), (1, 48, 40, 96, 3), (2, 32, 36, 80, 1), (1, 160, 72, 160, 3), (1, 16, 64, 272, 1), (3, 208, 32, 128, 1), (1, 144, 64, 320, 3),
+]
+
+
+@pytest.mark.parametrize("B,C,T,M,taps", WIDE_CASES)
+def test_conv1d_wide_tiles(lib, monkeypatch, B, C, T, M, taps):
+    """MUGD_CONV_WIDE=1 forces the M-split form wherever it exists: the waves of a workgroup own different row tiles and share every staged
+    window.  Plain conv + bias + residual, GroupNorm(+SiLU) / LayerNorm operand transforms, gated epilogues -- same results."""
+    monkeypatch.setenv("MUGD_CONV_WIDE", "1")
+    pad = (taps - 1) // 2
+    x, w, b = rnd(7, B, C, T), rnd(8, M, C, taps, scale=1.0 / math.sqrt(C * taps)), 0.1 * rnd(9, M)
+    ref = F.conv1d(x, w, b, 1, pad)
+    resid = rnd(10, *ref.shape)
+    lib.set_conv_tiling(0, 32)
+    try:
+        close(lib.op_conv1d(x, w, b, resid, dil=1, stride=1, pad=pad, Tout=T), ref + resid, 2e-5, what="wide conv1d")
+        if T % 4 == 0:
+            test_norm_conv1d_fused(lib, B, C, T, M, taps, 1, 1, 16, 1, 0)
+            if taps == 1:
+                test_norm_conv1d_fused(lib, B, C, T, M, 1, 1, 2, 0, 0, 0)
+    finally:
+        lib.set_conv_tiling(0, 0)
+
+
+@pytest.mark.parametrize("epi", [1, 2])
+def test_conv1d_gated_wide(lib, monkeypatch, epi):
+    monkeypatch.setenv("MUGD_CONV_WIDE", "1")
+    lib.set_conv_tiling(0, 32)
+    try:
+        test_conv1d_gated(lib, epi)
+    finally:
+        lib.set_conv_tiling(0, 0)
+
+
 @pytest.mark.parametrize("tn", [16, 32])
 @pytest.mark.parametrize("epi", [1, 2])
 def test_conv1d_gated_tile_widths(lib, tn, epi):
