@@ -269,10 +269,17 @@ void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
     bool tall = false;
     if (const char* e = getenv("MUGD_CONV_TALL")) tall = e[0] == '1' && !dual && a.epi == EPI_NONE && kind != 2 && !a.w16 && gy >= 2;
     if (tall) gy = (gy + 1) / 2;
-    // M-split ("wide") form: MUGD_CONV_WIDE=1 wherever it exists (plain fast windows, fp32 weights, >= 2 row tiles, not the score epilogue)
-    if (const char* e = getenv("MUGD_CONV_WIDE")) {
-        if (e[0] == '1' && !tall && kind == 0 && !a.w16 && a.epi != EPI_XSOFTMAX && gy >= 2) {
-            const int nw = gy >= 8 ? 8 : gy >= 4 ? 4 : 2;
+    // M-split ("wide") form (conv_body.h: MS; plain fast windows, fp32 weights, >= 2 row tiles, not the score epilogue).  Chosen where the
+    // per-launch table says it wins (profiles/r4_wide_ab.txt): tall M (>= 2 groups of 8 row tiles: 8-wave workgroups), short K (<= 32 chunks: the
+    // q/k/v and GEGLU projections) and enough workgroups that way (>= 160: batch 8 upwards); and the K = 48 input conv, whose K-split form is one
+    // wave per tile.  The long-K launches lose a wave per SIMD in this form and stay K-split.  MUGD_CONV_WIDE=1 forces it wherever it exists, =0 never.
+    {
+        const bool can = !tall && kind == 0 && !a.w16 && a.epi != EPI_XSOFTMAX && gy >= 2 && a.wk <= 0 && !getenv("MUGD_CONV_WK");      // a forced K-split wins
+        const int nw = gy >= 8 ? 8 : gy >= 4 ? 4 : 2;
+        const long long wgs = (long long)cdiv(gy, nw) * gx * gz;
+        bool wide = can && ((gy >= 16 && a.nchunk <= 32 && wgs >= 160) || (gy >= 4 && a.nchunk <= 4 && wgs >= 128));
+        if (const char* e = getenv("MUGD_CONV_WIDE")) wide = can && e[0] == '1';
+        if (wide) {
 #define MUGD_WIDE(N) case N: if (dual) launch_wide<N, true>(st, a, gx, gy, gz); else launch_wide<N, false>(st, a, gx, gy, gz); break;
             switch (nw) { MUGD_WIDE(2) MUGD_WIDE(4) MUGD_WIDE(8) }
 #undef MUGD_WIDE
