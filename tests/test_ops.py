@@ -187,6 +187,22 @@ def test_conv1d_wide_tiles(lib, monkeypatch, B, C, T, M, taps):
         lib.set_conv_tiling(0, 0)
 
 
+def test_conv1d_shape_the_host_rule_sends_to_the_wide_form(lib, monkeypatch):
+    """launch_conv_gemm picks the M-split form by itself for tall-M / short-K launches with >= 160 workgroups (k_conv.hip): such a shape,
+    default settings, against the reference convolution -- and the K-split form of the same launch (MUGD_CONV_WIDE=0) agrees."""
+    B, C, T, M = 8, 32, 320, 512              # 16 row tiles -> 2 groups of 8, 10 column tiles, batch 8: 160 workgroups; K = 2 chunks
+    x, w, b = rnd(31, B, C, T), rnd(32, M, C, 1, scale=1.0 / math.sqrt(C)), 0.1 * rnd(33, M)
+    ref = F.conv1d(x, w, b)
+    lib.set_conv_tiling(0, 32)
+    try:
+        got = lib.op_conv1d(x, w, b)
+        close(got, ref, 2e-5, what="rule-selected form")
+        monkeypatch.setenv("MUGD_CONV_WIDE", "0")
+        close(lib.op_conv1d(x, w, b), got, 2e-6, what="K-split form of the same launch")
+    finally:
+        lib.set_conv_tiling(0, 0)
+
+
 @pytest.mark.parametrize("epi", [1, 2])
 def test_conv1d_gated_wide(lib, monkeypatch, epi):
     monkeypatch.setenv("MUGD_CONV_WIDE", "1")
