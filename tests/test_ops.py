@@ -198,7 +198,7 @@ def test_conv1d_shape_the_host_rule_sends_to_the_wide_form(lib, monkeypatch):
         got = lib.op_conv1d(x, w, b)
         close(got, ref, 2e-5, what="rule-selected form")
         monkeypatch.setenv("MUGD_CONV_WIDE", "0")
-        close(lib.op_conv1d(x, w, b), got, 2e-6, what="K-split form of the same launch")
+        close(lib.op_conv1d(x, w, b), got.detach().cpu(), 2e-6, what="K-split form of the same launch")
     finally:
         lib.set_conv_tiling(0, 0)
 
