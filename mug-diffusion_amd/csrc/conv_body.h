@@ -739,15 +739,21 @@ constexpr int conv_lds_bytes() { return ConvLds<WK, DUAL, TN>::BYTES; }
 //       (weights: each wave streams both row tiles' fragments).  For launches with enough tiles to fill the chip at half the count
 //       (launch_conv_gemm); mt must be even, a missing last row tile (odd tile count) is computed on clamped weights and not stored.
 // TN: 32 | 16 output samples per tile (ConvGeo); the 16-wide tiles exist for KIND 0 without TALL.
-// MS ("M-split", launch_conv_gemm: wide): the WK waves own WK consecutive ROW tiles mt .. mt + WK - 1 of the same 32 columns instead of WK
+// MS ("M-split", launch_conv_gemm: wide) = 1: the WK waves own WK consecutive ROW tiles mt .. mt + WK - 1 of the same 32 columns instead of WK
 //       slices of K: every wave walks the whole K axis with its own weight stream, the windows are staged once per workgroup
 //       (run_segment_vec<COOP>), there is no K-split combine and every wave finishes its whole 32 x 32 tile itself.  For launches with enough
 //       column tiles to fill the chip that way (large batch); KIND 0, 32-wide tiles.
-template <int WK, bool DUAL, int KIND, int NITG, class WT, bool TALL = false, class A = ConvArgs, int TN = CONV_TN, bool MS = false>
+// MS = 2 (opt-in, MUGD_CONV_WIDE=2; NOT yet measured on hardware): M-split x K-split -- WK = NR row tiles x 2 K-slices; the NR waves of a K-slice
+//       share that slice's windows, the two partial tiles of a row tile are combined through LDS like the K-split form's.  Keeps two waves per
+//       SIMD on launches with few row tiles ("what comes next").
+template <int WK, bool DUAL, int KIND, int NITG, class WT, bool TALL = false, class A = ConvArgs, int TN = CONV_TN, int MS = 0>
 __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b, const int t0, const int rot, const int tid, char* lds, const bool live) {
     static_assert(!(DUAL && TALL), "gated layers already share their windows between two row sets");
     static_assert(TN == 32 || (KIND == 0 && !TALL), "16-wide tiles: plain fast-window kernels only");
     static_assert(!MS || (KIND == 0 && TN == 32 && !TALL && WK >= 2), "M-split: plain fast-window kernels, 32-wide tiles");
+    constexpr int KS = MS > 0 ? MS : 1;             // M-split: K-slices inside the workgroup
+    constexpr int NR = MS > 0 ? WK / KS : 1;        // M-split: row tiles per workgroup
+    static_assert(!MS || (NR * KS == WK && NR % 2 == 0), "M-split: WK = row tiles x K-slices, an even number of row tiles");
     constexpr bool A2 = DUAL || TALL;               // two weight streams / two accumulators per wave
     typedef ConvGeo<TN> G;
     typedef ConvLds<WK, A2, TN> L;
@@ -772,13 +778,13 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
     TL_STAMP(11);
 
     // K-slice of this wave: chunk boundaries balanced by cost on the host (a 3-tap chunk is ~2x a 1x1 chunk); M-split: all of K
+    const int wr = MS ? wave % NR : 0;             // M-split: this wave's row tile inside the group ...
+    const int wks = MS ? wave / NR : wave;         // ... and its K-slice; K-split form: the wave IS the K-slice
     int g0 = a.kb[0], g1 = a.kb[1];          // constant kernarg offsets + selects: no dependent scalar load
-    if (!MS) {
 #pragma unroll
-        for (int w = 1; w < WK; ++w)
-            if (wave == w) { g0 = a.kb[w]; g1 = a.kb[w + 1]; }
-    }
-    const int mtw = MS ? mt + wave : mt;           // this wave's row tile
+    for (int w = 1; w < (MS ? KS : WK); ++w)
+        if (wks == w) { g0 = a.kb[w]; g1 = a.kb[w + 1]; }
+    const int mtw = MS ? mt + wr : mt;             // this wave's row tile
     const int mtc = (MS && mtw >= gy) ? gy - 1 : mtw;      // M-split, ragged last group: a wave without a row tile computes on clamped weights, stores nothing
 
     ConvAcc<TN> ac;                              // values, second row set, and the 2^11-scaled cross terms of the H3 arithmetic
@@ -788,13 +794,14 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
     const bool has2 = !TALL || mt + 1 < gy;        // TALL: the second row tile exists
     const WT* wtile2 = DUAL ? wtile + (size_t)(a.Mout >> 5) * a.w_mt_stride : (TALL && has2) ? wtile + a.w_mt_stride : wtile;
     char* smem_bytes = lds;
-    const int wave_base = MS ? 0 : wave * G::WAVE_LDS * 4;
+    const int wave_base = MS ? wks * (2 * NR * G::WIN_LDS * 4) : wave * G::WAVE_LDS * 4;      // M-split: the K-slice's set of 2 x NR shared windows
 
     const float gn_inv_cg = a.gn_groups ? 1.0f / (float)a.gn_cg : 0.f;
 
     // ---- epilogue operands: the side loads (bias / row term / residual) are issued HERE, before the K loop, from
     // clamped addresses under wave-uniform conditions, so their latency is off the kernel's critical path.
-    constexpr int EPT = MS ? NREG : NREG / WK;       // tile rows (accumulator registers) finished by each wave
+    constexpr int EPT = MS ? NREG / KS : NREG / WK;  // tile rows (accumulator registers) finished by each wave
+    const int rbase = wks * EPT;                     // ... starting with this one
     float bv[EPT], bg[EPT], ra[EPT], rsv[EPT];
     size_t oo[EPT];
     int mm[EPT];
@@ -807,7 +814,7 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
     bool valid2[EPT2];
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
-        const int r = MS ? q : wave * EPT + q;
+        const int r = rbase + q;
         const int row = G::row(r, lane);
         const int m = mtw * 32 + row, t = t0 + cl;
         valid[q] = live && (m < a.Mout) && (t < a.Tout);
@@ -853,8 +860,8 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
             if (lo < hi) {
                 const WT* w1 = wtile + s.woff;
                 const WT* w2 = wtile2 + s.woff;
-#define MUGD_SEG_VARGS s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, ac, stl.gnst, stl.lnst, gn_inv_cg, rot, wave
-#define MUGD_COOP , WT, typename std::remove_cv<typename std::remove_reference<decltype(s)>::type>::type, (MS ? WK : 0)
+#define MUGD_SEG_VARGS s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, ac, stl.gnst, stl.lnst, gn_inv_cg, rot, wr
+#define MUGD_COOP , WT, typename std::remove_cv<typename std::remove_reference<decltype(s)>::type>::type, (MS ? NR : 0)
                 if constexpr (KIND == 0) {
                     // specialise on (transform, activation): branch-free chunk loops
 #define MUGD_SEG_XF(T, NHALO)                                                                     \
@@ -888,11 +895,32 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
         }
     }
 
+    if (MS && KS > 1) {
+        // the K-slices of an M-split workgroup run different numbers of phases (different chunk counts, different segments), and every phase
+        // ends in a WORKGROUP barrier: the slice with fewer of them arrives the difference here
+        int mine = 0, most = 0;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            int nb = 0;
+#pragma unroll
+            for (int si = 0; si < CONV_MAXSEG; ++si) {
+                if (si < a.nseg) {
+                    const int c0 = a.seg[si].chunk0, c1 = c0 + a.seg[si].C / CONV_CK;
+                    const int lo = a.kb[kk] > c0 ? a.kb[kk] : c0, hi = a.kb[kk + 1] < c1 ? a.kb[kk + 1] : c1;
+                    if (lo < hi) nb += 1 + (hi - lo + NR - 1) / NR;
+                }
+            }
+            most = nb > most ? nb : most;
+            if (kk == wks) mine = nb;
+        }
+        for (int e = mine; e < most; ++e) __syncthreads();
+    }
     if (conv_h3<WT>()) ac.fold_cross(A2);           // H3: fold the scaled cross terms in
     // ---- combine the WK K-slices through LDS (exchange region behind the staging windows)
     TL_STAMP(3);
     float acc_v[EPT], acc_g[EPT];
-    if (WK > 1 && !MS) {
+    if ((WK > 1 && !MS) || (MS && KS > 1)) {        // the partial tiles of a row tile: the WK K-slices, or the KS slices of the M-split x K-split form
+        constexpr int NP = MS ? KS : WK;
         float* ex = smem + WIN;
 #pragma unroll
         for (int r = 0; r < NREG; ++r) {
@@ -902,18 +930,19 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
-            const int r = wave * EPT + q;
+            const int r = rbase + q;
             acc_v[q] = 0.f;
             acc_g[q] = 0.f;
 #pragma unroll
-            for (int w = 0; w < WK; ++w) {
+            for (int pi = 0; pi < NP; ++pi) {
+                const int w = MS ? wr + NR * pi : pi;          // the waves that hold this row tile's partials
                 acc_v[q] += ex[(w * NREG + r) * 64 + lane];
                 if (A2) acc_g[q] += ex[RED + (w * NREG + r) * 64 + lane];
             }
         }
     } else {
 #pragma unroll
-        for (int q = 0; q < EPT; ++q) { acc_v[q] = ac.get(q); acc_g[q] = ac.get2(q); }
+        for (int q = 0; q < EPT; ++q) { acc_v[q] = ac.get(rbase + q); acc_g[q] = ac.get2(rbase + q); }
     }
     TL_STAMP(4);
     if (!A2 && !MS && a.epi == EPI_XSOFTMAX) {          // folded cross-attention: the tile is one head's key scores (conv_stats.h)
@@ -955,7 +984,7 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
             float s2 = s1 * s1;
 #pragma unroll
             for (int o = 1; o < TN; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-            const int r = MS ? q : wave * EPT + q;
+            const int r = rbase + q;
             const int m = mtw * 32 + G::row(r, lane);
             if (live && cl == 0 && m < a.Mout) {
                 double* o = a.rowstat + 2 * ((size_t)b * a.Mout + m);
@@ -981,17 +1010,30 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
-            const int r = MS ? q : wave * EPT + q;
+            const int r = rbase + q;
             const int m = mtw * 32 + G::row(r, lane);
             const float v = m < a.Mout ? acc_v[q] : 0.f;
             s1 += v; s2 += v * v;
         }
 #pragma unroll
         for (int o = TN; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }      // the lanes that hold the same column
-        if (MS) {                                        // the wave holds its row tile's complete column sums
+        if (MS && KS == 1) {                             // the wave holds its row tile's complete column sums
             if (live && mtw < gy && lane < TN && t0 + cl < a.Tout) {
                 float* o = a.colstat + 2 * (((size_t)b * gy + mtw) * a.Tout + t0 + cl);
                 o[0] = s1; o[1] = s2;
+            }
+            TL_STAMP(6);
+            return;
+        }
+        if (MS) {                                        // M-split x K-split: the KS waves of a row tile each hold a part of its rows
+            if (lane < TN) { cst[0][wave][cl] = s1; cst[1][wave][cl] = s2; }
+            __syncthreads();
+            if (live && wks == 0 && mtw < gy && lane < TN && t0 + cl < a.Tout) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) { t1 += cst[0][wr + NR * kk][cl]; t2 += cst[1][wr + NR * kk][cl]; }
+                float* o = a.colstat + 2 * (((size_t)b * gy + mtw) * a.Tout + t0 + cl);
+                o[0] = t1; o[1] = t2;
             }
             TL_STAMP(6);
             return;

@@ -47,7 +47,7 @@ namespace {
 // One workgroup = one tile: decodes blockIdx into (row tile, batch row, column tile) and runs the shared tile body (conv_body.h).
 // TN = 16: the 32 x 16 tiles of conv_body.h (ConvGeo) -- the same body, half the columns per workgroup.
 // MS: the M-split ("wide") form -- the grid's row axis counts GROUPS of WK row tiles (conv_body.h).
-template <int WK, bool DUAL, int KIND, int NITG, class WT = float, bool TALL = false, int TN = CONV_TN, bool MS = false>
+template <int WK, bool DUAL, int KIND, int NITG, class WT = float, bool TALL = false, int TN = CONV_TN, int MS = 0>
 __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel(const ConvArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[conv_lds_bytes<WK, DUAL || TALL, TN>()];
     TL_BEGIN();
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
     else { mt = fastdiv(lid, a.mgxz, gx * gz); rem = lid - mt * (gx * gz); }
     const int b = fastdiv(rem, a.mgx, gx);
     const int t0 = (rem - b * gx) * TN;
-    conv_tile<WK, DUAL, KIND, NITG, WT, TALL, ConvArgs, TN, MS>(a, TALL ? 2 * mt : MS ? WK * mt : mt, b, t0, rem, (int)threadIdx.x, lds, true);      // TALL / MS: the grid's row axis counts PAIRS / GROUPS of row tiles
+    conv_tile<WK, DUAL, KIND, NITG, WT, TALL, ConvArgs, TN, MS>(a, TALL ? 2 * mt : MS ? (WK / MS) * mt : mt, b, t0, rem, (int)threadIdx.x, lds, true);      // TALL / MS: the grid's row axis counts PAIRS / GROUPS of row tiles
     TL_END(a.tl, WK);
 }
 
@@ -113,16 +113,16 @@ __global__ void pack_weights_kernel(const PackArgs p) {
     }
 }
 
-// M-split form: NW row tiles per workgroup, no K-split (conv_body.h: MS)
-template <int NW, bool DUAL>
+// M-split form: NW / KS row tiles per workgroup, KS K-slices (conv_body.h: MS = KS; 1 = no K-split)
+template <int NW, bool DUAL, int KS = 1>
 void launch_wide(hipStream_t st, const ConvArgs& a0, int gx, int gy, int gz) {
     ConvArgs a = a0;
-    conv_split_k(a, 1);
-    const int gyg = cdiv(gy, NW);
+    conv_split_k(a, KS);
+    const int gyg = cdiv(gy, NW / KS);
     conv_set_grid(a, gx, gyg, gz);
     const dim3 grid((unsigned)gx * gyg * gz);
     a.tl = tl_claim((int)grid.x, NW, 32);
-    hipLaunchKernelGGL((conv_gemm_kernel<NW, DUAL, 0, 1, float, false, 32, true>), grid, dim3(NW * 64), 0, st, a);
+    hipLaunchKernelGGL((conv_gemm_kernel<NW, DUAL, 0, 1, float, false, 32, KS>), grid, dim3(NW * 64), 0, st, a);
 }
 
 template <int WK, bool DUAL>
@@ -278,7 +278,14 @@ void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
         const int nw = gy >= 8 ? 8 : gy >= 4 ? 4 : 2;
         const long long wgs = (long long)cdiv(gy, nw) * gx * gz;
         bool wide = can && ((gy >= 16 && a.nchunk <= 32 && wgs >= 160) || (gy >= 4 && a.nchunk <= 4 && wgs >= 128));
-        if (const char* e = getenv("MUGD_CONV_WIDE")) wide = can && e[0] == '1';
+        if (const char* e = getenv("MUGD_CONV_WIDE")) {
+            wide = can && e[0] == '1';
+            if (can && e[0] == '2' && a.nchunk >= 2) {      // development: M-split x K-split (conv_body.h: MS = 2), not measured on hardware yet
+                if (gy >= 4) { if (dual) launch_wide<8, true, 2>(st, a, gx, gy, gz); else launch_wide<8, false, 2>(st, a, gx, gy, gz); }
+                else { if (dual) launch_wide<4, true, 2>(st, a, gx, gy, gz); else launch_wide<4, false, 2>(st, a, gx, gy, gz); }
+                return;
+            }
+        }
         if (wide) {
 #define MUGD_WIDE(N) case N: if (dual) launch_wide<N, true>(st, a, gx, gy, gz); else launch_wide<N, false>(st, a, gx, gy, gz); break;
             switch (nw) { MUGD_WIDE(2) MUGD_WIDE(4) MUGD_WIDE(8) }

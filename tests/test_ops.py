@@ -167,11 +167,15 @@ WIDE_CASES = [
 ]
 
 
+@pytest.mark.parametrize("mode", ["1", "2"])
 @pytest.mark.parametrize("B,C,T,M,taps", WIDE_CASES)
-def test_conv1d_wide_tiles(lib, monkeypatch, B, C, T, M, taps):
+def test_conv1d_wide_tiles(lib, monkeypatch, B, C, T, M, taps, mode):
     """MUGD_CONV_WIDE=1 forces the M-split form wherever it exists: the waves of a workgroup own different row tiles and share every staged
-    window.  Plain conv + bias + residual, GroupNorm(+SiLU) / LayerNorm operand transforms, gated epilogues -- same results."""
-    monkeypatch.setenv("MUGD_CONV_WIDE", "1")
+    window (= 2: its M-split x K-split variant, two K-slices per workgroup).  Plain conv + bias + residual, GroupNorm(+SiLU) / LayerNorm
+    operand transforms, gated epilogues -- same results."""
+    if mode == "2" and lib.device.type == "cuda":
+        pytest.skip("M-split x K-split: emulator-verified only so far (DESIGN.md 9, what comes next)")
+    monkeypatch.setenv("MUGD_CONV_WIDE", mode)
     pad = (taps - 1) // 2
     x, w, b = rnd(7, B, C, T), rnd(8, M, C, taps, scale=1.0 / math.sqrt(C * taps)), 0.1 * rnd(9, M)
     ref = F.conv1d(x, w, b, 1, pad)
@@ -203,9 +207,12 @@ def test_conv1d_shape_the_host_rule_sends_to_the_wide_form(lib, monkeypatch):
         lib.set_conv_tiling(0, 0)
 
 
+@pytest.mark.parametrize("mode", ["1", "2"])
 @pytest.mark.parametrize("epi", [1, 2])
-def test_conv1d_gated_wide(lib, monkeypatch, epi):
-    monkeypatch.setenv("MUGD_CONV_WIDE", "1")
+def test_conv1d_gated_wide(lib, monkeypatch, epi, mode):
+    if mode == "2" and lib.device.type == "cuda":
+        pytest.skip("M-split x K-split: emulator-verified only so far")
+    monkeypatch.setenv("MUGD_CONV_WIDE", mode)
     lib.set_conv_tiling(0, 32)
     try:
         test_conv1d_gated(lib, epi)
