@@ -89,6 +89,15 @@ int mugd_set_s4_symmetric(mugd_ctx* ctx, int enabled);
  * evaluation: resident in the 256 MB Infinity Cache).  Outputs differ from the fp32 mode by the weight rounding (2^-9 relative
  * per weight); tests/test_nets.py states the flipped-note-cell bound.  Environment default: MUGD_WEIGHTS_BF16=1. */
 int mugd_set_weight_precision(mugd_ctx* ctx, int bf16);
+/* Names the conv / Linear arithmetic the library was built with.  The default build ("conv=f16x3-split MFMA"): fp32 tensors, every product
+ * block on the f16 matrix cores with both operands split into f16 hi + 2^11-scaled lo halves and fp32 accumulation (csrc/conv_body.h: H3;
+ * 2.7e-7 relative to float64 at K = 1024, below an fp32 fma chain's 7.7e-7).  DOMAIN: the whole fp32 range, like the reference
+ * (/root/reference/mug/diffusion/unet.py:27-33 runs fp32 end to end).  Both operands are carried as block floating point -- the weights of a
+ * packed set times one exact power of two, every staged 16-channel chunk of activations times a per-wave power of two that follows the data
+ * (scale changes move the fp32 accumulators by the exact ratio) -- so no operand meets the f16 exponent range: samples down to 2^-14
+ * (typically 2^-22) of their chunk's largest sample keep all 22 bits, smaller ones carry an absolute error below 2^-50 of that maximum; a
+ * weight keeps all 22 bits down to 2^-25 of the set's largest.  Inf / NaN operands propagate to exactly the outputs they reach in fp32.
+ * tests/test_ops.py holds op_conv1d / op_norm_conv1d / log_mel to the unit-scale fp32 tolerance at operand scales 1e-30 .. 1e30. */
 const char* mugd_version(void);
 
 /* ---- networks ------------------------------------------------------------------------- */
@@ -239,8 +248,10 @@ int mugd_op_timestep_embedding(mugd_ctx* ctx, const int64_t* t, float* out, int 
 /* ---- training (BASELINE configs[4]): loss pieces, one forward / backward entry point per block type, AdamW.
  * mug-diffusion_amd/mug/train.py strings them into the whole-model DDPM training step.  None of these entry
  * points synchronises the host: work is enqueued on the context's stream (order it against other streams with mugd_order_*). ---- */
-/* Arithmetic of the training GEMMs (conv / Linear forward, data gradients, weight gradients): 0 (default) fp32-input MFMA -- the
- * parity mode, bitwise an fp32 fma chain; 1 bf16-input MFMA with fp32 accumulation (BASELINE configs[4]: bf16; replaces what the
+/* Arithmetic of the training GEMMs (conv / Linear forward, data gradients, weight gradients): 0 (default) the fp32 parity mode -- forward
+ * and data-gradient GEMMs through conv_gemm (split-f16 operands, fp32-equivalent over the whole fp32 range: mugd_version above; gradients of
+ * 1e-12 keep their precision through the per-wave operand scale), weight gradients on the fp32-input MFMA (k_train.hip); 1 bf16-input MFMA
+ * with fp32 accumulation (BASELINE configs[4]: bf16; replaces what the
  * reference would get from Lightning's `precision: bf16`, main.py / configs/mug/mug_diffusion.yaml:151): operands are rounded to
  * bfloat16 on their way into the matrix cores; master weights, activations in memory, norms, softmax, S4 and reductions stay fp32. */
 int mugd_train_set_precision(mugd_ctx* ctx, int bf16);

@@ -84,7 +84,7 @@ extern "C" {
 #define MUGD_CONV_H3 1
 #endif
 const char* mugd_version(void) {
-    return MUGD_CONV_H3 ? "mugd 0.2 (gfx950, conv=f16x3-split MFMA, fp32-equivalent)" : "mugd 0.2 (gfx950, conv=fp32 MFMA)";
+    return MUGD_CONV_H3 ? "mugd 0.3 (gfx950, conv=f16x3-split MFMA, block-scaled operands: fp32-equivalent over the fp32 range)" : "mugd 0.2 (gfx950, conv=fp32 MFMA)";
 }
 
 int mugd_create(int device, void* stream, mugd_ctx** out) {
@@ -438,8 +438,9 @@ int mugd_op_conv1d(mugd_ctx* ctx, const float* x, const float* w, const float* b
         a.B = B; a.Mrows = M; a.Mout = epi ? M / 2 : M; a.Tout = Tout; a.nchunk = C / CONV_CK; a.epi = epi;
         a.wk = ctx->c.force_wk;
         a.tn = ctx->c.force_tn == 16 ? (conv16_supported(a) ? 16 : 32) : ctx->c.force_tn == 32 ? 32 : conv_pick_tn(a);
-        PackArgs pa{wpk, mts, 0, C, taps, w, C * taps, 0, M, 0, 0};
-        if (a.tn == 16) launch_pack_weights16(st, pa); else launch_pack_weights(st, pa);
+        unsigned* wmax = reinterpret_cast<unsigned*>(sc.get(1, false, st));
+        a.wmax = wmax;
+        pack_weights_scaled(st, PackArgs{wpk, mts, 0, C, taps, w, C * taps, 0, M, 0, 0, wmax}, a.tn);
         launch_conv(st, a);
         HIP_CHECK(hipStreamSynchronize(st));
     });
@@ -477,8 +478,9 @@ int mugd_op_norm_conv1d(mugd_ctx* ctx, const float* x, const float* gamma, const
         a.B = B; a.Mrows = M; a.Mout = M; a.Tout = T + 2 * pad - dil * (taps - 1); a.nchunk = C / CONV_CK; a.epi = EPI_NONE;
         a.wk = wk ? wk : ctx->c.force_wk;
         a.tn = ctx->c.force_tn == 16 ? (conv16_supported(a) ? 16 : 32) : ctx->c.force_tn == 32 ? 32 : conv_pick_tn(a);
-        PackArgs pa{wpk, mts, 0, C, taps, w, C * taps, 0, M, 0, 0};
-        if (a.tn == 16) launch_pack_weights16(st, pa); else launch_pack_weights(st, pa);
+        unsigned* wmax = reinterpret_cast<unsigned*>(sc.get(1, false, st));
+        a.wmax = wmax;
+        pack_weights_scaled(st, PackArgs{wpk, mts, 0, C, taps, w, C * taps, 0, M, 0, 0, wmax}, a.tn);
         launch_conv(st, a);
         HIP_CHECK(hipStreamSynchronize(st));
     });

@@ -53,13 +53,24 @@ struct ConvAcc;
 template <>
 struct ConvAcc<32> {
     f32x16 a, a2, l, l2;
+    float sx;            // H3 domain: the accumulators hold sum (w S_w)(x sx) -- sx = the wave's current activation scale, an exact power of two
+    float sxmin;         // ... and the smallest scale they have been at (bounds how far sx may rise again: h3_pick); both wave-uniform
     __device__ __forceinline__ void zero() {
 #pragma unroll
         for (int i = 0; i < 16; ++i) { a[i] = 0.f; a2[i] = 0.f; l[i] = 0.f; l2[i] = 0.f; }
+        sx = 1.0f; sxmin = 0x1p125f;
     }
-    __device__ __forceinline__ void fold_cross(bool two) {
+    __device__ __forceinline__ void scale_all(float r, bool two) {
+        a *= r; l *= r;
+        if (two) { a2 *= r; l2 *= r; }
+    }
+    // cross terms in, scales out: u = 1 / sx, w = 1 / S_w (two multiplies: either may sit at the edge of the exponent range)
+    __device__ __forceinline__ void fold_cross(bool two, float u, float w) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { a[r] += l[r] * (1.0f / 2048.0f); if (two) a2[r] += l2[r] * (1.0f / 2048.0f); }
+        for (int r = 0; r < 16; ++r) {
+            a[r] = ((a[r] + l[r] * (1.0f / 2048.0f)) * u) * w;
+            if (two) a2[r] = ((a2[r] + l2[r] * (1.0f / 2048.0f)) * u) * w;
+        }
     }
     __device__ __forceinline__ float get(int r) const { return a[r]; }
     __device__ __forceinline__ float get2(int r) const { return a2[r]; }
@@ -67,18 +78,29 @@ struct ConvAcc<32> {
 template <>
 struct ConvAcc<16> {
     f32x4 a[2], a2[2], l[2], l2[2];
+    float sx, sxmin;
     __device__ __forceinline__ void zero() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             a[0][i] = 0.f; a[1][i] = 0.f; a2[0][i] = 0.f; a2[1][i] = 0.f; l[0][i] = 0.f; l[1][i] = 0.f; l2[0][i] = 0.f; l2[1][i] = 0.f;
         }
+        sx = 1.0f; sxmin = 0x1p125f;
     }
-    __device__ __forceinline__ void fold_cross(bool two) {
+    __device__ __forceinline__ void scale_all(float r, bool two) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            a[0][i] += l[0][i] * (1.0f / 2048.0f); a[1][i] += l[1][i] * (1.0f / 2048.0f);
-            if (two) { a2[0][i] += l2[0][i] * (1.0f / 2048.0f); a2[1][i] += l2[1][i] * (1.0f / 2048.0f); }
+        for (int h = 0; h < 2; ++h) {
+            a[h] *= r; l[h] *= r;
+            if (two) { a2[h] *= r; l2[h] *= r; }
         }
+    }
+    __device__ __forceinline__ void fold_cross(bool two, float u, float w) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[h][i] = ((a[h][i] + l[h][i] * (1.0f / 2048.0f)) * u) * w;
+                if (two) a2[h][i] = ((a2[h][i] + l2[h][i] * (1.0f / 2048.0f)) * u) * w;
+            }
     }
     __device__ __forceinline__ float get(int r) const { return a[r >> 2][r & 3]; }
     __device__ __forceinline__ float get2(int r) const { return a2[r >> 2][r & 3]; }
@@ -141,6 +163,65 @@ __device__ __forceinline__ float h3_split(float v) {          // {hi | lo << 16}
 }
 template <class WT>
 constexpr bool conv_h3() { return MUGD_CONV_H3 != 0 && sizeof(WT) == 4; }
+
+// ---------------------------------------------------------------------------------------
+// The DOMAIN of H3 (round 5).  f16 halves carry 11 significant bits over the exponents 2^-14 .. 2^15: an operand above 65504 becomes inf
+// (the tile NaN), operands below ~2^-12 lose their low half to the f16 subnormals.  The reference is fp32 with +-3e38 (unet.py:27-33), so
+// both operands are carried as BLOCK floating point -- times an exact power of two, divided out of the fp32 accumulators at the end:
+//   weights     : S_w = h3_wscale(max |w| of the packed set), applied by the pack kernels (kernels.h), max |w| S_w in [2^13, 2^14);
+//   activations : a per-wave scale sx (ConvAcc::sx).  When a wave parks a chunk (16 channels x the window) it takes the max |v| of the
+//                 samples it holds (4 v_max3 per lane) and asks the wave two questions -- some lane with |v| sx >= 2^15?  no lane with
+//                 |v| sx >= 4? (two v_cmp, one scalar branch) -- and only then leaves the fast path: wave max, a new power of two that puts
+//                 it in [2^10, 2^11), and the accumulators follow by the exact ratio (fp32 x 2^k).  So every chunk is parked with its
+//                 largest sample in [4, 2^15): samples down to 2^-14 (typically 2^-22) of their chunk's maximum keep all 22 bits, smaller
+//                 ones carry an absolute error of 2^-36 / sx -- below 2^-50 of the chunk's maximum.  Chunks and segments of one launch
+//                 differ in scale freely; the K-slices of a tile each carry their own sx and are unscaled before they meet in LDS.
+//                 sx never rises more than 2^64 above the smallest scale the accumulators have seen (they cannot overflow: 2^42 2^64).
+//                 M-split forms: a parked window is shared, so its scale travels with it (one LDS word per window slot); a consumer
+//                 whose accumulators sit at another scale adopts the window's before the MFMAs.
+// Inf / NaN among the operands propagate as they do in fp32 (no scale is derived from them).
+// ---------------------------------------------------------------------------------------
+constexpr float H3_LIM = 32768.0f, H3_LOW = 4.0f;
+#ifndef MUGD_H3_DYN
+#define MUGD_H3_DYN 1          // 0: development A/B arm -- no dynamic activation scale (the round-4 behaviour: operands must sit in the f16 range)
+#endif
+__device__ __forceinline__ bool wave_any(bool c) {
+#ifdef MUGD_EMULATED
+    int f = c ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) f |= __shfl_xor(f, o);
+    return f != 0;
+#else
+    return __builtin_amdgcn_ballot_w64(c) != 0ull;
+#endif
+}
+__device__ __forceinline__ float rfl_f(float v) { return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); }
+// does a chunk whose lane maxima are m leave the band at scale sc?
+__device__ __forceinline__ bool h3_off_band(float m, float sc) {
+    const float ms = m * sc;
+    return wave_any(ms >= H3_LIM) || !wave_any(ms >= H3_LOW);
+}
+// the accumulators move from scale ac.sx to scale s
+template <int TN>
+__device__ __forceinline__ void h3_adopt(ConvAcc<TN>& ac, float s, bool two) {
+    ac.scale_all(h3_pow2_biased(127 + h3_biased_exp(s) - h3_biased_exp(ac.sx)), two);
+    ac.sx = s;
+    ac.sxmin = fminf(ac.sxmin, s);
+}
+// slow path of a park: m = this lane's max |v| of the chunk, sc = the scale the chunk would be parked at.  Returns the scale to park at;
+// adopt: the parking wave is the consumer (K-split forms) -- its accumulators follow at once
+template <int TN>
+__device__ __forceinline__ float h3_pick(ConvAcc<TN>& ac, float m, float sc, bool adopt, bool two) {
+    const float mw = wave_max(m);
+    const int E = h3_biased_exp(mw);
+    if (mw > 0.f && E < 255) {                                       // an all-zero chunk is parked at whatever scale; inf: no scale
+        const float cur = mw * sc;
+        if (!(cur >= H3_LOW && cur < H3_LIM)) sc = fminf(h3_pow2_biased(264 - (E < 1 ? 1 : E)), ac.sxmin * 0x1p64f);      // mw sc in [2^10, 2^11)
+    }
+    sc = rfl_f(sc);
+    if (adopt && sc != ac.sx) h3_adopt(ac, sc, two);
+    return sc;
+}
 
 // BF16 (the reduced-precision mode: bfloat16 weight fragments): the chunk's 8 channels per lane and tap -- A[i = 2 tap + g8] = weights
 // of channels 4 h + j + 8 g8, bf[...] = the same channels of the window -- are exactly the 8 k of ONE v_mfma_f32_32x32x16_bf16 per tap
@@ -306,8 +387,10 @@ __device__ __forceinline__ void conv_mfma(const char* smem_bytes, int rb0, int d
 template <int TN, int TAPS, bool DUAL, int NH, int XFK = -1, int ACT = -1, bool PIPE = false, class WT = float, class SEG = ConvSeg, int COOP = 0>
 __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, const WT* wseg2, int lo, int hi,
                                                 int b, int t0, int lane, char* smem_bytes, int wave_base,
-                                                ConvAcc<TN>& ac, const float2* gst, const float2* lnst, float inv_cg, int rot_seed, int coop_wave = 0) {
+                                                ConvAcc<TN>& ac, const float2* gst, const float2* lnst, float inv_cg, int rot_seed, int coop_wave = 0,
+                                                float* wsc = nullptr) {
     typedef ConvGeo<TN> G;
+
     constexpr int RSV = G::RS;
     constexpr int XV = TN / 16;                            // aligned float4 per lane and chunk (lane (row = lane / 4, q = lane % 4))
     constexpr int SPL = 4 * XV;                            // interior samples per lane
@@ -400,7 +483,7 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
     };
     auto load_gb = [&](int cr) -> float2 { return load_gb2(cr, gbg); };
     // transform the staged samples and park them in window `wofs` (byte offset 0 | WIN_LDS*4)
-    auto park_v = [&](int wofs, const float4 (&xq)[XV], const float (&xhh)[NHA], const float2 gbq, const int ggq) {
+    auto park_v = [&](int wofs, const float4 (&xq)[XV], const float (&xhh)[NHA], const float2 gbq, const int ggq, const int slot = 0) {
         float v[SPL];
         float vh[NHA];
 #pragma unroll
@@ -426,11 +509,19 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
                 for (int j = 0; j < NH; ++j) vh[j] = silu_fast(vh[j]);
             }
         }
-        if (conv_h3<WT>()) {                            // H3: the window holds the {hi | lo} f16 halves of every sample (0.f is {0 | 0})
+        if (conv_h3<WT>()) {                            // H3: the window holds the {hi | lo} f16 halves of every SCALED sample (0.f is {0 | 0})
+            float m = 0.f;
 #pragma unroll
-            for (int i = 0; i < SPL; ++i) v[i] = h3_split(v[i]);
+            for (int i = 0; i < SPL; ++i) m = fmaxf(m, fabsf(v[i]));
 #pragma unroll
-            for (int j = 0; j < NH; ++j) vh[j] = h3_split(vh[j]);
+            for (int j = 0; j < NH; ++j) m = fmaxf(m, fabsf(vh[j]));
+            float sc = ac.sx;
+            if (MUGD_H3_DYN && h3_off_band(m, sc)) sc = h3_pick<TN>(ac, m, sc, COOP == 0, DUAL);
+#pragma unroll
+            for (int i = 0; i < SPL; ++i) v[i] = h3_split(v[i] * sc);
+#pragma unroll
+            for (int j = 0; j < NH; ++j) vh[j] = h3_split(vh[j] * sc);
+            if (COOP > 0 && lane == 0) wsc[slot] = sc;   // M-split: the window's scale travels with it
         }
 #pragma unroll
         for (int x = 0; x < XV; ++x) {                  // zero padding AFTER the transform (component selects: no scratch)
@@ -468,7 +559,7 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
         if (1 < nch) fetch_a(1, 1);
         finish_ln();
         if (coop_wave < nch) {
-            park_v(coop_wave * W1, RX, RXH, RGB, RGG);
+            park_v(coop_wave * W1, RX, RXH, RGB, RGG, coop_wave);
             if (coop_wave + COOP < nch) fetch_x(coop_wave + COOP);
         }
         __syncthreads();
@@ -481,11 +572,15 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
             for (int j = 0; j < COOP; ++j) {
                 const int k = ph * COOP + j;
                 if (k < nch) {
+                    if (conv_h3<WT>()) {                    // the window was parked at ITS wave's scale: the accumulators follow
+                        const float ws = rfl_f(wsc[buf * COOP + j]);
+                        if (ws != ac.sx) h3_adopt<TN>(ac, ws, DUAL);
+                    }
                     conv_mfma<TN, TAPS, DUAL, WT>(smem_bytes + (buf * COOP + j) * W1, rb0, s.dil, RA[j & 1], RA2[j & 1], ac);
                     if (k + 2 < nch) fetch_a(k + 2, j & 1);
                 }
                 if (j == 0 && kn < nch) {                   // under the first chunk's MFMAs: the next phase's window, into the other buffer
-                    park_v(((buf ^ 1) * COOP + coop_wave) * W1, RX, RXH, RGB, RGG);
+                    park_v(((buf ^ 1) * COOP + coop_wave) * W1, RX, RXH, RGB, RGG, (buf ^ 1) * COOP + coop_wave);
                     if (kn + COOP < nch) fetch_x(kn + COOP);
                 }
             }
@@ -613,8 +708,7 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
 // ---------------------------------------------------------------------------------------
 template <int TAPS, bool DUAL, int NIT, bool XF, class SEG = ConvSeg>
 __device__ __forceinline__ void run_segment_gen(const SEG& s, const float* wseg, const float* wseg2, int lo, int hi,
-                                                int b, int t0, int lane, int h, int n, char* smem_bytes, int wave_base,
-                                                f32x16& acc, f32x16& acc2, f32x16& accL, f32x16& acc2L) {
+                                                int b, int t0, int lane, int h, int n, char* smem_bytes, int wave_base, ConvAcc<32>& ac) {
     const int RW = 31 * s.stride + (TAPS - 1) * s.dil + 1;
     const float inv = 1.0f / (float)RW;
     const int last = CONV_CK * RW - 1;
@@ -677,9 +771,14 @@ __device__ __forceinline__ void run_segment_gen(const SEG& s, const float* wseg,
                 for (int k = 0; k < NIT; ++k) v[k] = silu_f(v[k]);
             }
         }
-        if (conv_h3<float>()) {
+        if (conv_h3<float>()) {                        // H3 domain: as park_v of the fast path
+            float m = 0.f;
 #pragma unroll
-            for (int k = 0; k < NIT; ++k) v[k] = h3_split(v[k]);
+            for (int k = 0; k < NIT; ++k) m = fmaxf(m, fabsf(v[k]));
+            float sc = ac.sx;
+            if (MUGD_H3_DYN && h3_off_band(m, sc)) sc = h3_pick<32>(ac, m, sc, true, DUAL);
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) v[k] = h3_split(v[k] * sc);
         }
 #pragma unroll
         for (int k = 0; k < NIT; ++k) *reinterpret_cast<float*>(smem_bytes + loff[k]) = ok[k] ? v[k] : 0.f;
@@ -697,7 +796,7 @@ __device__ __forceinline__ void run_segment_gen(const SEG& s, const float* wseg,
                 for (int k = 0; k < NIT; ++k) gbr[k] = *reinterpret_cast<const float2*>(gb + 2 * rowk[k]);
             }
         }
-        mfma_chunk<TAPS, DUAL>(smem_bytes, rb0, s.dil, A, A2, acc, acc2, accL, acc2L);
+        mfma_chunk<TAPS, DUAL>(smem_bytes, rb0, s.dil, A, A2, ac.a, ac.a2, ac.l, ac.l2);
         wave_sync();
     };
 
@@ -845,6 +944,23 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
         }
     };
     if (PRELOAD) load_side();
+    // H3 domain: 1 / S_w of the packed weight set.  A VECTOR load on purpose (the index is laundered through a VGPR): the word is cold (its
+    // own line, last written when the set was packed) and a scalar load of it shares lgkmcnt with the LDS traffic and the kernel-argument
+    // loads -- the first LDS wait of every wave would sit out a trip to memory (measured: +1.1 us per launch, profiles/r5_h3_domain_ab.txt);
+    // as a vector load it returns in order with the statistics / epilogue operands requested around it, which are just as cold.
+    float winv = 1.0f;
+#ifndef MUGD_H3_WLOAD
+#define MUGD_H3_WLOAD 2
+#endif
+    if (conv_h3<WT>() && MUGD_H3_WLOAD && a.wmax) {
+#if MUGD_H3_WLOAD == 2 && !defined(MUGD_EMULATED)
+        int zi = 0;
+        asm volatile("" : "+v"(zi));
+        winv = h3_pow2_recip(h3_wscale(a.wmax[zi]));
+#else
+        winv = h3_pow2_recip(h3_wscale(*to_const_as(a.wmax)));
+#endif
+    }
     TL_STAMP(12);
     stats.finish(a, b, t0, tid, stl);      // reduce + workgroup barrier(s): the requests went out before the index math above
     TL_STAMP(1);
@@ -860,7 +976,7 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
             if (lo < hi) {
                 const WT* w1 = wtile + s.woff;
                 const WT* w2 = wtile2 + s.woff;
-#define MUGD_SEG_VARGS s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, ac, stl.gnst, stl.lnst, gn_inv_cg, rot, wr
+#define MUGD_SEG_VARGS s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, ac, stl.gnst, stl.lnst, gn_inv_cg, rot, wr, stl.wsc + (MS ? wks * 2 * NR : 0)
 #define MUGD_COOP , WT, typename std::remove_cv<typename std::remove_reference<decltype(s)>::type>::type, (MS ? NR : 0)
                 if constexpr (KIND == 0) {
                     // specialise on (transform, activation): branch-free chunk loops
@@ -885,8 +1001,8 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
                     if constexpr (sizeof(WT) == 4 && TN == 32) {          // the generic windows exist with fp32 weights and 32-wide tiles only
                         const float* f1 = reinterpret_cast<const float*>(w1);
                         const float* f2 = reinterpret_cast<const float*>(w2);
-                        if (s.taps == 3) run_segment_gen<3, A2, NITG, (NITG <= 9)>(s, f1, f2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, ac.a, ac.a2, ac.l, ac.l2);
-                        else run_segment_gen<1, A2, NITG, (NITG <= 9)>(s, f1, f2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, ac.a, ac.a2, ac.l, ac.l2);
+                        if (s.taps == 3) run_segment_gen<3, A2, NITG, (NITG <= 9)>(s, f1, f2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, ac);
+                        else run_segment_gen<1, A2, NITG, (NITG <= 9)>(s, f1, f2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, ac);
                     }
                 }
 #undef MUGD_SEG_VARGS
@@ -915,7 +1031,7 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
         }
         for (int e = mine; e < most; ++e) __syncthreads();
     }
-    if (conv_h3<WT>()) ac.fold_cross(A2);           // H3: fold the scaled cross terms in
+    if (conv_h3<WT>()) ac.fold_cross(A2, h3_pow2_recip(ac.sx), winv);      // H3: fold the scaled cross terms in, divide the two operand scales out
     // ---- combine the WK K-slices through LDS (exchange region behind the staging windows)
     TL_STAMP(3);
     float acc_v[EPT], acc_g[EPT];

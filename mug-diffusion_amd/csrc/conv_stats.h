@@ -34,6 +34,7 @@ struct WgStats {
         float2 gnst[32];                                  // GroupNorm {mean, rstd} per group
         float2 lnst[TN];                                  // LayerNorm {mean, rstd} per tile column
         float2 lnred[NTHR];                               // LayerNorm exchange [part][column]
+        float wsc[2 * WK];                                // M-split forms under H3: the scale each shared window was parked at (conv_body.h)
     };
 
     bool pending = false;

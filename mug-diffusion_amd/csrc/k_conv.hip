@@ -1,4 +1,4 @@
-// conv_gemm: conv1d / linear layers as an implicit GEMM on the gfx950 fp32 matrix cores.
+// conv_gemm: conv1d / linear layers as an implicit GEMM on the gfx950 matrix cores (fp32 tensors; f16 MFMA on split operands, fp32 accumulation).
 //
 // One workgroup = WK wavefronts = one 32(rows) x 32(samples) output tile of one batch row; the
 // WK waves split the reduction (K) axis between them (intra-workgroup split-K, combined through
@@ -24,9 +24,11 @@
 //                     their way into LDS, so the normalised tensor never exists in memory.
 //                     Zero padding is applied AFTER the transform, as in the reference (conv pads
 //                     the normalised tensor).
-//   v_mfma_f32_32x32x2_f32: lane (h,r) supplies A[row r][k=h], lane (h,n) supplies B[k=h][col n];
-//   the K order inside a chunk is permuted to (k=h -> channel 4h+j) so a lane's float4 of
-//   weights is used by 4 consecutive MFMAs.  fp32 in, fp32 accumulate: bitwise an fma chain.
+//   products:       since round 4 on the f16 matrix cores with split operands (conv_body.h: H3 -- three v_mfma_f32_32x32x16_f16 per
+//                     32 x 32 x 16 block, fp32 accumulation), since round 5 with both operands block-scaled so that the result is
+//                     fp32-equivalent over the whole fp32 range (conv_body.h: "The DOMAIN of H3").  The -DMUGD_CONV_H3=0 build keeps the
+//                     round 1-3 arithmetic: v_mfma_f32_32x32x2_f32, lane (h,r) supplies A[row r][k=h], lane (h,n) supplies B[k=h][col n],
+//                     the K order inside a chunk permuted to (k=h -> channel 4h+j) so a lane's float4 of weights feeds 4 consecutive MFMAs.
 //
 // Workgroups are renumbered so that each XCD (private L2) owns a contiguous range of row tiles,
 // i.e. of the weight stream.
@@ -80,8 +82,34 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
     TL_END(a.tl, WK);
 }
 
+// bits of max |w| over a block of a packed set (PackArgs::wmax, zeroed by the caller): grid-stride max, wave + workgroup reduction, one atomic
+__global__ void weight_absmax_kernel(const PackArgs p) {
+    __shared__ float red[4];
+    const long long total = (long long)p.rows * p.C * p.taps;
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % p.taps);
+        const long long q = i / p.taps;
+        const int ci = (int)(q % p.C);
+        const long long ms = q / p.C;
+        const float wv = fabsf(p.src[ms * p.src_ld + (long long)(p.src_ci_off + ci) * p.taps + tap]);
+        m = wv > m || wv != wv ? wv : m;                  // a NaN sticks: the set is then packed unscaled (h3_wscale) and the NaN propagates as in fp32
+    }
+    // bit patterns of non-negative floats (and of +NaN above them all) order like unsigned integers
+    unsigned u = __float_as_uint(m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned v = (unsigned)__shfl_xor((int)u, o); u = v > u ? v : u; }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = __uint_as_float(u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { const unsigned v = __float_as_uint(red[w]); u = v > u ? v : u; }
+        atomicMax(p.wmax, u);
+    }
+}
+
 __global__ void pack_weights_kernel(const PackArgs p) {
     const long long total = (long long)p.rows * p.C * p.taps;
+    const float wsc = (MUGD_CONV_H3 && !p.w16 && p.wmax) ? h3_wscale(*p.wmax) : 1.0f;      // H3 domain (conv_body.h)
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int tap = (int)(i % p.taps);
         const long long q = i / p.taps;
@@ -94,7 +122,7 @@ __global__ void pack_weights_kernel(const PackArgs p) {
         const int lane = hh * 32 + r;
         const long long d = (long long)mt * p.w_mt_stride + p.seg_woff + (long long)chunk * (p.taps * 512) +
                             (tap * 2 + g8) * 256 + lane * 4 + j;
-        const float wv = p.src[(long long)ms * p.src_ld + (long long)(p.src_ci_off + ci) * p.taps + tap];
+        const float wv = p.src[(long long)ms * p.src_ld + (long long)(p.src_ci_off + ci) * p.taps + tap] * wsc;
         if (p.w16) {
             const unsigned u = __float_as_uint(wv);
             reinterpret_cast<unsigned short*>(p.dst)[d] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);      // round to nearest even
@@ -150,6 +178,7 @@ void launch_wk(hipStream_t st, const ConvArgs& a0, dim3 grid, int gx, int gy, in
 // The 16-wide tiles' fragment order (conv_body.h: mfma_chunk16): per (tap, row half) [lane = kq * 16 + r][kg] = W[16 half + r][4 kg + kq].
 __global__ void pack_weights16_kernel(const PackArgs p) {
     const long long total = (long long)p.rows * p.C * p.taps;
+    const float wsc = (MUGD_CONV_H3 && !p.w16 && p.wmax) ? h3_wscale(*p.wmax) : 1.0f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int tap = (int)(i % p.taps);
         const long long q = i / p.taps;
@@ -162,7 +191,7 @@ __global__ void pack_weights16_kernel(const PackArgs p) {
         const int lane = kq * 16 + r;
         const long long d = (long long)mt * p.w_mt_stride + p.seg_woff + (long long)chunk * (p.taps * 512) +
                             (tap * 2 + half) * 256 + lane * 4 + kg;
-        const float wv = p.src[(long long)ms * p.src_ld + (long long)(p.src_ci_off + ci) * p.taps + tap];
+        const float wv = p.src[(long long)ms * p.src_ld + (long long)(p.src_ci_off + ci) * p.taps + tap] * wsc;
         if (p.w16) {
             const unsigned u = __float_as_uint(wv);
             reinterpret_cast<unsigned short*>(p.dst)[d] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);      // round to nearest even
@@ -309,6 +338,23 @@ void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
         default: MUGD_CHECK(false, -2, "conv_gemm: K-split must be 1, 2, 4 or 8");
     }
 #undef MUGD_WK
+}
+
+void launch_weight_absmax(hipStream_t st, const PackArgs& a) {
+    if (!MUGD_CONV_H3 || a.w16 || !a.wmax) return;
+    const long long total = (long long)a.rows * a.C * a.taps;
+    int blocks = (int)((total + 4095) / 4096);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(weight_absmax_kernel, dim3(blocks), dim3(256), 0, st, a);
+}
+
+void pack_weights_scaled(hipStream_t st, const PackArgs& a, int tn) {
+    if (MUGD_CONV_H3 && !a.w16 && a.wmax) {
+        HIP_CHECK(hipMemsetAsync(a.wmax, 0, sizeof(unsigned), st));
+        launch_weight_absmax(st, a);
+    }
+    if (tn == 16) launch_pack_weights16(st, a); else launch_pack_weights(st, a);
 }
 
 void launch_pack_weights(hipStream_t st, const PackArgs& a) {

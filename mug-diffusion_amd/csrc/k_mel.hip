@@ -143,6 +143,7 @@ std::vector<float> mel_filterbank(int sr, int n_fft, int n_mels, int kpad) {
 
 struct MelPlan {
     float* wpk = nullptr;
+    unsigned* wmax = nullptr;     // H3 weight scale word of the packed filterbank (ConvArgs::wmax)
     long long mts = 0;
     int kpad = 0;
 };
@@ -177,8 +178,8 @@ void log_mel(Ctx* ctx, const float* pcm, long long n, int sr, int n_fft, int hop
             const int MT = cdiv(n_mels, 32);
             HIP_CHECK(hipMalloc((void**)&p.wpk, (size_t)MT * p.mts * sizeof(float) + 8192));
             HIP_CHECK(hipMemsetAsync(p.wpk, 0, (size_t)MT * p.mts * sizeof(float) + 8192, st));
-            PackArgs pa{p.wpk, p.mts, 0, kpad, 1, wd, kpad, 0, n_mels, 0, 0};
-            launch_pack_weights(st, pa);
+            HIP_CHECK(hipMalloc((void**)&p.wmax, 256));
+            pack_weights_scaled(st, PackArgs{p.wpk, p.mts, 0, kpad, 1, wd, kpad, 0, n_mels, 0, 0, p.wmax}, 32);
             HIP_CHECK(hipStreamSynchronize(st));
             HIP_CHECK(hipFree(wd));
             it = plans.emplace(key, p).first;
@@ -203,7 +204,7 @@ void log_mel(Ctx* ctx, const float* pcm, long long n, int sr, int n_fft, int hop
     ConvArgs a{};
     a.nseg = 1;
     a.seg[0] = ConvSeg{P, kpad, frames, 1, 1, 1, 0, 0, 0, 0, 0};
-    a.wpk = plan.wpk; a.w_mt_stride = plan.mts; a.y = M;
+    a.wpk = plan.wpk; a.wmax = plan.wmax; a.w_mt_stride = plan.mts; a.y = M;
     a.B = 1; a.Mrows = a.Mout = n_mels; a.Tout = frames; a.nchunk = kpad / CONV_CK; a.epi = EPI_NONE;
     launch_conv_gemm(st, a);
     const long long tot = (long long)n_mels * frames;

@@ -7,7 +7,7 @@
 
 // ---------------------------------------------------------------------------------------
 // conv_gemm: Y[b,m,t] = epi( bias[m] + sum_seg sum_ci sum_tap W[m][ci][tap] * X_seg[b,ci,src(t,tap)] )
-// as an implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain).
+// as an implicit GEMM on the f16 matrix cores with split, block-scaled operands (conv_body.h: H3; fp32-equivalent over the fp32 range).
 //   - up to 4 K-segments (channel concat [h | audio | skip] and the fused 1x1 skip conv are
 //     extra segments: the concat is never materialised);
 //   - per segment: taps 1|3, dilation, stride 1|2, left pad, optional virtual nearest x2 upsample;
@@ -89,6 +89,8 @@ struct ConvArgs {
     const float* xs_rel; const float* xs_cemb;
     int xs_heads, xs_pmax, xs_ntok; float xs_scale;
     int kb[9];               // K-split: wave w of a workgroup reduces the global chunks [kb[w], kb[w+1]); filled by conv_split_k()
+    const unsigned* wmax;    // H3 weights (conv_body.h): device word holding the bits of max |w| over the whole packed set -- the pack kernels
+                             // stored w * h3_wscale(*wmax) (an exact power of two), the epilogue multiplies it back out.  null: unit scale
     unsigned long long* tl;  // development build (-DMUGD_TL) only: per-wave phase records [blocks][waves][TL_WORDS]; null otherwise
 };
 
@@ -155,9 +157,39 @@ struct PackArgs {
     int src_ld, src_ci_off;
     int rows, row_off;
     int w16;                 // 1: dst holds bfloat16 (round to nearest even)
+    unsigned* wmax;          // H3 (fp32 weights): the packed set's max |w| word (ConvArgs::wmax); null: packed unscaled
 };
 void launch_pack_weights(hipStream_t st, const PackArgs& a);        // fragment order of v_mfma_f32_32x32x2_f32
 void launch_pack_weights16(hipStream_t st, const PackArgs& a);      // fragment order of v_mfma_f32_16x16x4_f32 (two row halves)
+// *a.wmax = max(*a.wmax, bits of max |w| over the block a describes) -- run over EVERY block of a packed set (the word zeroed first) before any
+// of them is packed.  Bit patterns of non-negative floats order like the floats: one atomicMax per workgroup
+void launch_weight_absmax(hipStream_t st, const PackArgs& a);
+// the usual sequence for a set made of ONE block: zero the word, reduce, pack (tn = 16 | 32 picks the fragment order)
+void pack_weights_scaled(hipStream_t st, const PackArgs& a, int tn);
+
+// ---------------------------------------------------------------------------------------
+// H3 domain (conv_body.h): the split-f16 arithmetic is exact to fp32 level only while its operands sit inside the f16 exponent range, so
+// both operands are carried times an exact power of two: the weights times h3_wscale(max |w| of the packed set) -- max |w| S in [2^13, 2^14)
+// -- the staged activations times a per-wave dynamic scale.  These helpers turn a magnitude's bit pattern into the scale.
+// ---------------------------------------------------------------------------------------
+__host__ __device__ inline float h3_pow2_biased(int b) {          // 2^(b - 127), b clamped so that the scale AND its reciprocal are normal
+    b = b < 2 ? 2 : (b > 252 ? 252 : b);
+    const unsigned u = (unsigned)b << 23;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+__host__ __device__ inline int h3_biased_exp(float f) {
+    unsigned u;
+    __builtin_memcpy(&u, &f, 4);
+    return (int)((u >> 23) & 0xffu);
+}
+__host__ __device__ inline float h3_pow2_recip(float s) { return h3_pow2_biased(254 - h3_biased_exp(s)); }      // 1 / s for s = 2^k
+__host__ __device__ inline float h3_wscale(unsigned maxbits) {
+    const int E = (int)(maxbits >> 23);
+    if (maxbits == 0u || E >= 255) return 1.0f;                   // all-zero weights, or inf / NaN among them (propagates as in fp32)
+    return h3_pow2_biased(267 - (E < 1 ? 1 : E));                 // 2^(13 - floor(log2 max))
+}
 
 // ---------------------------------------------------------------------------------------
 // GroupNorm (+ optional SiLU) over a virtual channel concat, LayerNorm over channels

@@ -100,6 +100,7 @@ struct ConvSpec {
 
 struct PackedW {
     float* wpk = nullptr;
+    unsigned* wmax = nullptr;      // H3 domain: bits of max |w| over the set (ConvArgs::wmax); null for bfloat16 sets
     float* bias = nullptr;
     long long mt_stride = 0;
     int nchunk = 0;

@@ -496,18 +496,23 @@ const PackedW& Net::get_packed(const ConvSpec& s, int tn, bool w16) {
     pw.mt_stride = woff;
     const int MT = cdiv(s.Mrows, 32);
     pw.wpk = dev_alloc(w16 ? ((size_t)MT * pw.mt_stride + 1) / 2 : (size_t)MT * pw.mt_stride, true);       // bf16: half the bytes
-    for (auto& wb : s.w) {
-        const Param& p = P(wb.name);
-        MUGD_CHECK(p.dtype == 0 && p.shape.size() >= 2, -2, "conv: bad weight tensor " + wb.name);
-        const ConvIn& in = s.in[wb.seg];
-        const int rows = (int)p.shape[0];
-        const int cw = (int)p.shape[1];
-        const int tw = p.shape.size() > 2 ? (int)p.shape[2] : 1;
-        MUGD_CHECK(tw == in.taps, -2, "conv: kernel width mismatch for " + wb.name);
-        MUGD_CHECK(wb.ci_off + in.x.C <= cw && wb.row_off + rows <= s.Mrows, -2, "conv: weight block out of range: " + wb.name);
-        PackArgs pa{pw.wpk, pw.mt_stride, pw.woff[wb.seg], in.x.C, in.taps, (const float*)p.ptr, cw * tw, wb.ci_off, rows, wb.row_off, w16 ? 1 : 0};
-        if (tn == 16) launch_pack_weights16(ctx->stream, pa);
-        else launch_pack_weights(ctx->stream, pa);
+    if (!w16) pw.wmax = reinterpret_cast<unsigned*>(dev_alloc(1, true));
+    // pass 0: max |w| over every block of the set (the H3 weight scale is one power of two per set); pass 1: pack
+    for (int pass = 0; pass < 2; ++pass) {
+        for (auto& wb : s.w) {
+            const Param& p = P(wb.name);
+            MUGD_CHECK(p.dtype == 0 && p.shape.size() >= 2, -2, "conv: bad weight tensor " + wb.name);
+            const ConvIn& in = s.in[wb.seg];
+            const int rows = (int)p.shape[0];
+            const int cw = (int)p.shape[1];
+            const int tw = p.shape.size() > 2 ? (int)p.shape[2] : 1;
+            MUGD_CHECK(tw == in.taps, -2, "conv: kernel width mismatch for " + wb.name);
+            MUGD_CHECK(wb.ci_off + in.x.C <= cw && wb.row_off + rows <= s.Mrows, -2, "conv: weight block out of range: " + wb.name);
+            PackArgs pa{pw.wpk, pw.mt_stride, pw.woff[wb.seg], in.x.C, in.taps, (const float*)p.ptr, cw * tw, wb.ci_off, rows, wb.row_off, w16 ? 1 : 0, pw.wmax};
+            if (pass == 0) launch_weight_absmax(ctx->stream, pa);
+            else if (tn == 16) launch_pack_weights16(ctx->stream, pa);
+            else launch_pack_weights(ctx->stream, pa);
+        }
     }
     if (!s.bias.empty()) {
         pw.bias = dev_alloc(s.Mrows, true);
@@ -533,6 +538,7 @@ const PackedW& Net::get_packed_ext(const ConvSpec& s, int tn) {
         pw.nchunk = K / CONV_CK;
         pw.mt_stride = (long long)pw.nchunk * 512;
         pw.wpk = dev_alloc((size_t)Bn * cdiv(s.Mrows, 32) * pw.mt_stride, true);
+        pw.wmax = reinterpret_cast<unsigned*>(dev_alloc(1, true));
         if (!s.bias.empty()) {
             pw.bias = dev_alloc(s.Mrows, true);
             for (auto& b : s.bias) {
@@ -547,12 +553,16 @@ const PackedW& Net::get_packed_ext(const ConvSpec& s, int tn) {
     {   // per call: (re)pack every batch row's weight set
         const int K = s.in[0].x.C, M = s.Mrows, B = Bn;
         const float* src = s.ext_plain; float* dst = pw.wpk; const long long mts = pw.mt_stride;
+        unsigned* wmax = pw.wmax;
         const long long bstride = (long long)cdiv(M, 32) * mts;
         const bool save = to_pre;
         to_pre = true;
         emit([=](hipStream_t st) {
+            // one H3 weight scale for the B weight sets of the call: max |w| over all of them (the B sets are contiguous rows of src)
+            HIP_CHECK(hipMemsetAsync(wmax, 0, sizeof(unsigned), st));
+            launch_weight_absmax(st, PackArgs{nullptr, 0, 0, K, 1, src, K, 0, B * M, 0, 0, wmax});
             for (int b = 0; b < B; ++b) {
-                PackArgs pa{dst + (size_t)b * bstride, mts, 0, K, 1, src + (size_t)b * M * K, K, 0, M, 0, 0};
+                PackArgs pa{dst + (size_t)b * bstride, mts, 0, K, 1, src + (size_t)b * M * K, K, 0, M, 0, 0, wmax};
                 if (tn == 16) launch_pack_weights16(st, pa); else launch_pack_weights(st, pa);
             }
         }, OP_SMALL, 0, s.key + " pack per-call weights");
@@ -579,7 +589,7 @@ Tensor Net::conv(const ConvSpec& s) {
     a.w16 = (ctx->weights_bf16 && !s.ext_plain && conv_w16_supported(a)) ? 1 : 0;
     const PackedW& pw = s.ext_plain ? get_packed_ext(s, a.tn) : get_packed(s, a.tn, a.w16 != 0);       // the tile width decides the weight fragment order
     for (int i = 0; i < a.nseg; ++i) { a.seg[i].chunk0 = pw.chunk0[i]; a.seg[i].woff = pw.woff[i]; }
-    a.wpk = pw.wpk; a.w_mt_stride = pw.mt_stride; a.bias = pw.bias;
+    a.wpk = pw.wpk; a.wmax = pw.wmax; a.w_mt_stride = pw.mt_stride; a.bias = pw.bias;
     a.w_b_stride = s.ext_plain ? (long long)cdiv(s.Mrows, 32) * pw.mt_stride : 0;
     a.rowadd = s.rowadd; a.rowadd_stride = s.rowadd_stride;
     a.resid = s.resid.p;

@@ -244,8 +244,9 @@ void run_conv_ex(Ctx& c, Scratch& sc, const float* x, const float* w, bool trans
     a.wpk = wpk; a.w_mt_stride = mts; a.bias = bias; a.rowadd = rowadd; a.rowadd_stride = rowadd_stride; a.resid = resid; a.y = y;
     a.B = B; a.Mrows = M; a.Mout = M; a.Tout = Tout > 0 ? Tout : T; a.nchunk = C / CONV_CK; a.epi = EPI_NONE;
     a.tn = conv_pick_tn(a);
-    PackArgs pa{wpk, mts, 0, C, taps, w, C * taps, 0, M, 0, 0};
-    if (a.tn == 16) launch_pack_weights16(st, pa); else launch_pack_weights(st, pa);
+    unsigned* wmax = reinterpret_cast<unsigned*>(sc.get(1, false, st));
+    a.wmax = wmax;
+    pack_weights_scaled(st, PackArgs{wpk, mts, 0, C, taps, w, C * taps, 0, M, 0, 0, wmax}, a.tn);
     launch_conv(st, a);
 }
 void run_conv(Ctx& c, Scratch& sc, const float* x, const float* w, const float* bias, const float* rowadd, int rowadd_stride,

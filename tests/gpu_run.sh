@@ -1,0 +1,101 @@
+#!/bin/bash
+# The ONE GPU-side runner (development tool; run through gpurun from the repo root):
+#     gpurun --timeout 900 -- 'bash tests/gpu_run.sh TAG task [task ...]'
+# Every task appends to gpurun_out/TAG_<task>.log / writes gpurun_out/TAG_<task>.*; what is worth keeping is copied to profiles/ by hand.
+# Tasks (each bounded by its own `timeout`):
+#   ops            pytest tests/test_ops.py -m gpu
+#   suite          the whole -m gpu suite + smoke()
+#   parity         the headline parity transcript (pytest -s -k "headline or ten_minute or ddim_full")
+#   ab:LIB         DDIM step of the in-tree library against tests/var/LIB/libmugd.so, batch 4 / 8 / 16, A/B/A/B (tests/gpu_probe.py --quick)
+#   wide           per-launch tables with MUGD_CONV_WIDE = 0 | 1 | 2 at batch 8 and 16, A/B/A/B
+#   bench          the driver's command (bench.py --gpus 1 --steps 20 --warmup 3)
+#   stats          rocprofv3 --kernel-trace --stats of a short bench run
+#   traffic        FETCH_SIZE / WRITE_SIZE of conv_gemm (separate --pmc passes) -> TAG_conv_traffic.json
+#   mfma           matrix-pipe busy / VALU counters of one U-Net evaluation
+#   instr          executed instructions per wave by class (the r4_pmc_instr_per_wave table)
+#   layers:B       per-launch table of one U-Net / VAE / wave evaluation at batch B (MUGD_PROFILE_CSV)
+#   probe:B        tests/gpu_probe.py at batch B (all pieces of the pipeline)
+#   env:K=V        export K=V for the tasks that follow
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.." || exit 1
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+TAG=$1; shift
+O=gpurun_out/$TAG
+# the library is built in the authoring container and travels with the snapshot; build here only if it is missing
+[ -f mug-diffusion_amd/libmugd.so ] || python mug-diffusion_amd/build.py > ${O}_build.log 2>&1 || { tail -30 ${O}_build.log; exit 1; }
+
+probe_line() { grep -E "ms/step|total \(event|conv_gemm|attention|s4_conv|unet forward"; }
+
+for task in "$@"; do
+  arg=${task#*:}; name=${task%%:*}
+  echo "=== $task"
+  case $name in
+    env) export "$arg" ;;
+    ops)
+      ( time timeout 900 python -m pytest tests/test_ops.py -x -q -m gpu -p no:cacheprovider ) > ${O}_ops.log 2>&1; tail -5 ${O}_ops.log ;;
+    suite)
+      ( time timeout 1500 python -m pytest tests -x -q -m gpu -p no:cacheprovider ) > ${O}_suite.log 2>&1; tail -6 ${O}_suite.log
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > ${O}_smoke.log 2>&1; tail -1 ${O}_smoke.log ;;
+    parity)
+      ( timeout 1200 python -m pytest tests/test_nets.py -q -s -m gpu -p no:cacheprovider -k "headline or ten_minute or ddim_full" ) > ${O}_parity.log 2>&1
+      grep -E "flip|latent|passed|failed|error" ${O}_parity.log | tail -40 ;;
+    ab)
+      : > ${O}_ab_$arg.log
+      for B in 4 8 16; do for v in new $arg new $arg; do
+        echo "== B=$B lib=$v" >> ${O}_ab_$arg.log
+        if [ $v = new ]; then timeout 300 python tests/gpu_probe.py --B $B --quick 2>&1 | probe_line >> ${O}_ab_$arg.log
+        else MUGD_LIB_PATH=$PWD/tests/var/$arg/libmugd.so timeout 300 python tests/gpu_probe.py --B $B --quick 2>&1 | probe_line >> ${O}_ab_$arg.log; fi
+      done; done
+      grep -E "^==|ms/step" ${O}_ab_$arg.log ;;
+    wide)
+      : > ${O}_wide.log
+      for B in 16 8; do for v in 0 1 2 0 1 2; do
+        echo "== B=$B MUGD_CONV_WIDE=$v" >> ${O}_wide.log
+        rm -f ${O}_wide_layers_b${B}_w$v.csv
+        MUGD_CONV_WIDE=$v MUGD_PROFILE_CSV=${O}_wide_layers_b${B}_w$v.csv timeout 300 python tests/gpu_probe.py --B $B --quick 2>&1 | probe_line >> ${O}_wide.log
+      done; done
+      grep -E "^==|ms/step" ${O}_wide.log ;;
+    bench)
+      ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 3 ) > ${O}_bench.log 2>&1; grep '^{' ${O}_bench.log > ${O}_bench.json
+      python - "$O" <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1] + '_bench.json'))
+r = d['roofline']
+print('bench', d['value'], d['unit'], d['ms_per_step'], 'ms; ddim loop', d.get('ddim_loop_ms'), 'clock', d.get('shader_clock_mhz_under_matrix_load'))
+print('roofline', r['achieved'], r['unit'], 'frac', r['frac'], 'avg launch us', r.get('avg_launch_us'), 'traffic', r.get('traffic'))
+for k in ('throughput_mode', 'throughput_mode_4_songs', 'cfg_scale_5', 'training_step', 'training_step_fp32', 'reduced_precision_mode', 'cpu_baseline'):
+    v = d.get(k) or {}
+    print(k, v.get('value'), v.get('unit'), v.get('unet_sample_steps_per_s', ''))
+PY
+      ;;
+    stats)
+      rm -rf /tmp/prof_$TAG
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python $OLDPWD/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-training-step --no-throughput-mode --no-reduced-mode) > ${O}_bench_under_rocprof.log 2>&1
+      f=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1); cp "$f" ${O}_bench_kernel_stats.csv; head -8 ${O}_bench_kernel_stats.csv | cut -c1-180
+      grep '^{' ${O}_bench_under_rocprof.log > ${O}_bench_under_rocprof.json ;;
+    traffic)
+      rm -rf /tmp/pmc_$TAG
+      (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_$TAG/fetch -- python $OLDPWD/tests/gpu_unet_once.py --n 2) > ${O}_pmc_fetch.log 2>&1
+      (cd /tmp && timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_$TAG/write -- python $OLDPWD/tests/gpu_unet_once.py --n 2) > ${O}_pmc_write.log 2>&1
+      python tests/pmc_summary.py /tmp/pmc_$TAG ${O}_conv_traffic.json | tail -8 ;;
+    mfma)
+      rm -rf /tmp/pmcm_$TAG
+      (cd /tmp && timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVES --output-format csv -d /tmp/pmcm_$TAG -- python $OLDPWD/tests/gpu_unet_once.py --n 2) > ${O}_pmc_mfma.log 2>&1
+      python tests/pmc_mfma_summary.py /tmp/pmcm_$TAG ${O}_pmc_unet_mfma.txt | head -14 ;;
+    instr)
+      rm -rf /tmp/pmci_$TAG; : > ${O}_pmc_instr_per_wave.txt
+      for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM" "SQ_WAVES SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_MFMA" "SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY"; do
+        d=/tmp/pmci_$TAG/$(echo $set | tr ' ' '_')
+        (cd /tmp && timeout 300 rocprofv3 --pmc $set --output-format csv -d $d -- python $OLDPWD/tests/gpu_unet_once.py --n 2) >> ${O}_pmc_instr.log 2>&1
+        python tests/pmc_generic_summary.py $d >> ${O}_pmc_instr_per_wave.txt 2>&1
+      done
+      head -60 ${O}_pmc_instr_per_wave.txt ;;
+    layers)
+      rm -f ${O}_per_layer_z512_b$arg.csv
+      MUGD_PROFILE_CSV=${O}_per_layer_z512_b$arg.csv timeout 300 python tests/gpu_probe.py --B $arg > ${O}_probe_b$arg.txt 2>&1
+      grep -E "ddim|vae decode|wave encode|log-mel|unet forward|TFLOP" ${O}_probe_b$arg.txt ;;
+    probe)
+      timeout 300 python tests/gpu_probe.py --B $arg > ${O}_probe_b$arg.txt 2>&1; grep -E "ddim|vae decode|wave encode|log-mel|unet forward|TFLOP" ${O}_probe_b$arg.txt ;;
+    *) echo "unknown task $task" ;;
+  esac
+done

@@ -439,3 +439,148 @@ def test_reference_cli_runs_unchanged_on_the_drop_in(tmp_path, monkeypatch):
     for i in range(2):
         on2(i, job.Unit(audio=0, seed=seed + i, prompt={}), logits[i])
     assert [_sections(p) for p in written2] == [_sections(p) for p in two]
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the reference's web UI flow, unchanged, on the drop-in
+# ------------------------------------------------------------------------------------------------------------------------------
+_WEBUI = "/root/reference/webui.py"
+
+
+@pytest.mark.skipif(not os.path.exists(_WEBUI), reason="needs the reference checkout (authoring container only)")
+def test_reference_webui_start_mapping_runs_unchanged_on_the_drop_in(tmp_path, monkeypatch):
+    """`webui.py` of the REFERENCE imported through runpy (not a line changed; run_name != "__main__", so the Gradio Blocks are not
+    built) with the drop-in `mug` package ahead of it on sys.path, then its `startMapping` called the way the Generate button calls it
+    (webui.py:277-482): module level OmegaConf.load -> load_model_from_config (instantiate_from_config from the star imports,
+    load_state_dict(strict=False)) -> model.to(device) -> DDIMSampler(model, device); per click: seeds, generate_feature_dict ->
+    parse_feature twice (uc because scale = 5 != 1) -> load_audio_without_cache -> the length rule that MUTATES
+    dataset.max_audio_frame and model.z_length (webui.py:349-367; the clip is cut so that z_length really changes: 64 -> 32) -> `count`
+    stacked copies of one audio through wave_model -> sampler.sample(..., unconditional_guidance_scale=5.0, unconditional_conditioning=uc,
+    tqdm_class=progress.tqdm) = U-Net batch 2 x count -> decode -> parse_osu_file / save_osu_file with ITS gridify order (gridify, then
+    the mini-jack pass) -> the .osz.  Stubs (tests/refcaller_stubs, none of them installed here): gradio, minacalc, reamber, audioread,
+    eyed3, omegaconf; `requests.get` raises (no network: webui.py's own try / except swallows it) and a failing `ffmpeg` stands on PATH
+    (webui.py then copies the audio).  The charts it writes must equal the ones a direct use of the drop-in API produces for the same
+    seed, and mug.job's logits at scale = 5.0 for the same units written in the web UI's post-processing order."""
+    import runpy
+    import sys
+    import wave as wavmod
+    import yaml
+    from conftest import emu_lib, PKG
+    import mug._native as N
+    from mug import job
+    from mug.diffusion.ddim import DDIMSampler
+    case, S, seed, count, scale = cases.TINY, 4, 777, 2, 5.0
+    z_cfg, z = 64, 32                                  # configured latent length / the one the length rule picks for the short clip
+    lib = emu_lib()
+    monkeypatch.setattr(N, "_default", lib)
+    n_fft, sr, ratio = 512, 22050, case["audio_ratio"]
+    hop = n_fft // 4
+    nw_ratio = max(1, ratio // 2 ** (len(case["vae"]["channel_mult"]) - 1))
+    cfg = dict(version="test", model=model_config(case),
+               data=dict(params=dict(common_params=dict(n_fft=n_fft, sr=sr, n_mels=case["wave"]["n_freq"], max_audio_frame=z_cfg * ratio,
+                                                         audio_note_window_ratio=nw_ratio))))
+    cfg["model"]["params"]["z_length"] = z_cfg
+    (tmp_path / "models" / "ckpt").mkdir(parents=True)
+    (tmp_path / "models" / "ckpt" / "model.yaml").write_text(yaml.safe_dump(cfg))
+    man = weights.load_manifest(os.path.join(G, case["manifest"]))
+    sd = weights.set_s4_lengths(weights.make_state_dict(man, seed=0), case["unet"], z)
+    torch.save({"state_dict": sd}, tmp_path / "models" / "ckpt" / "model.ckpt")
+    n_pcm = hop * (z * ratio - 40)                     # t = z * ratio - 39 mel frames: int(t / ratio / 32) + 1 = 1 -> z = 32
+    pcm = (0.4 * np.sin(2 * np.pi * 440 * np.arange(n_pcm) / sr) + 0.2 * np.random.default_rng(3).standard_normal(n_pcm)).clip(-1, 1)
+    with wavmod.open(str(tmp_path / "song.wav"), "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(sr)
+        f.writeframes((pcm * 32767).astype("<i2").tobytes())
+    from test_osu_io import TEMPLATE
+    (tmp_path / "asset").mkdir()
+    (tmp_path / "asset" / "template.osu").write_text(TEMPLATE, encoding="utf-8")
+    (tmp_path / "asset" / "bg.jpg").write_bytes(b"jpg")
+    fy_path = os.path.join(G, "mania_beatmap_features.yaml")
+    (tmp_path / "configs" / "mug").mkdir(parents=True)
+    (tmp_path / "configs" / "mug" / "mania_beatmap_features.yaml").write_text(open(fy_path).read())
+    (tmp_path / "bin").mkdir()
+    (tmp_path / "bin" / "ffmpeg").write_text("#!/bin/sh\nexit 1\n")
+    os.chmod(tmp_path / "bin" / "ffmpeg", 0o755)
+    monkeypatch.setenv("PATH", str(tmp_path / "bin") + os.pathsep + os.environ.get("PATH", ""))
+    monkeypatch.chdir(tmp_path)
+    stubs = os.path.join(os.path.dirname(os.path.abspath(__file__)), "refcaller_stubs")
+    monkeypatch.setattr(sys, "path", [PKG, stubs] + [p for p in sys.path if "refstubs" not in p])
+    for m in ("omegaconf", "eyed3", "gradio", "minacalc", "reamber", "audioread", "audioread.ffdec"):
+        monkeypatch.delitem(sys.modules, m, raising=False)
+    import requests
+
+    def no_network(*a, **k):
+        raise requests.exceptions.ConnectionError("no network in the authoring container")
+    monkeypatch.setattr(requests, "get", no_network)
+
+    ns = runpy.run_path(_WEBUI, run_name="webui_under_test")
+    assert "mug-diffusion_amd" in sys.modules["mug.diffusion.ddim"].__file__ and ns["DDIMSampler"] is DDIMSampler
+    model = ns["model"]
+    assert model.z_length == z_cfg and isinstance(ns["sampler"], DDIMSampler)
+
+    class Upload:                                       # gr.File value: webui.py:289 reads .name
+        name = str(tmp_path / "song.wav")
+    import gradio
+    progress = gradio.Progress()
+    off = dict(cjs=False, cj="more", cjss=False, cjsc=20.0, stas=False, sta="more", stass=False, stasc=20.0, sss=True, ss="more chordjack", ssss=False, sssc=20.0,
+               jss=False, js="more", jsss=False, jssc=20.0, hss=False, hs="more", hsss=False, hssc=20.0, jsps=False, jsp="more", jspss=False, jspsc=20.0,
+               techs=False, tech="more", techss=False, techsc=20.0)
+    args = dict(audioPath=Upload(), audioTitle="Test Song", audioArtist="Test Artist", rss=True, rs="ranked/stable", srs=True, sr=4.0, etts=False, ett=20.0,
+                mts=True, lnrs=True, mapType="Hybrid (both)", lnr=0.3, count=count, step=S, scale=scale, rm_jack_interval=90, auto_snap=True, seed=seed,
+                progress=progress, **off)
+    out = ns["startMapping"](**args)
+    assert model.z_length == z                          # the length rule rewrote it (webui.py:356)
+    assert isinstance(out, list) and len(out) == 5 and out[1]["value"].endswith("Test Artist - Test Song.osz") and os.path.exists(out[1]["value"])
+    descs = [d for d, _ in progress.calls]
+    assert descs[0] == "Process prompts and audio" and "Post process charts" in descs and len(descs) == 3       # + the sampler's step loop
+    save_dir = os.path.join("outputs", "beatmaps", "Test Artist - Test Song")
+    charts = sorted(os.path.join(save_dir, f) for f in os.listdir(save_dir) if f.endswith(".osu"))
+    assert len(charts) == count and os.path.exists(os.path.join(save_dir, "audio.wav")) and os.path.exists(os.path.join(save_dir, "bg.jpg"))
+    assert len(_sections(charts[0])[1]) > 10 and _sections(charts[0]) != _sections(charts[1])
+
+    # ---- the same click through the drop-in API directly: same prompt ids, same seed -> same x_T, same post-processing order
+    from mug.data import convertor
+    from mug.data.utils import gridify, remove_intractable_mania_mini_jacks
+    from mug.util import feature_dict_to_embedding_ids, load_audio_without_cache
+    with open(fy_path) as f:
+        fy = yaml.safe_load(f)
+    fd, _ = ns["generate_feature_dict"](*[args[k] for k in ("audioPath", "audioTitle", "audioArtist")],
+                                        *[args[k] for k in "rss rs srs sr etts ett cjs cj cjss cjsc stas sta stass stasc sss ss ssss sssc jss js jsss jssc hss hs hsss hssc "
+                                                           "jsps jsp jspss jspsc techs tech techss techsc mts lnrs mapType lnr count step scale rm_jack_interval auto_snap seed".split()])
+    ids = torch.tensor([feature_dict_to_embedding_ids(fd, fy)] * count, dtype=torch.float32)
+    uids = torch.tensor([feature_dict_to_embedding_ids({}, fy)] * count, dtype=torch.float32)
+    mel = torch.from_numpy(load_audio_without_cache("song.wav", case["wave"]["n_freq"], hop, n_fft, sr, None).astype(np.float32))
+    assert mel.shape[1] == z * ratio - 39
+    m2 = job.fit_mel(mel, z, ratio)
+    w = model.model.wave_model(torch.stack([m2] * count))
+    x_T = torch.randn((count, 16, z), generator=torch.Generator().manual_seed(seed))
+    lat, _ = DDIMSampler(model).sample(S=S, c=model.model.cond_stage_model(ids), w=w, batch_size=count, shape=None, verbose=False, x_T=x_T, eta=0.0,
+                                       unconditional_guidance_scale=scale, unconditional_conditioning=model.model.cond_stage_model(uids))
+    logits = model.model.decode(lat).cpu().numpy()
+    frame_ms = hop / sr * nw_ratio * 1000
+
+    def webui_order(hit_objects):                       # webui.py:400-406 with auto_snap on
+        snapped, bpm, offset = gridify(hit_objects, verbose=False)
+        return bpm, offset, remove_intractable_mania_mini_jacks(snapped, verbose=False, jack_interval=90)
+
+    def write(rows, outdir):
+        os.makedirs(outdir, exist_ok=True)
+        _, meta = convertor.parse_osu_file("asset/template.osu", dict(frame_ms=frame_ms, max_frame=z * ratio // nw_ratio, from_logits=True))
+        paths = []
+        for i, row in enumerate(rows):
+            paths.append(os.path.join(outdir, "c%d.osu" % i))
+            convertor.save_osu_file(meta, row, path=paths[-1], override={"Version": "AI v%d" % (i + 1)}, gridify=webui_order)
+        return paths
+    assert [_sections(p) for p in write(logits, "api_out")] == [_sections(p) for p in charts]
+
+    # ---- mug.job at scale = 5.0: `count` units of one audio in one launch, x_T rows drawn per unit seed -> compare unit by unit with the API
+    rows = {}
+    units = [job.Unit(audio=0, seed=seed + 10 * i, prompt=fd) for i in range(count)]
+    monkeypatch.setattr(job, "z_length_for", lambda *a, **k: z)
+    job.run_job(model, DDIMSampler(model), units, lambda a: mel, fy, steps=S, scale=scale, batch=count, max_audio_frame=z * ratio, z_length_cfg=z,
+                on_chart=lambda i, u, row: rows.__setitem__(i, row.detach().cpu().numpy()))
+    xj = torch.stack([torch.randn((16, z), generator=torch.Generator().manual_seed(u["seed"])) for u in units])
+    latj, _ = DDIMSampler(model).sample(S=S, c=model.model.cond_stage_model(ids), w=w, batch_size=count, shape=None, verbose=False, x_T=xj, eta=0.0,
+                                        unconditional_guidance_scale=scale, unconditional_conditioning=model.model.cond_stage_model(uids))
+    want = model.model.decode(latj).cpu().numpy()
+    assert sorted(rows) == list(range(count))
+    assert [_sections(p) for p in write([rows[i] for i in range(count)], "job_out")] == [_sections(p) for p in write(want, "job_ref")]

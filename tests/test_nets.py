@@ -4,9 +4,10 @@ oracle/gen_golden.py) and (b) the oracle on fresh seeded inputs.
 
 `tiny` (a structurally complete miniature) runs on the emulated build in the CPU suite and on
 the GPU; `full` (the shipped configs/mug/mug_diffusion.yaml shapes, 151 M parameters) runs on
-the MI355X only.  Tolerances: the kernels are exact fp32 (MFMA fp32 = fma chain), so only
-summation order differs from PyTorch-CPU; the note grid (logit > 0) must match bit-for-bit
-except where the reference logit itself is within GRID_EPS of the threshold."""
+the MI355X only.  Tolerances: fp32 level -- conv / Linear products run on split-f16 operands with fp32 accumulation (csrc/conv_body.h: H3,
+fp32-equivalent at every operand scale: tests/test_ops.py operand-scale tests), attention / S4 / norms in fp32 -- so summation order and
+last-bit rounding differ from PyTorch-CPU; the note grid (logit > 0) must match bit-for-bit except where the reference logit itself is
+inside the measured logit error (and in any case within GRID_EPS of the threshold): grid_check prints every such cell."""
 import os
 
 import numpy as np
@@ -187,14 +188,28 @@ def run_ddim(lib, case, z, S, B, scale, g):
 
 
 def grid_check(logits, ref_logits):
+    """The note grid is a hard threshold on the decoder's logits (/root/reference/mug/data/convertor.py:212-216), so two correct fp32
+    implementations may differ exactly in the cells whose logit is smaller than their logit error.  Prints the logit error over the grid
+    rows, how many cells sit inside it (the only ones that CAN differ), and every cell that does; asserts that no cell flips outside
+    the error bound and none where the reference logit is GRID_EPS or more away from the threshold."""
     got = logits.detach().cpu().numpy()
     gs, gh = host.note_grid(got)
     rs, rh = host.note_grid(ref_logits)
-    flips = np.concatenate([(gs != rs).ravel(), (gh != rh).ravel()])
-    refv = np.concatenate([ref_logits[..., 0:4, :].ravel(), ref_logits[..., 8:12, :].ravel()])
+    rows = list(range(0, 4)) + list(range(8, 12))                      # start rows, hold rows (note_grid's thresholded channels)
+    refv = ref_logits[..., rows, :]
+    gotv = got[..., rows, :]
+    flips = np.concatenate([(gs != rs), (gh != rh)], axis=-2)
+    assert flips.shape == refv.shape, (flips.shape, refv.shape)
+    err = float(np.abs(gotv - refv).max())
+    at_risk = int((np.abs(refv) <= err).sum())
     n_flip = int(flips.sum())
     worst = float(np.abs(refv[flips]).max()) if n_flip else 0.0
-    print("note grid: %d / %d cells flipped, largest |ref logit| among them %.2e" % (n_flip, flips.size, worst))
+    print("note grid: %d / %d cells flipped (largest |ref logit| among them %.2e); logit error over the grid rows %.2e, cells with |ref logit| inside it: %d, "
+          "smallest |ref logit| %.2e" % (n_flip, flips.size, worst, err, at_risk, float(np.abs(refv).min())))
+    for idx in np.argwhere(flips)[:20]:
+        i = tuple(int(v) for v in idx)
+        print("    flipped cell %s: ref logit %+.3e, got %+.3e" % (i, float(refv[i]), float(gotv[i])))
+    assert worst <= err and n_flip <= at_risk, "a cell flipped outside the logit error bound"
     assert worst < GRID_EPS, "a note cell flipped although the reference logit is not near the threshold"
     return n_flip
 

@@ -1,6 +1,7 @@
 """Operator parity: each HIP kernel (through the C ABI) against the plain PyTorch-CPU fp32
 op it replaces, on seeded inputs.  Runs on the emulated build here and on the MI355X under
-`-m gpu`.  Tolerances are fp32-reassociation level (the kernels compute in exact fp32)."""
+`-m gpu`.  Tolerances are fp32-reassociation level: the attention / S4 / norm kernels compute in fp32, conv_gemm on split-f16 operands with
+fp32 accumulation (H3: fp32-equivalent at every operand scale, see the operand-scale tests below)."""
 import math
 
 import numpy as np
@@ -173,8 +174,6 @@ def test_conv1d_wide_tiles(lib, monkeypatch, B, C, T, M, taps, mode):
     """MUGD_CONV_WIDE=1 forces the M-split form wherever it exists: the waves of a workgroup own different row tiles and share every staged
     window (= 2: its M-split x K-split variant, two K-slices per workgroup).  Plain conv + bias + residual, GroupNorm(+SiLU) / LayerNorm
     operand transforms, gated epilogues -- same results."""
-    if mode == "2" and lib.device.type == "cuda":
-        pytest.skip("M-split x K-split: emulator-verified only so far (DESIGN.md 9, what comes next)")
     monkeypatch.setenv("MUGD_CONV_WIDE", mode)
     pad = (taps - 1) // 2
     x, w, b = rnd(7, B, C, T), rnd(8, M, C, taps, scale=1.0 / math.sqrt(C * taps)), 0.1 * rnd(9, M)
@@ -210,8 +209,6 @@ def test_conv1d_shape_the_host_rule_sends_to_the_wide_form(lib, monkeypatch):
 @pytest.mark.parametrize("mode", ["1", "2"])
 @pytest.mark.parametrize("epi", [1, 2])
 def test_conv1d_gated_wide(lib, monkeypatch, epi, mode):
-    if mode == "2" and lib.device.type == "cuda":
-        pytest.skip("M-split x K-split: emulator-verified only so far")
     monkeypatch.setenv("MUGD_CONV_WIDE", mode)
     lib.set_conv_tiling(0, 32)
     try:
@@ -238,6 +235,140 @@ def test_conv1d_gated(lib, epi):
     a, g = y.chunk(2, dim=1)
     ref = a * torch.sigmoid(g) if epi == 1 else a * F.gelu(g)
     close(lib.op_conv1d(x, w, b, epi=epi), ref, 2e-5, what="gated conv")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The DOMAIN of conv_gemm's split-f16 arithmetic (csrc/conv_body.h: "The DOMAIN of H3").  The reference is fp32 with a +-3e38 range
+# (/root/reference/mug/diffusion/unet.py:27-33: convert_module_to_f16 is a no-op); f16 halves alone overflow above 65504 and lose their
+# low half below ~2^-12 (round 4: all-NaN tiles at |x| ~ 1e5, relative error 1e-3 at 1e-8).  Both operands are therefore carried as
+# block floating point (weights: one power of two per packed set; activations: a per-wave power of two that follows the data), and
+# these tests hold the kernels to the SAME fp32 tolerance at every operand scale, against float64.
+# ---------------------------------------------------------------------------------------------------------------------
+SCALES = [1e-8, 1e-6, 1.0, 1e5, 1e7]
+
+
+def conv_ref64(x, w, b=None, stride=1, pad=0, dil=1):
+    return F.conv1d(x.double(), w.double(), None if b is None else b.double(), stride, pad, dil)
+
+
+def close_scaled(got, ref64, scale, atol=2e-5, rtol=1e-5, what=""):
+    """fp32 tolerance of the unit-scale tests, relative to the product of the operand scales."""
+    got = got.detach().cpu().double() / scale
+    ref = ref64 / scale
+    assert torch.isfinite(got).all(), "%s: %d non-finite outputs" % (what, int((~torch.isfinite(got)).sum()))
+    err = (got - ref).abs()
+    bad = err > atol + rtol * ref.abs()
+    assert not bad.any(), "%s: %d/%d off, max err %.3e (scaled units)" % (what, int(bad.sum()), bad.numel(), float(err.max()))
+
+
+@pytest.mark.parametrize("sw", [1e-6, 1.0, 1e5])
+@pytest.mark.parametrize("sx", SCALES)
+@pytest.mark.parametrize("B,C,T,M,taps,dil,stride,pad,ups", [CONV_CASES[0], CONV_CASES[1], CONV_CASES[6], CONV_CASES[9]])
+def test_conv1d_operand_scales(lib, sx, sw, B, C, T, M, taps, dil, stride, pad, ups):
+    x, w = rnd(7, B, C, T) * sx, rnd(8, M, C, taps, scale=1.0 / math.sqrt(C * taps)) * sw
+    b = 0.1 * rnd(9, M) * (sx * sw)
+    xin = F.pad(x, (0, 1)) if stride == 2 else x
+    ref = conv_ref64(xin, w, b, stride, pad, dil)
+    got = lib.op_conv1d(x, w, b, None, dil=dil, stride=stride, pad=pad, upsample=bool(ups), Tout=ref.shape[-1])
+    close_scaled(got, ref, sx * sw, what="conv1d sx=%g sw=%g" % (sx, sw))
+
+
+@pytest.mark.parametrize("sx,sw", [(1e-30, 1.0), (1e-20, 1e-10), (1e-12, 1.0), (1e20, 1.0), (1e30, 1e-3), (1e-3, 1e30), (1e25, 1e10)])
+def test_conv1d_operand_scales_far_out(lib, sx, sw):
+    """the ends of the fp32 range (the training step's data-gradient convs run on gradients of 1e-7 .. 1e-12: train.hip run_dgrad)"""
+    B, C, T, M, taps = 2, 64, 48, 48, 3
+    x, w = rnd(13, B, C, T) * sx, rnd(14, M, C, taps, scale=1.0 / math.sqrt(C * taps)) * sw
+    ref = conv_ref64(x, w, None, 1, 1, 1)
+    close_scaled(lib.op_conv1d(x, w, pad=1), ref, sx * sw, what="conv1d sx=%g sw=%g" % (sx, sw))
+
+
+@pytest.mark.parametrize("tn,wk", [(16, 0), (32, 1), (32, 2), (32, 8)])
+@pytest.mark.parametrize("sx", [1e-8, 1e7])
+def test_conv1d_operand_scales_tilings(lib, sx, tn, wk):
+    """every K-split and both tile widths carry their own per-wave scale"""
+    B, C, T, M, taps = 2, 128, 64, 96, 3
+    x, w = rnd(17, B, C, T) * sx, rnd(18, M, C, taps, scale=1.0 / math.sqrt(C * taps))
+    ref = conv_ref64(x, w, None, 1, 1, 1)
+    lib.set_conv_tiling(wk, tn)
+    try:
+        close_scaled(lib.op_conv1d(x, w, pad=1), ref, sx, what="conv1d tn=%d wk=%d sx=%g" % (tn, wk, sx))
+    finally:
+        lib.set_conv_tiling(0, 0)
+
+
+@pytest.mark.parametrize("wk", [0, 1, 2])
+def test_conv1d_channel_blocks_of_different_scale(lib, wk):
+    """Channel chunks 14 orders of magnitude apart inside one reduction: the per-wave scale moves DOWN for the large chunk and back UP
+    for the small ones, the accumulators follow exactly -- output rows that read only the small channels keep fp32 accuracy relative to
+    THEIR magnitude (a single scale per launch, or per tile, would not give that), and the rows that read everything match as well."""
+    B, C, T, M = 1, 64, 64, 64
+    x = rnd(21, B, C, T)
+    cs = torch.tensor([1e-6] * 16 + [1e8] * 16 + [1e-3] * 16 + [1.0] * 16)
+    x = x * cs[None, :, None]
+    w = rnd(22, M, C, 1, scale=1.0 / math.sqrt(C))
+    w[:16, 16:32] = 0.0                      # rows 0..15 never read the 1e8 channels
+    w[:8, 48:] = 0.0                         # rows 0..7 read the 1e-6 and 1e-3 channels only
+    ref = conv_ref64(x, w)
+    lib.set_conv_tiling(wk, 32)
+    try:
+        got = lib.op_conv1d(x, w).detach().cpu().double()
+    finally:
+        lib.set_conv_tiling(0, 0)
+    assert torch.isfinite(got).all()
+    for rows, mag in ((slice(0, 8), 1e-3), (slice(8, 16), 1.0), (slice(16, 64), 1e8)):
+        err = (got[:, rows] - ref[:, rows]).abs().max().item()
+        assert err <= 2e-5 * mag, "rows %s: max err %.3e at magnitude %g" % (rows, err, mag)
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("sx", [1e-8, 1e5, 1e7])
+def test_conv1d_operand_scales_wide(lib, monkeypatch, sx, mode):
+    """the M-split forms share their windows between waves: the window's scale travels with it"""
+    monkeypatch.setenv("MUGD_CONV_WIDE", mode)
+    B, C, T, M, taps = 2, 160, 72, 160, 3
+    x, w = rnd(27, B, C, T) * sx, rnd(28, M, C, taps, scale=1.0 / math.sqrt(C * taps)) * 1e5
+    x[:, 32:48] *= 1e6                       # one chunk far above the others: scales differ between the windows of a phase
+    ref = conv_ref64(x, w, None, 1, 1, 1)
+    lib.set_conv_tiling(0, 32)
+    try:
+        close_scaled(lib.op_conv1d(x, w, pad=1), ref, sx * 1e5 * 1e6, what="wide conv1d sx=%g" % sx)
+    finally:
+        lib.set_conv_tiling(0, 0)
+
+
+@pytest.mark.parametrize("norm,groups,silu", [(1, 32, 1), (1, 32, 2), (2, 0, 0)])
+@pytest.mark.parametrize("sg,sw", [(1e-6, 1e5), (1e5, 1e-6), (1e7, 1.0), (1.0, 1e7), (1e-8, 1.0)])
+def test_norm_conv1d_operand_scales(lib, sg, sw, norm, groups, silu):
+    """GroupNorm / LayerNorm affine parameters and the weights at the ends of the range (the normalised tensor is |gamma| sqrt(n) at
+    most, so gamma IS its scale); the input's own scale is normalised away, so it rides along at 1e5."""
+    B, C, T, M, taps = 2, 64, 48, 64, 3 if norm == 1 else 1
+    x = (rnd(30, B, C, T, scale=2.0) + 0.3) * 1e5
+    g, b = (1 + 0.1 * rnd(31, C)) * sg, 0.1 * rnd(32, C) * sg
+    w = rnd(33, M, C, taps, scale=1.0 / math.sqrt(C * taps)) * sw
+    xd = x.double()
+    if norm == 1:
+        n = F.group_norm(xd, groups, g.double(), b.double(), eps=1e-6)
+        if silu:
+            n = F.silu(n)
+    else:
+        n = F.layer_norm(xd.transpose(1, 2), (C,), g.double(), b.double(), eps=1e-5).transpose(1, 2)
+    pad = (taps - 1) // 2
+    ref = F.conv1d(n, w.double(), None, 1, pad)
+    got = lib.op_norm_conv1d(x, g, b, w, None, dil=1, pad=pad, norm=norm, groups=groups, silu=silu)
+    close_scaled(got, ref, sg * sw, atol=3e-5, what="norm+conv sg=%g sw=%g" % (sg, sw))
+
+
+def test_conv1d_non_finite_operands_propagate(lib):
+    """inf / NaN in an operand reach exactly the outputs they reach in fp32 (as non-finite values); every other output stays exact"""
+    B, C, T, M = 1, 32, 64, 32
+    x, w = rnd(41, B, C, T), rnd(42, M, C, 3, scale=1.0 / math.sqrt(C * 3))
+    x[0, 5, 20] = float("inf")
+    x[0, 17, 40] = float("nan")
+    ref = F.conv1d(x, w, None, 1, 1)
+    got = lib.op_conv1d(x, w, pad=1).detach().cpu()
+    assert torch.equal(torch.isfinite(got), torch.isfinite(ref))
+    fin = torch.isfinite(ref)
+    assert (got[fin] - ref[fin]).abs().max().item() <= 2e-5
 
 
 def ref_attention(q, k, v, rel, cemb, heads):
@@ -353,6 +484,25 @@ def test_log_mel(lib, seconds):
     ulp = torch.maximum(ref.abs(), torch.tensor(2.0 ** -14)) * 2.0 ** -10
     assert (err <= ulp * 1.01).all(), float((err / ulp).max())
     assert (err > 0).float().mean().item() < 0.02
+
+
+@pytest.mark.parametrize("kind", ["dc", "square30", "sine_fullscale", "quiet"])
+@pytest.mark.parametrize("n_fft,hop", [(512, 128), (1024, 256)])
+def test_log_mel_loud_and_quiet_audio(lib, kind, n_fft, hop):
+    """The mel filterbank GEMM reads the UN-normalised power spectrum: a constant 1.0 PCM has |X[0]|^2 = (n_fft / 2)^2 = 65536 at n_fft = 512
+    -- one above the f16 range (round 4: 21 632 of 22 144 mel cells NaN) -- a full-scale sine (n_fft / 4)^2 per bin, a -120 dB signal
+    1e-12 of that.  Same one-ulp-of-fp16 criterion as test_log_mel, no non-finite cell anywhere."""
+    from oracle import host
+    n = 22050 // 2
+    t = np.arange(n, dtype=np.float64) / 22050.0
+    y = {"dc": np.ones(n), "square30": np.sign(np.sin(2 * np.pi * 30.0 * t) + 1e-9), "sine_fullscale": np.sin(2 * np.pi * 440.0 * t),
+         "quiet": 1e-6 * np.sin(2 * np.pi * 440.0 * t)}[kind].astype(np.float32)
+    ref = torch.from_numpy(host.log_mel(y, n_fft=n_fft, hop=hop).astype(np.float32))
+    got = lib.log_mel(torch.from_numpy(y), n_fft=n_fft, hop=hop).cpu()
+    assert torch.isfinite(got).all(), int((~torch.isfinite(got)).sum())
+    err = (got - ref).abs()
+    ulp = torch.maximum(ref.abs(), torch.tensor(2.0 ** -14)) * 2.0 ** -10
+    assert (err <= ulp * 1.01).all(), float((err / ulp).max())
 
 
 @pytest.mark.parametrize("n_fft,hop,n_mels", [(64, 16, 16), (256, 64, 64), (1024, 256, 128)])
