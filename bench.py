@@ -11,8 +11,9 @@ the hot path with the PCM already resident in HBM:
     -> 50-step DDIM loop over the U-Net (one native call, eager launches) -> VAE decode -> thresholded 4K note grid.
 Every rank works on its own (song, seeds) units; there is no data-path collective (weak scaling).
 Weights are seeded synthetic values of the shipped architecture (no checkpoint exists offline), with the
-reference's zero-initialised tensors randomised so no branch is a no-op.  Arithmetic is fp32 end to end
-(fp32-input MFMA), like the reference.
+reference's zero-initialised tensors randomised so no branch is a no-op.  Tensors and accumulation are fp32 end to end like
+the reference; conv / Linear products run on the f16 matrix cores with split, block-scaled operands (fp32-equivalent over the
+fp32 range: include/mugd.h, mugd_version).
 
 Prints ONE JSON line (rank 0) with the contract's fields plus
   "roofline"     : the dominant kernel (conv_gemm, MFMA-bound) measured live with HIP events,
@@ -254,7 +255,10 @@ def main():
             "dtype": ("f32" if a.weights == "f32" else "bf16 weights, f32 activations / MFMA inputs after widening / accumulation (reduced-precision mode)"),
             "dtype_detail": ("fp32 tensors, fp32 accumulation; conv / linear products on the f16 matrix cores with BOTH operands split into f16 hi + 2^11-scaled lo "
                              "halves (3 MFMAs per block): fp32-equivalent -- measured error vs float64 2.7e-7 relative at K = 1024 against 7.7e-7 for the "
-                             "fp32-input MFMA chain (profiles/r4_h3_probe.txt); every parity test runs at the fp32 tolerances" if h3 else
+                             "fp32-input MFMA chain (profiles/r4_h3_probe.txt).  Domain: the whole fp32 range -- both operands are block-scaled by exact powers "
+                             "of two (weights per packed set, activations per wave and 16-channel chunk, following the data; include/mugd.h: mugd_version), "
+                             "tests/test_ops.py holds conv / norm+conv / log-mel to the unit-scale fp32 tolerance at operand scales 1e-30 .. 1e30; every "
+                             "parity test runs at the fp32 tolerances" if h3 else
                              "fp32 tensors, fp32-input MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulation") if a.weights == "f32" else None,
             "library": lib.version(),
             "shader_clock_mhz_under_matrix_load": lib.dev_clock_probe(),      # boxes of the pool differ by up to 25 % in what they sustain
@@ -336,6 +340,24 @@ def main():
                             "ddim_loop_ms": ev[0].elapsed_time(ev[1]),
                             "unet_sample_steps_per_s": npack * B * n_unet_steps / (ev[0].elapsed_time(ev[1]) * 1e-3), "launches": st2["launches"]}
                 note("throughput mode (%d songs per launch) done: %.1f charts/s" % (npack, npack * B / dt))
+        if world == 1 and not a.no_throughput_mode and a.pack_songs == 1 and a.audios_per_rank == 1 and a.cfg_scale == 1.0:
+            # the web UI's default click (webui.py:336-390: cfg scale 5 with an unconditional batch): U-Net batch 2 B, same pipeline, reported next to
+            # the no-guidance headline (BASELINE configs[1] is quoted without guidance)
+            def guided():
+                return job.run_job(model, timed, units, mel_of, fy, steps=S, scale=5.0, eta=0.0, batch=B, pack_songs=1,
+                                   max_audio_frame=SHIPPED["max_audio_frame"], z_length_cfg=z_cfg, gather=False)
+            guided()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            reps = 2
+            for _ in range(reps):
+                guided()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / reps
+            out["cfg_scale_5"] = {"what": "the same step with classifier-free guidance (unconditional_guidance_scale = 5.0, webui.py's default): %d seeds -> U-Net batch %d" % (B, 2 * B),
+                                  "value": len(units) / dt, "unit": "charts/s", "ms_per_step": dt * 1e3, "ddim_loop_ms": ev[0].elapsed_time(ev[1]),
+                                  "unet_sample_steps_per_s": 2 * B * n_unet_steps / (ev[0].elapsed_time(ev[1]) * 1e-3)}
+            note("cfg scale 5 leg done: %.1f charts/s" % (len(units) / dt))
         if world == 1 and not a.no_reduced_mode and a.weights == "f32" and a.pack_songs == 1 and a.audios_per_rank == 1:
             # reduced-precision mode, reported separately (never the headline: the reference is fp32): bf16 weight storage, fp32 everything
             # else; same pipeline, networks recompiled with re-packed weights
@@ -427,7 +449,8 @@ def training_leg(a, lib, model, dev, world, rank, grouped, sync_all, bf16=True):
     through all three networks (mug/train.py TrainPlan: native block forward / backward entry points, blocks keep their forward
     intermediates, no host synchronisation inside the step) -> bucketed all-reduce of the 1327 gradient tensors overlapped with the
     backward sweep (RCCL when N > 1) -> AdamW on every tensor (one launch).  bf16: the GEMMs on the bf16 matrix cores with fp32
-    accumulation (configs[4]'s precision; everything else fp32); else the fp32-input MFMA parity mode.  2 warm-up + 3 timed steps,
+    accumulation (configs[4]'s precision; everything else fp32); else the fp32 parity mode (forward / data-gradient GEMMs through conv_gemm's
+    split-f16 arithmetic, weight gradients on the fp32-input MFMA).  2 warm-up + 3 timed steps,
     barrier + synchronize on both sides, MAX over ranks; then one more step with an event pair around every GEMM launch for the
     GEMM roofline.  Reported next to the headline, never as it."""
     import torch.distributed as dist
@@ -474,7 +497,8 @@ def training_leg(a, lib, model, dev, world, rank, grouped, sync_all, bf16=True):
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
     gemm_ms = prof["conv"]["ms"] + prof["wgrad"]["ms"]
     gemm_fl = prof["conv"]["flops"] + prof["wgrad"]["flops"]
-    kern = "tconv_bf16_kernel / twgrad_bf16_kernel (v_mfma_f32_32x32x16_bf16)" if bf16 else "conv_gemm_kernel / wgrad_mfma_kernel (v_mfma_f32_32x32x2_f32)"
+    kern = "tconv_bf16_kernel / twgrad_bf16_kernel (v_mfma_f32_32x32x16_bf16)" if bf16 else \
+        "conv_gemm_kernel (forward, data gradients: 3 x v_mfma_f32_32x32x16_f16 per block on split operands) / wgrad_mfma_kernel (v_mfma_f32_32x32x2_f32)"
     gemm = {"kernel": kern + ": all %d GEMM launches of one step, HIP event pair around each on the library stream (bf16 mode: packed weights "
                              "come from the step bracket's cache and the split-K slices are summed by the step's one reduction launch -- both "
                              "outside the brackets)" % (prof["conv"]["launches"] + prof["wgrad"]["launches"]),
@@ -496,13 +520,15 @@ def training_leg(a, lib, model, dev, world, rank, grouped, sync_all, bf16=True):
                     "bound": "hbm", "achieved": per_step / dt / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": per_step / dt / 1e9 / PEAK_HBM_GBS,
                     "traffic": per_step, "traffic_source": "profiles/train_traffic.json: %s" % tr["source"],
                     "traffic_range_gb": [(tr["fetch_gb_raw"] + tr["write_gb"]) * Bt / tr["batch"], (tr["fetch_gb_x2"] + tr["write_gb"]) * Bt / tr["batch"]],
+                    # `frac` above uses the UPPER end of the range (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes); the lower end (raw counter) next to it
+                    "frac_range": [(tr["fetch_gb_raw"] + tr["write_gb"]) * 1e9 * Bt / tr["batch"] / dt / 1e9 / PEAK_HBM_GBS, per_step / dt / 1e9 / PEAK_HBM_GBS],
                     "gemm_mfma": gemm}
     except (OSError, ValueError, KeyError):
         pass
     return {"what": "configs[4] shape: DDPM training step (q_sample, wave encoder, prompt embedding, U-Net, smooth-L1, backward through all three "
                     "networks, bucketed gradient all-reduce overlapped with the backward sweep, AdamW), per-GPU batch %d, z = %d, synthetic data; %s"
                     % (Bt, z, "conv / Linear GEMMs (forward, data and weight gradients) with bf16 MFMA inputs and fp32 accumulation, fp32 master weights, "
-                              "activations, norms, softmax, S4 and reductions" if bf16 else "fp32-input MFMA everywhere (the parity mode)"),
+                              "activations, norms, softmax, S4 and reductions" if bf16 else "the fp32 parity mode: forward / data-gradient GEMMs on split-f16 operands (fp32-equivalent), weight gradients on the fp32-input MFMA"),
             "value": Bt * world / dt, "unit": "samples/s", "ms_per_step": dt * 1e3, "global_batch": Bt * world, "dtype": "bf16" if bf16 else "f32",
             "loss": float(loss), "gradient_tensors": len(grads), "trainable_parameters": int(nparam),
             "algorithmic_tflops_whole_step": TRAIN_GFLOP_PER_SAMPLE * Bt / dt / 1e3,

@@ -47,6 +47,8 @@ struct ConvGeo {
     __device__ static __forceinline__ int frag_row0(int lane) { return TN == 32 ? 4 * (lane >> 5) : (lane >> 4); }      // first window row of the lane's B fragment
 };
 
+// H3 domain (below): the activation scale every wave starts from -- O(1) data (max |v| in [2^-6, 2^7)) sits inside the band at once
+constexpr float H3_SX0 = 256.0f;
 // the accumulators of one wave: values, second row set (gate rows | TALL's second row tile), and the 2^11-scaled cross terms of H3
 template <int TN>
 struct ConvAcc;
@@ -58,7 +60,7 @@ struct ConvAcc<32> {
     __device__ __forceinline__ void zero() {
 #pragma unroll
         for (int i = 0; i < 16; ++i) { a[i] = 0.f; a2[i] = 0.f; l[i] = 0.f; l2[i] = 0.f; }
-        sx = 1.0f; sxmin = 0x1p125f;
+        sx = H3_SX0; sxmin = 0x1p125f;
     }
     __device__ __forceinline__ void scale_all(float r, bool two) {
         a *= r; l *= r;
@@ -84,7 +86,7 @@ struct ConvAcc<16> {
         for (int i = 0; i < 4; ++i) {
             a[0][i] = 0.f; a[1][i] = 0.f; a2[0][i] = 0.f; a2[1][i] = 0.f; l[0][i] = 0.f; l[1][i] = 0.f; l2[0][i] = 0.f; l2[1][i] = 0.f;
         }
-        sx = 1.0f; sxmin = 0x1p125f;
+        sx = H3_SX0; sxmin = 0x1p125f;
     }
     __device__ __forceinline__ void scale_all(float r, bool two) {
 #pragma unroll
@@ -161,6 +163,25 @@ __device__ __forceinline__ float h3_split(float v) {          // {hi | lo << 16}
     const unsigned u = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
     return __uint_as_float(u);
 }
+// the split of a SCALED sample, v sc with sc = 2^k: three VOP3P instructions -- hi = f16(v sc) into the low half, the exact fp32 residual
+// v sc - hi (one fused operation, the f16 read back through op_sel), lo = f16(residual 2^11) into the high half of the same dword --
+// instead of the eleven per sample PAIR the compiler makes of h3_split(v * sc) (multiply, two converts each way, subtract, multiply, pack).
+// Bit-identical to it: v sc is exact, each result is rounded once, to nearest even, like the converts.  -DMUGD_H3_MIX=0: the plain form.
+#ifndef MUGD_H3_MIX
+#define MUGD_H3_MIX 1
+#endif
+__device__ __forceinline__ float h3_split_scaled(float v, float sc) {
+#if MUGD_H3_MIX && !defined(MUGD_EMULATED)
+    unsigned d;
+    float r;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(d) : "v"(v), "v"(sc));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(v), "v"(sc), "v"(d));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(d) : "v"(r), "s"(2048.0f));
+    return __uint_as_float(d);
+#else
+    return h3_split(v * sc);
+#endif
+}
 template <class WT>
 constexpr bool conv_h3() { return MUGD_CONV_H3 != 0 && sizeof(WT) == 4; }
 
@@ -196,6 +217,18 @@ __device__ __forceinline__ bool wave_any(bool c) {
 #endif
 }
 __device__ __forceinline__ float rfl_f(float v) { return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); }
+// wave maximum of non-negative floats as a wave-uniform bit pattern: four row rotations (DPP: no LDS traffic) leave every lane of a 16-lane
+// row with the row's maximum, four v_readlane + scalar max join the rows (bit patterns of non-negative floats order like unsigned integers)
+__device__ __forceinline__ unsigned wave_max_bits(float m) {
+#define MUGD_ROW_ROR_MAX(n) m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x120 + (n), 0xf, 0xf, false)))
+    MUGD_ROW_ROR_MAX(1); MUGD_ROW_ROR_MAX(2); MUGD_ROW_ROR_MAX(4); MUGD_ROW_ROR_MAX(8);
+#undef MUGD_ROW_ROR_MAX
+    const unsigned u = __float_as_uint(m);
+    const unsigned a0 = (unsigned)__builtin_amdgcn_readlane((int)u, 0), a1 = (unsigned)__builtin_amdgcn_readlane((int)u, 16);
+    const unsigned a2 = (unsigned)__builtin_amdgcn_readlane((int)u, 32), a3 = (unsigned)__builtin_amdgcn_readlane((int)u, 48);
+    const unsigned b0 = a0 > a1 ? a0 : a1, b1 = a2 > a3 ? a2 : a3;
+    return b0 > b1 ? b0 : b1;
+}
 // does a chunk whose lane maxima are m leave the band at scale sc?
 __device__ __forceinline__ bool h3_off_band(float m, float sc) {
     const float ms = m * sc;
@@ -209,16 +242,22 @@ __device__ __forceinline__ void h3_adopt(ConvAcc<TN>& ac, float s, bool two) {
     ac.sxmin = fminf(ac.sxmin, s);
 }
 // slow path of a park: m = this lane's max |v| of the chunk, sc = the scale the chunk would be parked at.  Returns the scale to park at;
-// adopt: the parking wave is the consumer (K-split forms) -- its accumulators follow at once
+// adopt: the parking wave is the consumer (K-split forms) -- its accumulators follow at once.  All in the exponent domain on
+// wave-uniform values (scalar ALU): the wave max 2^e <= mw < 2^(e+1) times sc = 2^k is inside [4, 2^15) iff 2 <= e + k <= 14
 template <int TN>
 __device__ __forceinline__ float h3_pick(ConvAcc<TN>& ac, float m, float sc, bool adopt, bool two) {
-    const float mw = wave_max(m);
-    const int E = h3_biased_exp(mw);
-    if (mw > 0.f && E < 255) {                                       // an all-zero chunk is parked at whatever scale; inf: no scale
-        const float cur = mw * sc;
-        if (!(cur >= H3_LOW && cur < H3_LIM)) sc = fminf(h3_pow2_biased(264 - (E < 1 ? 1 : E)), ac.sxmin * 0x1p64f);      // mw sc in [2^10, 2^11)
+    const unsigned mb = wave_max_bits(m);
+    const int E = (int)(mb >> 23);
+    if (mb != 0u && E < 255) {                                       // an all-zero chunk is parked at whatever scale; inf: no scale
+        const int Ee = E < 1 ? 1 : E;                                // (fp32 subnormal maxima count as 2^-126)
+        const int cur = Ee + h3_biased_exp(sc) - 254;
+        if (cur < 2 || cur > 14) {
+            int b = 264 - Ee;                                        // mw sc in [2^10, 2^11)
+            const int cap = h3_biased_exp(ac.sxmin) + 64;            // ... but never more than 2^64 above the smallest scale so far
+            b = b < cap ? b : cap;
+            sc = h3_pow2_biased(b);
+        }
     }
-    sc = rfl_f(sc);
     if (adopt && sc != ac.sx) h3_adopt(ac, sc, two);
     return sc;
 }
@@ -516,11 +555,11 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
 #pragma unroll
             for (int j = 0; j < NH; ++j) m = fmaxf(m, fabsf(vh[j]));
             float sc = ac.sx;
-            if (MUGD_H3_DYN && h3_off_band(m, sc)) sc = h3_pick<TN>(ac, m, sc, COOP == 0, DUAL);
+            if (MUGD_H3_DYN && __builtin_expect(h3_off_band(m, sc), 0)) sc = h3_pick<TN>(ac, m, sc, COOP == 0, DUAL);
 #pragma unroll
-            for (int i = 0; i < SPL; ++i) v[i] = h3_split(v[i] * sc);
+            for (int i = 0; i < SPL; ++i) v[i] = h3_split_scaled(v[i], sc);
 #pragma unroll
-            for (int j = 0; j < NH; ++j) vh[j] = h3_split(vh[j] * sc);
+            for (int j = 0; j < NH; ++j) vh[j] = h3_split_scaled(vh[j], sc);
             if (COOP > 0 && lane == 0) wsc[slot] = sc;   // M-split: the window's scale travels with it
         }
 #pragma unroll
@@ -574,7 +613,7 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
                 if (k < nch) {
                     if (conv_h3<WT>()) {                    // the window was parked at ITS wave's scale: the accumulators follow
                         const float ws = rfl_f(wsc[buf * COOP + j]);
-                        if (ws != ac.sx) h3_adopt<TN>(ac, ws, DUAL);
+                        if (__builtin_expect(ws != ac.sx, 0)) h3_adopt<TN>(ac, ws, DUAL);
                     }
                     conv_mfma<TN, TAPS, DUAL, WT>(smem_bytes + (buf * COOP + j) * W1, rb0, s.dil, RA[j & 1], RA2[j & 1], ac);
                     if (k + 2 < nch) fetch_a(k + 2, j & 1);
@@ -776,9 +815,9 @@ __device__ __forceinline__ void run_segment_gen(const SEG& s, const float* wseg,
 #pragma unroll
             for (int k = 0; k < NIT; ++k) m = fmaxf(m, fabsf(v[k]));
             float sc = ac.sx;
-            if (MUGD_H3_DYN && h3_off_band(m, sc)) sc = h3_pick<32>(ac, m, sc, true, DUAL);
+            if (MUGD_H3_DYN && __builtin_expect(h3_off_band(m, sc), 0)) sc = h3_pick<32>(ac, m, sc, true, DUAL);
 #pragma unroll
-            for (int k = 0; k < NIT; ++k) v[k] = h3_split(v[k] * sc);
+            for (int k = 0; k < NIT; ++k) v[k] = h3_split_scaled(v[k], sc);
         }
 #pragma unroll
         for (int k = 0; k < NIT; ++k) *reinterpret_cast<float*>(smem_bytes + loff[k]) = ok[k] ? v[k] : 0.f;
@@ -842,9 +881,9 @@ constexpr int conv_lds_bytes() { return ConvLds<WK, DUAL, TN>::BYTES; }
 //       slices of K: every wave walks the whole K axis with its own weight stream, the windows are staged once per workgroup
 //       (run_segment_vec<COOP>), there is no K-split combine and every wave finishes its whole 32 x 32 tile itself.  For launches with enough
 //       column tiles to fill the chip that way (large batch); KIND 0, 32-wide tiles.
-// MS = 2 (opt-in, MUGD_CONV_WIDE=2; NOT yet measured on hardware): M-split x K-split -- WK = NR row tiles x 2 K-slices; the NR waves of a K-slice
-//       share that slice's windows, the two partial tiles of a row tile are combined through LDS like the K-split form's.  Keeps two waves per
-//       SIMD on launches with few row tiles ("what comes next").
+// MS = 2: M-split x K-split -- WK = NR row tiles x 2 K-slices; the NR waves of a K-slice share that slice's windows, the two partial tiles of a
+//       row tile are combined through LDS like the K-split form's.  Keeps two waves per SIMD on launches with few row tiles.  Measured in round 5
+//       (profiles/r5_wide2_ab.txt): wins 7 - 25 % on all-3-tap launches with >= 192 workgroups in this form -- launch_conv_gemm's rule -- loses elsewhere.
 template <int WK, bool DUAL, int KIND, int NITG, class WT, bool TALL = false, class A = ConvArgs, int TN = CONV_TN, int MS = 0>
 __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b, const int t0, const int rot, const int tid, char* lds, const bool live) {
     static_assert(!(DUAL && TALL), "gated layers already share their windows between two row sets");
@@ -944,23 +983,11 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
         }
     };
     if (PRELOAD) load_side();
-    // H3 domain: 1 / S_w of the packed weight set.  A VECTOR load on purpose (the index is laundered through a VGPR): the word is cold (its
-    // own line, last written when the set was packed) and a scalar load of it shares lgkmcnt with the LDS traffic and the kernel-argument
-    // loads -- the first LDS wait of every wave would sit out a trip to memory (measured: +1.1 us per launch, profiles/r5_h3_domain_ab.txt);
-    // as a vector load it returns in order with the statistics / epilogue operands requested around it, which are just as cold.
-    float winv = 1.0f;
-#ifndef MUGD_H3_WLOAD
-#define MUGD_H3_WLOAD 2
-#endif
-    if (conv_h3<WT>() && MUGD_H3_WLOAD && a.wmax) {
-#if MUGD_H3_WLOAD == 2 && !defined(MUGD_EMULATED)
-        int zi = 0;
-        asm volatile("" : "+v"(zi));
-        winv = h3_pow2_recip(h3_wscale(a.wmax[zi]));
-#else
-        winv = h3_pow2_recip(h3_wscale(*to_const_as(a.wmax)));
-#endif
-    }
+    // H3 domain: 1 / S_w of the packed weight set -- by value (ConvArgs::winv: sets packed when a network is compiled; the host read the word
+    // back once) or, for sets re-packed on the device per call (the folded cross-attention weights, the stand-alone operators, the training
+    // step's fp32 mode), from the set's device word: one cold load per wave, +0.4 us per launch (profiles/r5_h3_domain_ab.txt)
+    float winv = a.winv != 0.f ? a.winv : 1.0f;
+    if (conv_h3<WT>() && a.wmax) winv = h3_pow2_recip(h3_wscale(*to_const_as(a.wmax)));
     TL_STAMP(12);
     stats.finish(a, b, t0, tid, stl);      // reduce + workgroup barrier(s): the requests went out before the index math above
     TL_STAMP(1);

@@ -307,13 +307,23 @@ void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
         const int nw = gy >= 8 ? 8 : gy >= 4 ? 4 : 2;
         const long long wgs = (long long)cdiv(gy, nw) * gx * gz;
         bool wide = can && ((gy >= 16 && a.nchunk <= 32 && wgs >= 160) || (gy >= 4 && a.nchunk <= 4 && wgs >= 128));
-        if (const char* e = getenv("MUGD_CONV_WIDE")) {
+        // M-split x K-split (conv_body.h: MS = 2; 4 row tiles x 2 K-slices per workgroup), first measured in round 5 (profiles/r5_wide2_ab.txt):
+        // 7 - 25 % faster than the K-split form on launches whose segments are ALL 3-tap (the ResBlocks' GroupNorm + SiLU + conv3 over [h | skip |
+        // audio], the out_layers without a fused skip, the Upsample convs) when >= 192 workgroups remain that way (batch 16: levels 0 - 2);
+        // slower on mixed 3-tap / 1x1 reductions (the K-slices' phase counts differ) and wherever it leaves CUs without a workgroup.
+        bool wide2 = false;
+        if (can && !wide && !dual && gy >= 4 && a.nchunk >= 16 && (long long)cdiv(gy, 4) * gx * gz >= 192) {
+            wide2 = true;
+            for (int i = 0; i < a.nseg; ++i) wide2 = wide2 && a.seg[i].taps == 3;
+        }
+        if (const char* e = getenv("MUGD_CONV_WIDE")) {      // 0 never | 1 the M-split form wherever it exists | 2 the M-split x K-split form wherever it exists
             wide = can && e[0] == '1';
-            if (can && e[0] == '2' && a.nchunk >= 2) {      // development: M-split x K-split (conv_body.h: MS = 2), not measured on hardware yet
-                if (gy >= 4) { if (dual) launch_wide<8, true, 2>(st, a, gx, gy, gz); else launch_wide<8, false, 2>(st, a, gx, gy, gz); }
-                else { if (dual) launch_wide<4, true, 2>(st, a, gx, gy, gz); else launch_wide<4, false, 2>(st, a, gx, gy, gz); }
-                return;
-            }
+            wide2 = can && e[0] == '2' && a.nchunk >= 2;
+        }
+        if (wide2) {
+            if (gy >= 4) { if (dual) launch_wide<8, true, 2>(st, a, gx, gy, gz); else launch_wide<8, false, 2>(st, a, gx, gy, gz); }
+            else { if (dual) launch_wide<4, true, 2>(st, a, gx, gy, gz); else launch_wide<4, false, 2>(st, a, gx, gy, gz); }
+            return;
         }
         if (wide) {
 #define MUGD_WIDE(N) case N: if (dual) launch_wide<N, true>(st, a, gx, gy, gz); else launch_wide<N, false>(st, a, gx, gy, gz); break;

@@ -90,7 +90,8 @@ struct ConvArgs {
     int xs_heads, xs_pmax, xs_ntok; float xs_scale;
     int kb[9];               // K-split: wave w of a workgroup reduces the global chunks [kb[w], kb[w+1]); filled by conv_split_k()
     const unsigned* wmax;    // H3 weights (conv_body.h): device word holding the bits of max |w| over the whole packed set -- the pack kernels
-                             // stored w * h3_wscale(*wmax) (an exact power of two), the epilogue multiplies it back out.  null: unit scale
+                             // stored w * h3_wscale(*wmax) (an exact power of two), the epilogue multiplies it back out.  null: winv below
+    float winv;              // ... or, when the host knows the word (sets packed at network-compile time), 1 / h3_wscale by value; 0: unit scale
     unsigned long long* tl;  // development build (-DMUGD_TL) only: per-wave phase records [blocks][waves][TL_WORDS]; null otherwise
 };
 

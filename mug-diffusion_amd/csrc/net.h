@@ -101,6 +101,7 @@ struct ConvSpec {
 struct PackedW {
     float* wpk = nullptr;
     unsigned* wmax = nullptr;      // H3 domain: bits of max |w| over the set (ConvArgs::wmax); null for bfloat16 sets
+    float winv = 0.f;              // ... read back once for sets packed at compile time: 1 / h3_wscale, handed to the kernels by value (ConvArgs::winv)
     float* bias = nullptr;
     long long mt_stride = 0;
     int nchunk = 0;

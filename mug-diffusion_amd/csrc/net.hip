@@ -513,6 +513,12 @@ const PackedW& Net::get_packed(const ConvSpec& s, int tn, bool w16) {
             else if (tn == 16) launch_pack_weights16(ctx->stream, pa);
             else launch_pack_weights(ctx->stream, pa);
         }
+        if (pass == 0 && pw.wmax) {          // once per set and parameter load: the kernels get 1 / S_w by value instead of a cold load per wave
+            unsigned bits = 0;
+            HIP_CHECK(hipMemcpyAsync(&bits, pw.wmax, sizeof(bits), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            pw.winv = h3_pow2_recip(h3_wscale(bits));
+        }
     }
     if (!s.bias.empty()) {
         pw.bias = dev_alloc(s.Mrows, true);
@@ -589,7 +595,8 @@ Tensor Net::conv(const ConvSpec& s) {
     a.w16 = (ctx->weights_bf16 && !s.ext_plain && conv_w16_supported(a)) ? 1 : 0;
     const PackedW& pw = s.ext_plain ? get_packed_ext(s, a.tn) : get_packed(s, a.tn, a.w16 != 0);       // the tile width decides the weight fragment order
     for (int i = 0; i < a.nseg; ++i) { a.seg[i].chunk0 = pw.chunk0[i]; a.seg[i].woff = pw.woff[i]; }
-    a.wpk = pw.wpk; a.wmax = pw.wmax; a.w_mt_stride = pw.mt_stride; a.bias = pw.bias;
+    a.wpk = pw.wpk; a.w_mt_stride = pw.mt_stride; a.bias = pw.bias;
+    if (s.ext_plain) a.wmax = pw.wmax; else a.winv = pw.winv;        // H3 weight scale: device word for per-call sets, by value otherwise
     a.w_b_stride = s.ext_plain ? (long long)cdiv(s.Mrows, 32) * pw.mt_stride : 0;
     a.rowadd = s.rowadd; a.rowadd_stride = s.rowadd_stride;
     a.resid = s.resid.p;

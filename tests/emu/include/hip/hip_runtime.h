@@ -134,6 +134,13 @@ static inline int emu_update_dpp(int src, int ctrl) {
     int r; std::memcpy(&r, &f, 4); return r;
 }
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu_update_dpp((src), (ctrl))
+static inline int __builtin_amdgcn_readlane(int v, int lane) {           // v_readlane_b32: every lane gets lane `lane`'s value
+    float f; std::memcpy(&f, &v, 4);
+    f = emu::wave_xchg(f, lane & 63);
+    int r; std::memcpy(&r, &f, 4); return r;
+}
+static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
+static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 
 static inline float __shfl_xor(float v, int mask, int width = 64) { (void)width; return emu::wave_xchg(v, emu::lane_id() ^ mask); }
 static inline float __shfl_down(float v, unsigned d, int width = 64) {

@@ -6,7 +6,7 @@
 #   ops            pytest tests/test_ops.py -m gpu
 #   suite          the whole -m gpu suite + smoke()
 #   parity         the headline parity transcript (pytest -s -k "headline or ten_minute or ddim_full")
-#   ab:LIB         DDIM step of the in-tree library against tests/var/LIB/libmugd.so, batch 4 / 8 / 16, A/B/A/B (tests/gpu_probe.py --quick)
+#   ab:L1,L2[@B1,B2]  DDIM step of the in-tree library against tests/var/L*/libmugd.so, alternating, twice per batch size (default 4,8,16)
 #   wide           per-launch tables with MUGD_CONV_WIDE = 0 | 1 | 2 at batch 8 and 16, A/B/A/B
 #   bench          the driver's command (bench.py --gpus 1 --steps 20 --warmup 3)
 #   stats          rocprofv3 --kernel-trace --stats of a short bench run
@@ -40,13 +40,15 @@ for task in "$@"; do
       ( timeout 1200 python -m pytest tests/test_nets.py -q -s -m gpu -p no:cacheprovider -k "headline or ten_minute or ddim_full" ) > ${O}_parity.log 2>&1
       grep -E "flip|latent|passed|failed|error" ${O}_parity.log | tail -40 ;;
     ab)
-      : > ${O}_ab_$arg.log
-      for B in 4 8 16; do for v in new $arg new $arg; do
-        echo "== B=$B lib=$v" >> ${O}_ab_$arg.log
-        if [ $v = new ]; then timeout 300 python tests/gpu_probe.py --B $B --quick 2>&1 | probe_line >> ${O}_ab_$arg.log
-        else MUGD_LIB_PATH=$PWD/tests/var/$arg/libmugd.so timeout 300 python tests/gpu_probe.py --B $B --quick 2>&1 | probe_line >> ${O}_ab_$arg.log; fi
-      done; done
-      grep -E "^==|ms/step" ${O}_ab_$arg.log ;;
+      # ab:LIB1,LIB2,...[@B1,B2,...]: the in-tree library and each tests/var/LIB/libmugd.so alternating, twice, per batch size
+      libs=${arg%%@*}; bs=4,8,16; [ "$libs" != "$arg" ] && bs=${arg#*@}
+      L=${O}_ab_$(echo $libs | tr ',' '_').log; : > $L
+      for B in $(echo $bs | tr ',' ' '); do for rep in 1 2; do for v in new $(echo $libs | tr ',' ' '); do
+        echo "== B=$B lib=$v" >> $L
+        if [ $v = new ]; then timeout 300 python tests/gpu_probe.py --B $B --quick 2>&1 | probe_line >> $L
+        else MUGD_LIB_PATH=$PWD/tests/var/$v/libmugd.so timeout 300 python tests/gpu_probe.py --B $B --quick 2>&1 | probe_line >> $L; fi
+      done; done; done
+      grep -E "^==|ms/step" $L ;;
     wide)
       : > ${O}_wide.log
       for B in 16 8; do for v in 0 1 2 0 1 2; do
