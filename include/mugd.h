@@ -92,12 +92,22 @@ int mugd_set_weight_precision(mugd_ctx* ctx, int bf16);
 /* Names the conv / Linear arithmetic the library was built with.  The default build ("conv=f16x3-split MFMA"): fp32 tensors, every product
  * block on the f16 matrix cores with both operands split into f16 hi + 2^11-scaled lo halves and fp32 accumulation (csrc/conv_body.h: H3;
  * 2.7e-7 relative to float64 at K = 1024, below an fp32 fma chain's 7.7e-7).  DOMAIN: the whole fp32 range, like the reference
- * (/root/reference/mug/diffusion/unet.py:27-33 runs fp32 end to end).  Both operands are carried as block floating point -- the weights of a
- * packed set times one exact power of two, every staged 16-channel chunk of activations times a per-wave power of two that follows the data
- * (scale changes move the fp32 accumulators by the exact ratio) -- so no operand meets the f16 exponent range: samples down to 2^-14
- * (typically 2^-22) of their chunk's largest sample keep all 22 bits, smaller ones carry an absolute error below 2^-50 of that maximum; a
- * weight keeps all 22 bits down to 2^-25 of the set's largest.  Inf / NaN operands propagate to exactly the outputs they reach in fp32.
- * tests/test_ops.py holds op_conv1d / op_norm_conv1d / log_mel to the unit-scale fp32 tolerance at operand scales 1e-30 .. 1e30. */
+ * (/root/reference/mug/diffusion/unet.py:27-33 runs fp32 end to end).  No operand meets the f16 exponent range, because both are carried as
+ * block floating point -- times an exact power of two that is divided out of the fp32 accumulators at the end:
+ *   weights                 one scale per packed set, max |w| scale in [2^13, 2^14): a weight keeps all 22 bits down to 2^-25 of the set's largest;
+ *   raw activations         (no GroupNorm / LayerNorm in front: skip / resampling convs, attention and feed-forward outputs, the mel power
+ *                           spectrum, the training step's gradients) the fixed scale 2^8 while the largest sample of a wave's K-slice stays
+ *                           inside [2^-6, 2^7) -- checked once per slice from a running maximum; samples down to 2^-14 of the slice's
+ *                           largest keep all 22 bits, smaller ones carry an absolute error of 2^-44.  A slice that leaves that band (any
+ *                           sample >= 2^7, or a whole slice below 2^-6) makes the wave redo its tile with a scale that FOLLOWS THE DATA
+ *                           chunk by chunk: every 16-channel chunk is parked with its largest sample in [4, 2^15), the accumulators move by
+ *                           the exact ratio; samples down to 2^-14 (typically 2^-22) of their CHUNK's largest keep all 22 bits;
+ *   normalised activations  (GroupNorm / LayerNorm (+ SiLU) applied while the operand is staged) one static scale per tensor from the bound
+ *                           |v| <= max|gamma| sqrt(n) + max|beta| (n = elements per statistic): samples down to 2^-27 of the bound keep
+ *                           all 22 bits, smaller ones carry an absolute error below 2^-50 of the bound.
+ * Inf / NaN operands propagate to exactly the outputs they reach in fp32.  tests/test_ops.py holds op_conv1d / op_norm_conv1d / log_mel
+ * to the unit-scale fp32 tolerance at operand scales 1e-30 .. 1e30 (weights, inputs, affine parameters), with channel blocks 2^40 apart
+ * inside one reduction, on every tile form. */
 const char* mugd_version(void);
 
 /* ---- networks ------------------------------------------------------------------------- */

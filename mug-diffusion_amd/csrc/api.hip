@@ -79,6 +79,9 @@ __global__ __launch_bounds__(256) void clock_probe_kernel(int iters, float* sink
 
 extern "C" {
 
+#if defined(MUGD_EMULATED) && defined(MUGD_H3_COUNT)
+extern "C" { long long g_h3_events[8] = {0, 0, 0, 0, 0, 0, 0, 0}; }      // test build only (conv_body.h: H3_COUNT)
+#endif
 // conv_gemm's arithmetic is a build-time choice (conv_body.h: MUGD_CONV_H3): the version string names it so that measurements can label themselves
 #ifndef MUGD_CONV_H3
 #define MUGD_CONV_H3 1
@@ -474,6 +477,17 @@ int mugd_op_norm_conv1d(mugd_ctx* ctx, const float* x, const float* gamma, const
             launch_interleave2(st, gamma, beta, gb, C);
             a.seg[0].xf = 2; a.seg[0].act = silu; a.seg[0].xf_a = stat; a.seg[0].xf_b = gb; a.seg[0].xf_stride = 2 * T;
         }
+        {   // the static H3 scale of the normalised operand (kernels.h: h3_static_scale; Net::norm_scale does the same once per layer)
+            unsigned* gbm = reinterpret_cast<unsigned*>(sc.get(2, true, st));
+            launch_absmax(st, gamma, C, gbm);
+            launch_absmax(st, beta, C, gbm + 1);
+            unsigned bits[2] = {0, 0};
+            HIP_CHECK(hipMemcpyAsync(bits, gbm, sizeof(bits), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            float gm, bm;
+            memcpy(&gm, &bits[0], 4); memcpy(&bm, &bits[1], 4);
+            a.seg[0].sx0 = h3_static_scale(gm, bm, norm == 1 ? (double)(C / (groups > 0 ? groups : 1)) * T : (double)C);
+        }
         a.wpk = wpk; a.w_mt_stride = mts; a.bias = bias; a.y = y;
         a.B = B; a.Mrows = M; a.Mout = M; a.Tout = T + 2 * pad - dil * (taps - 1); a.nchunk = C / CONV_CK; a.epi = EPI_NONE;
         a.wk = wk ? wk : ctx->c.force_wk;
@@ -490,6 +504,7 @@ int mugd_op_norm_conv1d(mugd_ctx* ctx, const float* x, const float* gamma, const
 // cycled through so that with copies * M * C * taps * 4 bytes > 256 MiB every launch streams its weights from HBM, like a
 // layer inside the U-Net step does (the step's 0.4 GB of fp32 weights do not stay on die).  norm: 0 none | 1 GroupNorm(32)
 // + SiLU fused | 2 LayerNorm fused.  Returns the mean time per launch in microseconds (HIP events over `iters` launches).
+static const float H3_SX0_HOST = 256.0f;      // the benchmark's memset operands are O(1e-2): any in-range static scale times the launch the same
 int mugd_dev_bench_conv(mugd_ctx* ctx, int B, int C, int T, int M, int taps, int norm, int gated, int wk, int tn, int copies,
                         int iters, float* us_out) {
     return guarded(ctx, [&] {
@@ -502,14 +517,14 @@ int mugd_dev_bench_conv(mugd_ctx* ctx, int B, int C, int T, int M, int taps, int
         float* y = sc.get((size_t)B * M * T, false, st);
         float* aff = sc.get((size_t)B * C * 2 + (size_t)B * T * 2 + 2 * C, false, st);
         float* wpk = sc.get((size_t)copies * MT * mts, false, st);
-        HIP_CHECK(hipMemsetAsync(x, 0x3c, (size_t)B * C * T * 4, st));           // 0x3c3c3c3c ~ 0.0115: finite, non-zero operands
+        HIP_CHECK(hipMemsetAsync(x, 0x3e, (size_t)B * C * T * 4, st));           // 0x3e3e3e3e ~ 0.186: finite, non-zero operands inside the band of the H3 domain at its initial scale
         HIP_CHECK(hipMemsetAsync(aff, 0x3c, ((size_t)B * C * 2 + (size_t)B * T * 2 + 2 * C) * 4, st));
         HIP_CHECK(hipMemsetAsync(wpk, 0x3c, (size_t)copies * MT * mts * 4, st));
         ConvArgs a{};
         a.nseg = 1;
         a.seg[0] = ConvSeg{x, C, T, taps, 1, 1, taps / 2, 0, 0, 0, 0};
-        if (norm == 1) { a.seg[0].xf = 1; a.seg[0].act = ctx->c.fast_act ? 2 : 1; a.seg[0].xf_a = aff; a.seg[0].xf_stride = 2 * C; }
-        if (norm == 2) { a.seg[0].xf = 2; a.seg[0].xf_a = aff; a.seg[0].xf_b = aff + (size_t)B * T * 2; a.seg[0].xf_stride = 2 * T; }
+        if (norm == 1) { a.seg[0].xf = 1; a.seg[0].act = ctx->c.fast_act ? 2 : 1; a.seg[0].xf_a = aff; a.seg[0].xf_stride = 2 * C; a.seg[0].sx0 = H3_SX0_HOST; }
+        if (norm == 2) { a.seg[0].xf = 2; a.seg[0].xf_a = aff; a.seg[0].xf_b = aff + (size_t)B * T * 2; a.seg[0].xf_stride = 2 * T; a.seg[0].sx0 = H3_SX0_HOST; }
         a.w_mt_stride = mts; a.y = y;
         a.B = B; a.Mrows = M; a.Mout = gated ? M / 2 : M; a.Tout = T; a.nchunk = C / CONV_CK; a.epi = gated ? EPI_GEGLU : EPI_NONE;
         a.wk = wk;

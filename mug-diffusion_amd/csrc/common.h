@@ -86,7 +86,7 @@ __device__ __forceinline__ int fastdiv(int n, unsigned m, int d) {
 #endif
 
 // KARG_WARM: the first instructions of a kernel touch EVERY 64-byte line of its kernel-argument block -- ten for ConvArgs -- with
-// back-to-back scalar loads and wait once.  Each CU's scalar cache starts a launch without them, the compiler places the argument
+// back-to-back scalar loads and wait once (eleven since round 5: ConvSeg::sx0).  Each CU's scalar cache starts a launch without them, the compiler places the argument
 // loads lazily along the control flow (a load, a wait, a branch; the next load behind it), and a first touch of a line is a trip to
 // L2 / HBM: up to ten of those in series along the conv_gemm prologue.  After the touch they are scalar-cache hits.
 #ifdef MUGD_EMULATED
@@ -95,15 +95,15 @@ __device__ __forceinline__ int fastdiv(int n, unsigned m, int d) {
 // (one asm block: left to itself the compiler interleaves such loads with its own and waits four times)
 #define KARG_WARM(bytes)                                                                                                        \
     do {                                                                                                                        \
-        static_assert((bytes) > 576 && (bytes) <= 640, "KARG_WARM touches exactly ten 64-byte lines: the block must end in the tenth");                                                   \
+        static_assert((bytes) > 640, "KARG_WARM touches the first eleven 64-byte lines of the block");                                                   \
         const auto kw_p_ = __builtin_amdgcn_kernarg_segment_ptr();                           \
-        unsigned kw0_, kw1_, kw2_, kw3_, kw4_, kw5_, kw6_, kw7_, kw8_, kw9_;                                                    \
-        asm volatile("s_load_dword %0, %10, 0x0\n\ts_load_dword %1, %10, 0x40\n\ts_load_dword %2, %10, 0x80\n\t"              \
-                     "s_load_dword %3, %10, 0xc0\n\ts_load_dword %4, %10, 0x100\n\ts_load_dword %5, %10, 0x140\n\t"            \
-                     "s_load_dword %6, %10, 0x180\n\ts_load_dword %7, %10, 0x1c0\n\ts_load_dword %8, %10, 0x200\n\t"           \
-                     "s_load_dword %9, %10, 0x240\n\ts_waitcnt lgkmcnt(0)"                                                      \
+        unsigned kw0_, kw1_, kw2_, kw3_, kw4_, kw5_, kw6_, kw7_, kw8_, kw9_, kw10_;                                             \
+        asm volatile("s_load_dword %0, %11, 0x0\n\ts_load_dword %1, %11, 0x40\n\ts_load_dword %2, %11, 0x80\n\t"              \
+                     "s_load_dword %3, %11, 0xc0\n\ts_load_dword %4, %11, 0x100\n\ts_load_dword %5, %11, 0x140\n\t"            \
+                     "s_load_dword %6, %11, 0x180\n\ts_load_dword %7, %11, 0x1c0\n\ts_load_dword %8, %11, 0x200\n\t"           \
+                     "s_load_dword %9, %11, 0x240\n\ts_load_dword %10, %11, 0x280\n\ts_waitcnt lgkmcnt(0)"                        \
                      : "=&s"(kw0_), "=&s"(kw1_), "=&s"(kw2_), "=&s"(kw3_), "=&s"(kw4_), "=&s"(kw5_), "=&s"(kw6_), "=&s"(kw7_),  \
-                       "=&s"(kw8_), "=&s"(kw9_)                                                                                 \
+                       "=&s"(kw8_), "=&s"(kw9_), "=&s"(kw10_)                                                                   \
                      : "s"(kw_p_)                                                                                               \
                      : "memory");                                                                                               \
     } while (0)

@@ -17,6 +17,10 @@
 #ifndef MUGD_PIPE
 #define MUGD_PIPE true
 #endif
+// every lambda of the tile body must be inlined: one that is not turns the register arrays it captures by reference (ring stages, weight
+// fragments, staged samples) into scratch memory -- round 5 saw the WK = 8 kernels grow past the inliner's budget: 688 bytes of scratch per lane
+// and +20 us per launch.  Clang accepts the attribute between a lambda's parameter list and its body.
+#define MUGD_LI __attribute__((always_inline))
 
 namespace {
 
@@ -68,6 +72,16 @@ struct ConvAcc<32> {
     }
     // cross terms in, scales out: u = 1 / sx, w = 1 / S_w (two multiplies: either may sit at the edge of the exponent range)
     __device__ __forceinline__ void fold_cross(bool two, float u, float w) {
+        const int e = h3_biased_exp(u) + h3_biased_exp(w) - 127;
+        if (e > 20 && e < 234) {                 // u w and u w / 2^11 are normal powers of two (always, short of operands at the ends of the fp32 range)
+            const float uw = h3_pow2_biased(e), uwl = h3_pow2_biased(e - 11);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                a[r] = a[r] * uw + l[r] * uwl;   // both products exact: one rounding, like acc + accL / 2^11
+                if (two) a2[r] = a2[r] * uw + l2[r] * uwl;
+            }
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             a[r] = ((a[r] + l[r] * (1.0f / 2048.0f)) * u) * w;
@@ -96,12 +110,15 @@ struct ConvAcc<16> {
         }
     }
     __device__ __forceinline__ void fold_cross(bool two, float u, float w) {
+        const int e = h3_biased_exp(u) + h3_biased_exp(w) - 127;
+        const bool one = e > 20 && e < 234;
+        const float uw = h3_pow2_biased(e), uwl = h3_pow2_biased(e - 11);
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                a[h][i] = ((a[h][i] + l[h][i] * (1.0f / 2048.0f)) * u) * w;
-                if (two) a2[h][i] = ((a2[h][i] + l2[h][i] * (1.0f / 2048.0f)) * u) * w;
+                a[h][i] = one ? a[h][i] * uw + l[h][i] * uwl : ((a[h][i] + l[h][i] * (1.0f / 2048.0f)) * u) * w;
+                if (two) a2[h][i] = one ? a2[h][i] * uw + l2[h][i] * uwl : ((a2[h][i] + l2[h][i] * (1.0f / 2048.0f)) * u) * w;
             }
     }
     __device__ __forceinline__ float get(int r) const { return a[r >> 2][r & 3]; }
@@ -174,8 +191,8 @@ __device__ __forceinline__ float h3_split_scaled(float v, float sc) {
 #if MUGD_H3_MIX && !defined(MUGD_EMULATED)
     unsigned d;
     float r;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(d) : "v"(v), "v"(sc));
-    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(v), "v"(sc), "v"(d));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(d) : "v"(v), "s"(sc));                // the scale is wave-uniform: a scalar register operand
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(v), "s"(sc), "v"(d));
     asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(d) : "v"(r), "s"(2048.0f));
     return __uint_as_float(d);
 #else
@@ -203,6 +220,18 @@ constexpr bool conv_h3() { return MUGD_CONV_H3 != 0 && sizeof(WT) == 4; }
 // Inf / NaN among the operands propagate as they do in fp32 (no scale is derived from them).
 // ---------------------------------------------------------------------------------------
 constexpr float H3_LIM = 32768.0f, H3_LOW = 4.0f;
+// development builds only (-DMUGD_H3_COUNT): event counters of the domain machinery -- [0] parks, [1] slow paths, [2] rescales, [3] tile redos
+// (waves), [4] all-zero chunks, [5] off-band high, [6] off-band low.  Emulated build: a host array; GPU build: a device array of the k_conv.hip
+// translation unit (MUGD_H3_COUNT_TU), read back through mugd_dev_h3_counters
+#if defined(MUGD_EMULATED) && defined(MUGD_H3_COUNT)
+extern "C" long long g_h3_events[8];
+#define H3_COUNT(i) do { if (emu::lane_id() == 0) ++g_h3_events[i]; } while (0)
+#elif defined(MUGD_H3_COUNT) && defined(MUGD_H3_COUNT_TU)
+__device__ unsigned long long g_h3_dev[8];
+#define H3_COUNT(i) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_h3_dev[i], 1ull); } while (0)
+#else
+#define H3_COUNT(i) do {} while (0)
+#endif
 #ifndef MUGD_H3_DYN
 #define MUGD_H3_DYN 1          // 0: development A/B arm -- no dynamic activation scale (the round-4 behaviour: operands must sit in the f16 range)
 #endif
@@ -232,14 +261,19 @@ __device__ __forceinline__ unsigned wave_max_bits(float m) {
 // does a chunk whose lane maxima are m leave the band at scale sc?
 __device__ __forceinline__ bool h3_off_band(float m, float sc) {
     const float ms = m * sc;
-    return wave_any(ms >= H3_LIM) || !wave_any(ms >= H3_LOW);
+#ifdef MUGD_EMULATED
+    return wave_any(ms >= H3_LIM) | !wave_any(ms >= H3_LOW);
+#else
+    // two ballots, two scalar compares: inside the band iff no lane reaches the upper limit and some lane reaches the lower one
+    return __builtin_amdgcn_ballot_w64(ms >= H3_LIM) != 0ull || __builtin_amdgcn_ballot_w64(ms >= H3_LOW) == 0ull;
+#endif
 }
 // the accumulators move from scale ac.sx to scale s
 template <int TN>
 __device__ __forceinline__ void h3_adopt(ConvAcc<TN>& ac, float s, bool two) {
     ac.scale_all(h3_pow2_biased(127 + h3_biased_exp(s) - h3_biased_exp(ac.sx)), two);
-    ac.sx = s;
-    ac.sxmin = fminf(ac.sxmin, s);
+    ac.sx = rfl_f(s);                                    // wave-uniform by construction: keep the scale state in scalar registers
+    ac.sxmin = rfl_f(fminf(ac.sxmin, s));
 }
 // slow path of a park: m = this lane's max |v| of the chunk, sc = the scale the chunk would be parked at.  Returns the scale to park at;
 // adopt: the parking wave is the consumer (K-split forms) -- its accumulators follow at once.  All in the exponent domain on
@@ -248,10 +282,14 @@ template <int TN>
 __device__ __forceinline__ float h3_pick(ConvAcc<TN>& ac, float m, float sc, bool adopt, bool two) {
     const unsigned mb = wave_max_bits(m);
     const int E = (int)(mb >> 23);
+    H3_COUNT(1);
+    if (mb == 0u) H3_COUNT(4);
     if (mb != 0u && E < 255) {                                       // an all-zero chunk is parked at whatever scale; inf: no scale
         const int Ee = E < 1 ? 1 : E;                                // (fp32 subnormal maxima count as 2^-126)
         const int cur = Ee + h3_biased_exp(sc) - 254;
         if (cur < 2 || cur > 14) {
+            H3_COUNT(2);
+            if (cur > 14) H3_COUNT(5); else H3_COUNT(6);
             int b = 264 - Ee;                                        // mw sc in [2^10, 2^11)
             const int cap = h3_biased_exp(ac.sxmin) + 64;            // ... but never more than 2^64 above the smallest scale so far
             b = b < cap ? b : cap;
@@ -423,12 +461,42 @@ __device__ __forceinline__ void conv_mfma(const char* smem_bytes, int rb0, int d
 // transforms and parks the chunks k = w, w + COOP, ... (with exactly the per-wave staging code below) into slot w of a double-buffered set
 // of COOP shared windows, every wave consumes all COOP chunks of a phase with its own weight fragments, one workgroup barrier per phase:
 // the operand transform / split / park work per MFMA drops by COOP.  wave_base must be 0; coop_wave = the wave's index.
+// Returns true when the wave must REDO its tile in the careful mode (H3 domain, TRACK mode below); false otherwise.
 template <int TN, int TAPS, bool DUAL, int NH, int XFK = -1, int ACT = -1, bool PIPE = false, class WT = float, class SEG = ConvSeg, int COOP = 0>
-__device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, const WT* wseg2, int lo, int hi,
+__device__ __forceinline__ bool run_segment_vec(const SEG& s, const WT* wseg, const WT* wseg2, int lo, int hi,
                                                 int b, int t0, int lane, char* smem_bytes, int wave_base,
                                                 ConvAcc<TN>& ac, const float2* gst, const float2* lnst, float inv_cg, int rot_seed, int coop_wave = 0,
-                                                float* wsc = nullptr) {
+                                                float* wsc = nullptr, bool fresh = false) {
     typedef ConvGeo<TN> G;
+    // H3 domain, three ways to scale a segment's samples (conv_h3 above):
+    //   STATIC  (XFK >= 1: the transform is known at compile time to be a normalisation) the host's scale from the affine bound (ConvSeg::sx0):
+    //           no per-chunk work at all;
+    //   TRACK   (XFK == 0: raw samples, K-split forms) the fixed scale H3_SX0 and a RUNNING lane maximum -- 5 VALU per chunk, no compare, no
+    //           branch, the accumulators' scale a constant -- checked ONCE when the wave's slice of the segment is done: a slice whose largest
+    //           sample left the band [4, 2^15) makes the wave redo its whole tile in the careful mode (conv_tile), which is the rare path;
+    //   CAREFUL (the run-time-transform instantiation XFK == -1 -- also what a redo runs every segment through -- and the M-split forms) the
+    //           scale follows the data chunk by chunk: park, ask, and if the chunk left the band pick a new scale, move the accumulators,
+    //           park again.
+    constexpr int H3_OFF = 0, H3_STATIC = 1, H3_TRACK = 2, H3_CAREFUL = 3;
+    constexpr int H3M = !conv_h3<WT>() ? H3_OFF : XFK >= 1 ? H3_STATIC : !MUGD_H3_DYN ? H3_STATIC : (XFK == 0 && COOP == 0) ? H3_TRACK : H3_CAREFUL;
+    const float sx_fixed = H3M == H3_TRACK ? H3_SX0 : (H3M == H3_STATIC && XFK >= 1) ? rfl_f(s.sx0 != 0.f ? s.sx0 : 1.0f) : H3_SX0;
+    if ((H3M == H3_STATIC || H3M == H3_TRACK) && COOP == 0 && sx_fixed != ac.sx) {
+        if (fresh) { ac.sx = rfl_f(sx_fixed); ac.sxmin = ac.sx; }      // the wave's first segment: the accumulators are still zero
+        else h3_adopt<TN>(ac, sx_fixed, DUAL);
+    }
+    // TRACK: the lane's largest |sample| of the slice so far, as FOUR independent running maxima (one v_max3 each per chunk: a single
+    // running maximum is a chain of dependent VALU operations through every sample of every chunk -- measured +10 % on the long-K raw launches)
+    float mr[4] = {0.f, 0.f, 0.f, 0.f};
+    auto slice_verdict = [&]() MUGD_LI -> bool {                   // TRACK: did the slice leave the band?  (an all-zero slice did not)
+        if (H3M != H3_TRACK) return false;
+#if defined(MUGD_H3_TRACKMODE) && MUGD_H3_TRACKMODE == 1       // development A/B arm: the running maxima without the verdict
+        asm volatile("" :: "v"(mr[0]), "v"(mr[1]), "v"(mr[2]), "v"(mr[3]));
+        return false;
+#endif
+        const float mrun = fmaxf(fmaxf(mr[0], mr[1]), fmaxf(mr[2], mr[3]));
+        const float ms = mrun * H3_SX0;
+        return wave_any(ms >= H3_LIM) || (!wave_any(ms >= H3_LOW) && wave_any(mrun > 0.f));
+    };
 
     constexpr int RSV = G::RS;
     constexpr int XV = TN / 16;                            // aligned float4 per lane and chunk (lane (row = lane / 4, q = lane % 4))
@@ -493,7 +561,7 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
     }
 
     // LayerNorm statistics from the producer's column sums: reduced once per workgroup (conv_stats.h), read back from LDS here
-    auto finish_ln = [&]() {
+    auto finish_ln = [&]() MUGD_LI {
         if (s.xf != 3) return;
 #pragma unroll
         for (int i = 0; i < SPL; ++i) { const float2 st = lnst[SPL * q + i]; mu[i] = st.x; rsd[i] = st.y; }
@@ -512,7 +580,7 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
     float2 gbv = make_float2(1.f, 0.f);
 
     int gbg = 0;                                    // gn4: GroupNorm group of the channel gbv belongs to
-    auto load_gb2 = [&](int cr, int& gg) -> float2 {   // per-channel {g, b} of chunk lo + cr for this lane's row; for gn4 the raw
+    auto load_gb2 = [&](int cr, int& gg) MUGD_LI -> float2 {   // per-channel {g, b} of chunk lo + cr for this lane's row; for gn4 the raw
         if (gn4) {                                  // {gamma, beta}: the group statistics are folded in when the chunk is parked,
             const int c = s.xf_coff + (lo + cr) * CONV_CK + r;      // so no load here waits for the group reduction
             gg = (int)(((float)c + 0.5f) * inv_cg);
@@ -520,9 +588,11 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
         }
         return *reinterpret_cast<const float2*>(gb + (size_t)cr * (2 * CONV_CK));
     };
-    auto load_gb = [&](int cr) -> float2 { return load_gb2(cr, gbg); };
+    auto load_gb = [&](int cr) MUGD_LI -> float2 { return load_gb2(cr, gbg); };
     // transform the staged samples and park them in window `wofs` (byte offset 0 | WIN_LDS*4)
-    auto park_v = [&](int wofs, const float4 (&xq)[XV], const float (&xhh)[NHA], const float2 gbq, const int ggq, const int slot = 0) {
+    // mid(): the caller's next global loads (they may overwrite xq / xhh: the samples are in v[] by then), issued right behind the stores
+    auto no_mid = []() MUGD_LI {};
+    auto park_v = [&](int wofs, const float4 (&xq)[XV], const float (&xhh)[NHA], const float2 gbq, const int ggq, const int slot, auto&& mid) MUGD_LI {
         float v[SPL];
         float vh[NHA];
 #pragma unroll
@@ -548,30 +618,75 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
                 for (int j = 0; j < NH; ++j) vh[j] = silu_fast(vh[j]);
             }
         }
-        if (conv_h3<WT>()) {                            // H3: the window holds the {hi | lo} f16 halves of every SCALED sample (0.f is {0 | 0})
+        // split (H3) and store: zero padding AFTER the transform (component selects: no scratch)
+        auto put = [&](const float sc) MUGD_LI {
+            float w[SPL], wh[NHA];
+#pragma unroll
+            for (int i = 0; i < SPL; ++i) w[i] = conv_h3<WT>() ? h3_split_scaled(v[i], sc) : v[i];      // H3: the {hi | lo} f16 halves of the SCALED sample (0.f is {0 | 0})
+#pragma unroll
+            for (int j = 0; j < NH; ++j) wh[j] = conv_h3<WT>() ? h3_split_scaled(vh[j], sc) : vh[j];
+#pragma unroll
+            for (int x = 0; x < XV; ++x) {
+                f32x4 q4;
+                q4[0] = okv[x] ? w[4 * x] : 0.f; q4[1] = okv[x] ? w[4 * x + 1] : 0.f; q4[2] = okv[x] ? w[4 * x + 2] : 0.f; q4[3] = okv[x] ? w[4 * x + 3] : 0.f;
+#if MUGD_H3_MIX && !defined(MUGD_EMULATED)
+                // pin the four dwords in ONE register quad: the split's asm results are separate outputs, and left alone the store of them is
+                // emitted as two or three narrower LDS writes instead of one ds_write_b128 (+16 LDS instructions per wave: profiles/r5_h3_domain_ab.txt)
+                asm volatile("" : "+v"(q4));
+#endif
+                *reinterpret_cast<f32x4*>(smem_bytes + wofs + l0 + 16 * x) = q4;
+            }
+#pragma unroll
+            for (int j = 0; j < NH; ++j) *reinterpret_cast<float*>(smem_bytes + wofs + lh[j]) = okh[j] ? wh[j] : 0.f;
+        };
+        if (H3M == H3_STATIC || H3M == H3_TRACK) {
+#if !defined(MUGD_H3_TRACKMODE) || MUGD_H3_TRACKMODE != 2      // (development A/B arm 2: the verdict without the running maxima)
+            if (H3M == H3_TRACK) {
+#pragma unroll
+                for (int i = 0; i < SPL; i += 2) mr[(i >> 1) & 3] = fmaxf(mr[(i >> 1) & 3], fmaxf(fabsf(v[i]), fabsf(v[i + 1])));
+#pragma unroll
+                for (int j = 0; j < NH; ++j) mr[j & 3] = fmaxf(mr[j & 3], fabsf(vh[j]));
+            }
+#endif
+            put(sx_fixed);
+            H3_COUNT(0);
+            if (COOP > 0 && lane == 0) wsc[slot] = sx_fixed;   // M-split: the window's scale travels with it
+            // The caller's loads overwrite the very registers the maxima above read.  Left free, the scheduler hoists those loads ABOVE the
+            // readers, sends them to spare registers, and then has to wait for them (s_waitcnt vmcnt(0)) to copy them into the ring stage --
+            // inside the pipelined loop: +10 % on the long-K raw launches before this barrier (profiles/r5_h3_domain_ab.txt)
+            // (the empty asm pins the maxima in front of the barrier: to the IR they are pure arithmetic, free to sink below it)
+#ifndef MUGD_EMULATED
+            if (H3M == H3_TRACK) asm volatile("" :: "v"(mr[0]), "v"(mr[1]), "v"(mr[2]), "v"(mr[3]));
+#endif
+            if (H3M == H3_TRACK) __builtin_amdgcn_sched_barrier(0);
+            mid();
+        } else if (H3M == H3_CAREFUL) {
+            // park speculatively at the wave's current scale, collect the chunk's max |v| on the side, ask afterwards; a chunk that left the
+            // band is parked again at its new scale (K-split forms: the accumulators follow at once; M-split forms: the consumers adopt it)
+            float sc = ac.sx;
+            put(sc);
+            H3_COUNT(0);
             float m = 0.f;
 #pragma unroll
             for (int i = 0; i < SPL; ++i) m = fmaxf(m, fabsf(v[i]));
 #pragma unroll
             for (int j = 0; j < NH; ++j) m = fmaxf(m, fabsf(vh[j]));
-            float sc = ac.sx;
-            if (MUGD_H3_DYN && __builtin_expect(h3_off_band(m, sc), 0)) sc = h3_pick<TN>(ac, m, sc, COOP == 0, DUAL);
-#pragma unroll
-            for (int i = 0; i < SPL; ++i) v[i] = h3_split_scaled(v[i], sc);
-#pragma unroll
-            for (int j = 0; j < NH; ++j) vh[j] = h3_split_scaled(vh[j], sc);
-            if (COOP > 0 && lane == 0) wsc[slot] = sc;   // M-split: the window's scale travels with it
+#ifndef MUGD_EMULATED
+            asm volatile("" :: "v"(m));
+#endif
+            __builtin_amdgcn_sched_barrier(0);          // (as in the TRACK branch: the loads of mid() must not move above the readers of the samples)
+            mid();
+            if (__builtin_expect(h3_off_band(m, sc), 0)) {
+                const float s2 = h3_pick<TN>(ac, m, sc, COOP == 0, DUAL);
+                if (s2 != sc) { sc = s2; put(sc); }
+            }
+            if (COOP > 0 && lane == 0) wsc[slot] = sc;
+        } else {
+            put(1.0f);
+            mid();
         }
-#pragma unroll
-        for (int x = 0; x < XV; ++x) {                  // zero padding AFTER the transform (component selects: no scratch)
-            float4 w;
-            w.x = okv[x] ? v[4 * x] : 0.f; w.y = okv[x] ? v[4 * x + 1] : 0.f; w.z = okv[x] ? v[4 * x + 2] : 0.f; w.w = okv[x] ? v[4 * x + 3] : 0.f;
-            *reinterpret_cast<float4*>(smem_bytes + wofs + l0 + 16 * x) = w;
-        }
-#pragma unroll
-        for (int j = 0; j < NH; ++j) *reinterpret_cast<float*>(smem_bytes + wofs + lh[j]) = okh[j] ? vh[j] : 0.f;
     };
-    auto park = [&](int wofs) { park_v(wofs, xv, xh, gbv, gbg); };
+    auto park = [&](int wofs) MUGD_LI { park_v(wofs, xv, xh, gbv, gbg, 0, no_mid); };
 
     if constexpr (COOP > 0) {
         static_assert(COOP % 2 == 0, "the weight-fragment ring alternates with the chunk parity");
@@ -584,7 +699,7 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
         int RGG = 0;
 #pragma unroll
         for (int j = 0; j < NHA; ++j) RXH[j] = 0.f;
-        auto fetch_x = [&](int k) {
+        auto fetch_x = [&](int k) MUGD_LI {
             const char* xq = xb + (size_t)k * xstep;
 #pragma unroll
             for (int x = 0; x < XV; ++x) RX[x] = *reinterpret_cast<const float4*>(xq + gv[x]);
@@ -592,15 +707,12 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
             for (int j = 0; j < NH; ++j) RXH[j] = *reinterpret_cast<const float*>(xq + gh[j]);
             if (xf) RGB = load_gb2(k, RGG);
         };
-        auto fetch_a = [&](int k, int d) { load_a<TAPS, DUAL>(wp + (size_t)k * (TAPS * 512), wp2 + (size_t)k * (TAPS * 512), RA[d], RA2[d]); };
+        auto fetch_a = [&](int k, int d) MUGD_LI { load_a<TAPS, DUAL>(wp + (size_t)k * (TAPS * 512), wp2 + (size_t)k * (TAPS * 512), RA[d], RA2[d]); };
         if (coop_wave < nch) fetch_x(coop_wave);
         fetch_a(0, 0);
         if (1 < nch) fetch_a(1, 1);
         finish_ln();
-        if (coop_wave < nch) {
-            park_v(coop_wave * W1, RX, RXH, RGB, RGG, coop_wave);
-            if (coop_wave + COOP < nch) fetch_x(coop_wave + COOP);
-        }
+        if (coop_wave < nch) park_v(coop_wave * W1, RX, RXH, RGB, RGG, coop_wave, [&]() MUGD_LI { if (coop_wave + COOP < nch) fetch_x(coop_wave + COOP); });
         __syncthreads();
         TL_STAMP_ONCE(2);
         const int nph = (nch + COOP - 1) / COOP;
@@ -619,13 +731,12 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
                     if (k + 2 < nch) fetch_a(k + 2, j & 1);
                 }
                 if (j == 0 && kn < nch) {                   // under the first chunk's MFMAs: the next phase's window, into the other buffer
-                    park_v(((buf ^ 1) * COOP + coop_wave) * W1, RX, RXH, RGB, RGG, (buf ^ 1) * COOP + coop_wave);
-                    if (kn + COOP < nch) fetch_x(kn + COOP);
+                    park_v(((buf ^ 1) * COOP + coop_wave) * W1, RX, RXH, RGB, RGG, (buf ^ 1) * COOP + coop_wave, [&]() MUGD_LI { if (kn + COOP < nch) fetch_x(kn + COOP); });
                 }
             }
             __syncthreads();                                // next phase's windows complete; this phase's windows free
         }
-        return;
+        return false;
     }
 
     if (PIPE) {
@@ -654,7 +765,7 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
         // instead of 16 requests piling up on one pending miss (tests/gpu_l2bw.hip: 22-28 -> 33-34 B/clk/CU on a cold K = 4608
         // panel, no effect on short ones).  fp32 sums are order-dependent: the result stays deterministic, per column tile.
         const int rot = nch >= 8 ? rot_seed % nch : 0;
-        auto fetch_x = [&](int cr0, int d) {
+        auto fetch_x = [&](int cr0, int d) MUGD_LI {
             int cr = cr0 + rot;
             cr = cr >= nch ? cr - nch : cr;
             const char* xq = xb + (size_t)cr * xstep;
@@ -664,7 +775,7 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
             for (int j = 0; j < NH; ++j) RXH[d][j] = *reinterpret_cast<const float*>(xq + gh[j]);
             if (xf) RGB[d] = load_gb2(cr, RGG[d]);
         };
-        auto fetch_a = [&](int cr0, int d) {
+        auto fetch_a = [&](int cr0, int d) MUGD_LI {
             int cr = cr0 + rot;
             cr = cr >= nch ? cr - nch : cr;
             load_a<TAPS, DUAL>(wp + (size_t)cr * (TAPS * 512), wp2 + (size_t)cr * (TAPS * 512), RA[d], RA2[d]);
@@ -679,8 +790,7 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
         TL_STAMP_ONCE(15);
 #endif
         finish_ln();
-        park_v(0, RX[0], RXH[0], RGB[0], RGG[0]);
-        if (D < nch) fetch_x(D, 0);
+        park_v(0, RX[0], RXH[0], RGB[0], RGG[0], 0, [&]() MUGD_LI { if (D < nch) fetch_x(D, 0); });
         wave_sync();
         TL_STAMP_ONCE(2);
         for (int c = 0; c < nch; c += D) {
@@ -691,15 +801,14 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
                     const int dn = (d + 1) % D;
                     conv_mfma<TN, TAPS, DUAL, WT>(smem_bytes + (d & 1) * W1, rb0, s.dil, RA[d], RA2[d], ac);
                     if (cc + 1 < nch) {
-                        park_v(((d + 1) & 1) * W1, RX[dn], RXH[dn], RGB[dn], RGG[dn]);
-                        if (cc + 1 + D < nch) fetch_x(cc + 1 + D, dn);
+                        park_v(((d + 1) & 1) * W1, RX[dn], RXH[dn], RGB[dn], RGG[dn], 0, [&]() MUGD_LI { if (cc + 1 + D < nch) fetch_x(cc + 1 + D, dn); });
                     }
                     if (cc + D < nch) fetch_a(cc + D, d);
                     wave_sync();
                 }
             }
         }
-        return;
+        return slice_verdict();
     }
 
 #pragma unroll
@@ -713,7 +822,7 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
     if (xf) gbv = load_gb(0);
     finish_ln();
 
-    auto step = [&](const float4 (&A)[6], const float4 (&A2)[6], float4 (&An)[6], float4 (&An2)[6], bool more) {
+    auto step = [&](const float4 (&A)[6], const float4 (&A2)[6], float4 (&An)[6], float4 (&An2)[6], bool more) MUGD_LI {
         park(0);
         wave_sync();
         if (more) {
@@ -739,6 +848,7 @@ __device__ __forceinline__ void run_segment_vec(const SEG& s, const WT* wseg, co
         step(Ab, Ab2, Aa, Aa2, c + 1 < hi);
         if (++c >= hi) break;
     }
+    return slice_verdict();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -798,7 +908,7 @@ __device__ __forceinline__ void run_segment_gen(const SEG& s, const float* wseg,
         if (xf) gbr[k] = *reinterpret_cast<const float2*>(gb + 2 * rowk[k]);
     }
 
-    auto step = [&](const float4 (&A)[6], const float4 (&A2)[6], float4 (&An)[6], float4 (&An2)[6], bool more) {
+    auto step = [&](const float4 (&A)[6], const float4 (&A2)[6], float4 (&An)[6], float4 (&An2)[6], bool more) MUGD_LI {
         float v[NIT];
 #pragma unroll
         for (int k = 0; k < NIT; ++k) v[k] = xr[k];
@@ -968,7 +1078,7 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
         }
     }
     constexpr bool PRELOAD = TALL ? EPT <= 2 : EPT <= 4;   // wide per-wave epilogues (WK 1, 2; TALL: WK 4 too) load late instead: registers
-    auto load_side = [&]() {
+    auto load_side = [&]() MUGD_LI {
         if (a.bias) {
     #pragma unroll
             for (int q = 0; q < EPT; ++q) { bv[q] = a.bias[mm[q]]; if (DUAL) bg[q] = a.bias[mm[q] + a.Mout]; if (TALL) bg[q] = a.bias[mm2[q]]; }
@@ -993,6 +1103,11 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
     TL_STAMP(1);
     TL_SET(10, g1 - g0);
 
+    bool redo = false;                               // H3 domain: a raw segment's slice left the band at the fixed scale (run_segment_vec: TRACK)
+    // (this loop MUST be fully unrolled: left rolled, the dynamic index a.seg[si] moves the whole by-value argument block into scratch memory --
+    // 688 bytes per lane and +20 us per launch, seen in round 5 when the body outgrew the full-unroll budget on the WK = 8 instantiations.  That is
+    // why the run-time-transform instantiation is not part of this body any more: the rare transform / activation pairs without a specialised
+    // loop go through the careful pass below)
 #pragma unroll
     for (int si = 0; si < CONV_MAXSEG; ++si) {
         if (si < a.nseg) {
@@ -1003,18 +1118,18 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
             if (lo < hi) {
                 const WT* w1 = wtile + s.woff;
                 const WT* w2 = wtile2 + s.woff;
-#define MUGD_SEG_VARGS s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, ac, stl.gnst, stl.lnst, gn_inv_cg, rot, wr, stl.wsc + (MS ? wks * 2 * NR : 0)
+#define MUGD_SEG_VARGS s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, ac, stl.gnst, stl.lnst, gn_inv_cg, rot, wr, stl.wsc + (MS ? wks * 2 * NR : 0), g0 >= s.chunk0
 #define MUGD_COOP , WT, typename std::remove_cv<typename std::remove_reference<decltype(s)>::type>::type, (MS ? NR : 0)
                 if constexpr (KIND == 0) {
                     // specialise on (transform, activation): branch-free chunk loops
 #define MUGD_SEG_XF(T, NHALO)                                                                     \
     switch (s.xf * 4 + s.act) {                                                                   \
-        case 0: run_segment_vec<TN, T, A2, NHALO, 0, 0, MUGD_PIPE MUGD_COOP>(MUGD_SEG_VARGS); break;                      \
+        case 0: redo |= run_segment_vec<TN, T, A2, NHALO, 0, 0, MUGD_PIPE MUGD_COOP>(MUGD_SEG_VARGS); break;              \
         case 4: case 16: run_segment_vec<TN, T, A2, NHALO, 1, 0, MUGD_PIPE MUGD_COOP>(MUGD_SEG_VARGS); break;            \
         case 5: case 17: run_segment_vec<TN, T, A2, NHALO, 1, 1, MUGD_PIPE MUGD_COOP>(MUGD_SEG_VARGS); break;            \
         case 6: case 18: run_segment_vec<TN, T, A2, NHALO, 1, 2, MUGD_PIPE MUGD_COOP>(MUGD_SEG_VARGS); break;            \
         case 8: case 12: run_segment_vec<TN, T, A2, NHALO, 2, 0, MUGD_PIPE MUGD_COOP>(MUGD_SEG_VARGS); break;            \
-        default: run_segment_vec<TN, T, A2, NHALO, -1, -1, false MUGD_COOP>(MUGD_SEG_VARGS);                                  \
+        default: if constexpr (MS == 0) redo = true; else run_segment_vec<TN, T, A2, NHALO, -1, -1, false MUGD_COOP>(MUGD_SEG_VARGS);      \
     }
                     if (DUAL || s.taps == 1) { MUGD_SEG_XF(1, 0) }
                     else { MUGD_SEG_XF(3, 1) }
@@ -1034,6 +1149,45 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
                 }
 #undef MUGD_SEG_VARGS
 #undef MUGD_COOP
+            }
+        }
+    }
+    if constexpr (KIND == 0 && MS == 0) {
+        // H3 domain, rare (never on the shipped networks): some raw slice of this wave left the band at the fixed scale -- an operand above 2^7 or
+        // a whole slice below 2^-6 -- so what the accumulators hold may be inf or imprecise.  The wave starts its tile over and runs EVERY
+        // segment through the careful instantiation, whose scale follows the data chunk by chunk (no workgroup barrier lies between here and
+        // the K-split combine: the other waves simply wait there a little longer)
+        if (__builtin_expect(redo, 0)) {
+            H3_COUNT(3);
+            ac.zero();
+            // a ROLLED loop (one copy of the careful loops per tap count instead of four) that reads the segments through a pointer into
+            // MEMORY: a by-value kernel argument already sits in the kernarg segment, the executor's argument block in its op table -- a
+            // dynamic index into either is a scalar load, where a dynamic index into the by-value parameter itself would make the compiler
+            // copy the whole block into scratch at kernel entry (688 bytes per lane, +20 us per launch: seen in round 5)
+#ifdef MUGD_EMULATED
+            const A* am = &a;
+#else
+            const MUGD_CONST_AS ConvArgs* am;
+            if constexpr (std::is_same<typename std::remove_cv<A>::type, ConvArgs>::value)
+                am = (const MUGD_CONST_AS ConvArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+            else
+                am = &a;
+#endif
+#pragma nounroll
+            for (int si = 0; si < a.nseg; ++si) {
+                const auto& s = am->seg[si];
+                typedef typename std::remove_cv<typename std::remove_reference<decltype(s)>::type>::type SegT;
+                const int nch = s.C / CONV_CK;
+                const int lo = (g0 > s.chunk0 ? g0 : s.chunk0) - s.chunk0;
+                const int hi = (g1 < s.chunk0 + nch ? g1 : s.chunk0 + nch) - s.chunk0;
+                if (lo < hi) {
+                    const WT* w1 = wtile + s.woff;
+                    const WT* w2 = wtile2 + s.woff;
+                    if (DUAL || s.taps == 1)
+                        run_segment_vec<TN, 1, A2, 0, -1, -1, false, WT, SegT, 0>(s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, ac, stl.gnst, stl.lnst, gn_inv_cg, rot, 0, nullptr, g0 >= s.chunk0);
+                    else
+                        run_segment_vec<TN, 3, A2, 1, -1, -1, false, WT, SegT, 0>(s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, ac, stl.gnst, stl.lnst, gn_inv_cg, rot, 0, nullptr, g0 >= s.chunk0);
+                }
             }
         }
     }

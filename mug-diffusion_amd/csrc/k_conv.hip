@@ -38,6 +38,7 @@
 #include <algorithm>
 #include <cstdlib>
 
+#define MUGD_H3_COUNT_TU 1
 #include "conv_body.h"
 
 #ifndef MUGD_KARG_WARM
@@ -350,11 +351,31 @@ void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
 #undef MUGD_WK
 }
 
+#if defined(MUGD_H3_COUNT) && !defined(MUGD_EMULATED)
+// development build: read (and zero) the domain event counters
+extern "C" int mugd_dev_h3_counters(unsigned long long* out8) {
+    if (hipDeviceSynchronize() != hipSuccess) return -3;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_h3_dev), 8 * sizeof(unsigned long long)) != hipSuccess) return -3;
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_h3_dev), z, sizeof(z)) != hipSuccess) return -3;
+    return 0;
+}
+#endif
+
+void launch_absmax(hipStream_t st, const float* x, long long n, unsigned* out) {
+    if (n <= 0) return;
+    PackArgs a{};                                     // a flat block of n "rows" of one element
+    a.src = x; a.rows = (int)n; a.C = 1; a.taps = 1; a.src_ld = 1; a.wmax = out;
+    int blocks = (int)((n + 1023) / 1024);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(weight_absmax_kernel, dim3(blocks), dim3(256), 0, st, a);
+}
+
 void launch_weight_absmax(hipStream_t st, const PackArgs& a) {
     if (!MUGD_CONV_H3 || a.w16 || !a.wmax) return;
     const long long total = (long long)a.rows * a.C * a.taps;
-    int blocks = (int)((total + 4095) / 4096);
-    if (blocks > 1024) blocks = 1024;
+    int blocks = (int)((total + 1023) / 1024);         // short dependent chains: these launches sit in per-call pre-ops (the folded cross-attention sets)
+    if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(weight_absmax_kernel, dim3(blocks), dim3(256), 0, st, a);
 }

@@ -2,6 +2,7 @@
 // (B, C, T) "channel-major" fp32: T is the fastest axis, so a wavefront's 64 lanes
 // read 256 contiguous bytes of one channel row.
 #pragma once
+#include <cmath>
 #include <vector>
 #include "common.h"
 
@@ -48,7 +49,19 @@ struct ConvSeg {
     int xf_np;            // xf=3: number of row tiles summed per column
     float xf_eps;         // xf=3: LayerNorm eps
     int xf_coff;          // xf=4: first channel of this segment inside the normalised concat
+    float sx0;            // H3 domain (conv_body.h): xf != 0 -- the STATIC power-of-two scale of this segment's transformed samples, from the host's bound
+                          // |v| <= max|gamma| sqrt(n) + max|beta| (h3_static_scale below); 0 is read as 1.  Raw segments (xf == 0) are scaled dynamically
 };
+// the static scale of a normalised operand: the largest power of two that keeps bound * scale <= 2^15
+inline float h3_static_scale(float gmax, float bmax, double n) {
+    const double bound = (double)gmax * std::sqrt(n > 1 ? n : 1) + (double)bmax;
+    if (!(bound > 0) || !std::isfinite(bound)) return 1.0f;
+    int e = 0;
+    std::frexp(32768.0 / bound, &e);             // 32768 / bound = f 2^e, f in [0.5, 1): 2^(e-1) <= 32768 / bound
+    e -= 1;
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    return std::ldexp(1.0f, e);
+}
 
 // EPI_XSOFTMAX: the tile's 32 rows are the key scores of ONE attention head for the tile's query columns (row j < xs_ntok = key
 // j, the rest padding): (dot + Rel[clamp(j - i)]) * scale -> softmax over the keys -> * Cemb[clamp(j - i)]  (attention.py:103-123).
@@ -93,6 +106,9 @@ struct ConvArgs {
                              // stored w * h3_wscale(*wmax) (an exact power of two), the epilogue multiplies it back out.  null: winv below
     float winv;              // ... or, when the host knows the word (sets packed at network-compile time), 1 / h3_wscale by value; 0: unit scale
     unsigned long long* tl;  // development build (-DMUGD_TL) only: per-wave phase records [blocks][waves][TL_WORDS]; null otherwise
+#ifdef MUGD_KARG_PAD
+    char karg_pad_[MUGD_KARG_PAD];      // development A/B arm: how much a launch costs per extra byte of its argument block
+#endif
 };
 
 // development build (-DMUGD_TL): where instrumented launches put their phase records (common.h)
@@ -167,6 +183,8 @@ void launch_pack_weights16(hipStream_t st, const PackArgs& a);      // fragment 
 void launch_weight_absmax(hipStream_t st, const PackArgs& a);
 // the usual sequence for a set made of ONE block: zero the word, reduce, pack (tn = 16 | 32 picks the fragment order)
 void pack_weights_scaled(hipStream_t st, const PackArgs& a, int tn);
+// *out = max(*out, bits of max |x[i]|) over n floats (the GroupNorm / LayerNorm affine bounds of h3_static_scale)
+void launch_absmax(hipStream_t st, const float* x, long long n, unsigned* out);
 
 // ---------------------------------------------------------------------------------------
 // H3 domain (conv_body.h): the split-f16 arithmetic is exact to fp32 level only while its operands sit inside the f16 exponent range, so

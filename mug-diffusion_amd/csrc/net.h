@@ -73,7 +73,8 @@ private:
 };
 
 // operand transform of one conv input (ConvSeg::xf): the GroupNorm / LayerNorm in front of the conv
-struct Xf { int kind = 0; int act = 0; const float* a = nullptr; const float* b = nullptr; int stride = 0; int np = 0; float eps = 0.f; int coff = 0; };
+struct Xf { int kind = 0; int act = 0; const float* a = nullptr; const float* b = nullptr; int stride = 0; int np = 0; float eps = 0.f; int coff = 0;
+            float sx0 = 0.f; };      // ConvSeg::sx0: the static H3 scale of the normalised operand (Net::norm_scale)
 struct GnDomain { int nseg = 0, groups = 0, cg = 0; float count = 0.f, eps = 0.f; };     // ConvArgs::gn_*
 struct ConvIn { Tensor x; int taps = 1, dil = 1, stride = 1, pad = 0, ups = 0; Xf xf; };
 struct WBlock { std::string name; int seg; int row_off; int ci_off; };
@@ -164,6 +165,7 @@ protected:
     bool xmode = false;                           // the program being built / held is laid out for the executor (monotonic arena, 32-wide tiles)
     std::vector<XOp> xops;
     XOp* xops_dev = nullptr;
+    size_t xops_cap = 0;                          // entries the device table holds
     XSync* xsync = nullptr;
     unsigned xbarriers = 0;                       // XCD barriers executed so far on xsync
     struct XRun { int op_lo, op_hi; int x_lo, x_hi; };     // ops [op_lo, op_hi): x_lo < x_hi -> executor launch over xops [x_lo, x_hi), else plain launches
@@ -189,6 +191,9 @@ protected:
     // the same, as the leading inputs of `spec`; uses the producers' row sums (no statistics launch) when every segment has them
     void gn_inputs(ConvSpec& spec, const std::string& prefix, const std::vector<Tensor>& segs, int groups, bool silu, int taps, int dil, int pad);
     float* norm_table(const std::string& prefix, int C);      // interleaved {weight, bias} of a norm layer, baked once
+    float norm_scale(const std::string& prefix, double n);    // ConvSeg::sx0 of that layer's output: from max |weight|, max |bias| (read back once) and the
+                                                              // elements n a statistic runs over (GroupNorm: channels per group x T; LayerNorm: C)
+    std::map<std::string, std::pair<float, float>> norm_absmax;
     // fp64 row-sum accumulators: one contiguous block per program, zeroed by the first op of every step
     double* alloc_rowstat(size_t ndoubles);
     double* rs_base = nullptr; size_t rs_top = 0, rs_cap = 0;

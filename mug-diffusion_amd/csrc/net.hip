@@ -205,13 +205,14 @@ void Net::invalidate() {
     owned.clear();
     packed.clear();
     baked.clear();
+    norm_absmax.clear();
     derived.clear();
     rs_base = nullptr; rs_cap = 0; rs_top = 0;
     ops.clear();
     pre_ops.clear();
     emb_ops.clear();
     xops.clear(); xruns.clear();
-    xops_dev = nullptr; xsync = nullptr; xbarriers = 0;       // freed with `owned`
+    xops_dev = nullptr; xops_cap = 0; xsync = nullptr; xbarriers = 0;       // freed with `owned`
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -236,7 +237,10 @@ void Net::finish_xprogram() {
     xruns.clear();
     if (!xmode || xops.empty()) return;
     if (!xsync) xsync = reinterpret_cast<XSync*>(dev_alloc(sizeof(XSync) / 4 + 64, true));
-    xops_dev = reinterpret_cast<XOp*>(dev_alloc(xops.size() * sizeof(XOp) / 4 + 64));
+    if (xops.size() > xops_cap) {                                  // one table, grown when a re-keyed program needs more entries (a program's (batch,
+        xops_cap = xops.size() + xops.size() / 4;                  // length) key may alternate: the previous table is reused, not leaked)
+        xops_dev = reinterpret_cast<XOp*>(dev_alloc(xops_cap * sizeof(XOp) / 4 + 64));
+    }
     HIP_CHECK(hipMemcpyAsync(xops_dev, xops.data(), xops.size() * sizeof(XOp), hipMemcpyHostToDevice, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));                  // `xops` may be rebuilt before the copy would otherwise have run
     size_t i = 0;
@@ -349,8 +353,13 @@ Tensor Net::layer_norm(const std::string& prefix, const Tensor& x) {
 std::vector<ConvIn> Net::gn_inputs(const std::string& prefix, const std::vector<Tensor>& segs, int groups, bool silu, int taps, int dil, int pad) {
     if (ctx->fuse_norm) {
         std::vector<ConvIn> r = normed(segs, gn_stats(prefix, segs, groups), silu, taps, dil, pad);
-        if (ctx->fast_act)
-            for (auto& in : r) if (in.xf.act == 1) in.xf.act = 2;
+        int Ctot = 0;
+        for (auto& t : segs) Ctot += t.C;
+        const float sx0 = norm_scale(prefix, (double)std::max(1, Ctot / groups) * segs[0].T);
+        for (auto& in : r) {
+            in.xf.sx0 = sx0;
+            if (ctx->fast_act && in.xf.act == 1) in.xf.act = 2;
+        }
         return r;
     }
     return {ConvIn{group_norm(prefix, segs, groups, silu), taps, dil, 1, pad, 0}};
@@ -370,6 +379,7 @@ void Net::gn_inputs(ConvSpec& spec, const std::string& prefix, const std::vector
     for (auto& t : segs) {
         ConvIn in{t, taps, dil, 1, pad, 0};
         in.xf.kind = 4; in.xf.act = silu ? (ctx->fast_act ? 2 : 1) : 0;
+        in.xf.sx0 = norm_scale(prefix, (double)(Ctot / groups) * segs[0].T);
         in.xf.a = reinterpret_cast<const float*>(t.rowstat); in.xf.b = tab;
         in.xf.stride = 2 * t.C;                 // doubles per batch row
         in.xf.coff = off;
@@ -442,6 +452,26 @@ float* Net::norm_table(const std::string& prefix, int C) {
     return baked[key] = gb;
 }
 
+// |GroupNorm(x)| <= max|gamma| sqrt(n - 1) + max|beta| over the n elements of a group (LayerNorm: the C channels of a sample), SiLU only shrinks it:
+// the static H3 scale of the operand (kernels.h: h3_static_scale).  The two maxima are read back once per layer and parameter set.
+float Net::norm_scale(const std::string& prefix, double n) {
+    auto it = norm_absmax.find(prefix);
+    if (it == norm_absmax.end()) {
+        const Param& g = P(prefix + ".weight");
+        const Param& b = P(prefix + ".bias");
+        unsigned* w = reinterpret_cast<unsigned*>(dev_alloc(2, true));
+        launch_absmax(ctx->stream, (const float*)g.ptr, (long long)g.numel(), w);
+        launch_absmax(ctx->stream, (const float*)b.ptr, (long long)b.numel(), w + 1);
+        unsigned bits[2] = {0, 0};
+        HIP_CHECK(hipMemcpyAsync(bits, w, sizeof(bits), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        float gm, bm;
+        memcpy(&gm, &bits[0], 4); memcpy(&bm, &bits[1], 4);
+        it = norm_absmax.emplace(prefix, std::make_pair(gm, bm)).first;
+    }
+    return h3_static_scale(it->second.first, it->second.second, n);
+}
+
 double* Net::alloc_rowstat(size_t nd) {
     const size_t off = rs_top;
     rs_top += (nd + 31) / 32 * 32;
@@ -469,6 +499,7 @@ Xf Net::layer_norm_xf(const std::string& prefix, const Tensor& x) {
     if (x.colstat && x.T % 4 == 0 && ctx->fuse_stats) {             // statistics come from the producer conv's epilogue: no launch
         Xf xf;
         xf.kind = 3; xf.a = x.colstat; xf.b = gb; xf.stride = 2 * x.colstat_np * x.T; xf.np = x.colstat_np; xf.eps = 1e-5f;
+        xf.sx0 = norm_scale(prefix, (double)x.C);
         return xf;
     }
     float* stat = arena.alloc((size_t)Bn * x.T * 2);
@@ -476,6 +507,7 @@ Xf Net::layer_norm_xf(const std::string& prefix, const Tensor& x) {
     emit([a](hipStream_t st) { launch_ln_stats(st, a); }, OP_LAYER_NORM, 0, prefix + " C=" + std::to_string(x.C) + " T=" + std::to_string(x.T));
     Xf xf;
     xf.kind = 2; xf.a = stat; xf.b = gb; xf.stride = 2 * x.T;
+    xf.sx0 = norm_scale(prefix, (double)x.C);
     return xf;
 }
 
@@ -585,7 +617,7 @@ Tensor Net::conv(const ConvSpec& s) {
     for (int i = 0; i < a.nseg; ++i) {
         const ConvIn& in = s.in[i];
         a.seg[i] = ConvSeg{in.x.p, in.x.C, in.x.T, in.taps, in.dil, in.stride, in.pad, in.ups, 0, 0, in.x.bmod,
-                           in.xf.kind, in.xf.act, in.xf.a, in.xf.b, in.xf.stride, in.xf.np, in.xf.eps, in.xf.coff};
+                           in.xf.kind, in.xf.act, in.xf.a, in.xf.b, in.xf.stride, in.xf.np, in.xf.eps, in.xf.coff, in.xf.sx0};
     }
     a.gn_nseg = s.gn.nseg; a.gn_groups = s.gn.groups; a.gn_cg = s.gn.cg; a.gn_count = s.gn.count; a.gn_eps = s.gn.eps;
     a.B = Bn; a.Mrows = s.Mrows; a.Mout = s.Mout; a.Tout = s.Tout; a.epi = s.epi;

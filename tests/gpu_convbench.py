@@ -61,9 +61,18 @@ def sweep(lib):
         print("%-16s %7.3f %6d | (%2d,%d) %5.1f | %5.1f | %s" % (name, gf, tiles, best[0], best[1], res[best], auto, row), flush=True)
 
 
+def compare(lib):
+    """one line per hot shape: the launch the host rules pick (wk = 0, tn = 0), cold weights -- run under two libraries (MUGD_LIB_PATH) and diff"""
+    for name, B, C, T, M, taps, norm, gated in SWEEP:
+        copies = max(1, int(300e6 / (M * C * taps * 4)))
+        us = min(lib.dev_bench_conv(B, C, T, M, taps, norm, bool(gated), wk=0, tn=0, copies=copies, iters=200) for _ in range(3))
+        print("%-16s %6.2f us" % (name, us), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sweep", action="store_true")
+    ap.add_argument("--compare", action="store_true")
     ap.add_argument("--pmc", action="store_true")
     ap.add_argument("--shape", type=int, default=0)
     ap.add_argument("--tn", type=int, default=0)
@@ -71,6 +80,9 @@ def main():
     ap.add_argument("--hot", action="store_true", help="--pmc: one weight copy (L2-resident) instead of a fresh copy per launch")
     ap.add_argument("--B", type=int, default=0, help="--pmc: override the batch")
     a = ap.parse_args()
+    if a.compare:
+        compare(get_lib())
+        return
     lib = get_lib()
     if a.sweep:
         return sweep(lib)

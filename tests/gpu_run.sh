@@ -10,7 +10,9 @@
 #   wide           per-launch tables with MUGD_CONV_WIDE = 0 | 1 | 2 at batch 8 and 16, A/B/A/B
 #   bench          the driver's command (bench.py --gpus 1 --steps 20 --warmup 3)
 #   stats          rocprofv3 --kernel-trace --stats of a short bench run
+#   kstats:LIB[@B] rocprofv3 --kernel-trace --stats of tests/gpu_probe.py --quick, in-tree library and tests/var/LIB on one box
 #   traffic        FETCH_SIZE / WRITE_SIZE of conv_gemm (separate --pmc passes) -> TAG_conv_traffic.json
+#   train_traffic  FETCH_SIZE / WRITE_SIZE of a bf16 batch-32 training step by kernel class (tests/pp_train_pmc.py)
 #   mfma           matrix-pipe busy / VALU counters of one U-Net evaluation
 #   instr          executed instructions per wave by class (the r4_pmc_instr_per_wave table)
 #   layers:B       per-launch table of one U-Net / VAE / wave evaluation at batch B (MUGD_PROFILE_CSV)
@@ -75,11 +77,26 @@ PY
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python $OLDPWD/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-training-step --no-throughput-mode --no-reduced-mode) > ${O}_bench_under_rocprof.log 2>&1
       f=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1); cp "$f" ${O}_bench_kernel_stats.csv; head -8 ${O}_bench_kernel_stats.csv | cut -c1-180
       grep '^{' ${O}_bench_under_rocprof.log > ${O}_bench_under_rocprof.json ;;
+    kstats)
+      # kstats:LIB[@B]: rocprofv3 per-kernel statistics of tests/gpu_probe.py --quick for the in-tree library and tests/var/LIB, same box
+      lb=${arg%%@*}; B=4; [ "$lb" != "$arg" ] && B=${arg#*@}
+      for v in new $lb; do
+        rm -rf /tmp/ks_${TAG}_$v
+        if [ $v = new ]; then (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_${TAG}_$v -- python $OLDPWD/tests/gpu_probe.py --B $B --quick) > ${O}_kstats_$v.log 2>&1
+        else (cd /tmp && MUGD_LIB_PATH=$OLDPWD/tests/var/$v/libmugd.so timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_${TAG}_$v -- python $OLDPWD/tests/gpu_probe.py --B $B --quick) > ${O}_kstats_$v.log 2>&1; fi
+        f=$(find /tmp/ks_${TAG}_$v -name "*kernel_stats.csv" | head -1); cp "$f" ${O}_kstats_${v}_b$B.csv
+        grep "ms/step" ${O}_kstats_$v.log
+      done ;;
     traffic)
       rm -rf /tmp/pmc_$TAG
       (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_$TAG/fetch -- python $OLDPWD/tests/gpu_unet_once.py --n 2) > ${O}_pmc_fetch.log 2>&1
       (cd /tmp && timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_$TAG/write -- python $OLDPWD/tests/gpu_unet_once.py --n 2) > ${O}_pmc_write.log 2>&1
       python tests/pmc_summary.py /tmp/pmc_$TAG ${O}_conv_traffic.json | tail -8 ;;
+    train_traffic)
+      rm -rf /tmp/pmct_$TAG
+      (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmct_$TAG/fetch -- python $OLDPWD/tests/gpu_train_probe.py --B 32 --reps 2 --bf16 --adamw) > ${O}_pmc_train_fetch.log 2>&1
+      (cd /tmp && timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmct_$TAG/write -- python $OLDPWD/tests/gpu_train_probe.py --B 32 --reps 2 --bf16 --adamw) > ${O}_pmc_train_write.log 2>&1
+      python tests/pp_train_pmc.py /tmp/pmct_$TAG 2 > ${O}_train_hbm_traffic.txt 2>&1; cat ${O}_train_hbm_traffic.txt; grep step ${O}_pmc_train_fetch.log | tail -1 ;;
     mfma)
       rm -rf /tmp/pmcm_$TAG
       (cd /tmp && timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVES --output-format csv -d /tmp/pmcm_$TAG -- python $OLDPWD/tests/gpu_unet_once.py --n 2) > ${O}_pmc_mfma.log 2>&1

@@ -241,7 +241,8 @@ def test_conv1d_gated(lib, epi):
 # The DOMAIN of conv_gemm's split-f16 arithmetic (csrc/conv_body.h: "The DOMAIN of H3").  The reference is fp32 with a +-3e38 range
 # (/root/reference/mug/diffusion/unet.py:27-33: convert_module_to_f16 is a no-op); f16 halves alone overflow above 65504 and lose their
 # low half below ~2^-12 (round 4: all-NaN tiles at |x| ~ 1e5, relative error 1e-3 at 1e-8).  Both operands are therefore carried as
-# block floating point (weights: one power of two per packed set; activations: a per-wave power of two that follows the data), and
+# block floating point (weights: one power of two per packed set; normalised activations: one per tensor from the affine bound; raw
+# activations: 2^8 while a wave's K-slice stays inside the band, else a per-wave power of two that follows the data chunk by chunk), and
 # these tests hold the kernels to the SAME fp32 tolerance at every operand scale, against float64.
 # ---------------------------------------------------------------------------------------------------------------------
 SCALES = [1e-8, 1e-6, 1.0, 1e5, 1e7]
@@ -316,6 +317,51 @@ def test_conv1d_channel_blocks_of_different_scale(lib, wk):
         lib.set_conv_tiling(0, 0)
     assert torch.isfinite(got).all()
     for rows, mag in ((slice(0, 8), 1e-3), (slice(8, 16), 1.0), (slice(16, 64), 1e8)):
+        err = (got[:, rows] - ref[:, rows]).abs().max().item()
+        assert err <= 2e-5 * mag, "rows %s: max err %.3e at magnitude %g" % (rows, err, mag)
+
+
+def test_conv1d_small_chunk_inside_an_in_band_slice(lib):
+    """The stated limit of the fast mode for raw operands (include/mugd.h): while a wave's K-slice stays inside the band at the fixed scale 2^8
+    (largest sample in [2^-6, 2^7)) no chunk is looked at on its own, so a chunk 2^30 below the slice's largest sample is carried with an
+    ABSOLUTE error of 2^-36 / 2^8 per sample instead of a relative one: rows that read only those channels come out within ~1e-12 absolute (not
+    2e-5 of their 1e-9 magnitude), every other row at the fp32 tolerance.  (A slice that LEAVES the band is redone chunk by chunk: the tests above.)"""
+    B, C, T, M = 1, 64, 64, 64
+    x = rnd(61, B, C, T)
+    x[:, 16:32] *= 2.0 ** -30
+    w = rnd(62, M, C, 1, scale=1.0 / math.sqrt(C))
+    w[:16, :16] = 0.0
+    w[:16, 32:] = 0.0                        # rows 0..15 read the tiny channels only
+    ref = conv_ref64(x, w)
+    lib.set_conv_tiling(1, 32)
+    try:
+        got = lib.op_conv1d(x, w).detach().cpu().double()
+    finally:
+        lib.set_conv_tiling(0, 0)
+    assert (got[:, :16] - ref[:, :16]).abs().max().item() <= 1e-12
+    assert (got[:, 16:] - ref[:, 16:]).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("taps", [1, 3])
+@pytest.mark.parametrize("wk", [1, 2, 4])
+def test_conv1d_scale_jump_in_the_middle_of_a_long_reduction(lib, wk, taps):
+    """A slice that leaves the band at the fixed scale makes the wave redo its tile in the careful mode, whose scale follows the data chunk by chunk
+    (conv_body.h: conv_tile, "redo"): a 16-chunk reduction (rotated K order: >= 8 chunks per wave at wk = 1, 2) whose chunks 5
+    and 11 are 2^40 larger / smaller than the others, several batch rows and column tiles so that the rotation starts them at different chunks."""
+    B, C, T, M = 3, 256, 96, 64
+    x = rnd(51, B, C, T)
+    x[:, 80:96] *= 2.0 ** 40
+    x[:, 176:192] *= 2.0 ** -40
+    w = rnd(52, M, C, taps, scale=1.0 / math.sqrt(C * taps))
+    w[:32, 80:96] = 0.0                      # rows 0..31 never read the huge chunk: they must come out at THEIR magnitude
+    ref = conv_ref64(x, w, None, 1, (taps - 1) // 2)
+    lib.set_conv_tiling(wk, 32)
+    try:
+        got = lib.op_conv1d(x, w, pad=(taps - 1) // 2).detach().cpu().double()
+    finally:
+        lib.set_conv_tiling(0, 0)
+    assert torch.isfinite(got).all()
+    for rows, mag in ((slice(0, 32), 1.0), (slice(32, 64), 2.0 ** 40)):
         err = (got[:, rows] - ref[:, rows]).abs().max().item()
         assert err <= 2e-5 * mag, "rows %s: max err %.3e at magnitude %g" % (rows, err, mag)
 
