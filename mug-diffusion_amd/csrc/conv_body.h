@@ -207,16 +207,22 @@ constexpr bool conv_h3() { return MUGD_CONV_H3 != 0 && sizeof(WT) == 4; }
 // (the tile NaN), operands below ~2^-12 lose their low half to the f16 subnormals.  The reference is fp32 with +-3e38 (unet.py:27-33), so
 // both operands are carried as BLOCK floating point -- times an exact power of two, divided out of the fp32 accumulators at the end:
 //   weights     : S_w = h3_wscale(max |w| of the packed set), applied by the pack kernels (kernels.h), max |w| S_w in [2^13, 2^14);
-//   activations : a per-wave scale sx (ConvAcc::sx).  When a wave parks a chunk (16 channels x the window) it takes the max |v| of the
-//                 samples it holds (4 v_max3 per lane) and asks the wave two questions -- some lane with |v| sx >= 2^15?  no lane with
-//                 |v| sx >= 4? (two v_cmp, one scalar branch) -- and only then leaves the fast path: wave max, a new power of two that puts
-//                 it in [2^10, 2^11), and the accumulators follow by the exact ratio (fp32 x 2^k).  So every chunk is parked with its
-//                 largest sample in [4, 2^15): samples down to 2^-14 (typically 2^-22) of their chunk's maximum keep all 22 bits, smaller
-//                 ones carry an absolute error of 2^-36 / sx -- below 2^-50 of the chunk's maximum.  Chunks and segments of one launch
-//                 differ in scale freely; the K-slices of a tile each carry their own sx and are unscaled before they meet in LDS.
-//                 sx never rises more than 2^64 above the smallest scale the accumulators have seen (they cannot overflow: 2^42 2^64).
-//                 M-split forms: a parked window is shared, so its scale travels with it (one LDS word per window slot); a consumer
-//                 whose accumulators sit at another scale adopts the window's before the MFMAs.
+//   activations : three modes, chosen per segment at compile time (run_segment_vec: STATIC / TRACK / CAREFUL):
+//                 STATIC   normalised operands (the transform is a GroupNorm / LayerNorm known at compile time): the host's power of two from
+//                          the bound |v| <= max|gamma| sqrt(n) + max|beta| (ConvSeg::sx0, kernels.h: h3_static_scale).  No per-chunk work.
+//                 TRACK    raw operands in the K-split forms: the fixed scale H3_SX0 = 2^8 (O(1) data mid-band) and four running maxima of
+//                          |v| per lane -- one v_max3 each per chunk, no compare, no branch.  ONE check per wave and slice: a slice whose
+//                          largest sample left [2^-6, 2^7) makes the wave redo its tile in the careful mode (conv_tile: "redo").
+//                 CAREFUL  that redo pass, the run-time-transform instantiations (dilated / strided kernels) and the M-split forms: a per-wave
+//                          scale sx (ConvAcc::sx) that follows the data.  A chunk is parked at sx while the lane's max |v| is collected; two
+//                          v_cmp ask the wave whether its maximum left the band [4, 2^15); only then the slow path runs: wave max (DPP + v_readlane),
+//                          a new power of two that puts it in [2^10, 2^11), the accumulators follow by the exact ratio (fp32 x 2^k), the window
+//                          is parked again.  sx never rises more than 2^64 above the smallest scale the accumulators have seen (they cannot
+//                          overflow: 2^42 2^64).  M-split forms: a parked window is shared, so its scale travels with it (one LDS word per
+//                          window slot); a consumer whose accumulators sit at another scale adopts the window's before the MFMAs.
+//                 The K-slices of a tile each carry their own scale and are unscaled before they meet in LDS.  Precision: a sample keeps all
+//                 22 bits down to 2^-14 of the largest sample of its slice (TRACK) / of its chunk (CAREFUL), 2^-27 of the bound (STATIC);
+//                 smaller ones carry an absolute error of 2^-36 / scale.
 // Inf / NaN among the operands propagate as they do in fp32 (no scale is derived from them).
 // ---------------------------------------------------------------------------------------
 constexpr float H3_LIM = 32768.0f, H3_LOW = 4.0f;
@@ -489,10 +495,6 @@ __device__ __forceinline__ bool run_segment_vec(const SEG& s, const WT* wseg, co
     float mr[4] = {0.f, 0.f, 0.f, 0.f};
     auto slice_verdict = [&]() MUGD_LI -> bool {                   // TRACK: did the slice leave the band?  (an all-zero slice did not)
         if (H3M != H3_TRACK) return false;
-#if defined(MUGD_H3_TRACKMODE) && MUGD_H3_TRACKMODE == 1       // development A/B arm: the running maxima without the verdict
-        asm volatile("" :: "v"(mr[0]), "v"(mr[1]), "v"(mr[2]), "v"(mr[3]));
-        return false;
-#endif
         const float mrun = fmaxf(fmaxf(mr[0], mr[1]), fmaxf(mr[2], mr[3]));
         const float ms = mrun * H3_SX0;
         return wave_any(ms >= H3_LIM) || (!wave_any(ms >= H3_LOW) && wave_any(mrun > 0.f));
@@ -640,14 +642,12 @@ __device__ __forceinline__ bool run_segment_vec(const SEG& s, const WT* wseg, co
             for (int j = 0; j < NH; ++j) *reinterpret_cast<float*>(smem_bytes + wofs + lh[j]) = okh[j] ? wh[j] : 0.f;
         };
         if (H3M == H3_STATIC || H3M == H3_TRACK) {
-#if !defined(MUGD_H3_TRACKMODE) || MUGD_H3_TRACKMODE != 2      // (development A/B arm 2: the verdict without the running maxima)
             if (H3M == H3_TRACK) {
 #pragma unroll
                 for (int i = 0; i < SPL; i += 2) mr[(i >> 1) & 3] = fmaxf(mr[(i >> 1) & 3], fmaxf(fabsf(v[i]), fabsf(v[i + 1])));
 #pragma unroll
                 for (int j = 0; j < NH; ++j) mr[j & 3] = fmaxf(mr[j & 3], fabsf(vh[j]));
             }
-#endif
             put(sx_fixed);
             H3_COUNT(0);
             if (COOP > 0 && lane == 0) wsc[slot] = sx_fixed;   // M-split: the window's scale travels with it
