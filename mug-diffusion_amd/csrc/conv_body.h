@@ -53,7 +53,7 @@ struct ConvGeo {
 
 // H3 domain (below): the activation scale every wave starts from -- O(1) data (max |v| in [2^-6, 2^7)) sits inside the band at once
 constexpr float H3_SX0 = 256.0f;
-// the accumulators of one wave: values, second row set (gate rows | TALL's second row tile), and the 2^11-scaled cross terms of H3
+// the accumulators of one wave: values, second row set (the gate rows of the gated epilogues), and the 2^11-scaled cross terms of H3
 template <int TN>
 struct ConvAcc;
 template <>
@@ -982,11 +982,9 @@ constexpr int conv_lds_bytes() { return ConvLds<WK, DUAL, TN>::BYTES; }
 // KIND 1: fast window path, any dilation (wave encoder / VAE ResnetBlocks).
 // KIND 2: every segment through the generic window walk (stride 2, nearest-x2 upsample, T % 4 != 0); NITG = its
 //         staging passes.  Separate kernels keep each instantiation's register budget to what it needs.
-// TALL: the (virtual) workgroup owns TWO row tiles, mt and mt + 1 (64 x 32 outputs): the second accumulator of the gated kernels holds the
-//       second row tile instead of the gate rows, so every staged window element and every B fragment read from LDS feeds two MFMAs
-//       (weights: each wave streams both row tiles' fragments).  For launches with enough tiles to fill the chip at half the count
-//       (launch_conv_gemm); mt must be even, a missing last row tile (odd tile count) is computed on clamped weights and not stored.
-// TN: 32 | 16 output samples per tile (ConvGeo); the 16-wide tiles exist for KIND 0 without TALL.
+// TN: 32 | 16 output samples per tile (ConvGeo); the 16-wide tiles exist for KIND 0.
+// (A two-row-tile form, 64 x 32 outputs per workgroup, existed in rounds 4 - 5 as an opt-in arm: measured slower at every batch size under both
+//  arithmetics -- profiles/r4_tall_ab.txt -- and removed.)
 // MS ("M-split", launch_conv_gemm: wide) = 1: the WK waves own WK consecutive ROW tiles mt .. mt + WK - 1 of the same 32 columns instead of WK
 //       slices of K: every wave walks the whole K axis with its own weight stream, the windows are staged once per workgroup
 //       (run_segment_vec<COOP>), there is no K-split combine and every wave finishes its whole 32 x 32 tile itself.  For launches with enough
@@ -994,15 +992,14 @@ constexpr int conv_lds_bytes() { return ConvLds<WK, DUAL, TN>::BYTES; }
 // MS = 2: M-split x K-split -- WK = NR row tiles x 2 K-slices; the NR waves of a K-slice share that slice's windows, the two partial tiles of a
 //       row tile are combined through LDS like the K-split form's.  Keeps two waves per SIMD on launches with few row tiles.  Measured in round 5
 //       (profiles/r5_wide2_ab.txt): wins 7 - 25 % on all-3-tap launches with >= 192 workgroups in this form -- launch_conv_gemm's rule -- loses elsewhere.
-template <int WK, bool DUAL, int KIND, int NITG, class WT, bool TALL = false, class A = ConvArgs, int TN = CONV_TN, int MS = 0>
+template <int WK, bool DUAL, int KIND, int NITG, class WT, class A = ConvArgs, int TN = CONV_TN, int MS = 0>
 __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b, const int t0, const int rot, const int tid, char* lds, const bool live) {
-    static_assert(!(DUAL && TALL), "gated layers already share their windows between two row sets");
-    static_assert(TN == 32 || (KIND == 0 && !TALL), "16-wide tiles: plain fast-window kernels only");
-    static_assert(!MS || (KIND == 0 && TN == 32 && !TALL && WK >= 2), "M-split: plain fast-window kernels, 32-wide tiles");
+    static_assert(TN == 32 || KIND == 0, "16-wide tiles: plain fast-window kernels only");
+    static_assert(!MS || (KIND == 0 && TN == 32 && WK >= 2), "M-split: plain fast-window kernels, 32-wide tiles");
     constexpr int KS = MS > 0 ? MS : 1;             // M-split: K-slices inside the workgroup
     constexpr int NR = MS > 0 ? WK / KS : 1;        // M-split: row tiles per workgroup
     static_assert(!MS || (NR * KS == WK && NR % 2 == 0), "M-split: WK = row tiles x K-slices, an even number of row tiles");
-    constexpr bool A2 = DUAL || TALL;               // two weight streams / two accumulators per wave
+    constexpr bool A2 = DUAL;                       // two weight streams / two accumulators per wave (the gate rows)
     typedef ConvGeo<TN> G;
     typedef ConvLds<WK, A2, TN> L;
     constexpr int RED = L::RED;
@@ -1014,7 +1011,7 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
     typedef WgStats<WK, TN> Stats;
     typename Stats::Lds& stl = *reinterpret_cast<typename Stats::Lds*>(lds + L::STAT_OFF);
 
-    const int gy = (a.Mout + 31) >> 5;             // 32-row tiles of the output (the launch grid counts PAIRS of them under TALL)
+    const int gy = (a.Mout + 31) >> 5;             // 32-row tiles of the output
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, h = lane >> 5, n = lane & 31;      // (h, n): the 32-wide fragment coordinates (generic windows)
     const int cl = G::col(lane);                                  // this lane's tile column
@@ -1039,8 +1036,7 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
     ac.zero();
 
     const WT* wtile = reinterpret_cast<const WT*>(a.wpk) + (size_t)b * a.w_b_stride + (size_t)mtc * a.w_mt_stride + lane * 4;
-    const bool has2 = !TALL || mt + 1 < gy;        // TALL: the second row tile exists
-    const WT* wtile2 = DUAL ? wtile + (size_t)(a.Mout >> 5) * a.w_mt_stride : (TALL && has2) ? wtile + a.w_mt_stride : wtile;
+    const WT* wtile2 = DUAL ? wtile + (size_t)(a.Mout >> 5) * a.w_mt_stride : wtile;
     char* smem_bytes = lds;
     const int wave_base = MS ? wks * (2 * NR * G::WIN_LDS * 4) : wave * G::WAVE_LDS * 4;      // M-split: the K-slice's set of 2 x NR shared windows
 
@@ -1054,12 +1050,6 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
     size_t oo[EPT];
     int mm[EPT];
     bool valid[EPT];
-    // TALL: the same for the rows of the second row tile (m + 32)
-    constexpr int EPT2 = TALL ? EPT : 1;
-    float ra2[EPT2], rsv2[EPT2];
-    size_t oo2[EPT2];
-    int mm2[EPT2];
-    bool valid2[EPT2];
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
         const int r = rbase + q;
@@ -1069,27 +1059,20 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
         mm[q] = m < a.Mout ? m : a.Mout - 1;
         oo[q] = ((size_t)b * a.Mout + mm[q]) * a.Tout + (t < a.Tout ? t : a.Tout - 1);
         bv[q] = 0.f; bg[q] = 0.f; ra[q] = 0.f; rsv[q] = 0.f;
-        if (TALL) {
-            const int m2 = m + 32;
-            valid2[q] = live && has2 && (m2 < a.Mout) && (t < a.Tout);
-            mm2[q] = m2 < a.Mout ? m2 : a.Mout - 1;
-            oo2[q] = ((size_t)b * a.Mout + mm2[q]) * a.Tout + (t < a.Tout ? t : a.Tout - 1);
-            ra2[q] = 0.f; rsv2[q] = 0.f;
-        }
     }
-    constexpr bool PRELOAD = TALL ? EPT <= 2 : EPT <= 4;   // wide per-wave epilogues (WK 1, 2; TALL: WK 4 too) load late instead: registers
+    constexpr bool PRELOAD = EPT <= 4;   // wide per-wave epilogues (WK 1, 2) load late instead: registers
     auto load_side = [&]() MUGD_LI {
         if (a.bias) {
     #pragma unroll
-            for (int q = 0; q < EPT; ++q) { bv[q] = a.bias[mm[q]]; if (DUAL) bg[q] = a.bias[mm[q] + a.Mout]; if (TALL) bg[q] = a.bias[mm2[q]]; }
+            for (int q = 0; q < EPT; ++q) { bv[q] = a.bias[mm[q]]; if (DUAL) bg[q] = a.bias[mm[q] + a.Mout]; }
         }
         if (a.rowadd) {
     #pragma unroll
-            for (int q = 0; q < EPT; ++q) { ra[q] = a.rowadd[(size_t)b * a.rowadd_stride + mm[q]]; if (TALL) ra2[q] = a.rowadd[(size_t)b * a.rowadd_stride + mm2[q]]; }
+            for (int q = 0; q < EPT; ++q) { ra[q] = a.rowadd[(size_t)b * a.rowadd_stride + mm[q]]; }
         }
         if (a.resid) {
     #pragma unroll
-            for (int q = 0; q < EPT; ++q) { rsv[q] = a.resid[oo[q]]; if (TALL) rsv2[q] = a.resid[oo2[q]]; }
+            for (int q = 0; q < EPT; ++q) { rsv[q] = a.resid[oo[q]]; }
         }
     };
     if (PRELOAD) load_side();
@@ -1266,11 +1249,6 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
         v = (v + ra[q]) + rsv[q];
         if (valid[q]) a.y[oo[q]] = v;
         acc_v[q] = v;
-        if (TALL) {
-            float v2 = ((acc_g[q] + bg[q]) + ra2[q]) + rsv2[q];
-            if (valid2[q]) a.y[oo2[q]] = v2;
-            acc_g[q] = v2;
-        }
     }
     TL_STAMP(5);
     // ---- optional: add this tile's {sum, sum of squares} per row to the fp64 row accumulators (GroupNorm of the consumers)
@@ -1287,17 +1265,6 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
                 double* o = a.rowstat + 2 * ((size_t)b * a.Mout + m);
                 atomicAdd(o, (double)s1);
                 atomicAdd(o + 1, (double)s2);
-            }
-            if (TALL) {
-                float u1 = valid2[q] ? acc_g[q] : 0.f;
-                float u2 = u1 * u1;
-#pragma unroll
-                for (int o = 1; o < 32; o <<= 1) { u1 += __shfl_xor(u1, o); u2 += __shfl_xor(u2, o); }
-                if (live && has2 && cl == 0 && m + 32 < a.Mout) {
-                    double* o = a.rowstat + 2 * ((size_t)b * a.Mout + m + 32);
-                    atomicAdd(o, (double)u1);
-                    atomicAdd(o + 1, (double)u2);
-                }
             }
         }
     }
@@ -1343,28 +1310,6 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
             for (int w = 0; w < WK; ++w) { t1 += cst[0][w][tid]; t2 += cst[1][w][tid]; }
             float* o = a.colstat + 2 * (((size_t)b * gy + mt) * a.Tout + t0 + tid);
             o[0] = t1; o[1] = t2;
-        }
-        if (TALL) {                                      // the second row tile's column sums, through the same scratch
-            __syncthreads();
-            float u1 = 0.f, u2 = 0.f;
-#pragma unroll
-            for (int q = 0; q < EPT; ++q) {
-                const int r = wave * EPT + q;
-                const int m = mt * 32 + 32 + G::row(r, lane);
-                const float v = m < a.Mout ? acc_g[q] : 0.f;
-                u1 += v; u2 += v * v;
-            }
-            u1 += __shfl_xor(u1, 32);
-            u2 += __shfl_xor(u2, 32);
-            if (lane < TN) { cst[0][wave][cl] = u1; cst[1][wave][cl] = u2; }
-            __syncthreads();
-            if (live && has2 && tid < TN && t0 + tid < a.Tout) {
-                float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-                for (int w = 0; w < WK; ++w) { t1 += cst[0][w][tid]; t2 += cst[1][w][tid]; }
-                float* o = a.colstat + 2 * (((size_t)b * gy + mt + 1) * a.Tout + t0 + tid);
-                o[0] = t1; o[1] = t2;
-            }
         }
     }
     TL_STAMP(6);

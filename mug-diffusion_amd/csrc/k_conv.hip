@@ -50,9 +50,9 @@ namespace {
 // One workgroup = one tile: decodes blockIdx into (row tile, batch row, column tile) and runs the shared tile body (conv_body.h).
 // TN = 16: the 32 x 16 tiles of conv_body.h (ConvGeo) -- the same body, half the columns per workgroup.
 // MS: the M-split ("wide") form -- the grid's row axis counts GROUPS of WK row tiles (conv_body.h).
-template <int WK, bool DUAL, int KIND, int NITG, class WT = float, bool TALL = false, int TN = CONV_TN, int MS = 0>
+template <int WK, bool DUAL, int KIND, int NITG, class WT = float, int TN = CONV_TN, int MS = 0>
 __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel(const ConvArgs a) {
-    __shared__ __attribute__((aligned(16))) char lds[conv_lds_bytes<WK, DUAL || TALL, TN>()];
+    __shared__ __attribute__((aligned(16))) char lds[conv_lds_bytes<WK, DUAL, TN>()];
     TL_BEGIN();
 #if MUGD_KARG_WARM
     KARG_WARM(sizeof(ConvArgs));
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel
     else { mt = fastdiv(lid, a.mgxz, gx * gz); rem = lid - mt * (gx * gz); }
     const int b = fastdiv(rem, a.mgx, gx);
     const int t0 = (rem - b * gx) * TN;
-    conv_tile<WK, DUAL, KIND, NITG, WT, TALL, ConvArgs, TN, MS>(a, TALL ? 2 * mt : MS ? (WK / MS) * mt : mt, b, t0, rem, (int)threadIdx.x, lds, true);      // TALL / MS: the grid's row axis counts PAIRS / GROUPS of row tiles
+    conv_tile<WK, DUAL, KIND, NITG, WT, ConvArgs, TN, MS>(a, MS ? (WK / MS) * mt : mt, b, t0, rem, (int)threadIdx.x, lds, true);      // MS: the grid's row axis counts GROUPS of row tiles
     TL_END(a.tl, WK);
 }
 
@@ -151,20 +151,15 @@ void launch_wide(hipStream_t st, const ConvArgs& a0, int gx, int gy, int gz) {
     conv_set_grid(a, gx, gyg, gz);
     const dim3 grid((unsigned)gx * gyg * gz);
     a.tl = tl_claim((int)grid.x, NW, 32);
-    hipLaunchKernelGGL((conv_gemm_kernel<NW, DUAL, 0, 1, float, false, 32, KS>), grid, dim3(NW * 64), 0, st, a);
+    hipLaunchKernelGGL((conv_gemm_kernel<NW, DUAL, 0, 1, float, 32, KS>), grid, dim3(NW * 64), 0, st, a);
 }
 
 template <int WK, bool DUAL>
-void launch_wk(hipStream_t st, const ConvArgs& a0, dim3 grid, int gx, int gy, int gz, int kind, int nitg, bool tall) {
+void launch_wk(hipStream_t st, const ConvArgs& a0, dim3 grid, int gx, int gy, int gz, int kind, int nitg) {
     ConvArgs a = a0;
     conv_split_k(a, WK);
     conv_set_grid(a, gx, gy, gz);
     a.tl = tl_claim((int)grid.x, WK, 32);
-    if (tall) {                               // 64 x 32 tiles (conv_body.h: TALL): plain epilogue, fast windows (KIND 0 / 1), fp32 weights
-        if (kind == 0) hipLaunchKernelGGL((conv_gemm_kernel<WK, false, 0, 1, float, true>), grid, dim3(WK * 64), 0, st, a);
-        else hipLaunchKernelGGL((conv_gemm_kernel<WK, false, 1, 1, float, true>), grid, dim3(WK * 64), 0, st, a);
-        return;
-    }
 #define MUGD_CONV_LAUNCH(K, N) hipLaunchKernelGGL((conv_gemm_kernel<WK, DUAL, K, N>), grid, dim3(WK * 64), 0, st, a)
     if (a.w16) {
         MUGD_CHECK(kind == 0, -2, "conv_gemm: bfloat16 weights exist for the plain fast-window kernels only");
@@ -217,10 +212,10 @@ void launch16_wk(hipStream_t st, const ConvArgs& a0, dim3 grid, int gx, int gy, 
     conv_set_grid(a, gx, gy, gz);
     a.tl = tl_claim((int)grid.x, WK, 16);
     if (a.w16) {
-        if (dual) hipLaunchKernelGGL((conv_gemm_kernel<WK, true, 0, 1, unsigned short, false, 16>), grid, dim3(WK * 64), 0, st, a);
-        else hipLaunchKernelGGL((conv_gemm_kernel<WK, false, 0, 1, unsigned short, false, 16>), grid, dim3(WK * 64), 0, st, a);
-    } else if (dual) hipLaunchKernelGGL((conv_gemm_kernel<WK, true, 0, 1, float, false, 16>), grid, dim3(WK * 64), 0, st, a);
-    else hipLaunchKernelGGL((conv_gemm_kernel<WK, false, 0, 1, float, false, 16>), grid, dim3(WK * 64), 0, st, a);
+        if (dual) hipLaunchKernelGGL((conv_gemm_kernel<WK, true, 0, 1, unsigned short, 16>), grid, dim3(WK * 64), 0, st, a);
+        else hipLaunchKernelGGL((conv_gemm_kernel<WK, false, 0, 1, unsigned short, 16>), grid, dim3(WK * 64), 0, st, a);
+    } else if (dual) hipLaunchKernelGGL((conv_gemm_kernel<WK, true, 0, 1, float, 16>), grid, dim3(WK * 64), 0, st, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<WK, false, 0, 1, float, 16>), grid, dim3(WK * 64), 0, st, a);
 }
 
 }  // namespace
@@ -293,18 +288,12 @@ void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
     }
     else MUGD_CHECK(a.Mrows == a.Mout, -2, "conv_gemm: Mrows != Mout");
     int gx = cdiv(a.Tout, CONV_TN), gy = cdiv(a.Mout, 32), gz = a.B;
-    // 64 x 32 tiles (conv_body.h: TALL): opt-in only (MUGD_CONV_TALL=1, wherever the form exists).  Measured slower than 32 x 32 tiles at every
-    // batch size under both arithmetics (profiles/r4_tall_ab.txt: the second accumulator pair and weight stream push the kernel to 256 VGPRs
-    // + scratch; with the H3 arithmetic batch 16 runs 4.87 ms / step without it and 5.46 with it)
-    bool tall = false;
-    if (const char* e = getenv("MUGD_CONV_TALL")) tall = e[0] == '1' && !dual && a.epi == EPI_NONE && kind != 2 && !a.w16 && gy >= 2;
-    if (tall) gy = (gy + 1) / 2;
     // M-split ("wide") form (conv_body.h: MS; plain fast windows, fp32 weights, >= 2 row tiles, not the score epilogue).  Chosen where the
     // per-launch table says it wins (profiles/r4_wide_ab.txt): tall M (>= 2 groups of 8 row tiles: 8-wave workgroups), short K (<= 32 chunks: the
     // q/k/v and GEGLU projections) and enough workgroups that way (>= 160: batch 8 upwards); and the K = 48 input conv, whose K-split form is one
     // wave per tile.  The long-K launches lose a wave per SIMD in this form and stay K-split.  MUGD_CONV_WIDE=1 forces it wherever it exists, =0 never.
     {
-        const bool can = !tall && kind == 0 && !a.w16 && a.epi != EPI_XSOFTMAX && gy >= 2 && a.wk <= 0 && !getenv("MUGD_CONV_WK");      // a forced K-split wins
+        const bool can = kind == 0 && !a.w16 && a.epi != EPI_XSOFTMAX && gy >= 2 && a.wk <= 0 && !getenv("MUGD_CONV_WK");      // a forced K-split wins
         const int nw = gy >= 8 ? 8 : gy >= 4 ? 4 : 2;
         const long long wgs = (long long)cdiv(gy, nw) * gx * gz;
         bool wide = can && ((gy >= 16 && a.nchunk <= 32 && wgs >= 160) || (gy >= 4 && a.nchunk <= 4 && wgs >= 128));
@@ -341,8 +330,8 @@ void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
     }
 #define MUGD_WK(W)                                                             \
     case W:                                                                    \
-        if (dual) launch_wk<W, true>(st, a, grid, gx, gy, gz, kind, nitg, false);     \
-        else launch_wk<W, false>(st, a, grid, gx, gy, gz, kind, nitg, tall);         \
+        if (dual) launch_wk<W, true>(st, a, grid, gx, gy, gz, kind, nitg);     \
+        else launch_wk<W, false>(st, a, grid, gx, gy, gz, kind, nitg);         \
         break;
     switch (wk) {
         MUGD_WK(1) MUGD_WK(2) MUGD_WK(4) MUGD_WK(8)

@@ -132,35 +132,6 @@ def test_conv1d_tile_widths(lib, tn, B, C, T, M, taps, dil, stride, pad, ups):
         lib.set_conv_tiling(0, 0)
 
 
-TALL_CASES = [
-    # B, C, T, M, taps, dil: 64 x 32 tiles (conv_body.h: TALL) -- even / ODD row-tile counts, M off the 32-row grid, ragged last column tile
-    (2, 64, 64, 64, 3, 1), (1, 48, 40, 96, 3, 1), (2, 32, 36, 80, 1, 1), (1, 64, 72, 160, 3, 2), (1, 32, 64, 96, 3, 8), (3, 128, 32, 128, 1, 1),
-]
-
-
-@pytest.mark.parametrize("B,C,T,M,taps,dil", TALL_CASES)
-def test_conv1d_tall_tiles(lib, monkeypatch, B, C, T, M, taps, dil):
-    """MUGD_CONV_TALL=1 forces the two-row-tile (64 x 32) form of conv_gemm wherever it exists: plain conv + bias + residual for every
-    K-split, and GroupNorm(+SiLU) / LayerNorm operand transforms in front of it -- same results as the reference convolution."""
-    monkeypatch.setenv("MUGD_CONV_TALL", "1")
-    pad = dil * (taps - 1) // 2
-    x, w, b = rnd(7, B, C, T), rnd(8, M, C, taps, scale=1.0 / math.sqrt(C * taps)), 0.1 * rnd(9, M)
-    ref = F.conv1d(x, w, b, 1, pad, dil)
-    resid = rnd(10, *ref.shape)
-    try:
-        for wk in (0, 1, 2, 4, 8):
-            if wk > max(1, C // 16):
-                continue
-            lib.set_conv_tiling(wk, 32)
-            close(lib.op_conv1d(x, w, b, resid, dil=dil, stride=1, pad=pad, Tout=T), ref + resid, 2e-5, what="tall conv1d wk=%d" % wk)
-    finally:
-        lib.set_conv_tiling(0, 0)
-    if T % 4 == 0:
-        test_norm_conv1d_fused(lib, B, C, T, M, taps, dil, 1, 16, 1, 0)
-        if taps == 1:
-            test_norm_conv1d_fused(lib, B, C, T, M, 1, 1, 2, 0, 0, 0)
-
-
 WIDE_CASES = [
     # B, C, T, M, taps: the M-split ("wide") form of conv_gemm (conv_body.h: MS) -- 2 / 4 / 8 row tiles per workgroup, ragged last row group,
     # M off the 32-row grid, ragged last column tile, K not a multiple of the group (partial last phase), K shorter than one phase
