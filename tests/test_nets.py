@@ -102,6 +102,26 @@ def test_unet_forward_vs_reference_golden(lib, case, z, B):
     assert d < 2e-4 * max(1.0, s)
 
 
+@pytest.mark.parametrize("sx,sa", [(1e6, 1e5), (1e-6, 1e-5), (1e4, 1e-6)])
+@pytest.mark.parametrize("case,z", CASES[:2])
+def test_unet_forward_at_input_scales_outside_the_f16_range(lib, case, z, sx, sa):
+    """The domain of conv_gemm's split-f16 arithmetic end to end (csrc/conv_body.h: "The DOMAIN of H3"): a latent and audio feature maps far above
+    65504 / far below 2^-14 enter the U-Net through RAW operands (the input conv, every skip conv over [h | audio], the first GroupNorm only
+    normalises what follows) -- the fp32 oracle (= the reference's arithmetic, /root/reference/mug/diffusion/unet.py:27-33) has no trouble with
+    them, round 4's kernels returned NaN.  Same network-level tolerance as the golden test, no non-finite value."""
+    lib = lib_for(lib, case)
+    B, seed = 2, 77
+    x, t = cases.x_T(seed, B, z) * sx, torch.full((B,), 481, dtype=torch.long)
+    c, w = cases.context(case, seed, B), [m * sa for m in cases.audio_maps(case, seed, B, z)]
+    sd = state_dict(case, z)
+    ref = nets.unet_forward(sd, case["unet"], x, t, c, w)
+    assert torch.isfinite(ref).all()
+    got = native(lib, case, z, "unet").forward(x, t, c, w)
+    assert torch.isfinite(got.detach().cpu()).all()
+    d, s = report("unet %s z=%d latent x %g, audio x %g" % (case["name"], z, sx, sa), got, ref)
+    assert d < 2e-4 * max(1.0, s)
+
+
 @pytest.mark.parametrize("case,z", CASES)
 def test_vae_decode_vs_reference_golden(lib, case, z):
     lib = lib_for(lib, case)
