@@ -11,6 +11,8 @@
 #   bench          the driver's command (bench.py --gpus 1 --steps 20 --warmup 3)
 #   stats          rocprofv3 --kernel-trace --stats of a short bench run
 #   kstats:LIB[@B] rocprofv3 --kernel-trace --stats of tests/gpu_probe.py --quick, in-tree library and tests/var/LIB on one box
+#   shapepmc:LIB@I,J   executed instructions per wave of single launch shapes, in-tree library vs tests/var/LIB
+#   convbench:L1,L2    us per launch of every hot conv shape (tests/gpu_convbench.py --compare), in-tree library and tests/var/L*
 #   traffic        FETCH_SIZE / WRITE_SIZE of conv_gemm (separate --pmc passes) -> TAG_conv_traffic.json
 #   train_traffic  FETCH_SIZE / WRITE_SIZE of a bf16 batch-32 training step by kernel class (tests/pp_train_pmc.py)
 #   mfma           matrix-pipe busy / VALU counters of one U-Net evaluation
@@ -87,6 +89,24 @@ PY
         f=$(find /tmp/ks_${TAG}_$v -name "*kernel_stats.csv" | head -1); cp "$f" ${O}_kstats_${v}_b$B.csv
         grep "ms/step" ${O}_kstats_$v.log
       done ;;
+    shapepmc)
+      # shapepmc:LIB@I,J,...: executed instructions per wave of single conv_gemm launch shapes (tests/gpu_convbench.py --pmc --shape I), in-tree library vs tests/var/LIB
+      lb=${arg%%@*}; shapes=${arg#*@}; : > ${O}_shape_pmc.txt
+      for shape in $(echo $shapes | tr ',' ' '); do for v in new $lb; do
+        for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM" "SQ_WAVES SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM" "SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY"; do
+          d=/tmp/spmc_${TAG}_${shape}_${v}_$(echo $set | tr ' ' '_'); rm -rf $d
+          if [ $v = new ]; then (cd /tmp && timeout 120 rocprofv3 --pmc $set --output-format csv -d $d -- python $OLDPWD/tests/gpu_convbench.py --pmc --shape $shape) > /dev/null 2>&1
+          else (cd /tmp && MUGD_LIB_PATH=$OLDPWD/tests/var/$v/libmugd.so timeout 120 rocprofv3 --pmc $set --output-format csv -d $d -- python $OLDPWD/tests/gpu_convbench.py --pmc --shape $shape) > /dev/null 2>&1; fi
+          echo "== shape $shape lib $v" >> ${O}_shape_pmc.txt
+          python tests/pmc_generic_summary.py $d 2>/dev/null | grep -E "^kernel|conv_gemm" >> ${O}_shape_pmc.txt
+        done
+      done; done
+      cat ${O}_shape_pmc.txt ;;
+    convbench)
+      # convbench:LIB1,LIB2: tests/gpu_convbench.py --compare (us per launch of every hot shape) for the in-tree library and each tests/var/LIB
+      python tests/gpu_convbench.py --compare > ${O}_cb_new.txt 2>&1
+      for v in $(echo $arg | tr ',' ' '); do MUGD_LIB_PATH=$PWD/tests/var/$v/libmugd.so python tests/gpu_convbench.py --compare > ${O}_cb_$v.txt 2>&1; done
+      paste ${O}_cb_*.txt | head -40 ;;
     traffic)
       rm -rf /tmp/pmc_$TAG
       (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_$TAG/fetch -- python $OLDPWD/tests/gpu_unet_once.py --n 2) > ${O}_pmc_fetch.log 2>&1
