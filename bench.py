@@ -82,6 +82,31 @@ def host_threads():
         return os.cpu_count() or 1
 
 
+def pin_near_gpu(dev):
+    """Best effort: restrict this rank's threads (the enqueue thread above all) to the CPUs of the NUMA node its GPU hangs off, so that eight
+    ranks sharing a host do not migrate across sockets between launches.  Returns a description for the JSON line (None: nothing to do)."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(dev)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None
+        with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+            cpus = set()
+            for part in f.read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= set(os.sched_getaffinity(0))
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return {"pci": bdf, "numa_node": node, "cpus": len(cpus)}
+    except Exception:                                  # noqa: BLE001 -- no sysfs / no such property: leave the affinity alone
+        return None
+
+
 def synth_audio(seconds, sr, seed):
     """0.5 sin(2pi 440 t) + 0.25 chirp(110 -> 3110 Hz) + N(0, 0.01)."""
     n = np.arange(int(round(seconds * sr)), dtype=np.float64)
@@ -137,6 +162,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: libmugd has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    affinity = pin_near_gpu(dev)
     import torch.distributed as dist
     grouped = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)      # under torch.distributed.run also at N = 1: the same
     if grouped:                                                                          # RCCL code path (init, barrier, gather) then runs on one GPU
@@ -298,6 +324,14 @@ def main():
                 traffic = tj.get("hbm_bytes_per_launch")
                 traffic_source = "profiles/conv_traffic.json (%s): separate rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled " \
                                  "per MI355X_MICROARCH.md; not measured by this run" % tj.get("round", "round 1 tree")
+            # host side of a step: wall clock around back-to-back enqueues of the same program (no events, no synchronisation inside)
+            host_us, host_ops = unet.native().host_enqueue(5)
+            out["host_enqueue"] = {"us_per_unet_eval": host_us, "launches_per_unet_eval": host_ops, "us_per_launch": host_us / max(host_ops, 1),
+                                   "gpu_us_per_unet_eval": graph_ms * 1e3, "host_over_gpu": host_us / max(graph_ms * 1e3, 1e-9),
+                                   "thread_affinity": affinity,
+                                   "what": "mugd_net_host_enqueue: one thread enqueueing the U-Net program of the timed run 5 times back to back from an idle "
+                                           "stream; conv launches are prepared once per compiled program (validation, kernel form, K-slices), a step only "
+                                           "calls hipLaunchKernel"}
             peak = PEAK_H3_TFLOPS if h3 else PEAK_FP32_MFMA_TFLOPS
             out["roofline"] = {"kernel": "conv_gemm_kernel<..., TN = 32 | 16> (implicit-GEMM conv1d / linear, 32x32 and 32x16 tiles of one template, %s; "
                                          "all %d launches of one U-Net evaluation, HIP events around every launch on the library stream, "

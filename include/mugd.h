@@ -62,20 +62,11 @@ int mugd_order_before(mugd_ctx* ctx, void* other_stream);
  * 1: replay each DDIM step from a captured hipGraph;
  * 2: capture the whole S-step loop into ONE graph (one hipGraphLaunch per sampling call; re-captured when S changes). */
 int mugd_set_graph_mode(mugd_ctx* ctx, int enabled);
-/* How a U-Net program (mugd_unet_forward / mugd_ddim_sample) is put on the GPU, for programs COMPILED after the call (a new batch /
- * length, or mugd_net_invalidate):
- *   0: one kernel launch per op (229 dependent launches per evaluation of the shipped model);
- *   1: the XCD-RESIDENT EXECUTOR -- when the network batch is a multiple of 8, the whole per-step op chain (every conv / Linear GEMM, the
- *      self-attention tiles, the S4 convolutions) runs inside ONE persistent kernel: batch row b is computed by the 32 CUs of XCD b % 8,
- *      its activations never leave that XCD's L2, and ops are separated by XCD-local barriers (~1 us) instead of kernel boundaries.
- *      Same device code per tile as mode 0, same results up to the summation order of the GroupNorm row sums.  Other batch sizes and
- *      devices without 8 x 32 CUs fall back to mode 0.  In this mode mugd_ddim_sample / mugd_unet_forward synchronise the host at the end
- *      of the call (they verify that no persistent launch gave up waiting for its peers).  Graph modes are ignored (launches are eager).
- * The default is read from MUGD_XEXEC at mugd_create. */
-int mugd_set_exec_mode(mugd_ctx* ctx, int mode);
 /* Tuning / test knob: force the conv_gemm decomposition for networks COMPILED and operators run after the call
- * (wk: waves splitting K per workgroup, 1|2|4|8; tn: output tile width 16|32; 0 = pick per layer).  Call
- * mugd_net_invalidate on existing networks to recompile them. */
+ * (wk: waves splitting K per workgroup, 1|2|4|8; tn: output tile width 16|32; 0 = pick per layer).  Development sweeps may also
+ * pass wk = 0x100 | waves << 4 | kslices: the M-split form with that workgroup geometry (waves / kslices row tiles sharing every staged
+ * window) on the launches where it exists, the library's own choice elsewhere.  Call mugd_net_invalidate on existing networks to
+ * recompile them. */
 int mugd_set_conv_tiling(mugd_ctx* ctx, int wk, int tn);
 /* S4 kernel generation (mug/model/s4.py:706-832): which Cauchy backend of the reference to reproduce.  0 (default): cauchy_naive
  * (s4.py:140-147, the sum over the stored half of the poles -- what the reference runs when neither pykeops nor its CUDA
@@ -177,6 +168,11 @@ int mugd_ddim_sample(mugd_net* unet, float* x, const float* c, const float* uc, 
 #define MUGD_PROFILE_KINDS 7
 int mugd_net_profile(mugd_net* net, double* ms, double* flops, int64_t* launches);
 const char* mugd_profile_kind_name(int k);
+/* Measurement hook: the HOST time of a step -- wall clock around `passes` (1..64) back-to-back enqueues of the program last compiled for
+ * this network (no event pairs, no synchronisation between them; the stream is idle when the clock starts and is synchronised after it
+ * stops): *us_per_pass microseconds per pass on the calling thread, *launches_per_pass ops per pass.  One enqueue thread per GPU must stay
+ * below the GPU time of a pass, or the step becomes host-bound (bench.py reports both). */
+int mugd_net_host_enqueue(mugd_net* net, int passes, double* us_per_pass, int64_t* launches_per_pass);
 
 /* AutoencoderKL.decode (mug/firststage/autoencoder.py:75-77): z (B,z_ch,z) -> logits (B,x_ch,z*2^(n_levels-1)). */
 int mugd_vae_decode(mugd_net* vae, const float* z_lat, float* logits, int B, int z);
@@ -197,6 +193,12 @@ int mugd_cond_embed(mugd_ctx* ctx, const float* table, const int64_t* ids, float
  * librosa.feature.melspectrogram, n_fft 512 / hop 128 / 128 mels by default): mono fp32 PCM at
  * `sr` (device) -> log1p(mel power) rounded to fp16 and widened to fp32, (n_mels, 1 + n/hop). */
 int mugd_log_mel(mugd_ctx* ctx, const float* pcm, int64_t n, int sr, int n_fft, int hop, int n_mels, float* out);
+/* How mugd_log_mel pads its centred STFT frames -- like mugd_set_s4_symmetric a "which environment produced the checkpoint" switch: the
+ * reference calls librosa.feature.melspectrogram with librosa UNPINNED (requirements.txt:8; mug/util.py:138-143) and librosa changed
+ * the default of stft(pad_mode=) between 0.9 ('reflect') and 0.10 ('constant', zeros).  0 (default; MUGD_MEL_PAD unset): zeros,
+ * librosa >= 0.10;  1 (MUGD_MEL_PAD=reflect): numpy 'reflect' padding, librosa <= 0.9 (needs n > n_fft / 2 samples, like librosa).
+ * Only the first and last n_fft / (2 hop) frames of a song differ.  Applies to calls made afterwards. */
+int mugd_set_mel_pad_mode(mugd_ctx* ctx, int reflect);
 
 /* Sample-rate conversion in front of mugd_log_mel (the reference resamples on the host inside
  * librosa.load(sr=22050), mug/util.py:126): polyphase FIR with the specification of scipy.signal.resample_poly(x, up, down)

@@ -43,6 +43,76 @@ def _run(cmd):
     return r.stdout
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# Register-pressure guard (round 6): a hot kernel that starts spilling gets slower without failing anything, so the build reads every
+# kernel's resource record out of the code objects (llvm-readelf --notes: .private_segment_fixed_size = scratch bytes per lane) and FAILS
+# when a kernel has scratch that this table does not allow.  An entry is (regex over the demangled name, max bytes, why it is tolerated).
+# ---------------------------------------------------------------------------------------------------------------------------
+SCRATCH_ALLOWED = [
+    # conv_gemm_kernel<WK, DUAL, KIND, NIT, WT, TN, MS>
+    (r"conv_gemm_kernel<\d, (true|false), 0, 1, (float|unsigned short), 16, 0>.*", 0, None),
+    (r"conv_gemm_kernel<1, (true|false), 0, 1, (float|unsigned short), 16, 0>", 192,
+     "one-wave 16-wide tiles: only launches with a single K chunk AND <= 128 tiles pick them (never on the shipped networks' hot paths)"),
+    (r"conv_gemm_kernel<\d, true, 2, 9, float, 32, 0>", 400,
+     "gated epilogue over generic windows: a GLU / GEGLU projection at a length that is not a multiple of 4 (cold path, kept for completeness)"),
+    (r"conv_gemm_kernel<8, true, 0, 1, float, 32, 4>", 128,
+     "experimental M-split geometry (2 row tiles x 4 K-slices, gated): development sweeps only (mugd_set_conv_tiling wk = 0x184), no host rule selects it"),
+    (r"conv_gemm_kernel<2, true, 0, 1, float, 32, 0>", 16,
+     "the GEGLU projections at batch 4: at most one 64-bit address parked outside the chunk loops"),
+    (r"conv_gemm_kernel<[48], true, 0, 1, float, 32, 0>", 128,
+     "the S4 GLU projections (8 / 4 waves per tile): 10 - 25 dwords spilled around the prologue / epilogue, none inside the chunk loop "
+     "(checked in the ISA: profiles/r6_gated_scratch.txt); two accumulator pairs + two weight streams sit at the 256-VGPR budget"),
+    (r"conv_gemm_kernel<4, false, 1, 1, float, 32, 0>", 64,
+     "dilated ResnetBlock convs of the wave encoder / VAE at 4 waves per tile: run-time transform + 4 halo loads per lane"),
+    (r"wgrad_mfma_kernel", 256, "weight gradient of the fp32 (parity) training mode; the bf16 mode of record runs twgrad_bf16_kernel"),
+]
+
+
+def kernel_resources(obj):
+    """[(demangled kernel name, vgprs, sgprs, scratch bytes, LDS bytes)] of the gfx950 code object inside a hipcc object file."""
+    import re
+    import tempfile
+    bindir = "/opt/rocm/lib/llvm/bin"
+    with tempfile.TemporaryDirectory() as d:
+        shutil.copy(obj, os.path.join(d, "o.o"))
+        subprocess.run([os.path.join(bindir, "llvm-objdump"), "--offloading", "o.o"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        cos = [f for f in os.listdir(d) if "gfx950" in f]
+        if not cos:
+            return []
+        notes = subprocess.run([os.path.join(bindir, "llvm-readelf"), "--notes", os.path.join(d, cos[0])], stdout=subprocess.PIPE, text=True).stdout
+    rows = []
+    for k in re.split(r"\n\s+- \.agpr_count", notes)[1:]:
+        def g(f):
+            m = re.search(r"\.%s:\s+(\d+)" % f, k)
+            return int(m.group(1)) if m else 0
+        rows.append([re.search(r"\.name:\s+(\S+)", k).group(1), g("vgpr_count"), g("sgpr_count"), g("private_segment_fixed_size"), g("group_segment_fixed_size")])
+    names = subprocess.run(["c++filt"], input="\n".join(r[0] for r in rows), stdout=subprocess.PIPE, text=True).stdout.split("\n")
+    for r, n in zip(rows, names):
+        r[0] = n.replace("(anonymous namespace)::", "").replace("void ", "")
+    return [tuple(r) for r in rows]
+
+
+def check_scratch(objs, verbose=True):
+    """Raises if a kernel of the library uses more scratch than SCRATCH_ALLOWED grants (everything unlisted: none)."""
+    import re
+    bad, seen = [], 0
+    for obj in sorted(objs):
+        for name, vgpr, sgpr, scratch, lds in kernel_resources(obj):
+            seen += 1
+            if scratch == 0:
+                continue
+            limit = 0
+            for pat, mx, _why in SCRATCH_ALLOWED:
+                if re.fullmatch(pat, name.split("(")[0].strip()):
+                    limit = max(limit, mx)
+            if scratch > limit:
+                bad.append("%s: %d bytes of scratch per lane (%d VGPRs; allowed: %d) in %s" % (name, scratch, vgpr, limit, os.path.basename(obj)))
+    if bad:
+        raise RuntimeError("register-pressure guard: kernels spill beyond what build.py: SCRATCH_ALLOWED tolerates\n  " + "\n  ".join(bad))
+    if verbose:
+        print("register-pressure guard: %d kernels checked, none spills beyond its allowance" % seen)
+
+
 def build_variant(name, defines, verbose=True):
     """DEVELOPMENT A/B builds: the same sources with extra -D flags into tests/var/<name>/libmugd.so (git-ignored; loaded through
     MUGD_LIB_PATH by the GPU probes, never by the product)."""
@@ -62,6 +132,38 @@ def build_variant(name, defines, verbose=True):
     _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib])
     if verbose:
         print("built", lib)
+    return lib
+
+
+def build_rev(rev, name, verbose=True):
+    """DEVELOPMENT A/B: the library as of git revision `rev` (its own csrc/ and include/, extracted with `git archive`) into
+    tests/var/<name>/libmugd.so -- the "before" arm of same-box comparisons (tests/gpu_run.sh ab:<name>; the binding loads it with
+    MUGD_LIB_LENIENT=1 because an older library lacks the newer entry points)."""
+    import tarfile
+    import io
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    outdir = os.path.join(ROOT, "tests", "var", name)
+    src = os.path.join(outdir, "src")
+    shutil.rmtree(src, ignore_errors=True)
+    os.makedirs(src)
+    blob = subprocess.run(["git", "-C", ROOT, "archive", rev, "mug-diffusion_amd/csrc", "include"], stdout=subprocess.PIPE, check=True).stdout
+    tarfile.open(fileobj=io.BytesIO(blob)).extractall(src)
+    objdir = os.path.join(outdir, "build")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+
+    def cc(s):
+        obj = os.path.join(objdir, os.path.basename(s) + ".o")
+        _run([hipcc] + flags + ["-c", s, "-o", obj])
+        return obj
+    with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(cc, sorted(glob.glob(os.path.join(src, "mug-diffusion_amd", "csrc", "*.hip")))))
+    lib = os.path.join(outdir, "libmugd.so")
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib])
+    shutil.rmtree(src, ignore_errors=True)
+    shutil.rmtree(objdir, ignore_errors=True)
+    if verbose:
+        print("built", lib, "from", rev)
     return lib
 
 
@@ -90,6 +192,8 @@ def build(force=False, verbose=True, timeline=False):
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(cc, _sources()))
+    if not timeline:
+        check_scratch(objs, verbose)                 # fails the build when a hot kernel starts spilling
     tmp = LIB + ".tmp.%d" % os.getpid()              # never expose a half-linked library to a concurrent loader
     _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp])
     os.replace(tmp, LIB)
@@ -107,7 +211,7 @@ def build_emulated(force=False, verbose=True):
         cxx = shutil.which("clang++") or shutil.which("g++")
     objdir = os.path.join(EMU_DIR, "build")
     os.makedirs(objdir, exist_ok=True)
-    flags = ["-std=c++17", "-O2", "-g", "-fPIC", "-I", os.path.join(EMU_DIR, "include"), "-Wno-unused-value"]
+    flags = ["-std=c++17", "-O2", "-fPIC", "-I", os.path.join(EMU_DIR, "include"), "-Wno-unused-value"]
 
     def cc(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
@@ -123,9 +227,16 @@ def build_emulated(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    if "--variant" in sys.argv:
+    if "--rev" in sys.argv:                           # python build.py --rev <git revision> <name>
+        i = sys.argv.index("--rev")
+        build_rev(sys.argv[i + 1], sys.argv[i + 2])
+    elif "--variant" in sys.argv:
         i = sys.argv.index("--variant")
         build_variant(sys.argv[i + 1], sys.argv[i + 2:])
+    elif "--resources" in sys.argv:                   # table of every kernel's registers / scratch / LDS (the guard's input)
+        for obj in sorted(glob.glob(os.path.join(HERE, "build", "*.hip.o"))):
+            for row in kernel_resources(obj):
+                print("%-22s vgpr %3d sgpr %3d scratch %4d lds %6d  %s" % (os.path.basename(obj), row[1], row[2], row[3], row[4], row[0][:140]))
     elif "--emu" in sys.argv:
         build_emulated(force="--force" in sys.argv)
     elif "--tl" in sys.argv:

@@ -110,7 +110,6 @@ int mugd_create(int device, void* stream, mugd_ctx** out) {
         // MUGD_GRAPH=1 | 2 selects the per-step / whole-loop graph
         const char* gm = getenv("MUGD_GRAPH");
         ctx->c.use_graph = (gm && (gm[0] == '1' || gm[0] == '2')) ? gm[0] - '0' : 0;
-        if (const char* xe = getenv("MUGD_XEXEC")) ctx->c.xexec = xe[0] == '1' ? 1 : 0;      // the XCD-resident executor (mugd_set_exec_mode)
         const char* u = getenv("MUGD_UNFUSED_NORM");
         ctx->c.fuse_norm = !(u && u[0] == '1');
         const char* ns = getenv("MUGD_NO_STATS_FUSION");
@@ -123,6 +122,8 @@ int mugd_create(int device, void* stream, mugd_ctx** out) {
         ctx->c.weights_bf16 = wb && wb[0] == '1';
         const char* sy = getenv("MUGD_S4_SYMMETRIC");
         ctx->c.s4_symmetric = sy && sy[0] == '1';
+        const char* mp = getenv("MUGD_MEL_PAD");
+        ctx->c.mel_reflect = mp && (mp[0] == 'r' || mp[0] == '1');
         const char* fa = getenv("MUGD_EXACT_SILU");            // default: SiLU of the fused GroupNorm path on v_exp_f32 / v_rcp_f32
         ctx->c.fast_act = !(fa && fa[0] == '1');
     });
@@ -176,15 +177,15 @@ int mugd_set_graph_mode(mugd_ctx* ctx, int enabled) {
     return MUGD_OK;
 }
 
-int mugd_set_exec_mode(mugd_ctx* ctx, int mode) {
-    if (!ctx) return MUGD_ERR_INVALID;
-    ctx->c.xexec = mode != 0 ? 1 : 0;
-    return MUGD_OK;
-}
-
 int mugd_set_weight_precision(mugd_ctx* ctx, int bf16) {
     if (!ctx) return MUGD_ERR_INVALID;
     ctx->c.weights_bf16 = bf16 != 0;
+    return MUGD_OK;
+}
+
+int mugd_set_mel_pad_mode(mugd_ctx* ctx, int reflect) {
+    if (!ctx) return MUGD_ERR_INVALID;
+    ctx->c.mel_reflect = reflect != 0;
     return MUGD_OK;
 }
 
@@ -197,7 +198,8 @@ int mugd_set_s4_symmetric(mugd_ctx* ctx, int enabled) {
 int mugd_set_conv_tiling(mugd_ctx* ctx, int wk, int tn) {
     if (!ctx) return MUGD_ERR_INVALID;
     return guarded(ctx, [&] {
-        MUGD_CHECK(wk == 0 || wk == 1 || wk == 2 || wk == 4 || wk == 8, MUGD_ERR_INVALID, "wk must be 0, 1, 2, 4 or 8");
+        MUGD_CHECK(wk == 0 || wk == 1 || wk == 2 || wk == 4 || wk == 8 || (wk & ~0xff) == 0x100, MUGD_ERR_INVALID,
+                   "wk must be 0, 1, 2, 4 or 8 (or 0x100 | waves << 4 | K-slices: a forced M-split form)");
         MUGD_CHECK(tn == 0 || tn == 16 || tn == 32, MUGD_ERR_INVALID, "tn must be 0, 16 or 32");
         ctx->c.force_wk = wk;
         ctx->c.force_tn = tn;
@@ -306,6 +308,14 @@ int mugd_net_profile(mugd_net* net, double* ms, double* flops, int64_t* launches
         ProfileRow rows[OP_KINDS];
         net->net->profile_program(rows);
         for (int k = 0; k < OP_KINDS; ++k) { ms[k] = rows[k].ms; flops[k] = rows[k].flops; launches[k] = rows[k].launches; }
+    });
+}
+
+int mugd_net_host_enqueue(mugd_net* net, int passes, double* us_per_pass, int64_t* launches_per_pass) {
+    if (!net) return MUGD_ERR_INVALID;
+    return guarded(net->ctx, [&] {
+        MUGD_CHECK(passes >= 1 && passes <= 64 && us_per_pass && launches_per_pass, MUGD_ERR_INVALID, "bad argument");
+        net->net->host_enqueue(passes, us_per_pass, launches_per_pass);
     });
 }
 
@@ -533,10 +543,11 @@ int mugd_dev_bench_conv(mugd_ctx* ctx, int B, int C, int T, int M, int taps, int
         hipEvent_t e0, e1;
         HIP_CHECK(hipEventCreate(&e0));
         HIP_CHECK(hipEventCreate(&e1));
+        ConvLaunch L = conv_prepare(a);                  // like a compiled program op: prepared once, launched per step
         for (int it = -3; it < iters; ++it) {
             if (it == 0) HIP_CHECK(hipEventRecord(e0, st));
-            a.wpk = wpk + (size_t)((it + 3) % copies) * MT * mts;
-            launch_conv(st, a);
+            L.a.wpk = wpk + (size_t)((it + 3) % copies) * MT * mts;
+            conv_launch(st, L);
         }
         HIP_CHECK(hipEventRecord(e1, st));
         HIP_CHECK(hipStreamSynchronize(st));

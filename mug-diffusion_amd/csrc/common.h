@@ -75,6 +75,8 @@ __device__ __forceinline__ int fastdiv(int n, unsigned m, int d) {
     q -= (q * (unsigned)d > (unsigned)n) ? 1u : 0u;
     return (int)q;
 }
+// b % d for the batch-row sharing of the audio maps (ConvSeg::bmod; d <= 0: every batch row has its own copy)
+__device__ __forceinline__ int batch_row_mod(int b, unsigned m, int d) { return d > 0 ? b - fastdiv(b, m, d) * d : b; }
 
 // Kernel arguments are fetched by scalar loads the compiler places lazily, one dependent round trip per first use: the conv_gemm
 // prologue paid ~25 of them in series (profiles/r2_timeline_*: 0.8-1.2 us "setup").  KARG_PIN forces the listed values into SGPRs

@@ -264,6 +264,11 @@ __device__ __forceinline__ unsigned wave_max_bits(float m) {
     const unsigned b0 = a0 > a1 ? a0 : a1, b1 = a2 > a3 ? a2 : a3;
     return b0 > b1 ? b0 : b1;
 }
+// |v| of a finite sample, 0 for inf / NaN: the scale of a chunk follows its FINITE content -- an inf among the samples propagates by itself
+// (inf x w), the finite samples next to it must still be rescaled into the f16 range (round 6; ADVICE r5: a 1e3 next to an inf overflowed)
+__device__ __forceinline__ float h3_finite_abs(float v) {
+    return (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u ? 0.f : fabsf(v);
+}
 // does a chunk whose lane maxima are m leave the band at scale sc?
 __device__ __forceinline__ bool h3_off_band(float m, float sc) {
     const float ms = m * sc;
@@ -274,13 +279,24 @@ __device__ __forceinline__ bool h3_off_band(float m, float sc) {
     return __builtin_amdgcn_ballot_w64(ms >= H3_LIM) != 0ull || __builtin_amdgcn_ballot_w64(ms >= H3_LOW) == 0ull;
 #endif
 }
-// the accumulators move from scale ac.sx to scale s
+// the accumulators move from scale ac.sx to scale s.  The ratio is applied exactly whatever its size: a step DOWN of more than 2^125 (a chunk
+// 2^125 above everything before it) flushes what the accumulators held -- in fp32 those terms are below the new chunk's rounding error by
+// a hundred orders of magnitude; a step UP is bounded by the callers (h3_rise_ok): never more than 2^64 above the smallest scale so far
 template <int TN>
 __device__ __forceinline__ void h3_adopt(ConvAcc<TN>& ac, float s, bool two) {
-    ac.scale_all(h3_pow2_biased(127 + h3_biased_exp(s) - h3_biased_exp(ac.sx)), two);
+    const int d = h3_biased_exp(s) - h3_biased_exp(ac.sx);
+    if (d < -125) { ac.scale_all(0x1p-125f, two); ac.scale_all(h3_pow2_biased(127 + (d + 125 < -125 ? -125 : d + 125)), two); }
+    else ac.scale_all(h3_pow2_biased(127 + (d > 125 ? 125 : d)), two);
     ac.sx = rfl_f(s);                                    // wave-uniform by construction: keep the scale state in scalar registers
     ac.sxmin = rfl_f(fminf(ac.sxmin, s));
 }
+// may the accumulators rise to scale s?  Not beyond 2^64 above the smallest scale they have been at: they hold up to 2^42 at that scale and
+// must stay finite.  Operands parked above that bound are more than 2^64 below the largest operand the accumulators have seen -- 2^40 below
+// the fp32 rounding error of the terms already summed -- and are dropped (M-split consumers: the window is skipped; static scales: the
+// segment is parked at the bound instead and underflows there).  Round 6: before, only the K-split park path applied the bound -- an
+// M-split consumer adopted whatever scale its (lagging) parking wave had picked, and a tiny-gamma static scale rose unchecked.
+template <int TN>
+__device__ __forceinline__ bool h3_rise_ok(const ConvAcc<TN>& ac, float s) { return h3_biased_exp(s) <= h3_biased_exp(ac.sxmin) + 64; }
 // slow path of a park: m = this lane's max |v| of the chunk, sc = the scale the chunk would be parked at.  Returns the scale to park at;
 // adopt: the parking wave is the consumer (K-split forms) -- its accumulators follow at once.  All in the exponent domain on
 // wave-uniform values (scalar ALU): the wave max 2^e <= mw < 2^(e+1) times sc = 2^k is inside [4, 2^15) iff 2 <= e + k <= 14
@@ -468,11 +484,16 @@ __device__ __forceinline__ void conv_mfma(const char* smem_bytes, int rb0, int d
 // of COOP shared windows, every wave consumes all COOP chunks of a phase with its own weight fragments, one workgroup barrier per phase:
 // the operand transform / split / park work per MFMA drops by COOP.  wave_base must be 0; coop_wave = the wave's index.
 // Returns true when the wave must REDO its tile in the careful mode (H3 domain, TRACK mode below); false otherwise.
-template <int TN, int TAPS, bool DUAL, int NH, int XFK = -1, int ACT = -1, bool PIPE = false, class WT = float, class SEG = ConvSeg, int COOP = 0>
+// pre_park(): called once per call, AFTER the segment's first global loads (window + weights of the first ring stages) have been issued and
+// BEFORE the first chunk is transformed and parked -- conv_tile hands in the workgroup's statistics reduction (conv_stats.h: finish(), a
+// no-op after the first call), so that the operand requests of a normalised launch are in flight while the wave waits for the producers'
+// sums, reduces them and meets the other waves at the barrier (round 6; before, the ring was requested only behind that barrier).
+struct NoPrePark { __device__ __forceinline__ void operator()() const {} };
+template <int TN, int TAPS, bool DUAL, int NH, int XFK = -1, int ACT = -1, bool PIPE = false, class WT = float, class SEG = ConvSeg, int COOP = 0, class PP = NoPrePark>
 __device__ __forceinline__ bool run_segment_vec(const SEG& s, const WT* wseg, const WT* wseg2, int lo, int hi,
                                                 int b, int t0, int lane, char* smem_bytes, int wave_base,
                                                 ConvAcc<TN>& ac, const float2* gst, const float2* lnst, float inv_cg, int rot_seed, int coop_wave = 0,
-                                                float* wsc = nullptr, bool fresh = false) {
+                                                float* wsc = nullptr, bool fresh = false, PP&& pre_park = PP(), int zwin = 0) {
     typedef ConvGeo<TN> G;
     // H3 domain, three ways to scale a segment's samples (conv_h3 above):
     //   STATIC  (XFK >= 1: the transform is known at compile time to be a normalisation) the host's scale from the affine bound (ConvSeg::sx0):
@@ -485,10 +506,13 @@ __device__ __forceinline__ bool run_segment_vec(const SEG& s, const WT* wseg, co
     //           park again.
     constexpr int H3_OFF = 0, H3_STATIC = 1, H3_TRACK = 2, H3_CAREFUL = 3;
     constexpr int H3M = !conv_h3<WT>() ? H3_OFF : XFK >= 1 ? H3_STATIC : !MUGD_H3_DYN ? H3_STATIC : (XFK == 0 && COOP == 0) ? H3_TRACK : H3_CAREFUL;
-    const float sx_fixed = H3M == H3_TRACK ? H3_SX0 : (H3M == H3_STATIC && XFK >= 1) ? rfl_f(s.sx0 != 0.f ? s.sx0 : 1.0f) : H3_SX0;
+    float sx_fixed = H3M == H3_TRACK ? H3_SX0 : (H3M == H3_STATIC && XFK >= 1) ? rfl_f(s.sx0 != 0.f ? s.sx0 : 1.0f) : H3_SX0;
     if ((H3M == H3_STATIC || H3M == H3_TRACK) && COOP == 0 && sx_fixed != ac.sx) {
         if (fresh) { ac.sx = rfl_f(sx_fixed); ac.sxmin = ac.sx; }      // the wave's first segment: the accumulators are still zero
-        else h3_adopt<TN>(ac, sx_fixed, DUAL);
+        else {
+            if (!h3_rise_ok<TN>(ac, sx_fixed)) sx_fixed = h3_pow2_biased(h3_biased_exp(ac.sxmin) + 64);      // (h3_rise_ok: park at the bound)
+            h3_adopt<TN>(ac, sx_fixed, DUAL);
+        }
     }
     // TRACK: the lane's largest |sample| of the slice so far, as FOUR independent running maxima (one v_max3 each per chunk: a single
     // running maximum is a chain of dependent VALU operations through every sample of every chunk -- measured +10 % on the long-K raw launches)
@@ -569,7 +593,7 @@ __device__ __forceinline__ bool run_segment_vec(const SEG& s, const WT* wseg, co
         for (int i = 0; i < SPL; ++i) { const float2 st = lnst[SPL * q + i]; mu[i] = st.x; rsd[i] = st.y; }
     };
 
-    const int bb = s.bmod > 0 ? b % s.bmod : b;
+    const int bb = batch_row_mod(b, s.mbmod, s.bmod);
     const char* xb = reinterpret_cast<const char*>(s.x + ((size_t)bb * s.C + (size_t)lo * CONV_CK) * Tin);
     const size_t xstep = (size_t)CONV_CK * Tin * 4;
     const WT* wp = wseg + (size_t)lo * (TAPS * 512);
@@ -668,9 +692,9 @@ __device__ __forceinline__ bool run_segment_vec(const SEG& s, const WT* wseg, co
             H3_COUNT(0);
             float m = 0.f;
 #pragma unroll
-            for (int i = 0; i < SPL; ++i) m = fmaxf(m, fabsf(v[i]));
+            for (int i = 0; i < SPL; ++i) m = fmaxf(m, h3_finite_abs(v[i]));
 #pragma unroll
-            for (int j = 0; j < NH; ++j) m = fmaxf(m, fabsf(vh[j]));
+            for (int j = 0; j < NH; ++j) m = fmaxf(m, h3_finite_abs(vh[j]));
 #ifndef MUGD_EMULATED
             asm volatile("" :: "v"(m));
 #endif
@@ -680,6 +704,10 @@ __device__ __forceinline__ bool run_segment_vec(const SEG& s, const WT* wseg, co
                 const float s2 = h3_pick<TN>(ac, m, sc, COOP == 0, DUAL);
                 if (s2 != sc) { sc = s2; put(sc); }
             }
+            // the accumulators are about to hold products at this scale: it bounds every later rise, ALSO when it is the scale they started
+            // at (round 6: a first chunk that needed no rescale left sxmin at its "nothing accumulated" value and a tiny second chunk could then
+            // lift non-zero accumulators by 2^117)
+            if (COOP == 0) ac.sxmin = rfl_f(fminf(ac.sxmin, ac.sx));
             if (COOP > 0 && lane == 0) wsc[slot] = sc;
         } else {
             put(1.0f);
@@ -711,6 +739,7 @@ __device__ __forceinline__ bool run_segment_vec(const SEG& s, const WT* wseg, co
         if (coop_wave < nch) fetch_x(coop_wave);
         fetch_a(0, 0);
         if (1 < nch) fetch_a(1, 1);
+        pre_park();
         finish_ln();
         if (coop_wave < nch) park_v(coop_wave * W1, RX, RXH, RGB, RGG, coop_wave, [&]() MUGD_LI { if (coop_wave + COOP < nch) fetch_x(coop_wave + COOP); });
         __syncthreads();
@@ -723,11 +752,19 @@ __device__ __forceinline__ bool run_segment_vec(const SEG& s, const WT* wseg, co
             for (int j = 0; j < COOP; ++j) {
                 const int k = ph * COOP + j;
                 if (k < nch) {
+                    int wofs = (buf * COOP + j) * W1;
                     if (conv_h3<WT>()) {                    // the window was parked at ITS wave's scale: the accumulators follow
                         const float ws = rfl_f(wsc[buf * COOP + j]);
-                        if (__builtin_expect(ws != ac.sx, 0)) h3_adopt<TN>(ac, ws, DUAL);
+                        if (__builtin_expect(ws != ac.sx, 0)) {
+                            // a window parked more than 2^64 above the smallest scale the accumulators have been at (h3_rise_ok: its samples are
+                            // below the rounding error of what is already summed) is DROPPED -- branch-free: its products are taken from the
+                            // workgroup's all-zero window instead (no control flow around the accumulator vectors)
+                            if (h3_rise_ok<TN>(ac, ws)) h3_adopt<TN>(ac, ws, DUAL);
+                            else wofs = zwin - wave_base;
+                        }
+                        ac.sxmin = rfl_f(fminf(ac.sxmin, ac.sx));      // (also when the window sits at the scale the accumulators started at)
                     }
-                    conv_mfma<TN, TAPS, DUAL, WT>(smem_bytes + (buf * COOP + j) * W1, rb0, s.dil, RA[j & 1], RA2[j & 1], ac);
+                    conv_mfma<TN, TAPS, DUAL, WT>(smem_bytes + wofs, rb0, s.dil, RA[j & 1], RA2[j & 1], ac);
                     if (k + 2 < nch) fetch_a(k + 2, j & 1);
                 }
                 if (j == 0 && kn < nch) {                   // under the first chunk's MFMAs: the next phase's window, into the other buffer
@@ -764,7 +801,9 @@ __device__ __forceinline__ bool run_segment_vec(const SEG& s, const WT* wseg, co
         // chunks, wrapping around: a weight line is then first touched by one workgroup and found in L2 by the others later,
         // instead of 16 requests piling up on one pending miss (tests/gpu_l2bw.hip: 22-28 -> 33-34 B/clk/CU on a cold K = 4608
         // panel, no effect on short ones).  fp32 sums are order-dependent: the result stays deterministic, per column tile.
-        const int rot = nch >= 8 ? rot_seed % nch : 0;
+        // (which chunk a column tile starts at only has to DIFFER between neighbours: floor(hash(seed) nch / 2^32) -- two multiplies -- instead of
+        // seed % nch, a 25-instruction integer-division sequence in front of the first loads of every segment)
+        const int rot = nch >= 8 ? (int)__umulhi((unsigned)rot_seed * 0x9E3779B1u, (unsigned)nch) : 0;
         auto fetch_x = [&](int cr0, int d) MUGD_LI {
             int cr = cr0 + rot;
             cr = cr >= nch ? cr - nch : cr;
@@ -785,6 +824,7 @@ __device__ __forceinline__ bool run_segment_vec(const SEG& s, const WT* wseg, co
         for (int d = 0; d < D; ++d)                     // requested chunk by chunk (window first): the memory system serves a cold
             if (d < nch) { fetch_x(d, d); fetch_a(d, d); }      // burst roughly in order, so chunk 0 is complete after 1/D of it
         TL_STAMP_ONCE(14);                                   // timeline build: the ring's first loads are issued
+        pre_park();                                          // the workgroup's statistics (conv_tile), behind the requests
 #if defined(MUGD_TL) && !defined(MUGD_EMULATED)
         asm volatile("" :: "v"(RX[0][0].x));                // ... and chunk 0's window has arrived
         TL_STAMP_ONCE(15);
@@ -820,6 +860,7 @@ __device__ __forceinline__ bool run_segment_vec(const SEG& s, const WT* wseg, co
     load_a<TAPS, DUAL>(wp, wp2, Aa, Aa2);
     int crel = 0;
     if (xf) gbv = load_gb(0);
+    pre_park();
     finish_ln();
 
     auto step = [&](const float4 (&A)[6], const float4 (&A2)[6], float4 (&An)[6], float4 (&An2)[6], bool more) MUGD_LI {
@@ -890,7 +931,7 @@ __device__ __forceinline__ void run_segment_gen(const SEG& s, const float* wseg,
     const float* gb = nullptr;
     if (xf == 1) gb = s.xf_a + (size_t)b * s.xf_stride + 2 * (size_t)lo * CONV_CK;
     else if (xf == 2) gb = s.xf_b + 2 * (size_t)lo * CONV_CK;
-    const int bb = s.bmod > 0 ? b % s.bmod : b;
+    const int bb = batch_row_mod(b, s.mbmod, s.bmod);
     const char* xb = reinterpret_cast<const char*>(s.x + ((size_t)bb * s.C + (size_t)lo * CONV_CK) * s.Tin);
     const size_t xstep = (size_t)CONV_CK * s.Tin * 4;
     const float* wp = wseg + (size_t)lo * (TAPS * 512);
@@ -923,9 +964,10 @@ __device__ __forceinline__ void run_segment_gen(const SEG& s, const float* wseg,
         if (conv_h3<float>()) {                        // H3 domain: as park_v of the fast path
             float m = 0.f;
 #pragma unroll
-            for (int k = 0; k < NIT; ++k) m = fmaxf(m, fabsf(v[k]));
+            for (int k = 0; k < NIT; ++k) m = fmaxf(m, h3_finite_abs(v[k]));
             float sc = ac.sx;
             if (MUGD_H3_DYN && __builtin_expect(h3_off_band(m, sc), 0)) sc = h3_pick<32>(ac, m, sc, true, DUAL);
+            ac.sxmin = rfl_f(fminf(ac.sxmin, ac.sx));
 #pragma unroll
             for (int k = 0; k < NIT; ++k) v[k] = h3_split_scaled(v[k], sc);
         }
@@ -962,7 +1004,7 @@ __device__ __forceinline__ void run_segment_gen(const SEG& s, const float* wseg,
 // ---------------------------------------------------------------------------------------
 // LDS block of one (virtual) workgroup: [staging windows: WK waves x 2][K-split exchange (x 2 gated)][pad][statistics tables][epilogue scratch]
 // ---------------------------------------------------------------------------------------
-template <int WK, bool DUAL, int TN = CONV_TN>
+template <int WK, bool DUAL, int TN = CONV_TN, int MS = 0>
 struct ConvLds {
     static constexpr int RED = WK > 1 ? WK * ConvGeo<TN>::NREG * 64 : 0;   // floats for one partial-tile exchange
     static constexpr int WIN = WK * ConvGeo<TN>::WAVE_LDS;
@@ -971,11 +1013,13 @@ struct ConvLds {
     static constexpr int STAT_BYTES = (int)sizeof(typename WgStats<WK, TN>::Lds);
     static constexpr int EPI_OFF = STAT_OFF + STAT_BYTES;
     static constexpr int EPI_BYTES = 32 * (TN + 1) * 4;                    // xs[32][TN + 1] of EPI_XSOFTMAX; cst[2][WK][TN] fits inside
-    static constexpr int BYTES = (EPI_OFF + EPI_BYTES + 15) / 16 * 16;
+    static constexpr int ZERO_OFF = (EPI_OFF + EPI_BYTES + 15) / 16 * 16;  // M-split forms under H3: one all-zero window (run_segment_vec: dropped windows)
+    static constexpr int ZERO_BYTES = (MS > 0 && MUGD_CONV_H3) ? ConvGeo<TN>::WIN_LDS * 4 : 0;
+    static constexpr int BYTES = (ZERO_OFF + ZERO_BYTES + 15) / 16 * 16;
     static_assert(2 * WK * TN * 4 <= EPI_BYTES, "column-sum scratch must fit the epilogue block");
 };
-template <int WK, bool DUAL, int TN = CONV_TN>
-constexpr int conv_lds_bytes() { return ConvLds<WK, DUAL, TN>::BYTES; }
+template <int WK, bool DUAL, int TN = CONV_TN, int MS = 0>
+constexpr int conv_lds_bytes() { return ConvLds<WK, DUAL, TN, MS>::BYTES; }
 
 // KIND 0: every segment takes the fast window path with dilation 1 (the whole U-Net except its 6 resampling convs):
 //         chunk loops specialised on the operand transform and software-pipelined.
@@ -1001,7 +1045,7 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
     static_assert(!MS || (NR * KS == WK && NR % 2 == 0), "M-split: WK = row tiles x K-slices, an even number of row tiles");
     constexpr bool A2 = DUAL;                       // two weight streams / two accumulators per wave (the gate rows)
     typedef ConvGeo<TN> G;
-    typedef ConvLds<WK, A2, TN> L;
+    typedef ConvLds<WK, A2, TN, MS> L;
     constexpr int RED = L::RED;
     constexpr int WIN = L::WIN;
     constexpr int NREG = G::NREG;
@@ -1021,6 +1065,9 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
     Stats stats;
     stats.issue(a, b, t0, tid);
     TL_STAMP(11);
+    if constexpr (L::ZERO_BYTES > 0) {               // (visible to every wave behind the workgroup barrier that follows the first park)
+        for (int i = tid; i < L::ZERO_BYTES / 4; i += WK * 64) reinterpret_cast<float*>(lds + L::ZERO_OFF)[i] = 0.f;
+    }
 
     // K-slice of this wave: chunk boundaries balanced by cost on the host (a 3-tap chunk is ~2x a 1x1 chunk); M-split: all of K
     const int wr = MS ? wave % NR : 0;             // M-split: this wave's row tile inside the group ...
@@ -1047,7 +1094,8 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
     constexpr int EPT = MS ? NREG / KS : NREG / WK;  // tile rows (accumulator registers) finished by each wave
     const int rbase = wks * EPT;                     // ... starting with this one
     float bv[EPT], bg[EPT], ra[EPT], rsv[EPT];
-    size_t oo[EPT];
+    unsigned oo[EPT];                                // element offsets into the (B, Mout, Tout) output: < 2^32 (conv_prepare checks); one register
+                                                     // per row instead of two -- the gated kernels sit at the 256-VGPR budget
     int mm[EPT];
     bool valid[EPT];
 #pragma unroll
@@ -1057,7 +1105,7 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
         const int m = mtw * 32 + row, t = t0 + cl;
         valid[q] = live && (m < a.Mout) && (t < a.Tout);
         mm[q] = m < a.Mout ? m : a.Mout - 1;
-        oo[q] = ((size_t)b * a.Mout + mm[q]) * a.Tout + (t < a.Tout ? t : a.Tout - 1);
+        oo[q] = ((unsigned)b * (unsigned)a.Mout + (unsigned)mm[q]) * (unsigned)a.Tout + (unsigned)(t < a.Tout ? t : a.Tout - 1);
         bv[q] = 0.f; bg[q] = 0.f; ra[q] = 0.f; rsv[q] = 0.f;
     }
     constexpr bool PRELOAD = EPT <= 4;   // wide per-wave epilogues (WK 1, 2) load late instead: registers
@@ -1082,29 +1130,45 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
     float winv = a.winv != 0.f ? a.winv : 1.0f;
     if (conv_h3<WT>() && a.wmax) winv = h3_pow2_recip(h3_wscale(*to_const_as(a.wmax)));
     TL_STAMP(12);
-    stats.finish(a, b, t0, tid, stl);      // reduce + workgroup barrier(s): the requests went out before the index math above
-    TL_STAMP(1);
+    // The statistics are reduced (+ workgroup barrier) INSIDE the wave's first segment, right behind that segment's first operand requests
+    // (run_segment_vec: pre_park) -- every wave runs the reduction exactly once wherever its K-slice starts; a wave without a segment, and the
+    // generic-window kernels (KIND 2: no deferred form), run it here / behind the loop.  Round 6: the timeline of round 4 had 1 - 2.5 us per
+    // normalised launch between "sums reduced" and "first operand loads issued" (profiles/r4_timeline2_z512_b4.txt) -- now the two overlap.
+    auto pre_park = [&]() MUGD_LI {
+        stats.finish(a, b, t0, tid, stl);
+        TL_STAMP_ONCE(1);
+    };
+    if constexpr (KIND == 2) pre_park();
     TL_SET(10, g1 - g0);
 
     bool redo = false;                               // H3 domain: a raw segment's slice left the band at the fixed scale (run_segment_vec: TRACK)
-    // (this loop MUST be fully unrolled: left rolled, the dynamic index a.seg[si] moves the whole by-value argument block into scratch memory --
-    // 688 bytes per lane and +20 us per launch, seen in round 5 when the body outgrew the full-unroll budget on the WK = 8 instantiations.  That is
-    // why the run-time-transform instantiation is not part of this body any more: the rare transform / activation pairs without a specialised
-    // loop go through the careful pass below)
-#pragma unroll
-    for (int si = 0; si < CONV_MAXSEG; ++si) {
-        if (si < a.nseg) {
-            const auto& s = a.seg[si];
-            const int nch = s.C / CONV_CK;
-            const int lo = (g0 > s.chunk0 ? g0 : s.chunk0) - s.chunk0;
-            const int hi = (g1 < s.chunk0 + nch ? g1 : s.chunk0 + nch) - s.chunk0;
-            if (lo < hi) {
-                const WT* w1 = wtile + s.woff;
-                const WT* w2 = wtile2 + s.woff;
-#define MUGD_SEG_VARGS s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, ac, stl.gnst, stl.lnst, gn_inv_cg, rot, wr, stl.wsc + (MS ? wks * 2 * NR : 0), g0 >= s.chunk0
+    // The segments are read through a pointer into MEMORY -- a by-value kernel argument already sits in the kernarg segment (scalar loads, hot in
+    // the scalar cache after KARG_WARM) -- so that the segment index may be a run-time value: a dynamic index into the by-value parameter itself
+    // makes the compiler copy the whole block into scratch at kernel entry (688 bytes per lane, +20 us per launch: round 5).  Round 6: the loop
+    // over the segments is ROLLED with its first executed iteration peeled off -- two copies of the specialised chunk loops instead of four
+    // unrolled ones (the kernel's code halves) -- because the peeled copy is the one place where the workgroup's statistics are reduced
+    // (pre_park, behind the wave's first operand requests): their partial sums are live in registers up to that point and must not stay live
+    // across every chunk loop of the kernel (measured: +20 ... 40 VGPRs, scratch in every hot instantiation, when the call sat in all of them).
+#ifdef MUGD_EMULATED
+    const A* am = &a;
+#else
+    const MUGD_CONST_AS ConvArgs* am;
+    if constexpr (std::is_same<typename std::remove_cv<A>::type, ConvArgs>::value)
+        am = (const MUGD_CONST_AS ConvArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    else
+        am = &a;
+#endif
+    auto run_seg = [&](const auto& s, auto&& pp) MUGD_LI {
+        const int nch = s.C / CONV_CK;
+        const int lo = (g0 > s.chunk0 ? g0 : s.chunk0) - s.chunk0;
+        const int hi = (g1 < s.chunk0 + nch ? g1 : s.chunk0 + nch) - s.chunk0;
+        if (lo >= hi) return;
+        const WT* w1 = wtile + s.woff;
+        const WT* w2 = wtile2 + s.woff;
+#define MUGD_SEG_VARGS s, w1, w2, lo, hi, b, t0, lane, smem_bytes, wave_base, ac, stl.gnst, stl.lnst, gn_inv_cg, rot, wr, stl.wsc + (MS ? wks * 2 * NR : 0), g0 >= s.chunk0, pp, L::ZERO_OFF
 #define MUGD_COOP , WT, typename std::remove_cv<typename std::remove_reference<decltype(s)>::type>::type, (MS ? NR : 0)
-                if constexpr (KIND == 0) {
-                    // specialise on (transform, activation): branch-free chunk loops
+        if constexpr (KIND == 0) {
+            // specialise on (transform, activation): branch-free chunk loops
 #define MUGD_SEG_XF(T, NHALO)                                                                     \
     switch (s.xf * 4 + s.act) {                                                                   \
         case 0: redo |= run_segment_vec<TN, T, A2, NHALO, 0, 0, MUGD_PIPE MUGD_COOP>(MUGD_SEG_VARGS); break;              \
@@ -1112,29 +1176,43 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
         case 5: case 17: run_segment_vec<TN, T, A2, NHALO, 1, 1, MUGD_PIPE MUGD_COOP>(MUGD_SEG_VARGS); break;            \
         case 6: case 18: run_segment_vec<TN, T, A2, NHALO, 1, 2, MUGD_PIPE MUGD_COOP>(MUGD_SEG_VARGS); break;            \
         case 8: case 12: run_segment_vec<TN, T, A2, NHALO, 2, 0, MUGD_PIPE MUGD_COOP>(MUGD_SEG_VARGS); break;            \
-        default: if constexpr (MS == 0) redo = true; else run_segment_vec<TN, T, A2, NHALO, -1, -1, false MUGD_COOP>(MUGD_SEG_VARGS);      \
+        default: if constexpr (MS == 0) { pp(); redo = true; } else run_segment_vec<TN, T, A2, NHALO, -1, -1, false MUGD_COOP>(MUGD_SEG_VARGS);      \
     }
-                    if (DUAL || s.taps == 1) { MUGD_SEG_XF(1, 0) }
-                    else { MUGD_SEG_XF(3, 1) }
+            if (DUAL || s.taps == 1) { MUGD_SEG_XF(1, 0) }
+            else { MUGD_SEG_XF(3, 1) }
 #undef MUGD_SEG_XF
-                } else if constexpr (KIND == 1) {
-                    if (s.taps == 1) run_segment_vec<TN, 1, A2, 0>(MUGD_SEG_VARGS);
-                    else if (s.dil <= 2) run_segment_vec<TN, 3, A2, 1>(MUGD_SEG_VARGS);
-                    else if (s.dil == 4) run_segment_vec<TN, 3, A2, 2>(MUGD_SEG_VARGS);
-                    else run_segment_vec<TN, 3, A2, 4>(MUGD_SEG_VARGS);
-                } else {
-                    if constexpr (sizeof(WT) == 4 && TN == 32) {          // the generic windows exist with fp32 weights and 32-wide tiles only
-                        const float* f1 = reinterpret_cast<const float*>(w1);
-                        const float* f2 = reinterpret_cast<const float*>(w2);
-                        if (s.taps == 3) run_segment_gen<3, A2, NITG, (NITG <= 9)>(s, f1, f2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, ac);
-                        else run_segment_gen<1, A2, NITG, (NITG <= 9)>(s, f1, f2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, ac);
-                    }
-                }
-#undef MUGD_SEG_VARGS
-#undef MUGD_COOP
+        } else if constexpr (KIND == 1) {
+            if (s.taps == 1) run_segment_vec<TN, 1, A2, 0>(MUGD_SEG_VARGS);
+            else if (s.dil <= 2) run_segment_vec<TN, 3, A2, 1>(MUGD_SEG_VARGS);
+            else if (s.dil == 4) run_segment_vec<TN, 3, A2, 2>(MUGD_SEG_VARGS);
+            else run_segment_vec<TN, 3, A2, 4>(MUGD_SEG_VARGS);
+        } else {
+            if constexpr (sizeof(WT) == 4 && TN == 32) {          // the generic windows exist with fp32 weights and 32-wide tiles only
+                const float* f1 = reinterpret_cast<const float*>(w1);
+                const float* f2 = reinterpret_cast<const float*>(w2);
+                if (s.taps == 3) run_segment_gen<3, A2, NITG, (NITG <= 9)>(s, f1, f2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, ac);
+                else run_segment_gen<1, A2, NITG, (NITG <= 9)>(s, f1, f2, lo, hi, b, t0, lane, h, n, smem_bytes, wave_base, ac);
             }
         }
+#undef MUGD_SEG_VARGS
+#undef MUGD_COOP
+    };
+    const int nseg = a.nseg;
+    int si = 0;
+    if constexpr (KIND != 2) {
+        if (KIND == 0 && MS == 0 && __builtin_expect(a.h3_careful != 0, 0)) {
+            // the caller knows its raw operands sit far from O(1) (ConvArgs::h3_careful: the training step's gradients, 1e-4 ... 1e-12): straight
+            // to the careful pass below instead of a fast pass whose slice check would send every wave there anyway (round 6)
+            redo = true; si = nseg;
+        } else {
+            // the wave's first segment: the one that holds chunk g0 (an empty K-slice -- g0 == g1 -- finds none)
+            while (si < nseg && !(g0 < g1 && g0 < am->seg[si].chunk0 + am->seg[si].C / CONV_CK)) ++si;
+            if (si < nseg) { run_seg(am->seg[si], pre_park); ++si; }
+        }
     }
+    pre_park();                                      // (a wave whose K-slice is empty: the workgroup's barrier count must match)
+#pragma nounroll
+    for (; si < nseg; ++si) run_seg(am->seg[si], NoPrePark());
     if constexpr (KIND == 0 && MS == 0) {
         // H3 domain, rare (never on the shipped networks): some raw slice of this wave left the band at the fixed scale -- an operand above 2^7 or
         // a whole slice below 2^-6 -- so what the accumulators hold may be inf or imprecise.  The wave starts its tile over and runs EVERY
@@ -1147,18 +1225,9 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
             // MEMORY: a by-value kernel argument already sits in the kernarg segment, the executor's argument block in its op table -- a
             // dynamic index into either is a scalar load, where a dynamic index into the by-value parameter itself would make the compiler
             // copy the whole block into scratch at kernel entry (688 bytes per lane, +20 us per launch: seen in round 5)
-#ifdef MUGD_EMULATED
-            const A* am = &a;
-#else
-            const MUGD_CONST_AS ConvArgs* am;
-            if constexpr (std::is_same<typename std::remove_cv<A>::type, ConvArgs>::value)
-                am = (const MUGD_CONST_AS ConvArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-            else
-                am = &a;
-#endif
 #pragma nounroll
-            for (int si = 0; si < a.nseg; ++si) {
-                const auto& s = am->seg[si];
+            for (int sj = 0; sj < nseg; ++sj) {
+                const auto& s = am->seg[sj];
                 typedef typename std::remove_cv<typename std::remove_reference<decltype(s)>::type>::type SegT;
                 const int nch = s.C / CONV_CK;
                 const int lo = (g0 > s.chunk0 ? g0 : s.chunk0) - s.chunk0;

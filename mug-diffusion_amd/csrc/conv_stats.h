@@ -42,24 +42,29 @@ struct WgStats {
     double2 gv[NG];
     float2 lv[NLN];
 
-    // fp64 {sum, sum of squares} of channel c of the normalised concat (segments 0 .. gn_nseg-1), batch row b; zero if !ok.
-    // One predicated load per segment with COMPILE-TIME segment indices: a per-lane segment index would turn the kernarg
-    // accesses into vector loads of the argument block -- a second dependent round trip in front of the sums themselves.
+    // fp64 {sum, sum of squares} of channel c of the normalised concat (segments 0 .. gn_nseg-1), batch row b.  Branch-free: the segment is
+    // picked with selects under COMPILE-TIME segment indices (a per-lane segment index would turn the kernarg accesses into vector loads of the
+    // argument block), then ONE unconditional load -- callers mask rows outside the concat when they sum (an out-of-range c reads segment 0's
+    // first row).  Round 6: the previous form -- one predicated load per segment -- compiled to an exec-mask branch per segment whose load
+    // had to WAIT for the previous segment's (same destination registers: s_waitcnt vmcnt(0) between them) and an integer-division sequence
+    // for b % bmod in every branch: up to three dependent memory round trips in front of the statistics of a multi-segment GroupNorm.
     template <class A>
-    static __device__ __forceinline__ double2 row_load(const A& a, int b, int c, bool ok) {
-        double2 v = make_double2(0.0, 0.0);
+    static __device__ __forceinline__ double2 row_load(const A& a, int b, int c) {
+        const double* p = nullptr;
+        int rel = 0, c0 = 0;
 #pragma unroll
         for (int si = 0; si < CONV_MAXSEG; ++si) {
             if (si < a.gn_nseg) {
                 const auto& s = a.seg[si];
-                if (ok && c >= 0 && c < s.C) {
-                    const int bb = s.bmod > 0 ? b % s.bmod : b;
-                    v = *reinterpret_cast<const double2*>(reinterpret_cast<const double*>(s.xf_a) + (size_t)bb * s.xf_stride + 2 * (size_t)c);
-                }
-                c -= s.C;
+                const double* sb = reinterpret_cast<const double*>(s.xf_a) + (size_t)batch_row_mod(b, s.mbmod, s.bmod) * s.xf_stride;      // wave-uniform
+                const bool in = si == 0 ? (c < s.C) : (c >= c0 && c < c0 + s.C);      // si == 0 also catches c < 0 / nothing matched: a valid address
+                const int r0 = c - c0;
+                if (si == 0) { p = sb; rel = (r0 >= 0 && r0 < s.C) ? r0 : 0; }
+                else { p = in ? sb : p; rel = in ? r0 : rel; }
+                c0 += s.C;
             }
         }
-        return v;
+        return *reinterpret_cast<const double2*>(p + 2 * (size_t)rel);
     }
 
     template <class A>
@@ -71,7 +76,7 @@ struct WgStats {
 #pragma unroll
             for (int u = 0; u < NG; ++u) {
                 const int cc = j + u * LPG;
-                gv[u] = row_load(a, b, g * cg + cc, g < a.gn_groups && cc < cg);
+                gv[u] = row_load(a, b, (g < a.gn_groups && cc < cg) ? g * cg + cc : 0);
             }
         }
         if (ln) {
@@ -92,15 +97,23 @@ struct WgStats {
     __device__ __forceinline__ void finish(const A& a, int b, int t0, int tid, Lds& l) {
         if (!pending) return;
         pending = false;
+        // The requested sums are consumed HERE and not earlier (the pins below): without them the scheduler hoists the first additions
+        // (0.0 + x cannot be folded) up to the requests themselves and waits for them there -- in front of the operand requests this reduction
+        // is meant to overlap with (round 6: seen in the ISA as v_add_f64 v, v, 0 behind an s_waitcnt vmcnt right after issue()).  The "memory"
+        // clobber keeps the operand loads issued before this point in front of it.  (Pinned only on the path that loaded them: a zero-initialised
+        // alternative makes the register allocator COPY the loaded values at the join -- another early wait.)
         if (a.gn_groups) {
             const int g = tid / LPG, j = tid % LPG, cg = a.gn_cg;
             const bool active = g < a.gn_groups;
+#ifndef MUGD_EMULATED
+            asm volatile("" : "+v"(gv[0].x), "+v"(gv[0].y), "+v"(gv[1].x), "+v"(gv[1].y), "+v"(gv[2].x), "+v"(gv[2].y) :: "memory");
+#endif
             double s1 = 0.0, s2 = 0.0;
 #pragma unroll
             for (int u = 0; u < NG; ++u)
                 if (active && j + u * LPG < cg) { s1 += gv[u].x; s2 += gv[u].y; }
             for (int cc = j + NG * LPG; active && cc < cg; cc += LPG) {         // groups wider than NG * LPG channels (not in the shipped nets at WK = 8)
-                const double2 v = row_load(a, b, g * cg + cc, true);
+                const double2 v = row_load(a, b, g * cg + cc);
                 s1 += v.x; s2 += v.y;
             }
             TL_STAMP(13);
@@ -117,6 +130,10 @@ struct WgStats {
         if (ln) {
             const auto& s = a.seg[0];
             const int col = tid % TN, part = tid / TN;
+#ifndef MUGD_EMULATED
+#pragma unroll
+            for (int u = 0; u < NLN; ++u) asm volatile("" : "+v"(lv[u].x), "+v"(lv[u].y) :: "memory");
+#endif
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int u = 0; u < NLN; ++u)

@@ -39,49 +39,9 @@
 #include <cstdlib>
 
 #define MUGD_H3_COUNT_TU 1
-#include "conv_body.h"
-
-#ifndef MUGD_KARG_WARM
-#define MUGD_KARG_WARM 1
-#endif
+#include "conv_kernel.h"
 
 namespace {
-
-// One workgroup = one tile: decodes blockIdx into (row tile, batch row, column tile) and runs the shared tile body (conv_body.h).
-// TN = 16: the 32 x 16 tiles of conv_body.h (ConvGeo) -- the same body, half the columns per workgroup.
-// MS: the M-split ("wide") form -- the grid's row axis counts GROUPS of WK row tiles (conv_body.h).
-template <int WK, bool DUAL, int KIND, int NITG, class WT = float, int TN = CONV_TN, int MS = 0>
-__global__ __launch_bounds__(WK * 64) MUGD_WAVES_PER_EU(2) void conv_gemm_kernel(const ConvArgs a) {
-    __shared__ __attribute__((aligned(16))) char lds[conv_lds_bytes<WK, DUAL, TN>()];
-    TL_BEGIN();
-#if MUGD_KARG_WARM
-    KARG_WARM(sizeof(ConvArgs));
-#endif
-
-    // ---- kernel arguments of the prologue in one batch (common.h: KARG_PIN)
-    const int gx = a.gx, gy = a.gy, gz = a.gz;
-    KARG_PIN4(gx, gy, gz, a.xcd_cols);
-    KARG_PIN4(a.mgx, a.mgy, a.mgxz, a.nseg);
-    KARG_PIN4(a.gn_groups, a.gn_cg, a.gn_nseg, a.Mout);
-    KARG_PIN4(a.wpk, a.w_mt_stride, a.Tout, a.nchunk);
-    KARG_PIN4(a.seg[0].x, a.seg[0].C, a.seg[0].Tin, a.seg[0].xf);
-    KARG_PIN4(a.seg[0].xf_a, a.seg[0].xf_stride, a.seg[0].bmod, a.seg[0].xf_np);
-    KARG_PIN4(a.bias, a.rowadd, a.resid, a.rowadd_stride);
-
-    // ---- XCD-aware renumbering: hardware deals consecutive workgroup ids round-robin to the 8 XCDs;
-    // give each XCD a contiguous slab of the (row tile major) tile order so a weight tile is pulled
-    // into ONE private L2 and reused there by all sample tiles / batch rows.
-    const int nblk = gx * gy * gz;
-    int lid = blockIdx.x;
-    if ((nblk & 7) == 0) lid = (lid & 7) * (nblk >> 3) + (lid >> 3);
-    int mt, rem;
-    if (a.xcd_cols) { rem = fastdiv(lid, a.mgy, gy); mt = lid - rem * gy; }       // row tile fastest: an XCD's slab is a range of column tiles
-    else { mt = fastdiv(lid, a.mgxz, gx * gz); rem = lid - mt * (gx * gz); }
-    const int b = fastdiv(rem, a.mgx, gx);
-    const int t0 = (rem - b * gx) * TN;
-    conv_tile<WK, DUAL, KIND, NITG, WT, ConvArgs, TN, MS>(a, MS ? (WK / MS) * mt : mt, b, t0, rem, (int)threadIdx.x, lds, true);      // MS: the grid's row axis counts GROUPS of row tiles
-    TL_END(a.tl, WK);
-}
 
 // bits of max |w| over a block of a packed set (PackArgs::wmax, zeroed by the caller): grid-stride max, wave + workgroup reduction, one atomic
 __global__ void weight_absmax_kernel(const PackArgs p) {
@@ -142,33 +102,46 @@ __global__ void pack_weights_kernel(const PackArgs p) {
     }
 }
 
-// M-split form: NW / KS row tiles per workgroup, KS K-slices (conv_body.h: MS = KS; 1 = no K-split)
-template <int NW, bool DUAL, int KS = 1>
-void launch_wide(hipStream_t st, const ConvArgs& a0, int gx, int gy, int gz) {
-    ConvArgs a = a0;
-    conv_split_k(a, KS);
-    const int gyg = cdiv(gy, NW / KS);
-    conv_set_grid(a, gx, gyg, gz);
-    const dim3 grid((unsigned)gx * gyg * gz);
-    a.tl = tl_claim((int)grid.x, NW, 32);
-    hipLaunchKernelGGL((conv_gemm_kernel<NW, DUAL, 0, 1, float, 32, KS>), grid, dim3(NW * 64), 0, st, a);
+// ---------------------------------------------------------------------------------------
+// Host side of a launch, in two halves (round 6): conv_prepare() does everything that depends only on the argument block -- validation, the
+// development knobs (environment), the choice of the kernel form, the K-split boundaries, the grid decode multipliers -- ONCE, when a network
+// program is compiled (net.hip: Net::conv keeps the ConvLaunch in the op); conv_launch() is the per-step part: one hipLaunchKernel.  Before,
+// every launch of every step re-validated its block, called getenv three times and copied the 700-byte block twice.
+// ---------------------------------------------------------------------------------------
+typedef void (*ConvKernel)(const ConvArgs);
+
+// M-split form: NW / KS row tiles per workgroup, KS K-slices (conv_body.h: MS = KS; 1 = no K-split); the kernels live in k_convw.hip
+void prepare_wide(ConvLaunch& L, int nw, bool dual, int ks, int gx, int gy, int gz) {
+    conv_split_k(L.a, ks);
+    const int gyg = cdiv(gy, nw / ks);
+    conv_set_grid(L.a, gx, gyg, gz);
+    L.grid = (unsigned)gx * gyg * gz; L.block = nw * 64; L.tn = 32;
+    L.kern = conv_kernel_wide(nw, dual, ks);
+    MUGD_CHECK(L.kern != nullptr, -2, "conv_gemm: no such M-split form");
 }
 
 template <int WK, bool DUAL>
-void launch_wk(hipStream_t st, const ConvArgs& a0, dim3 grid, int gx, int gy, int gz, int kind, int nitg) {
-    ConvArgs a = a0;
+void prepare_wk(ConvLaunch& L, int gx, int gy, int gz, int kind, int nitg) {
+    ConvArgs& a = L.a;
     conv_split_k(a, WK);
     conv_set_grid(a, gx, gy, gz);
-    a.tl = tl_claim((int)grid.x, WK, 32);
-#define MUGD_CONV_LAUNCH(K, N) hipLaunchKernelGGL((conv_gemm_kernel<WK, DUAL, K, N>), grid, dim3(WK * 64), 0, st, a)
+    L.grid = (unsigned)gx * gy * gz; L.block = WK * 64; L.tn = 32;
+#define MUGD_CONV_KERN(K, N) L.kern = reinterpret_cast<const void*>(static_cast<ConvKernel>(conv_gemm_kernel<WK, DUAL, K, N>))
     if (a.w16) {
         MUGD_CHECK(kind == 0, -2, "conv_gemm: bfloat16 weights exist for the plain fast-window kernels only");
-        hipLaunchKernelGGL((conv_gemm_kernel<WK, DUAL, 0, 1, unsigned short>), grid, dim3(WK * 64), 0, st, a);
-    } else if (kind == 0) MUGD_CONV_LAUNCH(0, 1);
-    else if (kind == 1) MUGD_CONV_LAUNCH(1, 1);
-    else if (nitg <= 9) MUGD_CONV_LAUNCH(2, 9);
-    else MUGD_CONV_LAUNCH(2, 17);
-#undef MUGD_CONV_LAUNCH
+        L.kern = conv_kernel32_w16(WK, DUAL);           // (k_convw.hip)
+    } else if (kind == 0) MUGD_CONV_KERN(0, 1);
+    else if (kind == 1) {
+        // (gated epilogues exist for 1x1 convs only and a 1x1 segment is never dilated: no gated KIND 1 instantiation -- they carried 500 - 900
+        // bytes of scratch for nothing)
+        if constexpr (DUAL) MUGD_CHECK(false, -2, "conv_gemm: gated epilogue on a dilated kernel");
+        else MUGD_CONV_KERN(1, 1);
+    } else if (nitg <= 9) MUGD_CONV_KERN(2, 9);
+    else {
+        if constexpr (DUAL) MUGD_CHECK(false, -2, "conv_gemm: gated epilogue on a strided / upsampling kernel");      // (a 1x1 window is 32 samples: 8 passes)
+        else MUGD_CONV_KERN(2, 17);
+    }
+#undef MUGD_CONV_KERN
 }
 
 // The 16-wide tiles' fragment order (conv_body.h: mfma_chunk16): per (tap, row half) [lane = kq * 16 + r][kg] = W[16 half + r][4 kg + kq].
@@ -205,17 +178,12 @@ __global__ void pack_weights16_kernel(const PackArgs p) {
     }
 }
 
-template <int WK>
-void launch16_wk(hipStream_t st, const ConvArgs& a0, dim3 grid, int gx, int gy, int gz, bool dual) {
-    ConvArgs a = a0;
-    conv_split_k(a, WK);
+void prepare16_wk(ConvLaunch& L, int wk, int gx, int gy, int gz, bool dual) {      // the kernels live in k_conv16.hip
+    ConvArgs& a = L.a;
+    conv_split_k(a, wk);
     conv_set_grid(a, gx, gy, gz);
-    a.tl = tl_claim((int)grid.x, WK, 16);
-    if (a.w16) {
-        if (dual) hipLaunchKernelGGL((conv_gemm_kernel<WK, true, 0, 1, unsigned short, 16>), grid, dim3(WK * 64), 0, st, a);
-        else hipLaunchKernelGGL((conv_gemm_kernel<WK, false, 0, 1, unsigned short, 16>), grid, dim3(WK * 64), 0, st, a);
-    } else if (dual) hipLaunchKernelGGL((conv_gemm_kernel<WK, true, 0, 1, float, 16>), grid, dim3(WK * 64), 0, st, a);
-    else hipLaunchKernelGGL((conv_gemm_kernel<WK, false, 0, 1, float, 16>), grid, dim3(WK * 64), 0, st, a);
+    L.grid = (unsigned)gx * gy * gz; L.block = wk * 64; L.tn = 16;
+    L.kern = conv_kernel16(wk, dual, a.w16 != 0);
 }
 
 }  // namespace
@@ -241,7 +209,10 @@ static int conv_pick_wk_tiles(long long tiles, int nchunk) {
 }
 int conv_pick_wk(const ConvArgs& a) { return conv_pick_wk_tiles((long long)cdiv(a.Tout, CONV_TN) * cdiv(a.Mout, 32) * a.B, a.nchunk); }
 
-void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
+static void prepare_conv32(ConvLaunch& L) {
+    ConvArgs& a = L.a;
     MUGD_CHECK(a.nseg >= 1 && a.nseg <= CONV_MAXSEG, -2, "conv_gemm: bad segment count");
     int nitg = 0;                         // staging passes of the generic path: ceil(16 * window / 64) for its widest segment
     bool lean = true, all_vec = true;
@@ -288,12 +259,13 @@ void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
     }
     else MUGD_CHECK(a.Mrows == a.Mout, -2, "conv_gemm: Mrows != Mout");
     int gx = cdiv(a.Tout, CONV_TN), gy = cdiv(a.Mout, 32), gz = a.B;
+    const int env_wk = env_int("MUGD_CONV_WK", 0);       // development / test knob: force the K-split
     // M-split ("wide") form (conv_body.h: MS; plain fast windows, fp32 weights, >= 2 row tiles, not the score epilogue).  Chosen where the
     // per-launch table says it wins (profiles/r4_wide_ab.txt): tall M (>= 2 groups of 8 row tiles: 8-wave workgroups), short K (<= 32 chunks: the
     // q/k/v and GEGLU projections) and enough workgroups that way (>= 160: batch 8 upwards); and the K = 48 input conv, whose K-split form is one
     // wave per tile.  The long-K launches lose a wave per SIMD in this form and stay K-split.  MUGD_CONV_WIDE=1 forces it wherever it exists, =0 never.
     {
-        const bool can = kind == 0 && !a.w16 && a.epi != EPI_XSOFTMAX && gy >= 2 && a.wk <= 0 && !getenv("MUGD_CONV_WK");      // a forced K-split wins
+        const bool can = kind == 0 && !a.w16 && a.epi != EPI_XSOFTMAX && gy >= 2 && (a.wk <= 0 || a.wk >= 0x100) && !env_wk;      // a forced K-split wins
         const int nw = gy >= 8 ? 8 : gy >= 4 ? 4 : 2;
         const long long wgs = (long long)cdiv(gy, nw) * gx * gz;
         bool wide = can && ((gy >= 16 && a.nchunk <= 32 && wgs >= 160) || (gy >= 4 && a.nchunk <= 4 && wgs >= 128));
@@ -306,38 +278,70 @@ void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
             wide2 = true;
             for (int i = 0; i < a.nseg; ++i) wide2 = wide2 && a.seg[i].taps == 3;
         }
-        if (const char* e = getenv("MUGD_CONV_WIDE")) {      // 0 never | 1 the M-split form wherever it exists | 2 the M-split x K-split form wherever it exists
-            wide = can && e[0] == '1';
-            wide2 = can && e[0] == '2' && a.nchunk >= 2;
+        const int env_wide = env_int("MUGD_CONV_WIDE", -1);      // 0 never | 1 the M-split form wherever it exists | 2 the M-split x K-split form wherever it exists
+        if (env_wide >= 0) {
+            wide = can && env_wide == 1;
+            wide2 = can && env_wide == 2 && a.nchunk >= 2;
+        }
+        // a FORCED M-split geometry (mugd_set_conv_tiling: wk = 0x100 | waves << 4 | K-slices -- development / per-shape sweeps): the named form
+        // where it exists for this launch, the host's own choice otherwise
+        if (can && a.wk >= 0x100) {
+            const int fnw = (a.wk >> 4) & 0xf, fks = a.wk & 0xf;
+            const int nr = fks > 0 ? fnw / fks : 0;
+            if (nr >= 2 && gy >= nr && a.nchunk >= fks) {
+                if (conv_kernel_wide(fnw, dual, fks)) { prepare_wide(L, fnw, dual, fks, gx, gy, gz); return; }
+            }
         }
         if (wide2) {
-            if (gy >= 4) { if (dual) launch_wide<8, true, 2>(st, a, gx, gy, gz); else launch_wide<8, false, 2>(st, a, gx, gy, gz); }
-            else { if (dual) launch_wide<4, true, 2>(st, a, gx, gy, gz); else launch_wide<4, false, 2>(st, a, gx, gy, gz); }
+            prepare_wide(L, gy >= 4 ? 8 : 4, dual, 2, gx, gy, gz);
             return;
         }
         if (wide) {
-#define MUGD_WIDE(N) case N: if (dual) launch_wide<N, true>(st, a, gx, gy, gz); else launch_wide<N, false>(st, a, gx, gy, gz); break;
-            switch (nw) { MUGD_WIDE(2) MUGD_WIDE(4) MUGD_WIDE(8) }
-#undef MUGD_WIDE
+            prepare_wide(L, nw, dual, 1, gx, gy, gz);
             return;
         }
     }
-    const dim3 grid((unsigned)gx * gy * gz);
-    int wk = a.wk > 0 ? a.wk : conv_pick_wk_tiles((long long)gx * gy * gz, a.nchunk);
-    if (const char* e = getenv("MUGD_CONV_WK")) {            // development / test knob: force the K-split
-        const int v = atoi(e);
-        if (v == 1 || v == 2 || v == 4 || v == 8) wk = v;
-    }
+    int wk = (a.wk > 0 && a.wk < 0x100) ? a.wk : conv_pick_wk_tiles((long long)gx * gy * gz, a.nchunk);
+    if (env_wk == 1 || env_wk == 2 || env_wk == 4 || env_wk == 8) wk = env_wk;
 #define MUGD_WK(W)                                                             \
     case W:                                                                    \
-        if (dual) launch_wk<W, true>(st, a, grid, gx, gy, gz, kind, nitg);     \
-        else launch_wk<W, false>(st, a, grid, gx, gy, gz, kind, nitg);         \
+        if (dual) prepare_wk<W, true>(L, gx, gy, gz, kind, nitg);              \
+        else prepare_wk<W, false>(L, gx, gy, gz, kind, nitg);                  \
         break;
     switch (wk) {
         MUGD_WK(1) MUGD_WK(2) MUGD_WK(4) MUGD_WK(8)
         default: MUGD_CHECK(false, -2, "conv_gemm: K-split must be 1, 2, 4 or 8");
     }
 #undef MUGD_WK
+}
+
+static void prepare_conv16(ConvLaunch& L);
+
+ConvLaunch conv_prepare(const ConvArgs& a0) {
+    ConvLaunch L{};
+    L.a = a0;
+    MUGD_CHECK((long long)a0.B * a0.Mout * a0.Tout < (1ll << 32), -2, "conv_gemm: output tensor beyond 2^32 elements (32-bit element offsets in the epilogue)");
+    L.a.tl = nullptr;
+    L.a.xcd_cols = conv_pick_order(L.a);
+    if (L.a.tn == 16) prepare_conv16(L); else prepare_conv32(L);
+    return L;
+}
+
+void conv_launch(hipStream_t st, const ConvLaunch& L) {
+    if (g_tl.buf) {                                   // development build: this launch's phase records
+        ConvArgs a = L.a;
+        a.tl = tl_claim((int)L.grid, L.block / 64, L.tn);
+        hipLaunchKernelGGL(reinterpret_cast<ConvKernel>(const_cast<void*>(L.kern)), dim3(L.grid), dim3((unsigned)L.block), 0, st, a);
+        return;
+    }
+    hipLaunchKernelGGL(reinterpret_cast<ConvKernel>(const_cast<void*>(L.kern)), dim3(L.grid), dim3((unsigned)L.block), 0, st, L.a);
+}
+
+// (the mel filter bank of k_mel.hip: a plain 32-wide launch)
+void launch_conv_gemm(hipStream_t st, const ConvArgs& a) {
+    ConvArgs b = a;
+    b.tn = 32;
+    conv_launch(st, conv_prepare(b));
 }
 
 #if defined(MUGD_H3_COUNT) && !defined(MUGD_EMULATED)
@@ -425,7 +429,8 @@ int conv_pick_order(const ConvArgs& a) {
     return col_major < row_major ? 1 : 0;
 }
 
-void launch_conv_gemm16(hipStream_t st, const ConvArgs& a) {
+static void prepare_conv16(ConvLaunch& L) {
+    ConvArgs& a = L.a;
     MUGD_CHECK(a.nseg >= 1 && a.nseg <= CONV_MAXSEG, -2, "conv_gemm (16-wide): bad segment count");
     MUGD_CHECK(conv16_supported(a), -2, "conv_gemm (16-wide): unsupported segment geometry");
     for (int i = 0; i < a.nseg; ++i) {
@@ -444,19 +449,11 @@ void launch_conv_gemm16(hipStream_t st, const ConvArgs& a) {
     if (dual) MUGD_CHECK(a.Mout % 32 == 0 && a.Mrows == 2 * a.Mout, -2, "conv_gemm (16-wide): gated epilogue needs Mout % 32 == 0");
     else MUGD_CHECK(a.Mrows == a.Mout, -2, "conv_gemm (16-wide): Mrows != Mout");
     const int gx = cdiv(a.Tout, 16), gy = cdiv(a.Mout, 32), gz = a.B;
-    const dim3 grid((unsigned)gx * gy * gz);
-    int wk = a.wk > 0 ? a.wk : conv_pick_wk_tiles((long long)gx * gy * gz, a.nchunk);
-    if (const char* e = getenv("MUGD_CONV_WK")) {
-        const int v = atoi(e);
-        if (v == 1 || v == 2 || v == 4 || v == 8) wk = v;
-    }
-    switch (wk) {
-        case 1: launch16_wk<1>(st, a, grid, gx, gy, gz, dual); break;
-        case 2: launch16_wk<2>(st, a, grid, gx, gy, gz, dual); break;
-        case 4: launch16_wk<4>(st, a, grid, gx, gy, gz, dual); break;
-        case 8: launch16_wk<8>(st, a, grid, gx, gy, gz, dual); break;
-        default: MUGD_CHECK(false, -2, "conv_gemm (16-wide): K-split must be 1, 2, 4 or 8");
-    }
+    int wk = (a.wk > 0 && a.wk < 0x100) ? a.wk : conv_pick_wk_tiles((long long)gx * gy * gz, a.nchunk);
+    const int env_wk = env_int("MUGD_CONV_WK", 0);
+    if (env_wk == 1 || env_wk == 2 || env_wk == 4 || env_wk == 8) wk = env_wk;
+    MUGD_CHECK(wk == 1 || wk == 2 || wk == 4 || wk == 8, -2, "conv_gemm (16-wide): K-split must be 1, 2, 4 or 8");
+    prepare16_wk(L, wk, gx, gy, gz, dual);
 }
 
 void launch_pack_weights16(hipStream_t st, const PackArgs& a) {

@@ -1,7 +1,8 @@
 // STFT -> mel front-end.  The reference delegates this to the third-party
 // librosa.feature.melspectrogram (mug/util.py:138-143; librosa is unpinned and not vendored);
 // this follows librosa's published algorithm (0.10.x defaults, named once in oracle/host.py: LIBROSA_TARGET): centred frames
-// with zero padding n_fft/2, periodic Hann, power spectrum, Slaney mel filterbank (area-normalised), then the reference's
+// with zero padding n_fft/2 (pad_mode='constant', the 0.10 default; 'reflect' -- the default of librosa <= 0.9, which the unpinned
+// requirements.txt:8 equally admits -- behind Ctx::mel_reflect / mugd_set_mel_pad_mode), periodic Hann, power spectrum, Slaney mel filterbank (area-normalised), then the reference's
 // log1p and fp16 rounding -- and librosa's PRECISION path: the window product and the FFT run in float64 (numpy's rfft of a
 // float64 frame), the spectrum is cast to complex64, and the power is |X|^2 formed in float32 as abs(X)**2.
 //
@@ -33,7 +34,7 @@ constexpr int NFFT_MAX = 1024;
 // float32 |X|^2 follow it.
 template <int NMAX>
 __global__ __launch_bounds__(256) void stft_power_kernel(const float* pcm, long long n, int n_fft, int log2n, int hop,
-                                                         int frames, int kpad, float* P) {
+                                                         int frames, int kpad, float* P, int reflect) {
     __shared__ double2 zb[4][NMAX];                        // per wave: the pair's complex buffer
     __shared__ double2 tw[NMAX / 2];                       // {cos, -sin}(2 pi i / N)
     __shared__ float tile[(NMAX / 2 + 1) * (FB + 1)];
@@ -54,7 +55,11 @@ __global__ __launch_bounds__(256) void stft_power_kernel(const float* pcm, long 
         for (int i = lane; i < n_fft; i += 64) {
             const double c = i < half ? tw[i].x : -tw[i - half].x;
             const double w = 0.5 - 0.5 * c;                // periodic Hann in float64 (scipy get_window) x float32 sample
-            const long long sa = (long long)fa * hop + i - half, sb = sa + hop;
+            long long sa = (long long)fa * hop + i - half, sb = sa + hop;
+            if (reflect) {                                 // numpy.pad(mode='reflect'): the edge sample is not repeated; n > n_fft / 2 (host check)
+                sa = sa < 0 ? -sa : sa; sa = sa >= n ? 2 * (n - 1) - sa : sa;
+                sb = sb < 0 ? -sb : sb; sb = sb >= n ? 2 * (n - 1) - sb : sb;
+            }
             double va = 0.0, vb = 0.0;
             if (fa < frames && sa >= 0 && sa < n) va = (double)pcm[sa] * w;
             if (fb < frames && sb >= 0 && sb < n) vb = (double)pcm[sb] * w;
@@ -161,6 +166,8 @@ void log_mel(Ctx* ctx, const float* pcm, long long n, int sr, int n_fft, int hop
     const long long frames_ll = 1 + n / hop;
     MUGD_CHECK(frames_ll < (1ll << 30), -2, "log_mel: audio too long");
     const int frames = (int)frames_ll;
+    const int reflect = ctx->mel_reflect ? 1 : 0;
+    MUGD_CHECK(!reflect || n > n_fft / 2, -2, "log_mel: reflect padding needs more than n_fft / 2 samples (librosa raises the same)");
 
     MelPlan plan;
     {
@@ -199,8 +206,8 @@ void log_mel(Ctx* ctx, const float* pcm, long long n, int sr, int n_fft, int hop
     }
     float* P = ctx->scratch;
     float* M = P + (((size_t)kpad * frames + 63) / 64) * 64;
-    if (n_fft <= 512) hipLaunchKernelGGL(stft_power_kernel<512>, dim3(cdiv(frames, FB)), dim3(256), 0, st, pcm, n, n_fft, log2n, hop, frames, kpad, P);
-    else hipLaunchKernelGGL(stft_power_kernel<NFFT_MAX>, dim3(cdiv(frames, FB)), dim3(256), 0, st, pcm, n, n_fft, log2n, hop, frames, kpad, P);
+    if (n_fft <= 512) hipLaunchKernelGGL(stft_power_kernel<512>, dim3(cdiv(frames, FB)), dim3(256), 0, st, pcm, n, n_fft, log2n, hop, frames, kpad, P, reflect);
+    else hipLaunchKernelGGL(stft_power_kernel<NFFT_MAX>, dim3(cdiv(frames, FB)), dim3(256), 0, st, pcm, n, n_fft, log2n, hop, frames, kpad, P, reflect);
     ConvArgs a{};
     a.nseg = 1;
     a.seg[0] = ConvSeg{P, kpad, frames, 1, 1, 1, 0, 0, 0, 0, 0};

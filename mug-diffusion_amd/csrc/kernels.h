@@ -51,6 +51,8 @@ struct ConvSeg {
     int xf_coff;          // xf=4: first channel of this segment inside the normalised concat
     float sx0;            // H3 domain (conv_body.h): xf != 0 -- the STATIC power-of-two scale of this segment's transformed samples, from the host's bound
                           // |v| <= max|gamma| sqrt(n) + max|beta| (h3_static_scale below); 0 is read as 1.  Raw segments (xf == 0) are scaled dynamically
+    unsigned mbmod;       // fastdiv multiplier of bmod (conv_set_grid fills it): b % bmod is one s_mul_hi instead of a 25-instruction division
+                          // sequence per segment and per GroupNorm row request (round 6: the ISA of the prologue)
 };
 // the static scale of a normalised operand: the largest power of two that keeps bound * scale <= 2^15
 inline float h3_static_scale(float gmax, float bmax, double n) {
@@ -62,7 +64,7 @@ inline float h3_static_scale(float gmax, float bmax, double n) {
     int e = 0;
     std::frexp(32768.0 / bound, &e);             // 32768 / bound = f 2^e, f in [0.5, 1): 2^(e-1) <= 32768 / bound
     e -= 1;
-    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    e = e < -120 ? -120 : (e > 120 ? 120 : e);     // (a rise is bounded again in the kernel: never 2^64 above the smallest scale the accumulators have seen)
     return std::ldexp(1.0f, e);
 }
 
@@ -108,6 +110,8 @@ struct ConvArgs {
     const unsigned* wmax;    // H3 weights (conv_body.h): device word holding the bits of max |w| over the whole packed set -- the pack kernels
                              // stored w * h3_wscale(*wmax) (an exact power of two), the epilogue multiplies it back out.  null: winv below
     float winv;              // ... or, when the host knows the word (sets packed at network-compile time), 1 / h3_wscale by value; 0: unit scale
+    int h3_careful;          // 1: the raw operands of this launch are known to sit far from O(1) (gradients): the plain fast-window kernels skip their
+                             // fixed-scale pass and run the data-following (careful) mode directly (conv_body.h: "The DOMAIN of H3")
     unsigned long long* tl;  // development build (-DMUGD_TL) only: per-wave phase records [blocks][waves][TL_WORDS]; null otherwise
 #ifdef MUGD_KARG_PAD
     char karg_pad_[MUGD_KARG_PAD];      // development A/B arm: how much a launch costs per extra byte of its argument block
@@ -153,19 +157,30 @@ inline unsigned conv_fastdiv_mul(unsigned d) { return d <= 1 ? 0u : (unsigned)((
 inline void conv_set_grid(ConvArgs& a, int gx, int gy, int gz) {
     a.gx = gx; a.gy = gy; a.gz = gz;
     a.mgx = conv_fastdiv_mul((unsigned)gx); a.mgy = conv_fastdiv_mul((unsigned)gy); a.mgxz = conv_fastdiv_mul((unsigned)(gx * gz));
+    for (int i = 0; i < CONV_MAXSEG; ++i) a.seg[i].mbmod = a.seg[i].bmod > 0 ? conv_fastdiv_mul((unsigned)a.seg[i].bmod) : 0u;
 }
-void launch_conv_gemm(hipStream_t st, const ConvArgs& a);        // 32 x 32 tiles
+// A launch in two halves (k_conv.hip): conv_prepare() -- validation, development knobs, the kernel form (tile width ConvArgs::tn, K-split /
+// M-split, XCD order), K-slice boundaries, grid decode -- once per compiled program op; conv_launch() -- the per-step hipLaunchKernel.
+struct ConvLaunch {
+    ConvArgs a;              // the final argument block
+    const void* kern;        // void (*)(const ConvArgs): the chosen conv_gemm_kernel instantiation
+    unsigned grid; int block;
+    int tn;                  // tile width of the chosen form (development build: the phase records' geometry)
+};
+typedef void (*ConvKernel)(const ConvArgs);
+// kernel addresses of the conv_gemm instantiations that live outside k_conv.hip (conv_kernel.h: three translation units)
+const void* conv_kernel16(int wk, bool dual, bool w16);                 // k_conv16.hip: 32 x 16 tiles
+const void* conv_kernel_wide(int nw, bool dual, int ks);                // k_convw.hip: M-split forms (null: no such form)
+const void* conv_kernel32_w16(int wk, bool dual);                       // k_convw.hip: 32 x 32 tiles, bfloat16 weights
+ConvLaunch conv_prepare(const ConvArgs& a);
+void conv_launch(hipStream_t st, const ConvLaunch& L);
+inline void launch_conv(hipStream_t st, const ConvArgs& a) { conv_launch(st, conv_prepare(a)); }      // stand-alone operators / one-off launches
+void launch_conv_gemm(hipStream_t st, const ConvArgs& a);        // 32 x 32 tiles, whatever ConvArgs::tn says (k_mel.hip)
 int conv_pick_wk(const ConvArgs& a);
-void launch_conv_gemm16(hipStream_t st, const ConvArgs& a);      // 32 x 16 tiles (the same kernel template with TN = 16)
 bool conv16_supported(const ConvArgs& a);
 bool conv_w16_supported(const ConvArgs& a);                      // bf16 weight variant exists for this launch shape (needs tn)
 int conv_pick_tn(const ConvArgs& a);                             // needs seg[], nseg, epi, B, Mout, Tout
 int conv_pick_order(const ConvArgs& a);                          // ConvArgs::xcd_cols for this launch (needs tn)
-inline void launch_conv(hipStream_t st, const ConvArgs& a0) {
-    ConvArgs a = a0;
-    a.xcd_cols = conv_pick_order(a);
-    if (a.tn == 16) launch_conv_gemm16(st, a); else launch_conv_gemm(st, a);
-}
 
 // packs rows [row_off, row_off+rows) x channels [0, C) of one K-segment.
 struct PackArgs {

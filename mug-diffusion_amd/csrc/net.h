@@ -11,7 +11,6 @@
 #include <vector>
 
 #include "kernels.h"
-#include "xexec.h"
 
 struct Tensor {
     float* p = nullptr;
@@ -45,13 +44,12 @@ struct Ctx {
     bool fast_act = true;       // SiLU of the fused GroupNorm path on v_exp_f32 / v_rcp_f32 (MUGD_EXACT_SILU=1: expf + IEEE divide)
     bool fuse_stats = true;     // false (MUGD_NO_STATS_FUSION=1): always run the GroupNorm / LayerNorm statistics kernels
     bool weights_bf16 = false;  // mugd_set_weight_precision / MUGD_WEIGHTS_BF16=1: packed conv / linear weights in bfloat16 (reduced-precision mode)
+    bool mel_reflect = false;   // mugd_set_mel_pad_mode / MUGD_MEL_PAD=reflect: centred STFT frames padded by reflection (librosa <= 0.9) instead of zeros (>= 0.10)
     bool s4_symmetric = false;  // mugd_set_s4_symmetric / MUGD_S4_SYMMETRIC=1: Cauchy sum over both conjugate halves (kernels.h: S4GenArgs)
     bool fold_proj_out = true;  // false (MUGD_NO_PROJ_FOLD=1): ff.net.2 and the transformer's proj_out as two launches instead of one with pre-multiplied weights
     bool fold_xattn = true;     // false (MUGD_NO_XATTN_FOLD=1): cross-attention as to_q -> attention kernel -> to_out instead of the folded two-GEMM form
     bool train_bf16 = false;    // mugd_train_set_precision: the training GEMMs (conv / Linear forward, data and weight gradients) on the bf16 matrix cores
     bool fuse_norm = true;      // false (MUGD_UNFUSED_NORM=1): materialise GroupNorm / LayerNorm outputs with the stand-alone kernels (A/B + debugging)
-    int xexec = 0;              // mugd_set_exec_mode / MUGD_XEXEC: 1 = U-Net programs whose batch is a multiple of 8 run their per-step op chain inside the
-                                // XCD-resident persistent executor (xexec.h) instead of one launch per op; 0 = one launch per op
 };
 
 class Arena {
@@ -59,10 +57,7 @@ public:
     void begin(bool dry) { dry_ = dry; top_ = 0; if (dry) peak_ = 0; }
     float* alloc(size_t nfloats);
     size_t mark() const { return top_; }
-    void release(size_t m) { if (!monotonic) top_ = m; }
-    // true: release() keeps the block -- every buffer of a program gets an address of its own (single assignment inside one pass over
-    // the program: what lets the executor's consumers use plain loads, xexec.h)
-    bool monotonic = false;
+    void release(size_t m) { top_ = m; }
     size_t peak() const { return peak_; }
     void reserve(size_t bytes);
     void free_all();
@@ -117,7 +112,6 @@ struct Op {
     int kind;
     double flops;     // algorithmic 2*MAC count of the contractions (0 for bandwidth-class ops)
     std::string label;
-    int xi = -1;      // index into Net::xops when the op can run inside the XCD-resident executor
 };
 
 struct ProfileRow { double ms = 0, flops = 0; long long launches = 0; };
@@ -130,6 +124,9 @@ public:
     virtual void invalidate();       // parameters changed: drop packed weights / baked kernels / programs
     // runs the currently compiled program once, eagerly, with a HIP event pair around every launch
     void profile_program(ProfileRow* rows /*[OP_KINDS]*/);
+    // host time to ENQUEUE the compiled program (no event pairs, no synchronisation inside): `passes` back-to-back passes from an idle stream,
+    // wall clock around the enqueue loop only -- what a step costs the launching thread
+    void host_enqueue(int passes, double* us_per_pass, int64_t* launches_per_pass);
 #ifdef MUGD_TL
     void timeline_program(const char* path, const char* raw_path, int raw_op);     // development build: per-launch phase table (common.h)
 #endif
@@ -161,23 +158,6 @@ protected:
         if (!dry) (to_pre ? pre_ops : to_emb ? emb_ops : ops).push_back(Op{std::move(f), kind, flops, label});
     }
     void run_ops(hipStream_t st);
-    // ---- XCD-resident executor (xexec.h): ops that can run inside it carry an entry of `xops`; runs of consecutive such ops become ONE launch
-    bool xmode = false;                           // the program being built / held is laid out for the executor (monotonic arena, 32-wide tiles)
-    std::vector<XOp> xops;
-    XOp* xops_dev = nullptr;
-    size_t xops_cap = 0;                          // entries the device table holds
-    XSync* xsync = nullptr;
-    unsigned xbarriers = 0;                       // XCD barriers executed so far on xsync
-    struct XRun { int op_lo, op_hi; int x_lo, x_hi; };     // ops [op_lo, op_hi): x_lo < x_hi -> executor launch over xops [x_lo, x_hi), else plain launches
-    std::vector<XRun> xruns;
-    void emit_x(std::function<void(hipStream_t)> f, int kind, double flops, const std::string& label, const XOp& x) {
-        if (dry) return;
-        if (to_pre || to_emb || !xmode) { emit(std::move(f), kind, flops, label); return; }
-        ops.push_back(Op{std::move(f), kind, flops, label, (int)xops.size()});
-        xops.push_back(x);
-    }
-    void finish_xprogram();                       // after build(false): upload the table, cut the program into runs
-    void check_xexec();                           // throws if an executor launch gave up (synchronises)
     void run_pre_ops(hipStream_t st) { for (auto& o : pre_ops) o.fn(st); }
 
     // layer emitters

@@ -1,6 +1,7 @@
 #include "net.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 
@@ -78,47 +79,20 @@ void Net::profile_program(ProfileRow* rows) {
         }
     }
     for (auto& e : ev) hipEventDestroy(e);
-    // executor mode: the same program once more as persistent launches, with the per-phase clock stamps of every XCD (xexec.h)
-    if (xmode && !xruns.empty()) {
-        const char* path = getenv("MUGD_XEXEC_CSV");
-        for (const XRun& r : xruns) {
-            if (r.x_hi <= r.x_lo) { for (int i = r.op_lo; i < r.op_hi; ++i) ops[i].fn(st); continue; }
-            const int n = r.x_hi - r.x_lo;
-            const bool twice = getenv("MUGD_XEXEC_TWICE") != nullptr;       // development experiment, see xexec.hip (results invalid)
-            unsigned long long* tl = nullptr;
-            HIP_CHECK(hipMalloc((void**)&tl, (size_t)(2 * n + 1) * 8 * sizeof(unsigned long long)));
-            HIP_CHECK(hipMemsetAsync(tl, 0, (size_t)(2 * n + 1) * 8 * sizeof(unsigned long long), st));
-            launch_xexec(st, xops_dev, r.x_lo, r.x_hi, xsync, xbarriers, Bn | (twice ? 0x10000 : 0), tl);
-            xbarriers += (unsigned)(n - 1) + (twice ? (unsigned)n : 0u);
-            std::vector<unsigned long long> h((size_t)(2 * n + 1) * 8);
-            HIP_CHECK(hipStreamSynchronize(st));
-            HIP_CHECK(hipMemcpy(h.data(), tl, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-            hipFree(tl);
-            if (FILE* f = path ? fopen(path, "a") : nullptr) {
-                fprintf(f, "idx,kind,wk,variant,items,us_max_xcd,us_min_xcd,%slabel\n", twice ? "us_first_pass,us_second_pass_hot," : "");
-                for (int k = 0; k < n; ++k) {
-                    double mx = 0, mn = 1e30, p1 = 0, p2 = 0;
-                    for (int x = 0; x < 8; ++x) {
-                        const double us = (double)(h[(size_t)(k + 1) * 8 + x] - h[(size_t)k * 8 + x]) * 0.01;
-                        mx = std::max(mx, us); mn = std::min(mn, us);
-                        if (twice) {
-                            p1 = std::max(p1, (double)(h[(size_t)(n + 1 + k) * 8 + x] - h[(size_t)k * 8 + x]) * 0.01);
-                            p2 = std::max(p2, (double)(h[(size_t)(k + 1) * 8 + x] - h[(size_t)(n + 1 + k) * 8 + x]) * 0.01);
-                        }
-                    }
-                    const XOp& o = xops[r.x_lo + k];
-                    fprintf(f, "%d,%s,%d,%d,%d,%.2f,%.2f,", r.op_lo + k, op_kind_name(ops[r.op_lo + k].kind), o.wk, o.variant, o.items, mx, mn);
-                    if (twice) fprintf(f, "%.2f,%.2f,", p1, p2);
-                    fprintf(f, "%s\n", ops[r.op_lo + k].label.c_str());
-                }
-                double tot = 0;
-                for (int x = 0; x < 8; ++x) tot = std::max(tot, (double)(h[(size_t)n * 8 + x] - h[x]) * 0.01);
-                fprintf(f, "-1,total,0,0,0,%.2f,0,executor launch over %d ops\n", tot, n);
-                fclose(f);
-            }
-        }
-        check_xexec();
-    }
+}
+
+void Net::host_enqueue(int passes, double* us_per_pass, int64_t* launches_per_pass) {
+    hipStream_t st = ctx->stream;
+    MUGD_CHECK(!ops.empty(), -2, "host_enqueue: no compiled program (run the network once first)");
+    HIP_CHECK(hipStreamSynchronize(st));
+    run_ops(st);                                       // (first pass after a synchronisation: module / queue warm-up outside the clock)
+    HIP_CHECK(hipStreamSynchronize(st));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int p = 0; p < passes; ++p) run_ops(st);
+    const auto t1 = std::chrono::steady_clock::now();
+    HIP_CHECK(hipStreamSynchronize(st));
+    *us_per_pass = std::chrono::duration<double, std::micro>(t1 - t0).count() / passes;
+    *launches_per_pass = (int64_t)ops.size();
 }
 
 TlSink g_tl;
@@ -170,13 +144,17 @@ void Net::timeline_program(const char* path, const char* raw_path, int raw_op) {
                 ph[3].push_back((double)(r[4] - r[3])); ph[4].push_back((double)(r[5] - r[4])); ph[5].push_back((double)(r[6] - r[5]));
                 ph[6].push_back((double)(r[6] - r[0]));
                 chunks.push_back((double)r[10]);
+                // round 6 order of a wave's prologue: statistics requested (11) -> side operands requested (12) -> the first segment's operand
+                // ring issued (14) -> sums arrived (13) -> reduced + barrier (1) -> chunk 0's window arrived (15) -> parked (2)
+                auto dpos = [](unsigned long long a, unsigned long long b) { return a > b ? (double)(a - b) : 0.0; };
                 if (r[11] && r[12]) {
-                    const unsigned long long t13 = r[13] ? r[13] : r[12];
-                    su[0].push_back((double)(r[11] - r[0])); su[1].push_back((double)(r[12] - r[11]));
-                    su[2].push_back((double)(t13 - r[12])); su[3].push_back((double)(r[1] - t13));
+                    const unsigned long long t14 = r[14] ? r[14] : r[12];
+                    const unsigned long long t13 = r[13] ? r[13] : t14;
+                    su[0].push_back(dpos(r[11], r[0])); su[1].push_back(dpos(r[12], r[11]));
+                    su[2].push_back(dpos(t13, t14)); su[3].push_back(dpos(r[1], t13));          // wait for the sums BEHIND the ring issue; reduce + barrier
                 }
-                if (r[14] && r[15] && r[2]) {      // "first chunk parked" in detail: ring issued / chunk 0's window arrived / transformed + parked
-                    fd[0].push_back((double)(r[14] - r[1])); fd[1].push_back((double)(r[15] - r[14])); fd[2].push_back((double)(r[2] - r[15]));
+                if (r[14] && r[15] && r[2]) {      // ring issued (from the side operands) / chunk 0's window arrived (from statistics done) / transformed + parked
+                    fd[0].push_back(dpos(r[14], r[12])); fd[1].push_back(dpos(r[15], r[1])); fd[2].push_back(dpos(r[2], r[15]));
                 }
                 if (r[8] > r[7]) mhz.push_back((double)(r[6] - r[0]) / ((double)(r[8] - r[7]) * 10.0) * 1e3);
                 if (fr && ((int)i == raw_op || raw_op == -1 || (raw_label && ops[i].label.find(raw_label) != std::string::npos)))
@@ -211,63 +189,10 @@ void Net::invalidate() {
     ops.clear();
     pre_ops.clear();
     emb_ops.clear();
-    xops.clear(); xruns.clear();
-    xops_dev = nullptr; xops_cap = 0; xsync = nullptr; xbarriers = 0;       // freed with `owned`
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// The program as launches: one per op, or -- executor mode -- one persistent launch per run of consecutive executor-capable ops
-// ---------------------------------------------------------------------------------------------------------------------------
 void Net::run_ops(hipStream_t st) {
-    if (!xmode || xruns.empty()) {
-        for (auto& o : ops) o.fn(st);
-        return;
-    }
-    for (const XRun& r : xruns) {
-        if (r.x_hi > r.x_lo) {
-            launch_xexec(st, xops_dev, r.x_lo, r.x_hi, xsync, xbarriers, Bn);
-            xbarriers += (unsigned)(r.x_hi - r.x_lo - 1);
-        } else {
-            for (int i = r.op_lo; i < r.op_hi; ++i) ops[i].fn(st);
-        }
-    }
-}
-
-void Net::finish_xprogram() {
-    xruns.clear();
-    if (!xmode || xops.empty()) return;
-    if (!xsync) xsync = reinterpret_cast<XSync*>(dev_alloc(sizeof(XSync) / 4 + 64, true));
-    if (xops.size() > xops_cap) {                                  // one table, grown when a re-keyed program needs more entries (a program's (batch,
-        xops_cap = xops.size() + xops.size() / 4;                  // length) key may alternate: the previous table is reused, not leaked)
-        xops_dev = reinterpret_cast<XOp*>(dev_alloc(xops_cap * sizeof(XOp) / 4 + 64));
-    }
-    HIP_CHECK(hipMemcpyAsync(xops_dev, xops.data(), xops.size() * sizeof(XOp), hipMemcpyHostToDevice, ctx->stream));
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));                  // `xops` may be rebuilt before the copy would otherwise have run
-    size_t i = 0;
-    while (i < ops.size()) {
-        size_t j = i;
-        if (ops[i].xi >= 0) {
-            while (j + 1 < ops.size() && ops[j + 1].xi == ops[j].xi + 1) ++j;
-            xruns.push_back(XRun{(int)i, (int)j + 1, ops[i].xi, ops[j].xi + 1});
-        } else {
-            while (j + 1 < ops.size() && ops[j + 1].xi < 0) ++j;
-            xruns.push_back(XRun{(int)i, (int)j + 1, 0, 0});
-        }
-        i = j + 1;
-    }
-}
-
-void Net::check_xexec() {
-    if (!xmode || !xsync) return;
-    unsigned err = 0;
-    HIP_CHECK(hipMemcpyAsync(&err, &xsync->err[0], sizeof(err), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (err) {
-        HIP_CHECK(hipMemsetAsync(xsync, 0, sizeof(XSync), ctx->stream));
-        xbarriers = 0;
-        MUGD_CHECK(false, -7, "XCD-resident executor: a workgroup gave up at a phase barrier (workgroups not placed 32 per XCD, or the device is shared); "
-                              "results of this call are invalid -- run with mugd_set_exec_mode(ctx, 0)");
-    }
+    for (auto& o : ops) o.fn(st);
 }
 
 const Param& Net::P(const std::string& n) const {
@@ -622,7 +547,7 @@ Tensor Net::conv(const ConvSpec& s) {
     a.gn_nseg = s.gn.nseg; a.gn_groups = s.gn.groups; a.gn_cg = s.gn.cg; a.gn_count = s.gn.count; a.gn_eps = s.gn.eps;
     a.B = Bn; a.Mrows = s.Mrows; a.Mout = s.Mout; a.Tout = s.Tout; a.epi = s.epi;
     a.wk = ctx->force_wk;
-    a.tn = (xmode && !to_pre) ? 32 : ctx->force_tn == 16 ? (conv16_supported(a) ? 16 : 32) : ctx->force_tn == 32 ? 32 : conv_pick_tn(a);      // the executor's tiles are 32 wide
+    a.tn = ctx->force_tn == 16 ? (conv16_supported(a) ? 16 : 32) : ctx->force_tn == 32 ? 32 : conv_pick_tn(a);
     a.xs_rel = s.xs_rel; a.xs_cemb = s.xs_cemb; a.xs_heads = s.xs_heads; a.xs_pmax = s.xs_pmax; a.xs_ntok = s.xs_ntok; a.xs_scale = s.xs_scale;
     a.w16 = (ctx->weights_bf16 && !s.ext_plain && conv_w16_supported(a)) ? 1 : 0;
     const PackedW& pw = s.ext_plain ? get_packed_ext(s, a.tn) : get_packed(s, a.tn, a.w16 != 0);       // the tile width decides the weight fragment order
@@ -660,10 +585,11 @@ Tensor Net::conv(const ConvSpec& s) {
                               " nseg=" + std::to_string(a.nseg) + " tn=" + std::to_string(a.tn);
     const int okind = (s.epi == EPI_GLU || s.epi == EPI_GEGLU) ? OP_CONV_GATED : OP_CONV;
     const double oflops = 2.0 * s.Mrows * kdim * s.Tout * Bn;
-    if (xmode && !dry && !to_pre && !to_emb && !rowstat_pass && xexec_conv_supported(a))
-        emit_x([a](hipStream_t st) { launch_conv(st, a); }, okind, oflops, label, xexec_make_conv(a, Bn));
-    else
-        emit([a](hipStream_t st) { launch_conv(st, a); }, okind, oflops, label);
+    if (!dry) {
+        // validated, its kernel form chosen and its K-slices / grid decode filled in NOW; a step only launches (kernels.h: ConvLaunch)
+        const ConvLaunch L = conv_prepare(a);
+        emit([L](hipStream_t st) { conv_launch(st, L); }, okind, oflops, label);
+    }
     if (rowstat_pass) {
         const float* yp = y.p; double* rp = y.rowstat; const int rows = Bn * s.Mout, T = s.Tout;
         emit([=](hipStream_t st) { launch_row_sums_add(st, yp, rp, rows, T); }, OP_SMALL, 0, s.key + " row sums");
@@ -701,10 +627,7 @@ Tensor Net::attention(const std::string& prefix, const Tensor& q, const Tensor& 
     a.B = Bn; a.heads = heads; a.d = C / heads; a.Tq = q.T; a.Tk = k.T;
     a.scale = 1.0f / sqrtf((float)a.d);
     const std::string label = prefix + " d=" + std::to_string(a.d) + " Tq=" + std::to_string(q.T) + " Tk=" + std::to_string(k.T);
-    if (xmode && !dry && xexec_attn_supported(a))
-        emit_x([a](hipStream_t st) { launch_attention(st, a); }, OP_ATTENTION, 4.0 * Bn * C * (double)q.T * k.T, label, xexec_make_attn(a));
-    else
-        emit([a](hipStream_t st) { launch_attention(st, a); }, OP_ATTENTION, 4.0 * Bn * C * (double)q.T * k.T, label);
+    emit([a](hipStream_t st) { launch_attention(st, a); }, OP_ATTENTION, 4.0 * Bn * C * (double)q.T * k.T, label);
     return o;
 }
 
@@ -916,10 +839,7 @@ Tensor Net::s4_layer(const std::string& prefix, const Tensor& x) {
     S4ConvArgs ca{u.p, k, PF(prefix + ".s4_model.D"), y.p, Bn, H, L, aff,
                   in_kernel_gn ? PF(prefix + ".norm.weight") : nullptr, in_kernel_gn ? PF(prefix + ".norm.bias") : nullptr, 32, 1e-6f,
                   (in_kernel_gn && ctx->fuse_stats && x.bmod == 0) ? x.rowstat : nullptr};
-    if (xmode && !dry && in_kernel_gn && ca.rowstat && xexec_s4_supported(ca))
-        emit_x([ca](hipStream_t st) { launch_s4_conv(st, ca); }, OP_S4_CONV, 0, prefix + " H=" + std::to_string(H) + " L=" + std::to_string(L), xexec_make_s4(ca));
-    else
-        emit([ca](hipStream_t st) { launch_s4_conv(st, ca); }, OP_S4_CONV, 0, prefix + " H=" + std::to_string(H) + " L=" + std::to_string(L));
+    emit([ca](hipStream_t st) { launch_s4_conv(st, ca); }, OP_S4_CONV, 0, prefix + " H=" + std::to_string(H) + " L=" + std::to_string(L));
     ConvSpec gl;
     gl.key = prefix + ".s4_model.output_linear.0";
     gl.in.push_back(ConvIn{y});
@@ -1014,14 +934,10 @@ Tensor UNet::resblock(const std::string& prefix, const std::vector<Tensor>& segs
 
 void UNet::build(bool dry_run) {
     dry = dry_run;
-    // executor mode: batch rows map to XCDs (b % 8), so the batch must fill them; the workspace becomes single-assignment (xexec.h)
-    xmode = ctx->xexec != 0 && key.B % 8 == 0 && xexec_device_ok(ctx->device);
-    arena.monotonic = xmode;
     arena.begin(dry_run);
     ops.clear();
     pre_ops.clear();
     emb_ops.clear();
-    xops.clear();
     begin_rowstat();
     Bn = key.B;
     const int mc = cfg.model_channels, nl = (int)cfg.channel_mult.size(), z = key.z;
@@ -1157,8 +1073,6 @@ void UNet::drop_programs() {
     ops.clear();
     pre_ops.clear();
     emb_ops.clear();
-    xops.clear();
-    xruns.clear();
 }
 
 void UNet::ensure(int B, int z, int ntok, int bmod) {
@@ -1171,7 +1085,6 @@ void UNet::ensure(int B, int z, int ntok, int bmod) {
     build(true);
     arena.reserve(arena.peak());
     build(false);
-    finish_xprogram();
     built = true;
 }
 
@@ -1194,7 +1107,6 @@ void UNet::forward(const float* x, const long long* t, const float* context, int
     for (auto& o : emb_ops) o.fn(st);
     run_ops(st);
     HIP_CHECK(hipMemcpyAsync(eps, out_eps.p, (size_t)B * out_eps.C * z * sizeof(float), hipMemcpyDeviceToDevice, st));
-    check_xexec();
 }
 
 DdimStepArgs UNet::step_args(bool cfg_on, float scale, bool with_noise, bool with_pred, bool with_first, int nstate, int S, int mode) const {
@@ -1278,7 +1190,7 @@ void UNet::sample(float* x, const float* c, const float* uc, int n_tok, const fl
     }
     const bool wn = noise != nullptr, wp = pred_x0 != nullptr, wf = first != nullptr;
     launch_ddim_step(st, step_args(cfg_on, scale, wn, wp, wf, nstate, S, 0));      // x_T -> U-Net input, embedding rows of step 0
-    if (ctx->use_graph && !xmode) {             // executor launches carry a per-launch barrier base: not replayable
+    if (ctx->use_graph) {
         const int per_graph = ctx->use_graph == 2 ? std::max(S, 1) : 1;        // steps captured into one graph
         if (graph && (graph_steps != per_graph || graph_cfg != cfg_on || graph_noise != wn || graph_pred != wp || graph_first != wf || graph_scale != scale)) {
             HIP_CHECK(hipStreamSynchronize(st));
@@ -1301,7 +1213,6 @@ void UNet::sample(float* x, const float* c, const float* uc, int n_tok, const fl
     HIP_CHECK(hipMemcpyAsync(x, x_state, (size_t)nstate * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (wp) HIP_CHECK(hipMemcpyAsync(pred_x0, pred_dev, (size_t)nstate * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (wf) HIP_CHECK(hipMemcpyAsync(first, first_dev, 2 * (size_t)nstate * sizeof(float), hipMemcpyDeviceToDevice, st));
-    check_xexec();                 // executor mode only: synchronises and fails loudly if a persistent launch bailed out
 }
 
 // =======================================================================================

@@ -244,6 +244,7 @@ void run_conv_ex(Ctx& c, Scratch& sc, const float* x, const float* w, bool trans
     a.wpk = wpk; a.w_mt_stride = mts; a.bias = bias; a.rowadd = rowadd; a.rowadd_stride = rowadd_stride; a.resid = resid; a.y = y;
     a.B = B; a.Mrows = M; a.Mout = M; a.Tout = Tout > 0 ? Tout : T; a.nchunk = C / CONV_CK; a.epi = EPI_NONE;
     a.tn = conv_pick_tn(a);
+    a.h3_careful = transposed ? 1 : 0;        // a data gradient's operand is a gradient (1e-4 ... 1e-12 on this model): the fixed 2^8 scale of the fast pass never fits
     unsigned* wmax = reinterpret_cast<unsigned*>(sc.get(1, false, st));
     a.wmax = wmax;
     pack_weights_scaled(st, PackArgs{wpk, mts, 0, C, taps, w, C * taps, 0, M, 0, 0, wmax}, a.tn);

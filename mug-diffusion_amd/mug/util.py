@@ -160,21 +160,23 @@ def _read_wav(path):
     return y[: n * ch].reshape(n, ch), int(rate)
 
 
-def pcm_to_log_mel(y, n_mels, audio_hop_length, n_fft, sr):
+def pcm_to_log_mel(y, n_mels, audio_hop_length, n_fft, sr, pad_mode=None):
     """The arithmetic of load_audio_without_cache after decoding (mug/util.py:138-143), on the GPU:
     log1p(mel power spectrogram) rounded to float16.  Returns a numpy float16 (n_mels, frames) array
-    like the reference."""
+    like the reference.  pad_mode: how the centred STFT frames are padded -- 'constant' (librosa >= 0.10) or 'reflect'
+    (librosa <= 0.9; the reference leaves librosa unpinned, requirements.txt:8); None = the library context's setting
+    (Lib.set_mel_pad_mode / MUGD_MEL_PAD, default 'constant')."""
     from mug._native import get_lib
     lib = get_lib()
     pcm = y if isinstance(y, torch.Tensor) else torch.as_tensor(np.asarray(y, dtype=np.float32))
-    mel = lib.log_mel(pcm, sr=sr, n_fft=n_fft, hop=audio_hop_length, n_mels=n_mels)
+    mel = lib.log_mel(pcm, sr=sr, n_fft=n_fft, hop=audio_hop_length, n_mels=n_mels, pad_mode=pad_mode)
     return mel.cpu().numpy().astype(np.float16)
 
 
-def load_audio_without_cache(audio_path, n_mels, audio_hop_length, n_fft, sr, max_duration):
-    """mug/util.py:133-144."""
+def load_audio_without_cache(audio_path, n_mels, audio_hop_length, n_fft, sr, max_duration, pad_mode=None):
+    """mug/util.py:133-144 (pad_mode: see pcm_to_log_mel; the reference's positional signature is unchanged)."""
     y = _decode_audio(audio_path, sr, max_duration)
-    return pcm_to_log_mel(y, n_mels, audio_hop_length, n_fft, sr)
+    return pcm_to_log_mel(y, n_mels, audio_hop_length, n_fft, sr, pad_mode=pad_mode)
 
 
 def load_audio(cache_dir, audio_path, n_mels, audio_hop_length, n_fft, sr, max_duration):

@@ -69,8 +69,26 @@ def compare(lib):
         print("%-16s %6.2f us" % (name, us), flush=True)
 
 
+def forms(lib):
+    """round 6: the M-split geometries (waves per workgroup x K-slices; conv_body.h: MS) against the host's own choice on the tall-M launches of
+    the batch-4 step (gated projections, q/k/v) -- wk = 0x100 | waves << 4 | kslices forces a form where it exists (include/mugd.h)."""
+    cand = [("auto", 0), ("K-split wk2", 2), ("K-split wk4", 4), ("2x1", 0x121), ("4x1", 0x141), ("8x1", 0x181), ("2x2", 0x142), ("4x2", 0x182), ("2x4", 0x184)]
+    print("%-16s %7s | %s" % ("shape", "GFLOP", "  ".join("%11s" % n for n, _ in cand)))
+    for name, B, C, T, M, taps, norm, gated in SWEEP:
+        if not (name.startswith("ff1") or name.startswith("qkv") or name.startswith("s4glu")):
+            continue
+        for Bb in (B, 2 * B):
+            gf = 2.0 * M * C * taps * T * Bb / 1e9
+            copies = max(1, int(300e6 / (M * C * taps * 4)))
+            row = []
+            for _, wk in cand:
+                row.append(min(lib.dev_bench_conv(Bb, C, T, M, taps, norm, bool(gated), wk=wk, tn=32, copies=copies, iters=200) for _ in range(2)))
+            print("%-16s %7.3f | %s" % ("%s B%d" % (name, Bb), gf, "  ".join("%8.2f us" % u for u in row)), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--forms", action="store_true")
     ap.add_argument("--sweep", action="store_true")
     ap.add_argument("--compare", action="store_true")
     ap.add_argument("--pmc", action="store_true")
@@ -84,6 +102,8 @@ def main():
         compare(get_lib())
         return
     lib = get_lib()
+    if a.forms:
+        return forms(lib)
     if a.sweep:
         return sweep(lib)
     if a.pmc:

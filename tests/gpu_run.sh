@@ -19,6 +19,9 @@
 #   instr          executed instructions per wave by class (the r4_pmc_instr_per_wave table)
 #   layers:B       per-launch table of one U-Net / VAE / wave evaluation at batch B (MUGD_PROFILE_CSV)
 #   probe:B        tests/gpu_probe.py at batch B (all pieces of the pipeline)
+#   overlap        tests/gpu_overlap_probe.hip: a chain of dependent conv-shaped launches in order vs released early + epoch polling (round 6)
+#   forms          tests/gpu_convbench.py --forms: M-split geometries vs the host's choice on the tall-M launches (round 6)
+#   hostq          host microseconds to enqueue one U-Net evaluation (mugd_net_host_enqueue), in-tree library
 #   env:K=V        export K=V for the tasks that follow
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out
@@ -35,6 +38,31 @@ for task in "$@"; do
   echo "=== $task"
   case $name in
     env) export "$arg" ;;
+    overlap)
+      ( hipcc --offload-arch=gfx950 -O3 -o /tmp/overlap_probe tests/gpu_overlap_probe.hip && timeout 300 /tmp/overlap_probe 400 ) > ${O}_overlap.txt 2>&1; cat ${O}_overlap.txt ;;
+    forms)
+      timeout 600 python tests/gpu_convbench.py --forms > ${O}_forms.txt 2>&1; cat ${O}_forms.txt ;;
+    hostq)
+      timeout 300 python - > ${O}_hostq.txt 2>&1 <<'PY'
+import os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "mug-diffusion_amd"))
+import torch
+from oracle import cases, weights
+from mug._native import get_lib
+lib = get_lib(); case = cases.FULL
+man = weights.load_manifest(os.path.join(cases.GOLDEN, case["manifest"]))
+for B in (4, 16):
+    sd = weights.set_s4_lengths(weights.make_state_dict(man, 0), case["unet"], 512)
+    u = lib.unet(case["unet"]); u.set_params(sd, "model.unet_model.")
+    x = cases.x_T(1, B, 512).to(lib.device); t = torch.full((B,), 501, dtype=torch.long, device=lib.device)
+    c = cases.context(case, 1, B).to(lib.device); w = [m.to(lib.device) for m in cases.audio_maps(case, 1, 1, 512)]
+    u.forward(x, t, c, w); torch.cuda.synchronize()
+    for rep in range(3):
+        us, n = u.host_enqueue(5)
+        print("B=%d: host enqueue %.1f us per U-Net evaluation, %d ops, %.2f us per launch" % (B, us, n, us / n), flush=True)
+    u.close()
+PY
+      cat ${O}_hostq.txt ;;
     ops)
       ( time timeout 900 python -m pytest tests/test_ops.py -x -q -m gpu -p no:cacheprovider ) > ${O}_ops.log 2>&1; tail -5 ${O}_ops.log ;;
     suite)
@@ -50,7 +78,7 @@ for task in "$@"; do
       for B in $(echo $bs | tr ',' ' '); do for rep in 1 2; do for v in new $(echo $libs | tr ',' ' '); do
         echo "== B=$B lib=$v" >> $L
         if [ $v = new ]; then timeout 300 python tests/gpu_probe.py --B $B --quick 2>&1 | probe_line >> $L
-        else MUGD_LIB_PATH=$PWD/tests/var/$v/libmugd.so timeout 300 python tests/gpu_probe.py --B $B --quick 2>&1 | probe_line >> $L; fi
+        else MUGD_LIB_LENIENT=1 MUGD_LIB_PATH=$PWD/tests/var/$v/libmugd.so timeout 300 python tests/gpu_probe.py --B $B --quick 2>&1 | probe_line >> $L; fi
       done; done; done
       grep -E "^==|ms/step" $L ;;
     wide)
@@ -85,7 +113,7 @@ PY
       for v in new $lb; do
         rm -rf /tmp/ks_${TAG}_$v
         if [ $v = new ]; then (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_${TAG}_$v -- python $OLDPWD/tests/gpu_probe.py --B $B --quick) > ${O}_kstats_$v.log 2>&1
-        else (cd /tmp && MUGD_LIB_PATH=$OLDPWD/tests/var/$v/libmugd.so timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_${TAG}_$v -- python $OLDPWD/tests/gpu_probe.py --B $B --quick) > ${O}_kstats_$v.log 2>&1; fi
+        else (cd /tmp && MUGD_LIB_LENIENT=1 MUGD_LIB_PATH=$OLDPWD/tests/var/$v/libmugd.so timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_${TAG}_$v -- python $OLDPWD/tests/gpu_probe.py --B $B --quick) > ${O}_kstats_$v.log 2>&1; fi
         f=$(find /tmp/ks_${TAG}_$v -name "*kernel_stats.csv" | head -1); cp "$f" ${O}_kstats_${v}_b$B.csv
         grep "ms/step" ${O}_kstats_$v.log
       done ;;
@@ -96,7 +124,7 @@ PY
         for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM" "SQ_WAVES SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM" "SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY"; do
           d=/tmp/spmc_${TAG}_${shape}_${v}_$(echo $set | tr ' ' '_'); rm -rf $d
           if [ $v = new ]; then (cd /tmp && timeout 120 rocprofv3 --pmc $set --output-format csv -d $d -- python $OLDPWD/tests/gpu_convbench.py --pmc --shape $shape) > /dev/null 2>&1
-          else (cd /tmp && MUGD_LIB_PATH=$OLDPWD/tests/var/$v/libmugd.so timeout 120 rocprofv3 --pmc $set --output-format csv -d $d -- python $OLDPWD/tests/gpu_convbench.py --pmc --shape $shape) > /dev/null 2>&1; fi
+          else (cd /tmp && MUGD_LIB_LENIENT=1 MUGD_LIB_PATH=$OLDPWD/tests/var/$v/libmugd.so timeout 120 rocprofv3 --pmc $set --output-format csv -d $d -- python $OLDPWD/tests/gpu_convbench.py --pmc --shape $shape) > /dev/null 2>&1; fi
           echo "== shape $shape lib $v" >> ${O}_shape_pmc.txt
           python tests/pmc_generic_summary.py $d 2>/dev/null | grep -E "^kernel|conv_gemm" >> ${O}_shape_pmc.txt
         done
@@ -105,7 +133,7 @@ PY
     convbench)
       # convbench:LIB1,LIB2: tests/gpu_convbench.py --compare (us per launch of every hot shape) for the in-tree library and each tests/var/LIB
       python tests/gpu_convbench.py --compare > ${O}_cb_new.txt 2>&1
-      for v in $(echo $arg | tr ',' ' '); do MUGD_LIB_PATH=$PWD/tests/var/$v/libmugd.so python tests/gpu_convbench.py --compare > ${O}_cb_$v.txt 2>&1; done
+      for v in $(echo $arg | tr ',' ' '); do MUGD_LIB_LENIENT=1 MUGD_LIB_PATH=$PWD/tests/var/$v/libmugd.so python tests/gpu_convbench.py --compare > ${O}_cb_$v.txt 2>&1; done
       paste ${O}_cb_*.txt | head -40 ;;
     traffic)
       rm -rf /tmp/pmc_$TAG

@@ -37,8 +37,10 @@ def summarise(path, out):
     print("conv launches: %d   median shader clock %.0f MHz" % (n, mhz), file=out)
     print("sum of kernel spans (first wave in -> last wave out, 100 MHz counter): %.1f us" % (span / 1e3), file=out)
     print("sum over launches of the MEDIAN wave's phases, in us at the median clock (share of the median wave's life):", file=out)
-    for k, name in (("setup_med", "entry -> side operands requested (kernarg, index math)"),
-                    ("first_med", "-> first chunk parked (first global loads, statistics reduction)"),
+    # round 6: the first segment's operand ring is issued BEFORE the wave waits for / reduces the statistics, so "setup" now ends with the reduce +
+    # barrier and contains the ring issue; "first" is what is left until chunk 0 is parked
+    for k, name in (("setup_med", "entry -> statistics reduced (kernarg, index math, side + operand requests, sums, barrier)"),
+                    ("first_med", "-> first chunk parked (chunk 0 arrives, transform, LDS store)"),
                     ("loop_med", "-> K loop done"), ("combine_med", "-> K-split combine done (2 barriers + LDS)"),
                     ("store_med", "-> outputs stored"), ("tail_med", "-> row / column statistics done")):
         print("  %-66s %8.1f us  %5.1f%%" % (name, tot[k] / mhz, 100 * tot[k] / tot["total_med"]), file=out)
@@ -46,11 +48,11 @@ def summarise(path, out):
     print("  %-66s %8.1f us" % ("slowest wave total", tot["total_max"] / mhz), file=out)
     if "f_issue" in rows[0]:
         fi, fa, fp = (sum(f(r, k) for r in rows) / mhz for k in ("f_issue", "f_arrive", "f_park"))
-        print("  'first chunk parked' in detail: ring's first loads issued %.1f us, chunk 0's window arrived %.1f us, transformed + parked %.1f us" % (fi, fa, fp), file=out)
+        print("  in detail: side operands requested -> operand ring issued %.1f us; statistics done -> chunk 0's window arrived %.1f us; transformed + parked %.1f us" % (fi, fa, fp), file=out)
     skew = sum(f(r, "start_skew_ns") for r in rows)
     print("sum of start skews (last wave's entry - first wave's entry): %.1f us" % (skew / 1e3), file=out)
     # MFMA-ideal loop time: cycles per chunk if the SIMD's matrix pipe were the only limit
-    print("\nper launch (us at the median clock): span | setup (= statistics requested + epilogue operands requested + wait for the sums + reduce / barrier) first loop combine store tail | cyc/chunk | label", file=out)
+    print("\nper launch (us at the median clock): span | setup (= statistics requested + epilogue operands requested + [ring issue: see 'issue'] + wait for the sums behind it + reduce / barrier) first loop combine store tail | cyc/chunk | label", file=out)
     for r in rows:
         print("%4s tn%-2s wk%s blk%-5s %6.2f | %5.2f (%4.2f %4.2f %4.2f %4.2f) %5.2f %6.2f %5.2f %5.2f %5.2f | %6.0f | %s" % (
             r["op"], r["tn"], r["wk"], r["blocks"], f(r, "span_ns") / 1e3, f(r, "setup_med") / mhz,

@@ -424,103 +424,3 @@ def test_one_handle_follows_changing_lengths_and_batches(lib):
         first[(z, B)] = got
         orc = nets.unet_forward(sd64, case["unet"], x, t, c, [m.repeat(B, 1, 1) for m in w])
         assert (got - orc).abs().max().item() < 2e-4 * max(1.0, orc.abs().max().item())
-
-
-# ---------------------------------------------------------------------------------------------------------------------------
-# the XCD-resident executor (csrc/xexec.hip, mugd_set_exec_mode): the same program as ONE persistent launch per evaluation
-# ---------------------------------------------------------------------------------------------------------------------------
-def _exec_pair(lib, case, z, B, run):
-    """run(net) under exec mode 0 and 1 on fresh networks (the mode is read when a program is compiled)."""
-    sd = state_dict(case, z)
-    out = []
-    for mode in (0, 1):
-        lib.set_exec_mode(mode)
-        try:
-            n = lib.unet(case["unet"])
-            n.set_params(sd, "model.unet_model.")
-            out.append(run(n))
-            n.close()
-        finally:
-            lib.set_exec_mode(0)
-    return out
-
-
-@pytest.mark.parametrize("B", [8, 16])
-def test_executor_unet_forward_equals_per_op_launches_tiny(lib, B):
-    """Tiny model, batch 8 and 16 (one / two batch rows per XCD): the executor's evaluation against the per-op launches of the same
-    library and against the oracle.  Every op type of the U-Net goes through it: plain / gated / cross-attention-score conv_gemm tiles
-    with GroupNorm / LayerNorm operand transforms, stride-2 and upsampling convs, self-attention tiles, S4 rows.  (On the emulated
-    build the phases run as one launch each -- the emulation cannot wait on a barrier between workgroups -- so this checks the work
-    distribution and the tile bodies under virtual workgroups; the barrier itself is a GPU test.)"""
-    case, z = cases.TINY, 32
-    x, t = cases.x_T(3, B, z), torch.from_numpy(np.random.default_rng(4).integers(0, 1000, B))
-    c, w = cases.context(case, 3, B), cases.audio_maps(case, 3, B, z)
-    a, b = _exec_pair(lib, case, z, B, lambda n: n.forward(x, t, c, w).cpu())
-    ref = nets.unet_forward(state_dict(case, z), case["unet"], x, t, c, w)
-    d, s = report("executor tiny B=%d vs oracle" % B, b, ref)
-    assert d < 2e-4 * max(1.0, s)
-    assert same(a, b), (a - b).abs().max().item()
-
-
-def test_executor_ddim_loop_equals_per_op_launches_tiny(lib):
-    """The DDIM loop (2 steps, guidance on: network batch 8 = 2 x 4) through the executor: latent equal to the per-op path's up to
-    the row-sum order, with the audio maps shared by the batch rows (ConvSeg::bmod)."""
-    case, z, S, B = cases.TINY, 32, 2, 4
-    sd = state_dict(case, z)
-    steps = sampler.ddim_step_scalars(sd["alphas_cumprod"].numpy(), S, 0.0)
-    xT = cases.x_T(5, B, z)
-    c, uc = cases.context(case, 5, B), cases.context(case, 6, B)
-    w = cases.audio_maps(case, 5, 1, z)
-
-    def run(n):
-        return n.ddim_sample(xT, c, w, [s["t"] for s in steps], [[s["a_t"], s["a_prev"], s["sigma"], s["sqrt_1m_at"]] for s in steps],
-                             uc=uc, scale=3.0).cpu()
-    a, b = _exec_pair(lib, case, z, B, run)
-    assert same(a, b), (a - b).abs().max().item()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("B", [8, 16])
-def test_executor_full_unet_vs_oracle(gpu_lib, B):
-    """The shipped U-Net at the benchmark length, batch 8 / 16, through the executor -- 228 ops as one persistent kernel with 227
-    XCD-local barriers, plain loads on a single-assignment workspace -- against the oracle and against the per-op path."""
-    case, z = cases.FULL, 512
-    sd = state_dict(case, z)
-    x, t = cases.x_T(11, B, z), torch.from_numpy(np.random.default_rng(12).integers(0, 1000, B))
-    c, w = cases.context(case, 11, B), cases.audio_maps(case, 11, 1, z)
-    threads = torch.get_num_threads()
-    torch.set_num_threads(min(16, threads))
-    try:
-        ref = nets.unet_forward(sd, case["unet"], x, t, c, [m.repeat(B, 1, 1) for m in w])
-    finally:
-        torch.set_num_threads(threads)
-
-    def run(n):
-        outs = [n.forward(x, t, c, w).cpu() for _ in range(3)]          # repeated: the barrier counters run on across launches
-        assert same(outs[0], outs[1]) and same(outs[0], outs[2])
-        return outs[2]
-    a, b = _exec_pair(gpu_lib, case, z, B, run)
-    d, s = report("executor full z=%d B=%d vs oracle" % (z, B), b, ref)
-    assert d < 2e-4 * max(1.0, s)
-    assert same(a, b), (a - b).abs().max().item()
-    _net_cache.clear()
-
-
-@pytest.mark.gpu
-def test_executor_ddim_headline_shape_batch8(gpu_lib):
-    """50 DDIM steps at z = 512, batch 8 (BASELINE configs[2]'s per-GPU shape) through the executor: note grid identical to the per-op
-    path's, latent within the parity tolerance."""
-    case, z, S, B = cases.FULL, 512, 50, 8
-    sd = state_dict(case, z)
-    steps = sampler.ddim_step_scalars(sd["alphas_cumprod"].numpy(), S, 0.0)
-    xT, c, w = cases.x_T(31, B, z), cases.context(case, 31, B), cases.audio_maps(case, 31, 2, z)
-
-    def run(n):
-        return n.ddim_sample(xT, c, w, [s["t"] for s in steps], [[s["a_t"], s["a_prev"], s["sigma"], s["sqrt_1m_at"]] for s in steps]).cpu()
-    a, b = _exec_pair(gpu_lib, case, z, B, run)
-    d, s = report("executor ddim S=50 B=8", b, a)
-    assert d < 1e-3 * max(1.0, s)
-    vae = native(gpu_lib, case, z, "vae")
-    ga, gb = vae.decode(a).cpu() > 0, vae.decode(b).cpu() > 0
-    assert torch.equal(ga, gb), int((ga != gb).sum())
-    _net_cache.clear()

@@ -388,6 +388,81 @@ def test_conv1d_non_finite_operands_propagate(lib):
     assert (got[fin] - ref[fin]).abs().max().item() <= 2e-5
 
 
+def test_conv1d_inf_next_to_a_large_finite_sample(lib):
+    """An inf inside a chunk must not stop the chunk's FINITE samples from being rescaled (round 6; ADVICE r5: the chunk maximum was inf, no
+    scale was derived from it, and a 1e3 next to it overflowed the f16 halves -- 192 non-finite outputs where fp32 has 96): the non-finite
+    outputs are exactly fp32's, the outputs that read the large finite sample but not the inf are exact."""
+    B, C, T, M = 1, 32, 64, 32
+    x, w = rnd(41, B, C, T), rnd(42, M, C, 3, scale=1.0 / math.sqrt(C * 3))
+    x[0, 5, 20] = float("inf")
+    x[0, 6, 27] = 1e3
+    x[0, 9, 50] = -3e4
+    ref = F.conv1d(x, w, None, 1, 1)
+    for wk in (0, 1, 8):
+        lib.set_conv_tiling(wk, 32)
+        try:
+            got = lib.op_conv1d(x, w, pad=1).detach().cpu()
+        finally:
+            lib.set_conv_tiling(0, 0)
+        assert torch.equal(torch.isfinite(got), torch.isfinite(ref)), (wk, int((~torch.isfinite(got)).sum()), int((~torch.isfinite(ref)).sum()))
+        fin = torch.isfinite(ref)
+        assert (got[fin] - ref[fin]).abs().max().item() <= 2e-5 * 3e4
+
+
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
+@pytest.mark.parametrize("order", ["big_first", "small_first"])
+@pytest.mark.parametrize("big,small", [(1e30, 1e-30), (1e36, 1e-36)])
+def test_conv1d_chunks_sixty_orders_apart_every_tile_form(lib, monkeypatch, mode, order, big, small):
+    """One 16-channel chunk at 1e30 (1e36) and one at 1e-30 (1e-36) inside one reduction, the rest O(1), in either order, through the K-split
+    form and BOTH M-split forms (MUGD_CONV_WIDE = 1 | 2): finite everywhere and the float64 result at the fp32 tolerance of the large terms.
+    Round 6: a consumer of a shared window adopted whatever scale the (lagging) parking wave had picked -- the accumulators
+    jumped by 2^200 and every output of the M-split forms came out non-finite; now a rise is bounded where the accumulators live
+    (conv_body.h: h3_rise_ok) and a window that cannot be reached is dropped through the all-zero window."""
+    monkeypatch.setenv("MUGD_CONV_WIDE", mode)
+    B, C, T, M = 2, 160, 96, 128
+    x = rnd(51, B, C, T)
+    w = rnd(52, M, C, 3, scale=1.0 / math.sqrt(C * 3))
+    cs = torch.ones(C)
+    a, b = (16, 32) if order == "big_first" else (32, 16)
+    cs[a:a + 16] = big
+    cs[b:b + 16] = small
+    x = x * cs[None, :, None]
+    ref = conv_ref64(x, w, None, 1, 1, 1)
+    lib.set_conv_tiling(0, 32)
+    try:
+        got = lib.op_conv1d(x, w, pad=1).detach().cpu().double()
+    finally:
+        lib.set_conv_tiling(0, 0)
+    assert torch.isfinite(got).all(), "%d of %d outputs non-finite" % (int((~torch.isfinite(got)).sum()), got.numel())
+    assert ((got - ref).abs() / big).max().item() <= 2e-5
+    # (what a wave that walks BOTH chunks can promise is an error relative to the largest operand of its walk -- the stated contract of
+    # include/mugd.h -- not relative to each output row's own magnitude: rows with zero weights on the large chunk are not held to more here)
+
+
+@pytest.mark.parametrize("dil,wk", [(2, 1), (2, 2), (1, 1)])
+def test_conv1d_tiny_chunk_behind_an_in_band_first_chunk(lib, dil, wk):
+    """One wave walks an O(1) chunk (in band at the starting scale: no rescale) and then a chunk at 1e-36, in the data-following mode (dilated
+    kernels always; dil = 1: via a first chunk at 1e3, which sends the plain kernel's wave to its careful pass): the rise for the tiny chunk
+    is bounded by the scale the accumulators ALREADY hold products at (round 6: that scale was not recorded when the first chunk needed no
+    rescale, and the accumulators were lifted by 2^117 -> inf)."""
+    B, C, T, M = 1, 48, 64, 32
+    x = rnd(71, B, C, T)
+    cs = torch.ones(C)
+    cs[16:32] = 1e-36
+    if dil == 1:
+        cs[:16] = 1e3
+    x = x * cs[None, :, None]
+    w = rnd(72, M, C, 3, scale=1.0 / math.sqrt(C * 3))
+    ref = conv_ref64(x, w, None, 1, dil, dil)
+    lib.set_conv_tiling(wk, 32)
+    try:
+        got = lib.op_conv1d(x, w, dil=dil, pad=dil).detach().cpu().double()
+    finally:
+        lib.set_conv_tiling(0, 0)
+    assert torch.isfinite(got).all(), int((~torch.isfinite(got)).sum())
+    assert (got - ref).abs().max().item() <= 2e-5 * (1e3 if dil == 1 else 1.0)
+
+
 def ref_attention(q, k, v, rel, cemb, heads):
     """mug/model/attention.py:98-124 on channel-major tensors."""
     B, C, Tq = q.shape
@@ -501,6 +576,39 @@ def test_log_mel(lib, seconds):
     ulp = torch.maximum(ref.abs(), torch.tensor(2.0 ** -14)) * 2.0 ** -10
     assert (err <= ulp * 1.01).all(), float((err / ulp).max())
     assert (err > 0).float().mean().item() < 0.02
+
+
+@pytest.mark.parametrize("n_fft,hop,nsamp", [(512, 128, 8159), (512, 128, 300), (1024, 256, 5000), (64, 16, 33)])
+def test_log_mel_reflect_padding(lib, n_fft, hop, nsamp):
+    """librosa <= 0.9 framing (stft(pad_mode='reflect'); the reference leaves librosa unpinned: requirements.txt:8, mug/util.py:138-143) behind
+    mugd_set_mel_pad_mode / log_mel(pad_mode=): against oracle/host.py's log_mel(pad_mode='reflect') at the usual one-fp16-ulp criterion --
+    every frame, the edge frames in particular; songs barely longer than half a window (300 > 256, 33 > 32 samples: a frame reflects at BOTH
+    ends); the per-call override leaves the context's default ('constant') as it was; too-short audio is rejected like librosa does."""
+    from oracle import host
+    y = (host.synth_audio(nsamp / 22050.0 + 0.01, seed=11)[:nsamp] + 0.3).astype(np.float32)      # (+ DC: the padded edges matter)
+    n_mels = 128 if n_fft >= 512 else 16
+    for mode in ("reflect", "constant"):
+        ref = torch.from_numpy(host.log_mel(y, n_fft=n_fft, hop=hop, n_mels=n_mels, pad_mode=mode).astype(np.float32))
+        got = (lib.log_mel(torch.from_numpy(y), n_fft=n_fft, hop=hop, n_mels=n_mels, pad_mode="reflect") if mode == "reflect"
+               else lib.log_mel(torch.from_numpy(y), n_fft=n_fft, hop=hop, n_mels=n_mels)).cpu()
+        assert got.shape == ref.shape
+        err = (got - ref).abs()
+        ulp = torch.maximum(ref.abs(), torch.tensor(2.0 ** -14)) * 2.0 ** -10
+        assert (err <= ulp * 1.01).all(), (mode, float((err / ulp).max()))
+    edge = n_fft // (2 * hop) + 1
+    a = host.log_mel(y, n_fft=n_fft, hop=hop, n_mels=n_mels, pad_mode="reflect").astype(np.float32)
+    b = host.log_mel(y, n_fft=n_fft, hop=hop, n_mels=n_mels, pad_mode="constant").astype(np.float32)
+    assert np.abs(a[:, :edge] - b[:, :edge]).max() > 1e-3              # the two framings really differ at the edges ...
+    if a.shape[1] > 2 * edge + 2:
+        assert np.array_equal(a[:, edge:-edge], b[:, edge:-edge])     # ... and nowhere else
+    lib.set_mel_pad_mode("reflect")
+    try:
+        got = lib.log_mel(torch.from_numpy(y), n_fft=n_fft, hop=hop, n_mels=n_mels).cpu().numpy()      # the context-wide switch
+        assert np.abs(got - a).max() <= np.abs(a).max() * 2.0 ** -10 * 1.01
+        with pytest.raises(Exception):
+            lib.log_mel(torch.from_numpy(y[: n_fft // 2]), n_fft=n_fft, hop=hop, n_mels=n_mels)
+    finally:
+        lib.set_mel_pad_mode("constant")
 
 
 @pytest.mark.parametrize("kind", ["dc", "square30", "sine_fullscale", "quiet"])
