@@ -55,8 +55,6 @@ SCRATCH_ALLOWED = [
      "one-wave 16-wide tiles: only launches with a single K chunk AND <= 128 tiles pick them (never on the shipped networks' hot paths)"),
     (r"conv_gemm_kernel<\d, true, 2, 9, float, 32, 0>", 400,
      "gated epilogue over generic windows: a GLU / GEGLU projection at a length that is not a multiple of 4 (cold path, kept for completeness)"),
-    (r"conv_gemm_kernel<8, true, 0, 1, float, 32, 4>", 128,
-     "experimental M-split geometry (2 row tiles x 4 K-slices, gated): development sweeps only (mugd_set_conv_tiling wk = 0x184), no host rule selects it"),
     (r"conv_gemm_kernel<2, true, 0, 1, float, 32, 0>", 16,
      "the GEGLU projections at batch 4: at most one 64-bit address parked outside the chunk loops"),
     (r"conv_gemm_kernel<[48], true, 0, 1, float, 32, 0>", 128,
@@ -107,6 +105,9 @@ def check_scratch(objs, verbose=True):
                     limit = max(limit, mx)
             if scratch > limit:
                 bad.append("%s: %d bytes of scratch per lane (%d VGPRs; allowed: %d) in %s" % (name, scratch, vgpr, limit, os.path.basename(obj)))
+    if bad and os.environ.get("MUGD_GUARD") == "warn":       # development: experiments may link what the guard would refuse
+        print("register-pressure guard (MUGD_GUARD=warn):\n  " + "\n  ".join(bad))
+        return
     if bad:
         raise RuntimeError("register-pressure guard: kernels spill beyond what build.py: SCRATCH_ALLOWED tolerates\n  " + "\n  ".join(bad))
     if verbose:
@@ -135,7 +136,7 @@ def build_variant(name, defines, verbose=True):
     return lib
 
 
-def build_rev(rev, name, verbose=True):
+def build_rev(rev, name, verbose=True, defines=()):
     """DEVELOPMENT A/B: the library as of git revision `rev` (its own csrc/ and include/, extracted with `git archive`) into
     tests/var/<name>/libmugd.so -- the "before" arm of same-box comparisons (tests/gpu_run.sh ab:<name>; the binding loads it with
     MUGD_LIB_LENIENT=1 because an older library lacks the newer entry points)."""
@@ -150,7 +151,7 @@ def build_rev(rev, name, verbose=True):
     tarfile.open(fileobj=io.BytesIO(blob)).extractall(src)
     objdir = os.path.join(outdir, "build")
     os.makedirs(objdir, exist_ok=True)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"] + ["-D" + d for d in defines]
 
     def cc(s):
         obj = os.path.join(objdir, os.path.basename(s) + ".o")
@@ -229,7 +230,7 @@ def build_emulated(force=False, verbose=True):
 if __name__ == "__main__":
     if "--rev" in sys.argv:                           # python build.py --rev <git revision> <name>
         i = sys.argv.index("--rev")
-        build_rev(sys.argv[i + 1], sys.argv[i + 2])
+        build_rev(sys.argv[i + 1], sys.argv[i + 2], defines=sys.argv[i + 3:])
     elif "--variant" in sys.argv:
         i = sys.argv.index("--variant")
         build_variant(sys.argv[i + 1], sys.argv[i + 2:])

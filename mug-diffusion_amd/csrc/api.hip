@@ -544,10 +544,15 @@ int mugd_dev_bench_conv(mugd_ctx* ctx, int B, int C, int T, int M, int taps, int
         HIP_CHECK(hipEventCreate(&e0));
         HIP_CHECK(hipEventCreate(&e1));
         ConvLaunch L = conv_prepare(a);                  // like a compiled program op: prepared once, launched per step
+        // MUGD_BENCH_THRASH (development): 1 = a kernel that evicts every instruction cache runs in front of every launch (the launch then
+        // starts with cold code, as inside a network program); 2 = that kernel ALONE (its own time, to subtract)
+        const char* te = getenv("MUGD_BENCH_THRASH");
+        const int thrash = te ? atoi(te) : 0;
         for (int it = -3; it < iters; ++it) {
             if (it == 0) HIP_CHECK(hipEventRecord(e0, st));
             L.a.wpk = wpk + (size_t)((it + 3) % copies) * MT * mts;
-            conv_launch(st, L);
+            if (thrash) launch_icache_thrash(st);
+            if (thrash != 2) conv_launch(st, L);
         }
         HIP_CHECK(hipEventRecord(e1, st));
         HIP_CHECK(hipStreamSynchronize(st));

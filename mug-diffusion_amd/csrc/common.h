@@ -63,6 +63,51 @@ __device__ __forceinline__ float silu_fast(float x) {
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// The EXACT-erf GELU of the reference (attention.py:45 F.gelu, s4.py:1459 nn.GELU()) and the GLU's sigmoid, branch-free for the epilogues that
+// apply them to every output (round 6).  The library forms above compile to ~100 instructions per element -- erff evaluates BOTH of its
+// ranges under exec masks as soon as a wave's lanes disagree on |x| < 1, expf carries an extended-precision range reduction, 1 / (1 + e)
+// an IEEE division sequence -- and the gated conv epilogues spent 4 - 5 us per launch in them (profiles/r4_timeline2_z512_b4.txt: "store" of
+// the ff.net.0.proj rows), the S4 convolution as many instructions per output as on its 512 taps.  Same minimax polynomials as the device
+// library's erff (ROCm ocml erfF: |x| < 1: x + x P(x^2); else 1 - exp(-(|x| + |x| Q(|x|)))), both evaluated, one select; the exponential
+// on v_exp_f32 (1 ulp; the argument's rounding adds < 2e-7 relative to a term that is <= 0.16 of the result): |erf_fast - erff| <= 1 ulp
+// measured over 2^24 arguments (tests/test_ops.py::test_fast_erf_and_sigmoid_match_the_library_forms).  -DMUGD_EXACT_GATES=1: the library forms.
+#ifndef MUGD_EXACT_GATES
+#define MUGD_EXACT_GATES 0
+#endif
+__device__ __forceinline__ float erf_fast(float x) {
+    const float a = fabsf(x), s = x * x;
+    float p = fmaf(s, __builtin_bit_cast(float, 0xba1345e1u), __builtin_bit_cast(float, 0x3ba10414u));
+    p = fmaf(s, p, __builtin_bit_cast(float, 0xbcdac9b8u));
+    p = fmaf(s, p, __builtin_bit_cast(float, 0x3de703beu));
+    p = fmaf(s, p, __builtin_bit_cast(float, 0xbec09330u));
+    p = fmaf(s, p, __builtin_bit_cast(float, 0x3e0375d0u));
+    const float small = fmaf(a, p, a);
+    float q = fmaf(a, __builtin_bit_cast(float, 0x378e98abu), __builtin_bit_cast(float, 0xb9c68948u));
+    q = fmaf(a, q, __builtin_bit_cast(float, 0x3b7cd369u));
+    q = fmaf(a, q, __builtin_bit_cast(float, 0xbcc618b2u));
+    q = fmaf(a, q, __builtin_bit_cast(float, 0x3dda74e4u));
+    q = fmaf(a, q, __builtin_bit_cast(float, 0x3f228afdu));
+    q = fmaf(a, q, __builtin_bit_cast(float, 0x3e03c728u));
+    const float t = fmaf(a, q, a);
+    const float large = 1.0f - __builtin_amdgcn_exp2f(-1.44269504088896340736f * t);      // t >= ~17.4: 2^-25 and below -> 1
+    const float r = a < 1.0f ? small : large;
+    return __builtin_copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_gate(float x) {
+#if MUGD_EXACT_GATES
+    return gelu_erf_f(x);
+#else
+    return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f));
+#endif
+}
+__device__ __forceinline__ float sigmoid_gate(float x) {
+#if MUGD_EXACT_GATES
+    return sigmoid_f(x);
+#else
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));
+#endif
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // n / d with m = ceil(2^32 / d) precomputed on the host (conv_fastdiv_mul); d == 1 is encoded as m == 0.  The estimate

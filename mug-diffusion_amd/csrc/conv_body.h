@@ -17,6 +17,7 @@
 #ifndef MUGD_PIPE
 #define MUGD_PIPE true
 #endif
+
 // every lambda of the tile body must be inlined: one that is not turns the register arrays it captures by reference (ring stages, weight
 // fragments, staged samples) into scratch memory -- round 5 saw the WK = 8 kernels grow past the inliner's budget: 688 bytes of scratch per lane
 // and +20 us per launch.  Clang accepts the attribute between a lambda's parameter list and its body.
@@ -530,7 +531,11 @@ __device__ __forceinline__ bool run_segment_vec(const SEG& s, const WT* wseg, co
     constexpr int NHA = NH > 0 ? NH : 1;
     const int r = lane >> 2, q = lane & 3;
     const int Tin = s.Tin;
-    const int hw = (TAPS - 1) * s.dil;                     // halo samples per row (left pad + right rest)
+    // the pipelined, transform-specialised loops exist for the plain kernels only (KIND 0: every 3-tap segment has dilation 1, k_conv.hip:
+    // "lean"), so their tap offsets are compile-time constants -- immediate offsets of the fragment reads instead of a scalar load of the
+    // segment's dilation and an address per tap inside the chunk loop
+    const int dil = PIPE ? 1 : s.dil;
+    const int hw = (TAPS - 1) * dil;                       // halo samples per row (left pad + right rest)
     // ---- interior: samples t0 + SPL q + {0..3} (, {4..7})
     const int ti0 = t0 + SPL * q;
     bool okv[XV];                                          // Tin % 4 == 0: a float4 is wholly inside or outside
@@ -764,7 +769,7 @@ __device__ __forceinline__ bool run_segment_vec(const SEG& s, const WT* wseg, co
                         }
                         ac.sxmin = rfl_f(fminf(ac.sxmin, ac.sx));      // (also when the window sits at the scale the accumulators started at)
                     }
-                    conv_mfma<TN, TAPS, DUAL, WT>(smem_bytes + wofs, rb0, s.dil, RA[j & 1], RA2[j & 1], ac);
+                    conv_mfma<TN, TAPS, DUAL, WT>(smem_bytes + wofs, rb0, dil, RA[j & 1], RA2[j & 1], ac);
                     if (k + 2 < nch) fetch_a(k + 2, j & 1);
                 }
                 if (j == 0 && kn < nch) {                   // under the first chunk's MFMAs: the next phase's window, into the other buffer
@@ -801,9 +806,10 @@ __device__ __forceinline__ bool run_segment_vec(const SEG& s, const WT* wseg, co
         // chunks, wrapping around: a weight line is then first touched by one workgroup and found in L2 by the others later,
         // instead of 16 requests piling up on one pending miss (tests/gpu_l2bw.hip: 22-28 -> 33-34 B/clk/CU on a cold K = 4608
         // panel, no effect on short ones).  fp32 sums are order-dependent: the result stays deterministic, per column tile.
-        // (which chunk a column tile starts at only has to DIFFER between neighbours: floor(hash(seed) nch / 2^32) -- two multiplies -- instead of
-        // seed % nch, a 25-instruction integer-division sequence in front of the first loads of every segment)
-        const int rot = nch >= 8 ? (int)__umulhi((unsigned)rot_seed * 0x9E3779B1u, (unsigned)nch) : 0;
+        // (rot_seed % nch, not a hash: NEIGHBOURING column tiles must start at NEIGHBOURING chunks -- tile t + 1 then requests the weight lines
+        // tile t requested one chunk earlier and finds them in L2; round 6 tried floor(hash(seed) nch / 2^32) to save the 25-instruction division
+        // and lost 3 - 8 % on every long-K launch: profiles/r6_kstats_vs_r5.txt)
+        const int rot = nch >= 8 ? rot_seed % nch : 0;
         auto fetch_x = [&](int cr0, int d) MUGD_LI {
             int cr = cr0 + rot;
             cr = cr >= nch ? cr - nch : cr;
@@ -839,7 +845,7 @@ __device__ __forceinline__ bool run_segment_vec(const SEG& s, const WT* wseg, co
                 const int cc = c + d;
                 if (cc < nch) {
                     const int dn = (d + 1) % D;
-                    conv_mfma<TN, TAPS, DUAL, WT>(smem_bytes + (d & 1) * W1, rb0, s.dil, RA[d], RA2[d], ac);
+                    conv_mfma<TN, TAPS, DUAL, WT>(smem_bytes + (d & 1) * W1, rb0, dil, RA[d], RA2[d], ac);
                     if (cc + 1 < nch) {
                         park_v(((d + 1) & 1) * W1, RX[dn], RXH[dn], RGB[dn], RGG[dn], 0, [&]() MUGD_LI { if (cc + 1 + D < nch) fetch_x(cc + 1 + D, dn); });
                     }
@@ -878,7 +884,7 @@ __device__ __forceinline__ bool run_segment_vec(const SEG& s, const WT* wseg, co
             ++crel;
             if (xf) gbv = load_gb(crel);
         }
-        conv_mfma<TN, TAPS, DUAL, WT>(smem_bytes, rb0, s.dil, A, A2, ac);
+        conv_mfma<TN, TAPS, DUAL, WT>(smem_bytes, rb0, dil, A, A2, ac);
         wave_sync();               // all lanes done reading the window before it is overwritten
     };
 
@@ -1142,13 +1148,10 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
     TL_SET(10, g1 - g0);
 
     bool redo = false;                               // H3 domain: a raw segment's slice left the band at the fixed scale (run_segment_vec: TRACK)
-    // The segments are read through a pointer into MEMORY -- a by-value kernel argument already sits in the kernarg segment (scalar loads, hot in
-    // the scalar cache after KARG_WARM) -- so that the segment index may be a run-time value: a dynamic index into the by-value parameter itself
-    // makes the compiler copy the whole block into scratch at kernel entry (688 bytes per lane, +20 us per launch: round 5).  Round 6: the loop
-    // over the segments is ROLLED with its first executed iteration peeled off -- two copies of the specialised chunk loops instead of four
-    // unrolled ones (the kernel's code halves) -- because the peeled copy is the one place where the workgroup's statistics are reduced
-    // (pre_park, behind the wave's first operand requests): their partial sums are live in registers up to that point and must not stay live
-    // across every chunk loop of the kernel (measured: +20 ... 40 VGPRs, scratch in every hot instantiation, when the call sat in all of them).
+    // `am`: the argument block in MEMORY -- a by-value kernel argument already sits in the kernarg segment (scalar loads, hot in the scalar
+    // cache after KARG_WARM) -- for the one place that needs a RUN-TIME segment index, the careful redo pass below: a dynamic index into the
+    // by-value parameter itself makes the compiler copy the whole block into scratch at kernel entry (688 bytes per lane, +20 us per launch:
+    // round 5).  The main segment loop keeps compile-time indices (below).
 #ifdef MUGD_EMULATED
     const A* am = &a;
 #else
@@ -1198,21 +1201,46 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
 #undef MUGD_COOP
     };
     const int nseg = a.nseg;
-    int si = 0;
-    if constexpr (KIND != 2) {
-        if (KIND == 0 && MS == 0 && __builtin_expect(a.h3_careful != 0, 0)) {
-            // the caller knows its raw operands sit far from O(1) (ConvArgs::h3_careful: the training step's gradients, 1e-4 ... 1e-12): straight
-            // to the careful pass below instead of a fast pass whose slice check would send every wave there anyway (round 6)
-            redo = true; si = nseg;
-        } else {
-            // the wave's first segment: the one that holds chunk g0 (an empty K-slice -- g0 == g1 -- finds none)
-            while (si < nseg && !(g0 < g1 && g0 < am->seg[si].chunk0 + am->seg[si].C / CONV_CK)) ++si;
-            if (si < nseg) { run_seg(am->seg[si], pre_park); ++si; }
-        }
-    }
-    pre_park();                                      // (a wave whose K-slice is empty: the workgroup's barrier count must match)
+    // Statistics first, then the segment loop, fully unrolled over the by-value argument block (constant kernarg offsets; the compiler merges
+    // the four identical copies into one that walks a segment pointer).  Round 6 built and measured the alternative the round-5 verdict asked
+    // for -- the statistics reduction BEHIND the first segment's operand requests (run_segment_vec: pre_park), so that the requests travel
+    // while the wave waits for the producers' sums -- in three forms, each against this one on one box (profiles/r6_segloop_ab.txt):
+    //   * the reduction inside every segment's copy: the partial sums stay live across every chunk loop: +20 ... 40 VGPRs, scratch in every hot
+    //     instantiation;
+    //   * a ROLLED segment loop (segments read through the kernarg pointer) with its first iteration peeled: no scratch, the overlap works
+    //     (phase timeline: entry -> first chunk parked 857 instead of 920 us per evaluation) -- and the chunk loops take 52 us longer (operand
+    //     delivery, not the prologue, is what a launch waits for) and every launch pays 0.3 - 0.7 us for the dependent scalar loads behind a
+    //     run-time segment index: DDIM step -1.4 % at batch 4, +1 % at batch 16;
+    //   * segment 0 through the by-value block with the reduction inside, the rest rolled: scratch in the gated / dilated instantiations,
+    //     batch 16 +3 %.
+    // None beats statistics-first; -DMUGD_STATS_DEFERRED=1 keeps the last form as the A/B arm.
+#ifndef MUGD_STATS_DEFERRED
+#define MUGD_STATS_DEFERRED 0
+#endif
+    const bool careful_start = KIND == 0 && MS == 0 && a.h3_careful != 0;
+    // (careful_start: the caller knows its raw operands sit far from O(1) -- ConvArgs::h3_careful: the training step's gradients, 1e-4 ... 1e-12 --
+    // so the wave goes straight to the careful pass below instead of a fast pass whose slice check would send it there anyway; round 6)
+#if MUGD_STATS_DEFERRED
+    if (KIND == 2 || careful_start || !(g0 < g1 && g0 < a.seg[0].C / CONV_CK)) pre_park();      // the wave does not start in segment 0
+    if (__builtin_expect(careful_start, 0)) redo = true;
+    else {
+        run_seg(a.seg[0], pre_park);
 #pragma nounroll
-    for (; si < nseg; ++si) run_seg(am->seg[si], NoPrePark());
+        for (int su = 1; su < nseg; ++su) run_seg(am->seg[su], NoPrePark());
+    }
+#else
+    pre_park();
+    if (__builtin_expect(careful_start, 0)) redo = true;
+    else {
+        // (this loop MUST be fully unrolled: left rolled, the dynamic index a.seg[su] moves the whole by-value argument block into scratch memory
+        // -- 688 bytes per lane and +20 us per launch, seen in round 5 -- which is why the chunk loops stay lean enough for the unroller:
+        // build.py's guard fails the build if it ever happens again)
+#pragma unroll
+        for (int su = 0; su < CONV_MAXSEG; ++su)
+            if (su < nseg) run_seg(a.seg[su], NoPrePark());
+    }
+#endif
+    pre_park();                                      // (a wave that ran no segment-0 chunk loop -- an unspecialised transform, an empty slice: the barrier count must match)
     if constexpr (KIND == 0 && MS == 0) {
         // H3 domain, rare (never on the shipped networks): some raw slice of this wave left the band at the fixed scale -- an operand above 2^7 or
         // a whole slice below 2^-6 -- so what the accumulators hold may be inf or imprecise.  The wave starts its tile over and runs EVERY
@@ -1313,7 +1341,7 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
         float v = acc_v[q] + bv[q];
         if (DUAL) {
             const float gte = acc_g[q] + bg[q];
-            v = (a.epi == EPI_GLU) ? v * sigmoid_f(gte) : v * gelu_erf_f(gte);
+            v = (a.epi == EPI_GLU) ? v * sigmoid_gate(gte) : v * gelu_gate(gte);
         }
         v = (v + ra[q]) + rsv[q];
         if (valid[q]) a.y[oo[q]] = v;

@@ -42,28 +42,44 @@ struct WgStats {
     double2 gv[NG];
     float2 lv[NLN];
 
-    // fp64 {sum, sum of squares} of channel c of the normalised concat (segments 0 .. gn_nseg-1), batch row b.  Branch-free: the segment is
-    // picked with selects under COMPILE-TIME segment indices (a per-lane segment index would turn the kernarg accesses into vector loads of the
-    // argument block), then ONE unconditional load -- callers mask rows outside the concat when they sum (an out-of-range c reads segment 0's
-    // first row).  Round 6: the previous form -- one predicated load per segment -- compiled to an exec-mask branch per segment whose load
-    // had to WAIT for the previous segment's (same destination registers: s_waitcnt vmcnt(0) between them) and an integer-division sequence
-    // for b % bmod in every branch: up to three dependent memory round trips in front of the statistics of a multi-segment GroupNorm.
+    // Where the fp64 {sum, sum of squares} rows of the normalised concat live: per segment (0 .. gn_nseg - 1) the base of this batch row's block
+    // and the first concat channel it holds -- wave-uniform, computed ONCE per wave (scalar registers), so that a row request is selects + one
+    // unconditional load.  Round 6, in two steps: (i) the round-5 form -- one predicated load per segment -- compiled to an exec-mask branch per
+    // segment whose load WAITED for the previous segment's (same destination registers) plus an integer-division sequence for b % bmod in every
+    // branch; (ii) its branch-free replacement still recomputed the bases for every one of a lane's three rows (four scalar loads + waits,
+    // 64-bit multiplies: 160 instructions per row, 1 - 2 us of every GroupNorm launch before its first request, profiles/r6_timeline_*).
+    // (named members, no arrays: an array member -- even one indexed by unrolled compile-time indices only -- made the compiler keep the whole
+    // map in scratch memory, or promote it to LDS: 56 bytes of scratch in EVERY conv_gemm instantiation, caught by build.py's guard)
+    struct RowMap {
+        const double* b0; const double* b1; const double* b2; const double* b3;
+        int f1, f2, f3;                      // first concat channel of segments 1..3; INT_MAX for segments outside the GroupNorm domain
+    };
     template <class A>
-    static __device__ __forceinline__ double2 row_load(const A& a, int b, int c) {
-        const double* p = nullptr;
-        int rel = 0, c0 = 0;
-#pragma unroll
-        for (int si = 0; si < CONV_MAXSEG; ++si) {
-            if (si < a.gn_nseg) {
-                const auto& s = a.seg[si];
-                const double* sb = reinterpret_cast<const double*>(s.xf_a) + (size_t)batch_row_mod(b, s.mbmod, s.bmod) * s.xf_stride;      // wave-uniform
-                const bool in = si == 0 ? (c < s.C) : (c >= c0 && c < c0 + s.C);      // si == 0 also catches c < 0 / nothing matched: a valid address
-                const int r0 = c - c0;
-                if (si == 0) { p = sb; rel = (r0 >= 0 && r0 < s.C) ? r0 : 0; }
-                else { p = in ? sb : p; rel = in ? r0 : rel; }
-                c0 += s.C;
-            }
-        }
+    static __device__ __forceinline__ RowMap row_map(const A& a, int b) {
+        static_assert(CONV_MAXSEG == 4, "RowMap names four segments");
+        RowMap m;
+        const int n = a.gn_nseg;
+        auto base = [&](const auto& s) __attribute__((always_inline)) {
+            return reinterpret_cast<const double*>(s.xf_a) + (size_t)batch_row_mod(b, s.mbmod, s.bmod) * s.xf_stride;
+        };
+        m.b0 = base(a.seg[0]);
+        m.b1 = n > 1 ? base(a.seg[1]) : m.b0;
+        m.b2 = n > 2 ? base(a.seg[2]) : m.b0;
+        m.b3 = n > 3 ? base(a.seg[3]) : m.b0;
+        const int c1 = a.seg[0].C, c2 = c1 + a.seg[1].C, c3 = c2 + a.seg[2].C;
+        m.f1 = n > 1 ? c1 : 0x7fffffff;
+        m.f2 = n > 2 ? c2 : 0x7fffffff;
+        m.f3 = n > 3 ? c3 : 0x7fffffff;
+        return m;
+    }
+    // row c of the concat (0 <= c < channels of the domain; callers mask what they requested for inactive lanes).  Segments are in concat
+    // order: the last one whose first channel is <= c holds it
+    static __device__ __forceinline__ double2 row_load(const RowMap m, int c) {
+        const double* p = m.b0;
+        int rel = c;
+        if (c >= m.f1) { p = m.b1; rel = c - m.f1; }
+        if (c >= m.f2) { p = m.b2; rel = c - m.f2; }
+        if (c >= m.f3) { p = m.b3; rel = c - m.f3; }
         return *reinterpret_cast<const double2*>(p + 2 * (size_t)rel);
     }
 
@@ -73,10 +89,11 @@ struct WgStats {
         pending = ln || a.gn_groups != 0;
         if (a.gn_groups) {
             const int g = tid / LPG, j = tid % LPG, cg = a.gn_cg;
+            const RowMap rm = row_map(a, b);
 #pragma unroll
             for (int u = 0; u < NG; ++u) {
                 const int cc = j + u * LPG;
-                gv[u] = row_load(a, b, (g < a.gn_groups && cc < cg) ? g * cg + cc : 0);
+                gv[u] = row_load(rm, (g < a.gn_groups && cc < cg) ? g * cg + cc : 0);
             }
         }
         if (ln) {
@@ -112,15 +129,27 @@ struct WgStats {
 #pragma unroll
             for (int u = 0; u < NG; ++u)
                 if (active && j + u * LPG < cg) { s1 += gv[u].x; s2 += gv[u].y; }
-            for (int cc = j + NG * LPG; active && cc < cg; cc += LPG) {         // groups wider than NG * LPG channels (not in the shipped nets at WK = 8)
-                const double2 v = row_load(a, b, g * cg + cc);
-                s1 += v.x; s2 += v.y;
+            if (cg > NG * LPG) {                                                // groups wider than NG * LPG channels (not in the shipped nets at WK = 8)
+                const RowMap rm = row_map(a, b);
+                for (int cc = j + NG * LPG; active && cc < cg; cc += LPG) {
+                    const double2 v = row_load(rm, g * cg + cc);
+                    s1 += v.x; s2 += v.y;
+                }
             }
             TL_STAMP(13);
 #pragma unroll
             for (int o = 1; o < LPG; o <<= 1) { s1 += shfl_xor_d(s1, o); s2 += shfl_xor_d(s2, o); }
             if (active && j == 0) {
-                const double inv = 1.0 / (double)a.gn_count;
+                // 1 / count in double: v_rcp_f64 + one Newton step (full precision for an integer count) instead of the ~30-instruction IEEE
+                // division sequence every wave of every GroupNorm launch walked through
+                const double cnt = (double)a.gn_count;
+#ifdef MUGD_EMULATED
+                const double inv = 1.0 / cnt;
+#else
+                double inv = __builtin_amdgcn_rcp(cnt);
+                inv = inv * (2.0 - cnt * inv);
+                inv = inv * (2.0 - cnt * inv);
+#endif
                 const double mean = s1 * inv;
                 double var = s2 * inv - mean * mean;
                 var = var > 0.0 ? var : 0.0;

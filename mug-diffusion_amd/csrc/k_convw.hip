@@ -3,14 +3,15 @@
 // the library's three conv_gemm units compile in parallel (conv_kernel.h); the host side of a launch -- which form, when -- is k_conv.hip's.
 #include "conv_kernel.h"
 
-// NW waves per workgroup = NW / KS row tiles x KS K-slices.  Forms that exist: KS = 1 with 2 | 4 | 8 row tiles; 4 x 2 and 2 x 2 (round 5);
-// 2 x 4 (round 6: tall gated projections at batch 4, where 4 or 8 row tiles per workgroup leave CUs without one).  null: no such form.
+// NW waves per workgroup = NW / KS row tiles x KS K-slices.  Forms that exist: KS = 1 with 2 | 4 | 8 row tiles; 4 x 2 and 2 x 2 (round 5).
+// (Round 6 measured a 2 x 4 form for the tall gated projections at batch 4 -- 12 - 90 % SLOWER than the K-split form on every shape,
+// profiles/r6_forms_sweep.txt -- and did not keep it.)  null: no such form.
 const void* conv_kernel_wide(int nw, bool dual, int ks) {
 #define MUGD_KW(N, K)                                                                                                             \
     if (nw == N && ks == K)                                                                                                       \
         return dual ? reinterpret_cast<const void*>(static_cast<ConvKernel>(conv_gemm_kernel<N, true, 0, 1, float, 32, K>))       \
                     : reinterpret_cast<const void*>(static_cast<ConvKernel>(conv_gemm_kernel<N, false, 0, 1, float, 32, K>));
-    MUGD_KW(2, 1) MUGD_KW(4, 1) MUGD_KW(8, 1) MUGD_KW(4, 2) MUGD_KW(8, 2) MUGD_KW(8, 4)
+    MUGD_KW(2, 1) MUGD_KW(4, 1) MUGD_KW(8, 1) MUGD_KW(4, 2) MUGD_KW(8, 2)
 #undef MUGD_KW
     return nullptr;
 }

@@ -176,3 +176,24 @@ void launch_embed_tokens(hipStream_t st, const float* table, const long long* id
 void launch_bias_sum(hipStream_t st, const float* a, const float* b, float* out, int n) {
     hipLaunchKernelGGL(bias_sum_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, a, b, out, n);
 }
+
+// ---------------------------------------------------------------------------------------
+// Development probe (mugd_dev_bench_conv, MUGD_BENCH_THRASH): 128 KB of straight-line code -- twice a CU pair's instruction cache -- walked by
+// one wave per CU, so that the NEXT kernel starts with its code cold in every instruction cache (what a conv_gemm launch meets inside a network
+// program, where consecutive launches run different 100 - 300 KB instantiations), against back-to-back launches of ONE kernel, whose code stays
+// resident.  s_nop: 4 bytes, one issue cycle.
+// ---------------------------------------------------------------------------------------
+#ifndef MUGD_EMULATED
+#define MUGD_NOP1 asm volatile("s_nop 0");
+#define MUGD_NOP8 MUGD_NOP1 MUGD_NOP1 MUGD_NOP1 MUGD_NOP1 MUGD_NOP1 MUGD_NOP1 MUGD_NOP1 MUGD_NOP1
+#define MUGD_NOP64 MUGD_NOP8 MUGD_NOP8 MUGD_NOP8 MUGD_NOP8 MUGD_NOP8 MUGD_NOP8 MUGD_NOP8 MUGD_NOP8
+#define MUGD_NOP512 MUGD_NOP64 MUGD_NOP64 MUGD_NOP64 MUGD_NOP64 MUGD_NOP64 MUGD_NOP64 MUGD_NOP64 MUGD_NOP64
+#define MUGD_NOP4K MUGD_NOP512 MUGD_NOP512 MUGD_NOP512 MUGD_NOP512 MUGD_NOP512 MUGD_NOP512 MUGD_NOP512 MUGD_NOP512
+__global__ __launch_bounds__(64) void icache_thrash_kernel(int* sink) {
+    MUGD_NOP4K MUGD_NOP4K MUGD_NOP4K MUGD_NOP4K MUGD_NOP4K MUGD_NOP4K MUGD_NOP4K MUGD_NOP4K
+    if (sink && threadIdx.x == 12345) *sink = 1;
+}
+void launch_icache_thrash(hipStream_t st) { hipLaunchKernelGGL(icache_thrash_kernel, dim3(512), dim3(64), 0, st, (int*)nullptr); }
+#else
+void launch_icache_thrash(hipStream_t) {}
+#endif

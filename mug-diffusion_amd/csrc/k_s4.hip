@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void s4_conv_kernel(const S4ConvArgs a) {
         }
         for (; s <= t; ++s) a0 += ks[s] * us[t - s];
         const float v = (a0 + a1) + (a2 + a3) + Dh * us[t];
-        y[t] = gelu_erf_f(v);
+        y[t] = gelu_gate(v);
     }
 }
 

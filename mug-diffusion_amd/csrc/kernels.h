@@ -350,6 +350,8 @@ std::vector<float> resample_poly_taps(int up, int down);
 long long resample_poly_out_len(long long n_in, int up, int down);
 void launch_resample_poly(hipStream_t st, const ResampleArgs& a);
 
+void launch_icache_thrash(hipStream_t st);         // development probe (k_misc.hip): evicts every CU's instruction cache
+
 // chart post-processing (k_timing.hip)
 struct TimingSweepArgs {
     const float* times; int n;                     // note start times (ms), float32 like the reference's time_list

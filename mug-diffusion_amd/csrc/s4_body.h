@@ -141,7 +141,7 @@ __device__ __forceinline__ void s4_conv_fast_row(const A& a, const int h, const 
     for (int i = tid; live && i < L; i += 256) {
         const int i1 = LP + i;
         const float conv = ((part[0][i] + part[1][i]) + part[2][i]) + part[3][i];
-        y[i] = gelu_erf_f(conv + Dh * uw[i1 + (i1 >> 5)]);
+        y[i] = gelu_gate(conv + Dh * uw[i1 + (i1 >> 5)]);
     }
 }
 

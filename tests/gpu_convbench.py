@@ -72,7 +72,7 @@ def compare(lib):
 def forms(lib):
     """round 6: the M-split geometries (waves per workgroup x K-slices; conv_body.h: MS) against the host's own choice on the tall-M launches of
     the batch-4 step (gated projections, q/k/v) -- wk = 0x100 | waves << 4 | kslices forces a form where it exists (include/mugd.h)."""
-    cand = [("auto", 0), ("K-split wk2", 2), ("K-split wk4", 4), ("2x1", 0x121), ("4x1", 0x141), ("8x1", 0x181), ("2x2", 0x142), ("4x2", 0x182), ("2x4", 0x184)]
+    cand = [("auto", 0), ("K-split wk2", 2), ("K-split wk4", 4), ("2x1", 0x121), ("4x1", 0x141), ("8x1", 0x181), ("2x2", 0x142), ("4x2", 0x182)]
     print("%-16s %7s | %s" % ("shape", "GFLOP", "  ".join("%11s" % n for n, _ in cand)))
     for name, B, C, T, M, taps, norm, gated in SWEEP:
         if not (name.startswith("ff1") or name.startswith("qkv") or name.startswith("s4glu")):
@@ -86,8 +86,24 @@ def forms(lib):
             print("%-16s %7.3f | %s" % ("%s B%d" % (name, Bb), gf, "  ".join("%8.2f us" % u for u in row)), flush=True)
 
 
+def icache(lib):
+    """round 6: what a launch pays for starting with COLD code.  Per hot shape: back-to-back launches of one kernel (its code stays in the
+    instruction caches) against the same launches each preceded by a kernel that walks 128 KB of straight-line code on every CU
+    (MUGD_BENCH_THRASH, csrc/k_misc.hip) -- minus that kernel's own time."""
+    print("%-16s | warm us | cold us (thrash + conv - thrash alone) | penalty us" % "shape")
+    for name, B, C, T, M, taps, norm, gated in SWEEP:
+        copies = max(1, int(300e6 / (M * C * taps * 4)))
+        r = {}
+        for mode in ("0", "1", "2"):
+            os.environ["MUGD_BENCH_THRASH"] = mode
+            r[mode] = min(lib.dev_bench_conv(B, C, T, M, taps, norm, bool(gated), wk=0, tn=0, copies=copies, iters=100) for _ in range(3))
+        os.environ["MUGD_BENCH_THRASH"] = "0"
+        print("%-16s | %7.2f | %7.2f (%6.2f - %6.2f) | %+6.2f" % (name, r["0"], r["1"] - r["2"], r["1"], r["2"], r["1"] - r["2"] - r["0"]), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--icache", action="store_true")
     ap.add_argument("--forms", action="store_true")
     ap.add_argument("--sweep", action="store_true")
     ap.add_argument("--compare", action="store_true")
@@ -102,6 +118,8 @@ def main():
         compare(get_lib())
         return
     lib = get_lib()
+    if a.icache:
+        return icache(lib)
     if a.forms:
         return forms(lib)
     if a.sweep:

@@ -19,7 +19,9 @@
 #   instr          executed instructions per wave by class (the r4_pmc_instr_per_wave table)
 #   layers:B       per-launch table of one U-Net / VAE / wave evaluation at batch B (MUGD_PROFILE_CSV)
 #   probe:B        tests/gpu_probe.py at batch B (all pieces of the pipeline)
+#   timeline:B     per-wave phase timeline of one U-Net evaluation at batch B (development library tests/tl/libmugd_tl.so)
 #   overlap        tests/gpu_overlap_probe.hip: a chain of dependent conv-shaped launches in order vs released early + epoch polling (round 6)
+#   icache         tests/gpu_convbench.py --icache: per hot shape, launches with warm vs evicted instruction caches (round 6)
 #   forms          tests/gpu_convbench.py --forms: M-split geometries vs the host's choice on the tall-M launches (round 6)
 #   hostq          host microseconds to enqueue one U-Net evaluation (mugd_net_host_enqueue), in-tree library
 #   env:K=V        export K=V for the tasks that follow
@@ -40,6 +42,9 @@ for task in "$@"; do
     env) export "$arg" ;;
     overlap)
       ( hipcc --offload-arch=gfx950 -O3 -o /tmp/overlap_probe tests/gpu_overlap_probe.hip && timeout 300 /tmp/overlap_probe 400 ) > ${O}_overlap.txt 2>&1; cat ${O}_overlap.txt ;;
+    icache)
+      timeout 600 python tests/gpu_convbench.py --icache > ${O}_icache.txt 2>&1; cat ${O}_icache.txt
+      for v in $IC_OTHERS; do MUGD_LIB_LENIENT=1 MUGD_LIB_PATH=$PWD/tests/var/$v/libmugd.so timeout 600 python tests/gpu_convbench.py --icache > ${O}_icache_$v.txt 2>&1; cat ${O}_icache_$v.txt; done ;;
     forms)
       timeout 600 python tests/gpu_convbench.py --forms > ${O}_forms.txt 2>&1; cat ${O}_forms.txt ;;
     hostq)
@@ -161,6 +166,12 @@ PY
       rm -f ${O}_per_layer_z512_b$arg.csv
       MUGD_PROFILE_CSV=${O}_per_layer_z512_b$arg.csv timeout 300 python tests/gpu_probe.py --B $arg > ${O}_probe_b$arg.txt 2>&1
       grep -E "ddim|vae decode|wave encode|log-mel|unet forward|TFLOP" ${O}_probe_b$arg.txt ;;
+    timeline)
+      # timeline:B -- per-wave phase stamps of every conv_gemm launch of one U-Net evaluation (tests/tl/libmugd_tl.so: build.py --tl, built in the authoring container)
+      timeout 600 python tests/gpu_timeline.py --z 512 --B $arg --out ${O}_timeline_z512_b$arg.csv > /dev/null 2>${O}_timeline_err.log; head -16 ${O}_timeline_z512_b$arg.txt
+      for v in $TL_OTHERS; do      # env:TL_OTHERS="r5tl ..." -- the same with tests/var/<name>/libmugd.so (a -DMUGD_TL build of another revision)
+        timeout 600 python tests/gpu_timeline.py --z 512 --B $arg --lib tests/var/$v/libmugd.so --out ${O}_timeline_${v}_z512_b$arg.csv > /dev/null 2>>${O}_timeline_err.log; head -16 ${O}_timeline_${v}_z512_b$arg.txt
+      done ;;
     probe)
       timeout 300 python tests/gpu_probe.py --B $arg > ${O}_probe_b$arg.txt 2>&1; grep -E "ddim|vae decode|wave encode|log-mel|unet forward|TFLOP" ${O}_probe_b$arg.txt ;;
     *) echo "unknown task $task" ;;

@@ -67,10 +67,13 @@ def main():
     ap.add_argument("--B", type=int, default=4)
     ap.add_argument("--out", default="gpurun_out/timeline.csv")
     ap.add_argument("--raw-op", type=int, default=-2, help="also dump every wave's raw record of this op index (-1: all)")
+    ap.add_argument("--lib", default=TL_LIB, help="another -DMUGD_TL build (build.py --rev <rev> <name> MUGD_TL=1): same-box comparisons")
     a = ap.parse_args()
-    if not os.path.exists(TL_LIB):
+    if not os.path.exists(a.lib):
         raise SystemExit("build the timeline library first: python mug-diffusion_amd/build.py --tl")
-    lib = Lib(path=TL_LIB)
+    if a.lib != TL_LIB:
+        os.environ["MUGD_LIB_PATH"] = a.lib; os.environ["MUGD_LIB_LENIENT"] = "1"
+    lib = Lib(path=a.lib)
     lib.dll.raw.mugd_dev_timeline.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int]
     lib.dll.raw.mugd_dev_timeline.restype = C.c_int
     case = cases.FULL
