@@ -108,6 +108,15 @@ __device__ __forceinline__ float sigmoid_gate(float x) {
 #endif
 }
 
+// sum over the 16 lanes of a DPP row, left in EVERY lane of the row: four row rotations (v_add with a DPP operand: no LDS crossbar trip, ~10
+// cycles each) instead of four ds_bpermute round trips (~60 - 100 cycles each, dependent)
+__device__ __forceinline__ float row16_sum(float v) {
+#define MUGD_ROW_ROR_ADD(n) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + (n), 0xf, 0xf, false))
+    MUGD_ROW_ROR_ADD(1); MUGD_ROW_ROR_ADD(2); MUGD_ROW_ROR_ADD(4); MUGD_ROW_ROR_ADD(8);
+#undef MUGD_ROW_ROR_ADD
+    return v;
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // n / d with m = ceil(2^32 / d) precomputed on the host (conv_fastdiv_mul); d == 1 is encoded as m == 0.  The estimate

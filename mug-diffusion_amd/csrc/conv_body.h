@@ -1354,8 +1354,9 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
         for (int q = 0; q < EPT; ++q) {
             float s1 = valid[q] ? acc_v[q] : 0.f;
             float s2 = s1 * s1;
-#pragma unroll
-            for (int o = 1; o < TN; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+            // the tile's columns of one row sit in 16 (TN = 16) or 2 x 16 (TN = 32) consecutive lanes: DPP row sums, one shuffle across the rows
+            s1 = row16_sum(s1); s2 = row16_sum(s2);
+            if (TN == 32) { s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16); }
             const int r = rbase + q;
             const int m = mtw * 32 + G::row(r, lane);
             if (live && cl == 0 && m < a.Mout) {

@@ -82,6 +82,10 @@ __global__ __launch_bounds__(256) void ddim_step_kernel(const DdimStepArgs a) {
     const int nrow = a.mode ? (step + 1 < S ? step + 1 : step) : step;
     const float* row = a.emb_table + (size_t)nrow * a.emb_total;
     for (int j = i; j < a.Bnet * a.emb_total; j += gridDim.x * blockDim.x) a.emb_rows[j] = row[j % a.emb_total];
+    if (a.zero_p) {                                  // the next evaluation's GroupNorm row-sum accumulators (16-byte stores)
+        double2* z = reinterpret_cast<double2*>(a.zero_p);
+        for (long long j = i; j < a.zero_n / 2; j += (long long)gridDim.x * blockDim.x) z[j] = make_double2(0.0, 0.0);
+    }
     if (a.mode) {
         __syncthreads();
         if (threadIdx.x == 0) {

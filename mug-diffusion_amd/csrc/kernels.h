@@ -339,6 +339,8 @@ struct DdimStepArgs {
     float* emb_rows;         // [Bnet][emb_total]
     int n, cfg, Bnet, emb_total, mode;
     float scale;
+    double* zero_p; long long zero_n;   // null, or the U-Net program's fp64 row-sum accumulators (ConvArgs::rowstat): cleared here for the NEXT evaluation,
+                                        // so that the step needs no separate fill launch (even count: the block is padded to 32 doubles per tensor)
 };
 void launch_ddim_step(hipStream_t st, const DdimStepArgs& a);
 // audio ingest (k_resample.hip): scipy.signal.resample_poly / librosa res_type="polyphase"

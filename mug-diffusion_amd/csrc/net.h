@@ -177,6 +177,7 @@ protected:
     // fp64 row-sum accumulators: one contiguous block per program, zeroed by the first op of every step
     double* alloc_rowstat(size_t ndoubles);
     double* rs_base = nullptr; size_t rs_top = 0, rs_cap = 0;
+    int rs_zero_op = -1; size_t rs_zero_n = 0;                // index of the program's "zero the accumulators" op (-1: none) and the doubles it clears
     void begin_rowstat();                                     // call at the start of build(): emits the per-step memset
     Tensor group_norm(const std::string& prefix, const std::vector<Tensor>& segs, int groups, bool silu);   // stand-alone kernel
     Tensor layer_norm(const std::string& prefix, const Tensor& x);

@@ -411,8 +411,10 @@ void Net::begin_rowstat() {
             rs_cap = rs_top;
             rs_base = reinterpret_cast<double*>(dev_alloc(rs_cap * 2));
         }
+        rs_zero_op = -1; rs_zero_n = 0;
         if (rs_cap) {
             double* p = rs_base; const size_t bytes = rs_top * sizeof(double);
+            rs_zero_op = (int)ops.size(); rs_zero_n = rs_top;       // (the DDIM loop zeroes them from its per-step kernel instead: UNet::step_body)
             emit([p, bytes](hipStream_t st) { HIP_CHECK(hipMemsetAsync(p, 0, bytes, st)); }, OP_SMALL, 0, "zero row-sum accumulators");
         }
     }
@@ -1115,12 +1117,16 @@ DdimStepArgs UNet::step_args(bool cfg_on, float scale, bool with_noise, bool wit
     d.sched = sched_dev; d.step_idx = step_dev; d.ticket = ticket_dev; d.in_x = in_x.p;
     d.emb_table = emb_table; d.emb_rows = emb_rowadd;
     d.n = nstate; d.cfg = cfg_on ? 1 : 0; d.Bnet = key.B; d.emb_total = rowadd_total; d.mode = mode; d.scale = scale;
+    d.zero_p = rs_zero_op >= 0 ? rs_base : nullptr; d.zero_n = rs_zero_op >= 0 ? (long long)rs_zero_n : 0;
     return d;
 }
 
 // one DDIM step = the U-Net program + ONE more launch (CFG combine, DDIM update, next input, next time-embedding rows, counter)
 void UNet::step_body(hipStream_t st, bool cfg_on, float scale, bool with_noise, bool with_pred, bool with_first, int nstate, int S) {
-    run_ops(st);
+    // the program without its "zero the row-sum accumulators" fill: the per-step kernel of the PREVIOUS step (mode 0 before the first) has
+    // zeroed them (DdimStepArgs::zero_p) -- one launch less per step
+    for (size_t i = 0; i < ops.size(); ++i)
+        if ((int)i != rs_zero_op) ops[i].fn(st);
     launch_ddim_step(st, step_args(cfg_on, scale, with_noise, with_pred, with_first, nstate, S, 1));
 }
 
