@@ -140,14 +140,12 @@ struct WgStats {
             if constexpr (LPG == 16) {
                 // 8-wave workgroups: a group's 16 lanes are one DPP row -- four row rotations of the two dwords of each sum (v_mov_dpp) instead of
                 // four ds_bpermute round trips per dword; every lane of the row ends up with the group's totals
-#pragma unroll
-                for (int n = 1; n < 16; n <<= 1) {
-                    const double r1 = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(s1), 0x120 + n, 0xf, 0xf, false),
-                                                       __builtin_amdgcn_update_dpp(0, __double2loint(s1), 0x120 + n, 0xf, 0xf, false));
-                    const double r2 = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(s2), 0x120 + n, 0xf, 0xf, false),
-                                                       __builtin_amdgcn_update_dpp(0, __double2loint(s2), 0x120 + n, 0xf, 0xf, false));
-                    s1 += r1; s2 += r2;
-                }
+#define MUGD_ROR_D(v, n) __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + (n), 0xf, 0xf, false), \
+                                          __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + (n), 0xf, 0xf, false))
+#define MUGD_ROR_STEP(n) { const double r1 = MUGD_ROR_D(s1, n), r2 = MUGD_ROR_D(s2, n); s1 += r1; s2 += r2; }
+                MUGD_ROR_STEP(1) MUGD_ROR_STEP(2) MUGD_ROR_STEP(4) MUGD_ROR_STEP(8)      // (the DPP control is an immediate: no loop variable)
+#undef MUGD_ROR_STEP
+#undef MUGD_ROR_D
             } else {
 #pragma unroll
                 for (int o = 1; o < LPG; o <<= 1) { s1 += shfl_xor_d(s1, o); s2 += shfl_xor_d(s2, o); }
