@@ -96,9 +96,16 @@ int mugd_set_weight_precision(mugd_ctx* ctx, int bf16);
  *   normalised activations  (GroupNorm / LayerNorm (+ SiLU) applied while the operand is staged) one static scale per tensor from the bound
  *                           |v| <= max|gamma| sqrt(n) + max|beta| (n = elements per statistic): samples down to 2^-27 of the bound keep
  *                           all 22 bits, smaller ones carry an absolute error below 2^-50 of the bound.
- * Inf / NaN operands propagate to exactly the outputs they reach in fp32.  tests/test_ops.py holds op_conv1d / op_norm_conv1d / log_mel
- * to the unit-scale fp32 tolerance at operand scales 1e-30 .. 1e30 (weights, inputs, affine parameters), with channel blocks 2^40 apart
- * inside one reduction, on every tile form. */
+ * One bound ties the chunks of a reduction together: the accumulators of a wave never rise more than 2^64 above the smallest scale they hold
+ * products at (they must stay finite), so a chunk whose largest sample is more than 2^64 BELOW the largest sample that wave has already
+ * summed is carried with an absolute error (or, in the tile forms whose waves share staged windows, dropped): it is below 2^-40 of the fp32
+ * rounding error of the terms already in the sum.  What a wave promises is therefore an error relative to the largest operand of ITS walk
+ * through K, not relative to each output row's own magnitude.
+ * Inf / NaN operands propagate to exactly the outputs they reach in fp32 (a chunk's scale follows its FINITE samples).  tests/test_ops.py holds
+ * op_conv1d / op_norm_conv1d / log_mel to the unit-scale fp32 tolerance at operand scales 1e-30 .. 1e30 (weights, inputs, affine parameters),
+ * with channel blocks 2^40 apart inside one reduction and -- finite, at the tolerance of the large terms -- 2^200 apart, on every tile form.
+ * The exact-erf GELU of the GEGLU projections and of the S4 layers and the GLU's sigmoid are evaluated branch-free with the device library's
+ * own minimax polynomials and v_exp_f32 / v_rcp_f32 (csrc/common.h: erf_fast: <= 8.7e-8 absolute from float64 erf, the accuracy of erff). */
 const char* mugd_version(void);
 
 /* ---- networks ------------------------------------------------------------------------- */

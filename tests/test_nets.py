@@ -424,3 +424,26 @@ def test_one_handle_follows_changing_lengths_and_batches(lib):
         first[(z, B)] = got
         orc = nets.unet_forward(sd64, case["unet"], x, t, c, [m.repeat(B, 1, 1) for m in w])
         assert (got - orc).abs().max().item() < 2e-4 * max(1.0, orc.abs().max().item())
+
+
+def test_host_enqueue_hook_replays_the_compiled_program(lib):
+    """mugd_net_host_enqueue (include/mugd.h): wall clock around back-to-back enqueues of the last compiled program -- it reports the program's
+    op count and a positive time, refuses a network that has not run yet, and leaves the program's results as they were (the program includes
+    its own accumulator reset)."""
+    case = cases.TINY
+    z, B = 32, 2
+    sd = state_dict(case, z)
+    n = lib.unet(case["unet"])
+    n.set_params(sd, "model.unet_model.")
+    with pytest.raises(Exception):
+        n.host_enqueue(1)
+    x = cases.x_T(1, B, z)
+    t = torch.tensor([501, 21], dtype=torch.long)
+    c = cases.context(case, 1, B)
+    w = [m.repeat(B, 1, 1) for m in cases.audio_maps(case, 1, 1, z)]
+    a = n.forward(x, t, c, w).detach().cpu()
+    us, ops = n.host_enqueue(3)
+    assert ops > 10 and us > 0.0
+    b = n.forward(x, t, c, w).detach().cpu()
+    assert (a - b).abs().max().item() <= 2e-6 * max(1.0, a.abs().max().item())
+    n.close()

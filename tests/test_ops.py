@@ -208,6 +208,30 @@ def test_conv1d_gated(lib, epi):
     close(lib.op_conv1d(x, w, b, epi=epi), ref, 2e-5, what="gated conv")
 
 
+@pytest.mark.parametrize("epi", [1, 2])
+def test_fast_erf_and_sigmoid_match_the_library_forms(lib, epi):
+    """The gated epilogues' branch-free erf-GELU / sigmoid (csrc/common.h: erf_fast, gelu_gate, sigmoid_gate) on a dense sweep of gate values,
+    isolated from the GEMM: value rows = 1 (zero weights, unit bias), gate rows = one input channel each (unit weight), so the output IS
+    gelu(x) resp. sigmoid(x) up to the exact products 1 * x.  Against float64: the accuracy of torch's / libm's fp32 forms (a few 1e-7 of
+    max(1, |x|)), on both sides of the polynomial switch at |x / sqrt(2)| = 1 and out to where erf saturates."""
+    C, T = 16, 2048
+    xs = torch.linspace(-9.0, 9.0, C * T, dtype=torch.float64).reshape(T, C).t().contiguous()      # channel c, sample t
+    x = xs.float()[None]                                                                             # (1, C, T)
+    M = 64                                                                                           # rows 0..31 value, 32..63 gate
+    w = torch.zeros(M, C, 1)
+    for m in range(32):
+        w[32 + m, m % C, 0] = 1.0
+    b = torch.zeros(M)
+    b[:32] = 1.0
+    got = lib.op_conv1d(x, w, b, epi=epi).detach().cpu().double()[0]                                # (32, T): row m = gate channel m % 16
+    g = x[0].double()
+    ref = (torch.sigmoid(g) if epi == 1 else 0.5 * g * (1.0 + torch.erf(g / math.sqrt(2.0))))
+    for m in range(32):
+        err = (got[m] - ref[m % C]).abs()
+        tol = 4e-7 * torch.clamp(g[m % C].abs(), min=1.0)
+        assert (err <= tol).all(), (epi, m, float((err / tol).max()))
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # The DOMAIN of conv_gemm's split-f16 arithmetic (csrc/conv_body.h: "The DOMAIN of H3").  The reference is fp32 with a +-3e38 range
 # (/root/reference/mug/diffusion/unet.py:27-33: convert_module_to_f16 is a no-op); f16 halves alone overflow above 65504 and lose their
