@@ -1093,7 +1093,13 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
     char* smem_bytes = lds;
     const int wave_base = MS ? wks * (2 * NR * G::WIN_LDS * 4) : wave * G::WAVE_LDS * 4;      // M-split: the K-slice's set of 2 x NR shared windows
 
+#ifdef MUGD_EMULATED
     const float gn_inv_cg = a.gn_groups ? 1.0f / (float)a.gn_cg : 0.f;
+#else
+    // (v_rcp_f32, not the IEEE division sequence every launch used to walk through: the quotient (c + 0.5) / cg is only floored, and c + 0.5
+    // sits half a channel away from every group boundary)
+    const float gn_inv_cg = a.gn_groups ? __builtin_amdgcn_rcpf((float)a.gn_cg) : 0.f;
+#endif
 
     // ---- epilogue operands: the side loads (bias / row term / residual) are issued HERE, before the K loop, from
     // clamped addresses under wave-uniform conditions, so their latency is off the kernel's critical path.
@@ -1229,15 +1235,25 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
         for (int su = 1; su < nseg; ++su) run_seg(am->seg[su], NoPrePark());
     }
 #else
-    pre_park();
-    if (__builtin_expect(careful_start, 0)) redo = true;
-    else {
-        // (this loop MUST be fully unrolled: left rolled, the dynamic index a.seg[su] moves the whole by-value argument block into scratch memory
-        // -- 688 bytes per lane and +20 us per launch, seen in round 5 -- which is why the chunk loops stay lean enough for the unroller:
-        // build.py's guard fails the build if it ever happens again)
+    if constexpr (DUAL && KIND != 2) {
+        // A gated launch has ONE segment (conv_prepare: a single 1x1 input): no loop, no segment pointer to carry, and -- the one place where
+        // it pays -- the statistics reduction BEHIND the segment's operand requests (pre_park inside run_segment_vec): the LayerNorm-fed GEGLU
+        // projections are tall (64 - 128 row tiles re-stage the same window), their operand ring takes 2 - 4 us to issue, and the reduction
+        // used to sit in front of it (phase timeline, one box: entry -> first chunk parked 6.1 vs 9.0 us on ff.net.0.proj M = 4096,
+        // profiles/r6_timeline_*).  These kernels have the registers for it since they lost the loop (184 - 208 VGPRs, no scratch).
+        if (__builtin_expect(careful_start, 0)) { pre_park(); redo = true; }
+        else run_seg(a.seg[0], pre_park);
+    } else {
+        pre_park();
+        if (__builtin_expect(careful_start, 0)) redo = true;
+        else {
+            // (this loop MUST be fully unrolled: left rolled, the dynamic index a.seg[su] moves the whole by-value argument block into scratch
+            // memory -- 688 bytes per lane and +20 us per launch, seen in round 5 -- which is why the chunk loops stay lean enough for the
+            // unroller: build.py's guard fails the build if it ever happens again)
 #pragma unroll
-        for (int su = 0; su < CONV_MAXSEG; ++su)
-            if (su < nseg) run_seg(a.seg[su], NoPrePark());
+            for (int su = 0; su < CONV_MAXSEG; ++su)
+                if (su < nseg) run_seg(a.seg[su], NoPrePark());
+        }
     }
 #endif
     pre_park();                                      // (a wave that ran no segment-0 chunk loop -- an unspecialised transform, an empty slice: the barrier count must match)

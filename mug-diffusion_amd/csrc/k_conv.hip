@@ -254,6 +254,7 @@ static void prepare_conv32(ConvLaunch& L) {
                        a.nseg == 1 && a.seg[0].taps == 1, -2, "conv_gemm: bad cross-attention score epilogue");
     MUGD_CHECK((!a.colstat && !a.rowstat) || !dual, -2, "conv_gemm: row / column sums are not produced by gated epilogues");
     if (dual) {
+        MUGD_CHECK(a.nseg == 1, -2, "conv_gemm: gated epilogue takes a single input segment");      // (conv_body.h: the gated kernels run segment 0 only)
         MUGD_CHECK(a.Mout % 32 == 0 && a.Mrows == 2 * a.Mout, -2, "conv_gemm: gated epilogue needs Mout % 32 == 0");
         for (int i = 0; i < a.nseg; ++i) MUGD_CHECK(a.seg[i].taps == 1, -2, "conv_gemm: gated epilogue is implemented for 1x1 convs");
     }
@@ -446,7 +447,7 @@ static void prepare_conv16(ConvLaunch& L) {
         MUGD_CHECK(a.xs_rel && a.xs_cemb && a.xs_heads > 0 && a.Mout == 32 * a.xs_heads && a.xs_ntok >= 1 && a.xs_ntok <= 32 && !a.rowstat && !a.colstat &&
                        a.nseg == 1 && a.seg[0].taps == 1, -2, "conv_gemm: bad cross-attention score epilogue");
     MUGD_CHECK((!a.colstat && !a.rowstat) || !dual, -2, "conv_gemm (16-wide): row / column sums are not produced by gated epilogues");
-    if (dual) MUGD_CHECK(a.Mout % 32 == 0 && a.Mrows == 2 * a.Mout, -2, "conv_gemm (16-wide): gated epilogue needs Mout % 32 == 0");
+    if (dual) MUGD_CHECK(a.nseg == 1 && a.Mout % 32 == 0 && a.Mrows == 2 * a.Mout, -2, "conv_gemm (16-wide): gated epilogue needs one segment and Mout % 32 == 0");
     else MUGD_CHECK(a.Mrows == a.Mout, -2, "conv_gemm (16-wide): Mrows != Mout");
     const int gx = cdiv(a.Tout, 16), gy = cdiv(a.Mout, 32), gz = a.B;
     int wk = (a.wk > 0 && a.wk < 0x100) ? a.wk : conv_pick_wk_tiles((long long)gx * gy * gz, a.nchunk);

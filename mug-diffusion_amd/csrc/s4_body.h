@@ -111,30 +111,72 @@ __device__ __forceinline__ void s4_conv_fast_row(const A& a, const int h, const 
     __syncthreads();
 
     const int t0 = lane * R, s0 = wave * SEG;
-    float w[R], acc[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int i = LP + t0 + r - s0;
-        w[r] = uw[i + (i >> 5)];
-        acc[r] = 0.f;
-    }
     const int base = LP + t0 - 1 - s0;               // sample index of u[t0 - s0 - 1]
     constexpr int STEP = R < SEG ? R : SEG;          // R = 1: SEG = 16 taps, one per iteration
     const int s_end = (L - s0 < SEG) ? (L - s0) : SEG;     // taps >= L are zero: skip whole blocks of them
-    for (int s = 0; s < s_end; s += STEP) {
-        float kv[R];
+    if constexpr (R >= 2) {
+        // Round 6: the R multiply-adds of a tap as R / 2 PACKED fp32 FMAs (v_pk_fma_f32: two lanes' worth per issue slot -- this loop is the
+        // kernel, and it is bound by the VALU at 4 cycles per wave instruction).  A packed operand is an even-aligned register pair, and the
+        // window slides by ONE sample per tap, so the window is kept twice: WA pairs (w0 w1)(w2 w3)..., WB the same window shifted by one,
+        // (w1 w2)(w3 w4)...(w[R-1] w0); even taps read WA, odd taps WB; a tap's new sample goes into both (one extra move per tap).  The tap
+        // coefficient is broadcast to both halves by the instruction's operand select.  Same products, same order per output: bit-identical
+        // to the scalar form.
+        typedef float s4f2 __attribute__((ext_vector_type(2)));
+        s4f2 WA[R / 2], WB[R / 2], acc2[R / 2];
 #pragma unroll
-        for (int j = 0; j < STEP; ++j) kv[j] = ks[s0 + s + j];
-#pragma unroll
-        for (int j = 0; j < STEP; ++j) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] += kv[j] * w[(r - j + R) % R];      // w[(r-j) mod R] holds u[t0 + r - (s0+s+j)]
-            const int i = base - (s + j);
-            w[(2 * R - 1 - j) % R] = uw[i + (i >> 5)];                               // u[t0 - (s0+s+j) - 1] for the next tap
+        for (int r = 0; r < R; ++r) {
+            const int i = LP + t0 + r - s0;
+            const float v = uw[i + (i >> 5)];
+            WA[r / 2][r % 2] = v;
+            WB[((r + R - 1) % R) / 2][((r + R - 1) % R) % 2] = v;          // WB[i] = w[i + 1]
         }
-    }
 #pragma unroll
-    for (int r = 0; r < R; ++r) part[wave][t0 + r] = acc[r];
+        for (int p = 0; p < R / 2; ++p) acc2[p] = (s4f2){0.f, 0.f};
+        for (int s = 0; s < s_end; s += STEP) {
+            float kv[R];
+#pragma unroll
+            for (int j = 0; j < STEP; ++j) kv[j] = ks[s0 + s + j];
+#pragma unroll
+            for (int j = 0; j < STEP; ++j) {
+                const s4f2 kk = {kv[j], kv[j]};
+#pragma unroll
+                for (int p = 0; p < R / 2; ++p) {
+                    const int a0 = ((2 * p - j) % R + R) % R;                  // window index of output 2p's sample for this tap
+                    const s4f2 wv = (j % 2 == 0) ? WA[a0 / 2] : WB[((a0 + R - 1) % R) / 2];      // (w[a0], w[a0 + 1])
+                    acc2[p] = __builtin_elementwise_fma(kk, wv, acc2[p]);
+                }
+                const int i = base - (s + j);
+                const float nv = uw[i + (i >> 5)];                              // u[t0 - (s0+s+j) - 1] for the next tap
+                const int q = (2 * R - 1 - j) % R;
+                WA[q / 2][q % 2] = nv;
+                WB[((q + R - 1) % R) / 2][((q + R - 1) % R) % 2] = nv;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) part[wave][t0 + r] = acc2[r / 2][r % 2];
+    } else {
+        float w[R], acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = LP + t0 + r - s0;
+            w[r] = uw[i + (i >> 5)];
+            acc[r] = 0.f;
+        }
+        for (int s = 0; s < s_end; s += STEP) {
+            float kv[R];
+#pragma unroll
+            for (int j = 0; j < STEP; ++j) kv[j] = ks[s0 + s + j];
+#pragma unroll
+            for (int j = 0; j < STEP; ++j) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] += kv[j] * w[(r - j + R) % R];      // w[(r-j) mod R] holds u[t0 + r - (s0+s+j)]
+                const int i = base - (s + j);
+                w[(2 * R - 1 - j) % R] = uw[i + (i >> 5)];                               // u[t0 - (s0+s+j) - 1] for the next tap
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) part[wave][t0 + r] = acc[r];
+    }
     __syncthreads();
     const float Dh = a.D[h];
     float* y = a.y + ((size_t)b * a.H + h) * L;
