@@ -1235,12 +1235,14 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
         for (int su = 1; su < nseg; ++su) run_seg(am->seg[su], NoPrePark());
     }
 #else
-    if constexpr (DUAL && KIND != 2) {
+    if constexpr (DUAL && KIND != 2 && TN == 32) {
         // A gated launch has ONE segment (conv_prepare: a single 1x1 input): no loop, no segment pointer to carry, and -- the one place where
         // it pays -- the statistics reduction BEHIND the segment's operand requests (pre_park inside run_segment_vec): the LayerNorm-fed GEGLU
         // projections are tall (64 - 128 row tiles re-stage the same window), their operand ring takes 2 - 4 us to issue, and the reduction
         // used to sit in front of it (phase timeline, one box: entry -> first chunk parked 6.1 vs 9.0 us on ff.net.0.proj M = 4096,
         // profiles/r6_timeline_*).  These kernels have the registers for it since they lost the loop (184 - 208 VGPRs, no scratch).
+        // (32-wide tiles only: the 16-wide gated tiles -- the S4 GLU projections of the deepest level, 4 launches per evaluation -- have a short
+        // ring and measured 8.5 vs 7.5 us with the reduction behind it)
         if (__builtin_expect(careful_start, 0)) { pre_park(); redo = true; }
         else run_seg(a.seg[0], pre_park);
     } else {

@@ -15,6 +15,7 @@
 #   convbench:L1,L2    us per launch of every hot conv shape (tests/gpu_convbench.py --compare), in-tree library and tests/var/L*
 #   traffic        FETCH_SIZE / WRITE_SIZE of conv_gemm (separate --pmc passes) -> TAG_conv_traffic.json
 #   train_traffic  FETCH_SIZE / WRITE_SIZE of a bf16 batch-32 training step by kernel class (tests/pp_train_pmc.py)
+#   train_stats    rocprofv3 --kernel-trace --stats of the bf16 batch-32 training step (tests/gpu_train_probe.py)
 #   mfma           matrix-pipe busy / VALU counters of one U-Net evaluation
 #   instr          executed instructions per wave by class (the r4_pmc_instr_per_wave table)
 #   layers:B       per-launch table of one U-Net / VAE / wave evaluation at batch B (MUGD_PROFILE_CSV)
@@ -145,6 +146,11 @@ PY
       (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_$TAG/fetch -- python $OLDPWD/tests/gpu_unet_once.py --n 2) > ${O}_pmc_fetch.log 2>&1
       (cd /tmp && timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_$TAG/write -- python $OLDPWD/tests/gpu_unet_once.py --n 2) > ${O}_pmc_write.log 2>&1
       python tests/pmc_summary.py /tmp/pmc_$TAG ${O}_conv_traffic.json | tail -8 ;;
+    train_stats)
+      rm -rf /tmp/ts_$TAG
+      (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ts_$TAG -- python $OLDPWD/tests/gpu_train_probe.py --B 32 --reps 4 --bf16 --adamw) > ${O}_train_stats.log 2>&1
+      f=$(find /tmp/ts_$TAG -name "*kernel_stats.csv" | head -1); cp "$f" ${O}_train_kernel_stats.csv; grep -i "step" ${O}_train_stats.log | tail -3
+      python tests/pp_train_trace.py /tmp/ts_$TAG ${O}_train_step_digest.txt; head -60 ${O}_train_step_digest.txt ;;
     train_traffic)
       rm -rf /tmp/pmct_$TAG
       (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmct_$TAG/fetch -- python $OLDPWD/tests/gpu_train_probe.py --B 32 --reps 2 --bf16 --adamw) > ${O}_pmc_train_fetch.log 2>&1
