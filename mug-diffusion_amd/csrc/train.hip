@@ -803,7 +803,12 @@ int mugd_train_add(mugd_ctx* ctx, const float* a, const float* b, float* out, in
 
 int mugd_train_release_states(mugd_ctx* ctx) {
     return guarded(ctx, [&] {
-        HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
+        // The pool is STREAM-ORDERED like every Scratch block (a block given back is only ever handed to launches enqueued later on the context's
+        // stream), so nothing waits here -- round 6: the hipStreamSynchronize that used to stand here drained the device twice per training step,
+        // in front of the step's reduction-table launch and AdamW: 0.5 - 1.8 ms of idle GPU per batch-32 step (tests/pp_train_trace.py) and a
+        // host that could never run ahead.  (With the weight-gradient side stream on, its kernels may still read saved tensors: join first.)
+        if (ctx->saved.empty()) return;
+        if (ctx->step.side_mode) HIP_CHECK(hipStreamSynchronize(ctx->c.stream));
         for (auto& kv : ctx->saved)
             for (void* p : kv.second) ctx->pool.give(p);
         ctx->saved.clear();
