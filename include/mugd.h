@@ -320,7 +320,8 @@ typedef struct {
  * keeps the block inputs of its forward sweep and calls the block again with dy in the backward sweep (block-level checkpointing).
  * `state` (last argument of the five block entry points, nullable): forward-only call with state != NULL -> the block KEEPS its forward
  * intermediates and writes an id to *state; backward call with that id (same x / emb / context / parameters) -> the forward is not
- * recomputed, the intermediates are released and *state is cleared.  mugd_train_release_states drops ids that were never consumed. */
+ * recomputed, the intermediates are released and *state is cleared.  mugd_train_release_states drops ids that were never consumed; it does
+ * not wait for the device (their blocks go back to the context's stream-ordered scratch pool). */
 int mugd_train_release_states(mugd_ctx* ctx);
 int mugd_train_resblock(mugd_ctx* ctx, const mugd_resblock_params* p, const float* x, const float* emb, const float* dy, float* y, float* dx,
                         float* demb, const mugd_resblock_grads* g, int B, int Cin, int Cout, int T, int Kemb, int groups, int64_t* state);
