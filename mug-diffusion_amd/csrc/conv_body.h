@@ -1367,7 +1367,8 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
     }
     TL_STAMP(5);
     // ---- optional: add this tile's {sum, sum of squares} per row to the fp64 row accumulators (GroupNorm of the consumers)
-    if (!DUAL && a.rowstat) {
+    const bool group_sinks = !DUAL && MS == 0 && a.gsink[0].p != nullptr;      // (wave-uniform: a kernel argument)
+    if (!DUAL && (a.rowstat || group_sinks)) {
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
             float s1 = valid[q] ? acc_v[q] : 0.f;
@@ -1377,10 +1378,42 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
             if (TN == 32) { s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16); }
             const int r = rbase + q;
             const int m = mtw * 32 + G::row(r, lane);
-            if (live && cl == 0 && m < a.Mout) {
+            if (a.rowstat && live && cl == 0 && m < a.Mout) {
                 double* o = a.rowstat + 2 * ((size_t)b * a.Mout + m);
                 atomicAdd(o, (double)s1);
                 atomicAdd(o + 1, (double)s2);
+            }
+            if (MS == 0 && group_sinks && cl == 0) stl.grow[G::row(r, lane)] = make_float2(s1, s2);      // (rows beyond Mout: zeros)
+        }
+    }
+    // ---- optional: this tile's sums per GROUP of the consumers' GroupNorm domains (ConvArgs::gsink, round 6): the 32 row sums meet in LDS, lane j of
+    // each half of wave 0 owns the j-th group the tile touches in sink 0 / sink 1 and adds ONE fp64 pair -- the consumers then load finished group
+    // sums instead of mapping, fetching and reducing rows behind a workgroup barrier in their prologue (conv_stats.h)
+    if constexpr (!DUAL && MS == 0) {
+        if (group_sinks) {
+            __syncthreads();
+            if (wave == 0) {
+                // (selects over constant kernarg offsets: a lane-dependent index into the by-value block would move it into scratch)
+                const bool second = lane >= 32;
+                double* const skp = second ? a.gsink[1].p : a.gsink[0].p;
+                const int skoff = second ? a.gsink[1].coff : a.gsink[0].coff, skcg = second ? a.gsink[1].cg : a.gsink[0].cg;
+                const int j = lane & 31;
+                if (skp != nullptr && live) {
+                    const int m0 = mtw * 32;
+                    const int rows = a.Mout - m0 < 32 ? a.Mout - m0 : 32;            // rows of this tile that exist
+                    const int c0 = skoff + m0;                                        // domain channel of tile row 0
+                    const int g = c0 / skcg + j;                                      // the j-th group this tile touches
+                    int lo_r = g * skcg - c0, hi_r = lo_r + skcg;
+                    lo_r = lo_r < 0 ? 0 : lo_r;
+                    hi_r = hi_r > rows ? rows : hi_r;
+                    if (lo_r < hi_r) {
+                        double t1 = 0.0, t2 = 0.0;
+                        for (int rr = lo_r; rr < hi_r; ++rr) { const float2 v = stl.grow[rr]; t1 += (double)v.x; t2 += (double)v.y; }
+                        double* o = skp + 2 * ((size_t)b * 32 + g);
+                        atomicAdd(o, t1);
+                        atomicAdd(o + 1, t2);
+                    }
+                }
             }
         }
     }

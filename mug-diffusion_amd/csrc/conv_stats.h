@@ -35,6 +35,7 @@ struct WgStats {
         float2 lnst[TN];                                  // LayerNorm {mean, rstd} per tile column
         float2 lnred[NTHR];                               // LayerNorm exchange [part][column]
         float wsc[2 * WK];                                // M-split forms under H3: the scale each shared window was parked at (conv_body.h)
+        float2 grow[32];                                  // producer side of the group tables: the tile's 32 row sums (conv_body.h, ConvArgs::gsink)
     };
 
     bool pending = false;
@@ -87,7 +88,12 @@ struct WgStats {
     __device__ __forceinline__ void issue(const A& a, int b, int t0, int tid) {
         ln = a.seg[0].xf == 3;
         pending = ln || a.gn_groups != 0;
-        if (a.gn_groups) {
+        if (a.gn_groups && a.gn_table) {
+            // group tables (round 6; ConvArgs::gn_table): the producers' tiles added this domain's sums PER GROUP -- lane g of every wave fetches
+            // group g's pair; nothing to map, nothing to reduce
+            const int g = tid & 63;
+            gv[0] = *reinterpret_cast<const double2*>(a.gn_table + 2 * ((size_t)b * 32 + (g < a.gn_groups ? g : 0)));
+        } else if (a.gn_groups) {
             const int g = tid / LPG, j = tid % LPG, cg = a.gn_cg;
             const RowMap rm = row_map(a, b);
 #pragma unroll
@@ -119,7 +125,31 @@ struct WgStats {
         // is meant to overlap with (round 6: seen in the ISA as v_add_f64 v, v, 0 behind an s_waitcnt vmcnt right after issue()).  The "memory"
         // clobber keeps the operand loads issued before this point in front of it.  (Pinned only on the path that loaded them: a zero-initialised
         // alternative makes the register allocator COPY the loaded values at the join -- another early wait.)
-        if (a.gn_groups) {
+        if (a.gn_groups && a.gn_table) {
+            // EVERY wave turns the 32 pairs into {mean, rstd} and writes the same 32 table entries (identical bits from identical loads: the
+            // waves' stores do not race for a value); a wave reads the table only behind its own stores, so the GroupNorm-only prologue needs
+            // no workgroup barrier at all
+#ifndef MUGD_EMULATED
+            asm volatile("" : "+v"(gv[0].x), "+v"(gv[0].y) :: "memory");
+#endif
+            TL_STAMP(13);
+            const int g = tid & 63;
+            if (g < a.gn_groups) {
+                const double cnt = (double)a.gn_count;
+#ifdef MUGD_EMULATED
+                const double inv = 1.0 / cnt;
+#else
+                double inv = __builtin_amdgcn_rcp(cnt);
+                inv = inv * (2.0 - cnt * inv);
+                inv = inv * (2.0 - cnt * inv);
+#endif
+                const double mean = gv[0].x * inv;
+                double var = gv[0].y * inv - mean * mean;
+                var = var > 0.0 ? var : 0.0;
+                l.gnst[g] = make_float2((float)mean, 1.0f / sqrtf((float)var + a.gn_eps));
+            }
+            if (!ln) return;
+        } else if (a.gn_groups) {
             const int g = tid / LPG, j = tid % LPG, cg = a.gn_cg;
             const bool active = g < a.gn_groups;
 #ifndef MUGD_EMULATED

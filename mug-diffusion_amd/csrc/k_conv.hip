@@ -117,6 +117,7 @@ void prepare_wide(ConvLaunch& L, int nw, bool dual, int ks, int gx, int gy, int 
     conv_set_grid(L.a, gx, gyg, gz);
     L.grid = (unsigned)gx * gyg * gz; L.block = nw * 64; L.tn = 32;
     L.kern = conv_kernel_wide(nw, dual, ks);
+    L.ms = ks;
     MUGD_CHECK(L.kern != nullptr, -2, "conv_gemm: no such M-split form");
 }
 

@@ -96,6 +96,14 @@ struct ConvArgs {
     // GroupNorm domain of the xf == 4 segments (they are the first gn_nseg segments, in concat order)
     int gn_nseg, gn_groups, gn_cg;
     float gn_count, gn_eps;  // elements per group (cg * T), eps
+    // GROUP sums (round 6).  Consumer side: gn_table != null -> the {sum, sum of squares} of every group of this launch's GroupNorm domain are
+    // already complete in (B, 32, 2) fp64 words (the producers of its segments added them: gsink below): one 16-byte load per lane, no row map, no
+    // lane reduction, no workgroup barrier in the prologue (conv_stats.h); the segments' xf_a row sums are then not read.
+    const double* gn_table;
+    // Producer side: up to two consumers' group tables this launch's output rows belong to (a tensor read directly by the next block's GroupNorm
+    // and again through a skip concat sits in two domains): output row m is channel coff + m of a domain with cg channels per group.  Every
+    // tile combines its 32 row sums in LDS and adds ONE fp64 pair per group it touches.  p == null: unused.
+    struct GnSink { double* p; int coff, cg; } gsink[2];
     int wk;                  // K-split (waves per workgroup): 1|2|4|8, 0 = pick from the shape
     int tn;                  // output tile width: 32 | 16 (conv_body.h: ConvGeo; one kernel template, k_conv.hip); decides the weight packing
     int xcd_cols;            // workgroup order inside an XCD's slab: 0 = row tile major (a weight tile lives in one L2, every XCD reads
@@ -166,6 +174,7 @@ struct ConvLaunch {
     const void* kern;        // void (*)(const ConvArgs): the chosen conv_gemm_kernel instantiation
     unsigned grid; int block;
     int tn;                  // tile width of the chosen form (development build: the phase records' geometry)
+    int ms;                  // 0: K-split form; > 0: an M-split form (conv_body.h: MS) -- those do not feed group tables (ConvArgs::gsink)
 };
 typedef void (*ConvKernel)(const ConvArgs);
 // kernel addresses of the conv_gemm instantiations that live outside k_conv.hip (conv_kernel.h: three translation units)

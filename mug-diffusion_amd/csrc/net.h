@@ -4,6 +4,7 @@
 // launches over arena buffers; the DDIM sampler wraps the U-Net program and replays it from a
 // captured hipGraph, one replay per denoising step.
 #pragma once
+#include <deque>
 #include <functional>
 #include <map>
 #include <memory>
@@ -22,6 +23,9 @@ struct Tensor {
     // fp64 {sum, sum of squares} per (batch, channel) row, accumulated by the producing conv (ConvArgs::rowstat) or computed
     // once per call for network inputs (audio maps): lets a consuming GroupNorm skip its statistics launch
     double* rowstat = nullptr;
+    // index into Net::prods of the conv launch whose epilogue accumulates `rowstat` (-1: none -- network inputs, separate row-sum passes): a
+    // consuming GroupNorm can ask that launch for GROUP sums instead (ConvArgs::gsink, round 6)
+    int prod = -1;
 };
 
 struct Param {
@@ -70,7 +74,7 @@ private:
 // operand transform of one conv input (ConvSeg::xf): the GroupNorm / LayerNorm in front of the conv
 struct Xf { int kind = 0; int act = 0; const float* a = nullptr; const float* b = nullptr; int stride = 0; int np = 0; float eps = 0.f; int coff = 0;
             float sx0 = 0.f; };      // ConvSeg::sx0: the static H3 scale of the normalised operand (Net::norm_scale)
-struct GnDomain { int nseg = 0, groups = 0, cg = 0; float count = 0.f, eps = 0.f; };     // ConvArgs::gn_*
+struct GnDomain { int nseg = 0, groups = 0, cg = 0; float count = 0.f, eps = 0.f; const double* table = nullptr; };     // ConvArgs::gn_*
 struct ConvIn { Tensor x; int taps = 1, dil = 1, stride = 1, pad = 0, ups = 0; Xf xf; };
 struct WBlock { std::string name; int seg; int row_off; int ci_off; };
 struct ConvSpec {
@@ -179,6 +183,13 @@ protected:
     double* rs_base = nullptr; size_t rs_top = 0, rs_cap = 0;
     int rs_zero_op = -1; size_t rs_zero_n = 0;                // index of the program's "zero the accumulators" op (-1: none) and the doubles it clears
     void begin_rowstat();                                     // call at the start of build(): emits the per-step memset
+    // conv launches of the program being built that accumulate row sums, in emission order (Tensor::prod); `L` points into `launches` (null in the
+    // dry pass), nsink counts the group tables already attached to it (ConvArgs::gsink holds two)
+    struct Prod { ConvLaunch* L; int nsink; int row_users; };      // row_users: consumers that read the launch's ROW sums (finish_stats)
+    void use_rowstat(const Tensor& t) { if (t.prod >= 0 && t.prod < (int)prods.size()) prods[t.prod].row_users++; }
+    void finish_stats();                                      // after build(false): launches whose row sums nobody reads stop accumulating them
+    std::vector<Prod> prods;
+    std::deque<ConvLaunch> launches;                          // the argument blocks of the program's conv ops (stable addresses: ops point here)
     Tensor group_norm(const std::string& prefix, const std::vector<Tensor>& segs, int groups, bool silu);   // stand-alone kernel
     Tensor layer_norm(const std::string& prefix, const Tensor& x);
     // LayerNorm over channels: statistics kernel + the {gamma, beta} table -> transform for a 1x1 conv input

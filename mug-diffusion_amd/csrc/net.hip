@@ -313,6 +313,46 @@ void Net::gn_inputs(ConvSpec& spec, const std::string& prefix, const std::vector
     }
     spec.gn.nseg = (int)segs.size(); spec.gn.groups = groups; spec.gn.cg = Ctot / groups;
     spec.gn.count = (float)(Ctot / groups) * (float)segs[0].T; spec.gn.eps = 1e-6f;
+    // GROUP tables (round 6; ConvArgs::gn_table / gsink): when every segment was produced by a conv launch of THIS program that still has a free
+    // sink, those launches add their tiles' sums per group of this domain and the consumer's prologue shrinks to one load per lane.  Eligibility
+    // depends on shapes and emission order only, so the dry pass and the real pass allocate alike; the real pass then falls back to the row sums
+    // if a producer turned out to run an M-split form (whose epilogue has no group combine).
+    // Measured on one box, six alternating runs each (profiles/r6_gn_group_ab.txt): -1.5 % per DDIM step at batch 4, -0.5 % at batch 8, +0.3 % at
+    // batch 16 (four rounds of workgroups per CU: every producer tile pays the combine barrier, the consumers' prologues overlap anyway) -- so
+    // programs compiled for more than 8 batch rows keep the row sums.  MUGD_GN_GROUP=1 forces the tables at any batch, =0 switches them off.
+    static const int group_env = getenv("MUGD_GN_GROUP") ? atoi(getenv("MUGD_GN_GROUP")) : -1;
+    bool eligible = group_env < 0 ? Bn <= 8 : group_env != 0;
+    for (auto& t : segs) eligible = eligible && t.prod >= 0 && t.prod < (int)prods.size() && t.bmod == 0 && prods[t.prod].nsink < 2;
+    for (size_t i = 0; i < segs.size() && eligible; ++i)          // (one launch feeding two segments of the same domain would need both its sinks)
+        for (size_t j = 0; j < i; ++j) eligible = eligible && segs[i].prod != segs[j].prod;
+    if (eligible) {
+        double* table = alloc_rowstat((size_t)Bn * 64);
+        bool ok = true;
+        for (auto& t : segs) { prods[t.prod].nsink++; ok = ok && (dry || (prods[t.prod].L && prods[t.prod].L->ms == 0)); }
+        if (!ok && getenv("MUGD_GN_GROUP_LOG")) fprintf(stderr, "[mugd] row sums (a producer runs an M-split form): %s\n", prefix.c_str());
+        if (ok && !dry) {
+            off = 0;
+            for (auto& t : segs) {
+                ConvArgs& pa = prods[t.prod].L->a;
+                const int k = pa.gsink[0].p ? 1 : 0;
+                pa.gsink[k].p = table; pa.gsink[k].coff = off; pa.gsink[k].cg = Ctot / groups;
+                off += t.C;
+            }
+            spec.gn.table = table;
+            if (getenv("MUGD_GN_GROUP_LOG")) fprintf(stderr, "[mugd] group table: %s (%d segment(s), %d channels per group)\n", prefix.c_str(), (int)segs.size(), Ctot / groups);
+        }
+    }
+    if (!spec.gn.table) for (auto& t : segs) use_rowstat(t);      // this consumer maps, fetches and reduces its producers' ROW sums
+}
+
+// Launches that feed group tables and whose row sums no consumer reads (the next block's GroupNorm and the skip concat both took the group
+// form) stop accumulating rows: 32 fp64 atomic pairs per tile less.  MUGD_GN_KEEP_ROWS=1 keeps them (A/B arm).
+void Net::finish_stats() {
+    static const bool keep = getenv("MUGD_GN_KEEP_ROWS") && atoi(getenv("MUGD_GN_KEEP_ROWS")) != 0;
+    int n = 0;
+    for (auto& pr : prods)
+        if (pr.L && pr.L->a.gsink[0].p && pr.row_users == 0 && !keep) { pr.L->a.rowstat = nullptr; ++n; }
+    if (getenv("MUGD_GN_GROUP_LOG")) fprintf(stderr, "[mugd] %d of %d statistic-producing launches accumulate group sums only\n", n, (int)prods.size());
 }
 
 ConvIn Net::ln_input(const std::string& prefix, const Tensor& x) {
@@ -406,6 +446,8 @@ double* Net::alloc_rowstat(size_t nd) {
 }
 
 void Net::begin_rowstat() {
+    prods.clear();
+    launches.clear();                            // (the ops that pointed into it were cleared by build())
     if (!dry) {                                  // sized by the dry pass that just ran
         if (rs_top > rs_cap) {
             rs_cap = rs_top;
@@ -539,6 +581,7 @@ const PackedW& Net::get_packed_ext(const ConvSpec& s, int tn) {
 Tensor Net::conv(const ConvSpec& s) {
     MUGD_CHECK(!s.in.empty() && (int)s.in.size() <= CONV_MAXSEG, -2, "conv: bad segment count at " + s.key);
     Tensor y = s.out.p ? s.out : talloc(s.Mout, s.Tout);
+    y.prod = -1;
     ConvArgs a{};
     a.nseg = (int)s.in.size();
     for (int i = 0; i < a.nseg; ++i) {
@@ -546,7 +589,7 @@ Tensor Net::conv(const ConvSpec& s) {
         a.seg[i] = ConvSeg{in.x.p, in.x.C, in.x.T, in.taps, in.dil, in.stride, in.pad, in.ups, 0, 0, in.x.bmod,
                            in.xf.kind, in.xf.act, in.xf.a, in.xf.b, in.xf.stride, in.xf.np, in.xf.eps, in.xf.coff, in.xf.sx0};
     }
-    a.gn_nseg = s.gn.nseg; a.gn_groups = s.gn.groups; a.gn_cg = s.gn.cg; a.gn_count = s.gn.count; a.gn_eps = s.gn.eps;
+    a.gn_nseg = s.gn.nseg; a.gn_groups = s.gn.groups; a.gn_cg = s.gn.cg; a.gn_count = s.gn.count; a.gn_eps = s.gn.eps; a.gn_table = s.gn.table;
     a.B = Bn; a.Mrows = s.Mrows; a.Mout = s.Mout; a.Tout = s.Tout; a.epi = s.epi;
     a.wk = ctx->force_wk;
     a.tn = ctx->force_tn == 16 ? (conv16_supported(a) ? 16 : 32) : ctx->force_tn == 32 ? 32 : conv_pick_tn(a);
@@ -587,11 +630,15 @@ Tensor Net::conv(const ConvSpec& s) {
                               " nseg=" + std::to_string(a.nseg) + " tn=" + std::to_string(a.tn);
     const int okind = (s.epi == EPI_GLU || s.epi == EPI_GEGLU) ? OP_CONV_GATED : OP_CONV;
     const double oflops = 2.0 * s.Mrows * kdim * s.Tout * Bn;
+    ConvLaunch* Lp = nullptr;
     if (!dry) {
-        // validated, its kernel form chosen and its K-slices / grid decode filled in NOW; a step only launches (kernels.h: ConvLaunch)
-        const ConvLaunch L = conv_prepare(a);
-        emit([L](hipStream_t st) { conv_launch(st, L); }, okind, oflops, label);
+        // validated, its kernel form chosen and its K-slices / grid decode filled in NOW; a step only launches (kernels.h: ConvLaunch).  The block
+        // lives in `launches`: a consumer compiled later may still attach a group table to it (gn_inputs)
+        launches.push_back(conv_prepare(a));
+        Lp = &launches.back();
+        emit([Lp](hipStream_t st) { conv_launch(st, *Lp); }, okind, oflops, label);
     }
+    if (a.rowstat && s.epi == EPI_NONE) { y.prod = (int)prods.size(); prods.push_back(Prod{Lp, 0, 0}); }
     if (rowstat_pass) {
         const float* yp = y.p; double* rp = y.rowstat; const int rows = Bn * s.Mout, T = s.Tout;
         emit([=](hipStream_t st) { launch_row_sums_add(st, yp, rp, rows, T); }, OP_SMALL, 0, s.key + " row sums");
@@ -841,6 +888,7 @@ Tensor Net::s4_layer(const std::string& prefix, const Tensor& x) {
     S4ConvArgs ca{u.p, k, PF(prefix + ".s4_model.D"), y.p, Bn, H, L, aff,
                   in_kernel_gn ? PF(prefix + ".norm.weight") : nullptr, in_kernel_gn ? PF(prefix + ".norm.bias") : nullptr, 32, 1e-6f,
                   (in_kernel_gn && ctx->fuse_stats && x.bmod == 0) ? x.rowstat : nullptr};
+    if (ca.rowstat) use_rowstat(x);
     emit([ca](hipStream_t st) { launch_s4_conv(st, ca); }, OP_S4_CONV, 0, prefix + " H=" + std::to_string(H) + " L=" + std::to_string(L));
     ConvSpec gl;
     gl.key = prefix + ".s4_model.output_linear.0";
@@ -1087,6 +1135,7 @@ void UNet::ensure(int B, int z, int ntok, int bmod) {
     build(true);
     arena.reserve(arena.peak());
     build(false);
+    finish_stats();
     built = true;
 }
 
@@ -1264,6 +1313,7 @@ void VaeDecoder::decode(const float* z_lat, float* logits, int B, int z) {
         build(true);
         arena.reserve(arena.peak());
         build(false);
+        finish_stats();
         built = true;
     }
     hipStream_t st = ctx->stream;
@@ -1312,6 +1362,7 @@ void VaeEncoder::encode(const float* x, float* moments, int B, int T) {
         build(true);
         arena.reserve(arena.peak());
         build(false);
+        finish_stats();
         built = true;
     }
     hipStream_t st = ctx->stream;
@@ -1357,6 +1408,7 @@ void WaveEncoder::encode(const float* mel, float* const* outs, int B, int Ta) {
         build(true);
         arena.reserve(arena.peak());
         build(false);
+        finish_stats();
         built = true;
     }
     hipStream_t st = ctx->stream;

@@ -25,6 +25,7 @@
 #   icache         tests/gpu_convbench.py --icache: per hot shape, launches with warm vs evicted instruction caches (round 6)
 #   forms          tests/gpu_convbench.py --forms: M-split geometries vs the host's choice on the tall-M launches (round 6)
 #   hostq          host microseconds to enqueue one U-Net evaluation (mugd_net_host_enqueue), in-tree library
+#   envab:K=a,b[@B1,B2]  DDIM step (tests/gpu_probe.py --quick) with K=a and K=b alternating, six times per batch size (default 4,8,16)
 #   env:K=V        export K=V for the tasks that follow
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out
@@ -41,6 +42,30 @@ for task in "$@"; do
   echo "=== $task"
   case $name in
     env) export "$arg" ;;
+    envab)
+      spec=${arg%%@*}; bs=4,8,16; [ "$spec" != "$arg" ] && bs=${arg#*@}
+      var=${spec%%=*}; vals=${spec#*=}
+      F=${O}_envab_$var.txt; : > $F
+      for B in $(echo $bs | tr ',' ' '); do for rep in 1 2 3 4 5 6; do for v in $(echo $vals | tr ',' ' '); do
+        echo "== B=$B $var=$v" >> $F
+        env $var=$v timeout 300 python tests/gpu_probe.py --B $B --quick 2>&1 | grep -E "ms/step" >> $F
+      done; done; done
+      python - "$F" <<'PY'
+import re, sys, collections
+d, k = collections.OrderedDict(), None
+for line in open(sys.argv[1]):
+    m = re.match(r'== (B=\d+) (\S+)', line)
+    if m:
+        k = (m.group(1), m.group(2)); continue
+    m = re.search(r'([\d.]+) ms/step', line)
+    if m and k:
+        d.setdefault(k, []).append(float(m.group(1)))
+with open(sys.argv[1], 'a') as f:
+    for k, v in d.items():
+        line = "%s %s: mean %.4f ms/step over %d runs %s" % (k[0], k[1], sum(v) / len(v), len(v), v)
+        print(line); f.write("# " + line + "\n")
+PY
+      ;;
     overlap)
       ( hipcc --offload-arch=gfx950 -O3 -o /tmp/overlap_probe tests/gpu_overlap_probe.hip && timeout 300 /tmp/overlap_probe 400 ) > ${O}_overlap.txt 2>&1; cat ${O}_overlap.txt ;;
     icache)

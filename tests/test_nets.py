@@ -447,3 +447,58 @@ def test_host_enqueue_hook_replays_the_compiled_program(lib):
     b = n.forward(x, t, c, w).detach().cpu()
     assert (a - b).abs().max().item() <= 2e-6 * max(1.0, a.abs().max().item())
     n.close()
+
+
+_GN_FORMS_SCRIPT = r"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "mug-diffusion_amd")); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+from oracle import cases, weights
+import conftest
+lib = conftest.real_lib() if %(gpu)r else conftest.emu_lib()
+case, z, B = (cases.FULL, 96, 2) if %(gpu)r else (cases.TINY, 32, 2)
+man = weights.load_manifest(os.path.join(cases.GOLDEN, case["manifest"]))
+sd = weights.set_s4_lengths(weights.make_state_dict(man, 0), case["unet"], z)
+unet = lib.unet(case["unet"]); unet.set_params(sd, "model.unet_model.")
+x, t = cases.x_T(3, B, z), torch.full((B,), 417, dtype=torch.long)
+c, w = cases.context(case, 3, B), cases.audio_maps(case, 3, B, z)
+outs = [unet.forward(x, t, c, w).detach().cpu().numpy() for _ in range(2)]          # twice: the accumulators are cleared per evaluation
+np.save(sys.argv[1], np.stack(outs))
+"""
+
+
+def _gn_forms(tmp_path, gpu):
+    """U-Net forward in two fresh processes (the switch is read once per process): group tables forced on / off; returns both outputs and the logs."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("1", "0"):
+        out = str(tmp_path / ("eps_%s.npy" % mode))
+        env = dict(os.environ, MUGD_GN_GROUP=mode, MUGD_GN_GROUP_LOG="1")
+        p = subprocess.run([sys.executable, "-c", _GN_FORMS_SCRIPT % {"root": root, "gpu": gpu}, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[mode] = (np.load(out), p.stderr)
+    return res
+
+
+def _check_gn_forms(res):
+    (g, glog), (r, rlog) = res["1"], res["0"]
+    assert "group table:" in glog and "accumulate group sums only" in glog       # the tables are in use, some producers dropped their row sums
+    assert "group table:" not in rlog
+    scale = max(1.0, float(np.abs(r).max()))
+    assert float(np.abs(g[0] - g[1]).max()) <= 2e-6 * scale                      # second evaluation = first: the tables are cleared with the row sums
+    assert float(np.abs(g - r).max()) <= 2e-6 * scale                            # fp64 sums in another order: last fp32 bits of a statistic at most
+
+
+def test_unet_group_tables_agree_with_row_sums(lib, tmp_path):
+    """ConvArgs::gn_table / gsink (round 6): the producers' tiles add GROUP sums and the consuming GroupNorm loads them, instead of mapping,
+    fetching and reducing the producers' row sums -- same statistics, same network output."""
+    if lib.device.type == "cuda":
+        pytest.skip("the GPU variant of this test runs the full-size network")
+    _check_gn_forms(_gn_forms(tmp_path, False))
+
+
+@pytest.mark.gpu
+def test_unet_group_tables_agree_with_row_sums_gpu(gpu_lib, tmp_path):
+    _check_gn_forms(_gn_forms(tmp_path, True))
