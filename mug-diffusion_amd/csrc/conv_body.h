@@ -1418,8 +1418,19 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
         }
     }
     // ---- optional: {sum, sum of squares} of this tile's final values per column, for the LayerNorm of the consumer
-    if (!DUAL && a.colstat) {
+    if (!DUAL && (a.colstat || a.colsum)) {
         float (*cst)[WK][TN] = reinterpret_cast<float (*)[WK][TN]>(lds + L::EPI_OFF);      // [2][WK][TN]
+        // a row tile's finished column sums: stored as this tile's part (colstat), or ADDED to the column's accumulator pair (colsum)
+        auto put_col = [&](int mtile, int t, float c1, float c2) MUGD_LI {
+            if (a.colsum) {
+                double* o = a.colsum + 2 * ((size_t)b * a.Tout + t);
+                atomicAdd(o, (double)c1);
+                atomicAdd(o + 1, (double)c2);
+            } else {
+                float* o = a.colstat + 2 * (((size_t)b * gy + mtile) * a.Tout + t);
+                o[0] = c1; o[1] = c2;
+            }
+        };
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
@@ -1431,10 +1442,7 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
 #pragma unroll
         for (int o = TN; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }      // the lanes that hold the same column
         if (MS && KS == 1) {                             // the wave holds its row tile's complete column sums
-            if (live && mtw < gy && lane < TN && t0 + cl < a.Tout) {
-                float* o = a.colstat + 2 * (((size_t)b * gy + mtw) * a.Tout + t0 + cl);
-                o[0] = s1; o[1] = s2;
-            }
+            if (live && mtw < gy && lane < TN && t0 + cl < a.Tout) put_col(mtw, t0 + cl, s1, s2);
             TL_STAMP(6);
             return;
         }
@@ -1445,8 +1453,7 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
                 float t1 = 0.f, t2 = 0.f;
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk) { t1 += cst[0][wr + NR * kk][cl]; t2 += cst[1][wr + NR * kk][cl]; }
-                float* o = a.colstat + 2 * (((size_t)b * gy + mtw) * a.Tout + t0 + cl);
-                o[0] = t1; o[1] = t2;
+                put_col(mtw, t0 + cl, t1, t2);
             }
             TL_STAMP(6);
             return;
@@ -1457,8 +1464,7 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
             float t1 = 0.f, t2 = 0.f;
 #pragma unroll
             for (int w = 0; w < WK; ++w) { t1 += cst[0][w][tid]; t2 += cst[1][w][tid]; }
-            float* o = a.colstat + 2 * (((size_t)b * gy + mt) * a.Tout + t0 + tid);
-            o[0] = t1; o[1] = t2;
+            put_col(mt, t0 + tid, t1, t2);
         }
     }
     TL_STAMP(6);

@@ -102,7 +102,14 @@ struct WgStats {
                 gv[u] = row_load(rm, (g < a.gn_groups && cc < cg) ? g * cg + cc : 0);
             }
         }
-        if (ln) {
+        if (ln && a.seg[0].xf_np == 0) {
+            // column sums (round 6; ConvArgs::colsum of the producer): the row tiles' parts were ADDED by the producer's tiles -- every wave
+            // fetches the finished pair of each of the tile's columns (lane % TN); nothing to exchange
+            const auto& s = a.seg[0];
+            int t = t0 + tid % TN;
+            t = t < s.Tin ? t : s.Tin - 1;
+            gv[0] = *reinterpret_cast<const double2*>(reinterpret_cast<const double*>(s.xf_a) + 2 * ((size_t)b * s.Tin + t));
+        } else if (ln) {
             const auto& s = a.seg[0];
             const int col = tid % TN, part = tid / TN;
             int t = t0 + col;
@@ -148,6 +155,7 @@ struct WgStats {
                 var = var > 0.0 ? var : 0.0;
                 l.gnst[g] = make_float2((float)mean, 1.0f / sqrtf((float)var + a.gn_eps));
             }
+            wave_sync();                                     // the wave's other lanes read these entries (wavefront-scope fence: no instruction on the GPU)
             if (!ln) return;
         } else if (a.gn_groups) {
             const int g = tid / LPG, j = tid % LPG, cg = a.gn_cg;
@@ -196,6 +204,31 @@ struct WgStats {
                 var = var > 0.0 ? var : 0.0;
                 l.gnst[g] = make_float2((float)mean, 1.0f / sqrtf((float)var + a.gn_eps));
             }
+        }
+        if (ln && a.seg[0].xf_np == 0) {
+            // every wave writes the same TN table entries from the same loads and reads them only behind its own stores: no workgroup barrier
+            const auto& s = a.seg[0];
+#ifndef MUGD_EMULATED
+            asm volatile("" : "+v"(gv[0].x), "+v"(gv[0].y) :: "memory");
+#endif
+            TL_STAMP(13);
+            if ((tid & 63) < TN) {
+                const double cnt = (double)s.C;
+#ifdef MUGD_EMULATED
+                const double inv = 1.0 / cnt;
+#else
+                double inv = __builtin_amdgcn_rcp(cnt);
+                inv = inv * (2.0 - cnt * inv);
+                inv = inv * (2.0 - cnt * inv);
+#endif
+                // E[x^2] - mean^2 in fp64 (cancellation), 1/sqrt in fp32 like torch's LayerNorm
+                const double m = gv[0].x * inv;
+                float var = (float)(gv[0].y * inv - m * m);
+                var = var > 0.f ? var : 0.f;
+                l.lnst[tid % TN] = make_float2((float)m, 1.0f / sqrtf(var + s.xf_eps));
+            }
+            wave_sync();                                     // (as above)
+            return;
         }
         if (ln) {
             const auto& s = a.seg[0];

@@ -230,7 +230,7 @@ static void prepare_conv32(ConvLaunch& L) {
         MUGD_CHECK(s.xf >= 0 && s.xf <= 4 && (s.xf == 0 || s.xf_a) && (s.xf < 2 || s.xf_b), -2, "conv_gemm: bad operand transform");
         MUGD_CHECK(s.xf != 4 || (i < a.gn_nseg && a.gn_groups > 0 && a.gn_groups <= 32 && a.gn_cg > 0 && s.stride == 1 && !s.ups && (s.Tin & 3) == 0), -2,
                    "conv_gemm: GroupNorm from producer sums needs fast-path segments inside the GroupNorm domain");
-        MUGD_CHECK(s.xf != 3 || (s.taps == 1 && s.stride == 1 && !s.ups && (s.Tin & 3) == 0 && s.xf_np > 0), -2,
+        MUGD_CHECK(s.xf != 3 || (s.taps == 1 && s.stride == 1 && !s.ups && (s.Tin & 3) == 0 && s.xf_np >= 0), -2,
                    "conv_gemm: LayerNorm from producer sums needs a 1x1 fast-path segment");
         if (all_vec) {
             const int hw = (s.taps - 1) * s.dil;
@@ -441,7 +441,7 @@ static void prepare_conv16(ConvLaunch& L) {
         MUGD_CHECK((long long)CONV_CK * s.Tin * 4 < (1ll << 31), -2, "conv_gemm (16-wide): sequence too long for 32-bit window offsets");
         MUGD_CHECK(s.xf >= 0 && s.xf <= 4 && (s.xf == 0 || s.xf_a) && (s.xf < 2 || s.xf_b), -2, "conv_gemm (16-wide): bad operand transform");
         MUGD_CHECK(s.xf != 4 || (i < a.gn_nseg && a.gn_groups > 0 && a.gn_groups <= 32 && a.gn_cg > 0), -2, "conv_gemm (16-wide): bad GroupNorm domain");
-        MUGD_CHECK(s.xf != 3 || (s.taps == 1 && s.xf_np > 0), -2, "conv_gemm (16-wide): LayerNorm from producer sums needs a 1x1 segment");
+        MUGD_CHECK(s.xf != 3 || (s.taps == 1 && s.xf_np >= 0), -2, "conv_gemm (16-wide): LayerNorm from producer sums needs a 1x1 segment");
     }
     const bool dual = a.epi == EPI_GLU || a.epi == EPI_GEGLU;
     if (a.epi == EPI_XSOFTMAX)

@@ -46,7 +46,7 @@ struct ConvSeg {
                           //         xf_b = {gamma,beta} of the WHOLE GroupNorm (Ctot, 2), indexed by xf_coff + channel
     const float* xf_b;    // xf=2: {gamma,beta} (C, 2)
     int xf_stride;        // floats per batch row of xf_a
-    int xf_np;            // xf=3: number of row tiles summed per column
+    int xf_np;            // xf=3: number of row tiles summed per column; 0: xf_a holds FINISHED fp64 pairs (B, Tin, 2) (ConvArgs::colsum of the producer)
     float xf_eps;         // xf=3: LayerNorm eps
     int xf_coff;          // xf=4: first channel of this segment inside the normalised concat
     float sx0;            // H3 domain (conv_body.h): xf != 0 -- the STATIC power-of-two scale of this segment's transformed samples, from the host's bound
@@ -90,6 +90,9 @@ struct ConvArgs {
     int B, Mrows, Mout, Tout, nchunk, epi;
     float* colstat;          // null, or (B, ceil(Mout/32), Tout, 2): per output tile and column {sum, sum of squares} of the final values over
                              // the tile's rows -- the LayerNorm statistics of the consumer without a statistics launch (non-gated epilogues)
+    double* colsum;          // null, or (B, Tout, 2) fp64 accumulators, zeroed once per step: every tile ADDS its columns' {sum, sum of squares} over its
+                             // rows (round 6) instead of storing them per row tile (colstat) -- the consumer's LayerNorm loads ONE finished pair per
+                             // column (ConvSeg::xf_np == 0 marks that form; conv_stats.h) instead of summing the row tiles' parts through LDS
     double* rowstat;         // null, or (B, Mout, 2) fp64 accumulators, zeroed once per step: every tile ADDS the {sum, sum of squares} of its
                              // final values per row (fp64 atomics: the summation order only moves bit 53) -- the GroupNorm statistics of the
                              // consumers without a statistics launch (non-gated epilogues)

@@ -185,7 +185,9 @@ protected:
     void begin_rowstat();                                     // call at the start of build(): emits the per-step memset
     // conv launches of the program being built that accumulate row sums, in emission order (Tensor::prod); `L` points into `launches` (null in the
     // dry pass), nsink counts the group tables already attached to it (ConvArgs::gsink holds two)
-    struct Prod { ConvLaunch* L; int nsink; int row_users; };      // row_users: consumers that read the launch's ROW sums (finish_stats)
+    struct Prod { ConvLaunch* L; int nsink; int row_users; bool rows; double* colsum; };
+    // row_users: consumers that read the launch's ROW sums (finish_stats); rows: it accumulates row sums at all; colsum: the column accumulators a
+    // LayerNorm consumer switched it to (ConvArgs::colsum), null while it stores its column sums per row tile
     void use_rowstat(const Tensor& t) { if (t.prod >= 0 && t.prod < (int)prods.size()) prods[t.prod].row_users++; }
     void finish_stats();                                      // after build(false): launches whose row sums nobody reads stop accumulating them
     std::vector<Prod> prods;

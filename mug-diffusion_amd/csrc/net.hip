@@ -322,7 +322,7 @@ void Net::gn_inputs(ConvSpec& spec, const std::string& prefix, const std::vector
     // programs compiled for more than 8 batch rows keep the row sums.  MUGD_GN_GROUP=1 forces the tables at any batch, =0 switches them off.
     static const int group_env = getenv("MUGD_GN_GROUP") ? atoi(getenv("MUGD_GN_GROUP")) : -1;
     bool eligible = group_env < 0 ? Bn <= 8 : group_env != 0;
-    for (auto& t : segs) eligible = eligible && t.prod >= 0 && t.prod < (int)prods.size() && t.bmod == 0 && prods[t.prod].nsink < 2;
+    for (auto& t : segs) eligible = eligible && t.prod >= 0 && t.prod < (int)prods.size() && t.bmod == 0 && prods[t.prod].rows && prods[t.prod].nsink < 2;
     for (size_t i = 0; i < segs.size() && eligible; ++i)          // (one launch feeding two segments of the same domain would need both its sinks)
         for (size_t j = 0; j < i; ++j) eligible = eligible && segs[i].prod != segs[j].prod;
     if (eligible) {
@@ -352,7 +352,7 @@ void Net::finish_stats() {
     int n = 0;
     for (auto& pr : prods)
         if (pr.L && pr.L->a.gsink[0].p && pr.row_users == 0 && !keep) { pr.L->a.rowstat = nullptr; ++n; }
-    if (getenv("MUGD_GN_GROUP_LOG")) fprintf(stderr, "[mugd] %d of %d statistic-producing launches accumulate group sums only\n", n, (int)prods.size());
+    if (getenv("MUGD_GN_GROUP_LOG")) fprintf(stderr, "[mugd] %d of %d statistic-producing launches accumulate group sums only; accumulator block: %zu of %zu doubles, %zu cleared per evaluation\n", n, (int)prods.size(), rs_top, rs_cap, rs_zero_n);
 }
 
 ConvIn Net::ln_input(const std::string& prefix, const Tensor& x) {
@@ -469,6 +469,20 @@ Xf Net::layer_norm_xf(const std::string& prefix, const Tensor& x) {
         Xf xf;
         xf.kind = 3; xf.a = x.colstat; xf.b = gb; xf.stride = 2 * x.colstat_np * x.T; xf.np = x.colstat_np; xf.eps = 1e-5f;
         xf.sx0 = norm_scale(prefix, (double)x.C);
+        // Column SUMS (round 6; ConvArgs::colsum): the producer's tiles add their columns' sums to one fp64 pair per column (cleared with the
+        // row-sum block) instead of storing a part per row tile; the consumer loads the finished pair -- no parts to sum through LDS, no
+        // workgroup barrier in its prologue (conv_stats.h; xf.np == 0 marks the form).  Measured (profiles/r6_ln_sums_ab.txt, six alternating runs
+        // each on one box): +0.1 % per DDIM step at batch 4 (noise), -0.2 % at batch 8, -0.6 % at batch 16: on at every batch size;
+        // MUGD_LN_SUMS=0 keeps the per-row-tile parts (A/B arm).
+        static const bool sums_on = !(getenv("MUGD_LN_SUMS") && atoi(getenv("MUGD_LN_SUMS")) == 0);
+        const bool sums = sums_on && x.prod >= 0 && x.prod < (int)prods.size() && x.bmod == 0;
+        if (sums) {
+            Prod& pr = prods[x.prod];
+            if (!pr.colsum) pr.colsum = alloc_rowstat((size_t)Bn * x.T * 2);
+            if (!dry && pr.L) { pr.L->a.colsum = pr.colsum; pr.L->a.colstat = nullptr; }
+            xf.a = reinterpret_cast<const float*>(pr.colsum); xf.np = 0; xf.stride = 0;
+            if (!dry && getenv("MUGD_GN_GROUP_LOG")) fprintf(stderr, "[mugd] column sums: %s\n", prefix.c_str());
+        }
         return xf;
     }
     float* stat = arena.alloc((size_t)Bn * x.T * 2);
@@ -638,7 +652,7 @@ Tensor Net::conv(const ConvSpec& s) {
         Lp = &launches.back();
         emit([Lp](hipStream_t st) { conv_launch(st, *Lp); }, okind, oflops, label);
     }
-    if (a.rowstat && s.epi == EPI_NONE) { y.prod = (int)prods.size(); prods.push_back(Prod{Lp, 0, 0}); }
+    if ((a.rowstat || a.colstat) && s.epi == EPI_NONE) { y.prod = (int)prods.size(); prods.push_back(Prod{Lp, 0, 0, a.rowstat != nullptr, nullptr}); }
     if (rowstat_pass) {
         const float* yp = y.p; double* rp = y.rowstat; const int rows = Bn * s.Mout, T = s.Tout;
         emit([=](hipStream_t st) { launch_row_sums_add(st, yp, rp, rows, T); }, OP_SMALL, 0, s.key + " row sums");

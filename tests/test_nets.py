@@ -468,14 +468,14 @@ np.save(sys.argv[1], np.stack(outs))
 
 
 def _gn_forms(tmp_path, gpu):
-    """U-Net forward in two fresh processes (the switch is read once per process): group tables forced on / off; returns both outputs and the logs."""
+    """U-Net forward in two fresh processes (the switches are read once per process): group tables + column sums forced on / off; returns both outputs and the logs."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     for mode in ("1", "0"):
         out = str(tmp_path / ("eps_%s.npy" % mode))
-        env = dict(os.environ, MUGD_GN_GROUP=mode, MUGD_GN_GROUP_LOG="1")
+        env = dict(os.environ, MUGD_GN_GROUP=mode, MUGD_LN_SUMS=mode, MUGD_GN_GROUP_LOG="1")
         p = subprocess.run([sys.executable, "-c", _GN_FORMS_SCRIPT % {"root": root, "gpu": gpu}, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         res[mode] = (np.load(out), p.stderr)
@@ -485,15 +485,17 @@ def _gn_forms(tmp_path, gpu):
 def _check_gn_forms(res):
     (g, glog), (r, rlog) = res["1"], res["0"]
     assert "group table:" in glog and "accumulate group sums only" in glog       # the tables are in use, some producers dropped their row sums
-    assert "group table:" not in rlog
+    assert "column sums:" in glog                                                # ... and so are the LayerNorm column sums
+    assert "group table:" not in rlog and "column sums:" not in rlog
     scale = max(1.0, float(np.abs(r).max()))
     assert float(np.abs(g[0] - g[1]).max()) <= 2e-6 * scale                      # second evaluation = first: the tables are cleared with the row sums
     assert float(np.abs(g - r).max()) <= 2e-6 * scale                            # fp64 sums in another order: last fp32 bits of a statistic at most
 
 
 def test_unet_group_tables_agree_with_row_sums(lib, tmp_path):
-    """ConvArgs::gn_table / gsink (round 6): the producers' tiles add GROUP sums and the consuming GroupNorm loads them, instead of mapping,
-    fetching and reducing the producers' row sums -- same statistics, same network output."""
+    """ConvArgs::gn_table / gsink and ConvArgs::colsum (round 6): the producers' tiles add GROUP sums / finished column sums and the consuming
+    GroupNorm / LayerNorm loads them, instead of mapping, fetching and reducing the producers' row sums / per-row-tile column parts behind
+    workgroup barriers -- same statistics, same network output."""
     if lib.device.type == "cuda":
         pytest.skip("the GPU variant of this test runs the full-size network")
     _check_gn_forms(_gn_forms(tmp_path, False))
