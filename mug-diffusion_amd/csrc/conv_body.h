@@ -1386,9 +1386,12 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
             if (MS == 0 && group_sinks && cl == 0) stl.grow[G::row(r, lane)] = make_float2(s1, s2);      // (rows beyond Mout: zeros)
         }
     }
-    // ---- optional: this tile's sums per GROUP of the consumers' GroupNorm domains (ConvArgs::gsink, round 6): the 32 row sums meet in LDS, lane j of
-    // each half of wave 0 owns the j-th group the tile touches in sink 0 / sink 1 and adds ONE fp64 pair -- the consumers then load finished group
-    // sums instead of mapping, fetching and reducing rows behind a workgroup barrier in their prologue (conv_stats.h)
+    // ---- optional: this tile's sums per GROUP of the consumers' GroupNorm domains (ConvArgs::gsink, round 6): the 32 row sums meet in LDS; in wave 0
+    // lane j of each half (half 0: sink 0, half 1: sink 1) takes row j, an inclusive fp64 prefix sum runs over the half (four DPP row shifts +
+    // one cross-row step), and the lane that owns the j-th group the tile touches in its sink takes prefix[last row] - prefix[row before the first]
+    // and adds ONE fp64 pair -- the consumers then load finished group sums instead of mapping, fetching and reducing rows behind a workgroup
+    // barrier in their prologue (conv_stats.h).  (A loop over the group's rows -- up to 32 dependent LDS round trips for the 32 - 84 channel
+    // groups of the decoder's concats -- cost the producers more than the consumers saved.)
     if constexpr (!DUAL && MS == 0) {
         if (group_sinks) {
             __syncthreads();
@@ -1396,23 +1399,36 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
                 // (selects over constant kernarg offsets: a lane-dependent index into the by-value block would move it into scratch)
                 const bool second = lane >= 32;
                 double* const skp = second ? a.gsink[1].p : a.gsink[0].p;
-                const int skoff = second ? a.gsink[1].coff : a.gsink[0].coff, skcg = second ? a.gsink[1].cg : a.gsink[0].cg;
+                const int skoff = second ? a.gsink[1].coff : a.gsink[0].coff;
+                int skcg = second ? a.gsink[1].cg : a.gsink[0].cg;
+                skcg = skcg > 0 ? skcg : 1;
                 const int j = lane & 31;
-                if (skp != nullptr && live) {
-                    const int m0 = mtw * 32;
-                    const int rows = a.Mout - m0 < 32 ? a.Mout - m0 : 32;            // rows of this tile that exist
-                    const int c0 = skoff + m0;                                        // domain channel of tile row 0
-                    const int g = c0 / skcg + j;                                      // the j-th group this tile touches
-                    int lo_r = g * skcg - c0, hi_r = lo_r + skcg;
-                    lo_r = lo_r < 0 ? 0 : lo_r;
-                    hi_r = hi_r > rows ? rows : hi_r;
-                    if (lo_r < hi_r) {
-                        double t1 = 0.0, t2 = 0.0;
-                        for (int rr = lo_r; rr < hi_r; ++rr) { const float2 v = stl.grow[rr]; t1 += (double)v.x; t2 += (double)v.y; }
-                        double* o = skp + 2 * ((size_t)b * 32 + g);
-                        atomicAdd(o, t1);
-                        atomicAdd(o + 1, t2);
-                    }
+                const float2 rv = stl.grow[j];
+                double p1 = (double)rv.x, p2 = (double)rv.y;
+#define MUGD_SHR_D(v, n) __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + (n), 0xf, 0xf, true), \
+                                          __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + (n), 0xf, 0xf, true))
+#define MUGD_SHR_STEP(n) { const double q1 = MUGD_SHR_D(p1, n), q2 = MUGD_SHR_D(p2, n); p1 += q1; p2 += q2; }
+                MUGD_SHR_STEP(1) MUGD_SHR_STEP(2) MUGD_SHR_STEP(4) MUGD_SHR_STEP(8)      // inclusive prefix inside each 16-lane row (bound_ctrl: zeros shift in)
+#undef MUGD_SHR_STEP
+#undef MUGD_SHR_D
+                {   // rows 16..31 of a half: + the total of its rows 0..15 (lane 15 / 47)
+                    const double c1 = shfl_d(p1, (lane & 32) | 15), c2 = shfl_d(p2, (lane & 32) | 15);
+                    if (j >= 16) { p1 += c1; p2 += c2; }
+                }
+                const int m0 = mtw * 32;
+                const int rows = a.Mout - m0 < 32 ? a.Mout - m0 : 32;                // rows of this tile that exist (the others hold zeros)
+                const int c0 = skoff + m0;                                            // domain channel of tile row 0
+                const int g = c0 / skcg + j;                                          // the j-th group this tile touches
+                int lo_r = g * skcg - c0, hi_r = lo_r + skcg;
+                lo_r = lo_r < 0 ? 0 : lo_r;
+                hi_r = hi_r > rows ? rows : hi_r;
+                const bool mine = skp != nullptr && live && lo_r < hi_r;
+                const int ih = (lane & 32) | ((mine ? hi_r - 1 : 0) & 31), il = (lane & 32) | ((mine && lo_r > 0 ? lo_r - 1 : 0) & 31);
+                const double h1 = shfl_d(p1, ih), h2 = shfl_d(p2, ih), l1 = shfl_d(p1, il), l2 = shfl_d(p2, il);
+                if (mine) {
+                    double* o = skp + 2 * ((size_t)b * 32 + g);
+                    atomicAdd(o, lo_r > 0 ? h1 - l1 : h1);
+                    atomicAdd(o + 1, lo_r > 0 ? h2 - l2 : h2);
                 }
             }
         }

@@ -22,6 +22,10 @@ __device__ __forceinline__ double shfl_xor_d(double v, int o) {
     return __hiloint2double(__shfl_xor(__double2hiint(v), o), __shfl_xor(__double2loint(v), o));
 }
 
+__device__ __forceinline__ double shfl_d(double v, int src) {
+    return __hiloint2double(__shfl(__double2hiint(v), src), __shfl(__double2loint(v), src));
+}
+
 template <int WK, int TN>
 struct WgStats {
     static constexpr int NTHR = WK * 64;

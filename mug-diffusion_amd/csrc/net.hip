@@ -317,11 +317,11 @@ void Net::gn_inputs(ConvSpec& spec, const std::string& prefix, const std::vector
     // sink, those launches add their tiles' sums per group of this domain and the consumer's prologue shrinks to one load per lane.  Eligibility
     // depends on shapes and emission order only, so the dry pass and the real pass allocate alike; the real pass then falls back to the row sums
     // if a producer turned out to run an M-split form (whose epilogue has no group combine).
-    // Measured on one box, six alternating runs each (profiles/r6_gn_group_ab.txt): -1.5 % per DDIM step at batch 4, -0.5 % at batch 8, +0.3 % at
-    // batch 16 (four rounds of workgroups per CU: every producer tile pays the combine barrier, the consumers' prologues overlap anyway) -- so
-    // programs compiled for more than 8 batch rows keep the row sums.  MUGD_GN_GROUP=1 forces the tables at any batch, =0 switches them off.
-    static const int group_env = getenv("MUGD_GN_GROUP") ? atoi(getenv("MUGD_GN_GROUP")) : -1;
-    bool eligible = group_env < 0 ? Bn <= 8 : group_env != 0;
+    // Measured on one box, six alternating runs each (profiles/r6_gn_group_ab.txt): -2.9 % per DDIM step at batch 4, -1.8 % at batch 8, -1.2 % at
+    // batch 16 (with the first form of the producers' combine -- a loop over the group's rows -- it was -1.5 % / -0.5 % / +0.3 %).
+    // MUGD_GN_GROUP=0 switches the tables off (A/B arm).
+    static const bool group_on = !(getenv("MUGD_GN_GROUP") && atoi(getenv("MUGD_GN_GROUP")) == 0);
+    bool eligible = group_on;
     for (auto& t : segs) eligible = eligible && t.prod >= 0 && t.prod < (int)prods.size() && t.bmod == 0 && prods[t.prod].rows && prods[t.prod].nsink < 2;
     for (size_t i = 0; i < segs.size() && eligible; ++i)          // (one launch feeding two segments of the same domain would need both its sinks)
         for (size_t j = 0; j < i; ++j) eligible = eligible && segs[i].prod != segs[j].prod;

@@ -127,9 +127,17 @@ static inline void __builtin_amdgcn_wave_barrier_emu() { emu::wave_barrier(); }
 #define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_amdgcn_readfirstlane(x) (x)
 // DPP row rotate (ctrl 0x121..0x12f = row_ror:1..15): lane i of a 16-lane row reads lane (i - n) mod 16 of the same row
+// DPP row shift right (ctrl 0x111..0x11f = row_shr:1..15, used with bound_ctrl: the lanes without a source read 0)
 static inline int emu_update_dpp(int src, int ctrl) {
-    const int lane = emu::lane_id(), n = ctrl - 0x120;
+    const int lane = emu::lane_id();
     float f; std::memcpy(&f, &src, 4);
+    if (ctrl >= 0x111 && ctrl <= 0x11f) {
+        const int n = ctrl - 0x110;
+        const bool has = (lane & 15) >= n;
+        f = emu::wave_xchg(f, has ? lane - n : lane);
+        int r; std::memcpy(&r, &f, 4); return has ? r : 0;
+    }
+    const int n = ctrl - 0x120;
     f = emu::wave_xchg(f, (lane & ~15) | ((lane - n) & 15));
     int r; std::memcpy(&r, &f, 4); return r;
 }
