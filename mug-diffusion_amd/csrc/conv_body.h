@@ -1367,7 +1367,7 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
     }
     TL_STAMP(5);
     // ---- optional: add this tile's {sum, sum of squares} per row to the fp64 row accumulators (GroupNorm of the consumers)
-    const bool group_sinks = !DUAL && MS == 0 && a.gsink[0].p != nullptr;      // (wave-uniform: a kernel argument)
+    const bool group_sinks = !DUAL && a.gsink[0].p != nullptr;      // (wave-uniform: a kernel argument)
     if (!DUAL && (a.rowstat || group_sinks)) {
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
@@ -1383,7 +1383,7 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
                 atomicAdd(o, (double)s1);
                 atomicAdd(o + 1, (double)s2);
             }
-            if (MS == 0 && group_sinks && cl == 0) stl.grow[G::row(r, lane)] = make_float2(s1, s2);      // (rows beyond Mout: zeros)
+            if (group_sinks && cl == 0) stl.grow[MS ? wr : 0][G::row(r, lane)] = make_float2(s1, s2);      // (rows beyond Mout: zeros)
         }
     }
     // ---- optional: this tile's sums per GROUP of the consumers' GroupNorm domains (ConvArgs::gsink, round 6): the 32 row sums meet in LDS; in wave 0
@@ -1392,10 +1392,11 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
     // and adds ONE fp64 pair -- the consumers then load finished group sums instead of mapping, fetching and reducing rows behind a workgroup
     // barrier in their prologue (conv_stats.h).  (A loop over the group's rows -- up to 32 dependent LDS round trips for the 32 - 84 channel
     // groups of the decoder's concats -- cost the producers more than the consumers saved.)
-    if constexpr (!DUAL && MS == 0) {
+    // M-split forms: the workgroup holds NR row tiles (their rows spread over the KS waves of each); wave wr of the first K-slice takes tile wr.
+    if constexpr (!DUAL) {
         if (group_sinks) {
             __syncthreads();
-            if (wave == 0) {
+            if (MS ? wks == 0 : wave == 0) {
                 // (selects over constant kernarg offsets: a lane-dependent index into the by-value block would move it into scratch)
                 const bool second = lane >= 32;
                 double* const skp = second ? a.gsink[1].p : a.gsink[0].p;
@@ -1403,7 +1404,7 @@ __device__ __forceinline__ void conv_tile(const A& a, const int mt, const int b,
                 int skcg = second ? a.gsink[1].cg : a.gsink[0].cg;
                 skcg = skcg > 0 ? skcg : 1;
                 const int j = lane & 31;
-                const float2 rv = stl.grow[j];
+                const float2 rv = stl.grow[MS ? wr : 0][j];
                 double p1 = (double)rv.x, p2 = (double)rv.y;
 #define MUGD_SHR_D(v, n) __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + (n), 0xf, 0xf, true), \
                                           __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + (n), 0xf, 0xf, true))

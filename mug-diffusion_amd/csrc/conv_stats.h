@@ -39,7 +39,7 @@ struct WgStats {
         float2 lnst[TN];                                  // LayerNorm {mean, rstd} per tile column
         float2 lnred[NTHR];                               // LayerNorm exchange [part][column]
         float wsc[2 * WK];                                // M-split forms under H3: the scale each shared window was parked at (conv_body.h)
-        float2 grow[32];                                  // producer side of the group tables: the tile's 32 row sums (conv_body.h, ConvArgs::gsink)
+        float2 grow[WK][32];                              // producer side of the group tables: the 32 row sums of each of the workgroup's row tiles (conv_body.h, ConvArgs::gsink; K-split forms use [0])
     };
 
     bool pending = false;

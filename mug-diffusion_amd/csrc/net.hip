@@ -315,8 +315,8 @@ void Net::gn_inputs(ConvSpec& spec, const std::string& prefix, const std::vector
     spec.gn.count = (float)(Ctot / groups) * (float)segs[0].T; spec.gn.eps = 1e-6f;
     // GROUP tables (round 6; ConvArgs::gn_table / gsink): when every segment was produced by a conv launch of THIS program that still has a free
     // sink, those launches add their tiles' sums per group of this domain and the consumer's prologue shrinks to one load per lane.  Eligibility
-    // depends on shapes and emission order only, so the dry pass and the real pass allocate alike; the real pass then falls back to the row sums
-    // if a producer turned out to run an M-split form (whose epilogue has no group combine).
+    // depends on shapes and emission order only, so the dry pass and the real pass allocate alike (every kernel form -- K-split and M-split --
+    // has the group combine in its epilogue).
     // Measured on one box, six alternating runs each (profiles/r6_gn_group_ab.txt): -2.9 % per DDIM step at batch 4, -1.8 % at batch 8, -1.2 % at
     // batch 16 (with the first form of the producers' combine -- a loop over the group's rows -- it was -1.5 % / -0.5 % / +0.3 %).
     // MUGD_GN_GROUP=0 switches the tables off (A/B arm).
@@ -328,8 +328,7 @@ void Net::gn_inputs(ConvSpec& spec, const std::string& prefix, const std::vector
     if (eligible) {
         double* table = alloc_rowstat((size_t)Bn * 64);
         bool ok = true;
-        for (auto& t : segs) { prods[t.prod].nsink++; ok = ok && (dry || (prods[t.prod].L && prods[t.prod].L->ms == 0)); }
-        if (!ok && getenv("MUGD_GN_GROUP_LOG")) fprintf(stderr, "[mugd] row sums (a producer runs an M-split form): %s\n", prefix.c_str());
+        for (auto& t : segs) { prods[t.prod].nsink++; ok = ok && (dry || prods[t.prod].L != nullptr); }
         if (ok && !dry) {
             off = 0;
             for (auto& t : segs) {
