@@ -50,16 +50,10 @@ def _run(cmd):
 # ---------------------------------------------------------------------------------------------------------------------------
 SCRATCH_ALLOWED = [
     # conv_gemm_kernel<WK, DUAL, KIND, NIT, WT, TN, MS>
-    (r"conv_gemm_kernel<\d, (true|false), 0, 1, (float|unsigned short), 16, 0>.*", 0, None),
     (r"conv_gemm_kernel<1, (true|false), 0, 1, (float|unsigned short), 16, 0>", 192,
      "one-wave 16-wide tiles: only launches with a single K chunk AND <= 128 tiles pick them (never on the shipped networks' hot paths)"),
     (r"conv_gemm_kernel<\d, true, 2, 9, float, 32, 0>", 400,
      "gated epilogue over generic windows: a GLU / GEGLU projection at a length that is not a multiple of 4 (cold path, kept for completeness)"),
-    (r"conv_gemm_kernel<2, true, 0, 1, float, 32, 0>", 16,
-     "the GEGLU projections at batch 4: at most one 64-bit address parked outside the chunk loops"),
-    (r"conv_gemm_kernel<[48], true, 0, 1, float, 32, 0>", 128,
-     "the S4 GLU projections (8 / 4 waves per tile): 10 - 25 dwords spilled around the prologue / epilogue, none inside the chunk loop "
-     "(checked in the ISA: profiles/r6_gated_scratch.txt); two accumulator pairs + two weight streams sit at the 256-VGPR budget"),
     (r"conv_gemm_kernel<4, false, 1, 1, float, 32, 0>", 64,
      "dilated ResnetBlock convs of the wave encoder / VAE at 4 waves per tile: run-time transform + 4 halo loads per lane"),
     (r"wgrad_mfma_kernel", 256, "weight gradient of the fp32 (parity) training mode; the bf16 mode of record runs twgrad_bf16_kernel"),

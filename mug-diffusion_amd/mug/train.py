@@ -503,6 +503,7 @@ class TrainPlan:
         self.arena = FlatGrads(n_train, self.lib.device)
         self.packs = {}
         self.first = True
+        self._throttle = None         # event behind the previous step's backward sweep (step(): the host stays less than one step ahead)
         # the library's step bracket keys its packed-weight cache on tensor addresses: only when every parameter already lives on the
         # library's device as contiguous fp32 (no per-call staging copies whose addresses could be recycled inside a step)
         dev = torch.device(self.lib.device)
@@ -514,6 +515,14 @@ class TrainPlan:
         if lib._bracket_owner is not self:            # another plan (another model's tensors) used the bracket since: its cache entries go first
             lib.train_step_reset(owner=self)
         with lib.on_stream():                         # torch's fills / allocations and the library's kernels on ONE stream: no event per call
+            # Nothing inside a step waits for the device (mugd_train_release_states stopped draining the stream in round 6), so a loop of steps
+            # would let the host run as far ahead as the runtime's queue allows -- and a flooded queue makes the DEVICE slower (measured at batch
+            # 32: 74.5 ms per step against 63 with a host that waits once per step; profiles/r6_train_step_digest*.txt).  The wait that keeps the
+            # device fed: before enqueueing step N + 1, until the device has finished step N's BACKWARD sweep -- its reduction-table launch and
+            # AdamW are still queued then, so the stream never runs dry while the host catches up.
+            if self._throttle is not None:
+                self._throttle.synchronize()
+                self._throttle = None
             lib.train_release_states()                # intermediates of a sweep that was abandoned half-way
             if not self.first:
                 self.arena.buf.zero_()                # packs hold views of the arena: clear it, keep the layout
@@ -527,13 +536,20 @@ class TrainPlan:
                     reducer.before_launch = lib.train_step_flush
             try:
                 return _training_step(lib, self.sd, self.unet_cfg, self.wave_cfg, x0, noise, t, ids, mel, beta, add, reducer, self.recompute,
-                                      _Grads(reducer), self.packs)
+                                      _Grads(reducer), self.packs, mark=self._mark)
             finally:
                 if self.bracket:
                     lib.train_step_end()
                 if reducer is not None:
                     reducer.before_launch = None
                 lib.grad_arena = None
+
+
+    def _mark(self):
+        """Called by _training_step behind the backward sweep: the point the next step() waits for."""
+        if self.lib.device.type == "cuda":
+            self._throttle = torch.cuda.Event()
+            self._throttle.record(torch.cuda.current_stream(self.lib.device))
 
 
 def training_step(lib, sd, unet_cfg, wave_cfg, x0, noise, t, ids, mel, beta=0.02, add=0.01, reducer=None, recompute=False):
@@ -548,7 +564,7 @@ def training_step(lib, sd, unet_cfg, wave_cfg, x0, noise, t, ids, mel, beta=0.02
     return TrainPlan(lib, sd, unet_cfg, wave_cfg, recompute=recompute).step(x0, noise, t, ids, mel, beta=beta, add=add, reducer=reducer)
 
 
-def _training_step(lib, sd, unet_cfg, wave_cfg, x0, noise, t, ids, mel, beta, add, reducer, recompute, grads, packs=None):
+def _training_step(lib, sd, unet_cfg, wave_cfg, x0, noise, t, ids, mel, beta, add, reducer, recompute, grads, packs=None, mark=None):
     xt = lib.train_q_sample(x0, noise, t, sd["sqrt_alphas_cumprod"], sd["sqrt_one_minus_alphas_cumprod"])
     table = lib.f32(sd["model.cond_stage_model.embedding.weight"])
     context = lib.cond_embed(table, ids)
@@ -561,6 +577,8 @@ def _training_step(lib, sd, unet_cfg, wave_cfg, x0, noise, t, ids, mel, beta, ad
     grads.add("", {"model.cond_stage_model.embedding.weight": lib.train_embedding_bwd(ids, dctx, table.shape[0],
                                                                                      pack=None if packs is None else packs.setdefault("#embedding", {}))})
     wave.backward(daud, grads)
+    if mark is not None:
+        mark()
     if reducer is not None:
         reducer.finish()
     lib.train_release_states()                       # wave-encoder levels the U-Net does not read never run their backward

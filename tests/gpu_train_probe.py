@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--cprofile", action="store_true", help="cProfile of the host side of the last step")
     ap.add_argument("--adamw", action="store_true", help="include the optimiser step")
     ap.add_argument("--bf16", action="store_true", help="GEMMs on the bf16 matrix cores (mugd_train_set_precision)")
+    ap.add_argument("--nosync", action="store_true", help="no host synchronisation between the steps (what bench.py's training leg times): one line for all of them")
     a = ap.parse_args()
     case = cases.TINY if a.tiny else cases.FULL
     lib = get_lib()
@@ -44,6 +45,24 @@ def main():
     plan = train.TrainPlan(lib, sd, case["unet"], case["wave"])
     opt = None
     prof = None
+    if a.nosync:
+        for r in range(2):                       # warm-up: weights packed, pool filled
+            loss, grads = plan.step(x0, noise, t, ids, mel)
+            if a.adamw:
+                if opt is None:
+                    opt = train.AdamW(lib, {k: sd[k] for k in grads}, grads, lr=1e-6)
+                opt.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for r in range(a.reps):
+            loss, grads = plan.step(x0, noise, t, ids, mel)
+            if a.adamw:
+                opt.step()
+        t_host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print("%s %d steps without host synchronisation: %.2f ms per step (host enqueue %.2f ms per step), %.1f samples/s" % ("bf16" if a.bf16 else "fp32", a.reps, dt / a.reps * 1e3, t_host / a.reps * 1e3, B * a.reps / dt), flush=True)
+        return
     for r in range(a.reps):
         torch.cuda.synchronize()
         if a.cprofile and r == a.reps - 1:
