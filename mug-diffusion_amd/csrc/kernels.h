@@ -326,6 +326,9 @@ struct S4ConvArgs {      // y = gelu( causal_conv(k, u') + D*u' ),  u,y: (B,H,L)
     // (ConvArgs::rowstat): the workgroup sums its group's H / groups rows -- one short load next to the k / u loads instead
     // of a pass over the group's samples and a barrier
     const double* rowstat;
+    // or (round 6): the FINISHED {sum, sum of squares} of every group, (B, 32, 2) fp64 words the producer's tiles added (ConvArgs::gsink):
+    // one wave-uniform pair per workgroup, nothing to reduce
+    const double* gn_table;
 };
 bool s4_conv_fuses_group_norm(int L);
 void launch_s4_conv(hipStream_t st, const S4ConvArgs& a);

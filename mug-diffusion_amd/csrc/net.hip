@@ -900,8 +900,24 @@ Tensor Net::s4_layer(const std::string& prefix, const Tensor& x) {
     Tensor y = talloc(H, L);
     S4ConvArgs ca{u.p, k, PF(prefix + ".s4_model.D"), y.p, Bn, H, L, aff,
                   in_kernel_gn ? PF(prefix + ".norm.weight") : nullptr, in_kernel_gn ? PF(prefix + ".norm.bias") : nullptr, 32, 1e-6f,
-                  (in_kernel_gn && ctx->fuse_stats && x.bmod == 0) ? x.rowstat : nullptr};
-    if (ca.rowstat) use_rowstat(x);
+                  (in_kernel_gn && ctx->fuse_stats && x.bmod == 0) ? x.rowstat : nullptr, nullptr};
+    if (ca.rowstat) {
+        // the producer's GROUP sums instead (ConvArgs::gsink, like a conv consumer: gn_inputs) when it has a free sink: the kernel then loads
+        // one finished pair per workgroup instead of summing its group's rows over the wave
+        static const bool group_on = !(getenv("MUGD_GN_GROUP") && atoi(getenv("MUGD_GN_GROUP")) == 0);
+        if (group_on && H / 32 > 0 && x.prod >= 0 && x.prod < (int)prods.size() && prods[x.prod].rows && prods[x.prod].nsink < 2) {
+            double* table = alloc_rowstat((size_t)Bn * 64);
+            prods[x.prod].nsink++;
+            if (!dry && prods[x.prod].L) {
+                ConvArgs& pa = prods[x.prod].L->a;
+                const int k = pa.gsink[0].p ? 1 : 0;
+                pa.gsink[k].p = table; pa.gsink[k].coff = 0; pa.gsink[k].cg = H / 32;
+                ca.gn_table = table; ca.rowstat = nullptr;
+                if (getenv("MUGD_GN_GROUP_LOG")) fprintf(stderr, "[mugd] group table: %s (S4 kernel, %d channels per group)\n", prefix.c_str(), H / 32);
+            }
+        }
+        if (ca.rowstat) use_rowstat(x);
+    }
     emit([ca](hipStream_t st) { launch_s4_conv(st, ca); }, OP_S4_CONV, 0, prefix + " H=" + std::to_string(H) + " L=" + std::to_string(L));
     ConvSpec gl;
     gl.key = prefix + ".s4_model.output_linear.0";

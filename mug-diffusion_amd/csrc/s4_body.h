@@ -49,6 +49,18 @@ __device__ __forceinline__ void s4_conv_fast_row(const A& a, const int h, const 
     float ag = 1.f, ab = 0.f;
     if (a.aff) {
         ag = a.aff[2 * ((size_t)b * a.H + h)]; ab = a.aff[2 * ((size_t)b * a.H + h) + 1];
+    } else if (a.gn_gamma && a.gn_table) {
+        // GroupNorm statistics from the producer's GROUP sums: the workgroup's (b, h) row belongs to one group -- one pair, the same for every lane
+        const int cg = a.H / a.gn_groups;
+        const double* p = a.gn_table + 2 * ((size_t)b * 32 + h / cg);
+        const double s1 = p[0], s2 = p[1];
+        const double inv = 1.0 / ((double)cg * (double)L);
+        const double mean_d = s1 * inv;
+        double var_d = s2 * inv - mean_d * mean_d;
+        var_d = var_d > 0.0 ? var_d : 0.0;
+        const float rstd = 1.0f / sqrtf((float)var_d + a.gn_eps);
+        ag = a.gn_gamma[h] * rstd;
+        ab = a.gn_beta[h] - (float)mean_d * ag;
     } else if (a.gn_gamma && a.rowstat) {
         // GroupNorm statistics from the producer's fp64 row sums: every wave reduces the group's cg rows itself (no barrier)
         const int cg = a.H / a.gn_groups, c0 = (h / cg) * cg;
