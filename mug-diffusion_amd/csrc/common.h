@@ -117,6 +117,14 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// ... and the maximum over the row, likewise
+__device__ __forceinline__ float row16_max(float v) {
+#define MUGD_ROW_ROR_MAX(n) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + (n), 0xf, 0xf, false)))
+    MUGD_ROW_ROR_MAX(1); MUGD_ROW_ROR_MAX(2); MUGD_ROW_ROR_MAX(4); MUGD_ROW_ROR_MAX(8);
+#undef MUGD_ROW_ROR_MAX
+    return v;
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // n / d with m = ceil(2^32 / d) precomputed on the host (conv_fastdiv_mul); d == 1 is encoded as m == 0.  The estimate

@@ -299,13 +299,27 @@ __device__ __forceinline__ void xsoftmax_epilogue(const A& a, const float* xs, i
             sv[u] = ok ? (xs[j * (TN + 1) + col] + r0) * sl2 : -1e30f;
             m = fmaxf(m, sv[u]);
         }
+        // the column's lanes are LPC consecutive lanes: the first 16 of them one DPP row (row rotations instead of four dependent ds_bpermute round
+        // trips per reduction -- round 6: the same 64-lane shuffle chain cost the S4 kernel 1.2 us per launch), one shuffle across rows at LPC = 32
+        if constexpr (LPC >= 16) {
+            m = row16_max(m);
 #pragma unroll
-        for (int o = 1; o < LPC; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+            for (int o = 16; o < LPC; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+        } else {
+#pragma unroll
+            for (int o = 1; o < LPC; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+        }
         float l = 0.f;
 #pragma unroll
         for (int u = 0; u < NR; ++u) { sv[u] = __builtin_amdgcn_exp2f(sv[u] - m); l += sv[u]; }      // padding rows: 2^(-1e30 - m) = 0
+        if constexpr (LPC >= 16) {
+            l = row16_sum(l);
 #pragma unroll
-        for (int o = 1; o < LPC; o <<= 1) l += __shfl_xor(l, o);
+            for (int o = 16; o < LPC; o <<= 1) l += __shfl_xor(l, o);
+        } else {
+#pragma unroll
+            for (int o = 1; o < LPC; o <<= 1) l += __shfl_xor(l, o);
+        }
         const float inv = 1.0f / l;
         if (live && i < a.Tout) {
 #pragma unroll
